@@ -1,0 +1,185 @@
+/* rcf_hip.h -- C ABI of librcf_hip.so: the MI355X (gfx950) kernels of RCF's training hot path.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types.  `stream` is a hipStream_t passed as void*.
+ *   - every entry point returns 0 on success, a positive hipError_t on a HIP failure, or a
+ *     negative RCF_E* code on a bad argument.  Nothing calls exit() (the reference's
+ *     tools/torchCRF/src/permutohedral_gpu.cu:44-53 kills the process on a CUDA error).
+ *   - activations are NHWC fp32 ("pixel-major": element (n,y,x,c) at ((n*H+y)*W+x)*pitch + c,
+ *     pitch >= C so a tensor may be a channel slice of a wider buffer); conv weights are
+ *     [Cout][R][S][Cin] (= a torch OIHW tensor in channels_last memory format).
+ *   - nothing allocates: scratch is passed in, sized by the matching *_workspace_bytes().
+ *
+ * Each group cites the reference interface it stands in for (paths under the reference repo).
+ */
+#ifndef RCF_HIP_H
+#define RCF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCF_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define RCF_EWORKSPACE (-2) /* workspace too small */
+
+/* library identity: "rcf_hip <version> gfx950" */
+const char *rcf_version(void);
+
+/* ---- convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------------
+ * Replaces torch.nn.Conv2d / cuDNN for every conv on the path: models/resnet.py:164-203,565-572,
+ * models/res_layer.py:54-60, mmcv ConvModule in models/fcn_head.py:107-130, conv_seg :100-101,
+ * flow_feat_before_agg models/flow_aggregation_head_with_residual.py:84-93.
+ * Requirements: Cin % 4 == 0 (3-channel / 2-channel inputs are zero-padded to 4 by the caller),
+ * pitches % 4 == 0, pointers 16-byte aligned.  Square kernels/strides/dilations/pads (all the
+ * path uses).  act: 0 none, 1 LeakyReLU(slope).  bias may be NULL.  beta: 0 overwrite, 1 accumulate. */
+typedef struct {
+    int N, H, W, Cin;        /* input  [N,H,W,Cin], pixel pitch x_pitch */
+    int Ho, Wo, Cout;        /* output [N,Ho,Wo,Cout], pixel pitch y_pitch */
+    int R, S, stride, pad, dil;
+    int x_pitch, y_pitch;
+} rcf_conv_shape;
+
+int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
+                       int act, float slope, int beta, void *stream);
+/* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w) */
+int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
+                         void *stream);
+/* dw[Cout][R][S][Cin] (+)= sum_pixels dy * x.  Split over pixels into `workspace`, then reduced
+ * deterministically (no float atomics). */
+size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- batch norm (training), fused ReLU / residual add / Dropout2d channel scale -----------------
+ * Replaces (Sync)BatchNorm in models/resnet.py:159-162 and mmcv ConvModule's norm, the ReLU and
+ * `out += identity` of models/resnet.py:268-300, and nn.Dropout2d of models/decode_head.py:84-85.
+ * x is [rows][C] with pixel pitch `pitch` (rows = N*H*W).
+ * stats: per-channel sum and sum of squares accumulated in fp64 -> sums[2*C] (doubles, [sum | sumsq]).
+ * A data-parallel run all-reduces `sums` (and the row count) between stats and finalize: that IS SyncBN. */
+size_t rcf_bn_stats_workspace_bytes(long rows, int C);
+int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, double *sums, void *workspace,
+                     size_t workspace_bytes, void *stream);
+/* mean/invstd (biased var, eps) from sums over `count` rows; running stats updated with `momentum`
+ * and the unbiased variance; running_* may be NULL. */
+int rcf_bn_finalize_f32(const double *sums, double count, int C, float eps, float momentum, float *mean,
+                        float *invstd, float *running_mean, float *running_var, void *stream);
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) [* chan_scale[n][c]]
+ * rows_per_image only matters with chan_scale (Dropout2d keep-mask / keep-prob, NULL = off). */
+int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_pitch, float *y, int y_pitch,
+                     long rows, int C, const float *mean, const float *invstd, const float *gamma,
+                     const float *beta, int relu, const float *chan_scale, long rows_per_image, void *stream);
+/* eval-mode BN: same kernel with mean=running_mean, invstd from running_var */
+int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, float *invstd, void *stream);
+/* backward.  g = dy [* chan_scale] [* (y>0)];  sums2 = [sum g | sum g*xhat] (fp64).
+ * After a data-parallel all-reduce of sums2:  dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count),
+ * dgamma += sum_gx, dbeta += sum_g, and (if dres != NULL) dres (+)= g  (res_beta 0/1). */
+int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
+                          int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
+                          const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y, int y_pitch,
+                         float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta, long rows, int C,
+                         const float *mean, const float *invstd, const float *gamma, int relu,
+                         const float *chan_scale, long rows_per_image, const double *sums2, double count,
+                         float *dgamma, float *dbeta, void *stream);
+
+/* ---- pooling / resize / layout ------------------------------------------------------------------
+ * MaxPool2d(3,2,1): models/resnet.py:577.  argmax: uint8 window position (r*3+s), first max wins. */
+int rcf_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho,
+                             int Wo, void *stream);
+int rcf_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
+                             int Ho, int Wo, void *stream);
+/* bilinear resize, NHWC, align_corners 0/1 (mmseg `resize`: models/decode_head.py:157-163,
+ * models/rcf_model.py:213-220).  bwd is a gather over the contributing outputs (no atomics). */
+int rcf_resize_bilinear_nhwc_fwd_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi, int Wi,
+                                     int Ho, int Wo, int C, int align_corners, void *stream);
+int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta, int N,
+                                     int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void *stream);
+/* planar NCHW bilinear resize (ground-truth flows 480x854 -> mask size, models/rcf_model.py:438-442) */
+int rcf_resize_bilinear_nchw_f32(const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
+                                 int align_corners, void *stream);
+/* NCHW [N,C,H,W] -> NHWC [N,H,W,Cpad] (channels >= C zero-filled) and back (drops the padding) */
+int rcf_nchw_to_nhwc_f32(const float *x, float *y, int N, int C, int H, int W, int Cpad, void *stream);
+int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N, int C, int H, int W, void *stream);
+/* strided 2-D copy: dst[r*dpitch + c] (+)= src[r*spitch + c], c < C (concat / pair-concat / slices) */
+int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
+                   void *stream);
+/* column sums of [rows][C] (pitch) in fp64 -> out[C] (+)= (bias gradients of conv_seg) */
+int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ---- backward warp / occlusion / photometric residual -------------------------------------------
+ * utils/warp_utils.py:84-94 (flow_warp; pad 0 = 'border', 1 = 'zeros'), :107-113 + :27-81
+ * (get_occu_mask_backward), :97-104 (get_occu_mask_bidirection), models/amd/flow_loss.py:15-29 with
+ * models/amd/loss_blocks.py:46-65 (L1 + SSIM photometric loss).  Planar NCHW fp32 as the reference. */
+int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W, int pad_mode,
+                      void *stream);
+/* grads of flow_warp w.r.t. x (atomic scatter; dx must be zero-filled or hold a running sum) and flow */
+int rcf_flow_warp_bwd_f32(const float *x, const float *flow, const float *dout, float *dx, float *dflow, int B,
+                          int C, int H, int W, int pad_mode, void *stream);
+/* occ[B,1,H,W] = (clamp(splat(flow21),0,1) < th); scratch: B*H*W floats */
+int rcf_occu_mask_backward_f32(const float *flow21, float *occ, float th, float *scratch, int B, int H, int W,
+                               void *stream);
+int rcf_occu_mask_bidirection_f32(const float *flow12, const float *flow21, float *occ, float scale, float bias,
+                                  int B, int H, int W, void *stream);
+/* fused warp + occlusion-masked L1: out[0] = sum |im1 - warp(im2,flow)| * occ, out[1] = sum occ (fp64) */
+int rcf_warp_l1_residual_f32(const float *im1, const float *im2, const float *flow, const float *occ, double *out,
+                             int B, int C, int H, int W, int pad_mode, void *stream);
+/* loss_photomatric: (w_l1*mean(|a-b|*occ) + w_ssim*mean(SSIM(b*occ,a*occ))) / mean(occ) -> out[0] (fp32).
+ * scratch: 4 doubles. */
+int rcf_photometric_loss_f32(const float *im, const float *recon, const float *occ, float w_l1, float w_ssim,
+                             float *out, double *scratch, int B, int C, int H, int W, void *stream);
+
+/* ---- dense CRF (permutohedral mean-field) -------------------------------------------------------
+ * Replaces torchcrf_cpp.crf_soft / crf_hard (tools/torchCRF/src/torchcrf.cu:106-149), batched over
+ * frames, persistent caller-owned workspace instead of 12 cudaMalloc/cudaFree per frame.
+ *   rgb   : u8 [batch,H,W,3]         unary : f32 [batch,H*W,2] energies (label minor)
+ *   out   : i16 [batch,H,W] MAP      q_out : optional f32 [batch,H*W,2] final marginals (NULL = skip)
+ *   nvert : optional int32 [batch,2] lattice vertex counts (smoothness, appearance)
+ * A potential is active when its weight and sigma are > 0 (torchcrf.cu:28,41). */
+size_t rcf_crf_workspace_bytes(int W, int H, int batch);
+int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
+                 float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map,
+                 float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream);
+int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,
+                 float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence, int iters,
+                 int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
+                 void *stream);
+/* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
+ * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
+int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,
+                    int unstandardize, float crf_scale, uint8_t *rgb_out, float *unary_out, uint32_t *scratch,
+                    int batch, int H, int W, void *stream);
+
+/* ---- flow-aggregation head (relaxed common fate) ------------------------------------------------
+ * models/flow_aggregation_head_with_residual.py:235-310 (aggregate), :164-233 (per-segment affine
+ * least squares), :312-399 (forward, L1 / robust loss), and the softmax + double-softmax entropy of
+ * models/rcf_model.py:433-434,376-378.  See flowhead.hip for the tensor contracts. */
+typedef struct {
+    int B, C, h, w;          /* pairs, segments (mask_layer), mask size */
+    int h2, w2;              /* residual map size (decode_head3 output) */
+    int nf;                  /* flow feature channels (64) */
+    int affine;              /* 0 free_residual, 1 free_residual_with_affine, 2 + quadratic */
+    int robust;              /* outlier_robust_loss */
+    float eps, q;
+    float clamp_t;           /* < 0: no clamp */
+    float res_scale, div_coeff;
+    float w_seg, w_entropy;
+} rcf_flowhead_cfg;
+size_t rcf_flowhead_workspace_bytes(const rcf_flowhead_cfg *c);
+
+/* ---- optimiser / EMA ----------------------------------------------------------------------------
+ * torch.optim.Adam with coupled weight decay (main.py:299-307) over one flat fp32 buffer;
+ * EMA lerp of utils/model_utils.py:33-38 over flat buffers. */
+int rcf_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                      void *stream);
+int rcf_ema_update_f32(float *dest, const float *src, long n, float m, void *stream);
+int rcf_fill_f32(float *p, long n, float v, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCF_HIP_H */

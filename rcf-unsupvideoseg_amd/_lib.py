@@ -1,0 +1,114 @@
+"""ctypes binding of librcf_hip.so (the C ABI declared in include/rcf_hip.h).
+
+The product has NO CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_long, c_float, c_double, c_void_p, c_size_t, c_char_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librcf_hip.so")
+
+
+class RcfHipError(RuntimeError):
+    pass
+
+
+class ConvShape(ctypes.Structure):
+    """mirror of rcf_conv_shape"""
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad", "dil",
+                                     "x_pitch", "y_pitch")]
+
+
+class FlowHeadCfg(ctypes.Structure):
+    """mirror of rcf_flowhead_cfg"""
+    _fields_ = [(n, c_int) for n in ("B", "C", "h", "w", "h2", "w2", "nf", "affine", "robust")] + \
+               [(n, c_float) for n in ("eps", "q", "clamp_t", "res_scale", "div_coeff", "w_seg", "w_entropy")]
+
+
+P = c_void_p
+_CS = ctypes.POINTER(ConvShape)
+_FH = ctypes.POINTER(FlowHeadCfg)
+
+# name -> (restype, argtypes); every int-returning entry point is status-checked by `call`
+PROTOS = {
+    "rcf_version": (c_char_p, []),
+    "rcf_conv2d_fwd_f32": (c_int, [P, P, P, P, _CS, c_int, c_float, c_int, P]),
+    "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P]),
+    "rcf_conv2d_wgrad_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_wgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
+    "rcf_bn_stats_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "rcf_bn_stats_f32": (c_int, [P, c_long, c_int, c_int, P, P, c_size_t, P]),
+    "rcf_bn_finalize_f32": (c_int, [P, c_double, c_int, c_float, c_float, P, P, P, P, P]),
+    "rcf_bn_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P]),
+    "rcf_bn_invstd_from_var_f32": (c_int, [P, c_int, c_float, P, P]),
+    "rcf_bn_bwd_reduce_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_int, P, c_long, P, P,
+                                      c_size_t, P]),
+    "rcf_bn_bwd_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P,
+                                     c_int, P, c_long, P, c_double, P, P, P]),
+    "rcf_maxpool3x3s2_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_maxpool3x3s2_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_resize_bilinear_nhwc_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_resize_bilinear_nhwc_bwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_int, P]),
+    "rcf_resize_bilinear_nchw_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_nchw_to_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_nhwc_to_nchw_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "rcf_copy2d_f32": (c_int, [P, c_long, P, c_long, c_long, c_int, c_int, P]),
+    "rcf_colsum_f32": (c_int, [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P]),
+    "rcf_flow_warp_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_flow_warp_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_occu_mask_backward_f32": (c_int, [P, P, c_float, P, c_int, c_int, c_int, P]),
+    "rcf_occu_mask_bidirection_f32": (c_int, [P, P, P, c_float, c_float, c_int, c_int, c_int, P]),
+    "rcf_warp_l1_residual_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_photometric_loss_f32": (c_int, [P, P, P, c_float, c_float, P, P, c_int, c_int, c_int, c_int, P]),
+    "rcf_crf_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rcf_crf_soft": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P, P, P,
+                             P, c_size_t, P]),
+    "rcf_crf_hard": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
+                             P, P, P, P, c_size_t, P]),
+    "rcf_crf_prepare": (c_int, [P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),
+    "rcf_flowhead_workspace_bytes": (c_size_t, [_FH]),
+    "rcf_flowhead_fwd_f32": (c_int, [_FH, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "rcf_flowhead_bwd_f32": (c_int, [_FH, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "rcf_adam_step_f32": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "rcf_ema_update_f32": (c_int, [P, P, c_long, c_float, P]),
+    "rcf_fill_f32": (c_int, [P, c_long, c_float, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librcf_hip.so; raises RcfHipError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RcfHipError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build) first; "
+                              "there is no CPU fallback for the product path")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOS.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                continue            # reported by missing_symbols(); calling it raises
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def missing_symbols():
+    lib = load()
+    return [n for n in PROTOS if not hasattr(lib, n)]
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    fn = getattr(load(), name, None)
+    if fn is None:
+        raise RcfHipError(f"librcf_hip.so does not export {name}")
+    rc = fn(*args)
+    if PROTOS[name][0] is c_int and rc != 0:
+        raise RcfHipError(f"{name} failed with status {rc}" + (" (bad argument)" if rc == -1 else
+                                                              " (workspace too small)" if rc == -2 else " (HIP error)"))
+    return rc

@@ -1,0 +1,361 @@
+// Training-mode batch norm on NHWC fp32, with the ReLU, the residual add and the Dropout2d channel
+// scale of the reference fused in.  Reference: (Sync)BatchNorm built at models/resnet.py:159-162 and
+// by mmcv ConvModule (models/fcn_head.py:107-130), ReLU + `out += identity` models/resnet.py:268-300,
+// nn.Dropout2d models/decode_head.py:84-85.
+//
+// All kernels are HBM-bound column reductions / element-wise passes over a [rows][C] matrix whose
+// rows are pixels: a wavefront reads 64 x 16 B along C (coalesced), statistics accumulate in fp64
+// per thread, are combined through LDS per block and written as per-block partials that a second
+// tiny kernel sums in a fixed order (deterministic, no atomics).  The fp64 sums are what a
+// data-parallel run all-reduces (SyncBN).
+#include "rcf_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+struct ColGeom {
+    int cvB;      // float4 columns handled per block (<= 64)
+    int RG;       // row groups per block = 256 / cvB
+    int cgroups;  // blocks along C
+    int chunks;   // blocks along rows
+    long rows_per_chunk;
+};
+
+ColGeom col_geom(long rows, int C) {
+    ColGeom g;
+    const int CV = C / 4;
+    g.cvB = CV < 64 ? CV : 64;
+    g.RG = RED_THREADS / g.cvB;
+    g.cgroups = (CV + g.cvB - 1) / g.cvB;
+    long chunks = 2048 / g.cgroups;
+    const long min_rows = (long)g.RG * 8;
+    if (chunks > (rows + min_rows - 1) / min_rows) chunks = (rows + min_rows - 1) / min_rows;
+    if (chunks < 1) chunks = 1;
+    g.rows_per_chunk = (rows + chunks - 1) / chunks;
+    g.chunks = (int)((rows + g.rows_per_chunk - 1) / g.rows_per_chunk);
+    return g;
+}
+
+// Generic two-value column reduction.  F(row, c4, out a[4], out b[4]) produces the two addends.
+template <class F>
+__global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows, int C, int cvB, int RG,
+                                                                 long rows_per_chunk, double *__restrict__ partial) {
+    __shared__ double red[RED_THREADS * 8];
+    const int tid = threadIdx.x;
+    const int cv = tid % cvB, rg = tid / cvB;
+    const int c4 = (blockIdx.y * cvB + cv) * 4;
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    const long r1 = min(rows, r0 + rows_per_chunk);
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    if (rg < RG && c4 < C) {
+        for (long r = r0 + rg; r < r1; r += RG) {
+            float a[4], b[4];
+            f(r, c4, a, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa[e] += (double)a[e];
+                sb[e] += (double)b[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[tid * 8 + e] = sa[e];
+        red[tid * 8 + 4 + e] = sb[e];
+    }
+    __syncthreads();
+    if (rg == 0 && c4 < C) {
+        for (int g = 1; g < RG; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa[e] += red[(g * cvB + cv) * 8 + e];
+                sb[e] += red[(g * cvB + cv) * 8 + 4 + e];
+            }
+        }
+        double *dst = partial + (long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[c4 + e] = sa[e];
+            dst[C + c4 + e] = sb[e];
+        }
+    }
+}
+
+__global__ void partial_sum_kernel(const double *__restrict__ partial, int chunks, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int k = 0; k < chunks; ++k) s += partial[(long)k * n + i];
+    out[i] = s;
+}
+
+struct StatsOp {
+    const float *x;
+    int pitch;
+    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * pitch + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = v[e];
+            b[e] = v[e] * v[e];
+        }
+    }
+};
+
+struct BwdOp {
+    const float *dy, *x, *y, *mean, *invstd, *scale;
+    int dy_pitch, x_pitch, y_pitch, relu, C;
+    long rows_per_image;
+    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
+        if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
+        if (relu) {
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = g[e];
+            b[e] = g[e] * ((xv[e] - mu[e]) * is[e]);
+        }
+    }
+};
+
+__global__ void bn_finalize_kernel(const double *__restrict__ sums, double count, int C, float eps, float momentum,
+                                   float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ rmean,
+                                   float *__restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unbiased = count > 1 ? var * (count / (count - 1.0)) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void invstd_from_var_kernel(const float *__restrict__ var, int C, float eps, float *__restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__ x, int x_pitch,
+                                                       const float *__restrict__ res, int r_pitch,
+                                                       float *__restrict__ y, int y_pitch, long rows, int C,
+                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int relu, const float *__restrict__ scale, long rows_per_image) {
+    const int CV = C / 4;
+    const long total = rows * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long r = i / CV;
+        const int c4 = (int)(i - r * CV) * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
+        if (res) o += *reinterpret_cast<const f32x4 *>(res + r * r_pitch + c4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+        }
+        if (scale) o *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
+        *reinterpret_cast<f32x4 *>(y + r * y_pitch + c4) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
+    const float *__restrict__ dy, int dy_pitch, const float *__restrict__ x, int x_pitch, const float *__restrict__ y,
+    int y_pitch, float *__restrict__ dx, int dx_pitch, float *__restrict__ dres, int dres_pitch, int res_beta,
+    long rows, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
+    const double *__restrict__ sums2, double count, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int CV = C / 4;
+    const long total = rows * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dgamma) dgamma[c] += (float)sums2[C + c];
+            if (dbeta) dbeta[c] += (float)sums2[c];
+        }
+    }
+    const float inv_count = (float)(1.0 / count);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long r = i / CV;
+        const int c4 = (int)(i - r * CV) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
+        if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
+        if (relu) {
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu[e]) * is[e];
+            const float sg = (float)sums2[c4 + e] * inv_count;
+            const float sgx = (float)sums2[C + c4 + e] * inv_count;
+            o[e] = ga[e] * is[e] * (g[e] - sg - xh * sgx);
+        }
+        *reinterpret_cast<f32x4 *>(dx + r * dx_pitch + c4) = o;
+        if (dres) {
+            f32x4 *dr = reinterpret_cast<f32x4 *>(dres + r * dres_pitch + c4);
+            *dr = res_beta ? (*dr + g) : g;
+        }
+    }
+}
+
+struct ColsumOp {
+    const float *x;
+    int pitch;
+    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * pitch + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = v[e];
+            b[e] = 0.f;
+        }
+    }
+};
+
+__global__ void colsum_final_kernel(const double *__restrict__ partial, int chunks, int C, float *__restrict__ out,
+                                    int beta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < chunks; ++k) s += partial[(long)k * 2 * C + c];
+    out[c] = (beta ? out[c] : 0.f) + (float)s;
+}
+
+inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" size_t rcf_bn_stats_workspace_bytes(long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    const ColGeom g = col_geom(rows, C);
+    return (size_t)g.chunks * 2 * C * sizeof(double);
+}
+
+extern "C" int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, double *sums, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    if (!x || !sums || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const ColGeom g = col_geom(rows, C);
+    hipStream_t st = rcf_stream(stream);
+    StatsOp op{x, pitch};
+    hipLaunchKernelGGL(colreduce2_kernel<StatsOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
+                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 256)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, 2 * C, sums);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_finalize_f32(const double *sums, double count, int C, float eps, float momentum, float *mean,
+                                   float *invstd, float *running_mean, float *running_var, void *stream) {
+    if (!sums || !mean || !invstd || C <= 0 || count <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rcf_cdiv(C, 256)), dim3(256), 0, rcf_stream(stream), sums, count, C,
+                       eps, momentum, mean, invstd, running_mean, running_var);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, float *invstd, void *stream) {
+    if (!var || !invstd || C <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(invstd_from_var_kernel, dim3(rcf_cdiv(C, 256)), dim3(256), 0, rcf_stream(stream), var, C, eps,
+                       invstd);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_pitch, float *y,
+                                int y_pitch, long rows, int C, const float *mean, const float *invstd,
+                                const float *gamma, const float *beta, int relu, const float *chan_scale,
+                                long rows_per_image, void *stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
+    if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), x, x_pitch,
+                       residual, r_pitch, y, y_pitch, rows, C, mean, invstd, gamma, beta, relu, chan_scale,
+                       rows_per_image > 0 ? rows_per_image : 1);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
+                                     int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
+                                     const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!dy || !x || !mean || !invstd || !sums2 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (relu && !y) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || (relu && y_pitch % 4)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const ColGeom g = col_geom(rows, C);
+    hipStream_t st = rcf_stream(stream);
+    BwdOp op{dy, x, y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, relu, C,
+             rows_per_image > 0 ? rows_per_image : 1};
+    hipLaunchKernelGGL(colreduce2_kernel<BwdOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
+                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 256)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, 2 * C, sums2);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
+                                    int y_pitch, float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta,
+                                    long rows, int C, const float *mean, const float *invstd, const float *gamma,
+                                    int relu, const float *chan_scale, long rows_per_image, const double *sums2,
+                                    double count, float *dgamma, float *dbeta, void *stream) {
+    if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
+        return RCF_EINVAL;
+    if (relu && !y) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), dy,
+                       dy_pitch, x, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch, res_beta, rows, C, mean,
+                       invstd, gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2, count, dgamma,
+                       dbeta);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const ColGeom g = col_geom(rows, C);
+    hipStream_t st = rcf_stream(stream);
+    ColsumOp op{x, pitch};
+    hipLaunchKernelGGL(colreduce2_kernel<ColsumOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
+                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(rcf_cdiv(C, 256)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, C, out, beta);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}

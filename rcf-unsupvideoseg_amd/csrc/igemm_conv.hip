@@ -1,0 +1,492 @@
+// Convolution forward / data-gradient / weight-gradient as implicit GEMM on the fp32 matrix
+// cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles per SIMD, 157 TF/s chip peak).
+//
+// Stands in for torch.nn.Conv2d (cuDNN) on every conv of the RCF path -- reference call sites:
+// models/resnet.py:164-203,565-572, models/res_layer.py:54-60, models/fcn_head.py:100-130,
+// models/flow_aggregation_head_with_residual.py:84-93.
+//
+// Data layout: activations NHWC (pixel pitch may exceed C: channel slices of concat buffers),
+// weights [Cout][R][S][Cin].  GEMM view: rows = output pixels, cols = output channels,
+// K = (r, s, cin) with cin fastest, so a K-slice of 16 is 64 contiguous bytes of one source pixel.
+//
+// Workgroup = 256 threads = 4 wave64 in a 2x2 grid; each wave owns MR x NR tiles of 32x32
+// (16 accumulator VGPRs each).  Per K-step of 16: global -> registers (float4, zero-filled out of
+// bounds: this is where padding / dilation / stride live) -> LDS stored K-major so that the MFMA
+// operand read `A[i = lane&31][k = lane>>5]` is one conflict-free ds_read_b32 -> MFMA.  LDS is
+// double buffered: the loads of K-step t+1 are in flight while step t is multiplied.
+// fp32 MFMA is slow enough (64 cycles for 4 KFLOP) that LDS and VALU addressing hide under it.
+//
+// Block -> tile mapping is XCD aware: workgroup b runs on XCD b%8 (MI355X_MICROARCH.md), so the
+// 8 consecutive ids take 8 different row tiles and ids b, b+8, b+16.. walk the column tiles of the
+// same row tile: the activation tile is re-read from that XCD's own L2.
+#include "rcf_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct IgemmParams {
+    const float *A;      // source activations (x for fwd, dy for dgrad)
+    const float *Bw;     // weights
+    const float *bias;   // per output column or null
+    float *Y;
+    int M, Ncol, K;
+    int Ho, Wo;          // spatial dims of the GEMM-row tensor
+    int Hs, Ws;          // spatial dims of the source tensor
+    int Cs;              // source channels per tap
+    int S;               // kernel width
+    int up, off, step, div;  // source coord t = y*up + off + r*step, valid iff t>=0, t%div==0, t/div<Hs
+    int a_pitch;
+    long a_img_stride;
+    int y_pitch;
+    int ldb;             // BMODE 0: elements between rows of B[j][k]; BMODE 1: between source channels
+    int act;
+    float slope;
+    int beta;
+    int mtiles, ntiles;
+};
+
+template <int MR, int NR>
+__device__ __forceinline__ void mma_tile(const float *__restrict__ As, const float *__restrict__ Bs, int lda,
+                                         int ldb, int wm, int wn, int lane, f32x16 (&acc)[MR][NR]) {
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        const int krow = 2 * kk + kh;
+        float a[MR], b[NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a[mr] = As[krow * lda + wm * 32 * MR + mr * 32 + l31];
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) b[nr] = Bs[krow * ldb + wn * 32 * NR + nr * 32 + l31];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+    }
+}
+
+// BMODE 0: B[j][k], k contiguous (forward: w[co][rs*Cin + c]).
+// BMODE 1: B[k = rs*Cs + kc][j], j contiguous (dgrad: w[co = kc][rs][c = j]).
+template <int MR, int NR, int BMODE>
+__global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int STAGE = BK * (LDA + LDB);
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * p.ntiles);
+    const int rem = bid - grp * 8 * p.ntiles;
+    const int tile_n = rem >> 3;
+    const int tile_m = grp * 8 + (rem & 7);
+    if (tile_m >= p.mtiles) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- A loader state: thread owns rows arow + 64*i, K-quad kq
+    const int kq = tid & 3, arow = tid >> 2;
+    long abase[MR];
+    int ay[MR], ax[MR];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int m = m0 + arow + 64 * i;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int pix = m - n * HoWo;
+            const int y = pix / p.Wo;
+            const int x = pix - y * p.Wo;
+            abase[i] = (long)n * p.a_img_stride;
+            ay[i] = y * p.up + p.off;
+            ax[i] = x * p.up + p.off;
+        } else {
+            abase[i] = 0;
+            ay[i] = -(1 << 28);
+            ax[i] = -(1 << 28);
+        }
+    }
+    // ---- B loader state
+    constexpr int BTPR = BN / 4;            // threads per k-row in BMODE 1
+    constexpr int BROWS = 256 / BTPR;       // k-rows per pass in BMODE 1
+    const int bjq = tid % BTPR, bkr = tid / BTPR;
+
+    f32x4 ra[MR], rb[NR];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kq * 4;
+        const bool kv = k < p.K;
+        const int rs = kv ? k / p.Cs : 0;
+        const int c = k - rs * p.Cs;
+        const int r = rs / p.S;
+        const int s = rs - r * p.S;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            int ty = ay[i] + r * p.step, tx = ax[i] + s * p.step;
+            bool v = kv && ty >= 0 && tx >= 0;
+            if (p.div > 1) {
+                v = v && (ty % p.div == 0) && (tx % p.div == 0);
+                ty /= p.div;
+                tx /= p.div;
+            }
+            v = v && ty < p.Hs && tx < p.Ws;
+            if (v) {
+                const float *src = p.A + abase[i] + ((long)ty * p.Ws + tx) * p.a_pitch + c;
+                ra[i] = *reinterpret_cast<const f32x4 *>(src);
+            } else {
+                ra[i] = zero4;
+            }
+        }
+        if (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int j = n0 + arow + 64 * i;
+                if (kv && j < p.Ncol)
+                    rb[i] = *reinterpret_cast<const f32x4 *>(p.Bw + (long)j * p.ldb + k);
+                else
+                    rb[i] = zero4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int kb = kt * BK + bkr + i * BROWS;
+                const int j = n0 + bjq * 4;
+                if (kb < p.K && j < p.Ncol) {
+                    const int rsb = kb / p.Cs;
+                    const int kc = kb - rsb * p.Cs;
+                    rb[i] = *reinterpret_cast<const f32x4 *>(p.Bw + (long)kc * p.ldb + (long)rsb * p.Ncol + j);
+                } else {
+                    rb[i] = zero4;
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *As = smem + buf * STAGE;
+        float *Bs = As + BK * LDA;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(kq * 4 + e) * LDA + arow + 64 * i] = ra[i][e];
+        if (BMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(kq * 4 + e) * LDB + arow + 64 * i] = rb[i][e];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                *reinterpret_cast<f32x4 *>(Bs + (bkr + i * BROWS) * LDB + bjq * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int KT = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float *As = smem + cur * STAGE;
+        mma_tile<MR, NR>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (lane&31), rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int col = n0 + wn * 32 * NR + nr * 32 + l31;
+        if (col >= p.Ncol) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int rbase = m0 + wm * 32 * MR + mr * 32 + 4 * kh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row < p.M) {
+                    float *dst = p.Y + (long)row * p.y_pitch + col;
+                    float v = acc[mr][nr][e] + bv;
+                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                    if (p.beta) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- wgrad
+struct WgradParams {
+    const float *X, *DY;
+    float *OUT;
+    int Cout, Cin, R, S;
+    int H, W, Ho, Wo, stride, pad, dil;
+    int x_pitch, dy_pitch;
+    long M;            // N*Ho*Wo
+    long chunk;        // pixels per K-split (multiple of BK)
+    int itiles, jtiles;
+    long split_stride; // Cout*R*S*Cin
+    int beta;          // only honoured when gridDim.z == 1
+};
+
+// dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
+template <int MR, int NR>
+__global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int STAGE = BK * (LDA + LDB);
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int rs = blockIdx.y;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int ATPR = BM / 4, AROWS = 256 / ATPR;
+    constexpr int BTPR = BN / 4, BROWS = 256 / BTPR;
+    const int aiq = tid % ATPR, akr = tid / ATPR;
+    const int bjq = tid % BTPR, bkr = tid / BTPR;
+    const int HoWo = p.Ho * p.Wo;
+    const int dy_off = (p.pad);
+
+    f32x4 ra[MR], rb[NR];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](long kt) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const long m = kbeg + kt * BK + akr + i * AROWS;
+            const int co = i0 + aiq * 4;
+            if (m < kend && co < p.Cout)
+                ra[i] = *reinterpret_cast<const f32x4 *>(p.DY + m * p.dy_pitch + co);
+            else
+                ra[i] = zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const long m = kbeg + kt * BK + bkr + i * BROWS;
+            const int c = j0 + bjq * 4;
+            bool v = m < kend && c < p.Cin;
+            if (v) {
+                const int n = (int)(m / HoWo);
+                const int pix = (int)(m - (long)n * HoWo);
+                const int y = pix / p.Wo;
+                const int x = pix - y * p.Wo;
+                const int sy = y * p.stride - dy_off + r * p.dil;
+                const int sx = x * p.stride - dy_off + s * p.dil;
+                v = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+                if (v)
+                    rb[i] = *reinterpret_cast<const f32x4 *>(
+                        p.X + (((long)n * p.H + sy) * p.W + sx) * p.x_pitch + c);
+            }
+            if (!v) rb[i] = zero4;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *As = smem + buf * STAGE;
+        float *Bs = As + BK * LDA;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) *reinterpret_cast<f32x4 *>(As + (akr + i * AROWS) * LDA + aiq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4 *>(Bs + (bkr + i * BROWS) * LDB + bjq * 4) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const long KT = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    if (KT > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (long kt = 0; kt < KT; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float *As = smem + cur * STAGE;
+        mma_tile<MR, NR>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const long row_pitch = (long)p.R * p.S * p.Cin;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int c = j0 + wn * 32 * NR + nr * 32 + l31;
+        if (c >= p.Cin) continue;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int rbase = i0 + wm * 32 * MR + mr * 32 + 4 * kh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = rbase + (e & 3) + 8 * (e >> 2);
+                if (co < p.Cout) {
+                    float *dst = out + co * row_pitch + (long)rs * p.Cin + c;
+                    float v = acc[mr][nr][e];
+                    if (p.beta && gridDim.z == 1) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
+                                     int splits, int beta) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += step) {
+        f32x4 a = beta ? reinterpret_cast<const f32x4 *>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) a += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
+        reinterpret_cast<f32x4 *>(dw)[i] = a;
+    }
+}
+
+int check_shape(const rcf_conv_shape *s) {
+    if (!s) return RCF_EINVAL;
+    if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->R <= 0 || s->S <= 0) return RCF_EINVAL;
+    if (s->Cin % 4 || s->x_pitch % 4 || s->y_pitch % 4 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
+    if (s->stride <= 0 || s->dil <= 0 || s->pad < 0) return RCF_EINVAL;
+    const int ho = (s->H + 2 * s->pad - s->dil * (s->R - 1) - 1) / s->stride + 1;
+    const int wo = (s->W + 2 * s->pad - s->dil * (s->S - 1) - 1) / s->stride + 1;
+    if (ho != s->Ho || wo != s->Wo) return RCF_EINVAL;
+    if ((long)s->N * s->Ho * s->Wo >= (1L << 31) || (long)s->N * s->H * s->W >= (1L << 31)) return RCF_EINVAL;
+    return 0;
+}
+
+template <int BMODE>
+int launch_igemm(IgemmParams &p, hipStream_t st) {
+    const bool wide = p.Ncol > 64;
+    const int BM = 128, BN = wide ? 128 : 64;
+    p.mtiles = rcf_cdiv(p.M, BM);
+    p.ntiles = rcf_cdiv(p.Ncol, BN);
+    const int groups = rcf_cdiv(p.mtiles, 8);
+    const dim3 grid((unsigned)(groups * 8 * p.ntiles));
+    if (wide)
+        hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE>), grid, dim3(256), 0, st, p);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+struct WgradPlan {
+    int mr, nr, itiles, jtiles, splitk;
+    long chunk;
+};
+WgradPlan plan_wgrad(const rcf_conv_shape *s) {
+    WgradPlan pl;
+    pl.mr = s->Cout > 64 ? 2 : 1;
+    pl.nr = s->Cin > 64 ? 2 : 1;
+    pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
+    pl.jtiles = rcf_cdiv(s->Cin, 64 * pl.nr);
+    const long M = (long)s->N * s->Ho * s->Wo;
+    const long tiles = (long)pl.itiles * pl.jtiles * s->R * s->S;
+    long sk = (1536 + tiles - 1) / tiles;
+    const long maxsk = M / 1024 > 1 ? M / 1024 : 1;
+    if (sk > maxsk) sk = maxsk;
+    if (sk > 256) sk = 256;
+    if (sk < 1) sk = 1;
+    long chunk = (M + sk - 1) / sk;
+    chunk = (chunk + BK - 1) / BK * BK;
+    sk = (M + chunk - 1) / chunk;
+    pl.splitk = (int)sk;
+    pl.chunk = chunk;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y,
+                                  const rcf_conv_shape *s, int act, float slope, int beta, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !w || !y || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+    IgemmParams p{};
+    p.A = x; p.Bw = w; p.bias = bias; p.Y = y;
+    p.M = s->N * s->Ho * s->Wo; p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
+    p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
+    p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
+    p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
+    p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
+    return launch_igemm<0>(p, rcf_stream(stream));
+}
+
+extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
+                                    void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    if (s->Cout % 4) return RCF_EINVAL;
+    IgemmParams p{};
+    p.A = dy; p.Bw = w; p.bias = nullptr; p.Y = dx;
+    p.M = s->N * s->H * s->W; p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
+    p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
+    p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
+    p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
+    p.ldb = s->R * s->S * s->Cin; p.act = 0; p.slope = 0.f; p.beta = beta;
+    return launch_igemm<1>(p, rcf_stream(stream));
+}
+
+extern "C" size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s)) return 0;
+    const WgradPlan pl = plan_wgrad(s);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * s->Cout * s->R * s->S * s->Cin * sizeof(float);
+}
+
+extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !dy || !dw || !rcf_aligned16(x) || !rcf_aligned16(dy) || !rcf_aligned16(dw)) return RCF_EINVAL;
+    if (s->Cout % 4) return RCF_EINVAL;
+    const WgradPlan pl = plan_wgrad(s);
+    const size_t need = rcf_conv2d_wgrad_workspace_bytes(s);
+    if (need > 0 && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
+    hipStream_t st = rcf_stream(stream);
+    WgradParams p{};
+    p.X = x; p.DY = dy;
+    p.OUT = pl.splitk > 1 ? (float *)workspace : dw;
+    p.Cout = s->Cout; p.Cin = s->Cin; p.R = s->R; p.S = s->S;
+    p.H = s->H; p.W = s->W; p.Ho = s->Ho; p.Wo = s->Wo; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
+    p.x_pitch = s->x_pitch; p.dy_pitch = s->y_pitch;
+    p.M = (long)s->N * s->Ho * s->Wo; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
+    p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
+    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(s->R * s->S), (unsigned)pl.splitk);
+    if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
+    else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, p);
+    else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    RCF_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        const long n4 = p.split_stride / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)workspace, dw, n4,
+                           p.split_stride, pl.splitk, beta);
+        RCF_LAUNCH_CHECK();
+    }
+    return 0;
+}

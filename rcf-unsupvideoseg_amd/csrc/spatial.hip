@@ -1,0 +1,339 @@
+// Pooling, bilinear resize and layout kernels (all HBM-bound; one float4 of channels per thread so a
+// wavefront moves 1 KiB per access).  Reference call sites: MaxPool2d(3,2,1) models/resnet.py:577;
+// mmseg `resize` (bilinear) models/decode_head.py:157-163, models/rcf_model.py:213-220,438-442;
+// torch.cat models/decode_head.py:164; unflatten/flatten models/rcf_model.py:325.
+// PyTorch index arithmetic is reproduced exactly.
+#include "rcf_common.h"
+
+namespace {
+
+inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ------------------------------------------------------------------------------------------ maxpool
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          uint8_t *__restrict__ am, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
+    const int CV = C / 4;
+    const long total = (long)N * Ho * Wo * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int cv = (int)(i % CV);
+        long t = i / CV;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yi = yo * 2 - 1 + r;
+            if (yi < 0 || yi >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int xi = xo * 2 - 1 + s;
+                if (xi < 0 || xi >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + yi) * W + xi) * C + cv * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // torch max_pool2d: index starts at the first valid tap; later taps win on
+                    // strict '>' (or NaN)
+                    if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bi[e] = r * 3 + s;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(y + i * 4) = best;
+        uchar4 code = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
+        *reinterpret_cast<uchar4 *>(am + i * 4) = code;
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ am,
+                                                          float *__restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int CV = C / 4;
+    const long total = (long)N * H * W * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int cv = (int)(i % CV);
+        long t = i / CV;
+        const int xi = (int)(t % W);
+        t /= W;
+        const int yi = (int)(t % H);
+        const int n = (int)(t / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ty = yi + 1 - r;
+            if (ty < 0 || (ty & 1)) continue;
+            const int yo = ty >> 1;
+            if (yo >= Ho) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int tx = xi + 1 - s;
+                if (tx < 0 || (tx & 1)) continue;
+                const int xo = tx >> 1;
+                if (xo >= Wo) continue;
+                const long o = ((((long)n * Ho + yo) * Wo + xo) * CV + cv) * 4;
+                const uchar4 code = *reinterpret_cast<const uchar4 *>(am + o);
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + o);
+                const int want = r * 3 + s;
+                if (code.x == want) acc[0] += g[0];
+                if (code.y == want) acc[1] += g[1];
+                if (code.z == want) acc[2] += g[2];
+                if (code.w == want) acc[3] += g[3];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- resize
+// PyTorch area_pixel_compute_source_index (UpSample.h): align_corners ? scale*dst
+//   : max(scale*(dst+0.5)-0.5, 0); scale = align ? (in-1)/(out-1) : in/out.
+__device__ __forceinline__ void src_index(int dst, float scale, int align, int in_size, int &i0, int &i1, float &l1) {
+    float s = align ? scale * dst : fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - i0;
+}
+inline float host_scale(int in, int out, int align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+__global__ void __launch_bounds__(256) resize_nhwc_fwd_kernel(const float *__restrict__ x, int x_pitch,
+                                                              float *__restrict__ y, int y_pitch, int N, int Hi,
+                                                              int Wi, int Ho, int Wo, int C, int align, float sh,
+                                                              float sw) {
+    const int CV = C / 4;
+    const long total = (long)N * Ho * Wo * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int cv = (int)(i % CV);
+        long t = i / CV;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(yo, sh, align, Hi, y0, y1, ly);
+        src_index(xo, sw, align, Wi, x0, x1, lx);
+        const float *base = x + (long)n * Hi * Wi * x_pitch + cv * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(base + ((long)y0 * Wi + x0) * x_pitch);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(base + ((long)y0 * Wi + x1) * x_pitch);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(base + ((long)y1 * Wi + x0) * x_pitch);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(base + ((long)y1 * Wi + x1) * x_pitch);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+        *reinterpret_cast<f32x4 *>(y + (((long)n * Ho + yo) * Wo + xo) * y_pitch + cv * 4) = o;
+    }
+}
+
+
+// weights of output index o onto input index `in_idx`
+__device__ __forceinline__ float tap_weight(int o, int in_idx, float scale, int align, int in_size) {
+    int i0, i1;
+    float l1;
+    src_index(o, scale, align, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == in_idx) w += 1.f - l1;
+    if (i1 == in_idx) w += l1;
+    return w;
+}
+__device__ __forceinline__ void cand_range(int in_idx, float scale, int align, int out_size, int &lo, int &hi) {
+    if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+    const float inv = 1.f / scale;
+    float a, b;
+    if (align) { a = (in_idx - 1) * inv; b = (in_idx + 1) * inv; }
+    else { a = (in_idx - 0.5f) * inv - 0.5f; b = (in_idx + 1.5f) * inv - 0.5f; }
+    lo = (int)floorf(a) - 1;
+    hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
+__global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__restrict__ dy, int dy_pitch,
+                                                              float *__restrict__ dx, int dx_pitch, int beta, int N,
+                                                              int Hi, int Wi, int Ho, int Wo, int C, int align,
+                                                              float sh, float sw) {
+    const int CV = C / 4;
+    const long total = (long)N * Hi * Wi * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int cv = (int)(i % CV);
+        long t = i / CV;
+        const int xi = (int)(t % Wi);
+        t /= Wi;
+        const int yi = (int)(t % Hi);
+        const int n = (int)(t / Hi);
+        int ylo, yhi, xlo, xhi;
+        cand_range(yi, sh, align, Ho, ylo, yhi);
+        cand_range(xi, sw, align, Wo, xlo, xhi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int yo = ylo; yo <= yhi; ++yo) {
+            const float wy = tap_weight(yo, yi, sh, align, Hi);
+            if (wy == 0.f) continue;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                const float wx = tap_weight(xo, xi, sw, align, Wi);
+                if (wx == 0.f) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
+                acc += g * (wy * wx);
+            }
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4);
+        *dst = beta ? (*dst + acc) : acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) resize_nchw_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          int planes, int Hi, int Wi, int Ho, int Wo, int align,
+                                                          float sh, float sw) {
+    const long total = (long)planes * Ho * Wo;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int xo = (int)(i % Wo);
+        long t = i / Wo;
+        const int yo = (int)(t % Ho);
+        const long pl = t / Ho;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(yo, sh, align, Hi, y0, y1, ly);
+        src_index(xo, sw, align, Wi, x0, x1, lx);
+        const float *b = x + pl * Hi * Wi;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        y[i] = hy * (hx * b[(long)y0 * Wi + x0] + lx * b[(long)y0 * Wi + x1]) +
+               ly * (hx * b[(long)y1 * Wi + x0] + lx * b[(long)y1 * Wi + x1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- layout
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int N,
+                                                           int C, long HW, int Cpad) {
+    const long total = (long)N * HW;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long n = i / HW, p = i - n * HW;
+        const float *src = x + n * C * HW + p;
+        float *dst = y + i * Cpad;
+        for (int c = 0; c < Cpad; c += 4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (c + e) < C ? src[(long)(c + e) * HW] : 0.f;
+            *reinterpret_cast<f32x4 *>(dst + c) = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float *__restrict__ x, int x_pitch,
+                                                           float *__restrict__ y, int N, int C, long HW) {
+    const long total = (long)N * C * HW;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long p = i % HW;
+        const long t = i / HW;
+        const int c = (int)(t % C);
+        const long n = t / C;
+        y[i] = x[(n * HW + p) * x_pitch + c];
+    }
+}
+
+__global__ void __launch_bounds__(256) copy2d_kernel(const float *__restrict__ src, long spitch,
+                                                     float *__restrict__ dst, long dpitch, long rows, int C, int beta) {
+    const int CV = C / 4;
+    const long total = rows * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long r = i / CV;
+        const int c4 = (int)(i - r * CV) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * spitch + c4);
+        f32x4 *d = reinterpret_cast<f32x4 *>(dst + r * dpitch + c4);
+        *d = beta ? (*d + v) : v;
+    }
+}
+
+}  // namespace
+
+extern "C" int rcf_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho,
+                                        int Wo, void *stream) {
+    if (!x || !y || !argmax || C % 4 || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RCF_EINVAL;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       rcf_stream(stream), x, y, argmax, N, H, W, C, Ho, Wo);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
+                                        int Ho, int Wo, void *stream) {
+    if (!dy || !dx || !argmax || C % 4) return RCF_EINVAL;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, rcf_stream(stream),
+                       dy, argmax, dx, N, H, W, C, Ho, Wo);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_resize_bilinear_nhwc_fwd_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi,
+                                                int Wi, int Ho, int Wo, int C, int align_corners, void *stream) {
+    if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       rcf_stream(stream), x, x_pitch, y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners,
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners));
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta,
+                                                int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                                                void *stream) {
+    if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
+                       rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners));
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_resize_bilinear_nchw_f32(const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
+                                            int align_corners, void *stream) {
+    if (!x || !y || planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(resize_nchw_kernel, dim3(ew_blocks((long)planes * Ho * Wo)), dim3(256), 0, rcf_stream(stream), x,
+                       y, planes, Hi, Wi, Ho, Wo, align_corners, host_scale(Hi, Ho, align_corners),
+                       host_scale(Wi, Wo, align_corners));
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_nchw_to_nhwc_f32(const float *x, float *y, int N, int C, int H, int W, int Cpad, void *stream) {
+    if (!x || !y || Cpad % 4 || Cpad < C) return RCF_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long)N * H * W)), dim3(256), 0, rcf_stream(stream), x, y, N,
+                       C, (long)H * W, Cpad);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N, int C, int H, int W, void *stream) {
+    if (!x || !y || x_pitch < C) return RCF_EINVAL;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((long)N * C * H * W)), dim3(256), 0, rcf_stream(stream), x,
+                       x_pitch, y, N, C, (long)H * W);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
+                              void *stream) {
+    if (!src || !dst || C % 4 || spitch % 4 || dpitch % 4 || rows <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), src, spitch,
+                       dst, dpitch, rows, C, beta);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}

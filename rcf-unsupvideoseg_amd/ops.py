@@ -1,0 +1,327 @@
+"""Tensor-level wrappers over the C ABI (include/rcf_hip.h).
+
+torch is used here only as the owner of device memory and of the HIP stream: every function
+takes/returns torch CUDA tensors, pulls raw device pointers out of them and launches the
+hand-written kernels in librcf_hip.so on torch's current stream.  No torch arithmetic.
+
+Activation convention: NHWC fp32 tensors of shape [N,H,W,C] whose last dim is contiguous; a
+tensor may be a channel slice of a wider buffer (pitch = stride(2) > C).
+Conv weights: torch shape [Cout,Cin,R,S] in channels_last memory format, i.e. [Cout][R][S][Cin]
+in memory.
+"""
+import ctypes
+from ctypes import c_void_p, byref
+
+import torch
+
+from . import _lib
+from ._lib import ConvShape, call
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.RcfHipError("rcf_amd ops need CUDA (HIP) tensors: there is no CPU fallback")
+
+
+def pitch_of(x):
+    """Pixel pitch of an NHWC activation view; validates the layout."""
+    N, H, W, C = x.shape
+    if C > 1 and x.stride(3) != 1:
+        raise ValueError("NHWC activation must be channel-contiguous")
+    if W > 1:
+        p = x.stride(2)
+    elif H > 1:
+        p = x.stride(1)
+    elif N > 1:
+        p = x.stride(0)
+    else:
+        p = C
+    ok = (H == 1 or x.stride(1) == W * p) and (N == 1 or x.stride(0) == H * W * p) and p >= C
+    if not ok:
+        raise ValueError(f"not a pitched NHWC view: shape {tuple(x.shape)} strides {x.stride()}")
+    return p
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def weight_rsck(w):
+    """[Cout,Cin,R,S] parameter -> its [Cout,R,S,Cin] memory view (must be channels_last)."""
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise ValueError("conv weight must be in channels_last memory format ([Cout][R][S][Cin])")
+    return v
+
+
+def conv_out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None):
+    N, H, W, Cin = xshape
+    Cout, Cin_w, R, S = w.shape
+    assert Cin == Cin_w, f"channel mismatch {Cin} vs {Cin_w}"
+    Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+    return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout)
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0):
+    _need_cuda(x, w)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    if out is None:
+        out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
+    s.y_pitch = pitch_of(out)
+    call("rcf_conv2d_fwd_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), act, slope, beta, _stream())
+    return out
+
+
+def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0):
+    _need_cuda(dy, w)
+    if out is None:
+        out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
+    call("rcf_conv2d_dgrad_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _stream())
+    return out
+
+
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1):
+    """dw (same memory layout as the weight) (+)= wgrad."""
+    _need_cuda(x, dy, dw)
+    s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy))
+    need = _lib.load().rcf_conv2d_wgrad_workspace_bytes(byref(s))
+    ws = workspace(need, x.device) if need else None
+    call("rcf_conv2d_wgrad_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), beta, _p(ws), need, _stream())
+    return dw
+
+
+def _rows(x):
+    return x.shape[0] * x.shape[1] * x.shape[2]
+
+
+def bn_stats(x):
+    """fp64 [2C]: per-channel sum | sum of squares over all pixels."""
+    _need_cuda(x)
+    rows, C = _rows(x), x.shape[3]
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
+    ws = workspace(need, x.device)
+    call("rcf_bn_stats_f32", _p(x), rows, C, pitch_of(x), _p(sums), _p(ws), need, _stream())
+    return sums
+
+
+def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
+    C = sums.numel() // 2
+    mean = torch.empty(C, dtype=torch.float32, device=sums.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=sums.device)
+    call("rcf_bn_finalize_f32", _p(sums), float(count), C, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+         _p(running_var), _stream())
+    return mean, invstd
+
+
+def bn_invstd_from_var(var, eps):
+    out = torch.empty_like(var)
+    call("rcf_bn_invstd_from_var_f32", _p(var), var.numel(), eps, _p(out), _stream())
+    return out
+
+
+def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None):
+    _need_cuda(x)
+    if out is None:
+        out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    rows, C = _rows(x), x.shape[3]
+    call("rcf_bn_apply_f32", _p(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
+         _p(out), pitch_of(out), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(chan_scale),
+         x.shape[1] * x.shape[2], _stream())
+    return out
+
+
+def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None):
+    rows, C = _rows(x), x.shape[3]
+    sums2 = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
+    ws = workspace(need, x.device)
+    call("rcf_bn_bwd_reduce_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
+         rows, C, _p(mean), _p(invstd), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), _p(ws), need,
+         _stream())
+    return sums2
+
+
+def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbeta, dx=None, dres=None, res_beta=0,
+                 chan_scale=None):
+    rows, C = _rows(x), x.shape[3]
+    if dx is None:
+        dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    call("rcf_bn_bwd_apply_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
+         _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
+         _p(invstd), _p(gamma), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), float(count),
+         _p(dgamma), _p(dbeta), _stream())
+    return dx
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    am = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    call("rcf_maxpool3x3s2_fwd_f32", _p(x), _p(y), _p(am), N, H, W, C, Ho, Wo, _stream())
+    return y, am
+
+
+def maxpool_bwd(dy, am, xshape):
+    N, H, W, C = xshape
+    assert dy.is_contiguous()
+    dx = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
+    call("rcf_maxpool3x3s2_bwd_f32", _p(dy), _p(am), _p(dx), N, H, W, C, dy.shape[1], dy.shape[2], _stream())
+    return dx
+
+
+def resize_nhwc_fwd(x, size, align_corners=False, out=None):
+    N, Hi, Wi, C = x.shape
+    Ho, Wo = size
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    call("rcf_resize_bilinear_nhwc_fwd_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
+         int(align_corners), _stream())
+    return out
+
+
+def resize_nhwc_bwd(dy, in_size, align_corners=False, out=None, beta=0):
+    N, Ho, Wo, C = dy.shape
+    Hi, Wi = in_size
+    if out is None:
+        out = torch.empty((N, Hi, Wi, C), dtype=torch.float32, device=dy.device)
+    call("rcf_resize_bilinear_nhwc_bwd_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho, Wo, C,
+         int(align_corners), _stream())
+    return out
+
+
+def resize_nchw(x, size, align_corners=False):
+    assert x.is_contiguous()
+    Hi, Wi = x.shape[-2:]
+    out = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
+    planes = x.numel() // (Hi * Wi)
+    call("rcf_resize_bilinear_nchw_f32", _p(x), _p(out), planes, Hi, Wi, size[0], size[1], int(align_corners), _stream())
+    return out
+
+
+def nchw_to_nhwc(x, cpad=None):
+    assert x.is_contiguous()
+    N, C, H, W = x.shape
+    cpad = cpad or (C + 3) // 4 * 4
+    out = torch.empty((N, H, W, cpad), dtype=torch.float32, device=x.device)
+    call("rcf_nchw_to_nhwc_f32", _p(x), _p(out), N, C, H, W, cpad, _stream())
+    return out
+
+
+def nhwc_to_nchw(x, C=None):
+    N, H, W, Cx = x.shape
+    C = C or Cx
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    call("rcf_nhwc_to_nchw_f32", _p(x), pitch_of(x), _p(out), N, C, H, W, _stream())
+    return out
+
+
+def copy2d(src, spitch, dst, dpitch, rows, C, beta=0):
+    call("rcf_copy2d_f32", _p(src), spitch, _p(dst), dpitch, rows, C, beta, _stream())
+
+
+def colsum(x, out, beta=1):
+    rows, C = _rows(x), x.shape[3]
+    need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
+    ws = workspace(need, x.device)
+    call("rcf_colsum_f32", _p(x), rows, C, pitch_of(x), _p(out), beta, _p(ws), need, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------- warp family (NCHW planar)
+PAD = {"border": 0, "zeros": 1}
+
+
+def flow_warp(x, flow12, pad="border"):
+    _need_cuda(x, flow12)
+    x, flow12 = x.contiguous(), flow12.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    call("rcf_flow_warp_f32", _p(x), _p(flow12), _p(out), B, C, H, W, PAD[pad], _stream())
+    return out
+
+
+def flow_warp_bwd(x, flow12, dout, pad="border", need_dx=True, need_dflow=True):
+    x, flow12, dout = x.contiguous(), flow12.contiguous(), dout.contiguous()
+    B, C, H, W = x.shape
+    dx = torch.zeros_like(x) if need_dx else None
+    dflow = torch.empty_like(flow12) if need_dflow else None
+    call("rcf_flow_warp_bwd_f32", _p(x), _p(flow12), _p(dout), _p(dx), _p(dflow), B, C, H, W, PAD[pad], _stream())
+    return dx, dflow
+
+
+def occu_mask_backward(flow21, th=0.2):
+    flow21 = flow21.contiguous()
+    B, _, H, W = flow21.shape
+    occ = torch.empty((B, 1, H, W), dtype=torch.float32, device=flow21.device)
+    scratch = torch.empty((B, H, W), dtype=torch.float32, device=flow21.device)
+    call("rcf_occu_mask_backward_f32", _p(flow21), _p(occ), th, _p(scratch), B, H, W, _stream())
+    return occ
+
+
+def occu_mask_bidirection(flow12, flow21, scale=0.01, bias=0.5):
+    flow12, flow21 = flow12.contiguous(), flow21.contiguous()
+    B, _, H, W = flow12.shape
+    occ = torch.empty((B, 1, H, W), dtype=torch.float32, device=flow12.device)
+    call("rcf_occu_mask_bidirection_f32", _p(flow12), _p(flow21), _p(occ), scale, bias, B, H, W, _stream())
+    return occ
+
+
+def warp_l1_residual(im1, im2, flow, occ=None, pad="border"):
+    """fused |im1 - warp(im2, flow)| * occ: returns fp64 [2] = (sum of masked residual, sum of occ)."""
+    im1, im2, flow = im1.contiguous(), im2.contiguous(), flow.contiguous()
+    B, C, H, W = im1.shape
+    out = torch.empty(2, dtype=torch.float64, device=im1.device)
+    call("rcf_warp_l1_residual_f32", _p(im1), _p(im2), _p(flow), _p(occ.contiguous() if occ is not None else None),
+         _p(out), B, C, H, W, PAD[pad], _stream())
+    return out
+
+
+def photometric_loss(im, recon, occ, w_l1=0.15, w_ssim=0.85):
+    im, recon, occ = im.contiguous(), recon.contiguous(), occ.contiguous()
+    B, C, H, W = im.shape
+    out = torch.empty(1, dtype=torch.float32, device=im.device)
+    scratch = torch.empty(4, dtype=torch.float64, device=im.device)
+    call("rcf_photometric_loss_f32", _p(im), _p(recon), _p(occ), w_l1, w_ssim, _p(out), _p(scratch), B, C, H, W, _stream())
+    return out[0]
+
+
+# ------------------------------------------------------------------------------- optimiser
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              grad_scale=1.0):
+    call("rcf_adam_step_f32", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
+         eps, weight_decay, step, grad_scale, _stream())
+
+
+def ema_update(dest, src, m):
+    call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
+
+
+def fill(t, v):
+    call("rcf_fill_f32", _p(t), t.numel(), float(v), _stream())

@@ -1,0 +1,282 @@
+"""GPU parity of the individual HIP kernels against plain PyTorch fp64 on CPU (the float kernels'
+reference) and against the golden vectors captured from the reference (warp family)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rcf_amd  # noqa: F401  (package alias)
+from rcf_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def to_nhwc(x):  # [N,C,H,W] cpu -> [N,H,W,C] gpu contiguous
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def from_nhwc(y):
+    return y.permute(0, 3, 1, 2).cpu()
+
+
+def cl_weight(w):  # OIHW cpu -> channels_last gpu
+    return w.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # N, Cin, Cout, k, stride, pad, dil, H, W, bias, act
+    (2, 64, 256, 1, 1, 0, 1, 13, 17, False, 0),
+    (2, 64, 64, 3, 1, 1, 1, 13, 17, False, 0),
+    (1, 128, 128, 3, 1, 2, 2, 15, 22, False, 0),
+    (2, 32, 48, 3, 1, 6, 6, 20, 27, False, 0),
+    (2, 64, 128, 3, 2, 1, 1, 13, 18, False, 0),
+    (2, 64, 128, 1, 2, 0, 1, 13, 18, False, 0),
+    (2, 4, 64, 7, 2, 3, 1, 30, 41, False, 0),
+    (2, 256, 4, 1, 1, 0, 1, 12, 14, True, 0),
+    (2, 4, 64, 3, 1, 1, 1, 12, 14, True, 1),
+    (1, 260, 136, 3, 1, 4, 4, 11, 23, False, 0),
+    (3, 512, 256, 1, 1, 0, 1, 9, 31, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, report):
+    N, Cin, Cout, k, stride, pad, dil, H, W, has_bias, act = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case)))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    conv = F.conv2d(xd, wd, b.double() if has_bias else None, stride=stride, padding=pad, dilation=dil)
+    yref = F.leaky_relu(conv, 0.1) if act else conv
+    dy = torch.randn(yref.shape, generator=g)
+    yref.backward(dy.double())
+    xg, wg = to_nhwc(x), cl_weight(w)
+    y = ops.conv2d_fwd(xg, wg, b.to(DEV) if has_bias else None, stride, pad, dil, act=act, slope=0.1)
+    e_f = relerr(from_nhwc(y), yref)
+    # the backward kernels are linear maps of the gradient w.r.t. the conv output (pre-activation)
+    gpre = dy.double() * torch.where(conv.detach() > 0, 1.0, 0.1) if act else dy.double()
+    gg = to_nhwc(gpre.float())
+    dx = ops.conv2d_dgrad(gg, wg, xg.shape, stride, pad, dil)
+    e_d = relerr(from_nhwc(dx), xd.grad)
+    dw = torch.zeros_like(wg)
+    ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=1)
+    e_w = relerr(dw.cpu(), wd.grad)
+    dx2 = ops.conv2d_dgrad(gg, wg, xg.shape, stride, pad, dil, out=dx.clone(), beta=1)
+    e_acc = relerr(from_nhwc(dx2), 2 * xd.grad)
+    report(f"conv {case}: fwd {e_f:.2e} dgrad {e_d:.2e} wgrad {e_w:.2e} acc {e_acc:.2e}")
+    assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_acc < 2e-5
+
+
+def test_conv_large_wgrad_splitk(report):
+    """enough pixels for the split-K path (workspace + deterministic reduce)"""
+    g = torch.Generator().manual_seed(77)
+    N, Cin, Cout, H, W = 4, 64, 64, 60, 107
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.04
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    wd = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wd, padding=1).backward(dy.double())
+    xg, gg, wg = to_nhwc(x), to_nhwc(dy), cl_weight(w)
+    dw1, dw2 = torch.zeros_like(wg), torch.zeros_like(wg)
+    ops.conv2d_wgrad(xg, gg, wg, dw1, 1, 1, 1)
+    ops.conv2d_wgrad(xg, gg, wg, dw2, 1, 1, 1)
+    e = relerr(dw1.cpu(), wd.grad)
+    report(f"wgrad split-K: {e:.2e} deterministic={torch.equal(dw1, dw2)}")
+    assert e < 2e-5 and torch.equal(dw1, dw2)
+
+
+def test_conv_pitched_slices(report):
+    """input read from / output written into channel slices of wider NHWC buffers (concat layout)."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 9, 11
+    x = torch.randn(N, 64, H, W, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    big_in = torch.zeros(N, H, W, 96, device=DEV)
+    big_in[..., 16:80] = to_nhwc(x)
+    big_out = torch.full((N, H, W, 200), 7.0, device=DEV)
+    ops.conv2d_fwd(big_in[..., 16:80], cl_weight(w), None, 1, 1, 1, out=big_out[..., 8:136])
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    e = relerr(from_nhwc(big_out[..., 8:136]), ref)
+    report(f"conv pitched: {e:.2e}")
+    assert e < 2e-5
+    assert float(big_out[..., :8].min()) == 7.0 and float(big_out[..., 136:].max()) == 7.0
+
+
+@pytest.mark.parametrize("C,relu,res,drop", [(64, True, False, False), (256, True, True, False),
+                                             (128, False, False, False), (256, True, False, True),
+                                             (2048, True, True, False)])
+def test_batchnorm_train(C, relu, res, drop, report):
+    g = torch.Generator().manual_seed(C + relu)
+    N, H, W = 3, 7, 9
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.7)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    r = torch.randn(N, C, H, W, generator=g) if res else None
+    keep = (torch.rand(N, C, generator=g) > 0.3).float() / 0.7 if drop else None
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rd = r.double().requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y = F.batch_norm(xd, rm, rv, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        y = y + rd
+    if relu:
+        y = F.relu(y)
+    if drop:
+        y = y * keep.double()[:, :, None, None]
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+
+    xg = to_nhwc(x)
+    rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    sums = ops.bn_stats(xg)
+    count = N * H * W
+    mean, invstd = ops.bn_finalize(sums, count, 1e-5, 0.1, rmean, rvar)
+    gg, bg = gamma.to(DEV), beta.to(DEV)
+    rg = to_nhwc(r) if res else None
+    kg = keep.to(DEV) if drop else None
+    yg = ops.bn_apply(xg, mean, invstd, gg, bg, relu, residual=rg, chan_scale=kg)
+    e_y = relerr(from_nhwc(yg), y)
+    e_rm, e_rv = relerr(rmean, rm), relerr(rvar, rv)
+    dyg = to_nhwc(dy)
+    s2 = ops.bn_bwd_reduce(dyg, xg, yg, mean, invstd, relu, chan_scale=kg)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dres = torch.empty_like(xg) if res else None
+    dx = ops.bn_bwd_apply(dyg, xg, yg, mean, invstd, gg, relu, s2, count, dgam, dbet, dres=dres, chan_scale=kg)
+    e_dx, e_dg, e_db = relerr(from_nhwc(dx), xd.grad), relerr(dgam, gd.grad), relerr(dbet, bd.grad)
+    e_dr = relerr(from_nhwc(dres), rd.grad) if res else 0.0
+    report(f"bn C={C} relu={relu} res={res} drop={drop}: y {e_y:.2e} rm {e_rm:.2e} rv {e_rv:.2e} dx {e_dx:.2e} "
+           f"dgamma {e_dg:.2e} dbeta {e_db:.2e} dres {e_dr:.2e}")
+    assert max(e_y, e_rm, e_rv, e_dx, e_dg, e_db, e_dr) < 2e-5
+
+
+def test_maxpool(report):
+    g = torch.Generator().manual_seed(3)
+    for (N, C, H, W) in [(2, 64, 15, 22), (1, 8, 240, 427), (2, 4, 8, 8)]:
+        x = torch.relu(torch.randn(N, C, H, W, generator=g))   # many exact ties at 0, like post-ReLU maps
+        xd = x.double().requires_grad_(True)
+        y = F.max_pool2d(xd, 3, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy.double())
+        yg, am = ops.maxpool_fwd(to_nhwc(x))
+        dx = ops.maxpool_bwd(to_nhwc(dy), am, (N, H, W, C))
+        assert torch.equal(from_nhwc(yg).double(), y.detach())
+        e = relerr(from_nhwc(dx), xd.grad)
+        report(f"maxpool {(N, C, H, W)}: dx {e:.2e}")
+        assert e < 1e-6
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,align", [(60, 107, 120, 214, False), (15, 27, 30, 54, False),
+                                               (7, 9, 20, 31, False), (24, 40, 6, 10, False), (12, 16, 24, 33, True),
+                                               (30, 54, 15, 27, True), (5, 5, 5, 5, False)])
+def test_resize_nhwc(Hi, Wi, Ho, Wo, align, report):
+    g = torch.Generator().manual_seed(Hi * Wo)
+    N, C = 2, 8
+    x = torch.randn(N, C, Hi, Wi, generator=g)
+    xd = x.double().requires_grad_(True)
+    y = F.interpolate(xd, (Ho, Wo), mode="bilinear", align_corners=align)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    yg = ops.resize_nhwc_fwd(to_nhwc(x), (Ho, Wo), align)
+    dx = ops.resize_nhwc_bwd(to_nhwc(dy), (Hi, Wi), align)
+    e_y, e_dx = relerr(from_nhwc(yg), y), relerr(from_nhwc(dx), xd.grad)
+    yp = ops.resize_nchw(x.to(DEV), (Ho, Wo), align)
+    e_p = relerr(yp, y)
+    report(f"resize {(Hi, Wi)}->{(Ho, Wo)} align={align}: y {e_y:.2e} dx {e_dx:.2e} planar {e_p:.2e}")
+    assert max(e_y, e_dx, e_p) < 2e-5
+
+
+def test_layout_copy_colsum(report):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 3, 10, 13, generator=g)
+    nhwc = ops.nchw_to_nhwc(x.to(DEV), 4)
+    assert torch.equal(nhwc[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(nhwc[..., 3].abs().max()) == 0.0
+    back = ops.nhwc_to_nchw(nhwc, 3)
+    assert torch.equal(back.cpu(), x)
+    a = torch.randn(50, 16, generator=g).to(DEV)
+    dst = torch.zeros(50, 40, device=DEV)
+    ops.copy2d(a, 16, dst[:, 8:], 40, 50, 16)
+    ops.copy2d(a, 16, dst[:, 8:], 40, 50, 16, beta=1)
+    assert torch.equal(dst[:, 8:24], 2 * a) and float(dst[:, :8].abs().max()) == 0
+    assert float(dst[:, 24:].abs().max()) == 0
+    t = torch.randn(2, 31, 17, 16, generator=g)
+    out = torch.ones(16, device=DEV)
+    ops.colsum(t.to(DEV), out, beta=1)
+    e = relerr(out, 1 + t.double().sum(dim=(0, 1, 2)))
+    report(f"colsum: {e:.2e}")
+    assert e < 1e-6
+
+
+def test_adam_and_ema(report):
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(10007, generator=g)
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4, weight_decay=1e-4)
+    pg = p0.clone().to(DEV)
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    for step in range(1, 4):
+        gr = torch.randn(10007, generator=g)
+        pr.grad = gr.double()
+        opt.step()
+        ops.adam_step(pg, gr.to(DEV), m, v, 1e-4, step, weight_decay=1e-4)
+    e = float((pg.cpu().double() - pr.detach()).abs().max() / 3e-4)   # relative to the total update size
+    d, s = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    dg = d.clone().to(DEV)
+    ops.ema_update(dg, s.to(DEV), 0.999)
+    e2 = relerr(dg, d * 0.999 + s * (1 - 0.999))
+    report(f"adam: {e:.2e} (of update) ema: {e2:.2e}")
+    assert e < 1e-3 and e2 < 1e-6
+
+
+def test_warp_family_vs_golden(golden_dir, report):
+    fx = np.load(os.path.join(golden_dir, "warp.npz"))
+    x, y = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["y"]).to(DEV)
+    for name in ("random", "integer", "outofrange"):
+        f12 = torch.from_numpy(fx[f"{name}_f12"]).to(DEV)
+        f21 = torch.from_numpy(fx[f"{name}_f21"]).to(DEV)
+        wb = ops.flow_warp(x, f12, "border")
+        wz = ops.flow_warp(x, f12, "zeros")
+        e_b = float((wb.cpu() - torch.from_numpy(fx[f"{name}_warp_border"])).abs().max())
+        e_z = float((wz.cpu() - torch.from_numpy(fx[f"{name}_warp_zeros"])).abs().max())
+        ob = ops.occu_mask_backward(f21, 0.2)
+        obi = ops.occu_mask_bidirection(f12, f21)
+        m_b = float((ob.cpu() != torch.from_numpy(fx[f"{name}_occ_back"]).float()).float().mean())
+        m_bi = float((obi.cpu() != torch.from_numpy(fx[f"{name}_occ_bidir"]).float()).float().mean())
+        occ_ref = 1 - torch.from_numpy(fx[f"{name}_occ_back"]).float().to(DEV)
+        wb_ref = torch.from_numpy(fx[f"{name}_warp_border"])
+        ph = ops.photometric_loss(y, wb_ref.to(DEV), occ_ref)
+        e_p = abs(float(ph) - float(fx[f"{name}_photo"])) / abs(float(fx[f"{name}_photo"]))
+        l1 = ops.warp_l1_residual(y, x, f12, occ_ref, "border").cpu()
+        l1_ref = ((y.cpu() - wb_ref).abs().sum(1, keepdim=True) * occ_ref.cpu()).double().sum()
+        e_l1 = abs(float(l1[0]) - float(l1_ref)) / float(l1_ref)
+        report(f"warp {name}: border {e_b:.2e} zeros {e_z:.2e} occ_back mism {m_b:.2e} occ_bidir mism {m_bi:.2e} "
+               f"photo {e_p:.2e} fusedL1 {e_l1:.2e}")
+        assert e_b < 2e-5 and e_z < 2e-5 and m_b < 2e-3 and m_bi < 2e-3 and e_p < 1e-4 and e_l1 < 1e-5
+
+
+def test_warp_backward(report):
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = 2, 3, 17, 23
+    x = torch.randn(B, C, H, W, generator=g)
+    fl = torch.randn(B, 2, H, W, generator=g) * 3
+    dout = torch.randn(B, C, H, W, generator=g)
+    for pad in ("border", "zeros"):
+        xd, fd = x.double().requires_grad_(True), fl.double().requires_grad_(True)
+        xs = torch.arange(W, dtype=torch.float64).view(1, 1, W).expand(B, H, W)
+        ys = torch.arange(H, dtype=torch.float64).view(1, H, 1).expand(B, H, W)
+        gr = torch.stack([xs, ys], 1) + fd
+        gn = torch.stack([2.0 * gr[:, 0] / (W - 1) - 1.0, 2.0 * gr[:, 1] / (H - 1) - 1.0], dim=-1)
+        out = F.grid_sample(xd, gn, mode="bilinear", padding_mode=pad, align_corners=True)
+        out.backward(dout.double())
+        dx, dfl = ops.flow_warp_bwd(x.to(DEV), fl.to(DEV), dout.to(DEV), pad)
+        e1, e2 = relerr(dx, xd.grad), relerr(dfl, fd.grad)
+        report(f"warp bwd {pad}: dx {e1:.2e} dflow {e2:.2e}")
+        assert e1 < 2e-5 and e2 < 2e-4
