@@ -1,0 +1,203 @@
+"""ResNet backbone (`backbone2`) and FCN decode heads (`decode_head2/3`) on the HIP tape.
+
+Same constructor keywords and state-dict keys as the reference components they replace:
+  ResNet      models/resnet.py:371-466 (ctor), :630-645 (forward), :598-628 (init); stage assembly
+              models/res_layer.py:26-94 (contract_dilation :66-70); Bottleneck :95-302
+  FCNHead     models/fcn_head.py:50-140,142-147,211-218 + models/decode_head.py:45-90,141-170
+Only the options the RCF configs use are implemented; anything else raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import Act, BatchNorm2d, Conv2d, concat_channels, maxpool3x3s2
+
+
+def make_norm(norm_cfg, n):
+    t = (norm_cfg or {}).get("type", "BN")
+    if t not in ("BN", "SyncBN"):
+        raise NotImplementedError(f"norm type {t}")
+    return BatchNorm2d(n, requires_grad=bool((norm_cfg or {}).get("requires_grad", True)))
+
+
+class Downsample(nn.Module):
+    """nn.Sequential(conv, norm) of models/res_layer.py:53-63 -- keys `0.weight`, `1.*`."""
+
+    def __init__(self, conv, norm):
+        super().__init__()
+        self.add_module("0", conv)
+        self.add_module("1", norm)
+
+    def fwd(self, x, tape, dist):
+        return getattr(self, "1").fwd(getattr(self, "0").fwd(x, tape), tape, relu=False, dist=dist)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, dilation, downsample, norm_cfg):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = make_norm(norm_cfg, planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation)
+        self.bn2 = make_norm(norm_cfg, planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = make_norm(norm_cfg, planes * 4)
+        self.downsample = downsample
+
+    def fwd(self, x, tape, dist):
+        o = self.bn1.fwd(self.conv1.fwd(x, tape), tape, relu=True, dist=dist)
+        o = self.bn2.fwd(self.conv2.fwd(o, tape), tape, relu=True, dist=dist)
+        o = self.conv3.fwd(o, tape)
+        idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
+        return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist)   # relu(bn3 + identity)
+
+
+class Stage(nn.Module):
+    """children named 0..n-1 like the reference's ResLayer(nn.Sequential)."""
+
+    def __init__(self, blocks):
+        super().__init__()
+        for i, b in enumerate(blocks):
+            self.add_module(str(i), b)
+
+    def fwd(self, x, tape, dist):
+        for b in self.children():
+            x = b.fwd(x, tape, dist)
+        return x
+
+
+class ResNet(nn.Module):
+    blocks_per_depth = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=50, in_channels=3, stem_channels=64, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style="pytorch",
+                 norm_cfg=None, norm_eval=False, contract_dilation=False, zero_init_residual=True, **unsupported):
+        super().__init__()
+        for k, v in unsupported.items():
+            if v not in (None, False, -1, (False, False, False, False)):
+                raise NotImplementedError(f"ResNet option {k}={v!r} is off the RCF path")
+        if style != "pytorch" or depth not in self.blocks_per_depth or norm_eval:
+            raise NotImplementedError("only pytorch-style bottleneck ResNets with train-mode norm")
+        norm_cfg = norm_cfg or dict(type="BN", requires_grad=True)
+        self.out_indices, self.num_stages, self.zero_init_residual = tuple(out_indices), num_stages, zero_init_residual
+        self.conv1 = Conv2d(in_channels, stem_channels, 7, stride=2, padding=3)
+        self.bn1 = make_norm(norm_cfg, stem_channels)
+        inplanes = stem_channels
+        for i, nblocks in enumerate(self.blocks_per_depth[depth][:num_stages]):
+            planes, stride, dil = base_channels * 2 ** i, strides[i], dilations[i]
+            down = None
+            if stride != 1 or inplanes != planes * 4:
+                down = Downsample(Conv2d(inplanes, planes * 4, 1, stride=stride), make_norm(norm_cfg, planes * 4))
+            first = dil // 2 if (dil > 1 and contract_dilation) else dil
+            blocks = [Bottleneck(inplanes, planes, stride, first, down, norm_cfg)]
+            inplanes = planes * 4
+            blocks += [Bottleneck(inplanes, planes, 1, dil, None, norm_cfg) for _ in range(1, nblocks)]
+            setattr(self, f"layer{i + 1}", Stage(blocks))
+        self.feat_dim = inplanes
+
+    def init_weights(self, pretrained=None):
+        if pretrained is not None:
+            raise NotImplementedError("load checkpoints through load_state_dict (main.py:76-144 does)")
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def fwd(self, img, tape, dist=None):
+        """img: Act of the NHWC image zero-padded to 4 channels; returns the list of stage outputs."""
+        x = self.bn1.fwd(self.conv1.fwd(img, tape), tape, relu=True, dist=dist)
+        x = maxpool3x3s2(x, tape)
+        outs = []
+        for i in range(self.num_stages):
+            x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs
+
+    def forward(self, x):
+        """nn.Module surface (`backbone2(img [N,3,H,W]) -> tuple of 4 NCHW maps`), inference only."""
+        from .layers import Tape
+        img = Act(ops.nchw_to_nhwc(x.contiguous().float(), 4), needs_grad=False)
+        outs = self.fwd(img, Tape(enabled=False))
+        return tuple(ops.nhwc_to_nchw(o.t) for o in outs)
+
+
+class ConvModule(nn.Module):
+    """mmcv ConvModule as built by models/fcn_head.py:107-130: conv (bias only without norm) -> BN -> ReLU."""
+
+    def __init__(self, cin, cout, k, padding, dilation, stride, norm_cfg):
+        super().__init__()
+        if norm_cfg is None:
+            raise NotImplementedError("ConvModule without a norm layer is off the RCF path")
+        self.conv = Conv2d(cin, cout, k, stride=stride, padding=padding, dilation=dilation)
+        self.bn = make_norm(norm_cfg, cout)
+
+    def fwd(self, x, tape, dist, chan_scale=None):
+        return self.bn.fwd(self.conv.fwd(x, tape), tape, relu=True, chan_scale=chan_scale, dist=dist)
+
+
+class FCNHead(nn.Module):
+    def __init__(self, in_channels, channels, *, num_classes, num_convs=2, kernel_size=3, concat_input=True,
+                 dilation=1, input_stride=1, input_dilation=None, dropout_ratio=0.1, norm_cfg=None, in_index=-1,
+                 input_transform=None, align_corners=False, transform_scale=None, create_flownet=False,
+                 conv_cfg=None, act_cfg=None, loss_decode=None, ignore_index=255, sampler=None, mask_layer=1,
+                 ssim_sz=1, load_flownet=False, freeze_flownet=False, flow_model_path=""):
+        super().__init__()
+        if create_flownet:
+            raise NotImplementedError("FCNHead(create_flownet=True) is the AMD baseline (PWC-Lite), not RCF")
+        if concat_input or conv_cfg is not None or sampler is not None or num_convs < 1:
+            raise NotImplementedError("FCNHead option off the RCF path (concat_input / conv_cfg / sampler)")
+        self.input_transform, self.in_index = input_transform, in_index
+        if input_transform == "resize_concat":
+            in_channels = sum(in_channels)
+        elif input_transform is not None:
+            raise NotImplementedError(input_transform)
+        self.in_channels, self.channels, self.num_classes = in_channels, channels, num_classes
+        self.align_corners, self.transform_scale, self.dropout_ratio = align_corners, transform_scale, dropout_ratio
+        self.conv_seg = Conv2d(channels, num_classes, 1, bias=True)
+        nn.init.kaiming_uniform_(self.conv_seg.weight, a=5 ** 0.5)      # torch Conv2d default: never re-initialised
+        nn.init.uniform_(self.conv_seg.bias, -1 / channels ** 0.5, 1 / channels ** 0.5)   # 
+        if input_dilation is None:
+            input_dilation = dilation
+        convs = [ConvModule(in_channels, channels, kernel_size, input_dilation, input_dilation, input_stride, norm_cfg)]
+        convs += [ConvModule(channels, channels, kernel_size, dilation, dilation, 1, norm_cfg)
+                  for _ in range(num_convs - 1)]
+        self.convs = Stage(convs)
+        self.keep_mask = None           # tests may inject a Dropout2d keep-mask [N, channels]
+
+    def transform_inputs(self, feats, tape):
+        if self.input_transform == "resize_concat":
+            sel = [feats[i] for i in self.in_index]
+            size = tuple(sel[0].t.shape[1:3])
+            if self.transform_scale is not None:
+                size = tuple(s * self.transform_scale for s in size)
+            return concat_channels(sel, tape, size, self.align_corners)
+        return feats[self.in_index]
+
+    def fwd(self, feats, tape, dist=None):
+        x = self.transform_inputs(feats, tape)
+        mods = list(self.convs.children())
+        scale = None
+        if self.training and self.dropout_ratio > 0:
+            # nn.Dropout2d: one Bernoulli(1-p) per (n, c) plane, kept planes scaled by 1/(1-p)
+            if self.keep_mask is not None:
+                scale = self.keep_mask
+            else:
+                keep = 1.0 - self.dropout_ratio
+                scale = torch.bernoulli(torch.full((x.t.shape[0], self.channels), keep, device=x.t.device)) / keep
+        for i, m in enumerate(mods):
+            x = m.fwd(x, tape, dist, chan_scale=scale if i == len(mods) - 1 else None)
+        return self.conv_seg.fwd(x, tape)
+
+    def forward(self, inputs):
+        """nn.Module surface (list of NCHW maps -> NCHW logits), inference only."""
+        from .layers import Tape
+        feats = [Act(ops.nchw_to_nhwc(f.contiguous().float()), needs_grad=False) for f in inputs]
+        return ops.nhwc_to_nchw(self.fwd(feats, Tape(enabled=False)).t)

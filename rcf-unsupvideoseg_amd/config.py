@@ -1,0 +1,97 @@
+"""YAML config loading with `base_config` inheritance and dotted `--opts` overrides -- the part of
+utils/utils.py:8-16,36-65,83-148 the hot path needs (duplicate keys rejected, lists replaced,
+override type coerced from the existing value)."""
+import argparse
+import os
+
+import yaml
+
+
+class _UniqueKeyLoader(yaml.SafeLoader):
+    def construct_mapping(self, node, deep=False):
+        seen = set()
+        for key_node, _ in node.value:
+            key = self.construct_object(key_node, deep=deep)
+            if key in seen:
+                raise ValueError(f"Duplicate {key!r} key found in YAML.")
+            seen.add(key)
+        return super().construct_mapping(node, deep)
+
+
+def _merge(base, new):
+    for k, v in new.items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            _merge(base[k], v)
+        else:
+            base[k] = v
+    return base
+
+
+def load_yaml(path):
+    with open(path) as f:
+        cfg = yaml.load(f, Loader=_UniqueKeyLoader) or {}
+    parent = cfg.pop("base_config", None)
+    if parent:
+        if not os.path.isabs(parent) and not os.path.exists(parent):
+            parent = os.path.join(os.path.dirname(path), parent)
+        cfg = _merge(load_yaml(parent), cfg)
+    return cfg
+
+
+def apply_opts(cfg, opts):
+    assert len(opts) % 2 == 0, f"{len(opts)} should be even"
+    for key, value in zip(opts[::2], opts[1::2]):
+        node = cfg
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        old = node[parts[-1]]
+        if isinstance(old, bool):
+            if value in ("True", "true", "1"):
+                value = True
+            elif value in ("False", "false", "0"):
+                value = False
+            else:
+                raise ValueError(f"Unknown bool value for {key}: {value}")
+        elif isinstance(old, int):
+            value = int(value)
+        elif isinstance(old, float):
+            value = float(value)
+        assert type(old) == type(value), f"{type(old)} != {type(value)}"
+        node[parts[-1]] = value
+    return cfg
+
+
+def load_args(path, cli_opts=()):
+    return argparse.Namespace(**apply_opts(load_yaml(path), list(cli_opts)))
+
+
+def stage1_model_kwargs(mask_size=(120, 214), mask_layer=4, dropout=0.1, affine=False, norm="SyncBN"):
+    """`model_kwargs` of configs/rcf/rcf_stage1.yaml:63-148 with the mask size of the 480x854 runs
+    (SURVEY.md F1).  affine=True gives the STv2/FBMS variant (free_residual_with_affine)."""
+    ncfg = dict(type=norm, requires_grad=True)
+    return dict(
+        w_seg=1.0, w_sharpen=0, w_entropy=0.05, separate_residual=True, mask_layer=mask_layer, align_corners=False,
+        mask_size=list(mask_size),
+        backbone2=dict(type="ResNet", depth=50, num_stages=4, out_indices=[0, 1, 2, 3], dilations=[1, 1, 2, 4],
+                       strides=[1, 2, 1, 1], norm_cfg=dict(ncfg), norm_eval=False, style="pytorch",
+                       contract_dilation=True),
+        decode_head=dict(type="FlowAggregationHeadWithResidual", ssim_sz=1, create_flownet=True,
+                         mask_layer=mask_layer, flow_feat_before_agg_kernel_size=3, num_flow_feat_channels=64,
+                         mask_size=list(mask_size), norm_flow=False, clamp_flow_t=20., free_residual=not affine,
+                         free_residual_with_affine=affine, free_scale=False, outlier_robust_loss=False, eps=0.01,
+                         q=0.4, allow_residual_resize=True, residual_adjustment_scale=10., pred_div_coeff=10.),
+        decode_head2=dict(type="FCNHead", input_transform="resize_concat", concat_input=False, dilation=6,
+                          channels=256, in_channels=[256, 2048], in_index=[0, 3], num_convs=2, dropout_ratio=dropout,
+                          num_classes=mask_layer, norm_cfg=dict(ncfg), align_corners=False,
+                          loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0)),
+        decode_head3=dict(type="FCNHead", concat_input=False, dilation=6, channels=256, in_channels=4096, in_index=-1,
+                          num_convs=2, dropout_ratio=dropout, num_classes=4 * mask_layer, norm_cfg=dict(ncfg),
+                          align_corners=False,
+                          loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0)))
+
+
+def mask_size_for(H, W):
+    """spatial size after the 7x7/2 stem and the 3x3/2 max-pool."""
+    h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    return ((h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1)

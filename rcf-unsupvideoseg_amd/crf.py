@@ -1,0 +1,103 @@
+"""Dense-CRF refinement: `CRFHead` (models/crf_head.py:12-109) and a `torchcrf_cpp`-compatible
+module surface (`crf_soft` / `crf_hard`, tools/torchCRF/src/torchcrf.cu:106-149) over the HIP
+permutohedral mean-field kernels (csrc/crf.hip).  Frames are batched into ONE library call with a
+persistent workspace (the reference loops over frames in Python and cudaMallocs 12 buffers each).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import _p, _stream, workspace
+
+
+def _check(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")          # CHECK_CUDA, torchcrf.cu:18
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")             # CHECK_CONTIGUOUS, torchcrf.cu:19
+
+
+def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
+                     want_q=False, want_nvert=False):
+    """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2])."""
+    _check(rgb_u8, "rgbFeat")
+    _check(unary, "unaryEnergy")
+    n = rgb_u8.shape[0]
+    if tuple(rgb_u8.shape) != (n, H, W, 3) or tuple(unary.shape) != (n, H * W, 2):
+        raise RuntimeError("shape check not satisfied")               # CHECK_COND, torchcrf.cu:55-82
+    dev = rgb_u8.device
+    out = torch.empty((n, H, W), dtype=torch.int16, device=dev)
+    q = torch.empty((n, H * W, 2), dtype=torch.float32, device=dev) if want_q else None
+    nv = torch.zeros((n, 2), dtype=torch.int32, device=dev) if want_nvert else None
+    need = _lib.load().rcf_crf_workspace_bytes(W, H, n)
+    ws = workspace(need, dev)
+    _lib.call("rcf_crf_soft", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
+              int(iters), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
+    res = (out,)
+    if want_q:
+        res += (q,)
+    if want_nvert:
+        res += (nv,)
+    return res if len(res) > 1 else out
+
+
+def crf_soft(rgbFeat, unaryEnergy, W, H, scompSmooth=3.0, sxySmooth=3.0, scompApp=10.0, sxyApp=60.0, srgbApp=20.0,
+             iters=10):
+    """torchcrf_cpp.crf_soft: rgbFeat [H,W,3] (any dtype; uint8 on the RCF path), unary [H*W,2] f32."""
+    img = rgbFeat if rgbFeat.dtype == torch.uint8 else rgbFeat.round().clamp(0, 255).to(torch.uint8)
+    return crf_soft_batched(img.contiguous()[None], unaryEnergy.float()[None], W, H, scompSmooth, sxySmooth, scompApp,
+                            sxyApp, srgbApp, iters)[0]
+
+
+def crf_hard(rgbFeat, label, W, H, scompSmooth=3.0, sxySmooth=3.0, scompApp=10.0, sxyApp=60.0, srgbApp=20.0,
+             confidence=0.5, iters=10):
+    """torchcrf_cpp.crf_hard: label int16 [H,W] (-1 = unknown)."""
+    _check(rgbFeat, "rgbFeat")
+    _check(label, "label")
+    img = rgbFeat if rgbFeat.dtype == torch.uint8 else rgbFeat.round().clamp(0, 255).to(torch.uint8)
+    dev = img.device
+    out = torch.empty((1, H, W), dtype=torch.int16, device=dev)
+    need = _lib.load().rcf_crf_workspace_bytes(W, H, 1)
+    ws = workspace(need, dev)
+    _lib.call("rcf_crf_hard", _p(img.contiguous()), _p(label.to(torch.int16).contiguous()), W, H, 1, scompSmooth,
+              sxySmooth, scompApp, sxyApp, srgbApp, confidence, int(iters), _p(out), None, None, _p(ws), need, _stream())
+    return out[0]
+
+
+class CRFHead(nn.Module):
+    def __init__(self, args=None, srgb=5., scomp=5., sxy=60., scomp_smooth=0., sxy_smooth=0., refine_iters=50,
+                 crf_scale=0.7, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        super().__init__()
+        self.args = args
+        self.srgb, self.scomp, self.sxy = srgb, scomp, sxy
+        self.scomp_smooth, self.sxy_smooth = scomp_smooth, sxy_smooth
+        self.refine_iters, self.crf_scale = refine_iters, crf_scale
+        self._mean, self._std = tuple(mean), tuple(std)
+        self._consts = None
+
+    def _mean_std(self, device):
+        if self._consts is None or self._consts[0].device != device:
+            self._consts = (torch.tensor(self._mean, dtype=torch.float32, device=device),
+                            torch.tensor(self._std, dtype=torch.float32, device=device))
+        return self._consts
+
+    def prepare(self, imgs, masks, unstandardize=True):
+        """models/crf_head.py:33-37,43-55,95-98 on the GPU: -> (u8 image [N,H,W,3], unary [N,HW,2])."""
+        imgs, masks = imgs.contiguous().float(), masks.contiguous().float()
+        N, _, H, W = imgs.shape
+        mean, std = self._mean_std(imgs.device)
+        rgb = torch.empty((N, H, W, 3), dtype=torch.uint8, device=imgs.device)
+        unary = torch.empty((N, H * W, 2), dtype=torch.float32, device=imgs.device)
+        scratch = torch.empty(N, dtype=torch.int32, device=imgs.device)
+        _lib.call("rcf_crf_prepare", _p(imgs), _p(masks), _p(mean), _p(std), int(unstandardize), self.crf_scale,
+                  _p(rgb), _p(unary), _p(scratch), N, H, W, _stream())
+        return rgb, unary
+
+    @torch.no_grad()
+    def forward(self, imgs, masks, unstandardize=True):
+        """imgs [N,3,H,W] normalised, masks [N,H,W] in [0,1] -> refined masks [N,H,W] float 0/1."""
+        rgb, unary = self.prepare(imgs, masks, unstandardize)
+        N, H, W, _ = rgb.shape
+        m = crf_soft_batched(rgb, unary, W, H, self.scomp_smooth, self.sxy_smooth, self.scomp, self.sxy, self.srgb,
+                             self.refine_iters)
+        return m.float()

@@ -1,0 +1,249 @@
+"""Layer objects of the HIP training path: a small reverse-mode tape over NHWC activations.
+
+torch.nn.Module is used as the parameter container (so state-dict keys equal the reference's,
+SURVEY.md Appendix B, and `main.py`'s optimizer / checkpoint code sees ordinary Parameters), but no
+torch autograd graph is built: every `fwd` launches HIP kernels (ops.py) and pushes one closure on
+the tape that launches the matching backward kernels.  Gradients w.r.t. activations live in
+`Act.grad` and follow an explicit protocol -- the first producer writes (beta 0), later producers
+accumulate in the kernel epilogue (beta 1) -- so residual joins cost no extra pass.  Parameter
+gradients always accumulate into `param.grad` (zeroed once per step by the trainer).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Act:
+    """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
+    __slots__ = ("t", "grad", "needs_grad")
+
+    def __init__(self, t, needs_grad=True):
+        self.t, self.grad, self.needs_grad = t, None, needs_grad
+
+    def grad_slot(self):
+        """(tensor, beta) for the next gradient producer."""
+        if self.grad is None:
+            self.grad = torch.empty(tuple(self.t.shape), dtype=torch.float32, device=self.t.device)
+            return self.grad, 0
+        return self.grad, 1
+
+    def take_grad(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+class Tape:
+    def __init__(self, enabled=True):
+        self.ops, self.enabled = [], enabled
+
+    def push(self, fn):
+        if self.enabled:
+            self.ops.append(fn)
+
+    def backward(self):
+        while self.ops:
+            self.ops.pop()()
+
+
+class DistCtx:
+    """Data-parallel context for SyncBN statistics (torch.distributed over RCCL, or gloo in tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.on else 1
+
+    def allreduce_sum(self, t):
+        if self.on:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def _param_grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return p.grad
+
+
+class Conv2d(nn.Module):
+    """Bias-free (or biased) square conv; weight kept in channels_last memory ([Cout][R][S][Cin]).
+    `cin_pad`: the kernels need Cin % 4 == 0; 3-/2-channel inputs arrive zero-padded to 4 and the
+    [Cout,Cin,R,S] parameter is re-packed to [Cout][R][S][4] on the fly (state-dict shape unchanged)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False, act=0, slope=0.0):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.padding, self.dilation, self.act, self.slope = stride, padding, dilation, act, slope
+        self.cin_pad = (cin + 3) // 4 * 4
+        w = torch.empty(cout, cin, k, k)
+        if self.cin_pad == cin:
+            w = w.contiguous(memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.kaiming_normal_(self.weight, a=0, mode="fan_out", nonlinearity="relu")   # mmcv kaiming_init
+
+    def _packed_weight(self):
+        if self.cin_pad == self.cin:
+            return self.weight
+        # [Cout,Cin,R,S] contiguous is an "NCHW" tensor with N=Cout: the layout kernel pads C to 4
+        w = ops.nchw_to_nhwc(self.weight.detach().contiguous(), self.cin_pad)      # [Cout,R,S,4]
+        return w.permute(0, 3, 1, 2)
+
+    def fwd(self, x, tape, out=None):
+        w = self._packed_weight()
+        y = ops.conv2d_fwd(x.t, w, self.bias, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
+        ya = Act(y)
+        if tape.enabled:
+            def bwd():
+                dy = ya.take_grad()
+                if self.act:
+                    raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
+                if self.weight.requires_grad:
+                    if self.cin_pad == self.cin:
+                        ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
+                                         self.dilation, beta=1)
+                    else:
+                        dwp = torch.empty_like(w)
+                        ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0)
+                        dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), self.cin)          # [Cout,Cin,R,S]
+                        g = _param_grad(self.weight)
+                        ops.copy2d(dw, dw.numel(), g, g.numel(), 1, dw.numel(), beta=1)
+                if self.bias is not None and self.bias.requires_grad:
+                    ops.colsum(dy, _param_grad(self.bias), beta=1)
+                if x.needs_grad:
+                    gx, beta = x.grad_slot()
+                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta)
+            tape.push(bwd)
+        return ya
+
+
+class BatchNorm2d(nn.Module):
+    """(Sync)BatchNorm2d, eps 1e-5, momentum 0.1, with fused ReLU / residual add / Dropout2d scale.
+    Same parameter and buffer names as torch's (state-dict compatible)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, requires_grad=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features), requires_grad=requires_grad)
+        self.bias = nn.Parameter(torch.zeros(num_features), requires_grad=requires_grad)
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None):
+        xt = x.t
+        if self.training:
+            local_rows = xt.shape[0] * xt.shape[1] * xt.shape[2]
+            sums = ops.bn_stats(xt)
+            count = local_rows
+            if dist is not None and dist.on:                    # SyncBN: statistics over the global batch
+                dist.allreduce_sum(sums)
+                count = local_rows * dist.world
+            mean, invstd = ops.bn_finalize(sums, count, self.eps, self.momentum, self.running_mean, self.running_var)
+            self.num_batches_tracked += 1
+        else:
+            count = 0
+            mean, invstd = self.running_mean, ops.bn_invstd_from_var(self.running_var, self.eps)
+        y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
+                         residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out)
+        ya = Act(y)
+        if tape.enabled:
+            if not self.training:
+                raise RuntimeError("tape backward through eval-mode BN is not implemented")
+
+            def bwd():
+                dy = ya.take_grad()
+                s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale)
+                if dist is not None and dist.on:
+                    dist.allreduce_sum(s2)
+                dres, rbeta = (None, 0)
+                if residual is not None and residual.needs_grad:
+                    dres, rbeta = residual.grad_slot()
+                gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
+                ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
+                                 _param_grad(self.weight) if self.weight.requires_grad else None,
+                                 _param_grad(self.bias) if self.bias.requires_grad else None,
+                                 dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale)
+            tape.push(bwd)
+        return ya
+
+
+def maxpool3x3s2(x, tape):
+    y, am = ops.maxpool_fwd(x.t)
+    ya = Act(y)
+
+    def bwd():
+        dy = ya.take_grad()
+        if x.needs_grad:
+            assert x.grad is None
+            x.grad = ops.maxpool_bwd(dy, am, x.t.shape)
+    tape.push(bwd)
+    return ya
+
+
+def resize_into(x, tape, size, align_corners, out):
+    """Bilinear resize of x written into `out` (possibly a channel slice); returns nothing: the caller
+    owns the Act of the enclosing buffer and routes the slice gradient back through `bwd_from`."""
+    ops.resize_nhwc_fwd(x.t, size, align_corners, out=out)
+
+
+def concat_channels(parts, tape, size=None, align_corners=False):
+    """resize_concat of models/decode_head.py:151-164: every part is bilinearly resized to `size`
+    (default: the first part's) and written into its channel slice of one NHWC buffer."""
+    N, H, W, _ = parts[0].t.shape
+    if size is not None:
+        H, W = size
+    ctot = sum(p.t.shape[3] for p in parts)
+    buf = torch.empty((N, H, W, ctot), dtype=torch.float32, device=parts[0].t.device)
+    offs, o = [], 0
+    for p in parts:
+        c = p.t.shape[3]
+        sl = buf[..., o:o + c]
+        if tuple(p.t.shape[1:3]) == (H, W):
+            ops.copy2d(p.t, ops.pitch_of(p.t), sl, ctot, N * H * W, c)
+        else:
+            ops.resize_nhwc_fwd(p.t, (H, W), align_corners, out=sl)
+        offs.append(o)
+        o += c
+    ya = Act(buf)
+
+    def bwd():
+        g = ya.take_grad()
+        for p, o in zip(parts, offs):
+            if not p.needs_grad:
+                continue
+            c = p.t.shape[3]
+            gs = g[..., o:o + c]
+            gp, beta = p.grad_slot()
+            if tuple(p.t.shape[1:3]) == (H, W):
+                ops.copy2d(gs, ctot, gp, ops.pitch_of(gp), N * H * W, c, beta=beta)
+            else:
+                ops.resize_nhwc_bwd(gs, p.t.shape[1:3], align_corners, out=gp, beta=beta)
+    tape.push(bwd)
+    return ya
+
+
+def pair_concat(x, tape, B, I):
+    """[B*I,h,w,C] -> [B,h,w,I*C]: frames of a pair side by side on channels
+    (unflatten(0,(B,I)).flatten(1,2) of models/rcf_model.py:325 in NHWC)."""
+    N, H, W, C = x.t.shape
+    assert N == B * I and x.t.is_contiguous()
+    out = torch.empty((B, H, W, I * C), dtype=torch.float32, device=x.t.device)
+    for b in range(B):
+        for i in range(I):
+            ops.copy2d(x.t[b * I + i], C, out[b][..., i * C:], I * C, H * W, C)
+    ya = Act(out)
+
+    def bwd():
+        g = ya.take_grad()
+        if not x.needs_grad:
+            return
+        gx, beta = x.grad_slot()
+        for b in range(B):
+            for i in range(I):
+                ops.copy2d(g[b][..., i * C:], I * C, gx[b * I + i], C, H * W, C, beta=beta)
+    tape.push(bwd)
+    return ya

@@ -1,0 +1,239 @@
+"""RCFModel on the HIP tape -- drop-in for the reference's `models.RCFModel`
+(models/rcf_model.py:28-153 ctor, :410-611 forward_train, :275-320 forward_eval, :350-408 losses,
+:613-626 forward): same constructor keywords (the YAML under `model_kwargs`), same component
+registry by `type` name, same state-dict keys, same return contract (dict of 0-dim loss tensors in
+training mode whose 'loss' entry supports `.backward()`, softmax masks [B,C,h,w] in eval mode).
+
+Not reproduced: JPEG training visualisations / PNG export (:241-273,:456-462,:562-608) -- they need
+torchvision + flow_vis and are off the arithmetic path.
+"""
+import os
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone import FCNHead, ResNet
+from .crf import CRFHead
+from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual
+from .layers import Act, DistCtx, Tape, pair_concat
+
+REGISTRY = dict(ResNet=ResNet, FCNHead=FCNHead, FlowAggregationHeadWithResidual=FlowAggregationHeadWithResidual,
+                CompactnessHead=CompactnessHead, CRFHead=CRFHead)
+
+
+class _TapeBackward(torch.autograd.Function):
+    """Bridges `losses['loss'].backward()` (what main.py / Lightning call) to the HIP tape."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss_value, model):
+        ctx.model = model
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model.run_backward(grad_out)
+        return None, None, None
+
+
+@torch.no_grad()
+def copy_param_and_buffer(src, dest):
+    """utils/model_utils.py:12-19"""
+    s, d = src.state_dict(), dest.state_dict()
+    assert list(s.keys()) == list(d.keys())
+    for k in s:
+        d[k].data.copy_(s[k])
+
+
+@torch.no_grad()
+def momentum_update_param_and_buffer(src, dest, m):
+    """utils/model_utils.py:33-38: dest = dest*m + src*(1-m) over every state-dict entry (float
+    entries through the fused HIP kernel; num_batches_tracked keeps the reference's int64 truncation)."""
+    s, d = src.state_dict(), dest.state_dict()
+    for k in s:
+        if d[k].dtype == torch.float32 and d[k].is_cuda and d[k].is_contiguous() and s[k].is_contiguous():
+            ops.ema_update(d[k], s[k], m)
+        elif d[k].dtype == torch.float32 and d[k].is_cuda:
+            # channels_last conv weights: same memory order on both sides
+            ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m)
+        else:
+            d[k].data.copy_(d[k].data * m + s[k].data * (1.0 - m))
+
+
+class RCFModel(nn.Module):
+    def __init__(self, args, backbone2, decode_head, decode_head2, decode_head3, compactness_head=None,
+                 crf_head=None, crf_use_ema=False, ema_m=0.999, w_seg=2.0, w_sharpen=0, t_sharpen=0.25, w_entropy=0,
+                 w_compactness=0, w_pl=0, pl_pos_weight=1., pl_neg_weight=1., pl_mask_pos_th=0.35, w_crf=0,
+                 crf_pos_weight=1., crf_neg_weight=1., crf_mask_pos_th=-1., mask_layer=1, train_iter=0, train_cfg=None,
+                 test_cfg=None, align_corners=False, mask_size=(48, 48), log_interval=50, freeze_backbone=False,
+                 object_aware_sharpening=False, separate_residual=False, allow_mask_resize=False):
+        super().__init__()
+        self.args = args
+        ckpt = getattr(args, "checkpoints_dir", ".")
+        self.save_dir = os.path.join(ckpt, "saved")
+        self.save_dir_eval = os.path.join(ckpt, getattr(args, "saved_eval_dir_name", "saved_eval"))
+        self.save_dir_eval_export = os.path.join(ckpt, getattr(args, "saved_eval_export_dir_name", "saved_eval_export"))
+
+        def build(cfg, **extra):
+            # like the reference (rcf_model.py:161-197) this pops 'type'/'create_ema' from the caller's dict
+            ema = cfg.pop("create_ema", False)
+            mod = REGISTRY[cfg.pop("type")](**extra, **cfg)
+            mod_ema = None
+            if ema:
+                mod_ema = deepcopy(mod)
+                for p in mod_ema.parameters():
+                    p.requires_grad = False
+                mod_ema.eval()
+            return mod, mod_ema
+
+        self.backbone2, self.backbone2_ema = build(backbone2)
+        self.align_corners, self.mask_layer = align_corners, mask_layer
+        self.decode_head, _ = build(decode_head, args=args)
+        self.decode_head2, self.decode_head2_ema = build(decode_head2)
+        self.num_classes = self.decode_head2.num_classes
+        self.decode_head3, _ = build(decode_head3)
+        self.w_compactness, self.compactness_head = w_compactness, None
+        if compactness_head:
+            self.compactness_head, _ = build(compactness_head, args=args)
+            assert w_compactness != 0, "Compactness head is used but weight is 0"
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.backbone2.init_weights()
+        if freeze_backbone:
+            for p in self.backbone2.parameters():
+                p.requires_grad_(False)
+        self.train_iter = train_iter
+        self.w_seg, self.w_sharpen, self.t_sharpen, self.w_entropy = w_seg, w_sharpen, t_sharpen, w_entropy
+        assert not (w_sharpen != 0 and w_entropy != 0), "Only one of w_entropy and w_sharpen could be nonzero"
+        self.w_pl = w_pl
+        if w_pl > 0:
+            assert args.object_channel is not None, "Pseudo label loss requires an object channel"
+        self.pl_pos_weight, self.pl_neg_weight, self.pl_mask_pos_th = pl_pos_weight, pl_neg_weight, pl_mask_pos_th
+        self.w_crf, self.crf_head = w_crf, None
+        if crf_head:
+            self.crf_head, _ = build(crf_head, args=args)
+            assert w_crf != 0, "CRF head is used but weight is 0"
+        self.crf_pos_weight, self.crf_neg_weight, self.crf_mask_pos_th = crf_pos_weight, crf_neg_weight, crf_mask_pos_th
+        self.crf_use_ema, self.ema_m, self.log_interval = crf_use_ema, ema_m, log_interval
+        self.mask_size, self.allow_mask_resize = tuple(mask_size), allow_mask_resize
+        self.object_aware_sharpening, self.separate_residual = object_aware_sharpening, separate_residual
+        self.eval_on_ema = getattr(args, "eval_on_ema", False)
+        if self.eval_on_ema:
+            assert self.backbone2_ema is not None and self.decode_head2_ema is not None
+        if self.backbone2_ema is not None:
+            copy_param_and_buffer(self.backbone2, self.backbone2_ema)
+        if self.decode_head2_ema is not None:
+            copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
+        if w_sharpen > 0 or object_aware_sharpening:
+            raise NotImplementedError("sharpen loss (w_sharpen) is not used by any RCF stage config")
+        self._tape, self._root_grads, self._anchor = None, None, None
+        self.dist = None
+
+    # ------------------------------------------------------------------ plumbing
+    def train(self, mode=True):
+        super().train(mode)
+        for m in (self.backbone2_ema, self.decode_head2_ema):
+            if m is not None:
+                m.eval()
+        return self
+
+    def _dist(self):
+        if self.dist is None:
+            self.dist = DistCtx()
+        return self.dist
+
+    def _images_nhwc(self, imgs):
+        B, I, C3, H, W = imgs.shape
+        x = imgs.reshape(B * I, C3, H, W).contiguous().float()
+        if not x.is_cuda:
+            raise RuntimeError("RCFModel (HIP) needs the batch on the GPU: there is no CPU fallback")
+        return Act(ops.nchw_to_nhwc(x, 4), needs_grad=False)
+
+    def run_backward(self, grad_out=None):
+        """Backward of the last forward_train: fills param.grad (accumulating)."""
+        if self._tape is None:
+            raise RuntimeError("backward called twice or before forward")
+        tape, self._tape = self._tape, None
+        scale = 1.0 if grad_out is None else float(grad_out)
+        self._seed_backward(scale)
+        tape.backward()
+
+    # ------------------------------------------------------------------ training forward
+    def forward_train(self, imgs, gt_fw_flows, gt_bw_flows, pl_masks=None):
+        B, I = imgs.shape[:2]
+        dist = self._dist()
+        tape = Tape()
+        img = self._images_nhwc(imgs)
+        feats = self.backbone2.fwd(img, tape, dist)
+        logits = self.decode_head2.fwd(feats, tape, dist)                       # Act [B*I,h,w,C]
+        if self.allow_mask_resize and tuple(logits.t.shape[1:3]) != self.mask_size:
+            raise NotImplementedError("allow_mask_resize with a mismatching mask_size")
+        if self.separate_residual:
+            res = self.decode_head3.fwd([pair_concat(feats[-1], tape, B, I)], tape, dist)   # [B,h2,w2,4C]
+            res_swapped = None
+        else:
+            raise NotImplementedError("joint residual (separate_residual=False) is not used by the RCF configs")
+        # ground-truth flows to mask resolution (values not rescaled, rcf_model.py:438-442)
+        nf = gt_fw_flows.shape[1]
+        gfw = ops.resize_nchw(gt_fw_flows.reshape(B * nf, *gt_fw_flows.shape[2:]).contiguous().float(),
+                              self.mask_size, self.align_corners)
+        gbw = ops.resize_nchw(gt_bw_flows.reshape(B * nf, *gt_bw_flows.shape[2:]).contiguous().float(),
+                              self.mask_size, self.align_corners)
+        extra = {}
+        if self.w_pl > 0:
+            extra["pl_masks"] = ops.resize_nchw(pl_masks.contiguous().float(), self.mask_size, self.align_corners)
+        if self.w_crf > 0:
+            extra["crf_masks"] = self._crf_targets(img, imgs, logits, B, I)
+        losses, seed = self.decode_head.loss_and_grads(
+            self, logits, res, gfw.view(B, nf, 2, *self.mask_size), gbw.view(B, nf, 2, *self.mask_size), extra, B, I)
+        self._seed_backward = seed
+        self._tape = tape
+        if self.backbone2_ema is not None:
+            momentum_update_param_and_buffer(self.backbone2, self.backbone2_ema, self.ema_m)
+        if self.decode_head2_ema is not None:
+            momentum_update_param_and_buffer(self.decode_head2, self.decode_head2_ema, self.ema_m)
+        self.train_iter += 1
+        if torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != losses["loss"].device:
+                self._anchor = torch.zeros((), device=losses["loss"].device, requires_grad=True)
+            losses["loss"] = _TapeBackward.apply(self._anchor, losses["loss"], self)
+        return losses
+
+    @torch.no_grad()
+    def _crf_targets(self, img_act, imgs, logits, B, I):
+        """rcf_model.py:496-520: (EMA) masks -> object channel -> image size -> CRF -> mask size."""
+        oc = self.args.object_channel
+        if self.crf_use_ema:
+            t = Tape(enabled=False)
+            le = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img_act, t), t)
+        else:
+            le = logits
+        h, w = le.t.shape[1:3]
+        p = self.decode_head.softmax_masks(le.t, B, I)                           # [B,I,C,h,w]
+        H, W = imgs.shape[-2:]
+        obj = p.flatten(0, 1)[:, oc:oc + 1].contiguous()
+        up = ops.resize_nchw(obj, (H, W), self.align_corners)[:, 0]
+        crf = self.crf_head(imgs.reshape(B * I, *imgs.shape[2:]), up)            # [B*I,H,W] float 0/1
+        return ops.resize_nchw(crf.view(B, I, H, W).contiguous(), self.mask_size, self.align_corners)
+
+    # ------------------------------------------------------------------ eval forward
+    @torch.no_grad()
+    def forward_eval(self, imgs):
+        B, I = imgs.shape[:2]
+        t = Tape(enabled=False)
+        img = self._images_nhwc(imgs)
+        if self.eval_on_ema:
+            logits = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img, t), t)
+        else:
+            logits = self.decode_head2.fwd(self.backbone2.fwd(img, t), t)
+        return self.decode_head.softmax_masks(logits.t, B, I)[:, 0]
+
+    def forward(self, x, return_pred_vis_list=False):
+        imgs = torch.stack(x["imgs"], dim=1)
+        if self.training:
+            pl = torch.stack(x["pl_masks"], dim=1) if self.w_pl > 0 else None
+            return self.forward_train(imgs, torch.stack(x["gt_fw_flows"], dim=1),
+                                      torch.stack(x["gt_bw_flows"], dim=1), pl)
+        if return_pred_vis_list:
+            raise NotImplementedError("visualisation lists are not produced by the HIP model")
+        return self.forward_eval(imgs)

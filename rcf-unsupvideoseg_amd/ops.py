@@ -51,6 +51,33 @@ def pitch_of(x):
     return p
 
 
+class _Profile:
+    """Live per-kernel timing with HIP events on the launch stream (bench.py's `roofline` leg).
+    Only the selected kernel family is bracketed, so the timed region is barely perturbed."""
+
+    def __init__(self):
+        self.which, self.records = None, []
+
+    def start(self, which):
+        self.which, self.records = which, []
+
+    def bracket(self, which, flops):
+        if self.which != which:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((flops, e0, e1))
+        e0.record()
+        return e1
+
+    def stop(self):
+        torch.cuda.synchronize()
+        out = {"launches": len(self.records), "flops": float(sum(r[0] for r in self.records)),
+               "ms": float(sum(r[1].elapsed_time(r[2]) for r in self.records))}
+        self.which, self.records = None, []
+        return out
+
+
+PROFILE = _Profile()
 _workspaces = {}
 
 
@@ -90,7 +117,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
+    end = None
+    if PROFILE.which is not None and s.Cout > 64:
+        end = PROFILE.bracket("conv_fwd_wide", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), act, slope, beta, _stream())
+    if end is not None:
+        end.record()
     return out
 
 
