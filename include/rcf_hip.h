@@ -153,23 +153,6 @@ int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3
                     int unstandardize, float crf_scale, uint8_t *rgb_out, float *unary_out, uint32_t *scratch,
                     int batch, int H, int W, void *stream);
 
-/* ---- flow-aggregation head (relaxed common fate) ------------------------------------------------
- * models/flow_aggregation_head_with_residual.py:235-310 (aggregate), :164-233 (per-segment affine
- * least squares), :312-399 (forward, L1 / robust loss), and the softmax + double-softmax entropy of
- * models/rcf_model.py:433-434,376-378.  See flowhead.hip for the tensor contracts. */
-typedef struct {
-    int B, C, h, w;          /* pairs, segments (mask_layer), mask size */
-    int h2, w2;              /* residual map size (decode_head3 output) */
-    int nf;                  /* flow feature channels (64) */
-    int affine;              /* 0 free_residual, 1 free_residual_with_affine, 2 + quadratic */
-    int robust;              /* outlier_robust_loss */
-    float eps, q;
-    float clamp_t;           /* < 0: no clamp */
-    float res_scale, div_coeff;
-    float w_seg, w_entropy;
-} rcf_flowhead_cfg;
-size_t rcf_flowhead_workspace_bytes(const rcf_flowhead_cfg *c);
-
 /* ---- optimiser / EMA ----------------------------------------------------------------------------
  * torch.optim.Adam with coupled weight decay (main.py:299-307) over one flat fp32 buffer;
  * EMA lerp of utils/model_utils.py:33-38 over flat buffers. */

@@ -1,0 +1,669 @@
+// Dense-CRF mean-field inference on the permutohedral lattice, batched over frames.
+// Stands in for torchcrf_cpp (tools/torchCRF/src/torchcrf.cu:106-149): DenseCRFGPU<2> with Potts
+// potentials over a PermutohedralLatticeGPU<float, 5 or 2, 3>.  Algorithm restated from
+//   src/permutohedral_gpu.cu:169-275 (embedding, rounding, rank, barycentric, int16 keys), :76-92
+//   (hash), :303-378 (splat), :381-424 (blur), :427-451 (slice), :454-467 (scale factors);
+//   src/pairwise_gpu.cu:10-36; src/densecrf_gpu.cu:40-72,84-108,145-190; src/densecrf_base.cpp:15-46.
+//
+// MI355X design (HBM / L2 gather-scatter bound, no MFMA):
+//  * build once per frame: every (pixel, vertex) entry writes its key, then claims a hash bucket with
+//    ONE device-scope atomicCAS whose payload is a slot whose key is already globally visible (written
+//    by the previous kernel) -- no lock states, no duplicate keys, hence no cleanHashTable pass;
+//    atomicMin makes the bucket's representative the smallest slot => vertex numbering (hand-written
+//    3-kernel scan) is deterministic.  Blur neighbours are resolved ONCE into index lists instead of
+//    2 hash probes per vertex per axis per iteration.
+//  * per iteration: splat accumulates in 64-bit fixed point (2^-40) with integer atomics, so the sums
+//    are order independent: run-to-run bit-identical MAPs (the reference's float atomics are not);
+//    consecutive lanes hitting the same vertex are pre-reduced in the wavefront; 6 blur passes stream
+//    float4 vertex values; slice + Potts weight + softmax (+ MAP on the last iteration) are one kernel.
+//  * persistent caller-owned workspace, all frames of a batch in every launch (grid.y = frame).
+//  Algorithmic bytes per iteration: 192*N + 348*L, L = lattice vertices.
+#include "rcf_common.h"
+
+namespace {
+
+constexpr int MLAB = 2;
+constexpr int PD_MAX = 5;
+constexpr double FIX_SCALE = 1099511627776.0;   // 2^40
+constexpr float FIX_INV = 1.0f / 1099511627776.0f;
+
+struct Lattice {           // device pointers of one potential, for all frames (frame stride in elements)
+    int pd;
+    int N;                 // pixels per frame
+    long E;                // entries per frame = N*(pd+1)
+    float w;               // Potts weight
+    uint4 *keys;           // [F][E]   5 x int16 packed, zero padded
+    float *weight;         // [F][E]
+    int *entries;          // [F][2E]  bucket -> representative slot (-1 empty)
+    int *vid;              // [F][E]   bucket index after insert, then dense vertex id
+    int *slot_vid;         // [F][E]   scan scratch: vertex id of representative slots
+    int *vrep;             // [F][E]   vertex -> representative slot
+    int *nb;               // [F][E][2*(pd+1)] neighbour vertex ids (-1 = none), [axis][plus/minus]
+    long long *zacc;       // [F][E][4] fixed-point splat accumulators
+    float4 *val0, *val1;   // [F][E]   ping-pong blurred values
+    int *blocksum;         // [F][nblk+1]
+    int *L;                // [F]      vertex counts
+};
+
+__device__ __forceinline__ unsigned key_hash(const short *key, int pd) {
+    unsigned k = 0;
+    for (int i = 0; i < pd; i++) {
+        k += (unsigned)(int)key[i];
+        k *= 2531011u;
+    }
+    return k;
+}
+__device__ __forceinline__ uint4 pack_key(const short *key, int pd) {
+    unsigned short k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < pd; i++) k[i] = (unsigned short)key[i];
+    return make_uint4(k[0] | ((unsigned)k[1] << 16), k[2] | ((unsigned)k[3] << 16), k[4] | ((unsigned)k[5] << 16), 0u);
+}
+__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// ---------------------------------------------------------------------------------- build: keys
+__global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, int H,
+                                                           float posdev, float featdev) {
+    const int pd = Lt.pd;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= Lt.N) return;
+    float pos[PD_MAX];
+    const int wi = p % W, hi = p / W;
+    pos[0] = (float)wi / posdev;
+    pos[1] = (float)hi / posdev;
+    if (pd == 5) {
+        const uint8_t *c = rgb + ((long)f * Lt.N + p) * 3;
+        pos[2] = (float)c[0] / featdev;
+        pos[3] = (float)c[1] / featdev;
+        pos[4] = (float)c[2] / featdev;
+    }
+    float elevated[PD_MAX + 1];
+    int rem0[PD_MAX + 1], rank[PD_MAX + 1];
+    const float inv_std = (pd + 1) * sqrtf(2.0f / 3);
+    float sm = 0;
+    for (int i = pd; i > 0; i--) {
+        const float scale = 1.0f / (sqrtf((float)(i) * (i + 1))) * inv_std;   // scaleFactor[i-1]
+        const float cf = pos[i - 1] * scale;
+        elevated[i] = sm - i * cf;
+        sm += cf;
+    }
+    elevated[0] = sm;
+    short sum = 0;
+    for (int i = 0; i <= pd; i++) {
+        const float v = (float)(elevated[i] * (1.0 / (pd + 1)));
+        const float up = ceilf(v) * (pd + 1);
+        const float down = floorf(v) * (pd + 1);
+        rem0[i] = (up - elevated[i] < elevated[i] - down) ? (short)up : (short)down;
+        sum = (short)(sum + rem0[i]);
+    }
+    sum = (short)(sum / (pd + 1));
+    for (int i = 0; i <= pd; i++) rank[i] = 0;
+    for (int i = 0; i < pd; i++) {
+        const double di = elevated[i] - rem0[i];
+        for (int j = i + 1; j <= pd; j++) {
+            if (di < elevated[j] - rem0[j]) rank[i]++;
+            else rank[j]++;
+        }
+    }
+    for (int i = 0; i <= pd; i++) {
+        rank[i] += sum;
+        if (rank[i] < 0) { rank[i] += pd + 1; rem0[i] += pd + 1; }
+        else if (rank[i] > pd) { rank[i] -= pd + 1; rem0[i] -= pd + 1; }
+    }
+    float bary[PD_MAX + 2];
+    for (int i = 0; i <= pd + 1; i++) bary[i] = 0;
+    for (int i = 0; i <= pd; i++) {
+        const float delta = (float)((elevated[i] - rem0[i]) * (1.0 / (pd + 1)));
+        bary[pd - rank[i]] += delta;
+        bary[pd + 1 - rank[i]] -= delta;
+    }
+    bary[0] = (float)(bary[0] + (1.0 + bary[pd + 1]));
+    const long base = (long)f * Lt.E + (long)p * (pd + 1);
+    for (int r = 0; r <= pd; r++) {
+        short key[PD_MAX];
+        for (int i = 0; i < pd; i++) {
+            key[i] = (short)(rem0[i] + r);
+            if (rank[i] > pd - r) key[i] = (short)(key[i] - (pd + 1));
+        }
+        Lt.keys[base + r] = pack_key(key, pd);
+        Lt.weight[base + r] = bary[r];
+    }
+}
+
+__device__ __forceinline__ void unpack_key(const uint4 &k, short *key) {
+    key[0] = (short)(k.x & 0xffff); key[1] = (short)(k.x >> 16);
+    key[2] = (short)(k.y & 0xffff); key[3] = (short)(k.y >> 16);
+    key[4] = (short)(k.z & 0xffff);
+}
+
+// ---------------------------------------------------------------------------------- build: insert
+__global__ void __launch_bounds__(256) lattice_insert_kernel(Lattice Lt) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (e >= Lt.E) return;
+    const uint4 *keys = Lt.keys + (long)f * Lt.E;
+    int *entries = Lt.entries + (long)f * 2 * Lt.E;
+    const uint4 mine = keys[e];
+    short key[8];
+    unpack_key(mine, key);
+    const unsigned nb = (unsigned)(2 * Lt.E);
+    unsigned h = key_hash(key, Lt.pd) % nb;
+    for (;;) {
+        int cur = __hip_atomic_load(entries + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == -1) cur = atomicCAS(entries + h, -1, (int)e);
+        if (cur == -1 || key_eq(keys[cur], mine)) break;   // claimed, or bucket already holds my key
+        if (++h == nb) h = 0;
+    }
+    atomicMin(entries + h, (int)e);                         // representative = smallest slot with this key
+    Lt.vid[(long)f * Lt.E + e] = (int)h;
+}
+
+// ---------------------------------------------------------------------------------- build: numbering
+constexpr int SCAN_ITEMS = 8, SCAN_BLOCK = 256, SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_BLOCK / 64; i++) {
+        if (i < wv) off += wsum[i];
+        tot += wsum[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+
+// flag[e] = entry e is the representative of its bucket; local exclusive scan + block totals
+__global__ void __launch_bounds__(SCAN_BLOCK) lattice_scan_local_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+    const int *bucket = Lt.vid + (long)f * Lt.E;
+    const int *entries = Lt.entries + (long)f * 2 * Lt.E;
+    int flags[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long e = base + i;
+        flags[i] = (e < Lt.E && entries[bucket[e]] == (int)e) ? 1 : 0;
+        s += flags[i];
+    }
+    int total;
+    int off = block_exclusive_scan(s, &total);
+    int *out = Lt.slot_vid + (long)f * Lt.E;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long e = base + i;
+        if (e < Lt.E) out[e] = flags[i] ? off : -1;
+        off += flags[i];
+    }
+    if (threadIdx.x == 0) Lt.blocksum[(long)f * (gridDim.x + 1) + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) lattice_scan_blocks_kernel(Lattice Lt, int nblk) {
+    const int f = blockIdx.x;
+    int *bs = Lt.blocksum + (long)f * (nblk + 1);
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += SCAN_BLOCK) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nblk ? bs[b] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int carry = carry_s;
+        if (b < nblk) bs[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bs[nblk] = carry_s; Lt.L[f] = carry_s; }
+}
+
+// slot_vid += block offset; vrep[vid] = slot; entry -> dense vertex id is resolved in the next kernel
+__global__ void __launch_bounds__(SCAN_BLOCK) lattice_scan_apply_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const int off = Lt.blocksum[(long)f * (gridDim.x + 1) + blockIdx.x];
+    int *sv = Lt.slot_vid + (long)f * Lt.E;
+    int *vrep = Lt.vrep + (long)f * Lt.E;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long e = base + i;
+        if (e < Lt.E && sv[e] >= 0) {
+            sv[e] += off;
+            vrep[sv[e]] = (int)e;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) lattice_entry_vid_kernel(Lattice Lt) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (e >= Lt.E) return;
+    int *vid = Lt.vid + (long)f * Lt.E;
+    const int rep = Lt.entries[(long)f * 2 * Lt.E + vid[e]];
+    vid[e] = Lt.slot_vid[(long)f * Lt.E + rep];
+}
+
+// neighbour lists: what blur's two hash retrieves per axis resolve to (permutohedral_gpu.cu:392-407)
+__global__ void __launch_bounds__(256) lattice_neighbours_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const int pd = Lt.pd, nax = pd + 1;
+    const long Lf = Lt.L[f];
+    const uint4 *keys = Lt.keys + (long)f * Lt.E;
+    const int *entries = Lt.entries + (long)f * 2 * Lt.E;
+    const int *sv = Lt.slot_vid + (long)f * Lt.E;
+    const unsigned nbk = (unsigned)(2 * Lt.E);
+    const long total = Lf * nax * 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long v = i / (nax * 2);
+        const int rem = (int)(i - v * nax * 2);
+        const int axis = rem >> 1, sign = (rem & 1) ? -1 : 1;
+        short key[8];
+        unpack_key(keys[Lt.vrep[(long)f * Lt.E + v]], key);
+        for (int k = 0; k < pd; k++) key[k] = (short)(key[k] + sign);
+        if (axis < pd) key[axis] = (short)(key[axis] - sign * (pd + 1));
+        const uint4 want = pack_key(key, pd);
+        unsigned h = key_hash(key, pd) % nbk;
+        int res = -1;
+        for (;;) {
+            const int s = entries[h];
+            if (s == -1) break;
+            if (key_eq(keys[s], want)) { res = sv[s]; break; }
+            if (++h == nbk) h = 0;
+        }
+        Lt.nb[((long)f * Lt.E + v) * (2 * nax) + rem] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------- iteration
+__global__ void __launch_bounds__(256) zero_acc_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long n = (long)Lt.L[f] * 2;     // 2 x 16 B per vertex
+    int4 *z = reinterpret_cast<int4 *>(Lt.zacc + (long)f * Lt.E * 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        z[i] = make_int4(0, 0, 0, 0);
+}
+
+// values (Q0*w, Q1*w, w) of every entry added to its vertex, in 2^-40 fixed point.  Lanes of a
+// wavefront that hold consecutive equal vertex ids are summed first (segmented shuffle scan).
+__global__ void __launch_bounds__(256) splat_kernel(Lattice Lt, const float *__restrict__ Q) {
+    const int f = blockIdx.y;
+    const int nax = Lt.pd + 1;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over N*(pd+1), remainder-major
+    const long total = Lt.E;
+    // entry order: e' = r*N + p so that consecutive lanes are consecutive PIXELS of one remainder
+    int v = -1;
+    long long a0 = 0, a1 = 0, a2 = 0;
+    if (idx < total) {
+        const int r = (int)(idx / Lt.N);
+        const int p = (int)(idx - (long)r * Lt.N);
+        const long e = (long)f * Lt.E + (long)p * nax + r;
+        v = Lt.vid[e];
+        const float wgt = Lt.weight[e];
+        const float2 q = *reinterpret_cast<const float2 *>(Q + ((long)f * Lt.N + p) * MLAB);
+        a0 = __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
+        a1 = __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
+        a2 = __double2ll_rn((double)wgt * FIX_SCALE);
+    }
+    const int lane = threadIdx.x & 63;
+    // segmented inclusive scan over CONTIGUOUS runs of equal v: seg = first lane of my run
+    const int vprev = __shfl_up(v, 1, 64);
+    int seg = (lane == 0 || vprev != v) ? lane : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int so = __shfl_up(seg, o, 64);
+        if (lane >= o && so > seg) seg = so;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long b0 = __shfl_up(a0, o, 64), b1 = __shfl_up(a1, o, 64), b2 = __shfl_up(a2, o, 64);
+        if (lane - o >= seg) { a0 += b0; a1 += b1; a2 += b2; }
+    }
+    const int vnext = __shfl_down(v, 1, 64);
+    const bool tail = (lane == 63) || (vnext != v);
+    if (v >= 0 && tail) {
+        unsigned long long *z = reinterpret_cast<unsigned long long *>(Lt.zacc + ((long)f * Lt.E + v) * 4);
+        atomicAdd(z + 0, (unsigned long long)a0);
+        atomicAdd(z + 1, (unsigned long long)a1);
+        atomicAdd(z + 2, (unsigned long long)a2);
+    }
+}
+
+__device__ __forceinline__ float4 load_fixed(const long long *z) {
+    const longlong2 a = *reinterpret_cast<const longlong2 *>(z);
+    const long long c = z[2];
+    return make_float4((float)((double)a.x * (1.0 / FIX_SCALE)), (float)((double)a.y * (1.0 / FIX_SCALE)),
+                       (float)((double)c * (1.0 / FIX_SCALE)), 0.f);
+}
+
+// one blur pass along `axis`: new = 1/4 n+ + 1/2 me + 1/4 n-, missing neighbour = 0
+template <bool FROM_FIXED>
+__global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const float4 *__restrict__ in,
+                                                   float4 *__restrict__ out) {
+    const int f = blockIdx.y;
+    const int nax2 = 2 * (Lt.pd + 1);
+    const long Lf = Lt.L[f];
+    const long fb = (long)f * Lt.E;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.x * blockDim.x) {
+        const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb + v) * nax2 + 2 * axis);
+        float4 me, vp = make_float4(0, 0, 0, 0), vm = make_float4(0, 0, 0, 0);
+        if (FROM_FIXED) {
+            me = load_fixed(Lt.zacc + (fb + v) * 4);
+            if (n.x >= 0) vp = load_fixed(Lt.zacc + (fb + n.x) * 4);
+            if (n.y >= 0) vm = load_fixed(Lt.zacc + (fb + n.y) * 4);
+        } else {
+            me = in[fb + v];
+            if (n.x >= 0) vp = in[fb + n.x];
+            if (n.y >= 0) vm = in[fb + n.y];
+        }
+        float4 o;
+        o.x = 0.25f * vp.x + 0.5f * me.x + 0.25f * vm.x;
+        o.y = 0.25f * vp.y + 0.5f * me.y + 0.25f * vm.y;
+        o.z = 0.25f * vp.z + 0.5f * me.z + 0.25f * vm.z;
+        o.w = 0.f;
+        out[fb + v] = o;
+    }
+}
+
+// slice + Potts weight + (optionally) softmax and MAP.
+//   first: next = -U, else next = next_in;  next += w * slice;  last: Q = softmax(next) (+ MAP)
+__global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float4 *__restrict__ val,
+                                                    const float *__restrict__ unary, float *__restrict__ next,
+                                                    float *__restrict__ Q, short *__restrict__ map, int first,
+                                                    int last, int write_map) {
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Lt.N) return;
+    const int nax = Lt.pd + 1;
+    const long fb = (long)f * Lt.E;
+    const long pe = fb + (long)p * nax;
+    float s0 = 0, s1 = 0, sw = 0;
+    for (int r = 0; r < nax; r++) {
+        const float wgt = Lt.weight[pe + r];
+        const float4 v = val[fb + Lt.vid[pe + r]];
+        s0 += wgt * v.x;
+        s1 += wgt * v.y;
+        sw += wgt * v.z;
+    }
+    const float inv = (float)(1.0 / sw);
+    const long qi = ((long)f * Lt.N + p) * MLAB;
+    float n0, n1;
+    if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
+    else { n0 = next[qi]; n1 = next[qi + 1]; }
+    n0 += Lt.w * (s0 * inv);
+    n1 += Lt.w * (s1 * inv);
+    if (!last) { next[qi] = n0; next[qi + 1] = n1; return; }
+    const float mx = n0 < n1 ? n1 : n0;
+    const float e0 = __expf(n0 - mx), e1 = __expf(n1 - mx);
+    const float tt = e0 + e1;
+    const float q0 = e0 / tt, q1 = e1 / tt;
+    Q[qi] = q0;
+    Q[qi + 1] = q1;
+    if (write_map) map[(long)f * Lt.N + p] = (q0 < q1) ? 1 : 0;
+}
+
+// Q = softmax(scale * in)  (startInference: scale -1 on the unary; also T=0 MAP)
+__global__ void __launch_bounds__(256) softmax2_kernel(const float *__restrict__ in, float *__restrict__ Q,
+                                                       short *__restrict__ map, long n, float scale, int write_map) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float a = scale * in[p * 2], b = scale * in[p * 2 + 1];
+    const float mx = a < b ? b : a;
+    const float e0 = __expf(a - mx), e1 = __expf(b - mx);
+    const float tt = e0 + e1;
+    Q[p * 2] = e0 / tt;
+    Q[p * 2 + 1] = e1 / tt;
+    if (write_map) map[p] = (e0 / tt < e1 / tt) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) unary_from_label_kernel(const short *__restrict__ label,
+                                                               float *__restrict__ unary, long n, float u_energy,
+                                                               float n_energy, float p_energy) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const short l = label[p];
+    float a = (l == -1) ? u_energy : n_energy, b = a;
+    if (l == 0) a = p_energy;
+    if (l == 1) b = p_energy;
+    unary[p * 2] = a;
+    unary[p * 2 + 1] = b;
+}
+
+// ---------------------------------------------------------------------------------- CRFHead prologue
+__global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restrict__ img,
+                                                            const float *__restrict__ mask,
+                                                            const float *__restrict__ mean3,
+                                                            const float *__restrict__ std3, int unstd, float crf_scale,
+                                                            uint8_t *__restrict__ rgb, unsigned *__restrict__ qmax,
+                                                            int HW) {
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned q = 0;
+    if (p < HW) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float v = img[((long)f * 3 + c) * HW + p];
+            if (unstd) v = v * std3[c] + mean3[c];
+            v = v * 255.f;
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            rgb[((long)f * HW + p) * 3 + c] = (uint8_t)v;                 // truncation, like .type(torch.uint8)
+        }
+        float m = mask[(long)f * HW + p] * 255.f / crf_scale;
+        m = fminf(fmaxf(m, 0.f), 255.f);
+        q = (unsigned)(uint8_t)m;
+    }
+    for (int o = 32; o > 0; o >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(qmax + f, q);
+}
+
+__global__ void __launch_bounds__(256) prepare_unary_kernel(const float *__restrict__ mask, float crf_scale,
+                                                            const unsigned *__restrict__ qmax,
+                                                            float *__restrict__ unary, int HW) {
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float m = mask[(long)f * HW + p] * 255.f / crf_scale;
+    m = fminf(fmaxf(m, 0.f), 255.f);
+    const float q = (float)(uint8_t)m;
+    float U = q / ((float)qmax[f] + 1e-8f);
+    const float lo = 1e-6f, hi = (float)(1.0 - 1e-6);
+    U = fminf(fmaxf(U, lo), hi);
+    unary[((long)f * HW + p) * 2] = -logf(1.0f - U);
+    unary[((long)f * HW + p) * 2 + 1] = -logf(U);
+}
+
+// ---------------------------------------------------------------------------------- host side
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *base;
+    size_t off;
+    template <class T>
+    T *take(size_t count) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += align_up(count * sizeof(T));
+        return p;
+    }
+};
+
+inline int scan_blocks(long E) { return (int)((E + SCAN_TILE - 1) / SCAN_TILE); }
+
+void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
+    L.pd = pd;
+    L.N = N;
+    L.E = (long)N * (pd + 1);
+    const size_t FE = (size_t)F * L.E;
+    L.keys = c.take<uint4>(FE);
+    L.weight = c.take<float>(FE);
+    L.entries = c.take<int>(2 * FE);
+    L.vid = c.take<int>(FE);
+    L.slot_vid = c.take<int>(FE);
+    L.vrep = c.take<int>(FE);
+    L.nb = c.take<int>(FE * 2 * (pd + 1));
+    L.zacc = c.take<long long>(FE * 4);
+    L.val0 = c.take<float4>(FE);
+    L.val1 = c.take<float4>(FE);
+    L.blocksum = c.take<int>((size_t)F * (scan_blocks(L.E) + 1));
+    L.L = c.take<int>(F);
+}
+
+struct CrfBuffers {
+    Lattice smooth, app;
+    float *cur, *next, *unary_own;
+};
+
+size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
+    Carver c{base, 0};
+    const int N = W * H;
+    carve_lattice(c, b.smooth, 2, N, F);
+    carve_lattice(c, b.app, 5, N, F);
+    b.cur = c.take<float>((size_t)F * N * MLAB);
+    b.next = c.take<float>((size_t)F * N * MLAB);
+    b.unary_own = c.take<float>((size_t)F * N * MLAB);
+    return c.off;
+}
+
+#define CK(expr)                                 \
+    do {                                         \
+        hipError_t e__ = (expr);                 \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev, float weight,
+                  hipStream_t st) {
+    L.w = weight;
+    const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
+    const int nblk = scan_blocks(L.E);
+    CK(hipMemsetAsync(L.entries, 0xff, (size_t)F * 2 * L.E * sizeof(int), st));
+    hipLaunchKernelGGL(lattice_keys_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev);
+    hipLaunchKernelGGL(lattice_insert_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(lattice_scan_local_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(lattice_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
+    hipLaunchKernelGGL(lattice_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(lattice_entry_vid_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(lattice_neighbours_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+// tmp-free filter + Potts + softmax epilogue for one potential
+int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
+                  int first, int last, int write_map, hipStream_t st) {
+    const dim3 gv(1024, F), ge(rcf_cdiv(L.E, 256), F), gp(rcf_cdiv(L.N, 256), F);
+    hipLaunchKernelGGL(zero_acc_kernel, gv, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(splat_kernel, ge, dim3(256), 0, st, L, Q);
+    float4 *a = L.val0, *b = L.val1;
+    for (int axis = 0; axis <= L.pd; axis++) {
+        if (axis == 0) hipLaunchKernelGGL((blur_kernel<true>), gv, dim3(256), 0, st, L, axis, (const float4 *)nullptr, a);
+        else {
+            hipLaunchKernelGGL((blur_kernel<false>), gv, dim3(256), 0, st, L, axis, (const float4 *)a, b);
+            float4 *t = a; a = b; b = t;
+        }
+    }
+    hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float4 *)a, unary, next, Qout, map, first, last,
+                       write_map);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float scomp_smooth, float sxy_smooth,
+              float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *q_out,
+              int32_t *nvert, CrfBuffers &b, hipStream_t st) {
+    const bool has_s = scomp_smooth > 0.f && sxy_smooth > 0.f;     // torchcrf.cu:28
+    const bool has_a = scomp_app > 0.f && sxy_app > 0.f;           // torchcrf.cu:41
+    const long n = (long)F * W * H;
+    if (has_s) if (int e = build_lattice(b.smooth, rgb, W, H, F, sxy_smooth, 1.f, scomp_smooth, st)) return e;
+    if (has_a) if (int e = build_lattice(b.app, rgb, W, H, F, sxy_app, srgb_app, scomp_app, st)) return e;
+    const int npot = (has_s ? 1 : 0) + (has_a ? 1 : 0);
+    const bool direct = (iters == 0 || npot == 0);
+    hipLaunchKernelGGL(softmax2_kernel, dim3(rcf_cdiv(n, 256)), dim3(256), 0, st, unary, b.cur, (short *)out_map, n,
+                       -1.0f, direct ? 1 : 0);
+    RCF_LAUNCH_CHECK();
+    if (npot == 0 && iters > 0) {
+        // no pairwise term: every step is softmax(-U) again
+        iters = 0;
+    }
+    for (int it = 0; it < iters; it++) {
+        const int wm = (it == iters - 1) ? 1 : 0;
+        if (has_s) if (int e = apply_lattice(b.smooth, F, b.cur, unary, b.next, b.cur, (short *)out_map, 1, has_a ? 0 : 1, wm, st)) return e;
+        if (has_a) if (int e = apply_lattice(b.app, F, b.cur, unary, b.next, b.cur, (short *)out_map, has_s ? 0 : 1, 1, wm, st)) return e;
+    }
+    if (q_out) CK(hipMemcpyAsync(q_out, b.cur, n * MLAB * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (nvert) {
+        for (int f = 0; f < F; f++) {
+            if (has_s) CK(hipMemcpyAsync(nvert + 2 * f, b.smooth.L + f, sizeof(int), hipMemcpyDeviceToDevice, st));
+            else CK(hipMemsetAsync(nvert + 2 * f, 0, sizeof(int), st));
+            if (has_a) CK(hipMemcpyAsync(nvert + 2 * f + 1, b.app.L + f, sizeof(int), hipMemcpyDeviceToDevice, st));
+            else CK(hipMemsetAsync(nvert + 2 * f + 1, 0, sizeof(int), st));
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
+    if (W <= 0 || H <= 0 || batch <= 0) return 0;
+    CrfBuffers b;
+    return carve_all(nullptr, W, H, batch, b);
+}
+
+extern "C" int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
+                            float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
+                            int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    if (!rgb || !unary || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
+    if ((long)W * H * 6 >= (1L << 30)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_crf_workspace_bytes(W, H, batch) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+    CrfBuffers b;
+    carve_all((char *)workspace, W, H, batch, b);
+    return crf_infer(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
+                     q_out, nvert, b, rcf_stream(stream));
+}
+
+extern "C" int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,
+                            float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence,
+                            int iters, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    if (!rgb || !label || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
+    if (!(confidence > 0.f && confidence < 1.f)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_crf_workspace_bytes(W, H, batch) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+    CrfBuffers b;
+    carve_all((char *)workspace, W, H, batch, b);
+    hipStream_t st = rcf_stream(stream);
+    const long n = (long)batch * W * H;
+    // setUnaryEnergyFromLabel, densecrf_gpu.cu:84-143 (M = 2)
+    hipLaunchKernelGGL(unary_from_label_kernel, dim3(rcf_cdiv(n, 256)), dim3(256), 0, st, (const short *)label,
+                       b.unary_own, n, -logf(1.0f / MLAB), -logf((1.0f - confidence) / (MLAB - 1)), -logf(confidence));
+    RCF_LAUNCH_CHECK();
+    return crf_infer(rgb, b.unary_own, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
+                     out_map, q_out, nvert, b, st);
+}
+
+extern "C" int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,
+                               int unstandardize, float crf_scale, uint8_t *rgb_out, float *unary_out,
+                               uint32_t *scratch, int batch, int H, int W, void *stream) {
+    if (!img_nchw || !mask || !rgb_out || !unary_out || !scratch || batch <= 0 || H <= 0 || W <= 0) return RCF_EINVAL;
+    if (unstandardize && (!mean3 || !std3)) return RCF_EINVAL;
+    if (!(crf_scale > 0.f)) return RCF_EINVAL;
+    hipStream_t st = rcf_stream(stream);
+    const int HW = H * W;
+    CK(hipMemsetAsync(scratch, 0, batch * sizeof(uint32_t), st));
+    const dim3 g(rcf_cdiv(HW, 256), batch);
+    hipLaunchKernelGGL(prepare_image_kernel, g, dim3(256), 0, st, img_nchw, mask, mean3, std3, unstandardize, crf_scale,
+                       rgb_out, (unsigned *)scratch, HW);
+    hipLaunchKernelGGL(prepare_unary_kernel, g, dim3(256), 0, st, mask, crf_scale, (const unsigned *)scratch, unary_out,
+                       HW);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,117 @@
+"""GPU parity of the HIP dense-CRF (csrc/crf.hip) against the C restatement of the reference
+(oracle/crf_ref.c) through the C ABI, plus invariants at the full 480x854 size.
+
+Bars: lattice vertex count L identical; marginals Q within 1e-4 absolute (the only intended
+differences are __expf vs expf and fp32 summation order); MAP identical on every pixel whose
+marginal margin |Q1-Q0| exceeds 1e-3 and >= 99.9 % overall; run-to-run bit-identical output."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import crf_oracle
+import rcf_amd
+from rcf_amd import synth
+from rcf_amd.crf import crf_soft_batched
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _unary(mask, crf_scale=0.7):
+    q = (mask * 255.0 / crf_scale).clip(0, 255).astype(np.uint8)
+    U = np.clip(q.astype(np.float32) / (np.float32(q.max()) + np.float32(1e-8)), 1e-6, 1 - 1e-6).astype(np.float32)
+    return (-np.log(np.stack([1 - U, U], 0))).reshape(2, -1).T.copy().astype(np.float32)
+
+
+def _run_hip(rgbs, unaries, W, H, params, iters):
+    rgb = torch.from_numpy(np.stack(rgbs)).to(DEV)
+    un = torch.from_numpy(np.stack(unaries)).to(DEV)
+    m, q, nv = crf_soft_batched(rgb, un, W, H, *params, iters, want_q=True, want_nvert=True)
+    return m.cpu().numpy(), q.cpu().numpy(), nv.cpu().numpy()
+
+
+@pytest.mark.parametrize("H,W,kind,iters,params", [
+    (64, 96, "smooth", 1, (0., 0., 5., 60., 5.)),
+    (64, 96, "smooth", 5, (0., 0., 5., 60., 5.)),
+    (64, 96, "noise", 5, (0., 0., 5., 60., 5.)),
+    (48, 70, "smooth", 5, (3., 3., 5., 60., 5.)),        # smoothness kernel on as well
+    (48, 70, "smooth", 3, (3., 3., 0., 60., 5.)),        # smoothness only
+    (40, 52, "smooth", 50, (0., 0., 5., 60., 5.)),       # reference default iteration count
+    (480, 854, "smooth", 5, (0., 0., 5., 60., 5.)),      # BASELINE config 4
+])
+def test_crf_soft_vs_oracle(H, W, kind, iters, params, report):
+    F = 2
+    gen = synth.smooth_rgb if kind == "smooth" else synth.noise_rgb
+    rgbs = [gen(H, W, 4100 + i) for i in range(F)]
+    uns = [_unary(synth.soft_blob_mask(H, W, 4100 + i)) for i in range(F)]
+    m, q, nv = _run_hip(rgbs, uns, W, H, params, iters)
+    worst_q, agree_all, mism_sure = 0.0, 1.0, 0
+    for f in range(F):
+        mo, qo, nvo = crf_oracle.crf_soft_np(rgbs[f], uns[f], W, H, *params, iters)
+        assert tuple(nv[f]) == nvo, f"lattice size differs: hip {tuple(nv[f])} oracle {nvo}"
+        worst_q = max(worst_q, float(np.abs(q[f] - qo).max()))
+        agree_all = min(agree_all, float((m[f] == mo).mean()))
+        sure = np.abs(qo[:, 1] - qo[:, 0]).reshape(H, W) > 1e-3
+        mism_sure += int((m[f] != mo)[sure].sum())
+    report(f"crf {H}x{W} {kind} T={iters} params={params}: L={nv.tolist()} L/N={nv[:, 1].max() / (H * W):.3f} "
+           f"max|dQ| {worst_q:.2e} MAP agreement {agree_all:.6f} mismatches on sure pixels {mism_sure}")
+    assert worst_q < 1e-4 and agree_all >= 0.999 and mism_sure == 0
+
+
+def test_crf_deterministic_and_batch_independent(report):
+    H, W, F = 120, 214, 3
+    rgbs = [synth.smooth_rgb(H, W, 4200 + i) for i in range(F)]
+    uns = [_unary(synth.soft_blob_mask(H, W, 4200 + i)) for i in range(F)]
+    p = (0., 0., 5., 60., 5.)
+    m1, q1, _ = _run_hip(rgbs, uns, W, H, p, 5)
+    m2, q2, _ = _run_hip(rgbs, uns, W, H, p, 5)
+    assert np.array_equal(m1, m2) and np.array_equal(q1, q2), "CRF output is not run-to-run bit-identical"
+    ms, qs, _ = _run_hip(rgbs[1:2], uns[1:2], W, H, p, 5)
+    assert np.array_equal(ms[0], m1[1]) and np.array_equal(qs[0], q1[1]), "frame result depends on its batch"
+    report("crf determinism: bit-identical across runs and batch compositions")
+
+
+def test_crf_invariants_fullsize(report):
+    H, W = 480, 854
+    rgb = synth.noise_rgb(H, W, 4300)                      # worst-case lattice occupancy
+    un = _unary(synth.soft_blob_mask(H, W, 4300))
+    # zero pairwise weight -> MAP is the unary argmax whatever the iteration count
+    m, q, nv = _run_hip([rgb], [un], W, H, (0., 0., 0., 60., 5.), 5)
+    assert np.array_equal(m[0].ravel(), (un[:, 1] < un[:, 0]).astype(np.int16))
+    assert tuple(nv[0]) == (0, 0)
+    # marginals are distributions
+    m, q, nv = _run_hip([rgb], [un], W, H, (0., 0., 5., 60., 5.), 5)
+    assert np.abs(q[0].sum(1) - 1).max() < 1e-6 and q[0].min() >= 0
+    report(f"crf invariants 480x854 noise: L={int(nv[0, 1])} L/N={nv[0, 1] / (H * W):.3f}")
+    assert 0 < nv[0, 1] <= 6 * H * W
+
+
+def test_crf_hard_vs_oracle(report):
+    H, W = 48, 64
+    rgb = synth.smooth_rgb(H, W, 4400)
+    lab = (synth.soft_blob_mask(H, W, 4400) > 0.5).astype(np.int16)
+    lab[::7, ::5] = -1
+    out = rcf_amd.crf_hard(torch.from_numpy(rgb).to(DEV), torch.from_numpy(lab).to(DEV), W, H, 3., 3., 5., 60., 5., 0.7, 5)
+    mo, _, _ = crf_oracle.crf_hard_np(rgb, lab, W, H, 3., 3., 5., 60., 5., 0.7, 5)
+    agree = float((out.cpu().numpy() == mo).mean())
+    report(f"crf_hard agreement {agree:.6f}")
+    assert agree >= 0.999
+
+
+def test_crf_head_prepare_vs_reference_golden(golden_dir, report):
+    """CRFHead pre-FFI products (u8 image, unary) against what the reference's CRFHead handed to
+    torchcrf_cpp.crf_soft (captured in tests/golden/crf_pre.npz)."""
+    fx = np.load(os.path.join(golden_dir, "crf_pre.npz"))
+    H, W, seed = int(fx["H"]), int(fx["W"]), int(fx["seed"])
+    img = torch.from_numpy(synth.normalize_rgb(synth.smooth_rgb(H, W, seed)))[None].to(DEV)
+    msk = torch.from_numpy(synth.soft_blob_mask(H, W, seed))[None].to(DEV)
+    head = rcf_amd.CRFHead(None)
+    rgb, un = head.prepare(img, msk)
+    mism = int((rgb[0].cpu().numpy() != fx["img_u8"]).sum())
+    e = float(np.abs(un[0].cpu().numpy() - fx["unary"]).max())
+    report(f"crf prepare: u8 mismatches {mism}, unary max abs diff {e:.2e}")
+    assert mism == 0 and e < 1e-6
+    out = head(img, msk)
+    assert tuple(out.shape) == (1, H, W) and set(np.unique(out.cpu().numpy())) <= {0.0, 1.0}

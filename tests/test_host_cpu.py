@@ -1,0 +1,117 @@
+"""CPU: host-side logic of the product (config loader, synthetic data, state-dict schema, flat
+parameter buffers, model construction contract)."""
+import copy
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import rcf_amd
+import rcf_torch as orc
+from rcf_amd import config, synth
+from rcf_amd.trainer import FlatParams
+
+REF_CFG = "/root/reference/configs/rcf/rcf_stage1.yaml"
+
+
+def _args():
+    return types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None)
+
+
+def test_yaml_loader_base_config_and_opts(tmp_path):
+    base = tmp_path / "base.yaml"
+    base.write_text("a: 1\nb:\n  c: 2.5\n  d: [1, 2]\nflag: true\n")
+    child = tmp_path / "child.yaml"
+    child.write_text("base_config: base.yaml\nb:\n  d: [9]\nname: x\n")
+    cfg = config.load_args(str(child), ["a", "7", "b.c", "0.5", "flag", "false"])
+    assert cfg.a == 7 and cfg.b == {"c": 0.5, "d": [9]} and cfg.flag is False and cfg.name == "x"
+    dup = tmp_path / "dup.yaml"
+    dup.write_text("a: 1\na: 2\n")
+    with pytest.raises(ValueError):
+        config.load_yaml(str(dup))
+    with pytest.raises(KeyError):
+        config.load_args(str(child), ["missing.key", "1"])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference configs only exist in the build container")
+def test_reference_stage1_yaml_builds_the_model():
+    """the reference's own YAML drives the constructor unchanged (mask size aside)"""
+    args = config.load_args(REF_CFG, ["model_kwargs.mask_size", "[24, 40]"]) if False else config.load_args(REF_CFG)
+    kw = copy.deepcopy(args.model_kwargs)
+    want = config.stage1_model_kwargs((96, 96), dropout=0.1, norm="SyncBN")
+    assert kw == want, "stage1_model_kwargs drifted from configs/rcf/rcf_stage1.yaml"
+    args.object_channel = None
+    m = rcf_amd.RCFModel(args, **kw)
+    assert "type" not in kw["backbone2"]              # popped like the reference does (one model per dict)
+    assert m.num_classes == 4 and m.mask_size == (96, 96)
+
+
+def test_state_dict_schema_equals_oracle_and_counts():
+    kw = config.stage1_model_kwargs((24, 40), dropout=0.0)
+    hip, ora = rcf_amd.RCFModel(_args(), **copy.deepcopy(kw)), orc.RCFModel(_args(), **copy.deepcopy(kw))
+    a, b = hip.state_dict(), ora.state_dict()
+    assert list(a) == list(b) and len(a) == 354
+    assert all(tuple(a[k].shape) == tuple(b[k].shape) and a[k].dtype == b[k].dtype for k in a)
+    assert sum(p.numel() for p in hip.parameters()) == 39482902
+    # a plain (contiguous) checkpoint loads into the channels_last parameters and round-trips
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict({k: tuple(v.shape) for k, v in a.items()}).items()}
+    hip.load_state_dict(sd)
+    back = hip.state_dict()
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    w = hip.backbone2.layer1[0].conv2.weight if hasattr(hip.backbone2.layer1, "__getitem__") else \
+        getattr(hip.backbone2.layer1, "0").conv2.weight
+    assert w.permute(0, 2, 3, 1).is_contiguous()
+    # stage 2.1 adds the EMA copies under the reference's names
+    kw2 = config.stage1_model_kwargs((24, 40), dropout=0.0)
+    kw2["backbone2"]["create_ema"] = True
+    kw2["decode_head2"]["create_ema"] = True
+    m2 = rcf_amd.RCFModel(_args(), **kw2)
+    keys = set(m2.state_dict())
+    assert any(k.startswith("backbone2_ema.") for k in keys) and any(k.startswith("decode_head2_ema.") for k in keys)
+    assert not any(p.requires_grad for p in m2.backbone2_ema.parameters())
+
+
+def test_flat_params_views_and_zero_init():
+    kw = config.stage1_model_kwargs((24, 40), dropout=0.0)
+    m = rcf_amd.RCFModel(_args(), **kw)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    fp = FlatParams(m, torch.device("cpu"))
+    assert fp.total >= 39482902 and fp.total % FlatParams.ALIGN == 0
+    for (n, p), o in zip(((n, p) for n, p in m.named_parameters() if p.requires_grad), fp.offsets):
+        assert torch.equal(p.detach(), before[n]), n                          # values preserved
+        assert p.data_ptr() == fp.flat.data_ptr() + 4 * o and o % 4 == 0      # 16-byte aligned views
+        assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o
+    from rcf_amd.layers import Conv2d
+    for mod in m.modules():                                # the HIP convs keep [Cout][R][S][Cin] memory order
+        if isinstance(mod, Conv2d) and mod.cin % 4 == 0 and mod.weight.requires_grad:
+            assert mod.weight.permute(0, 2, 3, 1).is_contiguous()
+            assert mod.weight.grad.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_synthetic_data_is_deterministic_and_well_formed():
+    a, b = synth.make_batch(2, 48, 64, config_id=3), synth.make_batch(2, 48, 64, config_id=3)
+    for k in ("imgs", "gt_fw_flows", "gt_bw_flows"):
+        for x, y in zip(a[k], b[k]):
+            assert np.array_equal(x, y)
+    assert a["imgs"][0].shape == (2, 3, 48, 64) and a["gt_fw_flows"][0].shape == (2, 2, 48, 64)
+    assert np.sqrt((a["gt_fw_flows"][0] ** 2).sum(1)).max() <= 20.0 + 1e-4
+    assert synth.smooth_rgb(16, 16, 1).dtype == np.uint8 and not np.array_equal(synth.smooth_rgb(16, 16, 1), synth.smooth_rgb(16, 16, 2))
+    assert config.mask_size_for(480, 854) == (120, 214) and config.mask_size_for(384, 384) == (96, 96)
+
+
+def test_unsupported_options_raise_instead_of_silently_diverging():
+    kw = config.stage1_model_kwargs((24, 40))
+    kw["decode_head3"]["create_flownet"] = True
+    with pytest.raises(NotImplementedError):
+        rcf_amd.RCFModel(_args(), **kw)
+    kw = config.stage1_model_kwargs((24, 40))
+    kw["decode_head"]["free_residual"] = False
+    with pytest.raises(NotImplementedError):
+        rcf_amd.RCFModel(_args(), **kw)
+    m = rcf_amd.RCFModel(_args(), **config.stage1_model_kwargs((24, 40)))
+    batch = {k: [torch.zeros(1, c, 96, 160)] * n for k, c, n in (("imgs", 3, 2), ("gt_fw_flows", 2, 1), ("gt_bw_flows", 2, 1))}
+    m.train()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(batch)
