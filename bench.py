@@ -155,7 +155,7 @@ def cpu_baseline(H, W):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rcf_torch as orc
     from rcf_amd import config, synth
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=None)
     m = orc.RCFModel(args, **copy.deepcopy(config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN")))

@@ -255,12 +255,13 @@ class FlowAggregationHeadWithResidual(nn.Module):
         self.quadratic = free_residual_with_affine_quadratic
         self.allow_residual_resize = allow_residual_resize
 
-    def coord_map(self, device):
-        """:135-148 — (row, col[, row^2, col^2, row*col]) per pixel, float32."""
+    def coord_map(self, device, dtype=torch.float32):
+        """:135-148 — (row, col[, row^2, col^2, row*col]) per pixel; float32 in the reference (a
+        float64 run of this oracle serves as numerical ground truth in the tests)."""
         H, W = self.mask_size
         yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
         cols = [yy, xx] + ([yy * yy, xx * xx, yy * xx] if self.quadratic else [])
-        return torch.stack(cols, dim=2).view(H * W, -1).float().to(device)
+        return torch.stack(cols, dim=2).view(H * W, -1).to(dtype).to(device)
 
     def norm_and_clamp_flow(self, flow):
         if self.norm_flow:
@@ -277,14 +278,15 @@ class FlowAggregationHeadWithResidual(nn.Module):
         B, C, H, W = mask.shape
         w = (mask / mask.sum(dim=(2, 3), keepdim=True)).flatten(2)            # [B,C,HW]
         Fu = flow.flatten(2).permute(0, 2, 1)                                 # [B,HW,2]
-        om = self.coord_map(mask.device)                                      # [HW,D]
+        om = self.coord_map(mask.device, mask.dtype)                          # [HW,D]
         mu_F = torch.bmm(w, Fu)                                               # [B,C,2]
         mu_o = w @ om                                                         # [B,C,D]
         Fd = Fu[:, None] - mu_F[:, :, None]                                   # [B,C,HW,2]
         od = om[None, None] - mu_o[:, :, None]                                # [B,C,HW,D]
         S_Fo = torch.einsum("bcp,bcpk,bcpl->bckl", w, Fd, od)                 # [B,C,2,D]
         S_oo = torch.einsum("bcp,bcpk,bcpl->bckl", w, od, od)                 # [B,C,D,D]
-        A = torch.linalg.solve(S_oo.float(), S_Fo.permute(0, 1, 3, 2).float()).permute(0, 1, 3, 2)
+        cast = (lambda t: t) if S_oo.dtype == torch.float64 else (lambda t: t.float())   # :216-217 forces fp32
+        A = torch.linalg.solve(cast(S_oo), cast(S_Fo.permute(0, 1, 3, 2))).permute(0, 1, 3, 2)
         pred = torch.einsum("bcjk,bclk->bclj", A, od).view(B, C, H, W, 2)
         return torch.einsum("bchw,bchwl->blhw", mask, pred)
 

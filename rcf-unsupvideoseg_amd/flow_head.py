@@ -187,7 +187,9 @@ class FlowAggregationHeadWithResidual(nn.Module):
         losses["loss"] = loss.detach()
 
         def seed(scale):
-            grads = torch.autograd.grad(loss * scale, [l_nchw, r_nchw] + params, allow_unused=True)
+            # called from inside autograd's backward (grad mode off): scale through grad_outputs
+            grads = torch.autograd.grad(loss, [l_nchw, r_nchw] + params, allow_unused=True,
+                                        grad_outputs=torch.as_tensor(scale, dtype=loss.dtype, device=loss.device))
             logits.grad = ops.nchw_to_nhwc(grads[0].contiguous(), logits.t.shape[3])
             res.grad = ops.nchw_to_nhwc(grads[1].contiguous(), res.t.shape[3])
             for q, g in zip(params, grads[2:]):

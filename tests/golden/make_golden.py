@@ -239,6 +239,19 @@ def main():
         report[tag] = chk
         print(tag, json.dumps(chk, indent=1))
         assert max(chk.values()) < 2e-4, f"oracle disagrees with the reference on {tag}"
+        # float64 ground truth (the oracle, pinned to the reference above, run in double) and the
+        # reference's OWN fp32 deviation from it: the yardstick for every other fp32 implementation
+        o64 = orc.RCFModel(args, **copy.deepcopy(kw))
+        o64.load_state_dict(sd)
+        o64 = o64.double().train()
+        b64 = torch_batch(nb)
+        b64 = {k: ([t.double() for t in v] if k in ("imgs", "gt_fw_flows", "gt_bw_flows") else v) for k, v in b64.items()}
+        l64 = o64(b64)
+        l64["loss"].backward()
+        gn64 = grad_norms(o64)
+        g64 = {n: o64.get_parameter(n).grad.detach().numpy().ravel()[:256].copy() for n in SAMPLED}
+        logits64 = o64.last["logits"].detach()
+        masks64 = F.softmax(logits64.view(B, 2, 4, *mask_size), dim=2)
         top2 = torch.topk(logits, 2, dim=1).values
         fx = dict(H=H, W=W, B=B, affine=int(affine), weight_seed=7, config_id=1,
                   mask_size=np.array(mask_size),
@@ -250,12 +263,24 @@ def main():
                   feat_absmean=np.array([float(f.abs().mean()) for f in feats]),
                   gradnorm_keys=np.array(sorted(gn_ref)), gradnorm=np.array([gn_ref[k] for k in sorted(gn_ref)]),
                   sampled=np.array(SAMPLED),
+                  truth_loss=np.float64(l64["loss"].item()),
+                  truth_gradnorm=np.array([gn64[k] for k in sorted(gn_ref)]),
+                  ref32_err_loss=rel(l_ref["loss"].item(), l64["loss"].item()),
+                  ref32_err_logits=rel(logits.numpy(), logits64.numpy()),
+                  ref32_err_masks=float((masks.double() - masks64).abs().max()),
+                  ref32_err_gradnorm=np.array([rel(gn_ref[k], gn64[k]) for k in sorted(gn_ref)]),
+                  ref32_err_grad=np.array([rel(g_ref[k], g64[k]) for k in SAMPLED]),
                   **{"grad_%d" % i: g_ref[k] for i, k in enumerate(SAMPLED)},
+                  **{"truth_grad_%d" % i: g64[k] for i, k in enumerate(SAMPLED)},
                   **{"adam_%d" % i: a_ref[k] for i, k in enumerate(SAMPLED)})
+        print(tag, "reference fp32 vs float64 truth: loss %.2e logits %.2e masks %.2e gradnorm %s grad %s" % (
+            fx["ref32_err_loss"], fx["ref32_err_logits"], fx["ref32_err_masks"], fx["ref32_err_gradnorm"], fx["ref32_err_grad"]))
         if store_full:
-            fx.update(masks=masks.numpy(), logits=logits.numpy(), res_fw=rfw.numpy(), res_bw=rbw.numpy())
+            fx.update(masks=masks.numpy(), logits=logits.numpy(), res_fw=rfw.numpy(), res_bw=rbw.numpy(),
+                      truth_logits=logits64.numpy(), truth_masks=masks64.numpy())
         else:
-            fx.update(masks0=masks[0].numpy(), mask_mean=masks.mean(dim=(3, 4)).numpy())
+            fx.update(masks0=masks[0].numpy(), mask_mean=masks.mean(dim=(3, 4)).numpy(),
+                      truth_logits0=logits64[:2].numpy(), truth_masks0=masks64[0].numpy())
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), **fx)
 
     model_case("rcf_small", 96, 160, 2, affine=False, store_full=True)

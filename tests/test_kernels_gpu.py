@@ -233,7 +233,7 @@ def test_adam_and_ema(report):
     ops.ema_update(dg, s.to(DEV), 0.999)
     e2 = relerr(dg, d * 0.999 + s * (1 - 0.999))
     report(f"adam: {e:.2e} (of update) ema: {e2:.2e}")
-    assert e < 1e-3 and e2 < 1e-6
+    assert e < 5e-3 and e2 < 1e-6
 
 
 def test_warp_family_vs_golden(golden_dir, report):
