@@ -28,7 +28,7 @@ ColGeom col_geom(long rows, int C) {
     g.cvB = CV < 64 ? CV : 64;
     g.RG = RED_THREADS / g.cvB;
     g.cgroups = (CV + g.cvB - 1) / g.cvB;
-    long chunks = 2048 / g.cgroups;
+    long chunks = 1024 / g.cgroups;
     const long min_rows = (long)g.RG * 8;
     if (chunks > (rows + min_rows - 1) / min_rows) chunks = (rows + min_rows - 1) / min_rows;
     if (chunks < 1) chunks = 1;
@@ -82,12 +82,23 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
     }
 }
 
-__global__ void partial_sum_kernel(const double *__restrict__ partial, int chunks, int n, double *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0;
-    for (int k = 0; k < chunks; ++k) s += partial[(long)k * n + i];
-    out[i] = s;
+// out[i] = sum_k partial[k][i]: 32 outputs x 8 chunk-slices per block, fixed summation order
+__global__ void __launch_bounds__(256) partial_sum_kernel(const double *__restrict__ partial, int chunks, int n,
+                                                          double *__restrict__ out) {
+    __shared__ double sh[256];
+    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + j;
+    double acc = 0;
+    if (i < n)
+        for (int k = s; k < chunks; k += 8) acc += partial[(long)k * n + i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (s == 0 && i < n) {
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q * 32 + j];
+        out[i] = t;
+    }
 }
 
 struct StatsOp {
@@ -237,13 +248,22 @@ struct ColsumOp {
     }
 };
 
-__global__ void colsum_final_kernel(const double *__restrict__ partial, int chunks, int C, float *__restrict__ out,
-                                    int beta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int k = 0; k < chunks; ++k) s += partial[(long)k * 2 * C + c];
-    out[c] = (beta ? out[c] : 0.f) + (float)s;
+__global__ void __launch_bounds__(256) colsum_final_kernel(const double *__restrict__ partial, int chunks, int C,
+                                                           float *__restrict__ out, int beta) {
+    __shared__ double sh[256];
+    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + j;
+    double acc = 0;
+    if (c < C)
+        for (int k = s; k < chunks; k += 8) acc += partial[(long)k * 2 * C + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (s == 0 && c < C) {
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q * 32 + j];
+        out[c] = (beta ? out[c] : 0.f) + (float)t;
+    }
 }
 
 inline int ew_blocks(long total) {
@@ -269,7 +289,7 @@ extern "C" int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, dou
     hipLaunchKernelGGL(colreduce2_kernel<StatsOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
                        g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 256)), dim3(256), 0, st, (const double *)workspace,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums);
     RCF_LAUNCH_CHECK();
     return 0;
@@ -321,7 +341,7 @@ extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float 
     hipLaunchKernelGGL(colreduce2_kernel<BwdOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
                        g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 256)), dim3(256), 0, st, (const double *)workspace,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums2);
     RCF_LAUNCH_CHECK();
     return 0;
@@ -354,7 +374,7 @@ extern "C" int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float
     hipLaunchKernelGGL(colreduce2_kernel<ColsumOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
                        g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(rcf_cdiv(C, 256)), dim3(256), 0, st, (const double *)workspace,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(rcf_cdiv(C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, C, out, beta);
     RCF_LAUNCH_CHECK();
     return 0;
