@@ -153,6 +153,54 @@ int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3
                     int unstandardize, float crf_scale, uint8_t *rgb_out, float *unary_out, uint32_t *scratch,
                     int batch, int H, int W, void *stream);
 
+/* ---- flow-aggregation head (relaxed common fate) + loss tail ------------------------------------
+ * models/flow_aggregation_head_with_residual.py:235-310 (aggregate), :164-233 (per-segment affine
+ * least squares), :312-399 (forward, L1 / robust loss); softmax + double-softmax entropy of
+ * models/rcf_model.py:433-434,376-378; asymmetric clamped MSE against pl / crf targets :380-408.
+ * "Direction image" n = 2*b + d: d = 0 forward (frame-0 masks, fw flow, residual channels [0,2C)),
+ * d = 1 backward (frame-1 masks, bw flow, residual channels [2C,4C)); P = h*w.
+ *   logits   NHWC [2B][P][logits_pitch]         (conv_seg output of decode_head2)
+ *   feat     NHWC [2B][P][64]                   (flow_feat_before_agg output, LeakyReLU applied)
+ *   residual NHWC [B][P][4C]                    (decode_head3 output resized to the mask size)
+ *   W1 [64][64], b1 [64], W2 [2][64], b2 [2]    (flow_feat_after_agg Conv1d weights)
+ *   targets  [2B][P] planar or NULL             (pl / crf masks at mask size)
+ * The same workspace must be passed to prepare -> fwd -> bwd of one step. */
+typedef struct {
+    int B, C, h, w;          /* pairs, segments (mask_layer), mask size */
+    int logits_pitch;
+    int nf;                  /* must be 64 */
+    int D;                   /* 0 free_residual, 2 free_residual_with_affine, 5 + quadratic */
+    int robust;              /* outlier_robust_loss */
+    int tanh_residual;       /* 1: scale*tanh(r/div) ; 0: plain r (residual_adjustment_scale == -1) */
+    float eps, q;
+    float clamp_t;           /* < 0: no clamp */
+    float res_scale, div_coeff;
+    float w_seg, w_entropy;
+    int n_targets, target_channel;
+    float t_wpos[2], t_wneg[2], t_weight[2], t_thresh[2];   /* t_thresh -1: soft target */
+} rcf_flowhead_cfg;
+size_t rcf_flowhead_workspace_bytes(const rcf_flowhead_cfg *c);
+/* gt_fw / gt_bw [B][2][P] -> clamped flows (kept in the workspace) and flow4 NHWC [2B][P][4], the
+ * zero-padded input of flow_feat_before_agg.0 */
+int rcf_flowhead_prepare_f32(const rcf_flowhead_cfg *c, const float *gt_fw, const float *gt_bw, float *flow4,
+                             void *workspace, size_t workspace_bytes, void *stream);
+/* losses_out[5] = seg_fw, seg_bw, entropy, target0, target1 (unweighted means).  masks_out [2B][C][P] and
+ * the four flow planes [2B][2][P] (overall, aggregated, residual adjustment, affine) are optional. */
+int rcf_flowhead_fwd_f32(const rcf_flowhead_cfg *c, const float *logits, const float *feat, const float *residual,
+                         const float *W1, const float *b1, const float *W2, const float *b2, const float *target0,
+                         const float *target1, float *losses_out, float *masks_out, float *flow_pred,
+                         float *flow_agg, float *flow_adj, float *flow_aff, void *workspace, size_t workspace_bytes,
+                         void *stream);
+/* gradients of grad_scale * (w_seg*seg + w_entropy*entropy + sum t_weight*target): dlogits (same layout as
+ * logits, written), dresidual [B][P][4C] (written), dfeat [2B][P][64] = gradient w.r.t. the PRE-activation of
+ * the second flow conv (written); dW1/db1/dW2/db2 accumulate. */
+int rcf_flowhead_bwd_f32(const rcf_flowhead_cfg *c, const float *feat, const float *residual, const float *W1,
+                         const float *W2, const float *target0, const float *target1, float grad_scale,
+                         float *dlogits, float *dresidual, float *dfeat, float *dW1, float *db1, float *dW2,
+                         float *db2, void *workspace, size_t workspace_bytes, void *stream);
+/* dx = dy * (y > 0 ? 1 : slope), y = LeakyReLU output (n % 4 == 0) */
+int rcf_lrelu_bwd_f32(const float *dy, const float *y, float *dx, long n, float slope, void *stream);
+
 /* ---- optimiser / EMA ----------------------------------------------------------------------------
  * torch.optim.Adam with coupled weight decay (main.py:299-307) over one flat fp32 buffer;
  * EMA lerp of utils/model_utils.py:33-38 over flat buffers. */

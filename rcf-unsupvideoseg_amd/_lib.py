@@ -20,8 +20,17 @@ class ConvShape(ctypes.Structure):
                                      "x_pitch", "y_pitch")]
 
 
+class FlowHeadCfg(ctypes.Structure):
+    """mirror of rcf_flowhead_cfg"""
+    _fields_ = [(n, c_int) for n in ("B", "C", "h", "w", "logits_pitch", "nf", "D", "robust", "tanh_residual")] + \
+               [(n, c_float) for n in ("eps", "q", "clamp_t", "res_scale", "div_coeff", "w_seg", "w_entropy")] + \
+               [("n_targets", c_int), ("target_channel", c_int)] + \
+               [(n, c_float * 2) for n in ("t_wpos", "t_wneg", "t_weight", "t_thresh")]
+
+
 P = c_void_p
 _CS = ctypes.POINTER(ConvShape)
+_FH = ctypes.POINTER(FlowHeadCfg)
 
 # name -> (restype, argtypes); every int-returning entry point is status-checked by `call`
 PROTOS = {
@@ -61,6 +70,11 @@ PROTOS = {
     "rcf_crf_hard": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                              P, P, P, P, c_size_t, P]),
     "rcf_crf_prepare": (c_int, [P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),
+    "rcf_flowhead_workspace_bytes": (c_size_t, [_FH]),
+    "rcf_flowhead_prepare_f32": (c_int, [_FH, P, P, P, P, c_size_t, P]),
+    "rcf_flowhead_fwd_f32": (c_int, [_FH] + [P] * 15 + [P, c_size_t, P]),
+    "rcf_flowhead_bwd_f32": (c_int, [_FH, P, P, P, P, P, P, c_float] + [P] * 7 + [P, c_size_t, P]),
+    "rcf_lrelu_bwd_f32": (c_int, [P, P, P, c_long, c_float, P]),
     "rcf_adam_step_f32": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "rcf_ema_update_f32": (c_int, [P, P, c_long, c_float, P]),
     "rcf_fill_f32": (c_int, [P, c_long, c_float, P]),

@@ -1,19 +1,26 @@
-"""Flow-aggregation head (`decode_head`) and the loss assembly of RCFModel.forward_train.
+"""Flow-aggregation head (`decode_head`) and the loss tail of RCFModel.forward_train.
 
 Reference: models/flow_aggregation_head_with_residual.py:50-148 (ctor), :150-162 (clamp), :164-233
 (per-segment affine least squares), :235-310 (aggregate), :312-399 (forward); losses
 models/rcf_model.py:350-408,433-434,464-523; compactness models/compactness_head.py:14-57.
 
-Same constructor keywords / state-dict keys as the reference head.  `loss_and_grads` evaluates the
-whole loss tail (softmax -> flow reconstruction -> L1 / entropy / pl / crf / compactness) and returns
-a closure that seeds the tape with d loss / d logits and d loss / d residual.
+Same constructor keywords / state-dict keys as the reference head.  The training path
+(`loss_and_grads`) runs on the hand-written kernels of csrc/flowhead.hip (softmax, segment pooling,
+MLP, fp64 affine least squares, reconstruction + loss, analytic backward) plus the implicit-GEMM conv
+kernels for the two 3x3 flow-feature convs.  A plain-torch evaluation of the same maths is kept for
+(a) the stand-alone `forward()` surface, which takes already-softmaxed masks, and (b) configs with a
+compactness head (STv2), whose loss is not in the HIP tail yet.
 """
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
-from .layers import Act, _param_grad
+from . import _lib, ops
+from ._lib import FlowHeadCfg
+from .layers import Conv2d, _param_grad
+from .ops import _p, _stream
 
 
 class CompactnessHead(nn.Module):
@@ -38,6 +45,35 @@ class CompactnessHead(nn.Module):
         return (((y - yc) ** 2 + (x - xc) ** 2) * m).mean()
 
 
+class _Pointwise(nn.Module):
+    """Parameter holder with nn.Conv1d(k=1)'s state-dict shape [out, in, 1] and default init."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.uniform_(self.bias, -1 / math.sqrt(cin), 1 / math.sqrt(cin))
+
+
+class _Indexed(nn.Module):
+    """children named like the slots of the reference's nn.Sequential (activations hold no state)."""
+
+    def __init__(self, **mods):
+        super().__init__()
+        for k, m in mods.items():
+            self.add_module(k, m)
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+
+def _torch_default_conv_init(conv):
+    nn.init.kaiming_uniform_(conv.weight, a=math.sqrt(5))          # nn.Conv2d.reset_parameters
+    fan_in = conv.weight.shape[1] * conv.weight.shape[2] * conv.weight.shape[3]
+    nn.init.uniform_(conv.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+
+
 class FlowAggregationHeadWithResidual(nn.Module):
     def __init__(self, args=None, ssim_sz=1, mask_layer=5, create_flownet=False, flow_feat_before_agg_kernel_size=3,
                  num_flow_feat_channels=64, outlier_robust_loss=False, eps=0.01, q=0.4, mask_size=(48, 48),
@@ -57,10 +93,14 @@ class FlowAggregationHeadWithResidual(nn.Module):
         if norm_flow or filter_flow_t is not None:
             raise NotImplementedError("norm_flow / filter_flow_t are not used by any RCF config")
         k, nf = flow_feat_before_agg_kernel_size, num_flow_feat_channels
-        self.flow_feat_before_agg = nn.Sequential(
-            nn.Conv2d(2, nf, k, padding=(k - 1) // 2), nn.LeakyReLU(0.1),
-            nn.Conv2d(nf, nf, k, padding=(k - 1) // 2), nn.LeakyReLU(0.1))
-        self.flow_feat_after_agg = nn.Sequential(nn.Conv1d(nf, nf, 1), nn.LeakyReLU(0.1), nn.Conv1d(nf, 2, 1))
+        if nf != 64:
+            raise NotImplementedError("num_flow_feat_channels must be 64 (the wavefront width the kernels map it to)")
+        c1 = Conv2d(2, nf, k, padding=(k - 1) // 2, bias=True, act=1, slope=0.1)
+        c2 = Conv2d(nf, nf, k, padding=(k - 1) // 2, bias=True, act=1, slope=0.1)
+        _torch_default_conv_init(c1)
+        _torch_default_conv_init(c2)
+        self.flow_feat_before_agg = _Indexed(**{"0": c1, "2": c2})
+        self.flow_feat_after_agg = _Indexed(**{"0": _Pointwise(nf, nf), "2": _Pointwise(nf, 2)})
         self.args = args
         self.mask_layer, self.mask_size, self.nf = mask_layer, tuple(mask_size), nf
         self.outlier_robust_loss, self.eps, self.q = outlier_robust_loss, eps, q
@@ -69,14 +109,114 @@ class FlowAggregationHeadWithResidual(nn.Module):
         self.free_residual, self.free_residual_with_affine = free_residual, free_residual_with_affine
         self.quadratic = free_residual_with_affine_quadratic
         self.allow_residual_resize = allow_residual_resize
+        self._ws = None
 
-    # ---------------------------------------------------------------- pieces
+    # ================================================================ HIP training path
     def softmax_masks(self, logits_nhwc, B, I):
         """NHWC logits [B*I,h,w,C] -> softmax masks [B,I,C,h,w] (models/rcf_model.py:430-433)."""
         C = self.mask_layer
         l = ops.nhwc_to_nchw(logits_nhwc, C)
         return F.softmax(l.view(B, I, C, *l.shape[-2:]), dim=2)
 
+    def _cfg(self, model, B, logits_pitch, targets):
+        c = FlowHeadCfg()
+        c.B, c.C, (c.h, c.w) = B, self.mask_layer, self.mask_size
+        c.logits_pitch, c.nf = logits_pitch, self.nf
+        c.D = 0 if not self.free_residual_with_affine else (5 if self.quadratic else 2)
+        c.robust = int(self.outlier_robust_loss)
+        c.tanh_residual = int(self.free_residual_with_affine or self.residual_adjustment_scale != -1.)
+        c.eps, c.q = self.eps, self.q
+        c.clamp_t = -1.0 if self.clamp_flow_t is None else float(self.clamp_flow_t)
+        c.res_scale, c.div_coeff = float(self.residual_adjustment_scale), float(self.pred_div_coeff)
+        c.w_seg, c.w_entropy = float(model.w_seg), float(model.w_entropy)
+        c.n_targets = len(targets)
+        c.target_channel = int(model.args.object_channel) if targets else 0
+        for i, (_, _, wpos, wneg, weight, th) in enumerate(targets):
+            c.t_wpos[i], c.t_wneg[i], c.t_weight[i], c.t_thresh[i] = wpos, wneg, weight, th
+        return c
+
+    def _workspace(self, cfg, device):
+        need = _lib.load().rcf_flowhead_workspace_bytes(cfg)
+        if need == 0:
+            raise _lib.RcfHipError("unsupported flow-head configuration for the HIP kernels")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)    # lives across fwd -> bwd
+        return self._ws, need
+
+    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I):
+        """Returns (losses, seed): seed(scale) writes d(scale*loss)/d logits and /d res into the Acts and
+        accumulates this head's parameter gradients."""
+        if model.compactness_head is not None:
+            return self._loss_and_grads_torch(model, logits, res, gfw, gbw, extra, B, I)
+        assert I == 2, "Other im_num not implemented"
+        C, (h, w) = self.mask_layer, self.mask_size
+        dev = logits.t.device
+        assert tuple(logits.t.shape) == (B * I, h, w, logits.t.shape[3]) and logits.t.shape[3] >= C
+        targets = []
+        if model.w_pl > 0:
+            targets.append(("loss_pl", extra["pl_masks"].contiguous(), model.pl_pos_weight, model.pl_neg_weight,
+                            model.w_pl, float(model.pl_mask_pos_th)))
+        if model.w_crf > 0:
+            targets.append(("loss_crf", extra["crf_masks"].contiguous(), model.crf_pos_weight, model.crf_neg_weight,
+                            model.w_crf, float(model.crf_mask_pos_th)))
+        cfg = self._cfg(model, B, ops.pitch_of(logits.t), targets)
+        ws, need = self._workspace(cfg, dev)
+        st = _stream()
+        gfw, gbw = gfw.contiguous(), gbw.contiguous()                           # [B,1,2,h,w]
+        flow4 = torch.empty((B * I, h, w, 4), dtype=torch.float32, device=dev)
+        _lib.call("rcf_flowhead_prepare_f32", cfg, _p(gfw), _p(gbw), _p(flow4), _p(ws), need, st)
+        c1, c2 = self.flow_feat_before_agg[0], self.flow_feat_before_agg[2]
+        l1, l2 = self.flow_feat_after_agg[0], self.flow_feat_after_agg[2]
+        w1p = c1._packed_weight()
+        a1 = ops.conv2d_fwd(flow4, w1p, c1.bias, 1, c1.padding, 1, act=1, slope=0.1)
+        feat = ops.conv2d_fwd(a1, c2.weight, c2.bias, 1, c2.padding, 1, act=1, slope=0.1)
+        if tuple(res.t.shape[1:3]) != (h, w):
+            if not self.allow_residual_resize:
+                raise RuntimeError("residual size differs from mask_size and allow_residual_resize is off")
+            R = ops.resize_nhwc_fwd(res.t, (h, w), False)                       # F.interpolate(bilinear), :272-273
+        else:
+            R = res.t
+        assert R.is_contiguous() and R.shape[3] == 4 * C
+        t0 = targets[0][1] if len(targets) > 0 else None
+        t1 = targets[1][1] if len(targets) > 1 else None
+        l5 = torch.empty(5, dtype=torch.float32, device=dev)
+        _lib.call("rcf_flowhead_fwd_f32", cfg, _p(logits.t), _p(feat), _p(R), _p(l1.weight), _p(l1.bias), _p(l2.weight),
+                  _p(l2.bias), _p(t0), _p(t1), _p(l5), None, None, None, None, None, _p(ws), need, st)
+        seg = l5[0] + l5[1]
+        losses = {"loss_warp_seg": seg}
+        loss = seg * model.w_seg
+        if model.w_entropy > 0:
+            losses["loss_entropy"] = l5[2]
+            loss = loss + l5[2] * model.w_entropy
+        for i, (name, _, _, _, weight, _) in enumerate(targets):
+            losses[name] = l5[3 + i]
+            loss = loss + l5[3 + i] * weight
+        losses["loss"] = loss
+
+        def seed(scale):
+            dlogits = torch.empty_like(logits.t)
+            dR = torch.empty_like(R)
+            dfeat = torch.empty_like(feat)
+            _lib.call("rcf_flowhead_bwd_f32", cfg, _p(feat), _p(R), _p(l1.weight), _p(l2.weight), _p(t0), _p(t1),
+                      float(scale), _p(dlogits), _p(dR), _p(dfeat), _p(_param_grad(l1.weight)), _p(_param_grad(l1.bias)),
+                      _p(_param_grad(l2.weight)), _p(_param_grad(l2.bias)), _p(ws), need, _stream())
+            logits.grad = dlogits
+            res.grad = dR if R is res.t else ops.resize_nhwc_bwd(dR, res.t.shape[1:3], False)
+            # second 3x3 conv (64 -> 64): dfeat already carries the LeakyReLU derivative
+            ops.conv2d_wgrad(a1, dfeat, c2.weight, _param_grad(c2.weight), 1, c2.padding, 1, beta=1)
+            ops.colsum(dfeat, _param_grad(c2.bias), beta=1)
+            da1 = ops.conv2d_dgrad(dfeat, c2.weight, a1.shape, 1, c2.padding, 1)
+            _lib.call("rcf_lrelu_bwd_f32", _p(da1), _p(a1), _p(da1), da1.numel(), 0.1, _stream())
+            # first 3x3 conv (2 -> 64, input zero-padded to 4 channels): no data gradient (input = RAFT flow)
+            dwp = torch.empty_like(w1p)
+            ops.conv2d_wgrad(flow4, da1, w1p, dwp, 1, c1.padding, 1, beta=0)
+            dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), c1.cin)
+            g = _param_grad(c1.weight)
+            ops.copy2d(dw, dw.numel(), g, g.numel(), 1, dw.numel(), beta=1)
+            ops.colsum(da1, _param_grad(c1.bias), beta=1)
+        return losses, seed
+
+    # ================================================================ plain-torch evaluation (off the hot path)
     def _coord_map(self, device):
         H, W = self.mask_size
         yy, xx = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
@@ -96,12 +236,19 @@ class FlowAggregationHeadWithResidual(nn.Module):
         pred = torch.einsum("bcjk,bclk->bclj", A, od).view(B, C, H, W, 2)
         return torch.einsum("bchw,bchwl->blhw", mask, pred)
 
+    def _features_torch(self, flow):
+        c1, c2 = self.flow_feat_before_agg[0], self.flow_feat_before_agg[2]
+        x = F.leaky_relu(F.conv2d(flow, c1.weight, c1.bias, padding=c1.padding), 0.1)
+        return F.leaky_relu(F.conv2d(x, c2.weight, c2.bias, padding=c2.padding), 0.1)
+
     def _aggregate(self, mask, flow, residual):
         B, C, H, W = mask.shape
         mhat = mask / mask.flatten(2).sum(dim=2).view(B, C, 1, 1)
-        feat = self.flow_feat_before_agg(flow)
+        feat = self._features_torch(flow)
         assert feat.shape[2:] == mask.shape[2:], f"{feat.shape[2:]} != {mask.shape[2:]}"
-        u = self.flow_feat_after_agg(torch.einsum("bkhw,bchw->bkc", feat, mhat))
+        l1, l2 = self.flow_feat_after_agg[0], self.flow_feat_after_agg[2]
+        pooled = torch.einsum("bkhw,bchw->bkc", feat, mhat)
+        u = F.conv1d(F.leaky_relu(F.conv1d(pooled, l1.weight, l1.bias), 0.1), l2.weight, l2.bias)
         agg = torch.einsum("bdc,bchw->bdhw", u, mask)
         affine = self._affine(mask, flow) if self.free_residual_with_affine else None
         if self.allow_residual_resize and tuple(residual.shape[-2:]) != self.mask_size:
@@ -128,7 +275,8 @@ class FlowAggregationHeadWithResidual(nn.Module):
         return {"seg_fw": l_fw, "seg_bw": l_bw, "seg": l_fw + l_bw}, (fw, bw, gt_fw, gt_bw)
 
     def forward(self, imgs, masks, gt_fw_flows, gt_bw_flows, res_fw, res_bw):
-        """nn.Module surface of the reference head (NCHW tensors): (flows dict, loss dict)."""
+        """nn.Module surface of the reference head (NCHW tensors, masks already softmaxed):
+        (flows dict, loss dict).  Plain torch, differentiable; not used by RCFModel's training step."""
         assert imgs.shape[1] == 2, "Other im_num not implemented"
         loss, (fw, bw, gt_fw, gt_bw) = self.flow_losses(masks, gt_fw_flows, gt_bw_flows, res_fw, res_bw)
 
@@ -141,16 +289,14 @@ class FlowAggregationHeadWithResidual(nn.Module):
                  "affine_flow": [vis(fw[3], bw[3])] if fw[3] is not None else []}
         return flows, loss
 
-    # ---------------------------------------------------------------- loss tail of forward_train
-    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I):
-        """Returns (losses, seed) -- seed(scale) puts d(scale*loss)/d logits, /d res into the Acts and
-        accumulates this head's parameter gradients."""
+    def _loss_and_grads_torch(self, model, logits, res, gfw, gbw, extra, B, I):
+        """Loss tail through torch autograd (only for configs with a compactness head)."""
         C = self.mask_layer
         with torch.enable_grad():
-            l_nchw = ops.nhwc_to_nchw(logits.t, C).requires_grad_(True)          # [B*I,C,h,w]
-            r_nchw = ops.nhwc_to_nchw(res.t, 4 * C).requires_grad_(True)          # [B,4C,h2,w2]
+            l_nchw = ops.nhwc_to_nchw(logits.t, C).requires_grad_(True)
+            r_nchw = ops.nhwc_to_nchw(res.t, 4 * C).requires_grad_(True)
             p = F.softmax(l_nchw.view(B, I, C, *l_nchw.shape[-2:]), dim=2)
-            logp = F.log_softmax(p, dim=2)                                        # double softmax (rcf_model.py:434)
+            logp = F.log_softmax(p, dim=2)
             lf, _ = self.flow_losses(p, gfw, gbw, r_nchw[:, :2 * C], r_nchw[:, 2 * C:])
             losses = {"loss_warp_seg": lf["seg"]}
             loss = lf["seg"] * model.w_seg
@@ -158,11 +304,10 @@ class FlowAggregationHeadWithResidual(nn.Module):
                 le = -(p * logp).sum(dim=2).mean()
                 loss = loss + le * model.w_entropy
                 losses["loss_entropy"] = le
-            if model.compactness_head is not None:
-                lc = model.compactness_head.get_compactness_loss(p)
-                if lc is not None:
-                    losses["loss_compactness"] = lc
-                    loss = loss + lc * model.w_compactness
+            lc = model.compactness_head.get_compactness_loss(p)
+            if lc is not None:
+                losses["loss_compactness"] = lc
+                loss = loss + lc * model.w_compactness
             oc = getattr(model.args, "object_channel", None)
 
             def asym_mse(target, pred, wpos, wneg):
@@ -170,15 +315,13 @@ class FlowAggregationHeadWithResidual(nn.Module):
                 return (d.clamp(min=0) ** 2).mean() * wpos + (d.clamp(max=0) ** 2).mean() * wneg
             if model.w_pl > 0:
                 t = extra["pl_masks"]
-                if model.pl_mask_pos_th != -1:
-                    t = (t > model.pl_mask_pos_th).float()
+                t = (t > model.pl_mask_pos_th).float() if model.pl_mask_pos_th != -1 else t
                 lp = asym_mse(t, p[:, :, oc], model.pl_pos_weight, model.pl_neg_weight)
                 losses["loss_pl"] = lp
                 loss = loss + lp * model.w_pl
             if model.w_crf > 0:
                 t = extra["crf_masks"]
-                if model.crf_mask_pos_th != -1.:
-                    t = (t > model.crf_mask_pos_th).float()
+                t = (t > model.crf_mask_pos_th).float() if model.crf_mask_pos_th != -1. else t
                 lcrf = asym_mse(t, p[:, :, oc], model.crf_pos_weight, model.crf_neg_weight)
                 losses["loss_crf"] = lcrf
                 loss = loss + lcrf * model.w_crf
@@ -187,7 +330,6 @@ class FlowAggregationHeadWithResidual(nn.Module):
         losses["loss"] = loss.detach()
 
         def seed(scale):
-            # called from inside autograd's backward (grad mode off): scale through grad_outputs
             grads = torch.autograd.grad(loss, [l_nchw, r_nchw] + params, allow_unused=True,
                                         grad_outputs=torch.as_tensor(scale, dtype=loss.dtype, device=loss.device))
             logits.grad = ops.nchw_to_nhwc(grads[0].contiguous(), logits.t.shape[3])

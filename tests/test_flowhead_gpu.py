@@ -1,0 +1,103 @@
+"""GPU parity of the hand-written flow head (csrc/flowhead.hip) against the REFERENCE's own outputs and
+gradients (tests/golden/head_*.npz): piecewise-constant + free residual, affine, quadratic affine and
+the outlier-robust loss."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import rcf_amd
+from rcf_amd import ops, synth
+from rcf_amd.layers import Act
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def to_nhwc(x, cpad=None):
+    return ops.nchw_to_nhwc(torch.from_numpy(np.ascontiguousarray(x)).to(DEV), cpad)
+
+
+@pytest.mark.parametrize("tag", ["head_free", "head_affine", "head_affine_quad", "head_free_robust"])
+def test_flow_head_vs_reference_golden(tag, golden_dir, report):
+    fx = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, C, h, w = (int(fx[k]) for k in ("B", "C", "h", "w"))
+    head = rcf_amd.FlowAggregationHeadWithResidual(
+        args=None, create_flownet=True, mask_layer=C, mask_size=(h, w), clamp_flow_t=20.,
+        free_residual=not bool(fx["affine"]), free_residual_with_affine=bool(fx["affine"]),
+        free_residual_with_affine_quadratic=bool(fx["quadratic"]), allow_residual_resize=True,
+        outlier_robust_loss=bool(fx["robust"]))
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=11).items()})
+    head = head.to(DEV)
+    model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.0, w_pl=0, w_crf=0, compactness_head=None,
+                                  args=types.SimpleNamespace(object_channel=None))
+    logits = Act(to_nhwc(fx["logits"].reshape(B * 2, C, h, w)))                 # n = b*2 + i
+    res = Act(to_nhwc(np.concatenate([fx["rfw"], fx["rbw"]], axis=1)))
+    gfw, gbw = torch.from_numpy(fx["gfw"]).to(DEV), torch.from_numpy(fx["gbw"]).to(DEV)
+    for p in head.parameters():
+        p.grad = None
+    losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {}, B, 2)
+    seed(1.0)
+    e = {"seg": rel(float(losses["loss_warp_seg"]), float(fx["seg"]))}
+    e["dlogits"] = rel(ops.nhwc_to_nchw(logits.grad, C).cpu().numpy().reshape(B, 2, C, h, w), fx["dlogits"])
+    dres = ops.nhwc_to_nchw(res.grad).cpu().numpy()
+    e["dres_fw"], e["dres_bw"] = rel(dres[:, :2 * C], fx["dres_fw"]), rel(dres[:, 2 * C:], fx["dres_bw"])
+    for n, p in head.named_parameters():
+        e["d" + n] = rel(p.grad.cpu().contiguous().numpy(), fx["dparam_" + n.replace(".", "_")])
+    report(f"flow head {tag}: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    # the robust loss has an unbounded second derivative near |d| -> 0: its gradients are conditioned worse
+    tol = 2e-3 if bool(fx["robust"]) else 2e-4
+    assert e["seg"] < 1e-5
+    assert max(v for k, v in e.items() if k != "seg") < tol, e
+
+
+def test_flow_head_entropy_and_targets_vs_torch(report):
+    """entropy (double softmax) and pl / crf target terms: HIP tail vs torch autograd of the same formulas"""
+    import torch.nn.functional as F
+    g = np.random.Generator(np.random.PCG64(5))
+    B, C, h, w = 2, 4, 20, 28
+    head = rcf_amd.FlowAggregationHeadWithResidual(args=None, create_flownet=True, mask_layer=C, mask_size=(h, w),
+                                                   clamp_flow_t=20., free_residual=True, allow_residual_resize=True).to(DEV)
+    lg = g.normal(0, 2, size=(B * 2, C, h, w)).astype(np.float32)
+    rs = g.normal(0, 6, size=(B, 4 * C, h, w)).astype(np.float32)
+    gfw = torch.from_numpy(g.normal(0, 8, size=(B, 1, 2, h, w)).astype(np.float32)).to(DEV)
+    gbw = torch.from_numpy(g.normal(0, 8, size=(B, 1, 2, h, w)).astype(np.float32)).to(DEV)
+    pl = torch.from_numpy(g.random((B, 2, h, w)).astype(np.float32)).to(DEV)
+    crf = torch.from_numpy((g.random((B, 2, h, w)) > 0.5).astype(np.float32)).to(DEV)
+    model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.05, w_pl=3.0, pl_pos_weight=2.0, pl_neg_weight=1.0,
+                                  pl_mask_pos_th=0.35, w_crf=10.0, crf_pos_weight=2.0, crf_neg_weight=1.0,
+                                  crf_mask_pos_th=-1.0, compactness_head=None,
+                                  args=types.SimpleNamespace(object_channel=2))
+    logits, res = Act(to_nhwc(lg)), Act(to_nhwc(rs))
+    for p in head.parameters():
+        p.grad = None
+    losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {"pl_masks": pl, "crf_masks": crf}, B, 2)
+    seed(0.5)                                           # an upstream scale, like loss.backward(gradient=0.5)
+    # torch reference of the same tail
+    l = torch.from_numpy(lg).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rs).to(DEV).requires_grad_(True)
+    p = F.softmax(l.view(B, 2, C, h, w), dim=2)
+    lf, _ = head.flow_losses(p, gfw, gbw, r[:, :2 * C], r[:, 2 * C:])
+    ent = -(p * F.log_softmax(p, dim=2)).sum(dim=2).mean()
+
+    def asym(t, pred, wp, wn):
+        d = t - pred
+        return (d.clamp(min=0) ** 2).mean() * wp + (d.clamp(max=0) ** 2).mean() * wn
+    lpl = asym((pl > 0.35).float(), p[:, :, 2], 2.0, 1.0)
+    lcrf = asym(crf, p[:, :, 2], 2.0, 1.0)
+    total = lf["seg"] + 0.05 * ent + 3.0 * lpl + 10.0 * lcrf
+    gl, gr = torch.autograd.grad(total * 0.5, [l, r])
+    e = {"loss": rel(float(losses["loss"]), float(total)), "entropy": rel(float(losses["loss_entropy"]), float(ent)),
+         "pl": rel(float(losses["loss_pl"]), float(lpl)), "crf": rel(float(losses["loss_crf"]), float(lcrf)),
+         "dlogits": rel(ops.nhwc_to_nchw(logits.grad, C).cpu().numpy(), gl.cpu().numpy()),
+         "dres": rel(ops.nhwc_to_nchw(res.grad).cpu().numpy(), gr.cpu().numpy())}
+    report("flow head entropy/targets: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert max(e.values()) < 2e-4, e
