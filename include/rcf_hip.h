@@ -52,6 +52,10 @@ size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* tuning knob for A/B measurements of the conv kernels: bit0 K-step 32, bit1 row-major LDS tiles;
+ * -1 restores the built-in default.  Results are identical up to fp32 summation order. */
+int rcf_conv_set_variant(int variant);
+
 /* ---- batch norm (training), fused ReLU / residual add / Dropout2d channel scale -----------------
  * Replaces (Sync)BatchNorm in models/resnet.py:159-162 and mmcv ConvModule's norm, the ReLU and
  * `out += identity` of models/resnet.py:268-300, and nn.Dropout2d of models/decode_head.py:84-85.

@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 16;   // K-step of the weight-gradient kernel
 
 struct IgemmParams {
     const float *A;      // source activations (x for fwd, dy for dgrad)
@@ -44,14 +44,18 @@ struct IgemmParams {
     float slope;
     int beta;
     int mtiles, ntiles;
+    unsigned cs_magic, s_magic;   // floor(2^32/d)+1 for d = Cs, S (exact k/d for k*d < 2^32; 0 when d == 1)
 };
 
-template <int MR, int NR>
+__device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
+
+// K-major LDS tiles (X[k][ld]): operand fetch is one conflict-free ds_read_b32 per K=2 MFMA.
+template <int MR, int NR, int BKT>
 __device__ __forceinline__ void mma_tile(const float *__restrict__ As, const float *__restrict__ Bs, int lda,
                                          int ldb, int wm, int wn, int lane, f32x16 (&acc)[MR][NR]) {
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < BKT / 2; ++kk) {
         const int krow = 2 * kk + kh;
         float a[MR], b[NR];
 #pragma unroll
@@ -66,13 +70,53 @@ __device__ __forceinline__ void mma_tile(const float *__restrict__ As, const flo
     }
 }
 
+// Row-major A tile (A[row][BKT+4]): one ds_read_b128 per lane feeds FOUR K=2 MFMAs -- lanes 0-31 hold
+// k = 8g..8g+3, lanes 32-63 k = 8g+4..8g+7 of their row, and MFMA e of the group contracts the pair
+// {8g+e, 8g+4+e}.  Any pairing of k is valid as long as B uses the same one.  B is either row-major
+// too (B_RM, forward weights) or K-major (dgrad weights: ds_read_b32 at row 8g + 4*kh + e).
+template <int MR, int NR, int BKT, bool B_RM>
+__device__ __forceinline__ void mma_tile_rm(const float *__restrict__ As, const float *__restrict__ Bs, int ldb,
+                                            int wm, int wn, int lane, f32x16 (&acc)[MR][NR]) {
+    constexpr int LDK = BKT + 4;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < BKT / 8; ++g) {
+        f32x4 av[MR], bv[NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+            av[mr] = *reinterpret_cast<const f32x4 *>(As + (wm * 32 * MR + mr * 32 + l31) * LDK + g * 8 + kh * 4);
+        if (B_RM) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                bv[nr] = *reinterpret_cast<const f32x4 *>(Bs + (wn * 32 * NR + nr * 32 + l31) * LDK + g * 8 + kh * 4);
+        } else {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[nr][e] = Bs[(g * 8 + kh * 4 + e) * ldb + wn * 32 * NR + nr * 32 + l31];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][e], bv[nr][e], acc[mr][nr], 0, 0, 0);
+    }
+}
+
 // BMODE 0: B[j][k], k contiguous (forward: w[co][rs*Cin + c]).
 // BMODE 1: B[k = rs*Cs + kc][j], j contiguous (dgrad: w[co = kc][rs][c = j]).
-template <int MR, int NR, int BMODE>
+// BKT: K-step (16 or 32).  RM: row-major LDS tiles for the k-contiguous operands (A always, B in BMODE 0).
+// STRIDED: dgrad of a stride>1 conv (taps must also pass a divisibility test).
+template <int MR, int NR, int BMODE, int BKT, bool RM, bool STRIDED>
 __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
     constexpr int BM = 64 * MR, BN = 64 * NR;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int STAGE = BK * (LDA + LDB);
+    constexpr int LDA = BM + 4, LDB = BN + 4, LDK = BKT + 4;
+    constexpr bool B_RM = RM && BMODE == 0;
+    constexpr int A_SIZE = RM ? BM * LDK : BKT * LDA;
+    constexpr int B_SIZE = B_RM ? BN * LDK : BKT * LDB;
+    constexpr int STAGE = A_SIZE + B_SIZE;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int bid = blockIdx.x;
@@ -87,99 +131,116 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- A loader state: thread owns rows arow + 64*i, K-quad kq
-    const int kq = tid & 3, arow = tid >> 2;
-    long abase[MR];
-    int ay[MR], ax[MR];
+    // ---- loader geometry for k-contiguous operands: TPR threads cover one row's BKT floats
+    constexpr int TPR = BKT / 4, ROWS = 256 / TPR;
+    constexpr int A_PASS = BM / ROWS, B_PASS0 = BN / ROWS;
+    const int kq = tid % TPR, arow = tid / TPR;
+    const float *arowp[A_PASS];      // STRIDED: image base; else pointer of tap (0,0) of the row (may be out of range)
+    int ay[A_PASS], ax[A_PASS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        const int m = m0 + arow + 64 * i;
+    for (int i = 0; i < A_PASS; ++i) {
+        const int m = m0 + arow + ROWS * i;
         if (m < p.M) {
             const int n = m / HoWo;
             const int pix = m - n * HoWo;
             const int y = pix / p.Wo;
             const int x = pix - y * p.Wo;
-            abase[i] = (long)n * p.a_img_stride;
             ay[i] = y * p.up + p.off;
             ax[i] = x * p.up + p.off;
+            arowp[i] = p.A + (long)n * p.a_img_stride + (STRIDED ? 0L : ((long)ay[i] * p.Ws + ax[i]) * p.a_pitch);
         } else {
-            abase[i] = 0;
+            arowp[i] = p.A;
             ay[i] = -(1 << 28);
             ax[i] = -(1 << 28);
         }
     }
-    // ---- B loader state
-    constexpr int BTPR = BN / 4;            // threads per k-row in BMODE 1
-    constexpr int BROWS = 256 / BTPR;       // k-rows per pass in BMODE 1
+    // ---- BMODE 1 loader geometry (j-contiguous weights)
+    constexpr int BTPR = BN / 4, BROWS = 256 / BTPR, B_PASS1 = BKT / BROWS;
+    constexpr int B_PASS = BMODE == 0 ? B_PASS0 : B_PASS1;
     const int bjq = tid % BTPR, bkr = tid / BTPR;
 
-    f32x4 ra[MR], rb[NR];
+    f32x4 ra[A_PASS], rb[B_PASS];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // Branch-free loader: an out-of-image / out-of-range tap reads the (always valid) buffer base and is
+    // masked to zero, so the whole K-step is ONE basic block and the scheduler can slide the address
+    // arithmetic under the MFMAs.  k -> (r, s, c) by multiply-high with precomputed magics.
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + kq * 4;
+        const int k = kt * BKT + kq * 4;
         const bool kv = k < p.K;
-        const int rs = kv ? k / p.Cs : 0;
+        const int rs = fast_div(k, p.cs_magic);
         const int c = k - rs * p.Cs;
-        const int r = rs / p.S;
+        const int r = fast_div(rs, p.s_magic);
         const int s = rs - r * p.S;
+        const int dy = r * p.step, dx = s * p.step;
+        const long tapoff = ((long)dy * p.Ws + dx) * p.a_pitch + c;
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            int ty = ay[i] + r * p.step, tx = ax[i] + s * p.step;
-            bool v = kv && ty >= 0 && tx >= 0;
-            if (p.div > 1) {
-                v = v && (ty % p.div == 0) && (tx % p.div == 0);
+        for (int i = 0; i < A_PASS; ++i) {
+            int ty = ay[i] + dy, tx = ax[i] + dx;
+            bool v;
+            const float *src;
+            if (STRIDED) {
+                v = kv && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);
                 ty /= p.div;
                 tx /= p.div;
-            }
-            v = v && ty < p.Hs && tx < p.Ws;
-            if (v) {
-                const float *src = p.A + abase[i] + ((long)ty * p.Ws + tx) * p.a_pitch + c;
-                ra[i] = *reinterpret_cast<const f32x4 *>(src);
+                v = v && ty < p.Hs && tx < p.Ws;
+                src = arowp[i] + ((long)ty * p.Ws + tx) * p.a_pitch + c;
             } else {
-                ra[i] = zero4;
+                v = kv && (unsigned)ty < (unsigned)p.Hs && (unsigned)tx < (unsigned)p.Ws;
+                src = arowp[i] + tapoff;
             }
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? src : p.A);
+            ra[i] = v ? val : zero4;
         }
         if (BMODE == 0) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int j = n0 + arow + 64 * i;
-                if (kv && j < p.Ncol)
-                    rb[i] = *reinterpret_cast<const f32x4 *>(p.Bw + (long)j * p.ldb + k);
-                else
-                    rb[i] = zero4;
+            for (int i = 0; i < B_PASS; ++i) {
+                const int j = n0 + arow + ROWS * i;
+                const bool v = kv && j < p.Ncol;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)j * p.ldb + k : p.Bw);
+                rb[i] = v ? val : zero4;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int kb = kt * BK + bkr + i * BROWS;
+            for (int i = 0; i < B_PASS; ++i) {
+                const int kb = kt * BKT + bkr + i * BROWS;
                 const int j = n0 + bjq * 4;
-                if (kb < p.K && j < p.Ncol) {
-                    const int rsb = kb / p.Cs;
-                    const int kc = kb - rsb * p.Cs;
-                    rb[i] = *reinterpret_cast<const f32x4 *>(p.Bw + (long)kc * p.ldb + (long)rsb * p.Ncol + j);
-                } else {
-                    rb[i] = zero4;
-                }
+                const bool v = kb < p.K && j < p.Ncol;
+                const int rsb = fast_div(kb, p.cs_magic);
+                const int kc = kb - rsb * p.Cs;
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)kc * p.ldb + (long)rsb * p.Ncol + j : p.Bw);
+                rb[i] = v ? val : zero4;
             }
         }
     };
     auto store_tile = [&](int buf) {
         float *As = smem + buf * STAGE;
-        float *Bs = As + BK * LDA;
+        float *Bs = As + A_SIZE;
+        if (RM) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) As[(kq * 4 + e) * LDA + arow + 64 * i] = ra[i][e];
-        if (BMODE == 0) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(kq * 4 + e) * LDB + arow + 64 * i] = rb[i][e];
+            for (int i = 0; i < A_PASS; ++i)
+                *reinterpret_cast<f32x4 *>(As + (arow + ROWS * i) * LDK + kq * 4) = ra[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < NR; ++i)
+            for (int i = 0; i < A_PASS; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[(kq * 4 + e) * LDA + arow + ROWS * i] = ra[i][e];
+        }
+        if (BMODE == 0) {
+            if (B_RM) {
+#pragma unroll
+                for (int i = 0; i < B_PASS; ++i)
+                    *reinterpret_cast<f32x4 *>(Bs + (arow + ROWS * i) * LDK + kq * 4) = rb[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PASS; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Bs[(kq * 4 + e) * LDB + arow + ROWS * i] = rb[i][e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_PASS; ++i)
                 *reinterpret_cast<f32x4 *>(Bs + (bkr + i * BROWS) * LDB + bjq * 4) = rb[i];
         }
     };
@@ -192,17 +253,24 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
 
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT = (p.K + BKT - 1) / BKT;
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
+    // steady state is one straight-line block: loads of step t+1, MFMAs of step t, LDS stores of t+1
+    for (int kt = 0; kt < KT - 1; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        load_tile(kt + 1);
         const float *As = smem + cur * STAGE;
-        mma_tile<MR, NR>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+        if (RM) mma_tile_rm<MR, NR, BKT, B_RM>(As, As + A_SIZE, LDB, wm, wn, lane, acc);
+        else mma_tile<MR, NR, BKT>(As, As + A_SIZE, LDA, LDB, wm, wn, lane, acc);
+        store_tile(cur ^ 1);
         __syncthreads();
+    }
+    {
+        const float *As = smem + ((KT - 1) & 1) * STAGE;
+        if (RM) mma_tile_rm<MR, NR, BKT, B_RM>(As, As + A_SIZE, LDB, wm, wn, lane, acc);
+        else mma_tile<MR, NR, BKT>(As, As + A_SIZE, LDA, LDB, wm, wn, lane, acc);
     }
 
     // ---- epilogue: lane holds column (lane&31), rows (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -245,7 +313,9 @@ struct WgradParams {
 };
 
 // dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
-template <int MR, int NR>
+// SMALLC (Cin == 4, e.g. the zero-padded RGB stem): the taps become GEMM columns (j = rs*4 + c) instead of
+// grid.y, so a 7x7x4 filter is 196 useful columns rather than 49 launches of a 94 %-empty 64-wide tile.
+template <int MR, int NR, bool INCR, bool SMALLC>
 __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
     constexpr int BM = 64 * MR, BN = 64 * NR;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -253,9 +323,9 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
-    const int rs = blockIdx.y;
-    const int r = rs / p.S, s = rs - r * p.S;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int rs = SMALLC ? (j0 + (int)(threadIdx.x % (BN / 4)) * 4) / 4 : (int)blockIdx.y;   // SMALLC: this thread's tap
+    const int r = rs / p.S, s = rs - r * p.S;
     const long kbeg = (long)blockIdx.z * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
 
@@ -270,34 +340,54 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
 
     f32x4 ra[MR], rb[NR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // pixel (n, y, x) of each gathered row, advanced by BK per K-step (no divisions in the loop)
+    int pn[NR], py[NR], px_[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const long m = kbeg + bkr + i * BROWS;
+        pn[i] = (int)(m / HoWo);
+        const int pix = (int)(m - (long)pn[i] * HoWo);
+        py[i] = pix / p.Wo;
+        px_[i] = pix - py[i] * p.Wo;
+    }
+    const int co = i0 + aiq * 4, cc = j0 + bjq * 4;
+    const int ncols = SMALLC ? p.R * p.S * 4 : p.Cin;     // useful GEMM columns
+    const int xch = SMALLC ? 0 : cc;                      // channel offset inside the gathered pixel
+    const bool cov = co < p.Cout, ccv = cc < ncols;
+    // branch-free: invalid rows read the buffer base and are masked to zero
     auto load_tile = [&](long kt) {
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const long m = kbeg + kt * BK + akr + i * AROWS;
-            const int co = i0 + aiq * 4;
-            if (m < kend && co < p.Cout)
-                ra[i] = *reinterpret_cast<const f32x4 *>(p.DY + m * p.dy_pitch + co);
-            else
-                ra[i] = zero4;
+            const bool v = m < kend && cov;
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.DY + m * p.dy_pitch + co : p.DY);
+            ra[i] = v ? val : zero4;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const long m = kbeg + kt * BK + bkr + i * BROWS;
-            const int c = j0 + bjq * 4;
-            bool v = m < kend && c < p.Cin;
-            if (v) {
-                const int n = (int)(m / HoWo);
-                const int pix = (int)(m - (long)n * HoWo);
-                const int y = pix / p.Wo;
-                const int x = pix - y * p.Wo;
-                const int sy = y * p.stride - dy_off + r * p.dil;
-                const int sx = x * p.stride - dy_off + s * p.dil;
-                v = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-                if (v)
-                    rb[i] = *reinterpret_cast<const f32x4 *>(
-                        p.X + (((long)n * p.H + sy) * p.W + sx) * p.x_pitch + c);
+            const int sy = py[i] * p.stride - dy_off + r * p.dil;
+            const int sx = px_[i] * p.stride - dy_off + s * p.dil;
+            const bool v = m < kend && ccv && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(
+                v ? p.X + (((long)pn[i] * p.H + sy) * p.W + sx) * p.x_pitch + xch : p.X);
+            rb[i] = v ? val : zero4;
+            // advance to the row this thread gathers in the next K-step
+            if (INCR) {                       // Wo >= BK: at most one row wrap per K-step, as selects
+                px_[i] += BK;
+                const bool wx = px_[i] >= p.Wo;
+                px_[i] -= wx ? p.Wo : 0;
+                py[i] += wx ? 1 : 0;
+                const bool wy = py[i] == p.Ho;
+                py[i] = wy ? 0 : py[i];
+                pn[i] += wy ? 1 : 0;
+            } else {
+                const long mn = m + BK;
+                pn[i] = (int)(mn / HoWo);
+                const int pix = (int)(mn - (long)pn[i] * HoWo);
+                py[i] = pix / p.Wo;
+                px_[i] = pix - py[i] * p.Wo;
             }
-            if (!v) rb[i] = zero4;
         }
     };
     auto store_tile = [&](int buf) {
@@ -317,28 +407,32 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
 
-    const long KT = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    if (KT > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
+    // the launch plan guarantees every split owns at least one pixel (kend > kbeg)
+    const long KT = (kend - kbeg + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
-    for (long kt = 0; kt < KT; ++kt) {
+    for (long kt = 0; kt + 1 < KT; ++kt) {
         const int cur = (int)(kt & 1);
-        if (kt + 1 < KT) load_tile(kt + 1);
+        load_tile(kt + 1);
         const float *As = smem + cur * STAGE;
-        mma_tile<MR, NR>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+        mma_tile<MR, NR, BK>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
+        store_tile(cur ^ 1);
         __syncthreads();
+    }
+    {
+        const float *As = smem + (int)((KT - 1) & 1) * STAGE;
+        mma_tile<MR, NR, BK>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
     }
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const long row_pitch = (long)p.R * p.S * p.Cin;
     const int l31 = lane & 31, kh = lane >> 5;
+    const int rs_out = SMALLC ? 0 : (int)blockIdx.y;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int c = j0 + wn * 32 * NR + nr * 32 + l31;
-        if (c >= p.Cin) continue;
+        if (c >= ncols) continue;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int rbase = i0 + wm * 32 * MR + mr * 32 + 4 * kh;
@@ -346,7 +440,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int co = rbase + (e & 3) + 8 * (e >> 2);
                 if (co < p.Cout) {
-                    float *dst = out + co * row_pitch + (long)rs * p.Cin + c;
+                    float *dst = out + co * row_pitch + (long)rs_out * p.Cin + c;
                     float v = acc[mr][nr][e];
                     if (p.beta && gridDim.z == 1) v += *dst;
                     *dst = v;
@@ -379,20 +473,41 @@ int check_shape(const rcf_conv_shape *s) {
     return 0;
 }
 
-template <int BMODE>
-int launch_igemm(IgemmParams &p, hipStream_t st) {
+int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS.  -1: built-in default
+
+inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+
+template <int BMODE, int BKT, bool RM>
+int launch_igemm_v(IgemmParams &p, hipStream_t st) {
+    p.cs_magic = magic_of(p.Cs);
+    p.s_magic = magic_of(p.S);
+    if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
     const bool wide = p.Ncol > 64;
     const int BM = 128, BN = wide ? 128 : 64;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const int groups = rcf_cdiv(p.mtiles, 8);
     const dim3 grid((unsigned)(groups * 8 * p.ntiles));
-    if (wide)
-        hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE>), grid, dim3(256), 0, st, p);
+    if (BMODE == 1 && p.div > 1) {
+        if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
+    }
     RCF_LAUNCH_CHECK();
     return 0;
+}
+
+template <int BMODE>
+int launch_igemm(IgemmParams &p, hipStream_t st) {
+    const int v = g_conv_variant < 0 ? 0 : g_conv_variant;
+    switch (v & 3) {
+        case 1: return launch_igemm_v<BMODE, 32, false>(p, st);
+        case 2: return launch_igemm_v<BMODE, 16, true>(p, st);
+        case 3: return launch_igemm_v<BMODE, 32, true>(p, st);
+        default: return launch_igemm_v<BMODE, 16, false>(p, st);
+    }
 }
 
 struct WgradPlan {
@@ -401,12 +516,14 @@ struct WgradPlan {
 };
 WgradPlan plan_wgrad(const rcf_conv_shape *s) {
     WgradPlan pl;
+    const bool smallc = s->Cin == 4;
+    const int ncols = smallc ? s->R * s->S * 4 : s->Cin;
     pl.mr = s->Cout > 64 ? 2 : 1;
-    pl.nr = s->Cin > 64 ? 2 : 1;
+    pl.nr = ncols > 64 ? 2 : 1;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
-    pl.jtiles = rcf_cdiv(s->Cin, 64 * pl.nr);
+    pl.jtiles = rcf_cdiv(ncols, 64 * pl.nr);
     const long M = (long)s->N * s->Ho * s->Wo;
-    const long tiles = (long)pl.itiles * pl.jtiles * s->R * s->S;
+    const long tiles = (long)pl.itiles * pl.jtiles * (smallc ? 1 : s->R * s->S);
     long sk = (1536 + tiles - 1) / tiles;
     const long maxsk = M / 1024 > 1 ? M / 1024 : 1;
     if (sk > maxsk) sk = maxsk;
@@ -421,6 +538,12 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
 }
 
 }  // namespace
+
+/* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS */
+extern "C" int rcf_conv_set_variant(int v) {
+    g_conv_variant = v;
+    return 0;
+}
 
 extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                                   const rcf_conv_shape *s, int act, float slope, int beta, void *stream) {
@@ -475,11 +598,24 @@ extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, 
     p.x_pitch = s->x_pitch; p.dy_pitch = s->y_pitch;
     p.M = (long)s->N * s->Ho * s->Wo; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
-    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(s->R * s->S), (unsigned)pl.splitk);
-    if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
-    else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<2, 1>), grid, dim3(256), 0, st, p);
-    else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<1, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    const bool smallc = s->Cin == 4;
+    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(smallc ? 1 : s->R * s->S), (unsigned)pl.splitk);
+    const bool incr = s->Wo >= BK;
+#define RCF_WGRAD_LAUNCH(MRv, NRv)                                                                                \
+    do {                                                                                                          \
+        if (smallc) {                                                                                             \
+            if (incr) hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, true, true>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, true>), grid, dim3(256), 0, st, p);      \
+        } else {                                                                                                  \
+            if (incr) hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, true, false>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
+        }                                                                                                         \
+    } while (0)
+    if (pl.mr == 2 && pl.nr == 2) RCF_WGRAD_LAUNCH(2, 2);
+    else if (pl.mr == 2 && pl.nr == 1) RCF_WGRAD_LAUNCH(2, 1);
+    else if (pl.mr == 1 && pl.nr == 2) RCF_WGRAD_LAUNCH(1, 2);
+    else RCF_WGRAD_LAUNCH(1, 1);
+#undef RCF_WGRAD_LAUNCH
     RCF_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         const long n4 = p.split_stride / 4;

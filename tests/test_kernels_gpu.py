@@ -76,6 +76,31 @@ def test_conv_fwd_dgrad_wgrad(case, report):
     assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_acc < 2e-5
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_conv_kernel_variants(variant, report):
+    """the tuning variants of the implicit-GEMM kernel (K-step 16/32, K-major / row-major LDS) agree"""
+    from rcf_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.rcf_conv_set_variant(variant)
+        for case in (CONV_CASES[0], CONV_CASES[3], CONV_CASES[4], CONV_CASES[6], CONV_CASES[9], CONV_CASES[7]):
+            N, Cin, Cout, k, stride, pad, dil, H, W, has_bias, act = case
+            g = torch.Generator().manual_seed(variant * 100 + Cin)
+            x = torch.randn(N, Cin, H, W, generator=g)
+            w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+            xd, wd = x.double().requires_grad_(True), w.double()
+            yref = F.conv2d(xd, wd, None, stride=stride, padding=pad, dilation=dil)
+            dy = torch.randn(yref.shape, generator=g)
+            yref.backward(dy.double())
+            xg, wg = to_nhwc(x), cl_weight(w)
+            e_f = relerr(from_nhwc(ops.conv2d_fwd(xg, wg, None, stride, pad, dil)), yref)
+            e_d = relerr(from_nhwc(ops.conv2d_dgrad(to_nhwc(dy), wg, xg.shape, stride, pad, dil)), xd.grad)
+            report(f"conv variant {variant} {case}: fwd {e_f:.2e} dgrad {e_d:.2e}")
+            assert e_f < 2e-5 and e_d < 2e-5
+    finally:
+        lib.rcf_conv_set_variant(-1)
+
+
 def test_conv_large_wgrad_splitk(report):
     """enough pixels for the split-K path (workspace + deterministic reduce)"""
     g = torch.Generator().manual_seed(77)

@@ -36,6 +36,15 @@ def timeit(fn, iters=5):
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1]
+    for v in variants:
+        from rcf_amd import _lib
+        _lib.load().rcf_conv_set_variant(v)
+        print(f"==== conv variant {v} (bit0: BK=32, bit1: row-major LDS)")
+        run(N)
+
+
+def run(N):
     dev = "cuda:0"
     for name, Cin, Cout, k, stride, pad, dil, H, W in SHAPES:
         x = torch.randn(N, H, W, Cin, device=dev)

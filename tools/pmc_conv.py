@@ -1,0 +1,16 @@
+"""Runs one conv shape a few times (for rocprofv3 --pmc passes). usage: pmc_conv.py [fwd|dgrad|wgrad]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rcf_amd
+from rcf_amd import ops
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+N, Cin, Cout, H, W = 8, 512, 512, 60, 107
+x = torch.randn(N, H, W, Cin, device="cuda:0")
+w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0") * 0.05).contiguous(memory_format=torch.channels_last)
+y = ops.conv2d_fwd(x, w, None, 1, 4, 4)
+dy = torch.randn_like(y); dw = torch.zeros_like(w)
+for _ in range(3):
+    if which == "fwd": ops.conv2d_fwd(x, w, None, 1, 4, 4, out=y)
+    elif which == "dgrad": ops.conv2d_dgrad(dy, w, x.shape, 1, 4, 4, out=x)
+    else: ops.conv2d_wgrad(x, dy, w, dw, 1, 4, 4, beta=0)
+torch.cuda.synchronize()
