@@ -12,10 +12,12 @@
 //    atomicMin makes the bucket's representative the smallest slot => vertex numbering (hand-written
 //    3-kernel scan) is deterministic.  Blur neighbours are resolved ONCE into index lists instead of
 //    2 hash probes per vertex per axis per iteration.
-//  * per iteration: splat accumulates in 64-bit fixed point (2^-40) with integer atomics, so the sums
-//    are order independent: run-to-run bit-identical MAPs (the reference's float atomics are not);
-//    consecutive lanes hitting the same vertex are pre-reduced in the wavefront; 6 blur passes stream
-//    float4 vertex values; slice + Potts weight + softmax (+ MAP on the last iteration) are one kernel.
+//    The (pixel, vertex) entries are also grouped by vertex once (count -> scan -> fill: a CSR list).
+//  * per iteration: splat is a GATHER, one wavefront per vertex over its CSR list, accumulating in
+//    64-bit fixed point (2^-40) so the sum is independent of the list order: run-to-run bit-identical
+//    MAPs and no atomics at all in the iteration (the reference does 3 float atomics per entry per
+//    iteration); 6 blur passes stream float4 vertex values; slice + Potts weight + softmax (+ MAP on
+//    the last iteration) are one kernel.
 //  * persistent caller-owned workspace, all frames of a batch in every launch (grid.y = frame).
 //  Algorithmic bytes per iteration: 192*N + 348*L, L = lattice vertices.
 #include "rcf_common.h"
@@ -39,7 +41,9 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *slot_vid;         // [F][E]   scan scratch: vertex id of representative slots
     int *vrep;             // [F][E]   vertex -> representative slot
     int *nb;               // [F][E][2*(pd+1)] neighbour vertex ids (-1 = none), [axis][plus/minus]
-    long long *zacc;       // [F][E][4] fixed-point splat accumulators
+    int *cnt;              // [F][E]   entries per vertex, then fill cursor
+    int *off;              // [F][E]   CSR offsets (exclusive scan of cnt)
+    int2 *csr;             // [F][E]   (pixel, weight bits) grouped by vertex
     float4 *val0, *val1;   // [F][E]   ping-pong blurred values
     int *blocksum;         // [F][nblk+1]
     int *L;                // [F]      vertex counts
@@ -118,15 +122,16 @@ __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uin
         bary[pd + 1 - rank[i]] -= delta;
     }
     bary[0] = (float)(bary[0] + (1.0 + bary[pd + 1]));
-    const long base = (long)f * Lt.E + (long)p * (pd + 1);
+    // entries are stored remainder-major (e = r*N + p): every later pass is coalesced along the pixels
+    const long base = (long)f * Lt.E + p;
     for (int r = 0; r <= pd; r++) {
         short key[PD_MAX];
         for (int i = 0; i < pd; i++) {
             key[i] = (short)(rem0[i] + r);
             if (rank[i] > pd - r) key[i] = (short)(key[i] - (pd + 1));
         }
-        Lt.keys[base + r] = pack_key(key, pd);
-        Lt.weight[base + r] = bary[r];
+        Lt.keys[base + (long)r * Lt.N] = pack_key(key, pd);
+        Lt.weight[base + (long)r * Lt.N] = bary[r];
     }
 }
 
@@ -136,26 +141,65 @@ __device__ __forceinline__ void unpack_key(const uint4 &k, short *key) {
     key[4] = (short)(k.z & 0xffff);
 }
 
+// ---------------------------------------------------------------------------------- wavefront run helpers
+// Entries are laid out remainder-major (e = r*N + p), so the 64 lanes of a wavefront are 64 consecutive
+// pixels of one lattice remainder and long runs of lanes share a vertex.  `head` flags the
+// first lane of a run of equal items; run_head() / run_tail() give every lane its run's first / last lane.
+__device__ __forceinline__ int run_head(bool head, int lane) {
+    int seg = head ? lane : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int so = __shfl_up(seg, o, 64);
+        if (lane >= o && so > seg) seg = so;
+    }
+    return seg;
+}
+__device__ __forceinline__ int run_tail(bool tail, int lane) {
+    int t = tail ? lane : 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int to = __shfl_down(t, o, 64);
+        if (lane + o < 64 && to < t) t = to;
+    }
+    return t;
+}
+__device__ __forceinline__ long entry_of(long idx, int, int) { return idx; }
+
 // ---------------------------------------------------------------------------------- build: insert
 __global__ void __launch_bounds__(256) lattice_insert_kernel(Lattice Lt) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    if (e >= Lt.E) return;
+    const int lane = threadIdx.x & 63;
+    const bool live = idx < Lt.E;
+    const long e = live ? entry_of(idx, Lt.N, Lt.pd + 1) : 0;
     const uint4 *keys = Lt.keys + (long)f * Lt.E;
     int *entries = Lt.entries + (long)f * 2 * Lt.E;
-    const uint4 mine = keys[e];
-    short key[8];
-    unpack_key(mine, key);
-    const unsigned nb = (unsigned)(2 * Lt.E);
-    unsigned h = key_hash(key, Lt.pd) % nb;
-    for (;;) {
-        int cur = __hip_atomic_load(entries + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == -1) cur = atomicCAS(entries + h, -1, (int)e);
-        if (cur == -1 || key_eq(keys[cur], mine)) break;   // claimed, or bucket already holds my key
-        if (++h == nb) h = 0;
+    uint4 mine = live ? keys[e] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (unsigned)lane);
+    if (!live) mine.w = 1u + (unsigned)lane;                  // dead lanes never join a run
+    // only the first lane of a run of identical keys probes the table; e grows with the lane, so the run
+    // head also holds the smallest slot of the run
+    const uint4 prev = make_uint4(__shfl_up(mine.x, 1, 64), __shfl_up(mine.y, 1, 64), __shfl_up(mine.z, 1, 64),
+                                  __shfl_up(mine.w, 1, 64));
+    const bool head = lane == 0 || !(prev.x == mine.x && prev.y == mine.y && prev.z == mine.z && prev.w == mine.w);
+    const int seg = run_head(head, lane);
+    unsigned h = 0;
+    if (live && head) {
+        short key[8];
+        unpack_key(mine, key);
+        const unsigned nb = (unsigned)(2 * Lt.E);
+        h = key_hash(key, Lt.pd) % nb;
+        for (;;) {
+            int cur = __hip_atomic_load(entries + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == -1) cur = atomicCAS(entries + h, -1, (int)e);
+            if (cur == -1 || key_eq(keys[cur], mine)) break;   // claimed, or bucket already holds my key
+            if (++h == nb) h = 0;
+        }
+        // representative = smallest slot with this key; blocks run roughly in slot order, so most runs find a
+        // smaller slot already there and skip the atomic
+        if (__hip_atomic_load(entries + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int)e) atomicMin(entries + h, (int)e);
     }
-    atomicMin(entries + h, (int)e);                         // representative = smallest slot with this key
-    Lt.vid[(long)f * Lt.E + e] = (int)h;
+    h = (unsigned)__shfl((int)h, seg, 64);
+    if (live) Lt.vid[(long)f * Lt.E + e] = (int)h;
 }
 
 // ---------------------------------------------------------------------------------- build: numbering
@@ -254,7 +298,15 @@ __global__ void __launch_bounds__(256) lattice_entry_vid_kernel(Lattice Lt) {
     vid[e] = Lt.slot_vid[(long)f * Lt.E + rep];
 }
 
-// neighbour lists: what blur's two hash retrieves per axis resolve to (permutohedral_gpu.cu:392-407)
+// neighbour lists: what blur's two hash retrieves per axis resolve to (permutohedral_gpu.cu:392-407).
+// u = v + e_axis  <=>  v = u - e_axis, so only the '+' neighbour is probed; the same thread also writes v as
+// the '-' neighbour of u (each link has exactly one writer).
+__global__ void __launch_bounds__(256) neighbours_init_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long total = (long)Lt.L[f] * 2 * (Lt.pd + 1);
+    int *nb = Lt.nb + (long)f * Lt.E * 2 * (Lt.pd + 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) nb[i] = -1;
+}
 __global__ void __launch_bounds__(256) lattice_neighbours_kernel(Lattice Lt) {
     const int f = blockIdx.y;
     const int pd = Lt.pd, nax = pd + 1;
@@ -262,92 +314,177 @@ __global__ void __launch_bounds__(256) lattice_neighbours_kernel(Lattice Lt) {
     const uint4 *keys = Lt.keys + (long)f * Lt.E;
     const int *entries = Lt.entries + (long)f * 2 * Lt.E;
     const int *sv = Lt.slot_vid + (long)f * Lt.E;
+    int *nb = Lt.nb + (long)f * Lt.E * 2 * nax;
     const unsigned nbk = (unsigned)(2 * Lt.E);
-    const long total = Lf * nax * 2;
+    const long total = Lf * nax;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long v = i / (nax * 2);
-        const int rem = (int)(i - v * nax * 2);
-        const int axis = rem >> 1, sign = (rem & 1) ? -1 : 1;
+        const long v = i / nax;
+        const int axis = (int)(i - v * nax);
         short key[8];
         unpack_key(keys[Lt.vrep[(long)f * Lt.E + v]], key);
-        for (int k = 0; k < pd; k++) key[k] = (short)(key[k] + sign);
-        if (axis < pd) key[axis] = (short)(key[axis] - sign * (pd + 1));
+        for (int k = 0; k < pd; k++) key[k] = (short)(key[k] + 1);
+        if (axis < pd) key[axis] = (short)(key[axis] - (pd + 1));
         const uint4 want = pack_key(key, pd);
         unsigned h = key_hash(key, pd) % nbk;
-        int res = -1;
         for (;;) {
             const int s = entries[h];
             if (s == -1) break;
-            if (key_eq(keys[s], want)) { res = sv[s]; break; }
+            if (key_eq(keys[s], want)) {
+                const int u = sv[s];
+                nb[v * (2 * nax) + 2 * axis] = u;            // v's '+' neighbour
+                nb[(long)u * (2 * nax) + 2 * axis + 1] = (int)v;   // u's '-' neighbour
+                break;
+            }
             if (++h == nbk) h = 0;
         }
-        Lt.nb[((long)f * Lt.E + v) * (2 * nax) + rem] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------- build: CSR by vertex
+__global__ void __launch_bounds__(256) csr_count_kernel(Lattice Lt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const bool live = idx < Lt.E;
+    const long fb = (long)f * Lt.E;
+    const int v = live ? Lt.vid[fb + entry_of(idx, Lt.N, Lt.pd + 1)] : -1 - lane;
+    const int vp = __shfl_up(v, 1, 64), vn = __shfl_down(v, 1, 64);
+    const bool head = lane == 0 || vp != v, tail = lane == 63 || vn != v;
+    const int seg = run_head(head, lane);
+    if (live && tail) atomicAdd(Lt.cnt + fb + v, lane - seg + 1);     // one atomic per run of equal vertices
+}
+// exclusive scan of cnt over [0, E) (entries beyond L are zero): local pass, block totals in blocksum
+__global__ void __launch_bounds__(SCAN_BLOCK) csr_scan_local_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+    const int *cnt = Lt.cnt + (long)f * Lt.E;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = (base + i < Lt.E) ? cnt[base + i] : 0;
+        s += v[i];
+    }
+    int total;
+    int off = block_exclusive_scan(s, &total);
+    int *out = Lt.off + (long)f * Lt.E;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < Lt.E) out[base + i] = off;
+        off += v[i];
+    }
+    if (threadIdx.x == 0) Lt.blocksum[(long)f * (gridDim.x + 1) + blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) csr_scan_blocks_kernel(Lattice Lt, int nblk) {
+    const int f = blockIdx.x;
+    int *bs = Lt.blocksum + (long)f * (nblk + 1);
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += SCAN_BLOCK) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nblk ? bs[b] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int carry = carry_s;
+        if (b < nblk) bs[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+}
+// off += block offset; cnt is reset to serve as the fill cursor
+__global__ void __launch_bounds__(SCAN_BLOCK) csr_scan_apply_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const int add = Lt.blocksum[(long)f * (gridDim.x + 1) + blockIdx.x];
+    int *off = Lt.off + (long)f * Lt.E, *cnt = Lt.cnt + (long)f * Lt.E;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < Lt.E) { off[base + i] += add; cnt[base + i] = 0; }
+}
+__global__ void __launch_bounds__(256) csr_fill_kernel(Lattice Lt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const bool live = idx < Lt.E;
+    const long fb = (long)f * Lt.E;
+    const long e = live ? entry_of(idx, Lt.N, Lt.pd + 1) : 0;
+    const int v = live ? Lt.vid[fb + e] : -1 - lane;
+    const int vp = __shfl_up(v, 1, 64), vn = __shfl_down(v, 1, 64);
+    const bool head = lane == 0 || vp != v, tail = lane == 63 || vn != v;
+    const int seg = run_head(head, lane), tl = run_tail(tail, lane);
+    int base = 0;
+    if (live && tail) base = atomicAdd(Lt.cnt + fb + v, lane - seg + 1);   // the run reserves its slots at once
+    base = __shfl(base, tl, 64);
+    if (live) {
+        // payload in CSR order: (pixel, barycentric weight).  The order inside a vertex is free: the
+        // fixed-point sum of the gather does not depend on it.
+        const int pos = Lt.off[fb + v] + base + (lane - seg);
+        const int p = (int)(idx - (idx / Lt.N) * Lt.N);
+        Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + e]));
     }
 }
 
 // ---------------------------------------------------------------------------------- iteration
-__global__ void __launch_bounds__(256) zero_acc_kernel(Lattice Lt) {
-    const int f = blockIdx.y;
-    const long n = (long)Lt.L[f] * 2;     // 2 x 16 B per vertex
-    int4 *z = reinterpret_cast<int4 *>(Lt.zacc + (long)f * Lt.E * 4);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        z[i] = make_int4(0, 0, 0, 0);
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-// values (Q0*w, Q1*w, w) of every entry added to its vertex, in 2^-40 fixed point.  Lanes of a
-// wavefront that hold consecutive equal vertex ids are summed first (segmented shuffle scan).
-__global__ void __launch_bounds__(256) splat_kernel(Lattice Lt, const float *__restrict__ Q) {
+// splat as a gather over the CSR lists, accumulating (Q0*w, Q1*w, w) in 2^-40 fixed point (exact integer
+// adds: order independent) and writing the float4 vertex value directly.  A wavefront takes 64 vertices:
+// lists of up to SHORT entries are summed by their own lane (noise-like images: ~1 entry per vertex),
+// longer lists (smooth images: tens to thousands of entries) by the whole wavefront, one after another.
+constexpr int SHORT_LIST = 6;
+__device__ __forceinline__ void acc_entry(const int2 pw, const float *__restrict__ Qf, long long &a0, long long &a1,
+                                          long long &a2) {
+    const float wgt = __int_as_float(pw.y);
+    const float2 q = *reinterpret_cast<const float2 *>(Qf + (long)pw.x * MLAB);
+    a0 += __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
+    a1 += __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
+    a2 += __double2ll_rn((double)wgt * FIX_SCALE);
+}
+__device__ __forceinline__ float4 fixed_to_val(long long a0, long long a1, long long a2) {
+    return make_float4((float)((double)a0 * (1.0 / FIX_SCALE)), (float)((double)a1 * (1.0 / FIX_SCALE)),
+                       (float)((double)a2 * (1.0 / FIX_SCALE)), 0.f);
+}
+__global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q,
+                                                           float4 *__restrict__ out) {
     const int f = blockIdx.y;
-    const int nax = Lt.pd + 1;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over N*(pd+1), remainder-major
-    const long total = Lt.E;
-    // entry order: e' = r*N + p so that consecutive lanes are consecutive PIXELS of one remainder
-    int v = -1;
-    long long a0 = 0, a1 = 0, a2 = 0;
-    if (idx < total) {
-        const int r = (int)(idx / Lt.N);
-        const int p = (int)(idx - (long)r * Lt.N);
-        const long e = (long)f * Lt.E + (long)p * nax + r;
-        v = Lt.vid[e];
-        const float wgt = Lt.weight[e];
-        const float2 q = *reinterpret_cast<const float2 *>(Q + ((long)f * Lt.N + p) * MLAB);
-        a0 = __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
-        a1 = __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
-        a2 = __double2ll_rn((double)wgt * FIX_SCALE);
-    }
     const int lane = threadIdx.x & 63;
-    // segmented inclusive scan over CONTIGUOUS runs of equal v: seg = first lane of my run
-    const int vprev = __shfl_up(v, 1, 64);
-    int seg = (lane == 0 || vprev != v) ? lane : 0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int so = __shfl_up(seg, o, 64);
-        if (lane >= o && so > seg) seg = so;
+    const long Lf = Lt.L[f];
+    const long fb = (long)f * Lt.E;
+    const float *Qf = Q + (long)f * Lt.N * MLAB;
+    const int wpb = blockDim.x >> 6;
+    // vertices per wavefront: 64 when lists are short (every lane owns one), 8 when they are long (the
+    // wavefront walks them one after another, so fewer per wavefront = more wavefronts in flight)
+    const int chunk = (Lt.E <= 4 * Lf) ? 64 : 8;
+    for (long v0 = ((long)blockIdx.x * wpb + (threadIdx.x >> 6)) * chunk; v0 < Lf; v0 += (long)gridDim.x * wpb * chunk) {
+        const long v = v0 + lane;
+        int beg = 0, n = 0;
+        if (lane < chunk && v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
+        if (n > 0 && n <= SHORT_LIST) {
+            long long a0 = 0, a1 = 0, a2 = 0;
+            for (int i = 0; i < n; i++) acc_entry(Lt.csr[fb + beg + i], Qf, a0, a1, a2);
+            out[fb + v] = fixed_to_val(a0, a1, a2);
+        }
+        unsigned long long longm = __ballot(n > SHORT_LIST);
+        while (longm) {
+            const int j = __ffsll((long long)longm) - 1;
+            longm &= longm - 1;
+            const int bj = __shfl(beg, j, 64), nj = __shfl(n, j, 64);
+            long long a0 = 0, a1 = 0, a2 = 0;
+            for (int i = lane; i < nj; i += 64) acc_entry(Lt.csr[fb + bj + i], Qf, a0, a1, a2);
+            a0 = wave_sum_ll(a0);
+            a1 = wave_sum_ll(a1);
+            a2 = wave_sum_ll(a2);
+            if (lane == 0) out[fb + v0 + j] = fixed_to_val(a0, a1, a2);
+        }
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long b0 = __shfl_up(a0, o, 64), b1 = __shfl_up(a1, o, 64), b2 = __shfl_up(a2, o, 64);
-        if (lane - o >= seg) { a0 += b0; a1 += b1; a2 += b2; }
-    }
-    const int vnext = __shfl_down(v, 1, 64);
-    const bool tail = (lane == 63) || (vnext != v);
-    if (v >= 0 && tail) {
-        unsigned long long *z = reinterpret_cast<unsigned long long *>(Lt.zacc + ((long)f * Lt.E + v) * 4);
-        atomicAdd(z + 0, (unsigned long long)a0);
-        atomicAdd(z + 1, (unsigned long long)a1);
-        atomicAdd(z + 2, (unsigned long long)a2);
-    }
-}
-
-__device__ __forceinline__ float4 load_fixed(const long long *z) {
-    const longlong2 a = *reinterpret_cast<const longlong2 *>(z);
-    const long long c = z[2];
-    return make_float4((float)((double)a.x * (1.0 / FIX_SCALE)), (float)((double)a.y * (1.0 / FIX_SCALE)),
-                       (float)((double)c * (1.0 / FIX_SCALE)), 0.f);
 }
 
 // one blur pass along `axis`: new = 1/4 n+ + 1/2 me + 1/4 n-, missing neighbour = 0
-template <bool FROM_FIXED>
 __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const float4 *__restrict__ in,
                                                    float4 *__restrict__ out) {
     const int f = blockIdx.y;
@@ -356,16 +493,10 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const f
     const long fb = (long)f * Lt.E;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.x * blockDim.x) {
         const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb + v) * nax2 + 2 * axis);
-        float4 me, vp = make_float4(0, 0, 0, 0), vm = make_float4(0, 0, 0, 0);
-        if (FROM_FIXED) {
-            me = load_fixed(Lt.zacc + (fb + v) * 4);
-            if (n.x >= 0) vp = load_fixed(Lt.zacc + (fb + n.x) * 4);
-            if (n.y >= 0) vm = load_fixed(Lt.zacc + (fb + n.y) * 4);
-        } else {
-            me = in[fb + v];
-            if (n.x >= 0) vp = in[fb + n.x];
-            if (n.y >= 0) vm = in[fb + n.y];
-        }
+        const float4 me = in[fb + v];
+        float4 vp = make_float4(0, 0, 0, 0), vm = make_float4(0, 0, 0, 0);
+        if (n.x >= 0) vp = in[fb + n.x];
+        if (n.y >= 0) vm = in[fb + n.y];
         float4 o;
         o.x = 0.25f * vp.x + 0.5f * me.x + 0.25f * vm.x;
         o.y = 0.25f * vp.y + 0.5f * me.y + 0.25f * vm.y;
@@ -386,11 +517,11 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float4 *__
     if (p >= Lt.N) return;
     const int nax = Lt.pd + 1;
     const long fb = (long)f * Lt.E;
-    const long pe = fb + (long)p * nax;
     float s0 = 0, s1 = 0, sw = 0;
     for (int r = 0; r < nax; r++) {
-        const float wgt = Lt.weight[pe + r];
-        const float4 v = val[fb + Lt.vid[pe + r]];
+        const long pe = fb + (long)r * Lt.N + p;
+        const float wgt = Lt.weight[pe];
+        const float4 v = val[fb + Lt.vid[pe]];
         s0 += wgt * v.x;
         s1 += wgt * v.y;
         sw += wgt * v.z;
@@ -440,6 +571,12 @@ __global__ void __launch_bounds__(256) unary_from_label_kernel(const short *__re
 }
 
 // ---------------------------------------------------------------------------------- CRFHead prologue
+__device__ __forceinline__ unsigned to_u8(float v) {
+    v = v * 255.f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (unsigned)(uint8_t)v;                                      // truncation, like .type(torch.uint8)
+}
+// 4 pixels per thread: float4 loads from the three planes, 12 output bytes as three 32-bit stores
 __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restrict__ img,
                                                             const float *__restrict__ mask,
                                                             const float *__restrict__ mean3,
@@ -447,20 +584,34 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
                                                             uint8_t *__restrict__ rgb, unsigned *__restrict__ qmax,
                                                             int HW) {
     const int f = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     unsigned q = 0;
-    if (p < HW) {
+    if (p4 < HW) {
+        const bool full = (p4 + 3 < HW) && (HW % 4 == 0);
+        unsigned bytes[12];
+        for (int j = 0; j < 4; j++) {
+            const int p = p4 + j;
+            if (p >= HW) { bytes[3 * j] = bytes[3 * j + 1] = bytes[3 * j + 2] = 0; continue; }
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float v = img[((long)f * 3 + c) * HW + p];
-            if (unstd) v = v * std3[c] + mean3[c];
-            v = v * 255.f;
-            v = fminf(fmaxf(v, 0.f), 255.f);
-            rgb[((long)f * HW + p) * 3 + c] = (uint8_t)v;                 // truncation, like .type(torch.uint8)
+            for (int c = 0; c < 3; c++) {
+                float v = img[((long)f * 3 + c) * HW + p];
+                if (unstd) v = v * std3[c] + mean3[c];
+                bytes[3 * j + c] = to_u8(v);
+            }
+            float m = mask[(long)f * HW + p] * 255.f / crf_scale;
+            m = fminf(fmaxf(m, 0.f), 255.f);
+            q = max(q, (unsigned)(uint8_t)m);
         }
-        float m = mask[(long)f * HW + p] * 255.f / crf_scale;
-        m = fminf(fmaxf(m, 0.f), 255.f);
-        q = (unsigned)(uint8_t)m;
+        uint8_t *dst = rgb + ((long)f * HW + p4) * 3;
+        if (full) {
+            unsigned *d32 = reinterpret_cast<unsigned *>(dst);        // (f*HW + p4)*3 is a multiple of 4 bytes
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                d32[k] = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | (bytes[4 * k + 3] << 24);
+        } else {
+            for (int j = 0; j < 4 && p4 + j < HW; j++)
+                for (int c = 0; c < 3; c++) dst[3 * j + c] = (uint8_t)bytes[3 * j + c];
+        }
     }
     for (int o = 32; o > 0; o >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(qmax + f, q);
@@ -510,7 +661,9 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
     L.slot_vid = c.take<int>(FE);
     L.vrep = c.take<int>(FE);
     L.nb = c.take<int>(FE * 2 * (pd + 1));
-    L.zacc = c.take<long long>(FE * 4);
+    L.cnt = c.take<int>(FE);
+    L.off = c.take<int>(FE);
+    L.csr = c.take<int2>(FE);
     L.val0 = c.take<float4>(FE);
     L.val1 = c.take<float4>(FE);
     L.blocksum = c.take<int>((size_t)F * (scan_blocks(L.E) + 1));
@@ -551,7 +704,14 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     hipLaunchKernelGGL(lattice_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
     hipLaunchKernelGGL(lattice_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(lattice_entry_vid_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
     hipLaunchKernelGGL(lattice_neighbours_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    CK(hipMemsetAsync(L.cnt, 0, (size_t)F * L.E * sizeof(int), st));
+    hipLaunchKernelGGL(csr_count_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(csr_scan_local_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
+    hipLaunchKernelGGL(csr_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(csr_fill_kernel, ge, dim3(256), 0, st, L);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -559,16 +719,12 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
 // tmp-free filter + Potts + softmax epilogue for one potential
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
                   int first, int last, int write_map, hipStream_t st) {
-    const dim3 gv(1024, F), ge(rcf_cdiv(L.E, 256), F), gp(rcf_cdiv(L.N, 256), F);
-    hipLaunchKernelGGL(zero_acc_kernel, gv, dim3(256), 0, st, L);
-    hipLaunchKernelGGL(splat_kernel, ge, dim3(256), 0, st, L, Q);
+    const dim3 gv(1024, F), gp(rcf_cdiv(L.N, 256), F);
     float4 *a = L.val0, *b = L.val1;
+    hipLaunchKernelGGL(splat_gather_kernel, dim3(4096, F), dim3(256), 0, st, L, Q, a);
     for (int axis = 0; axis <= L.pd; axis++) {
-        if (axis == 0) hipLaunchKernelGGL((blur_kernel<true>), gv, dim3(256), 0, st, L, axis, (const float4 *)nullptr, a);
-        else {
-            hipLaunchKernelGGL((blur_kernel<false>), gv, dim3(256), 0, st, L, axis, (const float4 *)a, b);
-            float4 *t = a; a = b; b = t;
-        }
+        hipLaunchKernelGGL(blur_kernel, gv, dim3(256), 0, st, L, axis, (const float4 *)a, b);
+        float4 *t = a; a = b; b = t;
     }
     hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float4 *)a, unary, next, Qout, map, first, last,
                        write_map);
@@ -659,8 +815,8 @@ extern "C" int rcf_crf_prepare(const float *img_nchw, const float *mask, const f
     hipStream_t st = rcf_stream(stream);
     const int HW = H * W;
     CK(hipMemsetAsync(scratch, 0, batch * sizeof(uint32_t), st));
-    const dim3 g(rcf_cdiv(HW, 256), batch);
-    hipLaunchKernelGGL(prepare_image_kernel, g, dim3(256), 0, st, img_nchw, mask, mean3, std3, unstandardize, crf_scale,
+    const dim3 g(rcf_cdiv(HW, 256), batch), g4(rcf_cdiv(rcf_cdiv(HW, 4), 256), batch);
+    hipLaunchKernelGGL(prepare_image_kernel, g4, dim3(256), 0, st, img_nchw, mask, mean3, std3, unstandardize, crf_scale,
                        rgb_out, (unsigned *)scratch, HW);
     hipLaunchKernelGGL(prepare_unary_kernel, g, dim3(256), 0, st, mask, crf_scale, (const unsigned *)scratch, unary_out,
                        HW);
