@@ -110,9 +110,13 @@ def main():
     if rank == 0:
         n, flops, ms = prof["launches"], prof["flops"], prof["ms"]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload)
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and (B, H, W) == (8, 480, 854):
+            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         out["roofline"] = {"kernel": "igemm_conv_kernel<2,2,0> (forward implicit-GEMM conv, 128x128 tile)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None, "launches": n,
+                           "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "launches": n,
                            "avg_launch_ms": round(ms / max(n, 1), 4),
                            "flops_per_launch": round(flops / max(n, 1), 1)}
         # CRF ms/frame (second half of BASELINE's metric) -- 480x854, T iterations, batch of 8 frames
