@@ -77,8 +77,10 @@ int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_p
 /* eval-mode BN: same kernel with mean=running_mean, invstd from running_var */
 int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, float *invstd, void *stream);
 /* backward.  g = dy [* chan_scale] [* (y>0)];  sums2 = [sum g | sum g*xhat] (fp64).
- * After a data-parallel all-reduce of sums2:  dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count),
- * dgamma += sum_gx, dbeta += sum_g, and (if dres != NULL) dres (+)= g  (res_beta 0/1). */
+ * After a data-parallel all-reduce of sums2:  dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) with the
+ * GLOBAL sums and count; dgamma += sum_gx, dbeta += sum_g from sums2_local (this rank's sums before the
+ * all-reduce; NULL = sums2) because the gradient all-reduce adds the ranks later; and (if dres != NULL)
+ * dres (+)= g  (res_beta 0/1). */
 int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
                           int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
                           const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
@@ -86,8 +88,8 @@ int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_p
 int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y, int y_pitch,
                          float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta, long rows, int C,
                          const float *mean, const float *invstd, const float *gamma, int relu,
-                         const float *chan_scale, long rows_per_image, const double *sums2, double count,
-                         float *dgamma, float *dbeta, void *stream);
+                         const float *chan_scale, long rows_per_image, const double *sums2,
+                         const double *sums2_local, double count, float *dgamma, float *dbeta, void *stream);
 
 /* ---- pooling / resize / layout ------------------------------------------------------------------
  * MaxPool2d(3,2,1): models/resnet.py:577.  argmax: uint8 window position (r*3+s), first max wins. */

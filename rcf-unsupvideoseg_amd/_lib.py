@@ -48,7 +48,7 @@ PROTOS = {
     "rcf_bn_bwd_reduce_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_int, P, c_long, P, P,
                                       c_size_t, P]),
     "rcf_bn_bwd_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P,
-                                     c_int, P, c_long, P, c_double, P, P, P]),
+                                     c_int, P, c_long, P, P, c_double, P, P, P]),
     "rcf_maxpool3x3s2_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_maxpool3x3s2_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_resize_bilinear_nhwc_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

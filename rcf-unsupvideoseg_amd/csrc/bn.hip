@@ -194,14 +194,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     int y_pitch, float *__restrict__ dx, int dx_pitch, float *__restrict__ dres, int dres_pitch, int res_beta,
     long rows, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
-    const double *__restrict__ sums2, double count, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
+    float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int CV = C / 4;
     const long total = rows * CV;
     const long step = (long)gridDim.x * blockDim.x;
     if (blockIdx.x == 0) {
+        // parameter gradients come from THIS rank's sums: the data-parallel gradient all-reduce adds the ranks
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dgamma) dgamma[c] += (float)sums2[C + c];
-            if (dbeta) dbeta[c] += (float)sums2[c];
+            if (dgamma) dgamma[c] += (float)sums2_param[C + c];
+            if (dbeta) dbeta[c] += (float)sums2_param[c];
         }
     }
     const float inv_count = (float)(1.0 / count);
@@ -351,15 +353,16 @@ extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *
                                     int y_pitch, float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta,
                                     long rows, int C, const float *mean, const float *invstd, const float *gamma,
                                     int relu, const float *chan_scale, long rows_per_image, const double *sums2,
-                                    double count, float *dgamma, float *dbeta, void *stream) {
+                                    const double *sums2_local, double count, float *dgamma, float *dbeta,
+                                    void *stream) {
     if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
         return RCF_EINVAL;
     if (relu && !y) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), dy,
                        dy_pitch, x, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch, res_beta, rows, C, mean,
-                       invstd, gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2, count, dgamma,
-                       dbeta);
+                       invstd, gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
+                       sums2_local ? sums2_local : sums2, count, dgamma, dbeta);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -157,7 +157,9 @@ class BatchNorm2d(nn.Module):
             def bwd():
                 dy = ya.take_grad()
                 s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale)
+                s2_local = None
                 if dist is not None and dist.on:
+                    s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them
                     dist.allreduce_sum(s2)
                 dres, rbeta = (None, 0)
                 if residual is not None and residual.needs_grad:
@@ -166,7 +168,7 @@ class BatchNorm2d(nn.Module):
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
-                                 dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale)
+                                 dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale, sums2_local=s2_local)
             tape.push(bwd)
         return ya
 

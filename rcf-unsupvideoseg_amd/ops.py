@@ -199,14 +199,14 @@ def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None):
 
 
 def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbeta, dx=None, dres=None, res_beta=0,
-                 chan_scale=None):
+                 chan_scale=None, sums2_local=None):
     rows, C = _rows(x), x.shape[3]
     if dx is None:
         dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
     call("rcf_bn_bwd_apply_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
          _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
-         _p(invstd), _p(gamma), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), float(count),
-         _p(dgamma), _p(dbeta), _stream())
+         _p(invstd), _p(gamma), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), _p(sums2_local),
+         float(count), _p(dgamma), _p(dbeta), _stream())
     return dx
 
 

@@ -1,0 +1,80 @@
+"""GPU, world_size 2 on ONE device (gloo carries the collectives; RCCL refuses two ranks per GPU): the
+data-parallel training step -- SyncBN statistics exchange + flat gradient all-reduce -- reproduces the
+single-process step on the global batch."""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W, B = 64, 96, 2
+
+
+def _setup():
+    sys.path.insert(0, ROOT)
+    import rcf_amd
+    from rcf_amd import config, synth
+    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=None)
+    m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    nb = synth.make_batch(B, H, W, config_id=1)
+    return rcf_amd, m, nb
+
+
+def _batch(nb, sl, dev):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
+    return {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rcf_amd, m, nb = _setup()
+    tr = rcf_amd.Trainer(m, device="cuda:0")
+    assert tr.world == world
+    per = B // world
+    losses = tr.step(_batch(nb, slice(rank * per, (rank + 1) * per), "cuda:0"))
+    torch.cuda.synchronize()
+    names = ["backbone2.layer3.2.conv2.weight", "backbone2.bn1.weight", "backbone2.layer4.0.bn3.bias",
+             "decode_head2.convs.0.bn.weight", "decode_head3.conv_seg.bias", "decode_head.flow_feat_after_agg.2.weight"]
+    named = dict(m.named_parameters())
+    q.put((rank, float(losses["loss"]), {n: (named[n].grad * (1.0 / world)).cpu().contiguous().numpy().ravel()[:512] for n in names},
+           m.backbone2.bn1.running_var.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_global_batch_step(report):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rcf_amd, m, nb = _setup()
+    tr = rcf_amd.Trainer(m, device="cuda:0")
+    losses = tr.step(_batch(nb, slice(0, B), "cuda:0"))
+    named = dict(m.named_parameters())
+    loss_dp = 0.5 * (res[0][1] + res[1][1])
+    e_loss = abs(loss_dp - float(losses["loss"])) / abs(float(losses["loss"]))
+    worst = 0.0
+    for n, g in res[0][2].items():
+        ref = named[n].grad.cpu().contiguous().numpy().ravel()[:512]
+        assert np.array_equal(g, res[1][2][n]), "ranks disagree after the all-reduce"
+        worst = max(worst, float(np.abs(g - ref).max() / (np.abs(ref).max() + 1e-30)))
+    e_rv = float(np.abs(res[0][3] - m.backbone2.bn1.running_var.cpu().numpy()).max())
+    report(f"2-rank DP vs single process: loss {e_loss:.2e} worst sampled grad {worst:.2e} running_var {e_rv:.2e}")
+    assert e_loss < 1e-5 and worst < 2e-2 and e_rv < 1e-6
