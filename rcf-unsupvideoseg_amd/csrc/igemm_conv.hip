@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
     const int bjq = tid % BTPR, bkr = tid / BTPR;
 
     f32x4 ra[A_PASS], rb[B_PASS];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    bool va[A_PASS], vb[B_PASS];        // validity of the loaded quads: the zero-masking happens at LDS-store
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};   // time, so the loads stay in flight under the MFMAs
 
     // Branch-free loader: an out-of-image / out-of-range tap reads the (always valid) buffer base and is
     // masked to zero, so the whole K-step is ONE basic block and the scheduler can slide the address
@@ -190,16 +191,16 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
                 v = kv && (unsigned)ty < (unsigned)p.Hs && (unsigned)tx < (unsigned)p.Ws;
                 src = arowp[i] + tapoff;
             }
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? src : p.A);
-            ra[i] = v ? val : zero4;
+            ra[i] = *reinterpret_cast<const f32x4 *>(v ? src : p.A);
+            va[i] = v;
         }
         if (BMODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_PASS; ++i) {
                 const int j = n0 + arow + ROWS * i;
                 const bool v = kv && j < p.Ncol;
-                const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)j * p.ldb + k : p.Bw);
-                rb[i] = v ? val : zero4;
+                rb[i] = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)j * p.ldb + k : p.Bw);
+                vb[i] = v;
             }
         } else {
 #pragma unroll
@@ -209,14 +210,18 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
                 const bool v = kb < p.K && j < p.Ncol;
                 const int rsb = fast_div(kb, p.cs_magic);
                 const int kc = kb - rsb * p.Cs;
-                const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)kc * p.ldb + (long)rsb * p.Ncol + j : p.Bw);
-                rb[i] = v ? val : zero4;
+                rb[i] = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)kc * p.ldb + (long)rsb * p.Ncol + j : p.Bw);
+                vb[i] = v;
             }
         }
     };
     auto store_tile = [&](int buf) {
         float *As = smem + buf * STAGE;
         float *Bs = As + A_SIZE;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) ra[i] = va[i] ? ra[i] : zero4;
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) rb[i] = vb[i] ? rb[i] : zero4;
         if (RM) {
 #pragma unroll
             for (int i = 0; i < A_PASS; ++i)
@@ -261,9 +266,13 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
     for (int kt = 0; kt < KT - 1; ++kt) {
         const int cur = kt & 1;
         load_tile(kt + 1);
+        // keep the global loads ABOVE the MFMAs (LLVM otherwise sinks them next to the LDS stores that consume
+        // them and exposes the HBM latency on every K-step)
+        __builtin_amdgcn_sched_barrier(0);
         const float *As = smem + cur * STAGE;
         if (RM) mma_tile_rm<MR, NR, BKT, B_RM>(As, As + A_SIZE, LDB, wm, wn, lane, acc);
         else mma_tile<MR, NR, BKT>(As, As + A_SIZE, LDA, LDB, wm, wn, lane, acc);
+        __builtin_amdgcn_sched_barrier(0);
         store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -339,6 +348,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
     const int dy_off = (p.pad);
 
     f32x4 ra[MR], rb[NR];
+    bool va[MR], vb[NR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // pixel (n, y, x) of each gathered row, advanced by BK per K-step (no divisions in the loop)
     int pn[NR], py[NR], px_[NR];
@@ -360,8 +370,8 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
         for (int i = 0; i < MR; ++i) {
             const long m = kbeg + kt * BK + akr + i * AROWS;
             const bool v = m < kend && cov;
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(v ? p.DY + m * p.dy_pitch + co : p.DY);
-            ra[i] = v ? val : zero4;
+            ra[i] = *reinterpret_cast<const f32x4 *>(v ? p.DY + m * p.dy_pitch + co : p.DY);
+            va[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -369,9 +379,9 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
             const int sy = py[i] * p.stride - dy_off + r * p.dil;
             const int sx = px_[i] * p.stride - dy_off + s * p.dil;
             const bool v = m < kend && ccv && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(
+            rb[i] = *reinterpret_cast<const f32x4 *>(
                 v ? p.X + (((long)pn[i] * p.H + sy) * p.W + sx) * p.x_pitch + xch : p.X);
-            rb[i] = v ? val : zero4;
+            vb[i] = v;
             // advance to the row this thread gathers in the next K-step
             if (INCR) {                       // Wo >= BK: at most one row wrap per K-step, as selects
                 px_[i] += BK;
@@ -394,9 +404,11 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
         float *As = smem + buf * STAGE;
         float *Bs = As + BK * LDA;
 #pragma unroll
-        for (int i = 0; i < MR; ++i) *reinterpret_cast<f32x4 *>(As + (akr + i * AROWS) * LDA + aiq * 4) = ra[i];
+        for (int i = 0; i < MR; ++i)
+            *reinterpret_cast<f32x4 *>(As + (akr + i * AROWS) * LDA + aiq * 4) = va[i] ? ra[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4 *>(Bs + (bkr + i * BROWS) * LDB + bjq * 4) = rb[i];
+        for (int i = 0; i < NR; ++i)
+            *reinterpret_cast<f32x4 *>(Bs + (bkr + i * BROWS) * LDB + bjq * 4) = vb[i] ? rb[i] : zero4;
     };
 
     f32x16 acc[MR][NR];
@@ -415,8 +427,10 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
     for (long kt = 0; kt + 1 < KT; ++kt) {
         const int cur = (int)(kt & 1);
         load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);      // loads stay above the MFMAs (see igemm_conv_kernel)
         const float *As = smem + cur * STAGE;
         mma_tile<MR, NR, BK>(As, As + BK * LDA, LDA, LDB, wm, wn, lane, acc);
+        __builtin_amdgcn_sched_barrier(0);
         store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -482,15 +496,22 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
     p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    const bool strided = BMODE == 1 && p.div > 1;
+    // tile: 128x64 for narrow outputs, 128x128 by default, 128x256 (8 accumulator tiles per wave: twice the
+    // MFMA work per barrier) when the output is wide and there are enough row tiles to fill the chip
     const bool wide = p.Ncol > 64;
-    const int BM = 128, BN = wide ? 128 : 64;
+    const bool xwide = (g_conv_variant >= 0 ? (g_conv_variant & 4) != 0 : false) && !strided && p.Ncol % 256 == 0 &&
+                       (long)rcf_cdiv(p.M, 128) * (p.Ncol / 256) >= 1536;
+    const int BM = 128, BN = xwide ? 256 : (wide ? 128 : 64);
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const int groups = rcf_cdiv(p.mtiles, 8);
     const dim3 grid((unsigned)(groups * 8 * p.ntiles));
-    if (BMODE == 1 && p.div > 1) {
+    if (strided) {
         if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
+    } else if (xwide) {
+        hipLaunchKernelGGL((igemm_conv_kernel<2, 4, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
     } else {
         if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
