@@ -78,6 +78,7 @@ class Conv2d(nn.Module):
         self.cin, self.cout, self.k = cin, cout, k
         self.stride, self.padding, self.dilation, self.act, self.slope = stride, padding, dilation, act, slope
         self.cin_pad = (cin + 3) // 4 * 4
+        self.cout_pad = (cout + 3) // 4 * 4
         w = torch.empty(cout, cin, k, k)
         if self.cin_pad == cin:
             w = w.contiguous(memory_format=torch.channels_last)
@@ -86,15 +87,31 @@ class Conv2d(nn.Module):
         nn.init.kaiming_normal_(self.weight, a=0, mode="fan_out", nonlinearity="relu")   # mmcv kaiming_init
 
     def _packed_weight(self):
-        if self.cin_pad == self.cin:
+        """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded."""
+        if self.cin_pad == self.cin and self.cout_pad == self.cout:
             return self.weight
-        # [Cout,Cin,R,S] contiguous is an "NCHW" tensor with N=Cout: the layout kernel pads C to 4
-        w = ops.nchw_to_nhwc(self.weight.detach().contiguous(), self.cin_pad)      # [Cout,R,S,4]
+        if self.cin_pad != self.cin:
+            # [Cout,Cin,R,S] contiguous is an "NCHW" tensor with N=Cout: the layout kernel pads C to 4
+            assert self.cout_pad == self.cout
+            w = ops.nchw_to_nhwc(self.weight.detach().contiguous(), self.cin_pad)      # [Cout,R,S,4]
+            return w.permute(0, 3, 1, 2)
+        # Cout not a multiple of 4 (e.g. 3 segments): rows are contiguous, so padding = prefix copy + zero rows
+        w = torch.zeros((self.cout_pad, self.k, self.k, self.cin), dtype=torch.float32, device=self.weight.device)
+        n = self.weight.numel()
+        ops.copy2d(self.weight.detach().permute(0, 2, 3, 1), n, w, n, 1, n)
         return w.permute(0, 3, 1, 2)
 
+    def _packed_bias(self):
+        if self.bias is None or self.cout_pad == self.cout:
+            return self.bias
+        b = torch.zeros(self.cout_pad, dtype=torch.float32, device=self.bias.device)
+        b[:self.cout].copy_(self.bias.detach())
+        return b
+
     def fwd(self, x, tape, out=None):
-        w = self._packed_weight()
-        y = ops.conv2d_fwd(x.t, w, self.bias, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
+        """Returns an Act with cout_pad channels (the padded ones are exactly zero)."""
+        w, b = self._packed_weight(), self._packed_bias()
+        y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
         ya = Act(y)
         if tape.enabled:
             def bwd():
@@ -102,17 +119,26 @@ class Conv2d(nn.Module):
                 if self.act:
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
                 if self.weight.requires_grad:
-                    if self.cin_pad == self.cin:
+                    if self.cin_pad == self.cin and self.cout_pad == self.cout:
                         ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
                                          self.dilation, beta=1)
                     else:
                         dwp = torch.empty_like(w)
                         ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0)
-                        dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), self.cin)          # [Cout,Cin,R,S]
                         g = _param_grad(self.weight)
-                        ops.copy2d(dw, dw.numel(), g, g.numel(), 1, dw.numel(), beta=1)
+                        if self.cin_pad != self.cin:
+                            dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), self.cin)      # [Cout,Cin,R,S]
+                            ops.copy2d(dw, dw.numel(), g, g.numel(), 1, dw.numel(), beta=1)
+                        else:
+                            n = g.numel()                                                   # prefix = real rows
+                            ops.copy2d(dwp.permute(0, 2, 3, 1), n, g.permute(0, 2, 3, 1), n, 1, n, beta=1)
                 if self.bias is not None and self.bias.requires_grad:
-                    ops.colsum(dy, _param_grad(self.bias), beta=1)
+                    if self.cout_pad == self.cout:
+                        ops.colsum(dy, _param_grad(self.bias), beta=1)
+                    else:
+                        db = torch.zeros(self.cout_pad, dtype=torch.float32, device=dy.device)
+                        ops.colsum(dy, db, beta=0)
+                        _param_grad(self.bias).add_(db[:self.cout])
                 if x.needs_grad:
                     gx, beta = x.grad_slot()
                     ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta)

@@ -199,3 +199,41 @@ def test_fullsize_480x854_vs_reference_golden(golden_dir, report):
     assert e_logit < lim_logit and e_mask < lim_mask and e_mean < TOL and mism == 0
     assert max(e_loss.values()) < TOL
     assert all(e_gn[k] < lim_gn[k] for k in e_gn), (e_gn, lim_gn)
+
+
+@pytest.mark.parametrize("variant", ["fbms", "stv2"])
+def test_other_dataset_configs_vs_oracle(variant, report):
+    """the two non-DAVIS stage-1 variants of the reference (configs/rcf_fbms59, configs/rcf_stv2):
+    3 segments + affine flow; single-map decode head at 1/8 resolution + compactness loss."""
+    import rcf_torch as orc
+    H, W, B = 64, 96, 2
+    if variant == "fbms":
+        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), mask_layer=3, dropout=0.0, affine=True, norm="BN")
+    else:
+        h8 = ((config.mask_size_for(H, W)[0] - 1) // 2 + 1, (config.mask_size_for(H, W)[1] - 1) // 2 + 1)
+        kw = config.stage1_model_kwargs(h8, dropout=0.0, affine=True, norm="BN")
+        kw["decode_head"]["allow_residual_resize"] = False
+        kw["decode_head2"].update(in_channels=2048, in_index=3)
+        kw["decode_head2"].pop("input_transform")
+        kw.update(compactness_head=dict(type="CompactnessHead", compact_channel=0), w_compactness=1.0)
+    kw.update(log_interval=10 ** 9, train_iter=1)
+
+    def build(cls, dev):
+        m = cls(_args(), **copy.deepcopy(kw))
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+        return m.to(dev)
+    hip, ora = build(rcf_amd.RCFModel, DEV), build(orc.RCFModel, "cpu")
+    tr = rcf_amd.Trainer(hip, device=DEV)
+    lh = tr.step(_batch(B, H, W, DEV))
+    ora.train()
+    lo = ora(_batch(B, H, W, "cpu"))
+    lo["loss"].backward()
+    e = {k: rel(float(lh[k]), float(lo[k])) for k in lo if k.startswith("loss")}
+    gn = lambda m, pre: sum(float(p.grad.double().pow(2).sum()) for n, p in m.named_parameters()
+                            if p.grad is not None and n.startswith(pre)) ** 0.5
+    for pre in ("decode_head2.", "decode_head.", "backbone2.layer4."):
+        e["gn " + pre] = rel(gn(hip, pre), gn(ora, pre))
+    report(f"{variant} config vs oracle: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert max(v for k, v in e.items() if k.startswith("loss")) < TOL
+    assert max(v for k, v in e.items() if k.startswith("gn")) < 5e-2      # affine + L1 kinks: ill-conditioned (see goldens)
