@@ -52,33 +52,40 @@ __device__ __forceinline__ Taps make_taps(float px, float py, int W, int H, int 
     return t;
 }
 
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte load, dword aligned
+
+// the two horizontal taps of a row are adjacent: one 8-byte load when both are inside the image
+__device__ __forceinline__ float row_taps(const float *__restrict__ row, const Taps &t, float w0, float w1) {
+    if (t.inx0 && t.inx1) {
+        const f32x2_a4 v = *reinterpret_cast<const f32x2_a4 *>(row + t.x0);
+        return v[0] * w0 + v[1] * w1;
+    }
+    float r = 0.f;
+    if (t.inx0) r += row[t.x0] * w0;
+    if (t.inx1) r += row[t.x0 + 1] * w1;
+    return r;
+}
 __device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps &t, int W) {
     const float ex = 1.f - t.wx, ey = 1.f - t.wy;
     float v = 0.f;
-    if (t.iny0) {
-        const float *row = plane + (long)t.y0 * W;
-        if (t.inx0) v += row[t.x0] * (ey * ex);
-        if (t.inx1) v += row[t.x0 + 1] * (ey * t.wx);
-    }
-    if (t.iny1) {
-        const float *row = plane + (long)(t.y0 + 1) * W;
-        if (t.inx0) v += row[t.x0] * (t.wy * ex);
-        if (t.inx1) v += row[t.x0 + 1] * (t.wy * t.wx);
-    }
+    if (t.iny0) v += row_taps(plane + t.y0 * W, t, ey * ex, ey * t.wx);
+    if (t.iny1) v += row_taps(plane + (t.y0 + 1) * W, t, t.wy * ex, t.wy * t.wx);
     return v;
 }
 
 __global__ void __launch_bounds__(256) flow_warp_kernel(const float *__restrict__ x, const float *__restrict__ flow,
                                                         float *__restrict__ out, int B, int C, int H, int W,
                                                         int pad_mode) {
-    const long HW = (long)H * W, total = (long)B * HW;
-    const long step = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const long b = i / HW, p = i - b * HW;
-        const int py = (int)(p / W), px = (int)(p - (long)py * W);
-        const float fx = flow[(b * 2) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
-        const Taps t = make_taps((float)px + fx, (float)py + fy, W, H, pad_mode);
-        for (int c = 0; c < C; ++c) out[(b * C + c) * HW + p] = sample(x + (b * C + c) * HW, t, W);
+    // grid = (pixel chunks, images): no 64-bit divisions on the hot path
+    const int HW = H * W;
+    const long b = blockIdx.y;
+    const float *fl = flow + b * 2 * HW;
+    const float *xb = x + b * C * HW;
+    float *ob = out + b * C * HW;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        const int py = p / W, px = p - py * W;
+        const Taps t = make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode);
+        for (int c = 0; c < C; ++c) ob[c * HW + p] = sample(xb + c * HW, t, W);
     }
 }
 
@@ -180,15 +187,14 @@ __global__ void __launch_bounds__(256) warp_l1_kernel(const float *__restrict__ 
                                                       const float *__restrict__ flow, const float *__restrict__ occ,
                                                       double *__restrict__ out, int B, int C, int H, int W,
                                                       int pad_mode) {
-    const long HW = (long)H * W, total = (long)B * HW;
-    const long step = (long)gridDim.x * blockDim.x;
+    const int HW = H * W;
+    const long b = blockIdx.y;
+    const float *fl = flow + b * 2 * HW;
     double s = 0, so = 0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const long b = i / HW, p = i - b * HW;
-        const int py = (int)(p / W), px = (int)(p - (long)py * W);
-        const float fx = flow[(b * 2) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
-        const Taps t = make_taps((float)px + fx, (float)py + fy, W, H, pad_mode);
-        const float o = occ ? occ[i] : 1.f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        const int py = p / W, px = p - py * W;
+        const Taps t = make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode);
+        const float o = occ ? occ[b * HW + p] : 1.f;
         float acc = 0.f;
         for (int c = 0; c < C; ++c) acc += fabsf(im1[(b * C + c) * HW + p] - sample(im2 + (b * C + c) * HW, t, W));
         s += (double)(acc * o);
@@ -250,7 +256,8 @@ __global__ void photometric_final_kernel(const double *__restrict__ sums, float 
 extern "C" int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W,
                                  int pad_mode, void *stream) {
     if (!x || !flow || !out || B <= 0 || C <= 0 || H < 2 || W < 2 || (pad_mode != 0 && pad_mode != 1)) return RCF_EINVAL;
-    hipLaunchKernelGGL(flow_warp_kernel, dim3(px_blocks((long)B * H * W)), dim3(256), 0, rcf_stream(stream), x, flow,
+    if ((long)H * W >= (1L << 30)) return RCF_EINVAL;
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(rcf_cdiv((long)H * W, 256), B), dim3(256), 0, rcf_stream(stream), x, flow,
                        out, B, C, H, W, pad_mode);
     RCF_LAUNCH_CHECK();
     return 0;
@@ -294,9 +301,10 @@ extern "C" int rcf_warp_l1_residual_f32(const float *im1, const float *im2, cons
     hipStream_t st = rcf_stream(stream);
     hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
-    long nb = ((long)B * H * W + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(warp_l1_kernel, dim3((unsigned)nb), dim3(256), 0, st, im1, im2, flow, occ, out, B, C, H, W,
+    long nb = ((long)H * W + 255) / 256;              // <= ~2048 blocks in total: each ends in two fp64 atomics
+    const long cap = 2048 / B > 1 ? 2048 / B : 1;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(warp_l1_kernel, dim3((unsigned)nb, B), dim3(256), 0, st, im1, im2, flow, occ, out, B, C, H, W,
                        pad_mode);
     RCF_LAUNCH_CHECK();
     return 0;
