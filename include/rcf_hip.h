@@ -184,20 +184,28 @@ typedef struct {
     float w_seg, w_entropy;
     int n_targets, target_channel;
     float t_wpos[2], t_wneg[2], t_weight[2], t_thresh[2];   /* t_thresh -1: soft target */
+    /* models/compactness_head.py:14-57 (GWM compactness of one channel); weight 0 = off */
+    float w_compact;
+    int compact_channel;
+    /* models/rcf_model.py:350-374 sharpen loss: mode 0 off, 1 KL to the sharpened (p^(1/T)) masks,
+     * 2 object-aware hinge on |p_obj - max other| (object channel = target_channel) */
+    float w_sharpen, t_sharpen;
+    int sharpen_mode;
 } rcf_flowhead_cfg;
 size_t rcf_flowhead_workspace_bytes(const rcf_flowhead_cfg *c);
 /* gt_fw / gt_bw [B][2][P] -> clamped flows (kept in the workspace) and flow4 NHWC [2B][P][4], the
  * zero-padded input of flow_feat_before_agg.0 */
 int rcf_flowhead_prepare_f32(const rcf_flowhead_cfg *c, const float *gt_fw, const float *gt_bw, float *flow4,
                              void *workspace, size_t workspace_bytes, void *stream);
-/* losses_out[5] = seg_fw, seg_bw, entropy, target0, target1 (unweighted means).  masks_out [2B][C][P] and
+/* losses_out[8] = seg_fw, seg_bw, entropy, target0, target1, compactness, sharpen, 0 (unweighted means).  masks_out [2B][C][P] and
  * the four flow planes [2B][2][P] (overall, aggregated, residual adjustment, affine) are optional. */
 int rcf_flowhead_fwd_f32(const rcf_flowhead_cfg *c, const float *logits, const float *feat, const float *residual,
                          const float *W1, const float *b1, const float *W2, const float *b2, const float *target0,
                          const float *target1, float *losses_out, float *masks_out, float *flow_pred,
                          float *flow_agg, float *flow_adj, float *flow_aff, void *workspace, size_t workspace_bytes,
                          void *stream);
-/* gradients of grad_scale * (w_seg*seg + w_entropy*entropy + sum t_weight*target): dlogits (same layout as
+/* gradients of grad_scale * (w_seg*seg + w_entropy*entropy + sum t_weight*target + w_compact*compactness +
+ * w_sharpen*sharpen): dlogits (same layout as
  * logits, written), dresidual [B][P][4C] (written), dfeat [2B][P][64] = gradient w.r.t. the PRE-activation of
  * the second flow conv (written); dW1/db1/dW2/db2 accumulate. */
 int rcf_flowhead_bwd_f32(const rcf_flowhead_cfg *c, const float *feat, const float *residual, const float *W1,

@@ -25,7 +25,9 @@ class FlowHeadCfg(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "C", "h", "w", "logits_pitch", "nf", "D", "robust", "tanh_residual")] + \
                [(n, c_float) for n in ("eps", "q", "clamp_t", "res_scale", "div_coeff", "w_seg", "w_entropy")] + \
                [("n_targets", c_int), ("target_channel", c_int)] + \
-               [(n, c_float * 2) for n in ("t_wpos", "t_wneg", "t_weight", "t_thresh")]
+               [(n, c_float * 2) for n in ("t_wpos", "t_wneg", "t_weight", "t_thresh")] + \
+               [("w_compact", c_float), ("compact_channel", c_int), ("w_sharpen", c_float), ("t_sharpen", c_float),
+                ("sharpen_mode", c_int)]
 
 
 P = c_void_p

@@ -95,3 +95,41 @@ def mask_size_for(H, W):
     """spatial size after the 7x7/2 stem and the 3x3/2 max-pool."""
     h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     return ((h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1)
+
+
+VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj")
+
+
+def variant_model_kwargs(name, H, W, norm="BN"):
+    """Small-geometry stage-1 variants used by the parity fixtures/tests; returns (model_kwargs, object_channel).
+    fbms: configs/rcf_fbms59/rcf_stage1.yaml (3 segments + affine);  stv2: configs/rcf_stv2/rcf_stage1.yaml
+    (single-map head at 1/8 resolution, affine, compactness);  sharpen_kl / sharpen_obj: the two branches of
+    get_sharpen_loss (models/rcf_model.py:350-374);  joint: pred_joint_residual (:337-348);  compact_obj:
+    compactness on the object channel (compact_channel -1, models/compactness_head.py:19-24)."""
+    ms = mask_size_for(H, W)
+    oc = None
+    if name == "fbms":
+        kw = stage1_model_kwargs(ms, mask_layer=3, dropout=0.0, affine=True, norm=norm)
+    elif name == "stv2":
+        h8 = ((ms[0] - 1) // 2 + 1, (ms[1] - 1) // 2 + 1)
+        kw = stage1_model_kwargs(h8, dropout=0.0, affine=True, norm=norm)
+        kw["decode_head"]["allow_residual_resize"] = False
+        kw["decode_head2"].update(in_channels=2048, in_index=3)
+        kw["decode_head2"].pop("input_transform")
+        kw.update(compactness_head=dict(type="CompactnessHead", compact_channel=0), w_compactness=1.0)
+    elif name in ("sharpen_kl", "sharpen_obj"):
+        kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)
+        kw.update(w_sharpen=0.1, w_entropy=0, t_sharpen=0.25, object_aware_sharpening=(name == "sharpen_obj"))
+        oc = 1 if name == "sharpen_obj" else None
+    elif name == "joint":
+        kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)
+        kw["separate_residual"] = False
+        kw["decode_head3"]["num_classes"] = 2 * kw["mask_layer"]
+    elif name == "compact_obj":
+        kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)
+        kw.update(compactness_head=dict(type="CompactnessHead", compact_channel=-1), w_compactness=0.5)
+        oc = 2
+    else:
+        raise KeyError(name)
+    kw.update(log_interval=10 ** 9, train_iter=1)
+    return kw, oc

@@ -2,7 +2,8 @@
 // Reference: models/flow_aggregation_head_with_residual.py:235-310 (aggregate_flow_with_residual),
 // :164-233 (get_demean_affine_flow: per-segment weighted least squares), :150-162 (clamp), :312-399
 // (forward, L1 / robust loss); models/rcf_model.py:433-434 (softmax, log_softmax of the softmax),
-// :376-378 (entropy), :380-408 (asymmetric clamped MSE against pl / crf targets).
+// :376-378 (entropy), :350-374 (sharpen: KL to p^(1/T) or object-aware hinge), :380-408 (asymmetric
+// clamped MSE against pl / crf targets); models/compactness_head.py:14-57 (compactness of one channel).
 //
 // The reference materialises [B,64,C,h,w] and [B,C,hw,2,2] intermediates and solves the 2x2 (5x5)
 // systems through a batched LU library call.  Here every stage is one pass over the pixels of the
@@ -45,7 +46,8 @@ struct Ws {                   // workspace carve-up (all device pointers)
     double *T;                // [NB][C] sum_px w gw
     double *part;             // [NB][NCHUNK][PARTW] block partials
     double *red;              // [NB][PARTW] reduced partials
-    double *loss;             // [8]: seg_fw, seg_bw, entropy, target0, target1
+    double *loss;             // [8]: seg_fw, seg_bw, entropy, target0, target1, compactness, sharpen
+    double *cen;              // [NB][2] soft centroid (row/h, col/w) of the compact channel
     float *pgrad;             // [NB][NF*NF + NF + 2*NF + 2] per-image MLP parameter gradients
     float *poolpart;          // [NB][NCHUNK][NF][CMAX] pooling partials
 };
@@ -56,6 +58,10 @@ struct Cfg {
     float eps, q, clamp_t, res_scale, div_coeff, w_seg, w_entropy;
     int ntgt, tgt_channel;
     float t_wpos[2], t_wneg[2], t_w[2], t_th[2];
+    float w_compact;
+    int comp_ch;
+    float w_sharpen, t_sharpen;
+    int sharpen_mode;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -82,6 +88,7 @@ size_t carve(char *base, const Cfg &c, Ws &w) {
     w.part = (double *)take(NB * NCHUNK * PARTW * 8);
     w.red = (double *)take(NB * PARTW * 8);
     w.loss = (double *)take(8 * 8);
+    w.cen = (double *)take(NB * 2 * 8);
     w.pgrad = (float *)take(NB * (NF * NF + NF + 2 * NF + 2) * 4);
     w.poolpart = (float *)take(NB * NCHUNK * NF * CMAX * 4);
     return o;
@@ -140,14 +147,15 @@ __global__ void __launch_bounds__(RB) prepare_kernel(Cfg c, const float *__restr
 }
 
 // ------------------------------------------------------------------------------- softmax + scalar losses
-// partial row: [0..C) sum p_c ; [C] entropy sum ; [C+1], [C+2] target loss sums
+// partial row: [0..C) sum p_c ; [C] entropy sum ; [C+1], [C+2] target loss sums ; [C+3], [C+4] sum (row/h) m,
+// sum (col/w) m of the compact channel ; [C+5] sharpen loss sum
 __global__ void __launch_bounds__(RB) softmax_kernel(Cfg c, Ws w, const float *__restrict__ logits,
                                                      const float *__restrict__ tgt0, const float *__restrict__ tgt1) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int per = (c.P + NCHUNK - 1) / NCHUNK;
     const int p0 = chunk * per, p1 = min(c.P, p0 + per);
-    double acc[CMAX + 3];
-    for (int i = 0; i < CMAX + 3; i++) acc[i] = 0;
+    double acc[CMAX + 6];
+    for (int i = 0; i < CMAX + 6; i++) acc[i] = 0;
     for (int px = p0 + threadIdx.x; px < p1; px += RB) {
         const float *l = logits + ((long)n * c.P + px) * c.Cp;
         float v[CMAX], mx = -INFINITY;
@@ -170,21 +178,49 @@ __global__ void __launch_bounds__(RB) softmax_kernel(Cfg c, Ws w, const float *_
             const float d = tv - v[c.tgt_channel];
             acc[c.C + 1 + t] += (double)(d > 0.f ? c.t_wpos[t] * d * d : c.t_wneg[t] * d * d);
         }
+        if (c.w_compact != 0.f) {
+            const int y = px / c.w, x = px - y * c.w;
+            const float m = v[c.comp_ch];
+            acc[c.C + 3] += (double)(((float)y / (float)c.h) * m);
+            acc[c.C + 4] += (double)(((float)x / (float)c.w) * m);
+        }
+        if (c.sharpen_mode == 1) {
+            // F.kl_div(log_softmax(p), sharpen(p, T)) summed over channels: xlogy(t, t) - t * logp
+            float tt[CMAX], ts = 0.f;
+            for (int k = 0; k < c.C; k++) { tt[k] = powf(v[k], 1.f / c.t_sharpen); ts += tt[k]; }
+            float kl = 0.f;
+            for (int k = 0; k < c.C; k++) {
+                const float t = tt[k] / ts;
+                kl += (t > 0.f ? t * logf(t) : 0.f) - t * (v[k] - lse);
+            }
+            acc[c.C + 5] += (double)kl;
+        } else if (c.sharpen_mode == 2) {
+            float mo = 0.f;                                // max over the other channels (object channel zeroed)
+            for (int k = 0; k < c.C; k++) if (k != c.tgt_channel) mo = fmaxf(mo, v[k]);
+            acc[c.C + 5] += (double)fmaxf(c.t_sharpen - fabsf(v[c.tgt_channel] - mo), 0.f);
+        }
     }
-    block_reduce_store<CMAX + 3>(acc, c.C + 3, w.part + ((long)n * NCHUNK + chunk) * PARTW);
+    block_reduce_store<CMAX + 6>(acc, c.C + 6, w.part + ((long)n * NCHUNK + chunk) * PARTW);
 }
 
 __global__ void softmax_final_kernel(Cfg c, Ws w) {
     // one block; S[n][c] and the scalar losses
     const int t = threadIdx.x;
     if (t < c.NB * c.C) w.S[t] = w.red[(long)(t / c.C) * PARTW + (t % c.C)];
+    if (c.w_compact != 0.f && t < c.NB * 2)
+        w.cen[t] = w.red[(long)(t >> 1) * PARTW + c.C + 3 + (t & 1)] / w.red[(long)(t >> 1) * PARTW + c.comp_ch];
     if (t == 0) {
-        double ent = 0, t0 = 0, t1 = 0;
-        for (int n = 0; n < c.NB; n++) { ent += w.red[(long)n * PARTW + c.C]; t0 += w.red[(long)n * PARTW + c.C + 1]; t1 += w.red[(long)n * PARTW + c.C + 2]; }
+        double ent = 0, t0 = 0, t1 = 0, sh = 0;
+        for (int n = 0; n < c.NB; n++) {
+            ent += w.red[(long)n * PARTW + c.C]; t0 += w.red[(long)n * PARTW + c.C + 1]; t1 += w.red[(long)n * PARTW + c.C + 2];
+            sh += w.red[(long)n * PARTW + c.C + 5];
+        }
         const double cnt = (double)c.NB * c.P;
         w.loss[2] = ent / cnt;
         w.loss[3] = t0 / cnt;
         w.loss[4] = t1 / cnt;
+        w.loss[6] = c.sharpen_mode == 1 ? sh / (cnt * c.C) : sh / cnt;
+        w.loss[7] = 0;
     }
 }
 
@@ -339,12 +375,18 @@ __global__ void __launch_bounds__(RB) recon_kernel(Cfg c, Ws w, const float *__r
     const int p0 = chunk * per, p1 = min(c.P, p0 + per);
     const int b = n >> 1, d = n & 1, D = c.D;
     const float gcoef = c.w_seg / ((float)c.B * 2.f * (float)c.P);
-    double lacc[1] = {0};
+    double lacc[2] = {0, 0};
+    const float ycen = c.w_compact != 0.f ? (float)w.cen[2 * n] : 0.f, xcen = c.w_compact != 0.f ? (float)w.cen[2 * n + 1] : 0.f;
     for (int px = p0 + threadIdx.x; px < p1; px += RB) {
         float pv[CMAX];
         for (int cc = 0; cc < c.C; cc++) pv[cc] = w.p[((long)n * c.C + cc) * c.P + px];
         float om[DMAX];
         if (D) basis(px, c.w, D, om);
+        if (c.w_compact != 0.f) {
+            const int y = px / c.w, x = px - y * c.w;
+            const float dy = (float)y / (float)c.h - ycen, dx = (float)x / (float)c.w - xcen;
+            lacc[1] += (double)((dy * dy + dx * dx) * pv[c.comp_ch]);
+        }
         const float *r = R + ((long)b * c.P + px) * 4 * c.C + d * 2 * c.C;
         for (int dd = 0; dd < 2; dd++) {
             float agg = 0.f, adj = 0.f, aff = 0.f;
@@ -377,15 +419,16 @@ __global__ void __launch_bounds__(RB) recon_kernel(Cfg c, Ws w, const float *__r
             if (o_aff && D) o_aff[oi] = aff;
         }
     }
-    block_reduce_store<1>(lacc, 1, w.part + ((long)n * NCHUNK + chunk) * PARTW);
+    block_reduce_store<2>(lacc, 2, w.part + ((long)n * NCHUNK + chunk) * PARTW);
 }
 __global__ void recon_final_kernel(Cfg c, Ws w) {
     if (threadIdx.x != 0) return;
-    double fw = 0, bw = 0;
-    for (int n = 0; n < c.NB; n++) ((n & 1) ? bw : fw) += w.red[(long)n * PARTW];
+    double fw = 0, bw = 0, comp = 0;
+    for (int n = 0; n < c.NB; n++) { ((n & 1) ? bw : fw) += w.red[(long)n * PARTW]; comp += w.red[(long)n * PARTW + 1]; }
     const double cnt = (double)c.B * 2 * c.P;
     w.loss[0] = fw / cnt;
     w.loss[1] = bw / cnt;
+    w.loss[5] = comp / ((double)c.NB * c.P);
 }
 
 // ------------------------------------------------------------------------------- backward pass 1
@@ -564,6 +607,7 @@ __global__ void __launch_bounds__(RB) bwd_pixel_kernel(Cfg c, Ws w, const float 
     for (int cc = 0; cc < C; cc++) dgk[cc] = w.dg[((long)n * NF + k) * C + cc];
     const float ecoef = c.w_entropy / ((float)c.NB * (float)c.P);
     const float tcoef = 1.f / ((float)c.NB * (float)c.P);
+    const float ycen = c.w_compact != 0.f ? (float)w.cen[2 * n] : 0.f, xcen = c.w_compact != 0.f ? (float)w.cen[2 * n + 1] : 0.f;
     for (int px = blockIdx.x * 4 + wv; px < c.P; px += gridDim.x * 4) {
         float pv[CMAX], dp[CMAX];
         const float g0 = w.G[((long)n * 2) * c.P + px], g1 = w.G[((long)n * 2 + 1) * c.P + px];
@@ -615,6 +659,25 @@ __global__ void __launch_bounds__(RB) bwd_pixel_kernel(Cfg c, Ws w, const float 
             const float df = tv - pv[c.tgt_channel];
             dp[c.tgt_channel] += c.t_w[t] * tcoef * (-2.f) * df * (df > 0.f ? c.t_wpos[t] : c.t_wneg[t]);
         }
+        if (c.w_compact != 0.f) {
+            // d/dm of mean(err * m): the terms through the centroid vanish (sum_q m_q (y_q - y_c) = 0)
+            const int y = px / c.w, x = px - y * c.w;
+            const float dy = (float)y / (float)c.h - ycen, dx = (float)x / (float)c.w - xcen;
+            dp[c.comp_ch] += c.w_compact * tcoef * (dy * dy + dx * dx);
+        }
+        if (c.sharpen_mode == 1) {
+            // target detached; logp = log_softmax(p): d/dp_j = -(t_j - softmax(p)_j * sum t) / (NB*C*P)
+            float tt[CMAX], ts = 0.f;
+            for (int cc = 0; cc < C; cc++) { tt[cc] = powf(pv[cc], 1.f / c.t_sharpen); ts += tt[cc]; }
+            float tsum = 0.f;
+            for (int cc = 0; cc < C; cc++) { tt[cc] /= ts; tsum += tt[cc]; }
+            for (int cc = 0; cc < C; cc++) dp[cc] -= c.w_sharpen * (tcoef / (float)C) * (tt[cc] - expf(pv[cc] - lse) * tsum);
+        } else if (c.sharpen_mode == 2) {
+            float mo = 0.f;
+            for (int cc = 0; cc < C; cc++) if (cc != c.tgt_channel) mo = fmaxf(mo, pv[cc]);
+            const float df = pv[c.tgt_channel] - mo;
+            if (c.t_sharpen - fabsf(df) > 0.f) dp[c.tgt_channel] -= c.w_sharpen * tcoef * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        }
         if (k == 0) {
             float dot = 0.f;
             for (int cc = 0; cc < C; cc++) dot += pv[cc] * dp[cc];
@@ -640,7 +703,7 @@ __global__ void __launch_bounds__(256) lrelu_bwd_kernel(const float *__restrict_
 }
 
 __global__ void loss_to_float_kernel(const double *__restrict__ in, float *__restrict__ out) {
-    if (threadIdx.x < 5) out[threadIdx.x] = (float)in[threadIdx.x];
+    if (threadIdx.x < 8) out[threadIdx.x] = (float)in[threadIdx.x];
 }
 __global__ void scale_kernel(float *__restrict__ g, long n, float sc) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,13 +714,17 @@ int make_cfg(const rcf_flowhead_cfg *s, Cfg &c) {
     if (!s || s->B <= 0 || s->C <= 0 || s->C > CMAX || s->h <= 0 || s->w <= 0 || s->nf != NF) return RCF_EINVAL;
     if (s->D != 0 && s->D != 2 && s->D != 5) return RCF_EINVAL;
     if (s->logits_pitch < s->C || s->n_targets < 0 || s->n_targets > 2) return RCF_EINVAL;
-    if (s->n_targets && (s->target_channel < 0 || s->target_channel >= s->C)) return RCF_EINVAL;
+    if ((s->n_targets || s->sharpen_mode == 2) && (s->target_channel < 0 || s->target_channel >= s->C)) return RCF_EINVAL;
+    if (s->w_compact != 0.f && (s->compact_channel < 0 || s->compact_channel >= s->C)) return RCF_EINVAL;
+    if (s->sharpen_mode < 0 || s->sharpen_mode > 2 || (s->sharpen_mode && !(s->t_sharpen > 0.f))) return RCF_EINVAL;
     if (2 * s->B * s->C > 256 || (2 + 2 * s->D) * s->C > PARTW || (2 + s->D) * s->C > PARTW) return RCF_EINVAL;
     c.B = s->B; c.NB = 2 * s->B; c.C = s->C; c.P = s->h * s->w; c.h = s->h; c.w = s->w; c.Cp = s->logits_pitch;
     c.D = s->D; c.robust = s->robust; c.tanh_res = s->tanh_residual;
     c.eps = s->eps; c.q = s->q; c.clamp_t = s->clamp_t; c.res_scale = s->res_scale; c.div_coeff = s->div_coeff;
     c.w_seg = s->w_seg; c.w_entropy = s->w_entropy; c.ntgt = s->n_targets; c.tgt_channel = s->target_channel;
     for (int t = 0; t < 2; t++) { c.t_wpos[t] = s->t_wpos[t]; c.t_wneg[t] = s->t_wneg[t]; c.t_w[t] = s->t_weight[t]; c.t_th[t] = s->t_thresh[t]; }
+    c.w_compact = s->w_compact; c.comp_ch = s->compact_channel;
+    c.w_sharpen = s->sharpen_mode ? s->w_sharpen : 0.f; c.t_sharpen = s->t_sharpen; c.sharpen_mode = s->sharpen_mode;
     return 0;
 }
 
@@ -698,7 +765,7 @@ extern "C" int rcf_flowhead_fwd_f32(const rcf_flowhead_cfg *s, const float *logi
     if (!logits || !feat || !residual || !W1 || !b1 || !W2 || !b2 || !losses_out) return RCF_EINVAL;
     if ((c.ntgt > 0 && !target0) || (c.ntgt > 1 && !target1)) return RCF_EINVAL;
     hipLaunchKernelGGL(softmax_kernel, gch, dim3(RB), 0, st, c, w, logits, target0, target1);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(c.NB), dim3(128), 0, st, (const double *)w.part, w.red, c.C + 3);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(c.NB), dim3(128), 0, st, (const double *)w.part, w.red, c.C + 6);
     hipLaunchKernelGGL(softmax_final_kernel, dim3(1), dim3(256), 0, st, c, w);
     hipLaunchKernelGGL(pool_kernel, gch, dim3(RB), 0, st, c, w, feat);
     hipLaunchKernelGGL(pool_final_kernel, dim3(c.NB), dim3(64 * c.C), 0, st, c, w);
@@ -715,7 +782,7 @@ extern "C" int rcf_flowhead_fwd_f32(const rcf_flowhead_cfg *s, const float *logi
         }
     }
     hipLaunchKernelGGL(recon_kernel, gch, dim3(RB), 0, st, c, w, residual, flow_pred, flow_agg, flow_adj, flow_aff);
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(c.NB), dim3(128), 0, st, (const double *)w.part, w.red, 1);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(c.NB), dim3(128), 0, st, (const double *)w.part, w.red, 2);
     hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(64), 0, st, c, w);
     RCF_LAUNCH_CHECK();
     // losses_out (fp32): seg_fw, seg_bw, entropy, target0, target1  (device -> device conversion kernel-free: tiny copy)
@@ -739,6 +806,8 @@ extern "C" int rcf_flowhead_bwd_f32(const rcf_flowhead_cfg *s, const float *feat
     // an upstream scale (loss.backward(gradient=...)) multiplies every coefficient
     Cfg cs = c;
     cs.w_entropy *= grad_scale;
+    cs.w_compact *= grad_scale;
+    cs.w_sharpen *= grad_scale;
     for (int t = 0; t < 2; t++) cs.t_w[t] *= grad_scale;
     if (grad_scale != 1.f) {
         const long n = (long)c.NB * 2 * c.P;

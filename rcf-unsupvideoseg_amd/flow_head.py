@@ -7,9 +7,10 @@ models/rcf_model.py:350-408,433-434,464-523; compactness models/compactness_head
 Same constructor keywords / state-dict keys as the reference head.  The training path
 (`loss_and_grads`) runs on the hand-written kernels of csrc/flowhead.hip (softmax, segment pooling,
 MLP, fp64 affine least squares, reconstruction + loss, analytic backward) plus the implicit-GEMM conv
-kernels for the two 3x3 flow-feature convs.  A plain-torch evaluation of the same maths is kept for
-(a) the stand-alone `forward()` surface, which takes already-softmaxed masks, and (b) configs with a
-compactness head (STv2), whose loss is not in the HIP tail yet.
+kernels for the two 3x3 flow-feature convs; the sharpen and compactness losses are part of the same
+kernels.  A plain-torch evaluation of the flow maths is kept only for the stand-alone `forward()`
+surface of the reference head (already-softmaxed NCHW masks in, visualisation flows out), which
+RCFModel's training step does not use.
 """
 import math
 
@@ -133,6 +134,20 @@ class FlowAggregationHeadWithResidual(nn.Module):
         c.target_channel = int(model.args.object_channel) if targets else 0
         for i, (_, _, wpos, wneg, weight, th) in enumerate(targets):
             c.t_wpos[i], c.t_wneg[i], c.t_weight[i], c.t_thresh[i] = wpos, wneg, weight, th
+        oc = getattr(model.args, "object_channel", None)
+        c.w_compact, c.compact_channel = 0.0, 0
+        if model.compactness_head is not None:               # models/compactness_head.py:19-27
+            ch = model.compactness_head.compact_channel
+            ch = oc if ch == -1 else ch
+            if ch is not None:
+                c.w_compact, c.compact_channel = float(model.w_compactness), int(ch)
+        c.w_sharpen, c.t_sharpen, c.sharpen_mode = 0.0, float(model.t_sharpen), 0
+        if model.w_sharpen > 0 and (oc is not None or not model.object_aware_sharpening):   # rcf_model.py:471
+            c.w_sharpen = float(model.w_sharpen)
+            c.sharpen_mode = 2 if model.object_aware_sharpening else 1
+            if c.sharpen_mode == 2:
+                c.target_channel = int(oc)
+            c.w_entropy = 0.0                                 # `elif self.w_entropy > 0`, rcf_model.py:478
         return c
 
     def _workspace(self, cfg, device):
@@ -146,8 +161,6 @@ class FlowAggregationHeadWithResidual(nn.Module):
     def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I):
         """Returns (losses, seed): seed(scale) writes d(scale*loss)/d logits and /d res into the Acts and
         accumulates this head's parameter gradients."""
-        if model.compactness_head is not None:
-            return self._loss_and_grads_torch(model, logits, res, gfw, gbw, extra, B, I)
         assert I == 2, "Other im_num not implemented"
         C, (h, w) = self.mask_layer, self.mask_size
         dev = logits.t.device
@@ -179,15 +192,21 @@ class FlowAggregationHeadWithResidual(nn.Module):
         assert R.is_contiguous() and R.shape[3] == 4 * C
         t0 = targets[0][1] if len(targets) > 0 else None
         t1 = targets[1][1] if len(targets) > 1 else None
-        l5 = torch.empty(5, dtype=torch.float32, device=dev)
+        l5 = torch.empty(8, dtype=torch.float32, device=dev)
         _lib.call("rcf_flowhead_fwd_f32", cfg, _p(logits.t), _p(feat), _p(R), _p(l1.weight), _p(l1.bias), _p(l2.weight),
                   _p(l2.bias), _p(t0), _p(t1), _p(l5), None, None, None, None, None, _p(ws), need, st)
         seg = l5[0] + l5[1]
         losses = {"loss_warp_seg": seg}
         loss = seg * model.w_seg
-        if model.w_entropy > 0:
+        if cfg.sharpen_mode:
+            losses["loss_sharpen"] = l5[6]
+            loss = loss + l5[6] * model.w_sharpen
+        elif model.w_entropy > 0:
             losses["loss_entropy"] = l5[2]
             loss = loss + l5[2] * model.w_entropy
+        if cfg.w_compact != 0.0:
+            losses["loss_compactness"] = l5[5]
+            loss = loss + l5[5] * model.w_compactness
         for i, (name, _, _, _, weight, _) in enumerate(targets):
             losses[name] = l5[3 + i]
             loss = loss + l5[3 + i] * weight
@@ -288,53 +307,3 @@ class FlowAggregationHeadWithResidual(nn.Module):
                  "residual_adj": [vis(fw[2], bw[2])],
                  "affine_flow": [vis(fw[3], bw[3])] if fw[3] is not None else []}
         return flows, loss
-
-    def _loss_and_grads_torch(self, model, logits, res, gfw, gbw, extra, B, I):
-        """Loss tail through torch autograd (only for configs with a compactness head)."""
-        C = self.mask_layer
-        with torch.enable_grad():
-            l_nchw = ops.nhwc_to_nchw(logits.t, C).requires_grad_(True)
-            r_nchw = ops.nhwc_to_nchw(res.t, 4 * C).requires_grad_(True)
-            p = F.softmax(l_nchw.view(B, I, C, *l_nchw.shape[-2:]), dim=2)
-            logp = F.log_softmax(p, dim=2)
-            lf, _ = self.flow_losses(p, gfw, gbw, r_nchw[:, :2 * C], r_nchw[:, 2 * C:])
-            losses = {"loss_warp_seg": lf["seg"]}
-            loss = lf["seg"] * model.w_seg
-            if model.w_entropy > 0:
-                le = -(p * logp).sum(dim=2).mean()
-                loss = loss + le * model.w_entropy
-                losses["loss_entropy"] = le
-            lc = model.compactness_head.get_compactness_loss(p)
-            if lc is not None:
-                losses["loss_compactness"] = lc
-                loss = loss + lc * model.w_compactness
-            oc = getattr(model.args, "object_channel", None)
-
-            def asym_mse(target, pred, wpos, wneg):
-                d = target - pred
-                return (d.clamp(min=0) ** 2).mean() * wpos + (d.clamp(max=0) ** 2).mean() * wneg
-            if model.w_pl > 0:
-                t = extra["pl_masks"]
-                t = (t > model.pl_mask_pos_th).float() if model.pl_mask_pos_th != -1 else t
-                lp = asym_mse(t, p[:, :, oc], model.pl_pos_weight, model.pl_neg_weight)
-                losses["loss_pl"] = lp
-                loss = loss + lp * model.w_pl
-            if model.w_crf > 0:
-                t = extra["crf_masks"]
-                t = (t > model.crf_mask_pos_th).float() if model.crf_mask_pos_th != -1. else t
-                lcrf = asym_mse(t, p[:, :, oc], model.crf_pos_weight, model.crf_neg_weight)
-                losses["loss_crf"] = lcrf
-                loss = loss + lcrf * model.w_crf
-            params = [q for q in self.parameters() if q.requires_grad]
-        losses = {k: v.detach() for k, v in losses.items()}
-        losses["loss"] = loss.detach()
-
-        def seed(scale):
-            grads = torch.autograd.grad(loss, [l_nchw, r_nchw] + params, allow_unused=True,
-                                        grad_outputs=torch.as_tensor(scale, dtype=loss.dtype, device=loss.device))
-            logits.grad = ops.nchw_to_nhwc(grads[0].contiguous(), logits.t.shape[3])
-            res.grad = ops.nchw_to_nhwc(grads[1].contiguous(), res.t.shape[3])
-            for q, g in zip(params, grads[2:]):
-                if g is not None:
-                    _param_grad(q).add_(g)
-        return losses, seed

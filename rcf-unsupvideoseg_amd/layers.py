@@ -218,21 +218,23 @@ def resize_into(x, tape, size, align_corners, out):
     ops.resize_nhwc_fwd(x.t, size, align_corners, out=out)
 
 
-def concat_channels(parts, tape, size=None, align_corners=False):
+def concat_channels(parts, tape, size=None, align_corners=False, widths=None):
     """resize_concat of models/decode_head.py:151-164: every part is bilinearly resized to `size`
-    (default: the first part's) and written into its channel slice of one NHWC buffer."""
+    (default: the first part's) and written into its channel slice of one NHWC buffer.
+    `widths`: take only the first widths[i] channels of part i (drops zero-padded output channels)."""
     N, H, W, _ = parts[0].t.shape
     if size is not None:
         H, W = size
-    ctot = sum(p.t.shape[3] for p in parts)
+    widths = [p.t.shape[3] for p in parts] if widths is None else list(widths)
+    ctot = sum(widths)
     buf = torch.empty((N, H, W, ctot), dtype=torch.float32, device=parts[0].t.device)
     offs, o = [], 0
-    for p in parts:
-        c = p.t.shape[3]
+    for p, c in zip(parts, widths):
         sl = buf[..., o:o + c]
         if tuple(p.t.shape[1:3]) == (H, W):
             ops.copy2d(p.t, ops.pitch_of(p.t), sl, ctot, N * H * W, c)
         else:
+            assert c == p.t.shape[3]
             ops.resize_nhwc_fwd(p.t, (H, W), align_corners, out=sl)
         offs.append(o)
         o += c
@@ -240,12 +242,13 @@ def concat_channels(parts, tape, size=None, align_corners=False):
 
     def bwd():
         g = ya.take_grad()
-        for p, o in zip(parts, offs):
+        for p, o, c in zip(parts, offs, widths):
             if not p.needs_grad:
                 continue
-            c = p.t.shape[3]
             gs = g[..., o:o + c]
             gp, beta = p.grad_slot()
+            if c < p.t.shape[3] and beta == 0:
+                ops.fill(gp, 0.0)                  # the dropped (padded) channels carry no gradient
             if tuple(p.t.shape[1:3]) == (H, W):
                 ops.copy2d(gs, ctot, gp, ops.pitch_of(gp), N * H * W, c, beta=beta)
             else:
@@ -254,15 +257,17 @@ def concat_channels(parts, tape, size=None, align_corners=False):
     return ya
 
 
-def pair_concat(x, tape, B, I):
+def pair_concat(x, tape, B, I, order=None):
     """[B*I,h,w,C] -> [B,h,w,I*C]: frames of a pair side by side on channels
-    (unflatten(0,(B,I)).flatten(1,2) of models/rcf_model.py:325 in NHWC)."""
+    (unflatten(0,(B,I)).flatten(1,2) of models/rcf_model.py:325 in NHWC).  `order` permutes the frames
+    first (the [1, 0] swap of pred_joint_residual, models/rcf_model.py:342)."""
     N, H, W, C = x.t.shape
     assert N == B * I and x.t.is_contiguous()
+    order = list(range(I)) if order is None else list(order)
     out = torch.empty((B, H, W, I * C), dtype=torch.float32, device=x.t.device)
     for b in range(B):
         for i in range(I):
-            ops.copy2d(x.t[b * I + i], C, out[b][..., i * C:], I * C, H * W, C)
+            ops.copy2d(x.t[b * I + order[i]], C, out[b][..., i * C:], I * C, H * W, C)
     ya = Act(out)
 
     def bwd():
@@ -272,6 +277,6 @@ def pair_concat(x, tape, B, I):
         gx, beta = x.grad_slot()
         for b in range(B):
             for i in range(I):
-                ops.copy2d(g[b][..., i * C:], I * C, gx[b * I + i], C, H * W, C, beta=beta)
+                ops.copy2d(g[b][..., i * C:], I * C, gx[b * I + order[i]], C, H * W, C, beta=beta)
     tape.push(bwd)
     return ya

@@ -17,7 +17,7 @@ from . import ops
 from .backbone import FCNHead, ResNet
 from .crf import CRFHead
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual
-from .layers import Act, DistCtx, Tape, pair_concat
+from .layers import Act, DistCtx, Tape, concat_channels, pair_concat
 
 REGISTRY = dict(ResNet=ResNet, FCNHead=FCNHead, FlowAggregationHeadWithResidual=FlowAggregationHeadWithResidual,
                 CompactnessHead=CompactnessHead, CRFHead=CRFHead)
@@ -124,8 +124,6 @@ class RCFModel(nn.Module):
             copy_param_and_buffer(self.backbone2, self.backbone2_ema)
         if self.decode_head2_ema is not None:
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
-        if w_sharpen > 0 or object_aware_sharpening:
-            raise NotImplementedError("sharpen loss (w_sharpen) is not used by any RCF stage config")
         self._tape, self._root_grads, self._anchor = None, None, None
         self.dist = None
 
@@ -170,9 +168,13 @@ class RCFModel(nn.Module):
             raise NotImplementedError("allow_mask_resize with a mismatching mask_size")
         if self.separate_residual:
             res = self.decode_head3.fwd([pair_concat(feats[-1], tape, B, I)], tape, dist)   # [B,h2,w2,4C]
-            res_swapped = None
         else:
-            raise NotImplementedError("joint residual (separate_residual=False) is not used by the RCF configs")
+            # pred_joint_residual (rcf_model.py:337-348): the same head on (f0,f1) and on (f1,f0); each run
+            # gives 2C channels (fw resp. bw); laid side by side they form the [B,h2,w2,4C] residual
+            nc2 = self.decode_head3.num_classes
+            r_fw = self.decode_head3.fwd([pair_concat(feats[-1], tape, B, I)], tape, dist)
+            r_bw = self.decode_head3.fwd([pair_concat(feats[-1], tape, B, I, order=(1, 0))], tape, dist)
+            res = concat_channels([r_fw, r_bw], tape, widths=[nc2, nc2])
         # ground-truth flows to mask resolution (values not rescaled, rcf_model.py:438-442)
         nf = gt_fw_flows.shape[1]
         gfw = ops.resize_nchw(gt_fw_flows.reshape(B * nf, *gt_fw_flows.shape[2:]).contiguous().float(),

@@ -37,7 +37,8 @@ def test_flow_head_vs_reference_golden(tag, golden_dir, report):
     shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=11).items()})
     head = head.to(DEV)
-    model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.0, w_pl=0, w_crf=0, compactness_head=None,
+    model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.0, w_pl=0, w_crf=0, compactness_head=None, w_sharpen=0, t_sharpen=0.25,
+                                  object_aware_sharpening=False,
                                   args=types.SimpleNamespace(object_channel=None))
     logits = Act(to_nhwc(fx["logits"].reshape(B * 2, C, h, w)))                 # n = b*2 + i
     res = Act(to_nhwc(np.concatenate([fx["rfw"], fx["rbw"]], axis=1)))
@@ -74,7 +75,8 @@ def test_flow_head_entropy_and_targets_vs_torch(report):
     crf = torch.from_numpy((g.random((B, 2, h, w)) > 0.5).astype(np.float32)).to(DEV)
     model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.05, w_pl=3.0, pl_pos_weight=2.0, pl_neg_weight=1.0,
                                   pl_mask_pos_th=0.35, w_crf=10.0, crf_pos_weight=2.0, crf_neg_weight=1.0,
-                                  crf_mask_pos_th=-1.0, compactness_head=None,
+                                  crf_mask_pos_th=-1.0, compactness_head=None, w_sharpen=0, t_sharpen=0.25,
+                                  object_aware_sharpening=False,
                                   args=types.SimpleNamespace(object_channel=2))
     logits, res = Act(to_nhwc(lg)), Act(to_nhwc(rs))
     for p in head.parameters():

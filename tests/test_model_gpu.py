@@ -201,39 +201,38 @@ def test_fullsize_480x854_vs_reference_golden(golden_dir, report):
     assert all(e_gn[k] < lim_gn[k] for k in e_gn), (e_gn, lim_gn)
 
 
-@pytest.mark.parametrize("variant", ["fbms", "stv2"])
-def test_other_dataset_configs_vs_oracle(variant, report):
-    """the two non-DAVIS stage-1 variants of the reference (configs/rcf_fbms59, configs/rcf_stv2):
-    3 segments + affine flow; single-map decode head at 1/8 resolution + compactness loss."""
-    import rcf_torch as orc
-    H, W, B = 64, 96, 2
-    if variant == "fbms":
-        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), mask_layer=3, dropout=0.0, affine=True, norm="BN")
-    else:
-        h8 = ((config.mask_size_for(H, W)[0] - 1) // 2 + 1, (config.mask_size_for(H, W)[1] - 1) // 2 + 1)
-        kw = config.stage1_model_kwargs(h8, dropout=0.0, affine=True, norm="BN")
-        kw["decode_head"]["allow_residual_resize"] = False
-        kw["decode_head2"].update(in_channels=2048, in_index=3)
-        kw["decode_head2"].pop("input_transform")
-        kw.update(compactness_head=dict(type="CompactnessHead", compact_channel=0), w_compactness=1.0)
-    kw.update(log_interval=10 ** 9, train_iter=1)
-
-    def build(cls, dev):
-        m = cls(_args(), **copy.deepcopy(kw))
-        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
-        return m.to(dev)
-    hip, ora = build(rcf_amd.RCFModel, DEV), build(orc.RCFModel, "cpu")
-    tr = rcf_amd.Trainer(hip, device=DEV)
+@pytest.mark.parametrize("variant", list(config.VARIANTS))
+def test_config_variants_vs_reference_golden(variant, golden_dir, report):
+    """Configuration variants of the training step against numbers captured from the reference
+    (tests/golden/variants.json, written by make_golden_variants.py): FBMS (3 segments + affine), STv2
+    (single-map head + compactness), both sharpen-loss branches, joint residual head, compactness on the
+    object channel.  Losses: 1e-4 relative to the reference; gradient norms: against the float64 truth with
+    4x the reference's own fp32 error as the limit (floor 1e-4)."""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "variants.json")))[variant]
+    H, W, B = fx["H"], fx["W"], fx["B"]
+    kw, oc = config.variant_model_kwargs(variant, H, W)
+    assert oc == fx["object_channel"]
+    args = _args()
+    args.object_channel = oc
+    m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=fx["weight_seed"]).items()})
+    tr = rcf_amd.Trainer(m.to(DEV), device=DEV)
     lh = tr.step(_batch(B, H, W, DEV))
-    ora.train()
-    lo = ora(_batch(B, H, W, "cpu"))
-    lo["loss"].backward()
-    e = {k: rel(float(lh[k]), float(lo[k])) for k in lo if k.startswith("loss")}
-    gn = lambda m, pre: sum(float(p.grad.double().pow(2).sum()) for n, p in m.named_parameters()
-                            if p.grad is not None and n.startswith(pre)) ** 0.5
-    for pre in ("decode_head2.", "decode_head.", "backbone2.layer4."):
-        e["gn " + pre] = rel(gn(hip, pre), gn(ora, pre))
-    report(f"{variant} config vs oracle: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
-    assert max(v for k, v in e.items() if k.startswith("loss")) < TOL
-    assert max(v for k, v in e.items() if k.startswith("gn")) < 5e-2      # affine + L1 kinks: ill-conditioned (see goldens)
+    assert sorted(k for k in lh if "loss" in k) == sorted(fx["loss"]), (sorted(lh), sorted(fx["loss"]))
+    e = {k: rel(float(lh[k]), v) for k, v in fx["loss"].items()}
+    gn = {}
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+    e_gn = {k: rel(np.sqrt(gn[k]), v) for k, v in fx["truth_gradnorm"].items()}
+    lim = {k: max(TOL, 4 * v) for k, v in fx["ref32_err_gradnorm"].items()}
+    report(f"{variant} vs reference: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()) + " | gradnorm vs f64 " +
+           " ".join(f"{k} {v:.2e} (lim {lim[k]:.1e})" for k, v in e_gn.items()))
+    # total loss against the reference; every term against the float64 truth (a hinge over a handful of active
+    # pixels -- sharpen_obj -- is ill-conditioned in fp32: the reference itself is 2.4e-3 off there)
+    assert e["loss"] < TOL
+    e64 = {k: rel(float(lh[k]), v) for k, v in fx["truth_loss"].items()}
+    assert all(e64[k] < max(TOL, 4 * fx["ref32_err_loss"][k]) for k in e64), (e64, fx["ref32_err_loss"])
+    assert all(e_gn[k] < lim[k] for k in e_gn), (e_gn, lim)
