@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 GF_PER_FRAME = 2043.3              # fwd+bwd algorithmic GFLOP per 480x854 frame
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E, 8 TB/s
 
 
 def main():
@@ -125,6 +126,12 @@ def main():
         except Exception as e:                                  # noqa: BLE001 -- reported, not hidden
             out["crf_ms_per_frame"] = None
             out["crf_error"] = str(e)[:200]
+        # backward-warp + photometric L1 residual: HBM-bound, 64 frames per launch
+        try:
+            out["warp_roofline"] = warp_bench(torch, rcf_amd, synth, dev, H, W)
+        except Exception as e:                                  # noqa: BLE001
+            out["warp_roofline"] = None
+            out["warp_error"] = str(e)[:200]
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(out), flush=True)
@@ -134,7 +141,10 @@ def main():
 
 
 def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8):
+    """CRFHead on `nframes` 480x854 frames per call.  Roofline: algorithmic bytes per frame =
+    T*(192 N + 348 L) + build (68 N + 70 L), N pixels, L lattice vertices (measured, data dependent)."""
     import numpy as np
+    from rcf_amd.crf import crf_soft_batched
     head = rcf_amd.CRFHead(None, refine_iters=iters)
     imgs = torch.from_numpy(np.stack([synth.normalize_rgb(synth.smooth_rgb(H, W, 4000 + i)) for i in range(nframes)])).to(dev)
     masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4000 + i) for i in range(nframes)])).to(dev)
@@ -146,7 +156,48 @@ def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8):
         head(imgs, masks)
     e1.record()
     torch.cuda.synchronize()
-    return {"iters": iters, "frames_per_call": nframes, "value": round(e0.elapsed_time(e1) / 3 / nframes, 4)}
+    ms = e0.elapsed_time(e1) / 3 / nframes
+    rgb, unary = head.prepare(imgs, masks)
+    _, nv = crf_soft_batched(rgb, unary, W, H, head.scomp_smooth, head.sxy_smooth, head.scomp, head.sxy, head.srgb, 1,
+                             want_nvert=True)
+    N, L = H * W, float(nv[:, 1].float().mean())
+    alg = iters * (192.0 * N + 348.0 * L) + 68.0 * N + 70.0 * L
+    ach = alg / (ms * 1e-3) / 1e9
+    return {"iters": iters, "frames_per_call": nframes, "value": round(ms, 4), "pixels": N, "lattice_vertices": round(L),
+            "algorithmic_bytes_per_frame": round(alg),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4)}}
+
+
+def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):
+    """flow_warp fused with the occlusion-masked L1 residual on `nframes` frames per launch: 4*(2 + 2*3 + 1)
+    algorithmic bytes per pixel (flow, source taps once, target, occlusion mask; scalar output)."""
+    import numpy as np
+    from rcf_amd import ops
+    base = np.stack([synth.voronoi_affine_flow(H, W, 7000 + i)[0] for i in range(8)])
+    fl = torch.from_numpy(np.tile(base, (nframes // 8, 1, 1, 1))).to(dev)
+    x = torch.rand(nframes, 3, H, W, device=dev)
+    y = torch.rand(nframes, 3, H, W, device=dev)
+    occ = torch.ones(nframes, 1, H, W, device=dev)
+
+    def timeit(fn, n=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    px = nframes * H * W
+    t_l1 = timeit(lambda: ops.warp_l1_residual(y, x, fl, occ, "border"))
+    t_w = timeit(lambda: ops.flow_warp(x, fl, "border"))
+    ach = px * 36.0 / t_l1 / 1e9
+    return {"kernel": "warp_l1_kernel (bilinear backward warp + masked L1 residual)", "frames_per_launch": nframes,
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "us_per_frame": round(t_l1 / nframes * 1e6, 2),
+            "flow_warp_GBps": round(px * 32.0 / t_w / 1e9, 1), "flow_warp_us_per_frame": round(t_w / nframes * 1e6, 2)}
 
 
 def cpu_baseline(H, W):
