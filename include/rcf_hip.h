@@ -43,9 +43,12 @@ typedef struct {
 
 int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                        int act, float slope, int beta, void *stream);
-/* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w) */
+/* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w).
+ * `workspace` (rcf_conv2d_dgrad_workspace_bytes) holds the transposed weights [Cin][R][S][Cout] the
+ * split-bf16 kernels contract against. */
+size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
-                         void *stream);
+                         void *workspace, size_t workspace_bytes, void *stream);
 /* dw[Cout][R][S][Cin] (+)= sum_pixels dy * x.  Split over pixels into `workspace`, then reduced
  * deterministically (no float atomics). */
 size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);

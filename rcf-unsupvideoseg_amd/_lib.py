@@ -38,7 +38,8 @@ _FH = ctypes.POINTER(FlowHeadCfg)
 PROTOS = {
     "rcf_version": (c_char_p, []),
     "rcf_conv2d_fwd_f32": (c_int, [P, P, P, P, _CS, c_int, c_float, c_int, P]),
-    "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P]),
+    "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
     "rcf_conv_set_variant": (c_int, [c_int]),
     "rcf_conv2d_wgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_wgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),

@@ -307,6 +307,237 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- split-bf16 ("x3")
+// fp32 contraction on the bf16 matrix cores.  fp32 MFMA runs at 1/16 of the bf16 rate on gfx950, so
+// each fp32 operand is split EXACTLY into three bf16 parts x = h + m + l (round-to-nearest at every
+// level: 3 x 8 significand bits cover the 24 of fp32, residuals are exact in fp32) and the product is
+// formed from the six partial products whose weight is >= 2^-16:
+//     x*y ~= h*h' + (h*m' + m*h') + (m*m' + h*l' + l*h')        (dropped: m*l', l*m', l*l' <= 2^-25 |xy|)
+// bf16 x bf16 is exact in fp32 and the accumulation is fp32, so the result carries a relative error per
+// product (~2^-25) BELOW fp32's own rounding (2^-24): it is fp32 arithmetic at 6 MFMA passes of 1/16
+// cost each = 2.67x the fp32-MFMA rate (peak 2.5 PF / 6 = 417 TF/s).
+// The split happens ONCE per element, on the way from global memory into LDS; LDS holds three bf16
+// planes per operand, row-major [row][16 k] = 32 B per row; the two 16-byte halves of a row are swapped
+// on rows with bit 3 set so that the ds_read_b128 operand fetch (lane = row, lane>>5 = k half) and the
+// ds_write_b64 of the loader are both bank-conflict free without padding.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 &l) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+    const f32x2 sa = ra - __builtin_convertvector(ma, f32x2), sb = rb - __builtin_convertvector(mb, f32x2);
+    const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
+    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    l = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+
+// one K=16 step: 6 x MR x NR MFMAs (32x32x16 bf16), smallest partial products first
+template <int MR, int NR>
+__device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *__restrict__ Bs, int wm, int wn,
+                                       int lane, f32x16 (&acc)[MR][NR]) {
+    constexpr int PA = 64 * MR * 32, PB = 64 * NR * 32;      // bytes per bf16 plane
+    const int l31 = lane & 31;
+    const int swz = ((lane >> 5) ^ ((l31 >> 3) & 1)) << 4;
+    bf16x8 a[MR][3], b[NR][3];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            a[mr][q] = *reinterpret_cast<const bf16x8 *>(As + q * PA + (wm * 32 * MR + mr * 32 + l31) * 32 + swz);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            b[nr][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * PB + (wn * 32 * NR + nr * 32 + l31) * 32 + swz);
+    constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr][QA[t]], b[nr][QB[t]], acc[mr][nr], 0, 0, 0);
+}
+
+// forward / dgrad with k-contiguous weights B[j][k] (dgrad: the [Cin][R][S][Cout] transposed copy)
+template <int MR, int NR, bool STRIDED>
+__global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR, BKT = 16;
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * p.ntiles);
+    const int rem = bid - grp * 8 * p.ntiles;
+    const int tile_n = rem >> 3;
+    const int tile_m = grp * 8 + (rem & 7);
+    if (tile_m >= p.mtiles) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    constexpr int TPR = BKT / 4, ROWS = 256 / TPR;           // 4 threads per 16-float row, 64 rows per pass
+    constexpr int A_PASS = BM / ROWS, B_PASS = BN / ROWS;
+    const int kq = tid % TPR, arow = tid / TPR;
+    const int st_off = arow * 32 + ((((kq >> 1) ^ ((arow >> 3) & 1))) << 4) + (kq & 1) * 8;   // + ROWS*32 per pass
+    const float *arowp[A_PASS];
+    int ay[A_PASS], ax[A_PASS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+        const int m = m0 + arow + ROWS * i;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int pix = m - n * HoWo;
+            const int y = pix / p.Wo;
+            const int x = pix - y * p.Wo;
+            ay[i] = y * p.up + p.off;
+            ax[i] = x * p.up + p.off;
+            arowp[i] = p.A + (long)n * p.a_img_stride + (STRIDED ? 0L : ((long)ay[i] * p.Ws + ax[i]) * p.a_pitch);
+        } else {
+            arowp[i] = p.A;
+            ay[i] = -(1 << 28);
+            ax[i] = -(1 << 28);
+        }
+    }
+    f32x4 ra[A_PASS], rb[B_PASS];
+    bool va[A_PASS], vb[B_PASS];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BKT + kq * 4;
+        const bool kv = k < p.K;
+        const int rs = fast_div(k, p.cs_magic);
+        const int c = k - rs * p.Cs;
+        const int r = fast_div(rs, p.s_magic);
+        const int s = rs - r * p.S;
+        const int dy = r * p.step, dx = s * p.step;
+        const long tapoff = ((long)dy * p.Ws + dx) * p.a_pitch + c;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            int ty = ay[i] + dy, tx = ax[i] + dx;
+            bool v;
+            const float *src;
+            if (STRIDED) {
+                v = kv && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);
+                ty /= p.div;
+                tx /= p.div;
+                v = v && ty < p.Hs && tx < p.Ws;
+                src = arowp[i] + ((long)ty * p.Ws + tx) * p.a_pitch + c;
+            } else {
+                v = kv && (unsigned)ty < (unsigned)p.Hs && (unsigned)tx < (unsigned)p.Ws;
+                src = arowp[i] + tapoff;
+            }
+            ra[i] = *reinterpret_cast<const f32x4 *>(v ? src : p.A);
+            va[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int j = n0 + arow + ROWS * i;
+            const bool v = kv && j < p.Ncol;
+            rb[i] = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)j * p.ldb + k : p.Bw);
+            vb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *As = smem + buf * STAGE;
+        char *Bs = As + 3 * PA;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            u32x2 h, m, l;
+            split3(va[i] ? ra[i] : zero4, h, m, l);
+            char *d = As + st_off + i * ROWS * 32;
+            *reinterpret_cast<u32x2 *>(d) = h;
+            *reinterpret_cast<u32x2 *>(d + PA) = m;
+            *reinterpret_cast<u32x2 *>(d + 2 * PA) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            u32x2 h, m, l;
+            split3(vb[i] ? rb[i] : zero4, h, m, l);
+            char *d = Bs + st_off + i * ROWS * 32;
+            *reinterpret_cast<u32x2 *>(d) = h;
+            *reinterpret_cast<u32x2 *>(d + PB) = m;
+            *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int KT = (p.K + BKT - 1) / BKT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT - 1; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *As = smem + cur * STAGE;
+        mma_x3<MR, NR>(As, As + 3 * PA, wm, wn, lane, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    {
+        const char *As = smem + ((KT - 1) & 1) * STAGE;
+        mma_x3<MR, NR>(As, As + 3 * PA, wm, wn, lane, acc);
+    }
+
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int col = n0 + wn * 32 * NR + nr * 32 + l31;
+        if (col >= p.Ncol) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int rbase = m0 + wm * 32 * MR + mr * 32 + 4 * kh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row < p.M) {
+                    float *dst = p.Y + (long)row * p.y_pitch + col;
+                    float v = acc[mr][nr][e] + bv;
+                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                    if (p.beta) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// wt[c][rs][co] = w[co][rs][c]: the k-contiguous weight operand of the data gradient
+__global__ void __launch_bounds__(256) weight_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt,
+                                                               int Cout, int Cin, int RS) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = o0 + r, c = c0 + tx;
+        tile[r][tx] = (co < Cout && c < Cin) ? w[((long)co * RS + rs) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, co = o0 + tx;
+        if (c < Cin && co < Cout) wt[((long)c * RS + rs) * Cout + co] = tile[tx][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------- wgrad
 struct WgradParams {
     const float *X, *DY;
@@ -487,7 +718,9 @@ int check_shape(const rcf_conv_shape *s) {
     return 0;
 }
 
-int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS.  -1: built-in default
+int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 tile (fp32-MFMA kernels);
+                           // bit3: split-bf16 kernels.  -1: built-in default (= 8)
+inline bool use_x3() { return g_conv_variant < 0 || (g_conv_variant & 8) != 0; }
 
 inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
@@ -515,6 +748,29 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
     } else {
         if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
+    }
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+// split-bf16 launch (B always k-contiguous)
+int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
+    p.cs_magic = magic_of(p.Cs);
+    p.s_magic = magic_of(p.S);
+    if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    const bool strided = p.div > 1;
+    const bool wide = p.Ncol > 64;
+    const int BM = 128, BN = wide ? 128 : 64;
+    p.mtiles = rcf_cdiv(p.M, BM);
+    p.ntiles = rcf_cdiv(p.Ncol, BN);
+    const int groups = rcf_cdiv(p.mtiles, 8);
+    const dim3 grid((unsigned)(groups * 8 * p.ntiles));
+    if (strided) {
+        if (wide) hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 2, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 1, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 2, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 1, false>), grid, dim3(256), 0, st, p);
     }
     RCF_LAUNCH_CHECK();
     return 0;
@@ -560,7 +816,8 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
 
 }  // namespace
 
-/* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS */
+/* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
+ * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
     g_conv_variant = v;
     return 0;
@@ -577,11 +834,17 @@ extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *b
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
+    if (use_x3()) return launch_igemm_x3(p, rcf_stream(stream));
     return launch_igemm<0>(p, rcf_stream(stream));
 }
 
+extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s) || !use_x3()) return 0;
+    return (size_t)s->Cout * s->R * s->S * s->Cin * sizeof(float);
+}
+
 extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
-                                    void *stream) {
+                                    void *workspace, size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
     if (s->Cout % 4) return RCF_EINVAL;
@@ -592,6 +855,17 @@ extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, 
     p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.ldb = s->R * s->S * s->Cin; p.act = 0; p.slope = 0.f; p.beta = beta;
+    if (use_x3()) {
+        // k-contiguous weights for the bf16 operand fetch: wt[c][rs][co] (one small transpose per call)
+        const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
+        if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+        hipStream_t st = rcf_stream(stream);
+        hipLaunchKernelGGL(weight_transpose_kernel, dim3(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S),
+                           dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin, s->R * s->S);
+        p.Bw = (const float *)workspace;
+        p.ldb = p.K;
+        return launch_igemm_x3(p, st);
+    }
     return launch_igemm<1>(p, rcf_stream(stream));
 }
 

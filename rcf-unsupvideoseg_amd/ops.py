@@ -132,7 +132,9 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0):
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
-    call("rcf_conv2d_dgrad_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _stream())
+    need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
+    ws = workspace(need, dy.device) if need else None
+    call("rcf_conv2d_dgrad_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _p(ws), need, _stream())
     return out
 
 

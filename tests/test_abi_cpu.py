@@ -35,7 +35,7 @@ def test_bad_arguments_return_codes_not_crashes():
     s = _lib.ConvShape(1, 8, 8, 3, 8, 8, 8, 3, 3, 1, 1, 1, 3, 8)          # Cin % 4 != 0
     assert lib.rcf_conv2d_fwd_f32(None, None, None, None, ctypes.byref(s), 0, 0.0, 0, None) == -1
     s = _lib.ConvShape(1, 8, 8, 4, 7, 8, 8, 3, 3, 1, 1, 1, 4, 8)          # wrong Ho
-    assert lib.rcf_conv2d_dgrad_f32(None, None, None, ctypes.byref(s), 0, None) == -1
+    assert lib.rcf_conv2d_dgrad_f32(None, None, None, ctypes.byref(s), 0, None, 0, None) == -1
     assert lib.rcf_bn_stats_f32(None, 10, 6, 6, None, None, 0, None) == -1
     assert lib.rcf_crf_soft(None, None, 8, 8, 1, 0., 0., 5., 60., 5., 5, None, None, None, None, 0, None) == -1
     assert lib.rcf_flow_warp_f32(None, None, None, 1, 3, 8, 8, 0, None) == -1

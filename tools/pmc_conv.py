@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rcf_amd
 from rcf_amd import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-N, Cin, Cout, H, W = 8, 512, 512, 60, 107
+N, Cin, Cout, H, W = 16, 512, 512, 60, 107
 x = torch.randn(N, H, W, Cin, device="cuda:0")
 w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0") * 0.05).contiguous(memory_format=torch.channels_last)
 y = ops.conv2d_fwd(x, w, None, 1, 4, 4)
