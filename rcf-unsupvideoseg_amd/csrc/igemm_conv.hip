@@ -45,6 +45,7 @@ struct IgemmParams {
     int beta;
     int mtiles, ntiles;
     unsigned cs_magic, s_magic;   // floor(2^32/d)+1 for d = Cs, S (exact k/d for k*d < 2^32; 0 when d == 1)
+    int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
 };
 
 __device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
@@ -337,24 +338,27 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 
     l = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
-// one K=16 step: 6 x MR x NR MFMAs (32x32x16 bf16), smallest partial products first
-template <int MR, int NR>
-__device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *__restrict__ Bs, int wm, int wn,
+// one K=16 step: 6 x MR x NR MFMAs (32x32x16 bf16), smallest partial products first.
+// PA / PB: bytes per bf16 plane of the A / B tile; arow0 / brow0: first tile row of this wave.
+// PERM: tile rows are stored at x3_prow(row) (the weight-gradient loader's conflict-free write pattern).
+__device__ __forceinline__ int x3_prow(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int MR, int NR, int PA, int PB, bool PERM = false>
+__device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *__restrict__ Bs, int arow0, int brow0,
                                        int lane, f32x16 (&acc)[MR][NR]) {
-    constexpr int PA = 64 * MR * 32, PB = 64 * NR * 32;      // bytes per bf16 plane
-    const int l31 = lane & 31;
+    const int l31 = PERM ? x3_prow(lane & 31) : (lane & 31);
     const int swz = ((lane >> 5) ^ ((l31 >> 3) & 1)) << 4;
     bf16x8 a[MR][3], b[NR][3];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            a[mr][q] = *reinterpret_cast<const bf16x8 *>(As + q * PA + (wm * 32 * MR + mr * 32 + l31) * 32 + swz);
+            a[mr][q] = *reinterpret_cast<const bf16x8 *>(As + q * PA + (arow0 + mr * 32 + l31) * 32 + swz);
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            b[nr][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * PB + (wn * 32 * NR + nr * 32 + l31) * 32 + swz);
+            b[nr][q] = *reinterpret_cast<const bf16x8 *>(Bs + q * PB + (brow0 + nr * 32 + l31) * 32 + swz);
     constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 6; ++t)
@@ -365,10 +369,16 @@ __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *
                 acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr][QA[t]], b[nr][QB[t]], acc[mr][nr], 0, 0, 0);
 }
 
-// forward / dgrad with k-contiguous weights B[j][k] (dgrad: the [Cin][R][S][Cout] transposed copy)
-template <int MR, int NR, bool STRIDED>
-__global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
-    constexpr int BM = 64 * MR, BN = 64 * NR, BKT = 16;
+constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descriptor's num_records: loads return 0
+
+// forward / dgrad with k-contiguous weights B[j][k] (dgrad: the [Cin][R][S][Cout] transposed copy).
+// Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32: tile (32 MR WM) x (32 NR WN).
+// Global loads go through buffer descriptors (32-bit byte offsets; an invalid tap / row / K-tail gets an
+// out-of-range offset and the hardware returns zeros: no select on the data, no 64-bit address math).
+template <int MR, int NR, int WM, int WN, bool STRIDED>
+__global__ void __launch_bounds__(64 * WM * WN) igemm_conv_x3_kernel(IgemmParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
     constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -382,15 +392,22 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
 
-    constexpr int TPR = BKT / 4, ROWS = 256 / TPR;           // 4 threads per 16-float row, 64 rows per pass
+    constexpr int TPR = BKT / 4, ROWS = NT / TPR;            // 4 threads per 16-float row
     constexpr int A_PASS = BM / ROWS, B_PASS = BN / ROWS;
+    static_assert(A_PASS >= 1 && B_PASS >= 1, "tile smaller than one loader pass");
     const int kq = tid % TPR, arow = tid / TPR;
     const int st_off = arow * 32 + ((((kq >> 1) ^ ((arow >> 3) & 1))) << 4) + (kq & 1) * 8;   // + ROWS*32 per pass
-    const float *arowp[A_PASS];
-    int ay[A_PASS], ax[A_PASS];
+
     const int HoWo = p.Ho * p.Wo;
+    const int n_first = m0 / HoWo;                            // first image this tile touches (block-uniform)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.A + (long)n_first * p.a_img_stride), 0, (int)X3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Bw), 0, p.b_bytes, 0x00020000);
+
+    int abase[A_PASS];        // float offset of tap (0,0) of the row from the descriptor base (STRIDED: of the image)
+    int ay[A_PASS], ax[A_PASS];
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + arow + ROWS * i;
@@ -401,16 +418,20 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
             const int x = pix - y * p.Wo;
             ay[i] = y * p.up + p.off;
             ax[i] = x * p.up + p.off;
-            arowp[i] = p.A + (long)n * p.a_img_stride + (STRIDED ? 0L : ((long)ay[i] * p.Ws + ax[i]) * p.a_pitch);
+            abase[i] = (n - n_first) * (int)p.a_img_stride + (STRIDED ? 0 : (ay[i] * p.Ws + ax[i]) * p.a_pitch);
         } else {
-            arowp[i] = p.A;
+            abase[i] = 0;
             ay[i] = -(1 << 28);
             ax[i] = -(1 << 28);
         }
     }
+    unsigned bbase[B_PASS];   // byte offset of the weight row (out of range for columns past Ncol)
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+        const int j = n0 + arow + ROWS * i;
+        bbase[i] = j < p.Ncol ? (unsigned)j * (unsigned)p.ldb * 4u : X3_OOB;
+    }
     f32x4 ra[A_PASS], rb[B_PASS];
-    bool va[A_PASS], vb[B_PASS];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
         const int k = kt * BKT + kq * 4;
@@ -420,32 +441,29 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
         const int r = fast_div(rs, p.s_magic);
         const int s = rs - r * p.S;
         const int dy = r * p.step, dx = s * p.step;
-        const long tapoff = ((long)dy * p.Ws + dx) * p.a_pitch + c;
+        const int tapoff = (dy * p.Ws + dx) * p.a_pitch + c;
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             int ty = ay[i] + dy, tx = ax[i] + dx;
             bool v;
-            const float *src;
+            int off;
             if (STRIDED) {
                 v = kv && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);
                 ty /= p.div;
                 tx /= p.div;
                 v = v && ty < p.Hs && tx < p.Ws;
-                src = arowp[i] + ((long)ty * p.Ws + tx) * p.a_pitch + c;
+                off = abase[i] + (ty * p.Ws + tx) * p.a_pitch + c;
             } else {
                 v = kv && (unsigned)ty < (unsigned)p.Hs && (unsigned)tx < (unsigned)p.Ws;
-                src = arowp[i] + tapoff;
+                off = abase[i] + tapoff;
             }
-            ra[i] = *reinterpret_cast<const f32x4 *>(v ? src : p.A);
-            va[i] = v;
+            const unsigned bo = v ? (unsigned)off * 4u : X3_OOB;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
+        const unsigned kb = kv ? (unsigned)k * 4u : X3_OOB;
 #pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            const int j = n0 + arow + ROWS * i;
-            const bool v = kv && j < p.Ncol;
-            rb[i] = *reinterpret_cast<const f32x4 *>(v ? p.Bw + (long)j * p.ldb + k : p.Bw);
-            vb[i] = v;
-        }
+        for (int i = 0; i < B_PASS; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(bbase[i] + kb), 0, 0));
     };
     auto store_tile = [&](int buf) {
         char *As = smem + buf * STAGE;
@@ -453,7 +471,7 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             u32x2 h, m, l;
-            split3(va[i] ? ra[i] : zero4, h, m, l);
+            split3(ra[i], h, m, l);
             char *d = As + st_off + i * ROWS * 32;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PA) = m;
@@ -462,7 +480,7 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
             u32x2 h, m, l;
-            split3(vb[i] ? rb[i] : zero4, h, m, l);
+            split3(rb[i], h, m, l);
             char *d = Bs + st_off + i * ROWS * 32;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PB) = m;
@@ -478,6 +496,7 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
 
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
     const int KT = (p.K + BKT - 1) / BKT;
     load_tile(0);
     store_tile(0);
@@ -487,25 +506,24 @@ __global__ void __launch_bounds__(256) igemm_conv_x3_kernel(IgemmParams p) {
         load_tile(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem + cur * STAGE;
-        mma_x3<MR, NR>(As, As + 3 * PA, wm, wn, lane, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
         store_tile(cur ^ 1);
         __syncthreads();
     }
     {
         const char *As = smem + ((KT - 1) & 1) * STAGE;
-        mma_x3<MR, NR>(As, As + 3 * PA, wm, wn, lane, acc);
+        mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
     }
 
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
-        const int col = n0 + wn * 32 * NR + nr * 32 + l31;
+        const int col = n0 + brow0 + nr * 32 + l31;
         if (col >= p.Ncol) continue;
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
-            const int rbase = m0 + wm * 32 * MR + mr * 32 + 4 * kh;
+            const int rbase = m0 + arow0 + mr * 32 + 4 * kh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + (e & 3) + 8 * (e >> 2);
@@ -695,6 +713,159 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
     }
 }
 
+// Weight gradient on the split-bf16 path.  K = pixels is the strided dimension of both operands (dy and
+// x are channel-contiguous), so the loader transposes in registers: a thread loads one channel quad of
+// FOUR consecutive pixels (4 x float4), and for each of its 4 channels splits the 4 pixel values into
+// bf16 planes and writes them k-contiguous (one ds_write_b64 per plane).  Waves 0-1 stage dy (rows = co),
+// waves 2-3 gather x at the block's tap (rows = c).  Tile rows live at x3_prow(row) so that the 16 lanes
+// of a ds_write_b64 group (4 pixel groups x 4 channel quads) fill one aligned 128-byte window.
+template <int MR, int NR>
+__global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR;
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int rs = (int)blockIdx.y;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+    const int klen = (int)(kend - kbeg);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool isB = tid >= 128;                 // wave-uniform role
+    const int t = tid & 127, g = t & 3, q = t >> 2;
+    const int HoWo = p.Ho * p.Wo;
+    const int n_first = (int)(kbeg / HoWo);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.DY + kbeg * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
+
+    const int ch = (isB ? j0 : i0) + 4 * q;
+    const bool active = isB ? (q < BN / 4 && ch < p.Cin) : (q < BM / 4 && ch < p.Cout);
+    // pixel coordinates of this thread's 4 gathered pixels (B role), advanced by BK per K-step
+    int pn[4], py[4], px_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = kbeg + 4 * g + i;
+        pn[i] = (int)(m / HoWo);
+        const int pix = (int)(m - (long)pn[i] * HoWo);
+        py[i] = pix / p.Wo;
+        px_[i] = pix - py[i] * p.Wo;
+        pn[i] -= n_first;
+    }
+    const int row_l = 4 * q;                                              // first tile row of this thread
+    const int prow0 = x3_prow(row_l);                                     // rows row_l + e -> prow0 + 4 e
+    const int st_off = prow0 * 32 + (g & 1) * 8;                         // bit 3 of prow0 is clear; row e sets it to e>>1
+    const bool incr = p.Wo >= BK;
+
+    f32x4 rr[4];
+    auto load_tile = [&](int kt) {
+        if (!isB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int mk = kt * BK + 4 * g + i;
+                const unsigned bo = (active && mk < klen) ? (unsigned)(mk * p.dy_pitch + ch) * 4u : X3_OOB;
+                rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int mk = kt * BK + 4 * g + i;
+                const int sy = py[i] * p.stride - p.pad + r * p.dil;
+                const int sx = px_[i] * p.stride - p.pad + s * p.dil;
+                const bool v = active && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+                const unsigned bo = v ? (unsigned)(((pn[i] * p.H + sy) * p.W + sx) * p.x_pitch + ch) * 4u : X3_OOB;
+                rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+                if (incr) {
+                    px_[i] += BK;
+                    const bool wx = px_[i] >= p.Wo;
+                    px_[i] -= wx ? p.Wo : 0;
+                    py[i] += wx ? 1 : 0;
+                    const bool wy = py[i] == p.Ho;
+                    py[i] = wy ? 0 : py[i];
+                    pn[i] += wy ? 1 : 0;
+                } else {
+                    const long mn = kbeg + (long)(kt + 1) * BK + 4 * g + i;
+                    const int nn = (int)(mn / HoWo);
+                    const int pix = (int)(mn - (long)nn * HoWo);
+                    pn[i] = nn - n_first;
+                    py[i] = pix / p.Wo;
+                    px_[i] = pix - py[i] * p.Wo;
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *base = smem + buf * STAGE + (isB ? 3 * PA : 0) + st_off;
+        const int plane = isB ? PB : PA;
+        if (q < (isB ? BN : BM) / 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 h, m, l;
+                split3(f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]}, h, m, l);
+                char *d = base + e * 128 + (((g >> 1) ^ (e >> 1)) << 4);  // row prow0 + 4 e, 16-byte halves swizzled
+                *reinterpret_cast<u32x2 *>(d) = h;
+                *reinterpret_cast<u32x2 *>(d + plane) = m;
+                *reinterpret_cast<u32x2 *>(d + 2 * plane) = l;
+            }
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    const int KT = (klen + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *As = smem + cur * STAGE;
+        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    {
+        const char *As = smem + ((KT - 1) & 1) * STAGE;
+        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+    }
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const long row_pitch = (long)p.R * p.S * p.Cin;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int c = j0 + brow0 + nr * 32 + l31;
+        if (c >= p.Cin) continue;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = rbase + (e & 3) + 8 * (e >> 2);
+                if (co < p.Cout) {
+                    float *dst = out + co * row_pitch + (long)rs * p.Cin + c;
+                    float v = acc[mr][nr][e];
+                    if (p.beta && gridDim.z == 1) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
                                      int splits, int beta) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -720,7 +891,8 @@ int check_shape(const rcf_conv_shape *s) {
 
 int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 tile (fp32-MFMA kernels);
                            // bit3: split-bf16 kernels.  -1: built-in default (= 8)
-inline bool use_x3() { return g_conv_variant < 0 || (g_conv_variant & 8) != 0; }
+int g_x3_off = 0;           // debug mask: 1 forward, 2 dgrad, 4 wgrad stay on the fp32-MFMA kernels
+inline bool use_x3(int kind = 0) { return (g_conv_variant < 0 || (g_conv_variant & 8) != 0) && !(g_x3_off & kind); }
 
 inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
@@ -754,24 +926,34 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
 }
 
 // split-bf16 launch (B always k-contiguous)
+int g_x3_tile = -1;        // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 256x128
+
+template <int MR, int NR, int WM, int WN>
+void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st) {
+    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
+    p.mtiles = rcf_cdiv(p.M, BM);
+    p.ntiles = rcf_cdiv(p.Ncol, BN);
+    const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
+    if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false>), grid, dim3(64 * WM * WN), 0, st, p);
+}
+
 int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
     p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
+    const long per_tile_imgs = 256 / ((long)p.Ho * p.Wo) + 2;
+    if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
+    p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
     const bool strided = p.div > 1;
-    const bool wide = p.Ncol > 64;
-    const int BM = 128, BN = wide ? 128 : 64;
-    p.mtiles = rcf_cdiv(p.M, BM);
-    p.ntiles = rcf_cdiv(p.Ncol, BN);
-    const int groups = rcf_cdiv(p.mtiles, 8);
-    const dim3 grid((unsigned)(groups * 8 * p.ntiles));
-    if (strided) {
-        if (wide) hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 2, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 1, true>), grid, dim3(256), 0, st, p);
-    } else {
-        if (wide) hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 2, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_conv_x3_kernel<2, 1, false>), grid, dim3(256), 0, st, p);
-    }
+    int tile = g_x3_tile;
+    if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
+    if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st);
+    else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st);
+    else if (tile == 2) launch_x3_cfg<2, 4, 4, 2>(p, strided, st);
+    else if (tile == 3) launch_x3_cfg<4, 2, 2, 2>(p, strided, st);
+    else launch_x3_cfg<2, 2, 2, 2>(p, strided, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -808,6 +990,12 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
     if (sk < 1) sk = 1;
     long chunk = (M + sk - 1) / sk;
     chunk = (chunk + BK - 1) / BK * BK;
+    if (use_x3(4) && !smallc) {
+        // 32-bit descriptor offsets: the images (and dy rows) one pixel chunk touches must span < 2 GiB
+        const long img_bytes = (long)s->H * s->W * s->x_pitch * 4, HoWo = (long)s->Ho * s->Wo;
+        while (chunk > BK && ((chunk / HoWo + 2) * img_bytes >= (1L << 31) || chunk * s->y_pitch * 4 >= (1L << 31)))
+            chunk = (chunk / 2 + BK - 1) / BK * BK;
+    }
     sk = (M + chunk - 1) / chunk;
     pl.splitk = (int)sk;
     pl.chunk = chunk;
@@ -819,6 +1007,14 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
 /* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
+    g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
+    if (v >= 0) v &= 0xfff;
+    if (v >= 0 && (v & 0x100)) {           // 0x100 | tile << 4: pin the split-bf16 tile (tools/bench_conv.py)
+        g_x3_tile = (v >> 4) & 7;
+        v &= 15;
+    } else {
+        g_x3_tile = -1;
+    }
     g_conv_variant = v;
     return 0;
 }
@@ -834,12 +1030,12 @@ extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *b
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
-    if (use_x3()) return launch_igemm_x3(p, rcf_stream(stream));
+    if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
     return launch_igemm<0>(p, rcf_stream(stream));
 }
 
 extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {
-    if (check_shape(s) || !use_x3()) return 0;
+    if (check_shape(s) || !use_x3(2)) return 0;
     return (size_t)s->Cout * s->R * s->S * s->Cin * sizeof(float);
 }
 
@@ -855,7 +1051,7 @@ extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, 
     p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.ldb = s->R * s->S * s->Cin; p.act = 0; p.slope = 0.f; p.beta = beta;
-    if (use_x3()) {
+    if (use_x3(2)) {
         // k-contiguous weights for the bf16 operand fetch: wt[c][rs][co] (one small transpose per call)
         const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
         if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
@@ -906,7 +1102,13 @@ extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, 
             else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
         }                                                                                                         \
     } while (0)
-    if (pl.mr == 2 && pl.nr == 2) RCF_WGRAD_LAUNCH(2, 2);
+    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr == 2) {     // narrow tiles: the fp32-MFMA kernel is as fast
+        if ((long)(pl.chunk / ((long)s->Ho * s->Wo) + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
+        if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
+        else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
+        else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    } else if (pl.mr == 2 && pl.nr == 2) RCF_WGRAD_LAUNCH(2, 2);
     else if (pl.mr == 2 && pl.nr == 1) RCF_WGRAD_LAUNCH(2, 1);
     else if (pl.mr == 1 && pl.nr == 2) RCF_WGRAD_LAUNCH(1, 2);
     else RCF_WGRAD_LAUNCH(1, 1);

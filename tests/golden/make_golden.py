@@ -252,6 +252,33 @@ def main():
         g64 = {n: o64.get_parameter(n).grad.detach().numpy().ravel()[:256].copy() for n in SAMPLED}
         logits64 = o64.last["logits"].detach()
         masks64 = F.softmax(logits64.view(B, 2, 4, *mask_size), dim=2)
+        # fp32 is not one number: the SAME reference model evaluated with a different (equally valid) reduction
+        # order -- one thread, or channels_last convolutions -- moves its results by more than its default run is
+        # away from the float64 truth.  The yardstick stored as ref32_err_* is the worst of these reference runs.
+        ref32 = dict(loss=[rel(l_ref["loss"].item(), l64["loss"].item())], logits=[rel(logits.numpy(), logits64.numpy())],
+                     masks=[float((masks.double() - masks64).abs().max())],
+                     gradnorm=[[rel(gn_ref[k], gn64[k]) for k in sorted(gn_ref)]], grad=[[rel(g_ref[k], g64[k]) for k in SAMPLED]])
+        for nthreads, cl in ((1, False), (8, True)):
+            torch.set_num_threads(nthreads)
+            rv = ref_models.RCFModel(args, **copy.deepcopy(kw))
+            rv.load_state_dict(sd)
+            if cl:
+                rv = rv.to(memory_format=torch.channels_last)
+            rv.train()
+            with torch.no_grad():
+                sv = copy.deepcopy(rv.state_dict())
+                lg = rv.decode_head2(rv.backbone2(imgs.view(2 * B, 3, H, W)))
+                rv.load_state_dict(sv)
+            lv = rv(torch_batch(nb))
+            lv["loss"].backward()
+            gnv = grad_norms(rv)
+            ref32["loss"].append(rel(lv["loss"].item(), l64["loss"].item()))
+            ref32["logits"].append(rel(lg.numpy(), logits64.numpy()))
+            ref32["masks"].append(float((F.softmax(lg.view(B, 2, 4, *mask_size), dim=2).double() - masks64).abs().max()))
+            ref32["gradnorm"].append([rel(gnv[k], gn64[k]) for k in sorted(gn_ref)])
+            ref32["grad"].append([rel(rv.get_parameter(n).grad.detach().numpy().ravel()[:256], g64[n]) for n in SAMPLED])
+            torch.set_num_threads(8)
+        print(tag, "reference fp32 variants vs float64:", json.dumps(ref32))
         top2 = torch.topk(logits, 2, dim=1).values
         fx = dict(H=H, W=W, B=B, affine=int(affine), weight_seed=7, config_id=1,
                   mask_size=np.array(mask_size),
@@ -265,11 +292,11 @@ def main():
                   sampled=np.array(SAMPLED),
                   truth_loss=np.float64(l64["loss"].item()),
                   truth_gradnorm=np.array([gn64[k] for k in sorted(gn_ref)]),
-                  ref32_err_loss=rel(l_ref["loss"].item(), l64["loss"].item()),
-                  ref32_err_logits=rel(logits.numpy(), logits64.numpy()),
-                  ref32_err_masks=float((masks.double() - masks64).abs().max()),
-                  ref32_err_gradnorm=np.array([rel(gn_ref[k], gn64[k]) for k in sorted(gn_ref)]),
-                  ref32_err_grad=np.array([rel(g_ref[k], g64[k]) for k in SAMPLED]),
+                  ref32_err_loss=max(ref32["loss"]), ref32_err_logits=max(ref32["logits"]),
+                  ref32_err_masks=max(ref32["masks"]),
+                  ref32_err_gradnorm=np.array(ref32["gradnorm"]).max(axis=0),
+                  ref32_err_grad=np.array(ref32["grad"]).max(axis=0),
+                  logit_absmax=np.float64(logits.abs().max().item()),
                   **{"grad_%d" % i: g_ref[k] for i, k in enumerate(SAMPLED)},
                   **{"truth_grad_%d" % i: g64[k] for i, k in enumerate(SAMPLED)},
                   **{"adam_%d" % i: a_ref[k] for i, k in enumerate(SAMPLED)})

@@ -61,6 +61,19 @@ def main():
         o64 = orc.RCFModel(args, **copy.deepcopy(kw))
         o64.load_state_dict(sd)
         l64, g64 = step(o64.double(), dbl=True)
+        # reference fp32 under other (equally valid) reduction orders: 1 thread, channels_last
+        e_l = [{k: mg.rel(l_ref[k], l64[k]) for k in l_ref}]
+        e_g = [{k: mg.rel(g_ref[k], g64[k]) for k in g_ref}]
+        for nthreads, cl in ((1, False), (8, True)):
+            torch.set_num_threads(nthreads)
+            rv = ref_models.RCFModel(args, **copy.deepcopy(kw))
+            rv.load_state_dict(sd)
+            if cl:
+                rv = rv.to(memory_format=torch.channels_last)
+            lv, gv = step(rv)
+            e_l.append({k: mg.rel(lv[k], l64[k]) for k in l_ref})
+            e_g.append({k: mg.rel(gv[k], g64[k]) for k in g_ref})
+            torch.set_num_threads(8)
         chk = {k: mg.rel(l_ora[k], l_ref[k]) for k in l_ref}
         chk.update({"gradnorm." + k: mg.rel(g_ora[k], g_ref[k]) for k in g_ref})
         assert sorted(l_ora) == sorted(l_ref), (sorted(l_ora), sorted(l_ref))
@@ -68,8 +81,8 @@ def main():
         assert max(v for k, v in chk.items() if "loss" in k and "gradnorm" not in k) < 1e-5, name
         out[name] = dict(H=H, W=W, B=B, weight_seed=7, config_id=1, object_channel=oc,
                          loss=l_ref, gradnorm=g_ref, truth_loss=l64, truth_gradnorm=g64,
-                         ref32_err_loss={k: mg.rel(l_ref[k], l64[k]) for k in l_ref},
-                         ref32_err_gradnorm={k: mg.rel(g_ref[k], g64[k]) for k in g_ref},
+                         ref32_err_loss={k: max(e[k] for e in e_l) for k in l_ref},
+                         ref32_err_gradnorm={k: max(e[k] for e in e_g) for k in g_ref},
                          oracle_vs_reference=chk)
     json.dump(out, open(os.path.join(HERE, "variants.json"), "w"), indent=1)
     print("variants.json written")
