@@ -82,7 +82,7 @@ def main():
     for _ in range(a.warmup):
         trainer.step(batch)
     barrier()
-    ops.PROFILE.start("conv_fwd_wide")
+    ops.PROFILE.start("conv_x3_128x256")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = trainer.step(batch)
@@ -121,7 +121,7 @@ def main():
             traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         # The convs run as fp32 contractions on the bf16 matrix cores (each operand split exactly into 3 bf16
         # parts, 6 partial products, fp32 accumulate): the bound is the dense bf16 MFMA peak / 6 passes.
-        out["roofline"] = {"kernel": "igemm_conv_x3_kernel (forward implicit-GEMM conv, split-bf16, Cout > 64)",
+        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false> (implicit-GEMM conv, split-bf16, 128x256 tile: forward and data-gradient launches with > 128 output columns)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": X3_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(ach / X3_MFMA_PEAK_TF, 4), "traffic": traffic, "launches": n,
                            "avg_launch_ms": round(ms / max(n, 1), 4),

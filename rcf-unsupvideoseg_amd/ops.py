@@ -118,8 +118,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
-    if PROFILE.which is not None and s.Cout > 64:
-        end = PROFILE.bracket("conv_fwd_wide", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None and s.Cout > 128:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
+        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), act, slope, beta, _stream())
     if end is not None:
         end.record()
@@ -134,7 +134,12 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0):
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
+    end = None
+    if PROFILE.which is not None and s.Cin > 128 and stride == 1:      # same kernel instance as the wide forward convs
+        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_dgrad_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _p(ws), need, _stream())
+    if end is not None:
+        end.record()
     return out
 
 
