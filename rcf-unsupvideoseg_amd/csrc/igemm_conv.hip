@@ -46,6 +46,7 @@ struct IgemmParams {
     int mtiles, ntiles;
     unsigned cs_magic, s_magic;   // floor(2^32/d)+1 for d = Cs, S (exact k/d for k*d < 2^32; 0 when d == 1)
     int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
+    int dbg;                      // timing experiments only (tools/bench_conv.py): 1 = no global loads after the first K-step
 };
 
 __device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
@@ -376,7 +377,7 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // Global loads go through buffer descriptors (32-bit byte offsets; an invalid tap / row / K-tail gets an
 // out-of-range offset and the hardware returns zeros: no select on the data, no 64-bit address math).
 template <int MR, int NR, int WM, int WN, bool STRIDED>
-__global__ void __launch_bounds__(64 * WM * WN) igemm_conv_x3_kernel(IgemmParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
     constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
@@ -431,9 +432,12 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_conv_x3_kernel(IgemmParams
         const int j = n0 + arow + ROWS * i;
         bbase[i] = j < p.Ncol ? (unsigned)j * (unsigned)p.ldb * 4u : X3_OOB;
     }
-    f32x4 ra[A_PASS], rb[B_PASS];
+    // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets, ping-pong by the parity
+    // of the step); B (weights, L2 resident) one step ahead.
+    f32x4 ra[2][A_PASS], rb[B_PASS];
+    const unsigned dbg_oob = p.dbg ? X3_OOB : 0u;          // timing experiment: every load out of range
 
-    auto load_tile = [&](int kt) {
+    auto load_a = [&](int kt, f32x4 (&dst)[A_PASS]) {
         const int k = kt * BKT + kq * 4;
         const bool kv = k < p.K;
         const int rs = fast_div(k, p.cs_magic);
@@ -445,33 +449,36 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_conv_x3_kernel(IgemmParams
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             int ty = ay[i] + dy, tx = ax[i] + dx;
-            bool v;
-            int off;
+            int v, off;                      // v: 0 / 1, combined with bitwise ops (no short-circuit control flow)
             if (STRIDED) {
-                v = kv && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);
+                v = (int)kv & (int)(ty >= 0) & (int)(tx >= 0) & (int)(ty % p.div == 0) & (int)(tx % p.div == 0);
                 ty /= p.div;
                 tx /= p.div;
-                v = v && ty < p.Hs && tx < p.Ws;
+                v &= (int)(ty < p.Hs) & (int)(tx < p.Ws);
                 off = abase[i] + (ty * p.Ws + tx) * p.a_pitch + c;
             } else {
-                v = kv && (unsigned)ty < (unsigned)p.Hs && (unsigned)tx < (unsigned)p.Ws;
+                v = (int)kv & (int)((unsigned)ty < (unsigned)p.Hs) & (int)((unsigned)tx < (unsigned)p.Ws);
                 off = abase[i] + tapoff;
             }
-            const unsigned bo = v ? (unsigned)off * 4u : X3_OOB;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
+            // invalid -> offset with bit 31 set (beyond num_records): the load returns zeros without touching memory
+            const unsigned bo = (((unsigned)off * 4u) & ~X3_OOB) | ((unsigned)(v - 1) & X3_OOB) | dbg_oob;
+            dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
-        const unsigned kb = kv ? (unsigned)k * 4u : X3_OOB;
+    };
+    auto load_b = [&](int kt) {
+        const int k = kt * BKT + kq * 4;
+        const unsigned k4 = (unsigned)k * 4u, koob = ((unsigned)((int)(k < p.K) - 1) & X3_OOB) | dbg_oob;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i)
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(bbase[i] + kb), 0, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)((bbase[i] + k4) | koob), 0, 0));
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&src)[A_PASS]) {
         char *As = smem + buf * STAGE;
         char *Bs = As + 3 * PA;
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             u32x2 h, m, l;
-            split3(ra[i], h, m, l);
+            split3(src[i], h, m, l);
             char *d = As + st_off + i * ROWS * 32;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PA) = m;
@@ -498,20 +505,45 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_conv_x3_kernel(IgemmParams
 
     const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
     const int KT = (p.K + BKT - 1) / BKT;
-    load_tile(0);
-    store_tile(0);
+    load_a(0, ra[0]);
+    load_b(0);
+    load_a(1, ra[1]);                        // past the end of K: out-of-range offsets, zeros
+    store_tile(0, ra[0]);
     __syncthreads();
-    for (int kt = 0; kt < KT - 1; ++kt) {
-        const int cur = kt & 1;
-        load_tile(kt + 1);
+    // K-step kt: MFMAs on stage kt&1 while B(kt+1) and A(kt+2) are in flight; then A(kt+1) (loaded a step ago) and
+    // B(kt+1) are split into stage (kt+1)&1.  B is issued before A so that its wait does not cover the new A loads.
+    int kt = 0;
+    for (; kt + 2 <= KT - 1; kt += 2) {
+        {   // even step: next A tile is ra[1], the set freed by this step's LDS store is ra[0]
+            load_b(kt + 1);
+            load_a(kt + 2, ra[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const char *As = smem;
+            mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+            store_tile(1, ra[1]);
+            __syncthreads();
+        }
+        {   // odd step
+            load_b(kt + 2);
+            load_a(kt + 3, ra[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const char *As = smem + STAGE;
+            mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+            store_tile(0, ra[0]);
+            __syncthreads();
+        }
+    }
+    if (kt < KT - 1) {                       // one more full step (stage 0 -> stage 1)
+        load_b(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const char *As = smem + cur * STAGE;
+        const char *As = smem;
         mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
-        store_tile(cur ^ 1);
+        store_tile(1, ra[1]);
         __syncthreads();
+        ++kt;
     }
     {
-        const char *As = smem + ((KT - 1) & 1) * STAGE;
+        const char *As = smem + (kt & 1) * STAGE;
         mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
     }
 
@@ -891,6 +923,7 @@ int check_shape(const rcf_conv_shape *s) {
 
 int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 tile (fp32-MFMA kernels);
                            // bit3: split-bf16 kernels.  -1: built-in default (= 8)
+int g_x3_dbg = 0;
 int g_x3_off = 0;           // debug mask: 1 forward, 2 dgrad, 4 wgrad stay on the fp32-MFMA kernels
 inline bool use_x3(int kind = 0) { return (g_conv_variant < 0 || (g_conv_variant & 8) != 0) && !(g_x3_off & kind); }
 
@@ -946,6 +979,7 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
     const long per_tile_imgs = 256 / ((long)p.Ho * p.Wo) + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
+    p.dbg = g_x3_dbg;
     const bool strided = p.div > 1;
     int tile = g_x3_tile;
     if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
@@ -988,6 +1022,16 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
     if (sk > maxsk) sk = maxsk;
     if (sk > 256) sk = 256;
     if (sk < 1) sk = 1;
+    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr == 2) {
+        // the split-bf16 kernel runs 3 workgroups per CU (768 slots): pick the split whose last round is fullest
+        // (time ~ rounds / split; the fixed-order reduction costs ~ split)
+        const long slots = 768, hi = maxsk < 96 ? maxsk : 96;
+        double best = 1e30;
+        for (long c = 1; c <= hi; ++c) {
+            const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
+            if (cost < best - 1e-12) { best = cost; sk = c; }
+        }
+    }
     long chunk = (M + sk - 1) / sk;
     chunk = (chunk + BK - 1) / BK * BK;
     if (use_x3(4) && !smallc) {
@@ -1007,6 +1051,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
 /* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
+    g_x3_dbg = v >= 0 ? (v >> 15) & 1 : 0;
     g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
     if (v >= 0) v &= 0xfff;
     if (v >= 0 && (v & 0x100)) {           // 0x100 | tile << 4: pin the split-bf16 tile (tools/bench_conv.py)
