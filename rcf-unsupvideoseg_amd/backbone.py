@@ -112,10 +112,12 @@ class ResNet(nn.Module):
 
     def fwd(self, img, tape, dist=None):
         """img: Act of the NHWC image zero-padded to 4 channels; returns the list of stage outputs."""
+        tape.mark("stem")
         x = self.bn1.fwd(self.conv1.fwd(img, tape), tape, relu=True, dist=dist)
         x = maxpool3x3s2(x, tape)
         outs = []
         for i in range(self.num_stages):
+            tape.mark(f"layer{i + 1}")
             x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist)
             if i in self.out_indices:
                 outs.append(x)

@@ -89,8 +89,19 @@ __global__ void __launch_bounds__(256) partial_sum_kernel(const double *__restri
     const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + j;
     double acc = 0;
-    if (i < n)
-        for (int k = s; k < chunks; k += 8) acc += partial[(long)k * n + i];
+    if (i < n) {
+        // four independent chains (loads in flight), combined in a fixed order
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int k = s;
+        for (; k + 24 < chunks; k += 32) {
+            a0 += partial[(long)k * n + i];
+            a1 += partial[(long)(k + 8) * n + i];
+            a2 += partial[(long)(k + 16) * n + i];
+            a3 += partial[(long)(k + 24) * n + i];
+        }
+        for (; k < chunks; k += 8) a0 += partial[(long)k * n + i];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     if (s == 0 && i < n) {

@@ -34,12 +34,19 @@ class Act:
 
 
 class Tape:
-    def __init__(self, enabled=True):
-        self.ops, self.enabled = [], enabled
+    def __init__(self, enabled=True, on_mark=None):
+        self.ops, self.enabled, self.on_mark = [], enabled, on_mark
 
     def push(self, fn):
         if self.enabled:
             self.ops.append(fn)
+
+    def mark(self, name):
+        """Pushed BEFORE a group of layers runs forward, so it fires right AFTER their backward: every parameter
+        gradient of the group is final (the trainer starts that chunk's gradient all-reduce there)."""
+        if self.enabled and self.on_mark is not None:
+            cb = self.on_mark
+            self.ops.append(lambda: cb(name))
 
     def backward(self):
         while self.ops:

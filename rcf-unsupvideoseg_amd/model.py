@@ -126,6 +126,7 @@ class RCFModel(nn.Module):
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
         self._tape, self._root_grads, self._anchor = None, None, None
         self.dist = None
+        self.grad_ready_hook = None      # callable(group) set by the trainer: "heads", "layer4" ... "layer1", "stem"
 
     # ------------------------------------------------------------------ plumbing
     def train(self, mode=True):
@@ -160,9 +161,10 @@ class RCFModel(nn.Module):
     def forward_train(self, imgs, gt_fw_flows, gt_bw_flows, pl_masks=None):
         B, I = imgs.shape[:2]
         dist = self._dist()
-        tape = Tape()
+        tape = Tape(on_mark=self.grad_ready_hook)
         img = self._images_nhwc(imgs)
         feats = self.backbone2.fwd(img, tape, dist)
+        tape.mark("heads")                                                       # fires once all three heads are done
         logits = self.decode_head2.fwd(feats, tape, dist)                       # Act [B*I,h,w,C]
         if self.allow_mask_resize and tuple(logits.t.shape[1:3]) != self.mask_size:
             raise NotImplementedError("allow_mask_resize with a mismatching mask_size")

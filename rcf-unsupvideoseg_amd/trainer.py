@@ -3,8 +3,10 @@ data-parallel gradient all-reduce.  Stands in for main.py:158-178 (training_step
 (get_lr / configure_optimizers) and Lightning's DDP wrapper (main.py:453-455).
 
 One process per GPU; `torch.distributed` (backend "nccl" == RCCL over xGMI) carries exactly two
-kinds of traffic: the SyncBN statistics (inside the model) and ONE all-reduce of the flat fp32
-gradient buffer per step (157.9 MB for the stage-1 model) instead of DDP's 25 MB buckets.
+kinds of traffic: the SyncBN statistics (inside the model) and the all-reduce of the flat fp32 gradient
+buffer (157.9 MB for the stage-1 model), issued asynchronously in 6 contiguous chunks as backward finishes
+them (heads, layer4 ... layer1, stem: the tape fires a mark after each group) so that all but the last
+small chunk overlap with the rest of backward -- instead of DDP's 25 MB buckets.
 """
 import math
 
@@ -49,6 +51,25 @@ class FlatParams:
             return chunk.view(co, r, s, ci).permute(0, 3, 1, 2)
         return chunk.view(p.shape)
 
+    def group_ranges(self, model):
+        """Contiguous [start, end) ranges of the flat buffer per backward group, or None if the parameter order
+        does not split that way (then the trainer reduces the whole buffer at the end)."""
+        names = {id(p): n for n, p in model.named_parameters()}
+        ranges, order = {}, []
+        for p, o in zip(self.params, self.offsets):
+            n = names[id(p)]
+            m = n.split(".")
+            g = (m[1] if m[1].startswith("layer") else "stem") if m[0] == "backbone2" else "heads"
+            end = o + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if g not in ranges:
+                ranges[g] = [o, end]
+                order.append(g)
+            elif ranges[g][1] == o:
+                ranges[g][1] = end
+            else:
+                return None
+        return {g: tuple(r) for g, r in ranges.items()}
+
     def bind_grads(self):
         for p, gv in zip(self.params, self.grad_views):
             p.grad = gv
@@ -70,6 +91,18 @@ class Trainer:
         self.betas, self.eps = betas, eps
         self.epoch, self.step_count = 0, 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.ranges = self.fp.group_ranges(self.model) if self.world > 1 else None
+        self._pending, self._done = [], set()
+        if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
+            self.model.grad_ready_hook = self._grads_ready
+
+    def _grads_ready(self, group):
+        """tape mark: the group's gradients are final -> start their all-reduce behind the kernels queued so far"""
+        r = self.ranges.get(group) if self.ranges else None
+        if r is None or group in self._done:
+            return
+        self._done.add(group)
+        self._pending.append(dist.all_reduce(self.fp.grad[r[0]:r[1]], op=dist.ReduceOp.SUM, async_op=True))
 
     def lr(self):
         return self.base_lr * poly_lr_factor(self.epoch, self.epochs, self.power, self.base_lr, self.min_lr)
@@ -81,9 +114,16 @@ class Trainer:
         self.fp.zero_grad()
         with torch.no_grad():
             losses = self.model(batch)
+        self._pending, self._done = [], set()
         self.model.run_backward()
         if self.world > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
+            if self.ranges is None or not hasattr(self.model, "grad_ready_hook"):
+                dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
+            else:
+                for g in self.ranges:                           # groups whose mark did not fire (e.g. a frozen path)
+                    self._grads_ready(g)
+                for h in self._pending:
+                    h.wait()
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
                       self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)

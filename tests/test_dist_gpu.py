@@ -44,6 +44,9 @@ def _worker(rank, world, port, q):
     per = B // world
     losses = tr.step(_batch(nb, slice(rank * per, (rank + 1) * per), "cuda:0"))
     torch.cuda.synchronize()
+    # the gradient all-reduce went out in chunks as backward finished them (tape marks), in backward order
+    assert tr.ranges is not None and len(tr._pending) == 6 and tr._done == {"heads", "layer4", "layer3", "layer2", "layer1", "stem"}
+    assert sum(e - s for s, e in tr.ranges.values()) == tr.fp.total
     names = ["backbone2.layer3.2.conv2.weight", "backbone2.bn1.weight", "backbone2.layer4.0.bn3.bias",
              "decode_head2.convs.0.bn.weight", "decode_head3.conv_seg.bias", "decode_head.flow_feat_after_agg.2.weight"]
     named = dict(m.named_parameters())

@@ -287,6 +287,27 @@ def test_warp_family_vs_golden(golden_dir, report):
         assert e_b < 2e-5 and e_z < 2e-5 and m_b < 2e-3 and m_bi < 2e-3 and e_p < 1e-4 and e_l1 < 1e-5
 
 
+@pytest.mark.parametrize("H,W", [(6, 10), (7, 9), (12, 854)])
+def test_warp_odd_shapes_vs_oracle(H, W, report):
+    """flow_warp / fused warp+L1 on shapes whose rows are not multiples of the wavefront or of 4 (and the real
+    854-pixel row), against the oracle restatement of utils/warp_utils.py:84-94"""
+    import rcf_torch as orc
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    B, C = 2, 3
+    x, y = torch.rand(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g)
+    fl = torch.randn(B, 2, H, W, generator=g) * 2.5
+    occ = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+    for pad in ("border", "zeros"):
+        ref = orc.flow_warp(x, fl, pad=pad)
+        got = ops.flow_warp(x.to(DEV), fl.to(DEV), pad).cpu()
+        e = float((got - ref).abs().max())
+        l1 = ops.warp_l1_residual(y.to(DEV), x.to(DEV), fl.to(DEV), occ.to(DEV), pad).cpu()
+        l1_ref = ((y - ref).abs().sum(1, keepdim=True) * occ).double().sum()
+        e1 = abs(float(l1[0]) - float(l1_ref)) / float(l1_ref)
+        report(f"warp paths {H}x{W} {pad}: warp {e:.2e} fusedL1 {e1:.2e} occ sum {float(l1[1])} vs {float(occ.sum())}")
+        assert e < 2e-5 and e1 < 1e-5 and float(l1[1]) == float(occ.sum())
+
+
 def test_warp_backward(report):
     g = torch.Generator().manual_seed(21)
     B, C, H, W = 2, 3, 17, 23
