@@ -4,8 +4,9 @@
 registry by `type` name, same state-dict keys, same return contract (dict of 0-dim loss tensors in
 training mode whose 'loss' entry supports `.backward()`, softmax masks [B,C,h,w] in eval mode).
 
-Not reproduced: JPEG training visualisations / PNG export (:241-273,:456-462,:562-608) -- they need
-torchvision + flow_vis and are off the arithmetic path.
+The evaluation side effects are reproduced (eval JPEG, `pred_seg_*.png` export, :241-273,:296-315, through
+export.py's stand-in for torchvision.utils.save_image).  Not reproduced: the flow-colour training
+visualisations every `log_interval` steps (:456-462,:562-608; they need flow_vis and are off the arithmetic path).
 """
 import os
 from copy import deepcopy
@@ -14,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .export import save_image
 from .backbone import FCNHead, ResNet
 from .crf import CRFHead
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual
@@ -21,6 +23,15 @@ from .layers import Act, DistCtx, Tape, concat_channels, pair_concat
 
 REGISTRY = dict(ResNet=ResNet, FCNHead=FCNHead, FlowAggregationHeadWithResidual=FlowAggregationHeadWithResidual,
                 CompactnessHead=CompactnessHead, CRFHead=CRFHead)
+
+
+def _rank():
+    import torch.distributed as dist                            # rank_zero_only of the reference
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _item(v):
+    return v.item() if torch.is_tensor(v) else v
 
 
 class _TapeBackward(torch.autograd.Function):
@@ -221,8 +232,42 @@ class RCFModel(nn.Module):
         return ops.resize_nchw(crf.view(B, I, H, W).contiguous(), self.mask_size, self.align_corners)
 
     # ------------------------------------------------------------------ eval forward
+    def resize(self, x, size):
+        """mmseg.ops.resize(bilinear, align_corners=self.align_corners) on NCHW (rcf_model.py:208-214)"""
+        return ops.resize_nchw(x.contiguous().float(), tuple(size), self.align_corners)
+
+    def save_eval_visualizations(self, tosave, paths, seq_ids, seq_names, name="eval", train_iter=0):
+        """rcf_model.py:241-251: one JPEG of the whole batch grid, named after sample 0"""
+        if _rank() != 0:
+            return
+        frame_id = paths[0][0].split("/")[-1][:-4]
+        fn = f"{self.save_dir_eval}/{name}_{seq_names[0]}_{_item(seq_ids[0])}_{frame_id}_{train_iter:07}.jpg"
+        try:
+            save_image(tosave, fn)
+        except Exception as e:                                 # the reference logs and carries on
+            print(f"Error in saving: {fn} {e}")
+
+    def export_seg(self, tosave, paths, seq_ids, seq_names, name="eval", train_iter=0, subdir=""):
+        """rcf_model.py:253-267: one PNG per sample of the batch"""
+        if _rank() != 0:
+            return
+        sub = subdir + "/" if subdir else ""
+        for i, (path, seq_name, _seq_id) in enumerate(zip(paths[0], seq_names, seq_ids)):
+            frame_id = path.split("/")[-1][:-4]
+            fn = f"{self.save_dir_eval_export}/{sub}{name}_{seq_name}_{frame_id}_{train_iter:07}.png"
+            try:
+                save_image(tosave[i], fn)
+            except Exception as e:
+                print(f"Error in saving: {fn} {e}")
+
+    def export_all_seg(self, tosave, paths, seq_ids, seq_names, name="eval", train_iter=0):
+        for idx, item in enumerate(tosave):                    # rcf_model.py:269-273
+            self.export_seg(item, paths, seq_ids, seq_names, name, train_iter, subdir=str(idx))
+
     @torch.no_grad()
-    def forward_eval(self, imgs):
+    def forward_eval(self, imgs, seq_ids=None, seq_names=None, paths=None, return_pred_vis_list=False):
+        """rcf_model.py:275-320: softmax masks of the current frame [B,C,h,w]; with args.eval_save the 2x
+        visualisation grid (and with args.eval_export the object-channel / all-channel PNGs) are written."""
         B, I = imgs.shape[:2]
         t = Tape(enabled=False)
         img = self._images_nhwc(imgs)
@@ -230,7 +275,23 @@ class RCFModel(nn.Module):
             logits = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img, t), t)
         else:
             logits = self.decode_head2.fwd(self.backbone2.fwd(img, t), t)
-        return self.decode_head.softmax_masks(logits.t, B, I)[:, 0]
+        pred_masks = self.decode_head.softmax_masks(logits.t, B, I)[:, 0]
+        want_save = bool(getattr(self.args, "eval_save", False))
+        if not (want_save or return_pred_vis_list):
+            return pred_masks
+        h, w = pred_masks.shape[-2:]
+        img0 = (self.resize(imgs[:, 0], (h * 2, w * 2)) + 2.0) / 4.0
+        vis = [self.resize(pred_masks[:, i:i + 1].contiguous(), (h * 2, w * 2)).repeat(1, 3, 1, 1)
+               for i in range(min(self.mask_layer, pred_masks.shape[1]))]
+        if want_save:
+            self.save_eval_visualizations(torch.cat([img0] + vis, 2), paths, seq_ids, seq_names, train_iter=self.train_iter)
+            if getattr(self.args, "eval_export", False):
+                if getattr(self.args, "export_all_seg", False):
+                    self.export_all_seg(vis, paths, seq_ids, seq_names, name="pred_seg", train_iter=self.train_iter)
+                else:
+                    self.export_seg(vis[self.args.object_channel], paths, seq_ids, seq_names, name="pred_seg",
+                                    train_iter=self.train_iter)
+        return (pred_masks, vis) if return_pred_vis_list else pred_masks
 
     def forward(self, x, return_pred_vis_list=False):
         imgs = torch.stack(x["imgs"], dim=1)
@@ -238,6 +299,4 @@ class RCFModel(nn.Module):
             pl = torch.stack(x["pl_masks"], dim=1) if self.w_pl > 0 else None
             return self.forward_train(imgs, torch.stack(x["gt_fw_flows"], dim=1),
                                       torch.stack(x["gt_bw_flows"], dim=1), pl)
-        if return_pred_vis_list:
-            raise NotImplementedError("visualisation lists are not produced by the HIP model")
-        return self.forward_eval(imgs)
+        return self.forward_eval(imgs, x.get("seq_ids"), x.get("seq_names"), x.get("paths"), return_pred_vis_list)

@@ -115,3 +115,18 @@ def test_unsupported_options_raise_instead_of_silently_diverging():
     m.train()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(batch)
+
+
+def test_export_grid_and_rounding():
+    """export.py (stand-in for torchvision.utils.save_image, absent here: unpinned against it): single image passes
+    through, a batch is tiled with 2-pixel padding, values are rounded as x*255+0.5"""
+    import torch
+    from rcf_amd import export
+    one = torch.rand(1, 3, 5, 7)
+    assert torch.equal(export.make_grid(one), one[0])
+    assert tuple(export.make_grid(torch.rand(5, 7)).shape) == (3, 5, 7)          # grey -> 3 channels
+    g = export.make_grid(torch.ones(10, 3, 5, 7))                                # 8 per row, 2 rows
+    assert tuple(g.shape) == (3, 2 * 7 + 2, 8 * 9 + 2)
+    assert float(g[:, :2].abs().max()) == 0 and float(g[:, 2:7, 2:9].min()) == 1 and float(g[:, 9:14, 20:].max()) == 0
+    u8 = export.to_uint8_hwc(torch.tensor([[[0.0, 0.5, 1.0, 1.2, -0.3, 0.998]]]))
+    assert u8[0, :, 0].tolist() == [0, 128, 255, 255, 0, 254] and u8.shape == (1, 6, 3)

@@ -181,6 +181,45 @@ def test_eval_forward_matches_oracle(report):
     assert tuple(ph.shape) == tuple(po.shape) and e < TOL
 
 
+def test_eval_save_and_export(tmp_path, report):
+    """evaluation side effects of models/rcf_model.py:275-320: the 2x visualisation list, the eval JPEG grid and
+    the `pred_seg_*.png` export (file names and pixel values)"""
+    import torch.nn.functional as F
+    from PIL import Image
+    H, W, B = 64, 96, 2
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel).eval()
+    hip.save_dir_eval, hip.save_dir_eval_export = str(tmp_path / "saved_eval"), str(tmp_path / "saved_eval_export")
+    hip.args.eval_save, hip.args.eval_export, hip.args.object_channel = True, True, 1
+    hip.train_iter = 42
+    batch = _batch(B, H, W, DEV)
+    batch["paths"] = [[f"/data/JPEGImages/480p/seq{i}/{i:05d}.jpg" for i in range(B)]] * 2
+    batch["seq_names"], batch["seq_ids"] = [f"seq{i}" for i in range(B)], torch.tensor([3, 4])
+    with torch.no_grad():
+        masks, vis = hip(batch, return_pred_vis_list=True)
+    h, w = masks.shape[-2:]
+    assert len(vis) == 4 and tuple(vis[0].shape) == (B, 3, 2 * h, 2 * w)
+    up = F.interpolate(masks[:, 1:2].cpu(), size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+    e_vis = float((vis[1][:, 0].cpu() - up[:, 0]).abs().max())
+    jpg = tmp_path / "saved_eval" / "eval_seq0_3_00000_0000042.jpg"
+    pngs = [tmp_path / "saved_eval_export" / f"pred_seg_seq{i}_{i:05d}_0000042.png" for i in range(B)]
+    assert jpg.exists() and all(p.exists() for p in pngs), list(tmp_path.rglob("*"))
+    grid = np.asarray(Image.open(jpg))
+    assert grid.shape == (5 * 2 * h + 4, 2 * (2 * w + 2) + 2, 3)          # make_grid of B=2 images, padding 2
+    worst = 0
+    for i, p in enumerate(pngs):
+        img = np.asarray(Image.open(p)).astype(np.int32)
+        want = (up[i, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).numpy().astype(np.int32)
+        assert img.shape == (2 * h, 2 * w, 3)
+        worst = max(worst, int(np.abs(img[..., 0] - want).max()))
+    report(f"eval export: vis list vs torch bilinear {e_vis:.2e}, PNG max |u8 diff| {worst}")
+    assert e_vis < 2e-5 and worst <= 1
+    # all-channel export goes to numbered sub-directories
+    hip.args.export_all_seg = True
+    with torch.no_grad():
+        hip(batch)
+    assert all((tmp_path / "saved_eval_export" / str(c) / "pred_seg_seq0_00000_0000042.png").exists() for c in range(4))
+
+
 def test_fullsize_480x854_vs_reference_golden(golden_dir, report):
     """BASELINE config-1 geometry (480x854, mask 120x214), one pair, against the reference's own output."""
     fx = np.load(os.path.join(golden_dir, "rcf_480x854_b1.npz"))
