@@ -43,17 +43,32 @@ typedef struct {
 
 int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                        int act, float slope, int beta, void *stream);
+/* The same operators restricted to a rectangle of pixels (all channels): `region` is in OUTPUT coordinates for
+ * fwd (only those pixels of y are written) and wgrad (only those pixels of dy/x-patches contribute), in INPUT
+ * coordinates for dgrad (only those pixels of dx are written).  NULL = the whole tensor.  Used to evaluate
+ * conv(bilinear_2x(x)) as bilinear_2x(conv_half_dilation(x)) in the interior and directly on the border band
+ * (models/fcn_head.py:211-218 with input_transform='resize_concat'). */
+typedef struct { int y0, x0, h, w; } rcf_conv_region;
+int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
+                              const rcf_conv_region *region, int act, float slope, int beta, void *stream);
 /* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w).
  * `workspace` (rcf_conv2d_dgrad_workspace_bytes) holds the transposed weights [Cin][R][S][Cout] the
  * split-bf16 kernels contract against. */
 size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
                          void *workspace, size_t workspace_bytes, void *stream);
+int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s,
+                                const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
+                                void *stream);
 /* dw[Cout][R][S][Cin] (+)= sum_pixels dy * x.  Split over pixels into `workspace`, then reduced
  * deterministically (no float atomics). */
 size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta,
                          void *workspace, size_t workspace_bytes, void *stream);
+size_t rcf_conv2d_wgrad_region_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region);
+int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s,
+                                const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* tuning knob for A/B measurements of the conv kernels: bit0 K-step 32, bit1 row-major LDS tiles;
  * -1 restores the built-in default.  Results are identical up to fp32 summation order. */

@@ -20,6 +20,11 @@ class ConvShape(ctypes.Structure):
                                      "x_pitch", "y_pitch")]
 
 
+class ConvRegion(ctypes.Structure):
+    """mirror of rcf_conv_region"""
+    _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w")]
+
+
 class FlowHeadCfg(ctypes.Structure):
     """mirror of rcf_flowhead_cfg"""
     _fields_ = [(n, c_int) for n in ("B", "C", "h", "w", "logits_pitch", "nf", "D", "robust", "tanh_residual")] + \
@@ -33,11 +38,16 @@ class FlowHeadCfg(ctypes.Structure):
 P = c_void_p
 _CS = ctypes.POINTER(ConvShape)
 _FH = ctypes.POINTER(FlowHeadCfg)
+_CR = ctypes.POINTER(ConvRegion)
 
 # name -> (restype, argtypes); every int-returning entry point is status-checked by `call`
 PROTOS = {
     "rcf_version": (c_char_p, []),
     "rcf_conv2d_fwd_f32": (c_int, [P, P, P, P, _CS, c_int, c_float, c_int, P]),
+    "rcf_conv2d_fwd_region_f32": (c_int, [P, P, P, P, _CS, _CR, c_int, c_float, c_int, P]),
+    "rcf_conv2d_dgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
+    "rcf_conv2d_wgrad_region_workspace_bytes": (c_size_t, [_CS, _CR]),
+    "rcf_conv2d_wgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
     "rcf_conv_set_variant": (c_int, [c_int]),

@@ -44,7 +44,8 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *cnt;              // [F][E]   entries per vertex, then fill cursor
     int *off;              // [F][E]   CSR offsets (exclusive scan of cnt)
     int2 *csr;             // [F][E]   (pixel, weight bits) grouped by vertex
-    float4 *val0, *val1;   // [F][E]   ping-pong blurred values
+    float2 *val0, *val1;   // [F][E]   ping-pong blurred label values (float [F][E] for the homogeneous channel at build time)
+    float *inv;            // [F][N]   1 / (sliced homogeneous channel): iteration invariant, computed at build time
     int *blocksum;         // [F][nblk+1]
     int *L;                // [F]      vertex counts
 };
@@ -437,20 +438,28 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // lists of up to SHORT entries are summed by their own lane (noise-like images: ~1 entry per vertex),
 // longer lists (smooth images: tens to thousands of entries) by the whole wavefront, one after another.
 constexpr int SHORT_LIST = 6;
-__device__ __forceinline__ void acc_entry(const int2 pw, const float *__restrict__ Qf, long long &a0, long long &a1,
-                                          long long &a2) {
+// MODE 0: the two label channels (Q0*w, Q1*w) -> float2.  MODE 1: the homogeneous channel (w) -> float; it does not
+// depend on Q, so it is splatted, blurred and sliced ONCE per lattice (build_lattice) instead of every iteration
+// (same operations on the same inputs as the reference's third value channel: bit-identical normalisation).
+template <int MODE>
+__device__ __forceinline__ void acc_entry(const int2 pw, const float *__restrict__ Qf, long long &a0, long long &a1) {
     const float wgt = __int_as_float(pw.y);
-    const float2 q = *reinterpret_cast<const float2 *>(Qf + (long)pw.x * MLAB);
-    a0 += __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
-    a1 += __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
-    a2 += __double2ll_rn((double)wgt * FIX_SCALE);
+    if (MODE == 0) {
+        const float2 q = *reinterpret_cast<const float2 *>(Qf + (long)pw.x * MLAB);
+        a0 += __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
+        a1 += __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
+    } else {
+        a0 += __double2ll_rn((double)wgt * FIX_SCALE);
+    }
 }
-__device__ __forceinline__ float4 fixed_to_val(long long a0, long long a1, long long a2) {
-    return make_float4((float)((double)a0 * (1.0 / FIX_SCALE)), (float)((double)a1 * (1.0 / FIX_SCALE)),
-                       (float)((double)a2 * (1.0 / FIX_SCALE)), 0.f);
+__device__ __forceinline__ float fixed_to_float(long long a) { return (float)((double)a * (1.0 / FIX_SCALE)); }
+template <int MODE>
+__device__ __forceinline__ void store_val(void *out, long i, long long a0, long long a1) {
+    if (MODE == 0) reinterpret_cast<float2 *>(out)[i] = make_float2(fixed_to_float(a0), fixed_to_float(a1));
+    else reinterpret_cast<float *>(out)[i] = fixed_to_float(a0);
 }
-__global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q,
-                                                           float4 *__restrict__ out) {
+template <int MODE>
+__global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q, void *__restrict__ out) {
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const long Lf = Lt.L[f];
@@ -465,50 +474,67 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
         int beg = 0, n = 0;
         if (lane < chunk && v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
         if (n > 0 && n <= SHORT_LIST) {
-            long long a0 = 0, a1 = 0, a2 = 0;
-            for (int i = 0; i < n; i++) acc_entry(Lt.csr[fb + beg + i], Qf, a0, a1, a2);
-            out[fb + v] = fixed_to_val(a0, a1, a2);
+            long long a0 = 0, a1 = 0;
+            for (int i = 0; i < n; i++) acc_entry<MODE>(Lt.csr[fb + beg + i], Qf, a0, a1);
+            store_val<MODE>(out, fb + v, a0, a1);
         }
         unsigned long long longm = __ballot(n > SHORT_LIST);
         while (longm) {
             const int j = __ffsll((long long)longm) - 1;
             longm &= longm - 1;
             const int bj = __shfl(beg, j, 64), nj = __shfl(n, j, 64);
-            long long a0 = 0, a1 = 0, a2 = 0;
-            for (int i = lane; i < nj; i += 64) acc_entry(Lt.csr[fb + bj + i], Qf, a0, a1, a2);
+            long long a0 = 0, a1 = 0;
+            for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, a0, a1);
             a0 = wave_sum_ll(a0);
-            a1 = wave_sum_ll(a1);
-            a2 = wave_sum_ll(a2);
-            if (lane == 0) out[fb + v0 + j] = fixed_to_val(a0, a1, a2);
+            if (MODE == 0) a1 = wave_sum_ll(a1);
+            if (lane == 0) store_val<MODE>(out, fb + v0 + j, a0, a1);
         }
     }
 }
 
-// one blur pass along `axis`: new = 1/4 n+ + 1/2 me + 1/4 n-, missing neighbour = 0
-__global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const float4 *__restrict__ in,
-                                                   float4 *__restrict__ out) {
+__device__ __forceinline__ float2 blur3(float2 p, float2 m, float2 q) {
+    return make_float2(0.25f * p.x + 0.5f * m.x + 0.25f * q.x, 0.25f * p.y + 0.5f * m.y + 0.25f * q.y);
+}
+__device__ __forceinline__ float blur3(float p, float m, float q) { return 0.25f * p + 0.5f * m + 0.25f * q; }
+__device__ __forceinline__ void zero_of(float2 &v) { v = make_float2(0.f, 0.f); }
+__device__ __forceinline__ void zero_of(float &v) { v = 0.f; }
+
+// one blur pass along `axis`: new = 1/4 n+ + 1/2 me + 1/4 n-, missing neighbour = 0.  T = float2 (labels) / float
+template <class T>
+__global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T *__restrict__ in, T *__restrict__ out) {
     const int f = blockIdx.y;
     const int nax2 = 2 * (Lt.pd + 1);
     const long Lf = Lt.L[f];
     const long fb = (long)f * Lt.E;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.x * blockDim.x) {
         const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb + v) * nax2 + 2 * axis);
-        const float4 me = in[fb + v];
-        float4 vp = make_float4(0, 0, 0, 0), vm = make_float4(0, 0, 0, 0);
+        const T me = in[fb + v];
+        T vp, vm;
+        zero_of(vp);
+        zero_of(vm);
         if (n.x >= 0) vp = in[fb + n.x];
         if (n.y >= 0) vm = in[fb + n.y];
-        float4 o;
-        o.x = 0.25f * vp.x + 0.5f * me.x + 0.25f * vm.x;
-        o.y = 0.25f * vp.y + 0.5f * me.y + 0.25f * vm.y;
-        o.z = 0.25f * vp.z + 0.5f * me.z + 0.25f * vm.z;
-        o.w = 0.f;
-        out[fb + v] = o;
+        out[fb + v] = blur3(vp, me, vm);
     }
+}
+
+// build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
+__global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float *__restrict__ z) {
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Lt.N) return;
+    const long fb = (long)f * Lt.E;
+    float sw = 0;
+    for (int r = 0; r <= Lt.pd; r++) {
+        const long pe = fb + (long)r * Lt.N + p;
+        sw += Lt.weight[pe] * z[fb + Lt.vid[pe]];
+    }
+    Lt.inv[(long)f * Lt.N + p] = (float)(1.0 / sw);
 }
 
 // slice + Potts weight + (optionally) softmax and MAP.
 //   first: next = -U, else next = next_in;  next += w * slice;  last: Q = softmax(next) (+ MAP)
-__global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float4 *__restrict__ val,
+__global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__restrict__ val,
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
                                                     int last, int write_map) {
@@ -517,16 +543,15 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float4 *__
     if (p >= Lt.N) return;
     const int nax = Lt.pd + 1;
     const long fb = (long)f * Lt.E;
-    float s0 = 0, s1 = 0, sw = 0;
+    float s0 = 0, s1 = 0;
     for (int r = 0; r < nax; r++) {
         const long pe = fb + (long)r * Lt.N + p;
         const float wgt = Lt.weight[pe];
-        const float4 v = val[fb + Lt.vid[pe]];
+        const float2 v = val[fb + Lt.vid[pe]];
         s0 += wgt * v.x;
         s1 += wgt * v.y;
-        sw += wgt * v.z;
     }
-    const float inv = (float)(1.0 / sw);
+    const float inv = Lt.inv[(long)f * Lt.N + p];
     const long qi = ((long)f * Lt.N + p) * MLAB;
     float n0, n1;
     if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
@@ -664,8 +689,9 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
     L.cnt = c.take<int>(FE);
     L.off = c.take<int>(FE);
     L.csr = c.take<int2>(FE);
-    L.val0 = c.take<float4>(FE);
-    L.val1 = c.take<float4>(FE);
+    L.val0 = c.take<float2>(FE);
+    L.val1 = c.take<float2>(FE);
+    L.inv = c.take<float>((size_t)F * N);
     L.blocksum = c.take<int>((size_t)F * (scan_blocks(L.E) + 1));
     L.L = c.take<int>(F);
 }
@@ -712,6 +738,14 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
     hipLaunchKernelGGL(csr_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(csr_fill_kernel, ge, dim3(256), 0, st, L);
+    // homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
+    float *za = reinterpret_cast<float *>(L.val0), *zb = reinterpret_cast<float *>(L.val1);
+    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(4096, F), dim3(256), 0, st, L, (const float *)nullptr, (void *)za);
+    for (int axis = 0; axis <= L.pd; axis++) {
+        hipLaunchKernelGGL(blur_kernel<float>, dim3(1024, F), dim3(256), 0, st, L, axis, (const float *)za, zb);
+        float *t = za; za = zb; zb = t;
+    }
+    hipLaunchKernelGGL(slice_norm_kernel, gp, dim3(256), 0, st, L, (const float *)za);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -720,13 +754,13 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
                   int first, int last, int write_map, hipStream_t st) {
     const dim3 gv(1024, F), gp(rcf_cdiv(L.N, 256), F);
-    float4 *a = L.val0, *b = L.val1;
-    hipLaunchKernelGGL(splat_gather_kernel, dim3(4096, F), dim3(256), 0, st, L, Q, a);
+    float2 *a = L.val0, *b = L.val1;
+    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(4096, F), dim3(256), 0, st, L, Q, (void *)a);
     for (int axis = 0; axis <= L.pd; axis++) {
-        hipLaunchKernelGGL(blur_kernel, gv, dim3(256), 0, st, L, axis, (const float4 *)a, b);
-        float4 *t = a; a = b; b = t;
+        hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
+        float2 *t = a; a = b; b = t;
     }
-    hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float4 *)a, unary, next, Qout, map, first, last,
+    hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last,
                        write_map);
     RCF_LAUNCH_CHECK();
     return 0;

@@ -47,6 +47,9 @@ struct IgemmParams {
     unsigned cs_magic, s_magic;   // floor(2^32/d)+1 for d = Cs, S (exact k/d for k*d < 2^32; 0 when d == 1)
     int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
     int dbg;                      // timing experiments only (tools/bench_conv.py): 1 = no global loads after the first K-step
+    // split-bf16 kernels: the GEMM rows are the pixels of the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of every image
+    // of the [N, Ho, Wo] row tensor (M = N*rh*rw); the full tensor is the rectangle (0, 0, Ho, Wo)
+    int ry0, rx0, rh, rw;
 };
 
 __device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
@@ -401,7 +404,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const int kq = tid % TPR, arow = tid / TPR;
     const int st_off = arow * 32 + ((((kq >> 1) ^ ((arow >> 3) & 1))) << 4) + (kq & 1) * 8;   // + ROWS*32 per pass
 
-    const int HoWo = p.Ho * p.Wo;
+    const int HoWo = p.rh * p.rw;                             // rows per image (the region's pixels)
     const int n_first = m0 / HoWo;                            // first image this tile touches (block-uniform)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.A + (long)n_first * p.a_img_stride), 0, (int)X3_OOB, 0x00020000);
@@ -415,8 +418,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         if (m < p.M) {
             const int n = m / HoWo;
             const int pix = m - n * HoWo;
-            const int y = pix / p.Wo;
-            const int x = pix - y * p.Wo;
+            const int yr = pix / p.rw;
+            const int y = yr + p.ry0, x = pix - yr * p.rw + p.rx0;
             ay[i] = y * p.up + p.off;
             ax[i] = x * p.up + p.off;
             abase[i] = (n - n_first) * (int)p.a_img_stride + (STRIDED ? 0 : (ay[i] * p.Ws + ax[i]) * p.a_pitch);
@@ -547,25 +550,37 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
     }
 
+    // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int l31 = lane & 31, kh = lane >> 5;
+    const bool full = p.rh == p.Ho && p.rw == p.Wo;           // rows map linearly onto the output tensor
+    float bv[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = n0 + brow0 + nr * 32 + l31;
-        if (col >= p.Ncol) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        bv[nr] = (p.bias && col < p.Ncol) ? p.bias[col] : 0.f;
+    }
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            const int rbase = m0 + arow0 + mr * 32 + 4 * kh;
+    for (int mr = 0; mr < MR; ++mr) {
+        const int rbase = m0 + arow0 + mr * 32 + 4 * kh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = rbase + (e & 3) + 8 * (e >> 2);
-                if (row < p.M) {
-                    float *dst = p.Y + (long)row * p.y_pitch + col;
-                    float v = acc[mr][nr][e] + bv;
-                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                    if (p.beta) v += *dst;
-                    *dst = v;
-                }
+        for (int e = 0; e < 16; ++e) {
+            const int row = rbase + (e & 3) + 8 * (e >> 2);
+            if (row >= p.M) continue;
+            long lin = row;
+            if (!full) {
+                const int n = row / HoWo;
+                const int pix = row - n * HoWo;
+                const int yr = pix / p.rw;
+                lin = ((long)n * p.Ho + yr + p.ry0) * p.Wo + (pix - yr * p.rw + p.rx0);
+            }
+            float *drow = p.Y + lin * p.y_pitch + n0 + brow0 + l31;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (n0 + brow0 + nr * 32 + l31 >= p.Ncol) continue;
+                float v = acc[mr][nr][e] + bv[nr];
+                if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                if (p.beta) v += drow[nr * 32];
+                drow[nr * 32] = v;
             }
         }
     }
@@ -600,6 +615,7 @@ struct WgradParams {
     int itiles, jtiles;
     long split_stride; // Cout*R*S*Cin
     int beta;          // only honoured when gridDim.z == 1
+    int ry0, rx0, rh, rw;   // split-bf16 kernel: contributing output pixels = this rectangle of every image (M = N*rh*rw)
 };
 
 // dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
@@ -769,65 +785,63 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const bool isB = tid >= 128;                 // wave-uniform role
     const int t = tid & 127, g = t & 3, q = t >> 2;
-    const int HoWo = p.Ho * p.Wo;
+    const int HoWo = p.rh * p.rw;                 // contributing pixels per image
     const int n_first = (int)(kbeg / HoWo);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.DY + kbeg * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
+        const_cast<float *>(p.DY + (long)n_first * p.Ho * p.Wo * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
 
     const int ch = (isB ? j0 : i0) + 4 * q;
     const bool active = isB ? (q < BN / 4 && ch < p.Cin) : (q < BM / 4 && ch < p.Cout);
-    // pixel coordinates of this thread's 4 gathered pixels (B role), advanced by BK per K-step
+    // (image, row, column) of this thread's 4 pixels inside the rectangle, advanced by BK per K-step
     int pn[4], py[4], px_[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long m = kbeg + 4 * g + i;
         pn[i] = (int)(m / HoWo);
         const int pix = (int)(m - (long)pn[i] * HoWo);
-        py[i] = pix / p.Wo;
-        px_[i] = pix - py[i] * p.Wo;
+        py[i] = pix / p.rw;
+        px_[i] = pix - py[i] * p.rw;
         pn[i] -= n_first;
     }
     const int row_l = 4 * q;                                              // first tile row of this thread
     const int prow0 = x3_prow(row_l);                                     // rows row_l + e -> prow0 + 4 e
     const int st_off = prow0 * 32 + (g & 1) * 8;                         // bit 3 of prow0 is clear; row e sets it to e>>1
-    const bool incr = p.Wo >= BK;
+    const bool incr = p.rw >= BK;
 
     f32x4 rr[4];
     auto load_tile = [&](int kt) {
-        if (!isB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int mk = kt * BK + 4 * g + i;
-                const unsigned bo = (active && mk < klen) ? (unsigned)(mk * p.dy_pitch + ch) * 4u : X3_OOB;
+        for (int i = 0; i < 4; ++i) {
+            const int mk = kt * BK + 4 * g + i;
+            const int oy = py[i] + p.ry0, ox = px_[i] + p.rx0;              // output pixel in the image
+            if (!isB) {
+                const bool v = active && mk < klen;
+                const unsigned bo = v ? (unsigned)(((pn[i] * p.Ho + oy) * p.Wo + ox) * p.dy_pitch + ch) * 4u : X3_OOB;
                 rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int mk = kt * BK + 4 * g + i;
-                const int sy = py[i] * p.stride - p.pad + r * p.dil;
-                const int sx = px_[i] * p.stride - p.pad + s * p.dil;
+            } else {
+                const int sy = oy * p.stride - p.pad + r * p.dil;
+                const int sx = ox * p.stride - p.pad + s * p.dil;
                 const bool v = active && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
                 const unsigned bo = v ? (unsigned)(((pn[i] * p.H + sy) * p.W + sx) * p.x_pitch + ch) * 4u : X3_OOB;
                 rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
-                if (incr) {
-                    px_[i] += BK;
-                    const bool wx = px_[i] >= p.Wo;
-                    px_[i] -= wx ? p.Wo : 0;
-                    py[i] += wx ? 1 : 0;
-                    const bool wy = py[i] == p.Ho;
-                    py[i] = wy ? 0 : py[i];
-                    pn[i] += wy ? 1 : 0;
-                } else {
-                    const long mn = kbeg + (long)(kt + 1) * BK + 4 * g + i;
-                    const int nn = (int)(mn / HoWo);
-                    const int pix = (int)(mn - (long)nn * HoWo);
-                    pn[i] = nn - n_first;
-                    py[i] = pix / p.Wo;
-                    px_[i] = pix - py[i] * p.Wo;
-                }
+            }
+            if (incr) {                          // rw >= BK: at most one row wrap per K-step
+                px_[i] += BK;
+                const bool wx = px_[i] >= p.rw;
+                px_[i] -= wx ? p.rw : 0;
+                py[i] += wx ? 1 : 0;
+                const bool wy = py[i] == p.rh;
+                py[i] = wy ? 0 : py[i];
+                pn[i] += wy ? 1 : 0;
+            } else {
+                const long mn = kbeg + (long)(kt + 1) * BK + 4 * g + i;
+                const int nn = (int)(mn / HoWo);
+                const int pix = (int)(mn - (long)nn * HoWo);
+                pn[i] = nn - n_first;
+                py[i] = pix / p.rw;
+                px_[i] = pix - py[i] * p.rw;
             }
         }
     };
@@ -976,7 +990,7 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
-    const long per_tile_imgs = 256 / ((long)p.Ho * p.Wo) + 2;
+    const long per_tile_imgs = 256 / ((long)p.rh * p.rw) + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
     p.dbg = g_x3_dbg;
@@ -1007,7 +1021,7 @@ struct WgradPlan {
     int mr, nr, itiles, jtiles, splitk;
     long chunk;
 };
-WgradPlan plan_wgrad(const rcf_conv_shape *s) {
+WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullptr) {
     WgradPlan pl;
     const bool smallc = s->Cin == 4;
     const int ncols = smallc ? s->R * s->S * 4 : s->Cin;
@@ -1015,7 +1029,8 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
     pl.nr = ncols > 64 ? 2 : 1;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ncols, 64 * pl.nr);
-    const long M = (long)s->N * s->Ho * s->Wo;
+    const long RR = reg ? (long)reg->h * reg->w : (long)s->Ho * s->Wo;      // contributing pixels per image
+    const long M = (long)s->N * RR;
     const long tiles = (long)pl.itiles * pl.jtiles * (smallc ? 1 : s->R * s->S);
     long sk = (1536 + tiles - 1) / tiles;
     const long maxsk = M / 1024 > 1 ? M / 1024 : 1;
@@ -1036,8 +1051,8 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s) {
     chunk = (chunk + BK - 1) / BK * BK;
     if (use_x3(4) && !smallc) {
         // 32-bit descriptor offsets: the images (and dy rows) one pixel chunk touches must span < 2 GiB
-        const long img_bytes = (long)s->H * s->W * s->x_pitch * 4, HoWo = (long)s->Ho * s->Wo;
-        while (chunk > BK && ((chunk / HoWo + 2) * img_bytes >= (1L << 31) || chunk * s->y_pitch * 4 >= (1L << 31)))
+        const long img_bytes = (long)s->H * s->W * s->x_pitch * 4, dy_bytes = (long)s->Ho * s->Wo * s->y_pitch * 4;
+        while (chunk > BK && ((chunk / RR + 2) * img_bytes >= (1L << 31) || (chunk / RR + 2) * dy_bytes >= (1L << 31)))
             chunk = (chunk / 2 + BK - 1) / BK * BK;
     }
     sk = (M + chunk - 1) / chunk;
@@ -1064,18 +1079,36 @@ extern "C" int rcf_conv_set_variant(int v) {
     return 0;
 }
 
+namespace {
+// rectangle of the GEMM-row tensor [N, H, W]; null = everything.  Returns 0 / RCF_EINVAL.
+int set_region(IgemmParams &p, const rcf_conv_region *r, int N, int H, int W) {
+    p.ry0 = r ? r->y0 : 0; p.rx0 = r ? r->x0 : 0; p.rh = r ? r->h : H; p.rw = r ? r->w : W;
+    if (p.ry0 < 0 || p.rx0 < 0 || p.rh <= 0 || p.rw <= 0 || p.ry0 + p.rh > H || p.rx0 + p.rw > W) return RCF_EINVAL;
+    p.M = N * p.rh * p.rw;
+    return 0;
+}
+}  // namespace
+
 extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                                   const rcf_conv_shape *s, int act, float slope, int beta, void *stream) {
+    return rcf_conv2d_fwd_region_f32(x, w, bias, y, s, nullptr, act, slope, beta, stream);
+}
+
+extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y,
+                                         const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope,
+                                         int beta, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!x || !w || !y || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
     IgemmParams p{};
     p.A = x; p.Bw = w; p.bias = bias; p.Y = y;
-    p.M = s->N * s->Ho * s->Wo; p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
+    p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
     p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
+    if (int e = set_region(p, region, s->N, s->Ho, s->Wo)) return e;
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
     if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
+    if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
     return launch_igemm<0>(p, rcf_stream(stream));
 }
 
@@ -1086,13 +1119,20 @@ extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {
 
 extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
                                     void *workspace, size_t workspace_bytes, void *stream) {
+    return rcf_conv2d_dgrad_region_f32(dy, w, dx, s, nullptr, beta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s,
+                                           const rcf_conv_region *region, int beta, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
     if (s->Cout % 4) return RCF_EINVAL;
     IgemmParams p{};
     p.A = dy; p.Bw = w; p.bias = nullptr; p.Y = dx;
-    p.M = s->N * s->H * s->W; p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
+    p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
     p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
+    if (int e = set_region(p, region, s->N, s->H, s->W)) return e;
     p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.ldb = s->R * s->S * s->Cin; p.act = 0; p.slope = 0.f; p.beta = beta;
@@ -1107,23 +1147,40 @@ extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, 
         p.ldb = p.K;
         return launch_igemm_x3(p, st);
     }
+    if (region) return RCF_EINVAL;
     return launch_igemm<1>(p, rcf_stream(stream));
 }
 
+namespace {
+bool region_ok(const rcf_conv_region *r, int H, int W) {
+    return !r || (r->y0 >= 0 && r->x0 >= 0 && r->h > 0 && r->w > 0 && r->y0 + r->h <= H && r->x0 + r->w <= W);
+}
+}  // namespace
+
 extern "C" size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s) {
-    if (check_shape(s)) return 0;
-    const WgradPlan pl = plan_wgrad(s);
+    return rcf_conv2d_wgrad_region_workspace_bytes(s, nullptr);
+}
+
+extern "C" size_t rcf_conv2d_wgrad_region_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region) {
+    if (check_shape(s) || !region_ok(region, s->Ho, s->Wo)) return 0;
+    const WgradPlan pl = plan_wgrad(s, region);
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * s->Cout * s->R * s->S * s->Cin * sizeof(float);
 }
 
 extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta,
                                     void *workspace, size_t workspace_bytes, void *stream) {
+    return rcf_conv2d_wgrad_region_f32(x, dy, dw, s, nullptr, beta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, float *dw, const rcf_conv_shape *s,
+                                           const rcf_conv_region *region, int beta, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!x || !dy || !dw || !rcf_aligned16(x) || !rcf_aligned16(dy) || !rcf_aligned16(dw)) return RCF_EINVAL;
-    if (s->Cout % 4) return RCF_EINVAL;
-    const WgradPlan pl = plan_wgrad(s);
-    const size_t need = rcf_conv2d_wgrad_workspace_bytes(s);
+    if (s->Cout % 4 || !region_ok(region, s->Ho, s->Wo)) return RCF_EINVAL;
+    const WgradPlan pl = plan_wgrad(s, region);
+    const size_t need = rcf_conv2d_wgrad_region_workspace_bytes(s, region);
     if (need > 0 && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
     hipStream_t st = rcf_stream(stream);
     WgradParams p{};
@@ -1132,9 +1189,12 @@ extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, 
     p.Cout = s->Cout; p.Cin = s->Cin; p.R = s->R; p.S = s->S;
     p.H = s->H; p.W = s->W; p.Ho = s->Ho; p.Wo = s->Wo; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.x_pitch = s->x_pitch; p.dy_pitch = s->y_pitch;
-    p.M = (long)s->N * s->Ho * s->Wo; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
+    p.ry0 = region ? region->y0 : 0; p.rx0 = region ? region->x0 : 0;
+    p.rh = region ? region->h : s->Ho; p.rw = region ? region->w : s->Wo;
+    p.M = (long)s->N * p.rh * p.rw; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     const bool smallc = s->Cin == 4;
+    if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(smallc ? 1 : s->R * s->S), (unsigned)pl.splitk);
     const bool incr = s->Wo >= BK;
 #define RCF_WGRAD_LAUNCH(MRv, NRv)                                                                                \
@@ -1147,8 +1207,8 @@ extern "C" int rcf_conv2d_wgrad_f32(const float *x, const float *dy, float *dw, 
             else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
         }                                                                                                         \
     } while (0)
-    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr == 2) {     // narrow tiles: the fp32-MFMA kernel is as fast
-        if ((long)(pl.chunk / ((long)s->Ho * s->Wo) + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
+    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr == 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
+        if ((long)(pl.chunk / ((long)p.rh * p.rw) + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2>), grid, dim3(256), 0, st, p);

@@ -111,22 +111,32 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None):
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout)
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0):
+def _region(region):
+    """(y0, x0, h, w) -> ctypes pointer (None = the whole tensor)"""
+    if region is None:
+        return None
+    return byref(_lib.ConvRegion(*[int(v) for v in region]))
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None):
+    """region = (y0, x0, h, w) in output coordinates: only those pixels of `out` are written"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
-    if PROFILE.which is not None and s.Cout > 128:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
+    if PROFILE.which is not None and s.Cout > 128 and region is None:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
         end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
-    call("rcf_conv2d_fwd_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), act, slope, beta, _stream())
+    call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
+         slope, beta, _stream())
     if end is not None:
         end.record()
     return out
 
 
-def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0):
+def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None):
+    """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
@@ -135,21 +145,24 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0):
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
-    if PROFILE.which is not None and s.Cin > 128 and stride == 1:      # same kernel instance as the wide forward convs
+    if PROFILE.which is not None and s.Cin > 128 and stride == 1 and region is None:      # same kernel instance as the wide forward convs
         end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
-    call("rcf_conv2d_dgrad_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _p(ws), need, _stream())
+    call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
+         need, _stream())
     if end is not None:
         end.record()
     return out
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1):
-    """dw (same memory layout as the weight) (+)= wgrad."""
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None):
+    """dw (same memory layout as the weight) (+)= wgrad.  region = (y0, x0, h, w) in OUTPUT coordinates: only those
+    pixels of dy (and their input patches) contribute."""
     _need_cuda(x, dy, dw)
     s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy))
-    need = _lib.load().rcf_conv2d_wgrad_workspace_bytes(byref(s))
+    reg = _region(region)
+    need = _lib.load().rcf_conv2d_wgrad_region_workspace_bytes(byref(s), reg)
     ws = workspace(need, x.device) if need else None
-    call("rcf_conv2d_wgrad_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), beta, _p(ws), need, _stream())
+    call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     return dw
 
 

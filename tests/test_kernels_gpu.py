@@ -101,6 +101,50 @@ def test_conv_kernel_variants(variant, report):
         lib.rcf_conv_set_variant(-1)
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, stride, pad, dil, H, W, region (y0, x0, h, w) in output coords (fwd/wgrad) / input coords (dgrad)
+    (2, 32, 48, 3, 1, 6, 6, 20, 27, (7, 7, 6, 13)),
+    (2, 32, 48, 3, 1, 6, 6, 20, 27, (0, 0, 7, 27)),          # full-width strip: rows wrap inside the rectangle
+    (3, 64, 136, 3, 1, 3, 3, 11, 23, (2, 20, 9, 3)),         # 3-pixel-wide strip (narrower than a K-step)
+    (2, 256, 256, 1, 1, 0, 1, 9, 14, (1, 2, 5, 9)),
+])
+def test_conv_region(case, report):
+    """the rectangle-restricted forward / data-gradient / weight-gradient (rcf_conv2d_*_region_f32) against
+    float64 torch on the same rectangle; pixels outside the rectangle must stay untouched"""
+    N, Cin, Cout, k, stride, pad, dil, H, W, reg = case
+    y0, x0, rh, rw = reg
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:9])))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yref = torch.nn.functional.conv2d(xd, wd, None, stride, pad, dil)
+    dy = torch.randn(yref.shape, generator=g)
+    mask = torch.zeros_like(dy)
+    mask[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+    yref.backward((dy * mask).double())                          # only the rectangle's output pixels contribute
+    xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
+    out = torch.full((N, yref.shape[2], yref.shape[3], Cout), 7.0, device=DEV)
+    ops.conv2d_fwd(xg, wg, None, stride, pad, dil, out=out, region=reg)
+    o = from_nhwc(out)
+    e_f = relerr(o[:, :, y0:y0 + rh, x0:x0 + rw], yref.detach()[:, :, y0:y0 + rh, x0:x0 + rw])
+    outside = float(((o - 7.0).abs() * (1 - mask)).max())
+    dw = torch.zeros_like(wg)
+    ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=1, region=reg)
+    e_w = relerr(dw.cpu(), wd.grad)
+    # dgrad: rectangle in INPUT coordinates, full dy
+    xd2 = x.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd2, w.double(), None, stride, pad, dil).backward(dy.double())
+    dx = torch.full((N, H, W, Cin), 7.0, device=DEV)
+    ops.conv2d_dgrad(gg, wg, (N, H, W, Cin), stride, pad, dil, out=dx, region=reg)
+    d = from_nhwc(dx)
+    imask = torch.zeros(N, Cin, H, W)
+    imask[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+    e_d = relerr(d[:, :, y0:y0 + rh, x0:x0 + rw], xd2.grad[:, :, y0:y0 + rh, x0:x0 + rw])
+    outside_d = float(((d - 7.0).abs() * (1 - imask)).max())
+    report(f"conv region {case}: fwd {e_f:.2e} wgrad {e_w:.2e} dgrad {e_d:.2e} outside {outside} {outside_d}")
+    assert e_f < 2e-5 and e_w < 2e-5 and e_d < 2e-5 and outside == 0.0 and outside_d == 0.0
+
+
 def test_conv_large_wgrad_splitk(report):
     """enough pixels for the split-K path (workspace + deterministic reduce)"""
     g = torch.Generator().manual_seed(77)
