@@ -49,6 +49,7 @@ int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float 
  * conv(bilinear_2x(x)) as bilinear_2x(conv_half_dilation(x)) in the interior and directly on the border band
  * (models/fcn_head.py:211-218 with input_transform='resize_concat'). */
 typedef struct { int y0, x0, h, w; } rcf_conv_region;
+int rcf_conv_regions_available(void);     /* 1 while the split-bf16 kernels are selected (the default) */
 int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                               const rcf_conv_region *region, int act, float slope, int beta, void *stream);
 /* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w).
@@ -130,6 +131,10 @@ int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N, int C, in
 /* strided 2-D copy: dst[r*dpitch + c] (+)= src[r*spitch + c], c < C (concat / pair-concat / slices) */
 int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
                    void *stream);
+/* dense NHWC [N,H,W,C]: inside = src on the rectangle (0 elsewhere), outside = src off the rectangle (0 on it);
+ * either output may be NULL.  Splits a gradient into its interior / border-band parts (see rcf_conv_region). */
+int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0, int x0,
+                       int h, int w, void *stream);
 /* column sums of [rows][C] (pitch) in fp64 -> out[C] (+)= (bias gradients of conv_seg) */
 int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
                    size_t workspace_bytes, void *stream);

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import Act, BatchNorm2d, Conv2d, concat_channels, maxpool3x3s2
+from .layers import (Act, BatchNorm2d, Conv2d, commuted_concat_conv, commuted_concat_conv_ok, concat_channels,
+                     maxpool3x3s2)
 
 
 def make_norm(norm_cfg, n):
@@ -173,6 +174,7 @@ class FCNHead(nn.Module):
                   for _ in range(num_convs - 1)]
         self.convs = Stage(convs)
         self.keep_mask = None           # tests may inject a Dropout2d keep-mask [N, channels]
+        self.commute_upsample = True    # layers.commuted_concat_conv when its conditions hold
 
     def transform_inputs(self, feats, tape):
         if self.input_transform == "resize_concat":
@@ -184,8 +186,14 @@ class FCNHead(nn.Module):
         return feats[self.in_index]
 
     def fwd(self, feats, tape, dist=None):
-        x = self.transform_inputs(feats, tape)
         mods = list(self.convs.children())
+        first = None
+        if self.commute_upsample and self.input_transform == "resize_concat" and len(self.in_index) == 2 \
+                and self.transform_scale is None:
+            fa, fb = feats[self.in_index[0]], feats[self.in_index[1]]
+            if commuted_concat_conv_ok(fa, fb, mods[0].conv, self.align_corners):
+                first = commuted_concat_conv(fa, fb, mods[0].conv, tape)      # conv(concat(a, up2(b))) restructured
+        x = self.transform_inputs(feats, tape) if first is None else None
         scale = None
         if self.training and self.dropout_ratio > 0:
             # nn.Dropout2d: one Bernoulli(1-p) per (n, c) plane, kept planes scaled by 1/(1-p)
@@ -193,9 +201,14 @@ class FCNHead(nn.Module):
                 scale = self.keep_mask
             else:
                 keep = 1.0 - self.dropout_ratio
-                scale = torch.bernoulli(torch.full((x.t.shape[0], self.channels), keep, device=x.t.device)) / keep
+                src = (first if first is not None else x).t
+                scale = torch.bernoulli(torch.full((src.shape[0], self.channels), keep, device=src.device)) / keep
         for i, m in enumerate(mods):
-            x = m.fwd(x, tape, dist, chan_scale=scale if i == len(mods) - 1 else None)
+            cs = scale if i == len(mods) - 1 else None
+            if i == 0 and first is not None:
+                x = m.bn.fwd(first, tape, relu=True, chan_scale=cs, dist=dist)
+            else:
+                x = m.fwd(x, tape, dist, chan_scale=cs)
         return self.conv_seg.fwd(x, tape)
 
     def forward(self, inputs):

@@ -1089,6 +1089,8 @@ int set_region(IgemmParams &p, const rcf_conv_region *r, int N, int H, int W) {
 }
 }  // namespace
 
+extern "C" int rcf_conv_regions_available(void) { return use_x3(1) && use_x3(2) && use_x3(4) ? 1 : 0; }
+
 extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                                   const rcf_conv_shape *s, int act, float slope, int beta, void *stream) {
     return rcf_conv2d_fwd_region_f32(x, w, bias, y, s, nullptr, act, slope, beta, stream);

@@ -262,7 +262,36 @@ __global__ void __launch_bounds__(256) copy2d_kernel(const float *__restrict__ s
     }
 }
 
+// inside[p] = src[p] for pixels in the rectangle, 0 elsewhere; outside[p] = the complement (either may be null)
+__global__ void __launch_bounds__(256) split_rect_kernel(const float *__restrict__ src, float *__restrict__ inside,
+                                                         float *__restrict__ outside, long pixels, int H, int W, int C,
+                                                         int y0, int x0, int h, int w) {
+    const int CV = C / 4;
+    const long total = pixels * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long p = i / CV;
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const bool in = y >= y0 && y < y0 + h && x >= x0 && x < x0 + w;
+        const f32x4 v = reinterpret_cast<const f32x4 *>(src)[i];
+        if (inside) reinterpret_cast<f32x4 *>(inside)[i] = in ? v : z;
+        if (outside) reinterpret_cast<f32x4 *>(outside)[i] = in ? z : v;
+    }
+}
+
 }  // namespace
+
+extern "C" int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0,
+                                  int x0, int h, int w, void *stream) {
+    if (!src || (!inside && !outside) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (y0 < 0 || x0 < 0 || h <= 0 || w <= 0 || y0 + h > H || x0 + w > W) return RCF_EINVAL;
+    const long pixels = (long)N * H * W;
+    hipLaunchKernelGGL(split_rect_kernel, dim3(ew_blocks(pixels * (C / 4))), dim3(256), 0, rcf_stream(stream), src, inside,
+                       outside, pixels, H, W, C, y0, x0, h, w);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int rcf_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho,
                                         int Wo, void *stream) {

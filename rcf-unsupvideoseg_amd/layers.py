@@ -264,6 +264,79 @@ def concat_channels(parts, tape, size=None, align_corners=False, widths=None):
     return ya
 
 
+def commuted_concat_conv_ok(a, b, conv, align_corners):
+    """conv3x3(dilation d even, pad d, stride 1) over concat(a, bilinear_2x(b)): can the 2x upsampling be commuted?"""
+    h, w = a.t.shape[1:3]
+    d = conv.dilation
+    return (conv.k == 3 and conv.stride == 1 and d % 2 == 0 and d >= 2 and conv.padding == d and conv.bias is None
+            and not align_corners and (h, w) == (2 * b.t.shape[1], 2 * b.t.shape[2])
+            and conv.cin == a.t.shape[3] + b.t.shape[3] and conv.cout_pad == conv.cout and conv.cin_pad == conv.cin
+            and min(h, w) > 2 * (2 * d + 1) and a.t.is_contiguous() and b.t.is_contiguous() and ops.conv_regions_available())
+
+
+def commuted_concat_conv(a, b, conv, tape):
+    """y = conv(concat(a, U)), U = bilinear_2x(b) (decode_head2's first conv: models/decode_head.py:151-164 +
+    models/fcn_head.py:107-118) without running the wide conv over the up-sampled channels.
+
+    Bilinear 2x up-sampling (align_corners=False) is the same 2x2 stencil at every pixel of a given parity, and a
+    dilation-d (d even) tap moves by d/2 source pixels without changing parity, so
+        conv_d(U; Wb) == bilinear_2x(conv_{d/2}(b; Wb))
+    wherever neither the zero padding of the conv nor the edge clamp of the resize is involved: everywhere except a
+    band of d+1 pixels along the border (checked numerically in tests).  So: the up-sampled channels are convolved at
+    HALF resolution (1/4 of the FLOPs) and up-sampled afterwards, `a`'s channels are convolved on the interior only,
+    and the border band is computed directly from the concatenated tensor with the rectangle-restricted kernels.
+    The backward is the adjoint of exactly these pieces.  Same arithmetic up to fp32 summation order."""
+    N, h, w, Ca = a.t.shape
+    hb, wb, Cb = b.t.shape[1], b.t.shape[2], b.t.shape[3]
+    d, C, Co = conv.dilation, Ca + Cb, conv.cout
+    bw = d + 1                                   # border band (output pixels computed directly)
+    bi = bw + d                                  # input pixels the band's gradient reaches
+    W = conv.weight
+    wa = W[:, :Ca].contiguous(memory_format=torch.channels_last)
+    wbt = W[:, Ca:].contiguous(memory_format=torch.channels_last)
+    U = torch.empty((N, h, w, C), dtype=torch.float32, device=a.t.device)
+    ops.copy2d(a.t, Ca, U, C, N * h * w, Ca)
+    ops.resize_nhwc_fwd(b.t, (h, w), False, out=U[..., Ca:])
+    interior = (bw, bw, h - 2 * bw, w - 2 * bw)
+    strips = [(0, 0, bw, w), (h - bw, 0, bw, w), (bw, 0, h - 2 * bw, bw), (bw, w - bw, h - 2 * bw, bw)]
+    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2)
+    y = ops.resize_nhwc_fwd(Z, (h, w), False)
+    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, region=interior)
+    for r in strips:
+        ops.conv2d_fwd(U, W, None, 1, d, d, out=y, beta=0, region=r)
+    ya = Act(y)
+
+    def bwd():
+        dy = ya.take_grad()
+        dy_int, dy_band = ops.split_rect(dy, interior)
+        g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)
+        if W.requires_grad:
+            gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
+            for r in strips:                                               # band pixels: the full filter
+                ops.conv2d_wgrad(U, dy, W, _param_grad(W), 1, d, d, beta=1, region=r)
+            dwa = torch.empty_like(wa)
+            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0, region=interior)
+            ops.copy2d(dwa.permute(0, 2, 3, 1), Ca, gW[..., :Ca], C, Co * 9, Ca, beta=1)
+            dwb = torch.empty_like(wbt)
+            ops.conv2d_wgrad(b.t, g4, wbt, dwb, 1, d // 2, d // 2, beta=0)
+            ops.copy2d(dwb.permute(0, 2, 3, 1), Cb, gW[..., Ca:], C, Co * 9, Cb, beta=1)
+        if a.needs_grad or b.needs_grad:
+            dU = torch.empty_like(U)
+            ops.fill(dU, 0.0)
+            for r in [(0, 0, bi, w), (h - bi, 0, bi, w), (bi, 0, h - 2 * bi, bi), (bi, w - bi, h - 2 * bi, bi)]:
+                ops.conv2d_dgrad(dy_band, W, U.shape, 1, d, d, out=dU, beta=0, region=r)
+            if a.needs_grad:
+                ga, beta = a.grad_slot()
+                ops.copy2d(dU, C, ga, ops.pitch_of(ga), N * h * w, Ca, beta=beta)
+                ops.conv2d_dgrad(dy_int, wa, a.t.shape, 1, d, d, out=ga, beta=1)
+            if b.needs_grad:
+                gb, beta = b.grad_slot()
+                ops.resize_nhwc_bwd(dU[..., Ca:], (hb, wb), False, out=gb, beta=beta)
+                ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1)
+    tape.push(bwd)
+    return ya
+
+
 def pair_concat(x, tape, B, I, order=None):
     """[B*I,h,w,C] -> [B,h,w,I*C]: frames of a pair side by side on channels
     (unflatten(0,(B,I)).flatten(1,2) of models/rcf_model.py:325 in NHWC).  `order` permutes the frames

@@ -111,6 +111,11 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None):
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout)
 
 
+def conv_regions_available():
+    """the rectangle-restricted convs exist on the split-bf16 kernels (the default conv variant)"""
+    return bool(_lib.load().rcf_conv_regions_available())
+
+
 def _region(region):
     """(y0, x0, h, w) -> ctypes pointer (None = the whole tensor)"""
     if region is None:
@@ -296,6 +301,17 @@ def nhwc_to_nchw(x, C=None):
 
 def copy2d(src, spitch, dst, dpitch, rows, C, beta=0):
     call("rcf_copy2d_f32", _p(src), spitch, _p(dst), dpitch, rows, C, beta, _stream())
+
+
+def split_rect(x, rect, want_inside=True, want_outside=True):
+    """dense NHWC x -> (x on the rectangle (y0,x0,h,w) else 0, x off the rectangle else 0)"""
+    _need_cuda(x)
+    assert x.is_contiguous()
+    N, H, W, C = x.shape
+    ins = torch.empty_like(x) if want_inside else None
+    outs = torch.empty_like(x) if want_outside else None
+    call("rcf_split_rect_f32", _p(x), _p(ins), _p(outs), N, H, W, C, *[int(v) for v in rect], _stream())
+    return ins, outs
 
 
 def colsum(x, out, beta=1):

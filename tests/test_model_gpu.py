@@ -295,3 +295,35 @@ def test_config_variants_vs_reference_golden(variant, golden_dir, report):
     e64 = {k: rel(float(lh[k]), v) for k, v in fx["truth_loss"].items()}
     assert all(e64[k] < max(TOL, 4 * fx["ref32_err_loss"][k]) for k in e64), (e64, fx["ref32_err_loss"])
     assert all(e_gn[k] < lim[k] for k in e_gn), (e_gn, lim)
+
+
+def test_commuted_upsample_conv_matches_plain_path(report):
+    """decode_head2 with the 2x up-sampling commuted past the dilated conv (layers.commuted_concat_conv) against the
+    plain resize-concat-conv path of the same module: logits, input gradients and parameter gradients"""
+    from rcf_amd.backbone import FCNHead
+    from rcf_amd.layers import Act, Tape
+    g = torch.Generator().manual_seed(3)
+    N, h, w = 2, 40, 58
+    head = FCNHead([64, 128], 32, num_classes=4, num_convs=2, concat_input=False, dilation=6, in_index=[0, 1],
+                   input_transform="resize_concat", dropout_ratio=0.0, norm_cfg=dict(type="BN", requires_grad=True),
+                   align_corners=False).to(DEV).train()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).to(DEV) * 0.1 + (1.0 if p.dim() == 1 else 0.0))
+    fa = torch.randn(N, h, w, 64, generator=g).to(DEV)
+    fb = torch.randn(N, h // 2, w // 2, 128, generator=g).to(DEV)
+    dl = torch.randn(N, h, w, 4, generator=g).to(DEV)
+    res = {}
+    for fast in (False, True):
+        head.commute_upsample = fast
+        for p in head.parameters():
+            p.grad = None
+        a, b, tape = Act(fa.clone()), Act(fb.clone()), Tape()
+        out = head.fwd([a, b], tape)
+        out.grad = dl.clone()
+        tape.backward()
+        res[fast] = dict(out=out.t.clone(), ga=a.grad.clone(), gb=b.grad.clone(),
+                         **{"p." + n: p.grad.clone() for n, p in head.named_parameters()})
+    e = {k: rel(res[True][k].cpu().numpy(), res[False][k].cpu().numpy()) for k in res[True]}
+    report("commuted upsample conv vs plain path: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert max(e.values()) < 5e-5, e
