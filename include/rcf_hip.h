@@ -48,7 +48,10 @@ int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float 
  * coordinates for dgrad (only those pixels of dx are written).  NULL = the whole tensor.  Used to evaluate
  * conv(bilinear_2x(x)) as bilinear_2x(conv_half_dilation(x)) in the interior and directly on the border band
  * (models/fcn_head.py:211-218 with input_transform='resize_concat'). */
-typedef struct { int y0, x0, h, w; } rcf_conv_region;
+typedef struct {
+    int y0, x0, h, w;     /* rectangle */
+    int band;             /* 0: the whole rectangle; t > 0: only its border frame of thickness t (2t < h, w) */
+} rcf_conv_region;
 int rcf_conv_regions_available(void);     /* 1 while the split-bf16 kernels are selected (the default) */
 int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                               const rcf_conv_region *region, int act, float slope, int beta, void *stream);

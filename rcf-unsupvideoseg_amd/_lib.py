@@ -22,7 +22,7 @@ class ConvShape(ctypes.Structure):
 
 class ConvRegion(ctypes.Structure):
     """mirror of rcf_conv_region"""
-    _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w")]
+    _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w", "band")]
 
 
 class FlowHeadCfg(ctypes.Structure):

@@ -50,7 +50,36 @@ struct IgemmParams {
     // split-bf16 kernels: the GEMM rows are the pixels of the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of every image
     // of the [N, Ho, Wo] row tensor (M = N*rh*rw); the full tensor is the rectangle (0, 0, Ho, Wo)
     int ry0, rx0, rh, rw;
+    int rband;                    // > 0: only the frame of this thickness along the rectangle's border
+    int rr;                       // rows per image: rh*rw, or the frame's pixel count
 };
+
+// pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
+// strip (t x rw), the bottom strip, then the left and right strips (each (rh - 2t) x t), all row-major.
+__device__ __forceinline__ void region_yx(int pix, int ry0, int rx0, int rh, int rw, int t, int &y, int &x) {
+    if (t <= 0) {
+        const int yr = pix / rw;
+        y = yr + ry0;
+        x = pix - yr * rw + rx0;
+        return;
+    }
+    const int strip = t * rw;
+    if (pix < 2 * strip) {
+        const int bottom = pix >= strip;
+        const int q = pix - (bottom ? strip : 0);
+        const int yr = q / rw;
+        y = ry0 + yr + (bottom ? rh - t : 0);
+        x = rx0 + q - yr * rw;
+    } else {
+        int q = pix - 2 * strip;
+        const int side = t * (rh - 2 * t);
+        const int right = q >= side;
+        q -= right ? side : 0;
+        const int yr = q / t;
+        y = ry0 + t + yr;
+        x = rx0 + q - yr * t + (right ? rw - t : 0);
+    }
+}
 
 __device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
 
@@ -404,7 +433,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const int kq = tid % TPR, arow = tid / TPR;
     const int st_off = arow * 32 + ((((kq >> 1) ^ ((arow >> 3) & 1))) << 4) + (kq & 1) * 8;   // + ROWS*32 per pass
 
-    const int HoWo = p.rh * p.rw;                             // rows per image (the region's pixels)
+    const int HoWo = p.rr;                                    // rows per image (the region's pixels)
     const int n_first = m0 / HoWo;                            // first image this tile touches (block-uniform)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.A + (long)n_first * p.a_img_stride), 0, (int)X3_OOB, 0x00020000);
@@ -417,9 +446,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         const int m = m0 + arow + ROWS * i;
         if (m < p.M) {
             const int n = m / HoWo;
-            const int pix = m - n * HoWo;
-            const int yr = pix / p.rw;
-            const int y = yr + p.ry0, x = pix - yr * p.rw + p.rx0;
+            int y, x;
+            region_yx(m - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
             ay[i] = y * p.up + p.off;
             ax[i] = x * p.up + p.off;
             abase[i] = (n - n_first) * (int)p.a_img_stride + (STRIDED ? 0 : (ay[i] * p.Ws + ax[i]) * p.a_pitch);
@@ -552,7 +580,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
 
     // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int l31 = lane & 31, kh = lane >> 5;
-    const bool full = p.rh == p.Ho && p.rw == p.Wo;           // rows map linearly onto the output tensor
+    const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     float bv[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
@@ -569,9 +597,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             long lin = row;
             if (!full) {
                 const int n = row / HoWo;
-                const int pix = row - n * HoWo;
-                const int yr = pix / p.rw;
-                lin = ((long)n * p.Ho + yr + p.ry0) * p.Wo + (pix - yr * p.rw + p.rx0);
+                int y, x;
+                region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+                lin = ((long)n * p.Ho + y) * p.Wo + x;
             }
             float *drow = p.Y + lin * p.y_pitch + n0 + brow0 + l31;
 #pragma unroll
@@ -615,7 +643,8 @@ struct WgradParams {
     int itiles, jtiles;
     long split_stride; // Cout*R*S*Cin
     int beta;          // only honoured when gridDim.z == 1
-    int ry0, rx0, rh, rw;   // split-bf16 kernel: contributing output pixels = this rectangle of every image (M = N*rh*rw)
+    int ry0, rx0, rh, rw;   // split-bf16 kernel: contributing output pixels = this rectangle of every image (M = N*rr)
+    int rband, rr;          // frame thickness (0 = whole rectangle), pixels per image
 };
 
 // dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
@@ -785,7 +814,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const bool isB = tid >= 128;                 // wave-uniform role
     const int t = tid & 127, g = t & 3, q = t >> 2;
-    const int HoWo = p.rh * p.rw;                 // contributing pixels per image
+    const int HoWo = p.rr;                        // contributing pixels per image
     const int n_first = (int)(kbeg / HoWo);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.DY + (long)n_first * p.Ho * p.Wo * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
@@ -794,28 +823,27 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
 
     const int ch = (isB ? j0 : i0) + 4 * q;
     const bool active = isB ? (q < BN / 4 && ch < p.Cin) : (q < BM / 4 && ch < p.Cout);
-    // (image, row, column) of this thread's 4 pixels inside the rectangle, advanced by BK per K-step
-    int pn[4], py[4], px_[4];
+    // (image, row, column) of this thread's 4 pixels -- image coordinates -- advanced by BK per K-step
+    int pn[4], py[4], px_[4], ppix[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long m = kbeg + 4 * g + i;
         pn[i] = (int)(m / HoWo);
-        const int pix = (int)(m - (long)pn[i] * HoWo);
-        py[i] = pix / p.rw;
-        px_[i] = pix - py[i] * p.rw;
+        ppix[i] = (int)(m - (long)pn[i] * HoWo);          // pixel index inside the image's region
+        region_yx(ppix[i], p.ry0, p.rx0, p.rh, p.rw, p.rband, py[i], px_[i]);
         pn[i] -= n_first;
     }
     const int row_l = 4 * q;                                              // first tile row of this thread
     const int prow0 = x3_prow(row_l);                                     // rows row_l + e -> prow0 + 4 e
     const int st_off = prow0 * 32 + (g & 1) * 8;                         // bit 3 of prow0 is clear; row e sets it to e>>1
-    const bool incr = p.rw >= BK;
+    const bool incr = p.rw >= BK && p.rband <= 0;          // rows of a rectangle at least one K-step wide: walk by increments
 
     f32x4 rr[4];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mk = kt * BK + 4 * g + i;
-            const int oy = py[i] + p.ry0, ox = px_[i] + p.rx0;              // output pixel in the image
+            const int oy = py[i], ox = px_[i];                              // output pixel in the image
             if (!isB) {
                 const bool v = active && mk < klen;
                 const unsigned bo = v ? (unsigned)(((pn[i] * p.Ho + oy) * p.Wo + ox) * p.dy_pitch + ch) * 4u : X3_OOB;
@@ -829,19 +857,16 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
             }
             if (incr) {                          // rw >= BK: at most one row wrap per K-step
                 px_[i] += BK;
-                const bool wx = px_[i] >= p.rw;
+                const bool wx = px_[i] >= p.rx0 + p.rw;
                 px_[i] -= wx ? p.rw : 0;
                 py[i] += wx ? 1 : 0;
-                const bool wy = py[i] == p.rh;
-                py[i] = wy ? 0 : py[i];
+                const bool wy = py[i] == p.ry0 + p.rh;
+                py[i] = wy ? p.ry0 : py[i];
                 pn[i] += wy ? 1 : 0;
-            } else {
-                const long mn = kbeg + (long)(kt + 1) * BK + 4 * g + i;
-                const int nn = (int)(mn / HoWo);
-                const int pix = (int)(mn - (long)nn * HoWo);
-                pn[i] = nn - n_first;
-                py[i] = pix / p.rw;
-                px_[i] = pix - py[i] * p.rw;
+            } else {                             // narrow rectangle / frame: advance the region-linear index
+                ppix[i] += BK;
+                while (ppix[i] >= HoWo) { ppix[i] -= HoWo; ++pn[i]; }
+                region_yx(ppix[i], p.ry0, p.rx0, p.rh, p.rw, p.rband, py[i], px_[i]);
             }
         }
     };
@@ -990,7 +1015,7 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
-    const long per_tile_imgs = 256 / ((long)p.rh * p.rw) + 2;
+    const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
     p.dbg = g_x3_dbg;
@@ -1017,6 +1042,11 @@ int launch_igemm(IgemmParams &p, hipStream_t st) {
     }
 }
 
+inline int region_pixels(const rcf_conv_region *r, int H, int W) {
+    if (!r) return H * W;
+    return r->band > 0 ? 2 * r->band * r->w + 2 * r->band * (r->h - 2 * r->band) : r->h * r->w;
+}
+
 struct WgradPlan {
     int mr, nr, itiles, jtiles, splitk;
     long chunk;
@@ -1029,7 +1059,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     pl.nr = ncols > 64 ? 2 : 1;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ncols, 64 * pl.nr);
-    const long RR = reg ? (long)reg->h * reg->w : (long)s->Ho * s->Wo;      // contributing pixels per image
+    const long RR = region_pixels(reg, s->Ho, s->Wo);                       // contributing pixels per image
     const long M = (long)s->N * RR;
     const long tiles = (long)pl.itiles * pl.jtiles * (smallc ? 1 : s->R * s->S);
     long sk = (1536 + tiles - 1) / tiles;
@@ -1080,11 +1110,14 @@ extern "C" int rcf_conv_set_variant(int v) {
 }
 
 namespace {
-// rectangle of the GEMM-row tensor [N, H, W]; null = everything.  Returns 0 / RCF_EINVAL.
+// rectangle (or frame) of the GEMM-row tensor [N, H, W]; null = everything.  Returns 0 / RCF_EINVAL.
 int set_region(IgemmParams &p, const rcf_conv_region *r, int N, int H, int W) {
     p.ry0 = r ? r->y0 : 0; p.rx0 = r ? r->x0 : 0; p.rh = r ? r->h : H; p.rw = r ? r->w : W;
+    p.rband = r ? r->band : 0;
     if (p.ry0 < 0 || p.rx0 < 0 || p.rh <= 0 || p.rw <= 0 || p.ry0 + p.rh > H || p.rx0 + p.rw > W) return RCF_EINVAL;
-    p.M = N * p.rh * p.rw;
+    if (p.rband < 0 || (p.rband > 0 && (2 * p.rband >= p.rh || 2 * p.rband >= p.rw))) return RCF_EINVAL;
+    p.rr = region_pixels(r, H, W);
+    p.M = N * p.rr;
     return 0;
 }
 }  // namespace
@@ -1155,7 +1188,8 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
 
 namespace {
 bool region_ok(const rcf_conv_region *r, int H, int W) {
-    return !r || (r->y0 >= 0 && r->x0 >= 0 && r->h > 0 && r->w > 0 && r->y0 + r->h <= H && r->x0 + r->w <= W);
+    return !r || (r->y0 >= 0 && r->x0 >= 0 && r->h > 0 && r->w > 0 && r->y0 + r->h <= H && r->x0 + r->w <= W &&
+                  r->band >= 0 && (r->band == 0 || (2 * r->band < r->h && 2 * r->band < r->w)));
 }
 }  // namespace
 
@@ -1193,7 +1227,8 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     p.x_pitch = s->x_pitch; p.dy_pitch = s->y_pitch;
     p.ry0 = region ? region->y0 : 0; p.rx0 = region ? region->x0 : 0;
     p.rh = region ? region->h : s->Ho; p.rw = region ? region->w : s->Wo;
-    p.M = (long)s->N * p.rh * p.rw; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
+    p.rband = region ? region->band : 0; p.rr = region_pixels(region, s->Ho, s->Wo);
+    p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     const bool smallc = s->Cin == 4;
     if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
@@ -1210,7 +1245,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
         }                                                                                                         \
     } while (0)
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr == 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
-        if ((long)(pl.chunk / ((long)p.rh * p.rw) + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
+        if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2>), grid, dim3(256), 0, st, p);

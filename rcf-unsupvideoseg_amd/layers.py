@@ -298,12 +298,11 @@ def commuted_concat_conv(a, b, conv, tape):
     ops.copy2d(a.t, Ca, U, C, N * h * w, Ca)
     ops.resize_nhwc_fwd(b.t, (h, w), False, out=U[..., Ca:])
     interior = (bw, bw, h - 2 * bw, w - 2 * bw)
-    strips = [(0, 0, bw, w), (h - bw, 0, bw, w), (bw, 0, h - 2 * bw, bw), (bw, w - bw, h - 2 * bw, bw)]
+    band = (0, 0, h, w, bw)                      # the border frame of thickness bw, one launch
     Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2)
     y = ops.resize_nhwc_fwd(Z, (h, w), False)
     ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, region=interior)
-    for r in strips:
-        ops.conv2d_fwd(U, W, None, 1, d, d, out=y, beta=0, region=r)
+    ops.conv2d_fwd(U, W, None, 1, d, d, out=y, beta=0, region=band)
     ya = Act(y)
 
     def bwd():
@@ -312,8 +311,7 @@ def commuted_concat_conv(a, b, conv, tape):
         g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)
         if W.requires_grad:
             gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
-            for r in strips:                                               # band pixels: the full filter
-                ops.conv2d_wgrad(U, dy, W, _param_grad(W), 1, d, d, beta=1, region=r)
+            ops.conv2d_wgrad(U, dy, W, _param_grad(W), 1, d, d, beta=1, region=band)   # band pixels: the full filter
             dwa = torch.empty_like(wa)
             ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0, region=interior)
             ops.copy2d(dwa.permute(0, 2, 3, 1), Ca, gW[..., :Ca], C, Co * 9, Ca, beta=1)
@@ -323,8 +321,7 @@ def commuted_concat_conv(a, b, conv, tape):
         if a.needs_grad or b.needs_grad:
             dU = torch.empty_like(U)
             ops.fill(dU, 0.0)
-            for r in [(0, 0, bi, w), (h - bi, 0, bi, w), (bi, 0, h - 2 * bi, bi), (bi, w - bi, h - 2 * bi, bi)]:
-                ops.conv2d_dgrad(dy_band, W, U.shape, 1, d, d, out=dU, beta=0, region=r)
+            ops.conv2d_dgrad(dy_band, W, U.shape, 1, d, d, out=dU, beta=0, region=(0, 0, h, w, bi))
             if a.needs_grad:
                 ga, beta = a.grad_slot()
                 ops.copy2d(dU, C, ga, ops.pitch_of(ga), N * h * w, Ca, beta=beta)

@@ -116,11 +116,20 @@ def conv_regions_available():
     return bool(_lib.load().rcf_conv_regions_available())
 
 
+def _region_pixels(region, H, W):
+    if region is None:
+        return H * W
+    r = [int(v) for v in region] + [0]
+    return r[2] * r[3] if r[4] <= 0 else 2 * r[4] * r[3] + 2 * r[4] * (r[2] - 2 * r[4])
+
+
 def _region(region):
-    """(y0, x0, h, w) -> ctypes pointer (None = the whole tensor)"""
+    """(y0, x0, h, w[, band]) -> ctypes pointer (None = the whole tensor); band t > 0 = only the rectangle's border
+    frame of thickness t"""
     if region is None:
         return None
-    return byref(_lib.ConvRegion(*[int(v) for v in region]))
+    r = [int(v) for v in region]
+    return byref(_lib.ConvRegion(*(r + [0] * (5 - len(r)))))
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None):
@@ -131,8 +140,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
-    if PROFILE.which is not None and s.Cout > 128 and region is None:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
-        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None and s.Cout > 128:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
+        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
     if end is not None:
@@ -150,8 +159,10 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
-    if PROFILE.which is not None and s.Cin > 128 and stride == 1 and region is None:      # same kernel instance as the wide forward convs
-        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None and s.Cin > 128 and stride == 1:      # same kernel instance as the wide forward convs
+        # a data gradient restricted to input pixels: FLOPs scale with the pixels written
+        px = _region_pixels(region, s.H, s.W) * (s.Ho * s.Wo) / float(s.H * s.W)
+        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * px * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
          need, _stream())
     if end is not None:

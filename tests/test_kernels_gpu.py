@@ -107,26 +107,35 @@ def test_conv_kernel_variants(variant, report):
     (2, 32, 48, 3, 1, 6, 6, 20, 27, (0, 0, 7, 27)),          # full-width strip: rows wrap inside the rectangle
     (3, 64, 136, 3, 1, 3, 3, 11, 23, (2, 20, 9, 3)),         # 3-pixel-wide strip (narrower than a K-step)
     (2, 256, 256, 1, 1, 0, 1, 9, 14, (1, 2, 5, 9)),
+    (2, 32, 48, 3, 1, 6, 6, 20, 27, (0, 0, 20, 27, 7)),      # border frame of thickness 7 of the whole image
+    (3, 64, 136, 3, 1, 3, 3, 11, 23, (1, 2, 9, 20, 2)),      # frame of a sub-rectangle
 ])
 def test_conv_region(case, report):
     """the rectangle-restricted forward / data-gradient / weight-gradient (rcf_conv2d_*_region_f32) against
     float64 torch on the same rectangle; pixels outside the rectangle must stay untouched"""
     N, Cin, Cout, k, stride, pad, dil, H, W, reg = case
-    y0, x0, rh, rw = reg
+    y0, x0, rh, rw = reg[:4]
+    t = reg[4] if len(reg) > 4 else 0
+
+    def rect_mask(shape):
+        m = torch.zeros(shape)
+        m[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+        if t:
+            m[:, :, y0 + t:y0 + rh - t, x0 + t:x0 + rw - t] = 0
+        return m
     g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:9])))
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
     yref = torch.nn.functional.conv2d(xd, wd, None, stride, pad, dil)
     dy = torch.randn(yref.shape, generator=g)
-    mask = torch.zeros_like(dy)
-    mask[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+    mask = rect_mask(dy.shape)
     yref.backward((dy * mask).double())                          # only the rectangle's output pixels contribute
     xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
     out = torch.full((N, yref.shape[2], yref.shape[3], Cout), 7.0, device=DEV)
     ops.conv2d_fwd(xg, wg, None, stride, pad, dil, out=out, region=reg)
     o = from_nhwc(out)
-    e_f = relerr(o[:, :, y0:y0 + rh, x0:x0 + rw], yref.detach()[:, :, y0:y0 + rh, x0:x0 + rw])
+    e_f = relerr(o * mask, yref.detach() * mask)
     outside = float(((o - 7.0).abs() * (1 - mask)).max())
     dw = torch.zeros_like(wg)
     ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=1, region=reg)
@@ -137,9 +146,8 @@ def test_conv_region(case, report):
     dx = torch.full((N, H, W, Cin), 7.0, device=DEV)
     ops.conv2d_dgrad(gg, wg, (N, H, W, Cin), stride, pad, dil, out=dx, region=reg)
     d = from_nhwc(dx)
-    imask = torch.zeros(N, Cin, H, W)
-    imask[:, :, y0:y0 + rh, x0:x0 + rw] = 1
-    e_d = relerr(d[:, :, y0:y0 + rh, x0:x0 + rw], xd2.grad[:, :, y0:y0 + rh, x0:x0 + rw])
+    imask = rect_mask((N, Cin, H, W))
+    e_d = relerr(d * imask, xd2.grad * imask)
     outside_d = float(((d - 7.0).abs() * (1 - imask)).max())
     report(f"conv region {case}: fwd {e_f:.2e} wgrad {e_w:.2e} dgrad {e_d:.2e} outside {outside} {outside_d}")
     assert e_f < 2e-5 and e_w < 2e-5 and e_d < 2e-5 and outside == 0.0 and outside_d == 0.0
