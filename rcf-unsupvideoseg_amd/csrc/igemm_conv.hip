@@ -937,6 +937,168 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
     }
 }
 
+// two pixels of one channel -> three bf16 pairs (one dword per plane)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hv = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = v - __builtin_convertvector(hv, f32x2);
+    const bf16x2 mv = __builtin_convertvector(r, bf16x2);
+    const f32x2 q = r - __builtin_convertvector(mv, f32x2);
+    const bf16x2 lv = __builtin_convertvector(q, bf16x2);
+    h = __builtin_bit_cast(unsigned, hv);
+    m = __builtin_bit_cast(unsigned, mv);
+    l = __builtin_bit_cast(unsigned, lv);
+}
+
+// 128 x 256 tile of the weight gradient (Cout >= 128, Cin >= 256, whole tensors only): every thread stages one
+// x item (channel quad x 4 pixels, as in igemm_wgrad_x3_kernel) AND half a dy item (channel quad x 2 pixels, one
+// ds_write_b32 per plane), so the loader work is balanced over the four waves; each wave owns 2 x 4 MFMA tiles.
+__global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams p) {
+    constexpr int MR = 2, NR = 4, BM = 128, BN = 256;
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int rs = (int)blockIdx.y;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+    const int klen = (int)(kend - kbeg);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = tid & 3, q = tid >> 2;          // x item: pixels 4g..4g+3, channel quad q (0..63)
+    const int g2 = tid & 7, qa = tid >> 3;        // dy half-item: pixels 2 g2, 2 g2 + 1, channel quad qa (0..31)
+    const int HoWo = p.Ho * p.Wo;
+    const int n_first = (int)(kbeg / HoWo);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.DY + kbeg * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
+
+    const int cha = i0 + 4 * qa, chb = j0 + 4 * q;
+    const bool acta = cha < p.Cout, actb = chb < p.Cin;
+    int pn[4], py[4], px_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = kbeg + 4 * g + i;
+        pn[i] = (int)(m / HoWo);
+        const int pix = (int)(m - (long)pn[i] * HoWo);
+        py[i] = pix / p.Wo;
+        px_[i] = pix - py[i] * p.Wo;
+        pn[i] -= n_first;
+    }
+    const int prow_b = x3_prow(4 * q), prow_a = x3_prow(4 * qa);
+    const int st_b = prow_b * 32 + (g & 1) * 8;
+    const int st_a = prow_a * 32 + (g2 & 3) * 4;
+    const bool incr = p.Wo >= BK;
+
+    f32x4 ra[2], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mk = kt * BK + 2 * g2 + i;
+            const unsigned bo = (acta && mk < klen) ? (unsigned)(mk * p.dy_pitch + cha) * 4u : X3_OOB;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mk = kt * BK + 4 * g + i;
+            const int sy = py[i] * p.stride - p.pad + r * p.dil;
+            const int sx = px_[i] * p.stride - p.pad + s * p.dil;
+            const bool v = actb && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const unsigned bo = v ? (unsigned)(((pn[i] * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 4u : X3_OOB;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+            if (incr) {
+                px_[i] += BK;
+                const bool wx = px_[i] >= p.Wo;
+                px_[i] -= wx ? p.Wo : 0;
+                py[i] += wx ? 1 : 0;
+                const bool wy = py[i] == p.Ho;
+                py[i] = wy ? 0 : py[i];
+                pn[i] += wy ? 1 : 0;
+            } else {
+                const long mn = kbeg + (long)(kt + 1) * BK + 4 * g + i;
+                const int nn = (int)(mn / HoWo);
+                const int pix = (int)(mn - (long)nn * HoWo);
+                pn[i] = nn - n_first;
+                py[i] = pix / p.Wo;
+                px_[i] = pix - py[i] * p.Wo;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *As = smem + buf * STAGE, *Bs = As + 3 * PA;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h, m, l;
+            split3_pair(ra[0][e], ra[1][e], h, m, l);
+            char *d = As + st_a + e * 128 + (((g2 >> 2) ^ (e >> 1)) << 4);     // row prow_a + 4 e
+            *reinterpret_cast<unsigned *>(d) = h;
+            *reinterpret_cast<unsigned *>(d + PA) = m;
+            *reinterpret_cast<unsigned *>(d + 2 * PA) = l;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32x2 h, m, l;
+            split3(f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]}, h, m, l);
+            char *d = Bs + st_b + e * 128 + (((g >> 1) ^ (e >> 1)) << 4);      // row prow_b + 4 e
+            *reinterpret_cast<u32x2 *>(d) = h;
+            *reinterpret_cast<u32x2 *>(d + PB) = m;
+            *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    const int KT = (klen + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *As = smem + cur * STAGE;
+        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    {
+        const char *As = smem + ((KT - 1) & 1) * STAGE;
+        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+    }
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const long row_pitch = (long)p.R * p.S * p.Cin;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = rbase + (e & 3) + 8 * (e >> 2);
+            if (co >= p.Cout) continue;
+            float *drow = out + co * row_pitch + (long)rs * p.Cin + j0 + brow0 + l31;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
+                float v = acc[mr][nr][e];
+                if (p.beta && gridDim.z == 1) v += drow[nr * 32];
+                drow[nr * 32] = v;
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
                                      int splits, int beta) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,6 +1125,7 @@ int check_shape(const rcf_conv_shape *s) {
 int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 tile (fp32-MFMA kernels);
                            // bit3: split-bf16 kernels.  -1: built-in default (= 8)
 int g_x3_dbg = 0;
+int g_wgrad_wide = 1;      // 128 x 256 weight-gradient tile when the operands are wide enough
 int g_x3_off = 0;           // debug mask: 1 forward, 2 dgrad, 4 wgrad stay on the fp32-MFMA kernels
 inline bool use_x3(int kind = 0) { return (g_conv_variant < 0 || (g_conv_variant & 8) != 0) && !(g_x3_off & kind); }
 
@@ -1057,6 +1220,9 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     const int ncols = smallc ? s->R * s->S * 4 : s->Cin;
     pl.mr = s->Cout > 64 ? 2 : 1;
     pl.nr = ncols > 64 ? 2 : 1;
+    // 128 x 256 tile (igemm_wgrad_x3_wide_kernel): whole tensors, wide enough operands
+    const bool wide = use_x3(4) && g_wgrad_wide && !smallc && !reg && s->Cout >= 128 && s->Cin >= 256;
+    if (wide) pl.nr = 4;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ncols, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);                       // contributing pixels per image
@@ -1067,10 +1233,10 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     if (sk > maxsk) sk = maxsk;
     if (sk > 256) sk = 256;
     if (sk < 1) sk = 1;
-    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr == 2) {
+    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr >= 2) {
         // the split-bf16 kernel runs 3 workgroups per CU (768 slots): pick the split whose last round is fullest
         // (time ~ rounds / split; the fixed-order reduction costs ~ split)
-        const long slots = 768, hi = maxsk < 96 ? maxsk : 96;
+        const long slots = pl.nr == 4 ? 512 : 768, hi = maxsk < 96 ? maxsk : 96;     // (the 128 x 256 kernel: 2 per CU = 512)
         double best = 1e30;
         for (long c = 1; c <= hi; ++c) {
             const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
@@ -1097,6 +1263,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
     g_x3_dbg = v >= 0 ? (v >> 15) & 1 : 0;
+    g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
     g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
     if (v >= 0) v &= 0xfff;
     if (v >= 0 && (v & 0x100)) {           // 0x100 | tile << 4: pin the split-bf16 tile (tools/bench_conv.py)
@@ -1244,9 +1411,10 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
             else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
         }                                                                                                         \
     } while (0)
-    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr == 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
+    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
-        if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
+        if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel, grid, dim3(256), 0, st, p);
+        else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 1>), grid, dim3(256), 0, st, p);
