@@ -179,6 +179,9 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
                  float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence, int iters,
                  int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
                  void *stream);
+/* lattice build variant: 0 (default) packed 64-bit keys + block-local de-duplication when the key coordinates fit
+ * 12 bits, 1 always the array-of-keys build.  Results are identical. */
+int rcf_crf_set_variant(int variant);
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

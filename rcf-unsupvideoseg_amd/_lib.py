@@ -49,6 +49,7 @@ PROTOS = {
     "rcf_conv2d_wgrad_region_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv_regions_available": (c_int, []),
+    "rcf_crf_set_variant": (c_int, [c_int]),
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),

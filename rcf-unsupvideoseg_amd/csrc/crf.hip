@@ -48,6 +48,13 @@ struct Lattice {           // device pointers of one potential, for all frames (
     float *inv;            // [F][N]   1 / (sliced homogeneous channel): iteration invariant, computed at build time
     int *blocksum;         // [F][nblk+1]
     int *L;                // [F]      vertex counts
+    // packed build (12-bit key coordinates): the hash table holds the 64-bit keys themselves
+    unsigned long long *table;   // [F][2E]  (aliases `keys`)
+    unsigned *cursor;            // [F][2E]  entries per bucket (aliases `entries`)
+    int *rel;                    // [F][E]   position of the entry inside its vertex's CSR list
+    int *slot_vid2;              // [F][2E]  bucket -> dense vertex id (-1 empty)
+    int *slot_off;               // [F][2E]  bucket -> CSR offset
+    int *blocksum2;              // [F][2][nblk2+1]
 };
 
 __device__ __forceinline__ unsigned key_hash(const short *key, int pd) {
@@ -66,24 +73,22 @@ __device__ __forceinline__ uint4 pack_key(const short *key, int pd) {
 __device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 
 // ---------------------------------------------------------------------------------- build: keys
-__global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, int H,
-                                                           float posdev, float featdev) {
-    const int pd = Lt.pd;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    if (p >= Lt.N) return;
+// createLattice arithmetic for one pixel (permutohedral_gpu.cu:169-275), kept operation for operation: the lattice
+// point's remainder-0 coordinates, the ranks and the pd+1 barycentric weights
+__device__ __forceinline__ void lattice_point(int pd, int p, int f, int N, int W, const uint8_t *__restrict__ rgb,
+                                              float posdev, float featdev, int (&rem0)[PD_MAX + 1],
+                                              int (&rank)[PD_MAX + 1], float (&bary)[PD_MAX + 2]) {
     float pos[PD_MAX];
     const int wi = p % W, hi = p / W;
     pos[0] = (float)wi / posdev;
     pos[1] = (float)hi / posdev;
     if (pd == 5) {
-        const uint8_t *c = rgb + ((long)f * Lt.N + p) * 3;
+        const uint8_t *c = rgb + ((long)f * N + p) * 3;
         pos[2] = (float)c[0] / featdev;
         pos[3] = (float)c[1] / featdev;
         pos[4] = (float)c[2] / featdev;
     }
     float elevated[PD_MAX + 1];
-    int rem0[PD_MAX + 1], rank[PD_MAX + 1];
     const float inv_std = (pd + 1) * sqrtf(2.0f / 3);
     float sm = 0;
     for (int i = pd; i > 0; i--) {
@@ -115,7 +120,6 @@ __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uin
         if (rank[i] < 0) { rank[i] += pd + 1; rem0[i] += pd + 1; }
         else if (rank[i] > pd) { rank[i] -= pd + 1; rem0[i] -= pd + 1; }
     }
-    float bary[PD_MAX + 2];
     for (int i = 0; i <= pd + 1; i++) bary[i] = 0;
     for (int i = 0; i <= pd; i++) {
         const float delta = (float)((elevated[i] - rem0[i]) * (1.0 / (pd + 1)));
@@ -123,14 +127,29 @@ __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uin
         bary[pd + 1 - rank[i]] -= delta;
     }
     bary[0] = (float)(bary[0] + (1.0 + bary[pd + 1]));
+}
+__device__ __forceinline__ void lattice_key(int pd, int r, const int (&rem0)[PD_MAX + 1], const int (&rank)[PD_MAX + 1],
+                                            short *key) {
+    for (int i = 0; i < pd; i++) {
+        key[i] = (short)(rem0[i] + r);
+        if (rank[i] > pd - r) key[i] = (short)(key[i] - (pd + 1));
+    }
+}
+
+__global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, int H,
+                                                           float posdev, float featdev) {
+    const int pd = Lt.pd;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= Lt.N) return;
+    int rem0[PD_MAX + 1], rank[PD_MAX + 1];
+    float bary[PD_MAX + 2];
+    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
     // entries are stored remainder-major (e = r*N + p): every later pass is coalesced along the pixels
     const long base = (long)f * Lt.E + p;
     for (int r = 0; r <= pd; r++) {
         short key[PD_MAX];
-        for (int i = 0; i < pd; i++) {
-            key[i] = (short)(rem0[i] + r);
-            if (rank[i] > pd - r) key[i] = (short)(key[i] - (pd + 1));
-        }
+        lattice_key(pd, r, rem0, rank, key);
         Lt.keys[base + (long)r * Lt.N] = pack_key(key, pd);
         Lt.weight[base + (long)r * Lt.N] = bary[r];
     }
@@ -426,6 +445,214 @@ __global__ void __launch_bounds__(256) csr_fill_kernel(Lattice Lt) {
     }
 }
 
+// ---------------------------------------------------------------------------------- packed build
+// When every key coordinate fits 12 bits (|coordinate| < 2048: sxy 60 / srgb 5 at 480x854 gives < 260) the five
+// coordinates are the hash table's 64-bit value: one 64-bit CAS inserts a vertex and nothing ever re-reads a key
+// array.  A workgroup of 256 pixels first de-duplicates its 1536 (pixel, remainder) entries in an LDS table --
+// neighbouring pixels share most lattice vertices -- so only the distinct keys of the block touch the global table,
+// and the same pass reserves each entry's slot in its vertex's CSR list (LDS rank inside the block + one global
+// atomicAdd per distinct key), which removes the count pass and every atomic of the fill pass.
+constexpr unsigned long long PK_EMPTY = ~0ull;
+constexpr int LT_SLOTS = 2048;                      // >= 1536 entries of a block, power of two
+
+__device__ __forceinline__ unsigned long long pack64(const short *key, int pd) {
+    unsigned long long k = 0;
+    for (int i = 0; i < pd; i++) k |= (unsigned long long)((unsigned)(key[i] + 2048) & 0xfffu) << (12 * i);
+    return k;
+}
+__device__ __forceinline__ void unpack64(unsigned long long k, int pd, short *key) {
+    for (int i = 0; i < pd; i++) key[i] = (short)((int)((k >> (12 * i)) & 0xfffu) - 2048);
+}
+
+__global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W,
+                                                                   int H, float posdev, float featdev) {
+    __shared__ unsigned long long lkey[LT_SLOTS];
+    __shared__ unsigned lcnt[LT_SLOTS], lgs[LT_SLOTS], lbase[LT_SLOTS];
+    const int pd = Lt.pd, nax = pd + 1;
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < Lt.N;
+    for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) { lkey[i] = PK_EMPTY; lcnt[i] = 0u; }
+    __syncthreads();
+    float wgt[PD_MAX + 1];
+    int lh[PD_MAX + 1], lrank[PD_MAX + 1];
+    if (live) {
+        int rem0[PD_MAX + 1], rank[PD_MAX + 1];
+        float bary[PD_MAX + 2];
+        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+        for (int r = 0; r < nax; r++) {
+            short key[PD_MAX];
+            lattice_key(pd, r, rem0, rank, key);
+            const unsigned long long k = pack64(key, pd);
+            unsigned h = key_hash(key, pd) & (LT_SLOTS - 1);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&lkey[h], PK_EMPTY, k);
+                if (prev == PK_EMPTY || prev == k) break;
+                h = (h + 1) & (LT_SLOTS - 1);
+            }
+            lh[r] = (int)h;
+            lrank[r] = (int)atomicAdd(&lcnt[h], 1u);
+            wgt[r] = bary[r];
+        }
+    }
+    __syncthreads();
+    // the block's distinct keys: insert into the frame's table, reserve the block's share of the vertex's list
+    unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
+    unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
+    const unsigned nb = (unsigned)(2 * Lt.E);
+    for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) {
+        const unsigned long long k = lkey[i];
+        if (k == PK_EMPTY) continue;
+        short key[PD_MAX];
+        unpack64(k, pd, key);
+        unsigned h = key_hash(key, pd) % nb;
+        for (;;) {
+            unsigned long long cur = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == PK_EMPTY) cur = atomicCAS(table + h, PK_EMPTY, k);
+            if (cur == PK_EMPTY || cur == k) break;
+            if (++h == nb) h = 0;
+        }
+        lgs[i] = h;
+        lbase[i] = atomicAdd(cursor + h, lcnt[i]);
+    }
+    __syncthreads();
+    if (live) {
+        const long base = (long)f * Lt.E + p;
+        for (int r = 0; r < nax; r++) {
+            const long e = base + (long)r * Lt.N;
+            Lt.vid[e] = (int)lgs[lh[r]];                         // bucket for now; the fill pass turns it into the vertex id
+            Lt.rel[e] = (int)lbase[lh[r]] + lrank[r];
+            Lt.weight[e] = wgt[r];
+        }
+    }
+}
+
+// exclusive scans over the table's buckets: vertex numbering (occupied flag) and CSR offsets (entry counts)
+__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long S = 2 * Lt.E;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+    const unsigned *cursor = Lt.cursor + (long)f * S;
+    int fl[SCAN_ITEMS], cn[SCAN_ITEMS], sf = 0, sc = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long b = base + i;
+        cn[i] = (b < S) ? (int)cursor[b] : 0;
+        fl[i] = cn[i] > 0 ? 1 : 0;              // every inserted key counted at least one entry
+        sf += fl[i];
+        sc += cn[i];
+    }
+    int tf, tc;
+    int of = block_exclusive_scan(sf, &tf);
+    int oc = block_exclusive_scan(sc, &tc);
+    int *sv = Lt.slot_vid2 + (long)f * S, *so = Lt.slot_off + (long)f * S;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long b = base + i;
+        if (b < S) {
+            sv[b] = fl[i] ? of : -1;
+            if (fl[i]) so[b] = oc;              // offsets are only ever read for occupied buckets
+        }
+        of += fl[i];
+        oc += cn[i];
+    }
+    if (threadIdx.x == 0) {
+        int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
+        bs[blockIdx.x] = tf;
+        bs[gridDim.x + 1 + blockIdx.x] = tc;
+    }
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_blocks_kernel(Lattice Lt, int nblk) {
+    const int f = blockIdx.x;
+    __shared__ int carry_s;
+    for (int which = 0; which < 2; which++) {
+        int *bs = Lt.blocksum2 + (long)f * 2 * (nblk + 1) + which * (nblk + 1);
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < nblk; b0 += SCAN_BLOCK) {
+            const int b = b0 + threadIdx.x;
+            const int v = b < nblk ? bs[b] : 0;
+            int total;
+            const int ex = block_exclusive_scan(v, &total);
+            const int carry = carry_s;
+            if (b < nblk) bs[b] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s = carry + total;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && which == 0) Lt.L[f] = carry_s;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const long S = 2 * Lt.E;
+    const int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
+    const int addf = bs[blockIdx.x], addc = bs[gridDim.x + 1 + blockIdx.x];
+    int *sv = Lt.slot_vid2 + (long)f * S, *so = Lt.slot_off + (long)f * S;
+    const unsigned *cursor = Lt.cursor + (long)f * S;
+    const long fb = (long)f * Lt.E;
+    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const long b = base + i;
+        if (b >= S) continue;
+        if (sv[b] >= 0) {
+            const int off = so[b] + addc;
+            so[b] = off;
+            const int v = sv[b] + addf;
+            sv[b] = v;
+            Lt.vrep[fb + v] = (int)b;
+            Lt.off[fb + v] = off;
+            Lt.cnt[fb + v] = (int)cursor[b];
+        }
+    }
+}
+// entry -> (vertex id, CSR slot): a streaming pass, no atomics
+__global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (idx >= Lt.E) return;
+    const long fb = (long)f * Lt.E, S = 2 * Lt.E;
+    const int b = Lt.vid[fb + idx];
+    const int v = Lt.slot_vid2[(long)f * S + b];
+    const int pos = Lt.slot_off[(long)f * S + b] + Lt.rel[fb + idx];
+    const int p = (int)(idx - (idx / Lt.N) * Lt.N);
+    Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));
+    Lt.vid[fb + idx] = v;
+}
+__global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
+    const int f = blockIdx.y;
+    const int pd = Lt.pd, nax = pd + 1;
+    const long Lf = Lt.L[f], S = 2 * Lt.E;
+    const unsigned long long *table = Lt.table + (long)f * S;
+    const int *sv = Lt.slot_vid2 + (long)f * S;
+    int *nb = Lt.nb + (long)f * Lt.E * 2 * nax;
+    const unsigned nbk = (unsigned)S;
+    const long total = Lf * nax;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long v = i / nax;
+        const int axis = (int)(i - v * nax);
+        short key[8];
+        unpack64(table[Lt.vrep[(long)f * Lt.E + v]], pd, key);
+        for (int k = 0; k < pd; k++) key[k] = (short)(key[k] + 1);
+        if (axis < pd) key[axis] = (short)(key[axis] - (pd + 1));
+        const unsigned long long want = pack64(key, pd);
+        unsigned h = key_hash(key, pd) % nbk;
+        for (;;) {
+            const unsigned long long cur = table[h];
+            if (cur == PK_EMPTY) break;
+            if (cur == want) {
+                const int u = sv[h];
+                nb[v * (2 * nax) + 2 * axis] = u;
+                nb[(long)u * (2 * nax) + 2 * axis + 1] = (int)v;
+                break;
+            }
+            if (++h == nbk) h = 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- iteration
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -694,6 +921,12 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
     L.inv = c.take<float>((size_t)F * N);
     L.blocksum = c.take<int>((size_t)F * (scan_blocks(L.E) + 1));
     L.L = c.take<int>(F);
+    L.table = reinterpret_cast<unsigned long long *>(L.keys);      // 2E x 8 B == E x 16 B
+    L.cursor = reinterpret_cast<unsigned *>(L.entries);
+    L.rel = c.take<int>(FE);
+    L.slot_vid2 = c.take<int>(2 * FE);
+    L.slot_off = c.take<int>(2 * FE);
+    L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
 }
 
 struct CrfBuffers {
@@ -718,11 +951,48 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
+int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build
+int build_lattice_norm(Lattice &L, int F, hipStream_t st);
+
+// bound on |key coordinate| (see lattice_point): elevated[i] in [-i*cf_i, sum_j cf_j], keys within pd+1 of it
+bool keys_fit_12bit(int pd, int W, int H, float posdev, float featdev) {
+    double posmax[PD_MAX] = {(double)W / posdev, (double)H / posdev, 255.0 / featdev, 255.0 / featdev, 255.0 / featdev};
+    const double inv_std = (pd + 1) * sqrt(2.0 / 3.0);
+    double sum = 0, worst = 0;
+    for (int i = 1; i <= pd; i++) {
+        const double cf = posmax[i - 1] / sqrt((double)i * (i + 1)) * inv_std;
+        sum += cf;
+        if (i * cf > worst) worst = i * cf;
+    }
+    return (sum > worst ? sum : worst) + 4.0 * (pd + 1) < 2040.0;
+}
+
+int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev,
+                         hipStream_t st) {
+    const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
+    const int nblk2 = scan_blocks(2 * L.E);
+    CK(hipMemsetAsync(L.table, 0xff, (size_t)F * 2 * L.E * sizeof(unsigned long long), st));
+    CK(hipMemsetAsync(L.cursor, 0, (size_t)F * 2 * L.E * sizeof(unsigned), st));
+    hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev);
+    hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
+    hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(pk_fill_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(pk_neighbours_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev, float weight,
                   hipStream_t st) {
     L.w = weight;
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
+    if (g_crf_variant == 0 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
+        if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) return e;
+        return build_lattice_norm(L, F, st);
+    }
     CK(hipMemsetAsync(L.entries, 0xff, (size_t)F * 2 * L.E * sizeof(int), st));
     hipLaunchKernelGGL(lattice_keys_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev);
     hipLaunchKernelGGL(lattice_insert_kernel, ge, dim3(256), 0, st, L);
@@ -738,7 +1008,13 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
     hipLaunchKernelGGL(csr_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(csr_fill_kernel, ge, dim3(256), 0, st, L);
-    // homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
+    RCF_LAUNCH_CHECK();
+    return build_lattice_norm(L, F, st);
+}
+
+// homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
+int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
+    const dim3 gp(rcf_cdiv(L.N, 256), F);
     float *za = reinterpret_cast<float *>(L.val0), *zb = reinterpret_cast<float *>(L.val1);
     hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(4096, F), dim3(256), 0, st, L, (const float *)nullptr, (void *)za);
     for (int axis = 0; axis <= L.pd; axis++) {
@@ -801,6 +1077,13 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
 }
 
 }  // namespace
+
+/* 0 (default): packed 64-bit-key lattice build whenever the key coordinates fit 12 bits; 1: always the array-of-keys
+ * build (A/B measurements and tests; results are identical) */
+extern "C" int rcf_crf_set_variant(int v) {
+    g_crf_variant = v;
+    return 0;
+}
 
 extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
     if (W <= 0 || H <= 0 || batch <= 0) return 0;

@@ -88,6 +88,28 @@ def test_crf_invariants_fullsize(report):
     assert 0 < nv[0, 1] <= 6 * H * W
 
 
+def test_crf_build_variants_identical(report):
+    """the packed 64-bit-key lattice build (default) and the array-of-keys build give the same MAP, Q and vertex count"""
+    from rcf_amd import _lib, synth
+    from rcf_amd.crf import crf_soft_batched
+    H, W = 120, 214
+    head = rcf_amd.CRFHead(None, refine_iters=5)
+    imgs = torch.from_numpy(np.stack([synth.normalize_rgb(synth.smooth_rgb(H, W, 4100 + i)) for i in range(3)])).to(DEV)
+    masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4100 + i) for i in range(3)])).to(DEV)
+    rgb, unary = head.prepare(imgs, masks)
+    out = {}
+    try:
+        for v in (0, 1):
+            _lib.load().rcf_crf_set_variant(v)
+            out[v] = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 5, want_q=True, want_nvert=True)
+    finally:
+        _lib.load().rcf_crf_set_variant(0)
+    same_map = bool(torch.equal(out[0][0], out[1][0]))
+    dq = float((out[0][1] - out[1][1]).abs().max())
+    report(f"crf build variants: MAP identical {same_map}, max |dQ| {dq:.2e}, vertices {out[0][2][:, 1].tolist()} vs {out[1][2][:, 1].tolist()}")
+    assert same_map and dq == 0.0 and torch.equal(out[0][2], out[1][2])
+
+
 def test_crf_hard_vs_oracle(report):
     H, W = 48, 64
     rgb = synth.smooth_rgb(H, W, 4400)
