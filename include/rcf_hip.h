@@ -126,6 +126,13 @@ int rcf_resize_bilinear_nhwc_fwd_f32(const float *x, int x_pitch, float *y, int 
 int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta, int N,
                                      int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void *stream);
 /* planar NCHW bilinear resize (ground-truth flows 480x854 -> mask size, models/rcf_model.py:438-442) */
+/* the same restricted to the border frame of thickness `frame` (fine-resolution pixels): fwd writes only the frame's
+ * output pixels, bwd takes dy as zero off the frame (and does not read it there).  See rcf_conv_region. */
+int rcf_resize_bilinear_nhwc_fwd_frame_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi, int Wi,
+                                           int Ho, int Wo, int C, int align_corners, int frame, void *stream);
+int rcf_resize_bilinear_nhwc_bwd_frame_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta, int N,
+                                           int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int frame,
+                                           void *stream);
 int rcf_resize_bilinear_nchw_f32(const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
                                  int align_corners, void *stream);
 /* NCHW [N,C,H,W] -> NHWC [N,H,W,Cpad] (channels >= C zero-filled) and back (drops the padding) */

@@ -68,6 +68,10 @@ PROTOS = {
     "rcf_maxpool3x3s2_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_maxpool3x3s2_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_resize_bilinear_nhwc_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_resize_bilinear_nhwc_fwd_frame_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                       c_int, P]),
+    "rcf_resize_bilinear_nhwc_bwd_frame_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                       c_int, c_int, P]),
     "rcf_resize_bilinear_nhwc_bwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                  c_int, P]),
     "rcf_resize_bilinear_nchw_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -109,20 +109,44 @@ inline float host_scale(int in, int out, int align) {
     return (float)in / (float)out;
 }
 
+// pixel q of the border frame of thickness t of an H x W image (top strip, bottom strip, left, right; row-major each)
+__device__ __forceinline__ void frame_yx(int q, int H, int W, int t, int &y, int &x) {
+    const int strip = t * W;
+    if (q < 2 * strip) {
+        const int bottom = q >= strip;
+        q -= bottom ? strip : 0;
+        y = q / W + (bottom ? H - t : 0);
+        x = q % W;
+    } else {
+        q -= 2 * strip;
+        const int side = t * (H - 2 * t);
+        const int right = q >= side;
+        q -= right ? side : 0;
+        y = t + q / t;
+        x = q % t + (right ? W - t : 0);
+    }
+}
+__device__ __forceinline__ bool in_frame(int y, int x, int H, int W, int t) {
+    return y < t || y >= H - t || x < t || x >= W - t;
+}
+
+// frame > 0: only the output pixels within `frame` of the border are written
 __global__ void __launch_bounds__(256) resize_nhwc_fwd_kernel(const float *__restrict__ x, int x_pitch,
                                                               float *__restrict__ y, int y_pitch, int N, int Hi,
                                                               int Wi, int Ho, int Wo, int C, int align, float sh,
-                                                              float sw) {
+                                                              float sw, int frame) {
     const int CV = C / 4;
-    const long total = (long)N * Ho * Wo * CV;
+    const int per_img = frame > 0 ? 2 * frame * Wo + 2 * frame * (Ho - 2 * frame) : Ho * Wo;
+    const long total = (long)N * per_img * CV;
     const long step = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const int cv = (int)(i % CV);
         long t = i / CV;
-        const int xo = (int)(t % Wo);
-        t /= Wo;
-        const int yo = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        const int q = (int)(t % per_img);
+        const int n = (int)(t / per_img);
+        int yo, xo;
+        if (frame > 0) frame_yx(q, Ho, Wo, frame, yo, xo);
+        else { yo = q / Wo; xo = q - yo * Wo; }
         int y0, y1, x0, x1;
         float ly, lx;
         src_index(yo, sh, align, Hi, y0, y1, ly);
@@ -163,10 +187,11 @@ __device__ __forceinline__ void cand_range(int in_idx, float scale, int align, i
     if (hi > out_size - 1) hi = out_size - 1;
 }
 
+// frame > 0: dy is taken as zero outside the border frame of that thickness (and not read there)
 __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__restrict__ dy, int dy_pitch,
                                                               float *__restrict__ dx, int dx_pitch, int beta, int N,
                                                               int Hi, int Wi, int Ho, int Wo, int C, int align,
-                                                              float sh, float sw) {
+                                                              float sh, float sw, int frame) {
     const int CV = C / 4;
     const long total = (long)N * Hi * Wi * CV;
     const long step = (long)gridDim.x * blockDim.x;
@@ -187,6 +212,7 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__res
             for (int xo = xlo; xo <= xhi; ++xo) {
                 const float wx = tap_weight(xo, xi, sw, align, Wi);
                 if (wx == 0.f) continue;
+                if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) continue;
                 const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
                 acc += g * (wy * wx);
             }
@@ -316,7 +342,20 @@ extern "C" int rcf_resize_bilinear_nhwc_fwd_f32(const float *x, int x_pitch, flo
     if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     hipLaunchKernelGGL(resize_nhwc_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        rcf_stream(stream), x, x_pitch, y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners));
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_resize_bilinear_nhwc_fwd_frame_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi,
+                                                      int Wi, int Ho, int Wo, int C, int align_corners, int frame,
+                                                      void *stream) {
+    if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    if (frame <= 0 || 2 * frame >= Ho || 2 * frame >= Wo) return RCF_EINVAL;
+    const long px = (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame));
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel, dim3(ew_blocks(px * (C / 4))), dim3(256), 0, rcf_stream(stream), x, x_pitch,
+                       y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners, host_scale(Hi, Ho, align_corners),
+                       host_scale(Wi, Wo, align_corners), frame);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -327,7 +366,19 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, f
     if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
                        rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners));
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_resize_bilinear_nhwc_bwd_frame_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta,
+                                                      int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                                                      int frame, void *stream) {
+    if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    if (frame <= 0 || 2 * frame >= Ho || 2 * frame >= Wo) return RCF_EINVAL;
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
+                       rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -283,8 +283,9 @@ def commuted_concat_conv(a, b, conv, tape):
         conv_d(U; Wb) == bilinear_2x(conv_{d/2}(b; Wb))
     wherever neither the zero padding of the conv nor the edge clamp of the resize is involved: everywhere except a
     band of d+1 pixels along the border (checked numerically in tests).  So: the up-sampled channels are convolved at
-    HALF resolution (1/4 of the FLOPs) and up-sampled afterwards, `a`'s channels are convolved on the interior only,
-    and the border band is computed directly from the concatenated tensor with the rectangle-restricted kernels.
+    HALF resolution (1/4 of the FLOPs) and up-sampled afterwards, the border band is computed directly from the
+    up-sampled channels with the region-restricted kernels (the up-sampling itself is only materialised on the frame
+    the band's taps reach), and `a`'s channels are an ordinary 256-channel conv added on top.
     The backward is the adjoint of exactly these pieces.  Same arithmetic up to fp32 summation order."""
     N, h, w, Ca = a.t.shape
     hb, wb, Cb = b.t.shape[1], b.t.shape[2], b.t.shape[3]
@@ -294,42 +295,39 @@ def commuted_concat_conv(a, b, conv, tape):
     W = conv.weight
     wa = W[:, :Ca].contiguous(memory_format=torch.channels_last)
     wbt = W[:, Ca:].contiguous(memory_format=torch.channels_last)
-    U = torch.empty((N, h, w, C), dtype=torch.float32, device=a.t.device)
-    ops.copy2d(a.t, Ca, U, C, N * h * w, Ca)
-    ops.resize_nhwc_fwd(b.t, (h, w), False, out=U[..., Ca:])
+    # the up-sampled channels are only ever needed on the frame the band's taps reach (bi = bw + d pixels)
+    Uup = torch.empty((N, h, w, Cb), dtype=torch.float32, device=a.t.device)
+    ops.resize_nhwc_fwd(b.t, (h, w), False, out=Uup, frame=bi)
     interior = (bw, bw, h - 2 * bw, w - 2 * bw)
     band = (0, 0, h, w, bw)                      # the border frame of thickness bw, one launch
     Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2)
-    y = ops.resize_nhwc_fwd(Z, (h, w), False)
-    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, region=interior)
-    ops.conv2d_fwd(U, W, None, 1, d, d, out=y, beta=0, region=band)
+    y = ops.resize_nhwc_fwd(Z, (h, w), False)                              # interior: conv_d(up2(b)) = up2(conv_{d/2}(b))
+    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band)    # band: directly
+    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1)                  # a's channels: everywhere
     ya = Act(y)
 
     def bwd():
         dy = ya.take_grad()
         dy_int, dy_band = ops.split_rect(dy, interior)
-        g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)
+        g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)                  # adjoint of the interior's up-sampling
         if W.requires_grad:
             gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
-            ops.conv2d_wgrad(U, dy, W, _param_grad(W), 1, d, d, beta=1, region=band)   # band pixels: the full filter
             dwa = torch.empty_like(wa)
-            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0, region=interior)
+            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0)
             ops.copy2d(dwa.permute(0, 2, 3, 1), Ca, gW[..., :Ca], C, Co * 9, Ca, beta=1)
             dwb = torch.empty_like(wbt)
             ops.conv2d_wgrad(b.t, g4, wbt, dwb, 1, d // 2, d // 2, beta=0)
+            ops.conv2d_wgrad(Uup, dy, wbt, dwb, 1, d, d, beta=1, region=band)
             ops.copy2d(dwb.permute(0, 2, 3, 1), Cb, gW[..., Ca:], C, Co * 9, Cb, beta=1)
-        if a.needs_grad or b.needs_grad:
-            dU = torch.empty_like(U)
-            ops.fill(dU, 0.0)
-            ops.conv2d_dgrad(dy_band, W, U.shape, 1, d, d, out=dU, beta=0, region=(0, 0, h, w, bi))
-            if a.needs_grad:
-                ga, beta = a.grad_slot()
-                ops.copy2d(dU, C, ga, ops.pitch_of(ga), N * h * w, Ca, beta=beta)
-                ops.conv2d_dgrad(dy_int, wa, a.t.shape, 1, d, d, out=ga, beta=1)
-            if b.needs_grad:
-                gb, beta = b.grad_slot()
-                ops.resize_nhwc_bwd(dU[..., Ca:], (hb, wb), False, out=gb, beta=beta)
-                ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1)
+        if a.needs_grad:
+            ga, beta = a.grad_slot()
+            ops.conv2d_dgrad(dy, wa, a.t.shape, 1, d, d, out=ga, beta=beta)
+        if b.needs_grad:
+            gb, beta = b.grad_slot()
+            dUup = torch.empty_like(Uup)                                   # written (and read) on the bi-frame only
+            ops.conv2d_dgrad(dy_band, wbt, Uup.shape, 1, d, d, out=dUup, beta=0, region=(0, 0, h, w, bi))
+            ops.resize_nhwc_bwd(dUup, (hb, wb), False, out=gb, beta=beta, frame=bi)
+            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1)
     tape.push(bwd)
     return ya
 

@@ -264,23 +264,33 @@ def maxpool_bwd(dy, am, xshape):
     return dx
 
 
-def resize_nhwc_fwd(x, size, align_corners=False, out=None):
+def resize_nhwc_fwd(x, size, align_corners=False, out=None, frame=0):
+    """frame > 0: only the output pixels within `frame` of the border are written"""
     N, Hi, Wi, C = x.shape
     Ho, Wo = size
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    call("rcf_resize_bilinear_nhwc_fwd_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
-         int(align_corners), _stream())
+    if frame > 0:
+        call("rcf_resize_bilinear_nhwc_fwd_frame_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
+             int(align_corners), int(frame), _stream())
+    else:
+        call("rcf_resize_bilinear_nhwc_fwd_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
+             int(align_corners), _stream())
     return out
 
 
-def resize_nhwc_bwd(dy, in_size, align_corners=False, out=None, beta=0):
+def resize_nhwc_bwd(dy, in_size, align_corners=False, out=None, beta=0, frame=0):
+    """frame > 0: dy counts as zero (and is not read) outside the border frame of that thickness"""
     N, Ho, Wo, C = dy.shape
     Hi, Wi = in_size
     if out is None:
         out = torch.empty((N, Hi, Wi, C), dtype=torch.float32, device=dy.device)
-    call("rcf_resize_bilinear_nhwc_bwd_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho, Wo, C,
-         int(align_corners), _stream())
+    if frame > 0:
+        call("rcf_resize_bilinear_nhwc_bwd_frame_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho,
+             Wo, C, int(align_corners), int(frame), _stream())
+    else:
+        call("rcf_resize_bilinear_nhwc_bwd_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho, Wo, C,
+             int(align_corners), _stream())
     return out
 
 

@@ -339,6 +339,31 @@ def test_warp_family_vs_golden(golden_dir, report):
         assert e_b < 2e-5 and e_z < 2e-5 and m_b < 2e-3 and m_bi < 2e-3 and e_p < 1e-4 and e_l1 < 1e-5
 
 
+def test_resize_frame_variants(report):
+    """frame-restricted bilinear resize: fwd writes exactly the frame's pixels of the full resize; bwd equals the
+    full bwd of a gradient zeroed off the frame (and never reads it there: NaNs planted in the interior)"""
+    g = torch.Generator().manual_seed(9)
+    N, hi, wi, C, t = 2, 9, 13, 8, 4
+    x = torch.randn(N, hi, wi, C, generator=g).to(DEV)
+    full = ops.resize_nhwc_fwd(x, (2 * hi, 2 * wi), False)
+    out = torch.full_like(full, 7.0)
+    ops.resize_nhwc_fwd(x, (2 * hi, 2 * wi), False, out=out, frame=t)
+    m = torch.ones(2 * hi, 2 * wi, dtype=torch.bool)
+    m[t:-t, t:-t] = False
+    m = m.to(DEV)
+    ok_f = bool(torch.equal(out[:, m], full[:, m])) and float((out[:, ~m] - 7.0).abs().max()) == 0.0
+    dy = torch.randn(N, 2 * hi, 2 * wi, C, generator=g).to(DEV)
+    masked = dy.clone()
+    masked[:, ~m] = 0
+    ref = ops.resize_nhwc_bwd(masked, (hi, wi), False)
+    poisoned = dy.clone()
+    poisoned[:, ~m] = float("nan")
+    got = ops.resize_nhwc_bwd(poisoned, (hi, wi), False, frame=t)
+    e_b = float((got - ref).abs().max())
+    report(f"resize frame: fwd exact {ok_f}, bwd |d| {e_b:.2e}")
+    assert ok_f and e_b < 1e-6
+
+
 @pytest.mark.parametrize("H,W", [(6, 10), (7, 9), (12, 854)])
 def test_warp_odd_shapes_vs_oracle(H, W, report):
     """flow_warp / fused warp+L1 on shapes whose rows are not multiples of the wavefront or of 4 (and the real
