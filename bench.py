@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--width", type=int, default=854)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--crf-iters", type=int, default=5)
+    ap.add_argument("--no-stage2", action="store_true")
     a = ap.parse_args()
 
     import numpy as np
@@ -140,6 +141,16 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             out["warp_roofline"] = None
             out["warp_error"] = str(e)[:200]
+        # stage 2.1 (BASELINE configs[3]): the same step with CRF self-labels (16 frames through the HIP mean-field
+        # CRF, T=5) and the EMA teacher forward + update in the loop
+        if not a.no_stage2 and world == 1:
+            try:
+                del trainer, model
+                torch.cuda.empty_cache()
+                out["stage2_step"] = stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, a.crf_iters)
+            except Exception as e:                              # noqa: BLE001
+                out["stage2_step"] = None
+                out["stage2_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(out), flush=True)
@@ -175,6 +186,26 @@ def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8):
             "algorithmic_bytes_per_frame": round(alg),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4)}}
+
+
+def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, steps=3):
+    import types
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=1, eval_save=False, eval_export=False)
+    model = rcf_amd.RCFModel(args, **config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN",
+                                                                 refine_iters=iters))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev)
+    tr.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = tr.step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"stage 2.1 step: stage-1 step + EMA teacher forward + CRF (T={iters}) on {2 * B} frames + EMA update",
+            "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(2 * B / dt, 2),
+            "loss_crf": round(float(losses["loss_crf"]), 6)}
 
 
 def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):

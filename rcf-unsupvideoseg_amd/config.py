@@ -91,6 +91,17 @@ def stage1_model_kwargs(mask_size=(120, 214), mask_layer=4, dropout=0.1, affine=
                           loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0)))
 
 
+def stage21_model_kwargs(mask_size=(120, 214), dropout=0.1, norm="SyncBN", refine_iters=5):
+    """configs/rcf/rcf_stage2.1.yaml on top of stage 1: CRF self-labels from the EMA teacher (w_crf 10, pos/neg weights
+    2/1, ema 0.999); `refine_iters` 5 is BASELINE configs[3] (the reference default is 50)"""
+    kw = stage1_model_kwargs(mask_size, dropout=dropout, norm=norm)
+    kw.update(w_entropy=0, w_crf=10.0, crf_use_ema=True, ema_m=0.999, crf_pos_weight=2.0, crf_neg_weight=1.0,
+              crf_head=dict(type="CRFHead", refine_iters=refine_iters))
+    kw["backbone2"]["create_ema"] = True
+    kw["decode_head2"]["create_ema"] = True
+    return kw
+
+
 def mask_size_for(H, W):
     """spatial size after the 7x7/2 stem and the 3x3/2 max-pool."""
     h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -21,13 +21,7 @@ def rel(a, b):
 
 
 def _kwargs(H, W):
-    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
-    # configs/rcf/rcf_stage2.1.yaml: CRF loss on the EMA teacher's masks
-    kw.update(w_entropy=0, w_crf=10.0, crf_use_ema=True, ema_m=0.999, crf_pos_weight=2.0, crf_neg_weight=1.0,
-              crf_head=dict(type="CRFHead", refine_iters=5))
-    kw["backbone2"]["create_ema"] = True
-    kw["decode_head2"]["create_ema"] = True
-    return kw
+    return config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
 
 
 def test_stage21_step_vs_oracle(report):
