@@ -54,22 +54,39 @@ __device__ __forceinline__ Taps make_taps(float px, float py, int W, int H, int 
 
 typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte load, dword aligned
 
-// the two horizontal taps of a row are adjacent: one 8-byte load when both are inside the image
-__device__ __forceinline__ float row_taps(const float *__restrict__ row, const Taps &t, float w0, float w1) {
-    if (t.inx0 && t.inx1) {
-        const f32x2_a4 v = *reinterpret_cast<const f32x2_a4 *>(row + t.x0);
-        return v[0] * w0 + v[1] * w1;
-    }
-    float r = 0.f;
-    if (t.inx0) r += row[t.x0] * w0;
-    if (t.inx1) r += row[t.x0 + 1] * w1;
-    return r;
-}
-__device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps &t, int W) {
+// Branch-free bilinear sample: the two horizontal taps of a row are adjacent, so each row is ONE 8-byte load at a
+// clamped (always valid) position; taps that fall outside the image get weight 0 through selects, never through
+// control flow -- all tap loads of a pixel (2 per channel) issue back to back.
+struct Sampler {
+    int off0, off1;          // float offsets of the two row loads inside a plane
+    float w00, w01, w10, w11;   // weights of (row0: x0, x0+1), (row1: x0, x0+1); 0 for taps outside
+    bool s00, s01;           // which element of the loaded pair is tap x0 / x0+1 (false = [0], true = [1])
+};
+__device__ __forceinline__ Sampler make_sampler(const Taps &t, int W, int H) {
+    Sampler s;
+    const int xb = min(max(t.x0, 0), W - 2);                 // pair base: both elements inside the row
+    const int y0c = min(max(t.y0, 0), H - 1), y1c = min(max(t.y0 + 1, 0), H - 1);
+    s.off0 = y0c * W + xb;
+    s.off1 = y1c * W + xb;
+    s.s00 = t.x0 != xb;                                       // x0 == xb + 1 (only when x0 == W-1)
+    s.s01 = t.x0 + 1 != xb;                                   // false only when x0 == -1
     const float ex = 1.f - t.wx, ey = 1.f - t.wy;
+    const float m0 = t.inx0 ? 1.f : 0.f, m1 = t.inx1 ? 1.f : 0.f, r0 = t.iny0 ? 1.f : 0.f, r1 = t.iny1 ? 1.f : 0.f;
+    s.w00 = ey * ex * m0 * r0;
+    s.w01 = ey * t.wx * m1 * r0;
+    s.w10 = t.wy * ex * m0 * r1;
+    s.w11 = t.wy * t.wx * m1 * r1;
+    return s;
+}
+__device__ __forceinline__ float sample(const float *__restrict__ plane, const Sampler &s) {
+    const f32x2_a4 a = *reinterpret_cast<const f32x2_a4 *>(plane + s.off0);
+    const f32x2_a4 b = *reinterpret_cast<const f32x2_a4 *>(plane + s.off1);
+    const float a0 = s.s00 ? a[1] : a[0], a1 = s.s01 ? a[1] : a[0];
+    const float b0 = s.s00 ? b[1] : b[0], b1 = s.s01 ? b[1] : b[0];
+    // same order of operations as grid_sample's accumulation: row 0 (x0, x0+1), then row 1
     float v = 0.f;
-    if (t.iny0) v += row_taps(plane + t.y0 * W, t, ey * ex, ey * t.wx);
-    if (t.iny1) v += row_taps(plane + (t.y0 + 1) * W, t, t.wy * ex, t.wy * t.wx);
+    v += a0 * s.w00 + a1 * s.w01;
+    v += b0 * s.w10 + b1 * s.w11;
     return v;
 }
 
@@ -84,8 +101,8 @@ __global__ void __launch_bounds__(256) flow_warp_kernel(const float *__restrict_
     float *ob = out + b * C * HW;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
         const int py = p / W, px = p - py * W;
-        const Taps t = make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode);
-        for (int c = 0; c < C; ++c) ob[c * HW + p] = sample(xb + c * HW, t, W);
+        const Sampler sm = make_sampler(make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode), W, H);
+        for (int c = 0; c < C; ++c) ob[c * HW + p] = sample(xb + c * HW, sm);
     }
 }
 
@@ -161,8 +178,8 @@ __global__ void __launch_bounds__(256) occ_bidir_kernel(const float *__restrict_
         const long b = i / HW, p = i - b * HW;
         const int py = (int)(p / W), px = (int)(p - (long)py * W);
         const float ax = f12[(b * 2) * HW + p], ay = f12[(b * 2 + 1) * HW + p];
-        const Taps t = make_taps((float)px + ax, (float)py + ay, W, H, 1);
-        const float wx = sample(f21 + (b * 2) * HW, t, W), wy = sample(f21 + (b * 2 + 1) * HW, t, W);
+        const Sampler sm = make_sampler(make_taps((float)px + ax, (float)py + ay, W, H, 1), W, H);
+        const float wx = sample(f21 + (b * 2) * HW, sm), wy = sample(f21 + (b * 2 + 1) * HW, sm);
         const float dx = ax + wx, dy = ay + wy;
         const float mag = (ax * ax + ay * ay) + (wx * wx + wy * wy);
         occ[i] = (dx * dx + dy * dy) > scale * mag + bias ? 1.f : 0.f;
@@ -191,14 +208,30 @@ __global__ void __launch_bounds__(256) warp_l1_kernel(const float *__restrict__ 
     const long b = blockIdx.y;
     const float *fl = flow + b * 2 * HW;
     double s = 0, so = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    auto pixel = [&](int p, float &acc, float &o) {
         const int py = p / W, px = p - py * W;
-        const Taps t = make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode);
-        const float o = occ ? occ[b * HW + p] : 1.f;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += fabsf(im1[(b * C + c) * HW + p] - sample(im2 + (b * C + c) * HW, t, W));
-        s += (double)(acc * o);
-        so += (double)o;
+        const Sampler sm = make_sampler(make_taps((float)px + fl[p], (float)py + fl[HW + p], W, H, pad_mode), W, H);
+        o = occ ? occ[b * HW + p] : 1.f;
+        acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += fabsf(im1[(b * C + c) * HW + p] - sample(im2 + (b * C + c) * HW, sm));
+    };
+    const int stride = gridDim.x * blockDim.x;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // two independent pixels per trip: twice the loads in flight per wavefront
+    for (; p + stride < HW; p += 2 * stride) {
+        float a0, o0, a1, o1;
+        pixel(p, a0, o0);
+        pixel(p + stride, a1, o1);
+        s += (double)(a0 * o0);
+        so += (double)o0;
+        s += (double)(a1 * o1);
+        so += (double)o1;
+    }
+    if (p < HW) {
+        float a0, o0;
+        pixel(p, a0, o0);
+        s += (double)(a0 * o0);
+        so += (double)o0;
     }
     block_add2(s, so, out);
 }
