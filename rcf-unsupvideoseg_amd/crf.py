@@ -83,6 +83,12 @@ class CRFHead(nn.Module):
 
     def prepare(self, imgs, masks, unstandardize=True):
         """models/crf_head.py:33-37,43-55,95-98 on the GPU: -> (u8 image [N,H,W,3], unary [N,HW,2])."""
+        if not unstandardize:
+            # models/crf_head.py:93-98: without `unnormalize` there is no permute either -- the caller passes
+            # [N,H,W,3] images already in [0,1] (tools/SemanticConstraintsAndMAA/semantic_constraints.py:293-306)
+            if imgs.dim() != 4 or imgs.shape[-1] != 3:
+                raise RuntimeError("CRFHead(unstandardize=False) takes [N,H,W,3] images in [0,1]")
+            imgs = imgs.permute(0, 3, 1, 2)
         imgs, masks = imgs.contiguous().float(), masks.contiguous().float()
         N, _, H, W = imgs.shape
         mean, std = self._mean_std(imgs.device)

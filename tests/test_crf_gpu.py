@@ -110,6 +110,33 @@ def test_crf_build_variants_identical(report):
     assert same_map and dq == 0.0 and torch.equal(out[0][2], out[1][2])
 
 
+def test_offline_callers(report):
+    """the offline 480x854 CRF callers (rcf_amd.offline): the pydenseCRF-style `refine` against the C restatement run
+    on the same unary, and the double-CRF merge of semantic_constraints.py (unstandardize=False takes NHWC [0,1])"""
+    from rcf_amd import offline
+    H, W = 96, 130
+    img = synth.smooth_rgb(H, W, 4200)                                     # u8 [H,W,3]
+    soft = synth.soft_blob_mask(H, W, 4200)
+    mask_u8 = (np.asarray(soft) * 255 / 0.8).clip(0, 255).astype(np.uint8)   # tools/pydenseCRF/crf.py:174
+    got = offline.refine(mask_u8, img, 0.1, 60.0, 5.0, 5.0, None, iters=10)
+    unary = offline._unary_from_u8(mask_u8, 0.1)
+    ref = crf_oracle.crf_soft_np(img, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 10)[0]
+    agree = float((got == ref.astype(np.float32)).mean())
+    new_mask, iou = offline.refine(mask_u8, img, 0.1, 60.0, 5.0, 5.0, (np.asarray(soft) > 0.5).astype(np.float32), iters=10)
+    # double CRF merge: equals the product of the two heads run separately
+    head_a = rcf_amd.CRFHead(None, refine_iters=5, crf_scale=0.7)
+    head_b = rcf_amd.CRFHead(None, refine_iters=5, crf_scale=0.5)
+    imgs = torch.from_numpy(img[None].astype(np.float32) / 255.0).to(DEV)                  # [1,H,W,3] in [0,1]
+    m = torch.from_numpy(np.asarray(soft)[None].astype(np.float32)).to(DEV)
+    merged = offline.double_crf_merge(head_a, head_b, imgs, m, m)
+    rgb, _ = head_a.prepare(imgs, m, unstandardize=False)                  # models/crf_head.py:97-98: *255, clamp, truncate
+    same_u8 = bool(torch.equal(rgb, (imgs * 255.0).clamp(0.0, 255.0).to(torch.uint8)))
+    prod = head_a(imgs, m, unstandardize=False) * head_b(imgs, m, unstandardize=False)
+    e_merge = float((merged - prod).abs().max()) + (0.0 if same_u8 else 1.0)
+    report(f"offline refine vs C restatement: pixel agreement {agree:.5f}, iou vs blob {iou:.3f}; double-CRF merge |d| {e_merge}")
+    assert agree > 0.999 and 0.0 < iou <= 1.0 and e_merge == 0.0
+
+
 def test_crf_hard_vs_oracle(report):
     H, W = 48, 64
     rgb = synth.smooth_rgb(H, W, 4400)
