@@ -260,6 +260,26 @@ int rcf_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
 int rcf_ema_update_f32(float *dest, const float *src, long n, float m, void *stream);
 int rcf_fill_f32(float *p, long n, float v, void *stream);
 
+/* ---- DINO ViT forward + soft NCut -----------------------------------------
+ * models/dino_vit.py:110-167,176-276 (nn.Linear / attention products, LayerNorm eps 1e-6, softmax, GELU) and
+ * tools/SemanticConstraintsAndMAA/semantic_constraints.py:21-75 (soft NCut value, Adam refinement of the mask). */
+/* C[M][N] (pitch ldc) (+)= A[M][K] (pitch lda) . B[N][K]^T (pitch ldb) + bias[N]; act 0 none / 1 LeakyReLU / 2 GELU(erf).
+ * Runs on the split-bf16 conv kernel (fp32 accuracy).  K, lda, ldb, ldc multiples of 4. */
+int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
+                    int K, int act, float slope, int beta, void *stream);
+int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C, const float *gamma,
+                      const float *beta, float eps, void *stream);
+/* in place: row <- softmax(scale * row[0:n]); columns [n, pitch) are zeroed */
+int rcf_softmax_rows_f32(float *s, long pitch, long rows, int n, float scale, void *stream);
+/* dst[c][r] = src[r][c]; dst columns [rows, dpitch) zero-filled */
+int rcf_transpose2d_f32(const float *src, long spitch, float *dst, long dpitch, int rows, int cols, void *stream);
+int rcf_l2_normalize_rows_f32(const float *x, long x_pitch, float *y, long y_pitch, long rows, int C, void *stream);
+/* gram[i][j] <- gram[i][j] > tau ? 1 : eps */
+int rcf_affinity_threshold_f32(float *gram, long pitch, int n, float tau, float eps, void *stream);
+int rcf_ncut_value_grad_f32(const float *affinity, long pitch, int n, const float *x, double *u, double *rowsum,
+                            int compute_rowsum, float *grad, float *value_out, void *stream);
+int rcf_clamp01_f32(float *x, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

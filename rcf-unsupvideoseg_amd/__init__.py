@@ -6,7 +6,7 @@ helpers of utils/warp_utils.py and a `torchcrf_cpp`-shaped `crf_soft` / `crf_har
 """
 __version__ = "0.1.0"
 
-from . import _lib, offline, ops, synth  # noqa: F401
+from . import _lib, ncut, offline, ops, synth, vit  # noqa: F401
 from .backbone import FCNHead, ResNet  # noqa: F401
 from .crf import CRFHead, crf_hard, crf_soft  # noqa: F401
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual  # noqa: F401

@@ -49,6 +49,14 @@ PROTOS = {
     "rcf_conv2d_wgrad_region_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv_regions_available": (c_int, []),
+    "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "rcf_layernorm_f32": (c_int, [P, c_int, P, c_int, c_long, c_int, P, P, c_float, P]),
+    "rcf_softmax_rows_f32": (c_int, [P, c_long, c_long, c_int, c_float, P]),
+    "rcf_transpose2d_f32": (c_int, [P, c_long, P, c_long, c_int, c_int, P]),
+    "rcf_l2_normalize_rows_f32": (c_int, [P, c_long, P, c_long, c_long, c_int, P]),
+    "rcf_affinity_threshold_f32": (c_int, [P, c_long, c_int, c_float, c_float, P]),
+    "rcf_ncut_value_grad_f32": (c_int, [P, c_long, c_int, P, P, P, c_int, P, P, P]),
+    "rcf_clamp01_f32": (c_int, [P, c_int, P]),
     "rcf_crf_set_variant": (c_int, [c_int]),
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),

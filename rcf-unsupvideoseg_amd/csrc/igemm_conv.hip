@@ -607,6 +607,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 if (n0 + brow0 + nr * 32 + l31 >= p.Ncol) continue;
                 float v = acc[mr][nr][e] + bv[nr];
                 if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+                else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (erf form)
                 if (p.beta) v += drow[nr * 32];
                 drow[nr * 32] = v;
             }
@@ -1288,6 +1289,26 @@ int set_region(IgemmParams &p, const rcf_conv_region *r, int N, int H, int W) {
     return 0;
 }
 }  // namespace
+
+/* C[M][N] (pitch ldc) (+)= A[M][K] (pitch lda) . B[N][K]^T (pitch ldb) + bias[N], then act (0 none, 1 LeakyReLU,
+ * 2 GELU): nn.Linear / attention products of the DINO ViT (models/dino_vit.py:110-134) on the split-bf16 conv
+ * kernel -- a 1x1 convolution whose "pixels" are the M rows. */
+extern "C" int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
+                               int M, int N, int K, int act, float slope, int beta, void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || ldc % 4) return RCF_EINVAL;
+    if (lda < K || ldb < K || ldc < N || !rcf_aligned16(A) || !rcf_aligned16(B) || !rcf_aligned16(C)) return RCF_EINVAL;
+    if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29)) return RCF_EINVAL;      // 32-bit descriptor offsets
+    if (!use_x3(1)) return RCF_EINVAL;
+    IgemmParams p{};
+    p.A = A; p.Bw = B; p.bias = bias; p.Y = C;
+    p.M = M; p.Ncol = N; p.K = K;
+    p.Ho = M; p.Wo = 1; p.Hs = M; p.Ws = 1; p.Cs = K; p.S = 1;
+    p.up = 1; p.off = 0; p.step = 1; p.div = 1;
+    p.a_pitch = lda; p.a_img_stride = (long)M * lda; p.y_pitch = ldc;
+    p.ldb = ldb; p.act = act; p.slope = slope; p.beta = beta;
+    p.ry0 = 0; p.rx0 = 0; p.rh = M; p.rw = 1; p.rband = 0; p.rr = M;
+    return launch_igemm_x3(p, rcf_stream(stream));
+}
 
 extern "C" int rcf_conv_regions_available(void) { return use_x3(1) && use_x3(2) && use_x3(4) ? 1 : 0; }
 

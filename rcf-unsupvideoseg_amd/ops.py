@@ -414,3 +414,54 @@ def ema_update(dest, src, m):
 
 def fill(t, v):
     call("rcf_fill_f32", _p(t), t.numel(), float(v), _stream())
+
+
+# ---- DINO ViT / soft NCut helpers (csrc/vit.hip, rcf_gemm_nt_f32) ---------------------------------------------------
+def _row_pitch(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
+    return t.stride(0)
+
+
+def gemm_nt(a, b, bias=None, out=None, act=0, beta=0):
+    """out[M,N] (+)= a[M,K] @ b[N,K]^T + bias, act 0 none / 2 GELU.  a, b, out: row-major 2-D views (rows may be pitched)."""
+    _need_cuda(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty((M, (N + 3) // 4 * 4), dtype=torch.float32, device=a.device)[:, :N]
+    call("rcf_gemm_nt_f32", _p(a), _row_pitch(a), _p(b), _row_pitch(b), _p(bias), _p(out), _row_pitch(out), M, N, K,
+         int(act), 0.0, int(beta), _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    _need_cuda(x)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    call("rcf_layernorm_f32", _p(x), _row_pitch(x), _p(out), _row_pitch(out), rows, C, _p(gamma), _p(beta), float(eps),
+         _stream())
+    return out
+
+
+def softmax_rows_(s, n, scale):
+    """in place on a [rows, pitch] buffer: softmax(scale * s[:, :n]); columns >= n zeroed"""
+    call("rcf_softmax_rows_f32", _p(s), _row_pitch(s), s.shape[0], int(n), float(scale), _stream())
+    return s
+
+
+def transpose2d(src, out_cols=None):
+    """src [rows, cols] (pitched) -> dense [cols, out_cols >= rows], extra columns zero"""
+    rows, cols = src.shape
+    oc = rows if out_cols is None else int(out_cols)
+    dst = torch.empty((cols, oc), dtype=torch.float32, device=src.device)
+    call("rcf_transpose2d_f32", _p(src), _row_pitch(src), _p(dst), oc, rows, cols, _stream())
+    return dst
+
+
+def l2_normalize_rows(x):
+    rows, C = x.shape
+    out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    call("rcf_l2_normalize_rows_f32", _p(x), _row_pitch(x), _p(out), C, rows, C, _stream())
+    return out

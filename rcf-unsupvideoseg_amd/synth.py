@@ -147,3 +147,18 @@ def fill_state_dict(shapes, seed=7, bn3_gamma=0.5, seg_scale=10.0):
                 w *= seg_scale
             out[name] = w
     return out
+
+
+def fill_vit_state_dict(shapes, seed=21):
+    """Seeded weights for the DINO ViT parity fixtures (no checkpoint can be downloaded): N(0, 0.05) matrices,
+    N(0, 0.02) biases / tokens, LayerNorm scale 1 + N(0, 0.1).  Same generator on both sides of every comparison."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, shp in shapes.items():
+        if "norm" in k and k.endswith("weight"):
+            out[k] = (1.0 + 0.1 * g.standard_normal(shp)).astype(np.float32)
+        elif k.endswith("bias") or k in ("cls_token", "pos_embed"):
+            out[k] = (0.02 * g.standard_normal(shp)).astype(np.float32)
+        else:
+            out[k] = (0.05 * g.standard_normal(shp)).astype(np.float32)
+    return out

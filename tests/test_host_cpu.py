@@ -130,3 +130,13 @@ def test_export_grid_and_rounding():
     assert float(g[:, :2].abs().max()) == 0 and float(g[:, 2:7, 2:9].min()) == 1 and float(g[:, 9:14, 20:].max()) == 0
     u8 = export.to_uint8_hwc(torch.tensor([[[0.0, 0.5, 1.0, 1.2, -0.3, 0.998]]]))
     assert u8[0, :, 0].tolist() == [0, 128, 255, 255, 0, 254] and u8.shape == (1, 6, 3)
+
+
+def test_vit_state_dict_schema_matches_reference(golden_dir):
+    """parameter names / shapes of rcf_amd.vit.vit_small(patch_size=8) == models/dino_vit.py's (captured in the fixture)"""
+    import os
+    import numpy as np
+    from rcf_amd import vit
+    fx = np.load(os.path.join(golden_dir, "vit_small8.npz"))
+    mine = [f"{k}:{'x'.join(map(str, v.shape))}" for k, v in vit.vit_small(patch_size=8).state_dict().items()]
+    assert mine == [str(s) for s in fx["schema"]]
