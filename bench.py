@@ -151,6 +151,13 @@ def main():
             except Exception as e:                              # noqa: BLE001
                 out["stage2_step"] = None
                 out["stage2_error"] = str(e)[:200]
+        # DINO ViT-S/8 forward + soft NCut at 480x856 (the realisable part of BASELINE configs[4])
+        if not a.no_stage2 and world == 1:
+            try:
+                out["vit_s8_ncut"] = vit_bench(torch, rcf_amd, synth, dev)
+            except Exception as e:                              # noqa: BLE001
+                out["vit_s8_ncut"] = None
+                out["vit_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(out), flush=True)
@@ -206,6 +213,34 @@ def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, step
     return {"workload": f"stage 2.1 step: stage-1 step + EMA teacher forward + CRF (T={iters}) on {2 * B} frames + EMA update",
             "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(2 * B / dt, 2),
             "loss_crf": round(float(losses["loss_crf"]), 6)}
+
+
+def vit_bench(torch, rcf_amd, synth, dev, frames=2):
+    from rcf_amd import ncut, vit
+    m = vit.vit_small(patch_size=8)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_vit_state_dict(shapes, seed=21).items()})
+    m = m.to(dev).eval()
+    x = torch.randn(frames, 3, 480, 856, device=dev)
+    T = 60 * 107 + 1
+    gf = (12 * (2 * T * (384 * 1152 + 384 * 384 + 2 * 384 * 1536) + 4 * T * T * 384) + 2 * 6420 * 384 * 192) / 1e9
+
+    def timeit(fn, n=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    t_fwd = timeit(lambda: m(x)) / frames
+    feats = m.get_last_qkv(x[:1], "k")
+    mask = (torch.rand(60, 107, device=dev) > 0.5).float() * 0.8 + 0.1
+    t_nc = timeit(lambda: ncut.ncut_refine(feats, mask, steps=10, learning_rate=0.45))
+    return {"workload": "DINO ViT-S/8 forward at 480x856 (6421 tokens, 12 blocks, fp32 on split-bf16 MFMA) + soft NCut "
+                        "(6420^2 affinity, 10 Adam steps)", "vit_ms_per_frame": round(t_fwd * 1e3, 2),
+            "vit_gflop_per_frame": round(gf, 1), "vit_tflops": round(gf / 1e3 / t_fwd, 1),
+            "ncut_refine_ms_per_frame": round(t_nc * 1e3, 2)}
 
 
 def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):

@@ -267,6 +267,10 @@ int rcf_fill_f32(float *p, long n, float v, void *stream);
  * Runs on the split-bf16 conv kernel (fp32 accuracy).  K, lda, ldb, ldc multiples of 4. */
 int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
                     int K, int act, float slope, int beta, void *stream);
+/* batch0 x batch1 independent products in one launch (attention: images x heads); strides in elements */
+int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const float *B, int ldb, long b_s0, long b_s1,
+                            float *C, int ldc, long c_s0, long c_s1, int batch0, int batch1, int M, int N, int K, int act,
+                            float slope, int beta, void *stream);
 int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C, const float *gamma,
                       const float *beta, float eps, void *stream);
 /* in place: row <- softmax(scale * row[0:n]); columns [n, pitch) are zeroed */

@@ -52,6 +52,9 @@ struct IgemmParams {
     int ry0, rx0, rh, rw;
     int rband;                    // > 0: only the frame of this thickness along the rectangle's border
     int rr;                       // rows per image: rh*rw, or the frame's pixel count
+    // batched GEMM (rcf_gemm_nt_batched_f32): blockIdx.y = i0 * batch1 + i1 selects the operands of one product
+    int batch1;
+    long a_bs0, a_bs1, b_bs0, b_bs1, y_bs0, y_bs1;     // element strides of A / B / Y over the two batch indices
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -422,6 +425,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const int tile_m = grp * 8 + (rem & 7);
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (p.batch1 > 0) {                                       // one product of a batch per grid row
+        const int i0 = blockIdx.y / p.batch1, i1 = blockIdx.y - i0 * p.batch1;
+        p.A += i0 * p.a_bs0 + i1 * p.a_bs1;
+        p.Bw += i0 * p.b_bs0 + i1 * p.b_bs1;
+        p.Y += i0 * p.y_bs0 + i1 * p.y_bs1;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1165,16 +1174,16 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
 int g_x3_tile = -1;        // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 256x128
 
 template <int MR, int NR, int WM, int WN>
-void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st) {
+void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
-    const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
+    const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
     if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true>), grid, dim3(64 * WM * WN), 0, st, p);
     else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
-int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
+int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
@@ -1186,11 +1195,12 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st) {
     const bool strided = p.div > 1;
     int tile = g_x3_tile;
     if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
-    if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st);
-    else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st);
-    else if (tile == 2) launch_x3_cfg<2, 4, 4, 2>(p, strided, st);
-    else if (tile == 3) launch_x3_cfg<4, 2, 2, 2>(p, strided, st);
-    else launch_x3_cfg<2, 2, 2, 2>(p, strided, st);
+    if (p.Ncol <= 64 && (long)rcf_cdiv(p.M, 128) * batches < 512) launch_x3_cfg<1, 1, 2, 2>(p, strided, st, batches);   // few rows: 64x64 tiles fill more CUs
+    else if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st, batches);
+    else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st, batches);
+    else if (tile == 2) launch_x3_cfg<2, 4, 4, 2>(p, strided, st, batches);
+    else if (tile == 3) launch_x3_cfg<4, 2, 2, 2>(p, strided, st, batches);
+    else launch_x3_cfg<2, 2, 2, 2>(p, strided, st, batches);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1308,6 +1318,28 @@ extern "C" int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb,
     p.ldb = ldb; p.act = act; p.slope = slope; p.beta = beta;
     p.ry0 = 0; p.rx0 = 0; p.rh = M; p.rw = 1; p.rband = 0; p.rr = M;
     return launch_igemm_x3(p, rcf_stream(stream));
+}
+
+/* batch0 x batch1 independent products in one launch (attention: images x heads): operand / result of product (i0, i1)
+ * start at A + i0*a_s0 + i1*a_s1 etc. (element strides) */
+extern "C" int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const float *B, int ldb, long b_s0,
+                                       long b_s1, float *C, int ldc, long c_s0, long c_s1, int batch0, int batch1, int M,
+                                       int N, int K, int act, float slope, int beta, void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || ldc % 4) return RCF_EINVAL;
+    if (lda < K || ldb < K || ldc < N || !rcf_aligned16(A) || !rcf_aligned16(B) || !rcf_aligned16(C)) return RCF_EINVAL;
+    if (batch0 <= 0 || batch1 <= 0 || (long)batch0 * batch1 > 65535) return RCF_EINVAL;
+    if ((a_s0 | a_s1 | b_s0 | b_s1 | c_s0 | c_s1) % 4) return RCF_EINVAL;
+    if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29) || !use_x3(1)) return RCF_EINVAL;
+    IgemmParams p{};
+    p.A = A; p.Bw = B; p.bias = nullptr; p.Y = C;
+    p.M = M; p.Ncol = N; p.K = K;
+    p.Ho = M; p.Wo = 1; p.Hs = M; p.Ws = 1; p.Cs = K; p.S = 1;
+    p.up = 1; p.off = 0; p.step = 1; p.div = 1;
+    p.a_pitch = lda; p.a_img_stride = (long)M * lda; p.y_pitch = ldc;
+    p.ldb = ldb; p.act = act; p.slope = slope; p.beta = beta;
+    p.ry0 = 0; p.rx0 = 0; p.rh = M; p.rw = 1; p.rband = 0; p.rr = M;
+    p.batch1 = batch1; p.a_bs0 = a_s0; p.a_bs1 = a_s1; p.b_bs0 = b_s0; p.b_bs1 = b_s1; p.y_bs0 = c_s0; p.y_bs1 = c_s1;
+    return launch_igemm_x3(p, rcf_stream(stream), batch0 * batch1);
 }
 
 extern "C" int rcf_conv_regions_available(void) { return use_x3(1) && use_x3(2) && use_x3(4) ? 1 : 0; }

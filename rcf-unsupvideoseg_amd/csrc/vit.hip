@@ -56,11 +56,52 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict_
 }
 
 // in place: row r <- softmax(scale * row r) over the first n columns; columns [n, pitch) are zeroed (K padding of the
-// following P.V product).  One workgroup per row.
+// following P.V product).  One workgroup per row.  Rows of up to 256*4*QMAX floats with a 16-byte aligned pitch are
+// read ONCE into registers (float4 per lane) and written once; longer / unaligned rows take the three-pass path.
+constexpr int SM_QMAX = 8;                         // 8192 columns
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float *__restrict__ s, long pitch, int n, float scale) {
     __shared__ float red[4];
     float *row = s + (long)blockIdx.x * pitch;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool fast = (pitch % 4 == 0) && pitch <= 256L * 4 * SM_QMAX;
+    if (fast) {
+        const int nq = (int)(pitch / 4);
+        f32x4 q[SM_QMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < SM_QMAX; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < nq) {
+                q[k] = *reinterpret_cast<const f32x4 *>(row + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q[k][e] = (i * 4 + e < n) ? q[k][e] * scale : -INFINITY;
+                    mx = fmaxf(mx, q[k][e]);
+                }
+            }
+        }
+        mx = wave_max_f(mx);
+        if (lane == 0) red[wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SM_QMAX; ++k)
+            if (threadIdx.x + 256 * k < nq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { q[k][e] = expf(q[k][e] - mx); sum += q[k][e]; }   // exp(-inf) = 0 on the padding
+        sum = wave_sum_f(sum);
+        if (lane == 0) red[wv] = sum;
+        __syncthreads();
+        const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll
+        for (int k = 0; k < SM_QMAX; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < nq) *reinterpret_cast<f32x4 *>(row + i * 4) = q[k] * inv;
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i] * scale);
     mx = wave_max_f(mx);

@@ -435,6 +435,15 @@ def gemm_nt(a, b, bias=None, out=None, act=0, beta=0):
     return out
 
 
+def gemm_nt_batched(a, lda, a_strides, b, ldb, b_strides, out, ldc, c_strides, batch, M, N, K, beta=0):
+    """batch[0] x batch[1] products out_i = a_i[M,K] @ b_i[N,K]^T in one launch; a / b / out are base tensors (their data
+    pointers may carry an offset), strides in elements"""
+    call("rcf_gemm_nt_batched_f32", _p(a), int(lda), int(a_strides[0]), int(a_strides[1]), _p(b), int(ldb),
+         int(b_strides[0]), int(b_strides[1]), _p(out), int(ldc), int(c_strides[0]), int(c_strides[1]), int(batch[0]),
+         int(batch[1]), int(M), int(N), int(K), 0, 0.0, int(beta), _stream())
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     _need_cuda(x)
     rows, C = x.shape

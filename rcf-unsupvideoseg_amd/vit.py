@@ -79,6 +79,7 @@ class VisionTransformer(nn.Module):
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         nn.init.trunc_normal_(self.cls_token, std=.02)
         self._pos_cache = {}
+        self.attn_bytes = 6 << 30       # budget for the materialised attention scores of one launch
 
     # ---------------------------------------------------------------- parameter preprocessing (torch, cached)
     def interpolate_pos_encoding(self, npatch, w, h):
@@ -129,17 +130,21 @@ class VisionTransformer(nn.Module):
             self._last_qkv = qkv
         Tp = (T + 3) // 4 * 4
         out = torch.empty((B * T, dim), dtype=torch.float32, device=h1.device)
-        S = torch.empty((T, Tp), dtype=torch.float32, device=h1.device)
         attn = torch.empty((B, nh, T, T), dtype=torch.float32, device=h1.device) if want_attn else None
-        for b in range(B):
-            rows = qkv[b * T:(b + 1) * T]
-            for hh in range(nh):
-                q, k, v = (rows[:, i * dim + hh * hd:i * dim + (hh + 1) * hd] for i in range(3))
-                ops.gemm_nt(q, k, out=S[:, :T])                                                     # q k^T
-                ops.softmax_rows_(S, T, a.scale)                                                    # softmax(scale * .)
-                if want_attn:
-                    attn[b, hh].copy_(S[:, :T])
-                ops.gemm_nt(S, ops.transpose2d(v, Tp), out=out[b * T:(b + 1) * T, hh * hd:(hh + 1) * hd])   # attn v
+        # all heads of a chunk of images per launch (grid.y = image x head); the chunk bounds the [T, T] score buffers
+        chunk = max(1, min(B, int(self.attn_bytes // (nh * T * Tp * 4))))
+        S = torch.empty((chunk, nh, T, Tp), dtype=torch.float32, device=h1.device)
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            rows = qkv[b0 * T:(b0 + nb) * T]                                                        # [nb*T, 3 dim]
+            ops.gemm_nt_batched(rows, 3 * dim, (T * 3 * dim, hd), rows[:, dim:], 3 * dim, (T * 3 * dim, hd),
+                                S, Tp, (nh * T * Tp, T * Tp), (nb, nh), T, T, hd)                   # q k^T
+            ops.softmax_rows_(S.view(-1, Tp)[:nb * nh * T], T, a.scale)                             # softmax(scale * .)
+            if want_attn:
+                attn[b0:b0 + nb].copy_(S[:nb, :, :, :T])
+            Vt = torch.stack([ops.transpose2d(rows[i * T:(i + 1) * T, 2 * dim:], Tp) for i in range(nb)])   # [nb, dim, Tp]
+            ops.gemm_nt_batched(S, Tp, (nh * T * Tp, T * Tp), Vt, Tp, (dim * Tp, hd * Tp), out[b0 * T:], dim,
+                                (T * dim, hd), (nb, nh), T, hd, Tp)                                 # attn v
         return out, attn
 
     def _block(self, blk, X, B, T, last=False, want_attn=False):
