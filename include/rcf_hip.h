@@ -271,6 +271,10 @@ int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const floa
 int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const float *B, int ldb, long b_s0, long b_s1,
                             float *C, int ldc, long c_s0, long c_s1, int batch0, int batch1, int M, int N, int K, int act,
                             float slope, int beta, void *stream);
+/* fused multi-head attention forward (scores stay on chip): out[b*T+t][h*64+d] = softmax_j(scale q_t.k_j) v_j[d];
+ * qkv [B*T][3*nh*64] (q | k | v) as produced by the fused qkv linear (models/dino_vit.py:122-133).  head_dim = 64. */
+int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh, int head_dim,
+                          float scale, void *stream);
 int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C, const float *gamma,
                       const float *beta, float eps, void *stream);
 /* in place: row <- softmax(scale * row[0:n]); columns [n, pitch) are zeroed */

@@ -52,6 +52,7 @@ PROTOS = {
     "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "rcf_gemm_nt_batched_f32": (c_int, [P, c_int, c_long, c_long, P, c_int, c_long, c_long, P, c_int, c_long, c_long, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "rcf_attention_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "rcf_layernorm_f32": (c_int, [P, c_int, P, c_int, c_long, c_int, P, P, c_float, P]),
     "rcf_softmax_rows_f32": (c_int, [P, c_long, c_long, c_int, c_float, P]),
     "rcf_transpose2d_f32": (c_int, [P, c_long, P, c_long, c_int, c_int, P]),

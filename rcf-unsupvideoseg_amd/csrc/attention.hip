@@ -1,0 +1,252 @@
+// Fused multi-head attention forward for the DINO ViT (models/dino_vit.py:122-133): O = softmax(scale * Q K^T) V per
+// (image, head), fp32 accuracy on the bf16 matrix cores (every operand split exactly into three bf16 parts, six partial
+// products -- see igemm_conv.hip), the [T, T] scores never leave the chip.
+//
+// Workgroup = 4 wavefronts, each owning 32 queries; the key / value sequence is walked in tiles of 64 keys staged
+// (already split) in LDS for the whole workgroup.
+//   S^T = K Q^T   : v_mfma_f32_32x32x16_bf16 with A = K tile rows (keys), B = the wave's Q (queries as columns), so
+//                   in the accumulator layout every lane owns ONE query (column lane&31) and 16 of the 32 keys
+//                   (rows (e&3) + 8(e>>2) + 4(lane>>5)) -- the online softmax (running max / sum per query) is a
+//                   per-lane loop plus one exchange with lane^32.
+//   O += P V      : P = exp(S - m) is re-split in registers and is, as it stands, the A operand of the second product
+//                   (row = query = lane&31; the 8 values of accumulator registers 8j..8j+7 are the 8 k-elements of the
+//                   lane's half).  The contraction order over keys is therefore the accumulator's row order; V is staged
+//                   transposed ([dim][key]) so that the B operand supplies the same keys in the same order.
+// The running rescale exp(m_old - m_new) and the final 1/l are per query, but O's accumulator rows are queries spread
+// over registers, so they travel through a 32-float LDS row per wavefront.
+#include "rcf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 &l) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+    const f32x2 sa = ra - __builtin_convertvector(ma, f32x2), sb = rb - __builtin_convertvector(mb, f32x2);
+    const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
+    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    l = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+// eight floats -> three bf16x8 operand fragments
+__device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split3(f32x4{v[0], v[1], v[2], v[3]}, h0, m0, l0);
+    split3(f32x4{v[4], v[5], v[6], v[7]}, h1, m1, l1);
+    h = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    m = __builtin_bit_cast(bf16x8, u32x4{m0[0], m0[1], m1[0], m1[1]});
+    l = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+}
+// acc += A B with the six significant partial products (smallest first)
+__device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+constexpr int HD = 64;            // head dimension
+constexpr int BQ = 128;           // queries per workgroup (32 per wavefront)
+constexpr int BKEY = 64;          // keys per tile
+constexpr int KPLANE = 4 * BKEY * 32;          // K: [group 4][key 64][16 dims] bf16 = 32 B rows (halves swizzled)
+constexpr int VPITCH = BKEY * 2 + 8;           // V^T: [dim 64][64 keys] bf16, rows padded to 136 B (conflict-free b64)
+constexpr int VPLANE = HD * VPITCH;
+
+struct AttnParams {
+    const float *qkv;   // [B*T][3*dim] (q | k | v, heads side by side)
+    float *out;         // [B*T][dim]
+    int T, nh, ld, ldo; // tokens per image, heads, row pitches of qkv / out
+    float scale;
+};
+
+__global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char kS[3 * KPLANE];
+    __shared__ __attribute__((aligned(16))) char vS[3 * VPLANE];
+    __shared__ float rowv[4][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hs = lane >> 5;
+    const int b = blockIdx.y / p.nh, head = blockIdx.y - b * p.nh;
+    const int dim = p.nh * HD;
+    const float *base = p.qkv + (long)b * p.T * p.ld + head * HD;
+    const int q0 = blockIdx.x * BQ + wave * 32;                 // first query of this wavefront
+
+    // ---- Q as the B operand of S^T = K Q^T: lane (query l31, half hs) holds dims 16g + 8hs .. +7 of its query
+    bf16x8 qf[4][3];
+    {
+        const int q = q0 + l31;
+        const bool ok = q < p.T;
+        const float *qr = base + (long)(ok ? q : 0) * p.ld;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[8];
+            const f32x4 a = ok ? *reinterpret_cast<const f32x4 *>(qr + 16 * g + 8 * hs) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 c = ok ? *reinterpret_cast<const f32x4 *>(qr + 16 * g + 8 * hs + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = c[e]; }
+            split3x8(v, qf[g][0], qf[g][1], qf[g][2]);
+        }
+    }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                       // per query (same value on lanes l and l^32)
+
+    // loader roles.  K: thread (key kr, dim quad kq) per 16-dim group pass.  V: thread (dim quad vq, key group vg):
+    // 4 keys x 4 dims, transposed in registers.
+    const int kq = tid & 3, kr = tid >> 2;                      // kr 0..63
+    const int k_st = kr * 32 + ((((kq >> 1) ^ ((kr >> 3) & 1))) << 4) + (kq & 1) * 8;
+    const int vg = tid & 15, vq = tid >> 4;                     // vg: keys 4vg..4vg+3, vq: dims 4vq..4vq+3
+    const float *kbase = base + dim, *vbase = base + 2 * dim;
+
+    const int ntiles = (p.T + BKEY - 1) / BKEY;
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * BKEY;
+        // ---- stage the K and V tiles (split into bf16 planes)
+        __syncthreads();                                        // the previous tile's readers are done
+        {
+            const int key = key0 + kr;
+            const bool ok = key < p.T;
+            const float *kp = kbase + (long)(ok ? key : 0) * p.ld + kq * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(kp + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                u32x2 h, m, l;
+                split3(v, h, m, l);
+                char *d = kS + g * (BKEY * 32) + k_st;
+                *reinterpret_cast<u32x2 *>(d) = h;
+                *reinterpret_cast<u32x2 *>(d + KPLANE) = m;
+                *reinterpret_cast<u32x2 *>(d + 2 * KPLANE) = l;
+            }
+            f32x4 vv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = key0 + 4 * vg + i;
+                vv[i] = kk < p.T ? *reinterpret_cast<const f32x4 *>(vbase + (long)kk * p.ld + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                       // dim 4vq+e: its 4 keys, k-contiguous
+                u32x2 h, m, l;
+                split3(f32x4{vv[0][e], vv[1][e], vv[2][e], vv[3][e]}, h, m, l);
+                char *d = vS + (4 * vq + e) * VPITCH + vg * 8;
+                *reinterpret_cast<u32x2 *>(d) = h;
+                *reinterpret_cast<u32x2 *>(d + VPLANE) = m;
+                *reinterpret_cast<u32x2 *>(d + 2 * VPLANE) = l;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T tiles: [32 keys x 32 queries] x 2
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+            const int swz = (hs ^ ((l31 >> 3) & 1)) << 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    kf[q] = *reinterpret_cast<const bf16x8 *>(kS + q * KPLANE + g * (BKEY * 32) + (kt * 32 + l31) * 32 + swz);
+                mma6(kf, qf[g], sacc[kt]);
+            }
+        }
+        // ---- online softmax for this lane's query: 32 of the tile's 64 keys live here, 32 on lane^32
+        float pv[2][16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hs;
+                const float s = key < p.T ? sacc[kt][e] * p.scale : -INFINITY;
+                pv[kt][e] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                   // finite: every tile holds at least one real key
+        const float alpha = expf(m_run - m_new);                // 0 on the first tile (m_run = -inf)
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { pv[kt][e] = expf(pv[kt][e] - m_new); rs += pv[kt][e]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // ---- rescale O: alpha per query -> O's rows
+        if (hs == 0) rowv[wave][l31] = alpha;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float a = rowv[wave][(e & 3) + 8 * (e >> 2) + 4 * hs];
+            oacc[0][e] *= a;
+            oacc[1][e] *= a;
+        }
+        // ---- O += P V
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = pv[kt][8 * j + i];
+                bf16x8 pf[3];
+                split3x8(v8, pf[0], pf[1], pf[2]);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    bf16x8 vf[3];
+                    const char *vr = vS + (d * 32 + l31) * VPITCH + (kt * 32 + 16 * j + 4 * hs) * 2;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const u32x2 lo = *reinterpret_cast<const u32x2 *>(vr + q * VPLANE);          // keys +0..3
+                        const u32x2 hi = *reinterpret_cast<const u32x2 *>(vr + q * VPLANE + 16);     // keys +8..11
+                        vf[q] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                    }
+                    mma6(pf, vf, oacc[d]);
+                }
+            }
+    }
+    // ---- O / l, store: lane holds dims d*32 + l31 of queries (e&3) + 8(e>>2) + 4hs
+    __builtin_amdgcn_wave_barrier();
+    if (hs == 0) rowv[wave][l31] = 1.0f / l_run;
+    __builtin_amdgcn_wave_barrier();
+    float *ob = p.out + (long)b * p.T * p.ldo + head * HD;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hs;
+        const int q = q0 + r;
+        if (q >= p.T) continue;
+        const float inv = rowv[wave][r];
+        ob[(long)q * p.ldo + l31] = oacc[0][e] * inv;
+        ob[(long)q * p.ldo + 32 + l31] = oacc[1][e] * inv;
+    }
+}
+
+}  // namespace
+
+/* out[b*T + t][h*64 + d] = sum_j softmax_j(scale * q_t . k_j) v_j[d] for every image b and head h; qkv is the output of
+ * the fused qkv linear ([B*T][3*nh*64], q | k | v).  Head dimension 64 (every DINO ViT). */
+extern "C" int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh,
+                                     int head_dim, float scale, void *stream) {
+    if (!qkv || !out || B <= 0 || T <= 0 || nh <= 0 || head_dim != HD) return RCF_EINVAL;
+    if (ld_qkv % 4 || ld_out % 4 || ld_qkv < 3 * nh * HD || ld_out < nh * HD || !rcf_aligned16(qkv) || !rcf_aligned16(out)) return RCF_EINVAL;
+    if ((long)B * nh > 65535) return RCF_EINVAL;
+    AttnParams p{qkv, out, T, nh, ld_qkv, ld_out, scale};
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(rcf_cdiv(T, BQ), B * nh), dim3(256), 0, rcf_stream(stream), p);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}

@@ -444,6 +444,17 @@ def gemm_nt_batched(a, lda, a_strides, b, ldb, b_strides, out, ldc, c_strides, b
     return out
 
 
+def attention(qkv, B, T, nh, scale, out=None):
+    """fused softmax(scale q k^T) v for every image and head; qkv [B*T, 3*nh*64] -> [B*T, nh*64]"""
+    _need_cuda(qkv)
+    dim = qkv.shape[1] // 3
+    if out is None:
+        out = torch.empty((B * T, dim), dtype=torch.float32, device=qkv.device)
+    call("rcf_attention_fwd_f32", _p(qkv), _row_pitch(qkv), _p(out), _row_pitch(out), B, T, nh, dim // nh, float(scale),
+         _stream())
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     _need_cuda(x)
     rows, C = x.shape

@@ -80,6 +80,7 @@ class VisionTransformer(nn.Module):
         nn.init.trunc_normal_(self.cls_token, std=.02)
         self._pos_cache = {}
         self.attn_bytes = 6 << 30       # budget for the materialised attention scores of one launch
+        self.fused_attention = True     # False: q k^T / softmax / P v as separate launches (also used when maps are asked for)
 
     # ---------------------------------------------------------------- parameter preprocessing (torch, cached)
     def interpolate_pos_encoding(self, npatch, w, h):
@@ -128,6 +129,8 @@ class VisionTransformer(nn.Module):
         qkv = ops.gemm_nt(h1, a.qkv.weight, a.qkv.bias)                                             # [B*T, 3 dim]
         if keep_qkv:
             self._last_qkv = qkv
+        if not want_attn and hd == 64 and self.fused_attention:
+            return ops.attention(qkv, B, T, nh, a.scale), None           # scores never leave the chip (csrc/attention.hip)
         Tp = (T + 3) // 4 * 4
         out = torch.empty((B * T, dim), dtype=torch.float32, device=h1.device)
         attn = torch.empty((B, nh, T, T), dtype=torch.float32, device=h1.device) if want_attn else None

@@ -51,6 +51,21 @@ def test_gemm_layernorm_softmax_helpers(report):
     assert max(e_g, e_gelu, e_ln, e_sm) < 2e-5 and pad0 == 0.0 and ok_t
 
 
+@pytest.mark.parametrize("T", [97, 130, 257])
+def test_fused_attention_vs_float64(T, report):
+    """csrc/attention.hip against float64 softmax(q k^T / 8) v on random qkv (tails: T not a multiple of the 64-key /
+    128-query tiles)"""
+    g = torch.Generator().manual_seed(T)
+    B, nh, dim = 2, 6, 384
+    qkv = (torch.randn(B * T, 3 * dim, generator=g) * 1.5).to(DEV)
+    out = ops.attention(qkv, B, T, nh, 0.125).cpu().double()
+    q, k, v = (qkv.cpu().double().view(B, T, 3, nh, 64).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-2, -1) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(B * T, dim)
+    e = float((out - ref).abs().max() / ref.abs().max())
+    report(f"fused attention T={T}: {e:.2e}")
+    assert e < 2e-5
+
+
 def test_vit_small8_vs_reference_golden(golden_dir, report):
     fx = np.load(os.path.join(golden_dir, "vit_small8.npz"))
     m = _model(fx)
