@@ -112,34 +112,40 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
     const float *kbase = base + dim, *vbase = base + 2 * dim;
 
     const int ntiles = (p.T + BKEY - 1) / BKEY;
+    // the next tile's K / V rows travel in registers while the current tile is multiplied
+    f32x4 kreg[4], vreg[4];
+    auto load_tile = [&](int t) {
+        const int key0 = t * BKEY;
+        const int key = key0 + kr;
+        const bool ok = key < p.T;
+        const float *kp = kbase + (long)(ok ? key : 0) * p.ld + kq * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kreg[g] = ok ? *reinterpret_cast<const f32x4 *>(kp + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = key0 + 4 * vg + i;
+            vreg[i] = kk < p.T ? *reinterpret_cast<const f32x4 *>(vbase + (long)kk * p.ld + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * BKEY;
         // ---- stage the K and V tiles (split into bf16 planes)
         __syncthreads();                                        // the previous tile's readers are done
         {
-            const int key = key0 + kr;
-            const bool ok = key < p.T;
-            const float *kp = kbase + (long)(ok ? key : 0) * p.ld + kq * 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(kp + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
                 u32x2 h, m, l;
-                split3(v, h, m, l);
+                split3(kreg[g], h, m, l);
                 char *d = kS + g * (BKEY * 32) + k_st;
                 *reinterpret_cast<u32x2 *>(d) = h;
                 *reinterpret_cast<u32x2 *>(d + KPLANE) = m;
                 *reinterpret_cast<u32x2 *>(d + 2 * KPLANE) = l;
             }
-            f32x4 vv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kk = key0 + 4 * vg + i;
-                vv[i] = kk < p.T ? *reinterpret_cast<const f32x4 *>(vbase + (long)kk * p.ld + 4 * vq) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                       // dim 4vq+e: its 4 keys, k-contiguous
                 u32x2 h, m, l;
-                split3(f32x4{vv[0][e], vv[1][e], vv[2][e], vv[3][e]}, h, m, l);
+                split3(f32x4{vreg[0][e], vreg[1][e], vreg[2][e], vreg[3][e]}, h, m, l);
                 char *d = vS + (4 * vq + e) * VPITCH + vg * 8;
                 *reinterpret_cast<u32x2 *>(d) = h;
                 *reinterpret_cast<u32x2 *>(d + VPLANE) = m;
@@ -147,6 +153,7 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
             }
         }
         __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
 
         // ---- S^T tiles: [32 keys x 32 queries] x 2
         f32x16 sacc[2];
