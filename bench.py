@@ -52,11 +52,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  RCF_BENCH_BACKEND=gloo lets several ranks share one device (a functional check of the N > 1
+    # path on a single-GPU box: RCCL refuses two ranks per GPU); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("RCF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import rcf_amd
     from rcf_amd import config, ops, synth

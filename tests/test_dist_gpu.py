@@ -81,3 +81,22 @@ def test_two_rank_step_equals_global_batch_step(report):
     e_rv = float(np.abs(res[0][3] - m.backbone2.bn1.running_var.cpu().numpy()).max())
     report(f"2-rank DP vs single process: loss {e_loss:.2e} worst sampled grad {worst:.2e} running_var {e_rv:.2e}")
     assert e_loss < 1e-5 and worst < 2e-2 and e_rv < 1e-6
+
+
+def test_bench_two_ranks_end_to_end(report):
+    """bench.py launched exactly like the driver does for N > 1 (torch.distributed.run, one JSON line from rank 0), with
+    gloo carrying the collectives so that both ranks can share this box's single GPU"""
+    import json
+    import subprocess
+    env = dict(os.environ, RCF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29800 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pairs", "1", "--height", "64", "--width", "96", "--no-stage2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    report(f"bench.py --gpus 2 (gloo, shared GPU): {d['value']} frames/s, {d['ms_per_step']} ms/step")
+    assert d["n_gpus"] == 2 and d["config"]["global_pairs"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "roofline" in d and "cpu_baseline" not in d
