@@ -140,6 +140,8 @@ def main():
         # CRF ms/frame (second half of BASELINE's metric) -- 480x854, T iterations, batch of 8 frames
         try:
             out["crf_ms_per_frame"] = crf_bench(torch, rcf_amd, synth, dev, H, W, a.crf_iters)
+            if world == 1:                                      # the reference's default iteration count (crf_head.py:16)
+                out["crf_ms_per_frame_T50"] = crf_bench(torch, rcf_amd, synth, dev, H, W, 50)
         except Exception as e:                                  # noqa: BLE001 -- reported, not hidden
             out["crf_ms_per_frame"] = None
             out["crf_error"] = str(e)[:200]
