@@ -108,7 +108,7 @@ def mask_size_for(H, W):
     return ((h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1)
 
 
-VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj")
+VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj", "mask_resize")
 
 
 def variant_model_kwargs(name, H, W, norm="BN"):
@@ -140,6 +140,12 @@ def variant_model_kwargs(name, H, W, norm="BN"):
         kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)
         kw.update(compactness_head=dict(type="CompactnessHead", compact_channel=-1), w_compactness=0.5)
         oc = 2
+    elif name == "mask_resize":
+        # allow_mask_resize (models/rcf_model.py:421-422): the flow head works at a mask size the decode head does not
+        # produce (here 3/4 of it), the logits are bilinearly resized first
+        small = (ms[0] * 3 // 4, ms[1] * 3 // 4)
+        kw = stage1_model_kwargs(small, dropout=0.0, norm=norm)
+        kw["allow_mask_resize"] = True
     else:
         raise KeyError(name)
     kw.update(log_interval=10 ** 9, train_iter=1)

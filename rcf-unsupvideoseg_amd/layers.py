@@ -225,6 +225,20 @@ def resize_into(x, tape, size, align_corners, out):
     ops.resize_nhwc_fwd(x.t, size, align_corners, out=out)
 
 
+def resize_act(x, tape, size, align_corners=False):
+    """bilinear resize of an activation with its backward (mmseg.ops.resize on a tensor that needs a gradient,
+    models/rcf_model.py:421-422)"""
+    y = Act(ops.resize_nhwc_fwd(x.t, tuple(size), align_corners))
+
+    def bwd():
+        g = y.take_grad()
+        if x.needs_grad:
+            gx, beta = x.grad_slot()
+            ops.resize_nhwc_bwd(g, x.t.shape[1:3], align_corners, out=gx, beta=beta)
+    tape.push(bwd)
+    return y
+
+
 def concat_channels(parts, tape, size=None, align_corners=False, widths=None):
     """resize_concat of models/decode_head.py:151-164: every part is bilinearly resized to `size`
     (default: the first part's) and written into its channel slice of one NHWC buffer.

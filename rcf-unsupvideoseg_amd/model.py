@@ -19,7 +19,7 @@ from .export import save_image
 from .backbone import FCNHead, ResNet
 from .crf import CRFHead
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual
-from .layers import Act, DistCtx, Tape, concat_channels, pair_concat
+from .layers import Act, DistCtx, Tape, concat_channels, pair_concat, resize_act
 
 REGISTRY = dict(ResNet=ResNet, FCNHead=FCNHead, FlowAggregationHeadWithResidual=FlowAggregationHeadWithResidual,
                 CompactnessHead=CompactnessHead, CRFHead=CRFHead)
@@ -178,7 +178,7 @@ class RCFModel(nn.Module):
         tape.mark("heads")                                                       # fires once all three heads are done
         logits = self.decode_head2.fwd(feats, tape, dist)                       # Act [B*I,h,w,C]
         if self.allow_mask_resize and tuple(logits.t.shape[1:3]) != self.mask_size:
-            raise NotImplementedError("allow_mask_resize with a mismatching mask_size")
+            logits = resize_act(logits, tape, self.mask_size, self.align_corners)          # rcf_model.py:421-422
         if self.separate_residual:
             res = self.decode_head3.fwd([pair_concat(feats[-1], tape, B, I)], tape, dist)   # [B,h2,w2,4C]
         else:
