@@ -108,7 +108,7 @@ def mask_size_for(H, W):
     return ((h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1)
 
 
-VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj", "mask_resize")
+VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj", "mask_resize", "freeze")
 
 
 def variant_model_kwargs(name, H, W, norm="BN"):
@@ -146,6 +146,9 @@ def variant_model_kwargs(name, H, W, norm="BN"):
         small = (ms[0] * 3 // 4, ms[1] * 3 // 4)
         kw = stage1_model_kwargs(small, dropout=0.0, norm=norm)
         kw["allow_mask_resize"] = True
+    elif name == "freeze":
+        kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)                 # freeze_backbone (models/rcf_model.py:107-110)
+        kw["freeze_backbone"] = True
     else:
         raise KeyError(name)
     kw.update(log_interval=10 ** 9, train_iter=1)
