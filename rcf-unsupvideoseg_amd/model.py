@@ -174,7 +174,12 @@ class RCFModel(nn.Module):
         dist = self._dist()
         tape = Tape(on_mark=self.grad_ready_hook)
         img = self._images_nhwc(imgs)
-        feats = self.backbone2.fwd(img, tape, dist)
+        if any(q.requires_grad for q in self.backbone2.parameters()):
+            feats = self.backbone2.fwd(img, tape, dist)
+        else:                                            # freeze_backbone: nothing behind the features needs a gradient
+            feats = self.backbone2.fwd(img, Tape(enabled=False), dist)
+            for f in feats:
+                f.needs_grad = False
         tape.mark("heads")                                                       # fires once all three heads are done
         logits = self.decode_head2.fwd(feats, tape, dist)                       # Act [B*I,h,w,C]
         if self.allow_mask_resize and tuple(logits.t.shape[1:3]) != self.mask_size:
