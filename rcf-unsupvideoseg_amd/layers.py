@@ -33,6 +33,26 @@ class Act:
         return g
 
 
+# Weight gradients on a second HIP stream: wgrad and dgrad of a conv both read dy and are independent, so the one's
+# last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
+# (tape marks = all-reduce chunks, end of backward).
+OVERLAP_WGRAD = True
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_stream(device=None):
+    for idx, s in _side_streams.items():
+        if device is None or device.index == idx:
+            torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 class Tape:
     def __init__(self, enabled=True, on_mark=None):
         self.ops, self.enabled, self.on_mark = [], enabled, on_mark
@@ -46,11 +66,16 @@ class Tape:
         gradient of the group is final (the trainer starts that chunk's gradient all-reduce there)."""
         if self.enabled and self.on_mark is not None:
             cb = self.on_mark
-            self.ops.append(lambda: cb(name))
+
+            def fire():
+                join_side_stream()                       # the group's weight gradients are complete
+                cb(name)
+            self.ops.append(fire)
 
     def backward(self):
         while self.ops:
             self.ops.pop()()
+        join_side_stream()
 
 
 class DistCtx:
@@ -127,8 +152,17 @@ class Conv2d(nn.Module):
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
                 if self.weight.requires_grad:
                     if self.cin_pad == self.cin and self.cout_pad == self.cout:
-                        ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                         self.dilation, beta=1)
+                        if OVERLAP_WGRAD and x.needs_grad:
+                            side = _side_stream(dy.device)
+                            side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready
+                            with torch.cuda.stream(side):
+                                ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
+                                                 self.dilation, beta=1)
+                            dy.record_stream(side)
+                            x.t.record_stream(side)
+                        else:
+                            ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
+                                             self.dilation, beta=1)
                     else:
                         dwp = torch.empty_like(w)
                         ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0)
