@@ -130,7 +130,7 @@ def main():
             traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         # The convs run as fp32 contractions on the bf16 matrix cores (each operand split exactly into 3 bf16
         # parts, 6 partial products, fp32 accumulate): the bound is the dense bf16 MFMA peak / 6 passes.
-        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false> (implicit-GEMM conv, split-bf16, 128x256 tile: forward and data-gradient launches with > 128 output columns)",
+        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false,false> (implicit-GEMM conv, split-bf16, 128x256 tile: the forward launches with > 128 output channels; data gradients are the <...,true> instance and overlap the weight gradients of a second stream)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": X3_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(ach / X3_MFMA_PEAK_TF, 4), "traffic": traffic, "launches": n,
                            "avg_launch_ms": round(ms / max(n, 1), 4),

@@ -411,7 +411,9 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32: tile (32 MR WM) x (32 NR WN).
 // Global loads go through buffer descriptors (32-bit byte offsets; an invalid tap / row / K-tail gets an
 // out-of-range offset and the hardware returns zeros: no select on the data, no 64-bit address math).
-template <int MR, int NR, int WM, int WN, bool STRIDED>
+// DGRAD only names the instantiation (forward and data-gradient launches show up as different kernels in a profile:
+// the data gradients run beside the weight gradients of a second stream, the forward convs run alone)
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false>
 __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
@@ -1179,8 +1181,9 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
-    if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {

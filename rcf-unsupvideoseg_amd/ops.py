@@ -140,7 +140,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
-    if PROFILE.which is not None and s.Cout > 128:       # launches of igemm_conv_x3_kernel<2,4,2,2,false> (128x256 tile)
+    if PROFILE.which is not None and s.Cout > 128:       # forward launches of the 128x256-tile kernel instance
         end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
@@ -158,15 +158,8 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
-    end = None
-    if PROFILE.which is not None and s.Cin > 128 and stride == 1:      # same kernel instance as the wide forward convs
-        # a data gradient restricted to input pixels: FLOPs scale with the pixels written
-        px = _region_pixels(region, s.H, s.W) * (s.Ho * s.Wo) / float(s.H * s.W)
-        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * px * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
          need, _stream())
-    if end is not None:
-        end.record()
     return out
 
 

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stage2 > $R/gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -20,13 +20,13 @@ for k, d in agg.items():
     rows.append(((2 * f + w) * 1024 * n, k, n, f, w))
 rows.sort(reverse=True)
 with open("$R/gpurun_out/pmc_hbm_traffic.txt", "w") as o:
-    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline\n")
+    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stage2\n")
     o.write("# counter unit KiB; gfx950 correction: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md HBM section)\n")
     o.write("kernel | launches | FETCH_SIZE avg KiB | WRITE_SIZE avg KiB | corrected HBM MB per launch\n")
     for tot, k, n, f, w in rows[:40]:
         o.write(f"{k[:120]} | {n} | {f:.1f} | {w:.1f} | {(2*f+w)*1024/1e6:.1f}\n")
 for tot, k, n, f, w in rows:
-    if "igemm_conv_x3_kernel<2, 4, 2, 2, false>" in k:
-        json.dump({"kernel": k, "launches": n, "hbm_bytes_per_launch": (2 * f + w) * 1024, "note": "all launches of this kernel in a step (forward + dgrad, all layers)"}, open("$R/gpurun_out/pmc_traffic.json", "w"))
+    if "igemm_conv_x3_kernel<2, 4, 2, 2, false, false>" in k:
+        json.dump({"kernel": k, "launches": n, "hbm_bytes_per_launch": (2 * f + w) * 1024, "note": "all launches of this kernel instance in a step (forward convs with more than 128 output channels)"}, open("$R/gpurun_out/pmc_traffic.json", "w"))
         print(k[:80], n, (2 * f + w) * 1024 / 1e6, "MB/launch")
 PY
