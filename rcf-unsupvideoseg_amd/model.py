@@ -19,6 +19,7 @@ from .export import save_image
 from .backbone import FCNHead, ResNet
 from .crf import CRFHead
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual
+from . import layers
 from .layers import Act, DistCtx, Tape, concat_channels, pair_concat, resize_act
 
 REGISTRY = dict(ResNet=ResNet, FCNHead=FCNHead, FlowAggregationHeadWithResidual=FlowAggregationHeadWithResidual,
@@ -174,6 +175,14 @@ class RCFModel(nn.Module):
         dist = self._dist()
         tape = Tape(on_mark=self.grad_ready_hook)
         img = self._images_nhwc(imgs)
+        crf_side = None
+        if self.w_crf > 0 and self.crf_use_ema and layers.OVERLAP_WGRAD:
+            # the EMA teacher's forward + CRF need only the images: run them on the second stream beside the student's
+            # forward (its HBM-bound BN passes and the teacher's MFMA-bound convs fill each other's gaps)
+            crf_side = layers._side_stream(img.t.device)
+            crf_side.wait_stream(torch.cuda.current_stream(img.t.device))
+            with torch.cuda.stream(crf_side):
+                crf_early = self._crf_targets(img, imgs, None, B, I)
         if any(q.requires_grad for q in self.backbone2.parameters()):
             feats = self.backbone2.fwd(img, tape, dist)
         else:                                            # freeze_backbone: nothing behind the features needs a gradient
@@ -203,7 +212,11 @@ class RCFModel(nn.Module):
         if self.w_pl > 0:
             extra["pl_masks"] = ops.resize_nchw(pl_masks.contiguous().float(), self.mask_size, self.align_corners)
         if self.w_crf > 0:
-            extra["crf_masks"] = self._crf_targets(img, imgs, logits, B, I)
+            if crf_side is not None:
+                torch.cuda.current_stream(img.t.device).wait_stream(crf_side)
+                extra["crf_masks"] = crf_early
+            else:
+                extra["crf_masks"] = self._crf_targets(img, imgs, logits, B, I)
         losses, seed = self.decode_head.loss_and_grads(
             self, logits, res, gfw.view(B, nf, 2, *self.mask_size), gbw.view(B, nf, 2, *self.mask_size), extra, B, I)
         self._seed_backward = seed
