@@ -55,6 +55,17 @@ typedef struct {
 int rcf_conv_regions_available(void);     /* 1 while the split-bf16 kernels are selected (the default) */
 int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                               const rcf_conv_region *region, int act, float slope, int beta, void *stream);
+/* y = conv(x, w) (no bias, whole tensor) and, from the same kernel's epilogue, the batch-norm statistics of y:
+ * sums[2*Cout] (doubles, [sum | sumsq], the layout of rcf_bn_stats_f32; a lane's <= 64 values of a column are added
+ * in fp32, everything above that in fp64) -- the conv -> (Sync)BatchNorm pairs of
+ * models/resnet.py:268-300 and mmcv ConvModule without the statistics pass re-reading y.  Split-bf16 kernels only
+ * (RCF_EINVAL otherwise: the caller then runs rcf_bn_stats_f32). */
+size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
+                             void *workspace, size_t workspace_bytes, void *stream);
+/* out[i] = sum_k partial[k][i], k < chunks, i < n, in a fixed order; scratch (64 * n doubles, may be NULL) lets a
+ * long list of partial rows be summed in two levels */
+int rcf_sum_partials_f64(const double *partial, int chunks, int n, double *out, double *scratch, void *stream);
 /* dx[N,H,W,Cin] (pitch x_pitch) (+)= conv_transpose(dy[N,Ho,Wo,Cout] (pitch y_pitch), w).
  * `workspace` (rcf_conv2d_dgrad_workspace_bytes) holds the transposed weights [Cin][R][S][Cout] the
  * split-bf16 kernels contract against. */

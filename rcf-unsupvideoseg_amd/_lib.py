@@ -63,6 +63,9 @@ PROTOS = {
     "rcf_crf_set_variant": (c_int, [c_int]),
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
+    "rcf_sum_partials_f64": (c_int, [P, c_int, c_int, P, P, P]),
     "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
     "rcf_conv_set_variant": (c_int, [c_int]),
     "rcf_conv2d_wgrad_workspace_bytes": (c_size_t, [_CS]),

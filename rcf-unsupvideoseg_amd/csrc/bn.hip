@@ -112,6 +112,36 @@ __global__ void __launch_bounds__(256) partial_sum_kernel(const double *__restri
     }
 }
 
+// out[g][i] = sum of partial[k][i] over the g-th group of `per` rows (blockIdx.y = g); same fixed order as above
+__global__ void __launch_bounds__(256) partial_sum_groups_kernel(const double *__restrict__ partial, int chunks, int per,
+                                                                 int n, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + j;
+    const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
+    double acc = 0;
+    if (i < n) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int k = k0 + s;
+        for (; k + 24 < k1; k += 32) {
+            a0 += partial[(long)k * n + i];
+            a1 += partial[(long)(k + 8) * n + i];
+            a2 += partial[(long)(k + 16) * n + i];
+            a3 += partial[(long)(k + 24) * n + i];
+        }
+        for (; k < k1; k += 8) a0 += partial[(long)k * n + i];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (s == 0 && i < n) {
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q * 32 + j];
+        out[(long)blockIdx.y * n + i] = t;
+    }
+}
+
 struct StatsOp {
     const float *x;
     int pitch;
@@ -304,6 +334,24 @@ extern "C" int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, dou
     RCF_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_sum_partials_f64(const double *partial, int chunks, int n, double *out, double *scratch,
+                                    void *stream) {
+    if (!partial || !out || chunks <= 0 || n <= 0) return RCF_EINVAL;
+    hipStream_t st = rcf_stream(stream);
+    if (scratch && chunks >= 256) {
+        // many partial rows (one per conv row tile): G groups of rows first, so that more than n/32 workgroups read
+        const int G = chunks >= 2048 ? 64 : 16, per = rcf_cdiv(chunks, G);
+        hipLaunchKernelGGL(partial_sum_groups_kernel, dim3(rcf_cdiv(n, 32), G), dim3(256), 0, st, partial, chunks, per, n,
+                           scratch);
+        RCF_LAUNCH_CHECK();
+        partial = scratch;
+        chunks = G;
+    }
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(n, 32)), dim3(256), 0, st, partial, chunks, n, out);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -55,6 +55,9 @@ struct IgemmParams {
     // batched GEMM (rcf_gemm_nt_batched_f32): blockIdx.y = i0 * batch1 + i1 selects the operands of one product
     int batch1;
     long a_bs0, a_bs1, b_bs0, b_bs1, y_bs0, y_bs1;     // element strides of A / B / Y over the two batch indices
+    // split-bf16 forward only: per row tile, the fp64 column sums and sums of squares of the values written
+    // ([mtiles][2 * Ncol]; the batch-norm statistics of the output without reading it back).  Needs act == beta == 0.
+    double *stats;
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -592,11 +595,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
+    const bool want_stats = !DGRAD && p.stats != nullptr;
     float bv[NR];
+    float csum[NR], csq[NR];     // this lane's 16 MR values of a column in fp32; everything above that in fp64
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = n0 + brow0 + nr * 32 + l31;
         bv[nr] = (p.bias && col < p.Ncol) ? p.bias[col] : 0.f;
+        csum[nr] = 0.f;
+        csq[nr] = 0.f;
     }
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
@@ -621,7 +628,38 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (erf form)
                 if (p.beta) v += drow[nr * 32];
                 drow[nr * 32] = v;
+                if (want_stats) {
+                    csum[nr] += v;
+                    csq[nr] = fmaf(v, v, csq[nr]);
+                }
             }
+        }
+    }
+    if (want_stats) {                                         // block-uniform
+        // column sums of this row tile: lane halves by shuffle, the WM waves of a column through LDS, fixed order
+        __syncthreads();                                      // every wave is done with the operand stages
+        double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2]
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const double s = (double)csum[nr] + (double)__shfl_xor(csum[nr], 32);
+            const double q = (double)csq[nr] + (double)__shfl_xor(csq[nr], 32);
+            if (kh == 0) {
+                red[(wm * BN + brow0 + nr * 32 + l31) * 2] = s;
+                red[(wm * BN + brow0 + nr * 32 + l31) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            if (n0 + c >= p.Ncol) continue;
+            double s = 0, q = 0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s += red[(w * BN + c) * 2];
+                q += red[(w * BN + c) * 2 + 1];
+            }
+            double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
+            o[0] = s;
+            o[p.Ncol] = q;
         }
     }
 }
@@ -1368,6 +1406,32 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
     if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
     if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
     return launch_igemm<0>(p, rcf_stream(stream));
+}
+
+extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s) || !use_x3(1)) return 0;
+    // one row of partial sums per row tile (smallest tile: 64 rows) + the 64 rows of the two-level reduction
+    return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 64) + 64) * 2 * s->Cout * sizeof(double);
+}
+
+extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !w || !y || !sums || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+    if (!use_x3(1)) return RCF_EINVAL;                    // the statistics epilogue exists on the split-bf16 kernels only
+    if (!workspace || workspace_bytes < rcf_conv2d_fwd_stats_workspace_bytes(s)) return RCF_EWORKSPACE;
+    IgemmParams p{};
+    p.A = x; p.Bw = w; p.bias = nullptr; p.Y = y;
+    p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
+    p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
+    if (int e = set_region(p, nullptr, s->N, s->Ho, s->Wo)) return e;
+    p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
+    p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
+    p.ldb = p.K;
+    p.stats = (double *)workspace;
+    if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
+    return rcf_sum_partials_f64((const double *)workspace, p.mtiles, 2 * s->Cout, sums,
+                                (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, stream);
 }
 
 extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {

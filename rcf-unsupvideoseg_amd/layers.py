@@ -16,10 +16,11 @@ from . import ops
 
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
-    __slots__ = ("t", "grad", "needs_grad")
+    __slots__ = ("t", "grad", "needs_grad", "stats")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
+        self.stats = None            # fp64 [2C] column sums | sums of squares, when the producing conv computed them
 
     def grad_slot(self):
         """(tensor, beta) for the next gradient producer."""
@@ -37,6 +38,8 @@ class Act:
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
 OVERLAP_WGRAD = True
+# conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
+FUSE_BN_STATS = True
 _side_streams = {}
 
 
@@ -140,11 +143,18 @@ class Conv2d(nn.Module):
         b[:self.cout].copy_(self.bias.detach())
         return b
 
-    def fwd(self, x, tape, out=None):
-        """Returns an Act with cout_pad channels (the padded ones are exactly zero)."""
+    def fwd(self, x, tape, out=None, stats=False):
+        """Returns an Act with cout_pad channels (the padded ones are exactly zero).
+        stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics."""
         w, b = self._packed_weight(), self._packed_bias()
-        y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
-        ya = Act(y)
+        if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
+                and ops.conv_regions_available():
+            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation)
+            ya = Act(y)
+            ya.stats = sums
+        else:
+            y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
+            ya = Act(y)
         if tape.enabled:
             def bwd():
                 dy = ya.take_grad()
@@ -204,7 +214,7 @@ class BatchNorm2d(nn.Module):
         xt = x.t
         if self.training:
             local_rows = xt.shape[0] * xt.shape[1] * xt.shape[2]
-            sums = ops.bn_stats(xt)
+            sums = x.stats if x.stats is not None else ops.bn_stats(xt)
             count = local_rows
             if dist is not None and dist.on:                    # SyncBN: statistics over the global batch
                 dist.allreduce_sum(sums)

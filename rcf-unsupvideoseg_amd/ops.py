@@ -149,6 +149,24 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     return out
 
 
+def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1):
+    """conv (no bias) whose epilogue also yields the batch-norm statistics of the output: (y, fp64 [2*Cout] sums)"""
+    _need_cuda(x, w)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
+    s.y_pitch = pitch_of(out)
+    sums = torch.empty(2 * s.Cout, dtype=torch.float64, device=x.device)
+    need = _lib.load().rcf_conv2d_fwd_stats_workspace_bytes(byref(s))
+    ws = workspace(need, x.device)
+    end = None
+    if PROFILE.which is not None and s.Cout > 128:
+        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+    call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
+    if end is not None:
+        end.record()
+    return out, sums
+
+
 def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None):
     """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written"""
     _need_cuda(dy, w)

@@ -153,6 +153,33 @@ def test_conv_region(case, report):
     assert e_f < 2e-5 and e_w < 2e-5 and e_d < 2e-5 and outside == 0.0 and outside_d == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,Cout,k,stride,pad,dil,H,W", [
+    (2, 64, 64, 1, 1, 0, 1, 31, 45),           # 64-wide tiles, ragged last row tile
+    (2, 4, 64, 7, 2, 3, 1, 60, 107),           # stem
+    (3, 64, 256, 1, 1, 0, 1, 23, 29),          # 128 x 256 tiles
+    (2, 128, 136, 3, 1, 2, 2, 20, 27),         # ragged column tile
+    (9, 32, 32, 3, 2, 1, 1, 40, 40),           # several row tiles per image and images per tile
+])
+def test_conv_fwd_fused_bn_stats(N, Cin, Cout, k, stride, pad, dil, H, W, report):
+    """rcf_conv2d_fwd_stats_f32: the output is bit-identical to the plain forward and the epilogue's per-channel
+    sums equal the float64 column sums of that output to fp32 rounding of a lane-level partial sum (as the separate pass)"""
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g) + 0.3
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    xg, wg = to_nhwc(x), cl_weight(w)
+    y0 = ops.conv2d_fwd(xg, wg, None, stride, pad, dil)
+    y1, sums = ops.conv2d_fwd_stats(xg, wg, stride, pad, dil)
+    assert torch.equal(y0, y1)
+    ref = ops.bn_stats(y0)
+    yd = y0.double().reshape(-1, Cout)
+    truth = torch.cat([yd.sum(0), (yd * yd).sum(0)])
+    scale = torch.cat([yd.abs().sum(0), (yd * yd).sum(0)]).clamp_min(1e-30)
+    e_sep = float(((ref - truth).abs() / scale).max())
+    e_fused = float(((sums - truth).abs() / scale).max())
+    report(f"conv+bn-stats N{N} {Cin}->{Cout} k{k}: fused sums rel err {e_fused:.2e} (separate pass {e_sep:.2e})")
+    assert e_fused < 5e-7 and e_sep < 5e-7
+
+
 def test_conv_large_wgrad_splitk(report):
     """enough pixels for the split-K path (workspace + deterministic reduce)"""
     g = torch.Generator().manual_seed(77)
