@@ -39,7 +39,24 @@ typedef struct {
     int Ho, Wo, Cout;        /* output [N,Ho,Wo,Cout], pixel pitch y_pitch */
     int R, S, stride, pad, dil;
     int x_pitch, y_pitch;
+    /* Optional operand ranges: device scalars holding max |value| of x / w / dy as raw fp32 bits (rcf_absmax_f32);
+     * NULL = unknown.  When the two a launch contracts are known (fwd: x, w; dgrad: dy, w; wgrad: x, dy) the
+     * fp16-pair kernels run -- operands scaled by powers of two into fp16's range, split into 2 x fp16, 3 partial
+     * products on the matrix cores (fp32-level error, see csrc/igemm_conv.hip) -- otherwise the bf16-triple kernels
+     * (6 partial products).  A stale range that is too SMALL for its tensor overflows fp16: ranges must be fresh. */
+    const unsigned *amax_x, *amax_w, *amax_dy;
+    /* Optional, forward launches of the fp16-pair kernels: w already split by rcf_conv_weight_pairs_f32 with the
+     * range amax_w points to (the kernel then reads the two fp16 planes instead of splitting w in every row tile) */
+    const void *w_pairs;
 } rcf_conv_shape;
+
+/* planes: 4 bytes per weight, 16 per 4 consecutive input channels [Cout][R][S][Cin/4][h0 h1 h2 h3 m0 m1 m2 m3]
+ * (fp16 h and m of w * 2^k, k from *amax_w) */
+int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
+                              void *stream);
+
+/* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
+int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);
 
 int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                        int act, float slope, int beta, void *stream);
@@ -106,7 +123,12 @@ int rcf_bn_finalize_f32(const double *sums, double count, int C, float eps, floa
  * rows_per_image only matters with chan_scale (Dropout2d keep-mask / keep-prob, NULL = off). */
 int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_pitch, float *y, int y_pitch,
                      long rows, int C, const float *mean, const float *invstd, const float *gamma,
-                     const float *beta, int relu, const float *chan_scale, long rows_per_image, void *stream);
+                     const float *beta, int relu, const float *chan_scale, long rows_per_image,
+                     unsigned char *relu_mask, unsigned *amax_out, void *stream);
+/* amax_out (may be NULL; here and in rcf_bn_bwd_apply_f32): amax_out[0] = max(amax_out[0], bits(max |output|)), the
+ * operand range of the convs that read the output next (rcf_conv_shape), without another pass over it.
+ * relu_mask (may be NULL): with relu, one byte per 4 channels [rows][C/4], bit e = output channel 4j+e was positive
+ * before the clamp.  The backward kernels take it in place of y (1/16 of the bytes of re-reading y). */
 /* eval-mode BN: same kernel with mean=running_mean, invstd from running_var */
 int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, float *invstd, void *stream);
 /* backward.  g = dy [* chan_scale] [* (y>0)];  sums2 = [sum g | sum g*xhat] (fp64).
@@ -116,13 +138,15 @@ int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, float *invstd
  * dres (+)= g  (res_beta 0/1). */
 int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
                           int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
-                          const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
+                          double *sums2, void *workspace, size_t workspace_bytes, void *stream);
 int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y, int y_pitch,
                          float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta, long rows, int C,
                          const float *mean, const float *invstd, const float *gamma, int relu,
-                         const float *chan_scale, long rows_per_image, const double *sums2,
-                         const double *sums2_local, double count, float *dgamma, float *dbeta, void *stream);
+                         const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
+                         const double *sums2,
+                         const double *sums2_local, double count, float *dgamma, float *dbeta,
+                         unsigned *amax_out, void *stream);
 
 /* ---- pooling / resize / layout ------------------------------------------------------------------
  * MaxPool2d(3,2,1): models/resnet.py:577.  argmax: uint8 window position (r*3+s), first max wins. */

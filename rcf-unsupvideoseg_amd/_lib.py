@@ -17,7 +17,8 @@ class RcfHipError(RuntimeError):
 class ConvShape(ctypes.Structure):
     """mirror of rcf_conv_shape"""
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad", "dil",
-                                     "x_pitch", "y_pitch")]
+                                     "x_pitch", "y_pitch")] + \
+               [(n, ctypes.c_void_p) for n in ("amax_x", "amax_w", "amax_dy", "w_pairs")]
 
 
 class ConvRegion(ctypes.Structure):
@@ -62,6 +63,8 @@ PROTOS = {
     "rcf_clamp01_f32": (c_int, [P, c_int, P]),
     "rcf_crf_set_variant": (c_int, [c_int]),
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_absmax_f32": (c_int, [P, c_long, c_int, c_int, P, P]),
+    "rcf_conv_weight_pairs_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
@@ -73,12 +76,12 @@ PROTOS = {
     "rcf_bn_stats_workspace_bytes": (c_size_t, [c_long, c_int]),
     "rcf_bn_stats_f32": (c_int, [P, c_long, c_int, c_int, P, P, c_size_t, P]),
     "rcf_bn_finalize_f32": (c_int, [P, c_double, c_int, c_float, c_float, P, P, P, P, P]),
-    "rcf_bn_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P]),
+    "rcf_bn_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P, P, P]),
     "rcf_bn_invstd_from_var_f32": (c_int, [P, c_int, c_float, P, P]),
-    "rcf_bn_bwd_reduce_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_int, P, c_long, P, P,
+    "rcf_bn_bwd_reduce_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_int, P, P, c_long, P, P,
                                       c_size_t, P]),
     "rcf_bn_bwd_apply_f32": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P,
-                                     c_int, P, c_long, P, P, c_double, P, P, P]),
+                                     c_int, P, P, c_long, P, P, c_double, P, P, P, P]),
     "rcf_maxpool3x3s2_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_maxpool3x3s2_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_resize_bilinear_nhwc_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -142,6 +142,17 @@ __global__ void __launch_bounds__(256) partial_sum_groups_kernel(const double *_
     }
 }
 
+// block-wide max of non-negative raw float bits -> one atomicMax (the operand range of the fp16-pair conv kernels
+// that read this tensor next; include/rcf_hip.h rcf_conv_shape).  Every thread of the block must call it.
+__device__ __forceinline__ void block_amax(unsigned mx, unsigned *__restrict__ amax) {
+    __shared__ unsigned sh_amax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0) sh_amax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3])));
+}
+
 struct StatsOp {
     const float *x;
     int pitch;
@@ -159,13 +170,18 @@ struct BwdOp {
     const float *dy, *x, *y, *mean, *invstd, *scale;
     int dy_pitch, x_pitch, y_pitch, relu, C;
     long rows_per_image;
+    const unsigned char *mask;     // [rows][C/4]: bit e = output c4+e was positive (replaces the read of y)
     __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
         f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
         if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
-        if (relu) {
+        if (relu && mask) {
+            const unsigned m = mask[r * (C >> 2) + (c4 >> 2)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+        } else if (relu) {
             const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
@@ -205,10 +221,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
                                                        float *__restrict__ y, int y_pitch, long rows, int C,
                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                       int relu, const float *__restrict__ scale, long rows_per_image) {
+                                                       int relu, const float *__restrict__ scale, long rows_per_image,
+                                                       unsigned char *__restrict__ mask,
+                                                       unsigned *__restrict__ amax) {
     const int CV = C / 4;
     const long total = rows * CV;
     const long step = (long)gridDim.x * blockDim.x;
+    unsigned mx = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
@@ -222,12 +241,19 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
         for (int e = 0; e < 4; ++e) o[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
         if (res) o += *reinterpret_cast<const f32x4 *>(res + r * r_pitch + c4);
         if (relu) {
+            if (mask) mask[i] = (unsigned char)((o[0] > 0.f) | ((o[1] > 0.f) << 1) | ((o[2] > 0.f) << 2) | ((o[3] > 0.f) << 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
         }
         if (scale) o *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
         *reinterpret_cast<f32x4 *>(y + r * y_pitch + c4) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = o[e];
+            mx = max(mx, __float_as_uint(fabsf(f)));
+        }
     }
+    if (amax) block_amax(mx, amax);
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
@@ -236,7 +262,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     long rows, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
-    float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    float *__restrict__ dgamma, float *__restrict__ dbeta, const unsigned char *__restrict__ mask,
+    unsigned *__restrict__ amax) {
     const int CV = C / 4;
     const long total = rows * CV;
     const long step = (long)gridDim.x * blockDim.x;
@@ -248,12 +275,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
         }
     }
     const float inv_count = (float)(1.0 / count);
+    unsigned mx = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
         f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
         if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
-        if (relu) {
+        if (relu && mask) {
+            const unsigned m = mask[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+        } else if (relu) {
             const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
@@ -271,11 +303,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
             o[e] = ga[e] * is[e] * (g[e] - sg - xh * sgx);
         }
         *reinterpret_cast<f32x4 *>(dx + r * dx_pitch + c4) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = o[e];
+            mx = max(mx, __float_as_uint(fabsf(f)));
+        }
         if (dres) {
             f32x4 *dr = reinterpret_cast<f32x4 *>(dres + r * dres_pitch + c4);
             *dr = res_beta ? (*dr + g) : g;
         }
     }
+    if (amax) block_amax(mx, amax);
 }
 
 struct ColsumOp {
@@ -376,29 +414,29 @@ extern "C" int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, fl
 extern "C" int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_pitch, float *y,
                                 int y_pitch, long rows, int C, const float *mean, const float *invstd,
                                 const float *gamma, const float *beta, int relu, const float *chan_scale,
-                                long rows_per_image, void *stream) {
+                                long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
     if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), x, x_pitch,
                        residual, r_pitch, y, y_pitch, rows, C, mean, invstd, gamma, beta, relu, chan_scale,
-                       rows_per_image > 0 ? rows_per_image : 1);
+                       rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out);
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
                                      int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
-                                     const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
-                                     size_t workspace_bytes, void *stream) {
+                                     const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
+                                     double *sums2, void *workspace, size_t workspace_bytes, void *stream) {
     if (!dy || !x || !mean || !invstd || !sums2 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
-    if (relu && !y) return RCF_EINVAL;
-    if (dy_pitch % 4 || x_pitch % 4 || (relu && y_pitch % 4)) return RCF_EINVAL;
+    if (relu && !y && !relu_mask) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || (relu && !relu_mask && y_pitch % 4)) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
     const ColGeom g = col_geom(rows, C);
     hipStream_t st = rcf_stream(stream);
     BwdOp op{dy, x, y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, relu, C,
-             rows_per_image > 0 ? rows_per_image : 1};
+             rows_per_image > 0 ? rows_per_image : 1, relu_mask};
     hipLaunchKernelGGL(colreduce2_kernel<BwdOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
                        g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     RCF_LAUNCH_CHECK();
@@ -411,17 +449,17 @@ extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float 
 extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pitch, const float *y,
                                     int y_pitch, float *dx, int dx_pitch, float *dres, int dres_pitch, int res_beta,
                                     long rows, int C, const float *mean, const float *invstd, const float *gamma,
-                                    int relu, const float *chan_scale, long rows_per_image, const double *sums2,
-                                    const double *sums2_local, double count, float *dgamma, float *dbeta,
-                                    void *stream) {
+                                    int relu, const unsigned char *relu_mask, const float *chan_scale,
+                                    long rows_per_image, const double *sums2, const double *sums2_local, double count,
+                                    float *dgamma, float *dbeta, unsigned *amax_out, void *stream) {
     if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
         return RCF_EINVAL;
-    if (relu && !y) return RCF_EINVAL;
+    if (relu && !y && !relu_mask) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), dy,
                        dy_pitch, x, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch, res_beta, rows, C, mean,
                        invstd, gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
-                       sums2_local ? sums2_local : sums2, count, dgamma, dbeta);
+                       sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -58,6 +58,13 @@ struct IgemmParams {
     // split-bf16 forward only: per row tile, the fp64 column sums and sums of squares of the values written
     // ([mtiles][2 * Ncol]; the batch-norm statistics of the output without reading it back).  Needs act == beta == 0.
     double *stats;
+    // fp16-pair kernels: max |value| of the two operand tensors as raw fp32 bits (device scalars); both operands are
+    // scaled by powers of two into fp16's range before they are split, the accumulators are scaled back
+    const unsigned *amax_a, *amax_b;
+    // fp16-pair kernels: the weight operand already split and scaled by 2^k(amax_b), 16 bytes per 4 consecutive k of
+    // a row [Ncol][ldb/4][h0 h1 h2 h3 m0 m1 m2 m3] (the fp32 layout's addresses); null = fp32 weights in Bw, split on
+    // the way into LDS
+    const void *b_pairs;
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -364,6 +371,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 &l) {
     const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
@@ -377,16 +385,92 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 
     l = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
+// -------------------------------------------------------------------------------------------- fp16 pairs ("h2")
+// The same idea with HALF the matrix-core work: x * 2^k = h + m with h, m fp16 (2 x 11 significand bits; k brings the
+// tensor's largest magnitude to [2^14, 2^15) so that neither part overflows and m stays a normal number for every
+// element within 2^-18 of the largest) and x*y ~= h*h' + (h*m' + m*h'): the dropped m*m' and the representation error
+// are <= 2^-22 |xy| per product, the level of fp32's own rounding through the accumulation (measured against float64:
+// 3.0e-7 relative rms at K = 2304, torch's fp32 GEMM 3.1e-7).  3 MFMA passes: peak 2.5 PF / 3 = 833 TF/s.
+// The power-of-two scales are exact; they come from the tensors' max |value| (rcf_absmax_f32, a device scalar that the
+// caller can reuse between the forward, data-gradient and weight-gradient launches that share an operand).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// 2^k with k = 14 - floor(log2(max)), |k| <= 100 (amax: raw bits of a non-negative fp32)
+__device__ __forceinline__ int h2_exponent(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    if (amax_bits == 0u) return 0;
+    int k = 14 - (e - 127);
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+
+__device__ __forceinline__ void split2h(const f32x4 v, float s, u32x2 &h, u32x2 &m) {
+    const f32x2 a = {v[0] * s, v[1] * s}, b = {v[2] * s, v[3] * s};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const f16x2 ma = __builtin_convertvector(ra, f16x2), mb = __builtin_convertvector(rb, f16x2);
+    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+}
+
+// amax[0] = max(amax[0], bits(max |x|)) over a [rows][C] matrix with row pitch `pitch`: for non-negative floats the
+// raw bits order like the values, so the reduction is an integer max (order independent: deterministic with atomics)
+__global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x, long rows, int C, int pitch,
+                                                     unsigned *__restrict__ amax) {
+    __shared__ unsigned sh[4];
+    const int CV = C >> 2;
+    const long total = rows * CV, step = (long)gridDim.x * blockDim.x;
+    unsigned mx = 0u;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long r = i / CV;
+        const int c4 = (int)(i - r * CV) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * pitch + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = v[e];
+            mx = max(mx, __float_as_uint(fabsf(f)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+
 // one K=16 step: 6 x MR x NR MFMAs (32x32x16 bf16), smallest partial products first.
 // PA / PB: bytes per bf16 plane of the A / B tile; arow0 / brow0: first tile row of this wave.
 // PERM: tile rows are stored at x3_prow(row) (the weight-gradient loader's conflict-free write pattern).
 __device__ __forceinline__ int x3_prow(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <int MR, int NR, int PA, int PB, bool PERM = false>
+template <int MR, int NR, int PA, int PB, bool PERM = false, int NP = 3>
 __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *__restrict__ Bs, int arow0, int brow0,
                                        int lane, f32x16 (&acc)[MR][NR]) {
     const int l31 = PERM ? x3_prow(lane & 31) : (lane & 31);
     const int swz = ((lane >> 5) ^ ((l31 >> 3) & 1)) << 4;
+    if constexpr (NP == 2) {                 // fp16 pairs: m*h', h*m', h*h'
+        f16x8 a[MR][2], b[NR][2];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                a[mr][q] = *reinterpret_cast<const f16x8 *>(As + q * PA + (arow0 + mr * 32 + l31) * 32 + swz);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                b[nr][q] = *reinterpret_cast<const f16x8 *>(Bs + q * PB + (brow0 + nr * 32 + l31) * 32 + swz);
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mr][HA[t]], b[nr][HB[t]], acc[mr][nr], 0, 0, 0);
+        return;
+    }
     bf16x8 a[MR][3], b[NR][3];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
@@ -416,11 +500,13 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // out-of-range offset and the hardware returns zeros: no select on the data, no 64-bit address math).
 // DGRAD only names the instantiation (forward and data-gradient launches show up as different kernels in a profile:
 // the data gradients run beside the weight gradients of a second stream, the forward convs run alone)
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false>
+// NP: 3 = bf16 triples (6 partial products), 2 = fp16 pairs (3 partial products, operands scaled by p.amax_a / p.amax_b)
+// PRE (NP == 2 only): the weight operand arrives split (p.b_pairs: two fp16 planes)
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false>
 __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
-    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int bid = blockIdx.x;
@@ -451,7 +537,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const int n_first = m0 / HoWo;                            // first image this tile touches (block-uniform)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.A + (long)n_first * p.a_img_stride), 0, (int)X3_OOB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Bw), 0, p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (NP == 2 && PRE) ? const_cast<void *>(p.b_pairs) : (void *)const_cast<float *>(p.Bw), 0, p.b_bytes, 0x00020000);
 
     int abase[A_PASS];        // float offset of tap (0,0) of the row from the descriptor base (STRIDED: of the image)
     int ay[A_PASS], ax[A_PASS];
@@ -471,6 +558,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             ax[i] = -(1 << 28);
         }
     }
+    // fp16 pairs with the weights split beforehand: same addresses, 16 bytes = (h0..h3, m0..m3) of four k
+    constexpr bool pre = NP == 2 && PRE;
     unsigned bbase[B_PASS];   // byte offset of the weight row (out of range for columns past Ncol)
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
@@ -517,26 +606,44 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         for (int i = 0; i < B_PASS; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)((bbase[i] + k4) | koob), 0, 0));
     };
+    int ka = 0, kb = 0;                      // fp16 pairs: operand scales 2^ka, 2^kb
+    if constexpr (NP == 2) {
+        ka = h2_exponent(*p.amax_a);
+        kb = h2_exponent(*p.amax_b);
+    }
+    const float sa = pow2f(ka), sb = pow2f(kb);
     auto store_tile = [&](int buf, const f32x4 (&src)[A_PASS]) {
         char *As = smem + buf * STAGE;
-        char *Bs = As + 3 * PA;
+        char *Bs = As + NP * PA;
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             u32x2 h, m, l;
-            split3(src[i], h, m, l);
             char *d = As + st_off + i * ROWS * 32;
+            if constexpr (NP == 2) {
+                split2h(src[i], sa, h, m);
+            } else {
+                split3(src[i], h, m, l);
+                *reinterpret_cast<u32x2 *>(d + 2 * PA) = l;
+            }
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PA) = m;
-            *reinterpret_cast<u32x2 *>(d + 2 * PA) = l;
         }
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
             u32x2 h, m, l;
-            split3(rb[i], h, m, l);
             char *d = Bs + st_off + i * ROWS * 32;
+            if constexpr (pre) {
+                const u32x4 q = __builtin_bit_cast(u32x4, rb[i]);
+                h = u32x2{q[0], q[1]};
+                m = u32x2{q[2], q[3]};
+            } else if constexpr (NP == 2) {
+                split2h(rb[i], sb, h, m);
+            } else {
+                split3(rb[i], h, m, l);
+                *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
+            }
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PB) = m;
-            *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
         }
     };
 
@@ -564,7 +671,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 2, ra[0]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem;
-            mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(1, ra[1]);
             __syncthreads();
         }
@@ -573,7 +680,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 3, ra[1]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem + STAGE;
-            mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(0, ra[0]);
             __syncthreads();
         }
@@ -582,20 +689,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         load_b(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem;
-        mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
         store_tile(1, ra[1]);
         __syncthreads();
         ++kt;
     }
     {
         const char *As = smem + (kt & 1) * STAGE;
-        mma_x3<MR, NR, PA, PB>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
     // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     const bool want_stats = !DGRAD && p.stats != nullptr;
+    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     float bv[NR];
     float csum[NR], csq[NR];     // this lane's 16 MR values of a column in fp32; everything above that in fp64
 #pragma unroll
@@ -623,7 +731,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 if (n0 + brow0 + nr * 32 + l31 >= p.Ncol) continue;
-                float v = acc[mr][nr][e] + bv[nr];
+                float v = acc[mr][nr][e];
+                if constexpr (NP == 2) v = (v * inv_a) * inv_b;       // two exact steps: 2^-(ka+kb) may leave fp32's range
+                v += bv[nr];
                 if (p.act == 1) v = v > 0.f ? v : v * p.slope;
                 else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (erf form)
                 if (p.beta) v += drow[nr * 32];
@@ -681,6 +791,46 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float *__re
     }
 }
 
+// The weight operand of the fp16-pair kernels, split once per launch instead of once per row tile:
+// element i of the [rows][K] operand -> fp16 h at 2 i + (i & ~3) ... i.e. quads of 4 consecutive k keep their 16 bytes:
+// [h0 h1 h2 h3 m0 m1 m2 m3] of w * 2^k (k from the weights' range).  TRANSPOSE: i runs over wt[c][rs][co].
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restrict__ w, const unsigned *__restrict__ amax,
+                                                           _Float16 *__restrict__ planes, int Cout, int Cin, int RS) {
+    const float sc = pow2f(h2_exponent(*amax));
+    const long n = (long)Cout * RS * Cin;
+    if (!TRANSPOSE) {
+        const long step = (long)gridDim.x * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+            const float v = w[i] * sc;
+            const _Float16 h = (_Float16)v;
+            const long q = (i >> 2) * 8 + (i & 3);
+            planes[q] = h;
+            planes[q + 4] = (_Float16)(v - (float)h);
+        }
+        return;
+    }
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = o0 + r, c = c0 + tx;
+        tile[r][tx] = (co < Cout && c < Cin) ? w[((long)co * RS + rs) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, co = o0 + tx;
+        if (c < Cin && co < Cout) {
+            const float v = tile[tx][r] * sc;
+            const _Float16 h = (_Float16)v;
+            const long i = ((long)c * RS + rs) * Cout + co;
+            const long q = (i >> 2) * 8 + (i & 3);
+            planes[q] = h;
+            planes[q + 4] = (_Float16)(v - (float)h);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- wgrad
 struct WgradParams {
     const float *X, *DY;
@@ -695,6 +845,7 @@ struct WgradParams {
     int beta;          // only honoured when gridDim.z == 1
     int ry0, rx0, rh, rw;   // split-bf16 kernel: contributing output pixels = this rectangle of every image (M = N*rr)
     int rband, rr;          // frame thickness (0 = whole rectangle), pixels per image
+    const unsigned *amax_a, *amax_b;   // fp16-pair kernels: max |dy|, max |x| (raw fp32 bits, device scalars)
 };
 
 // dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
@@ -846,10 +997,10 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(WgradParams p) {
 // bf16 planes and writes them k-contiguous (one ds_write_b64 per plane).  Waves 0-1 stage dy (rows = co),
 // waves 2-3 gather x at the block's tap (rows = c).  Tile rows live at x3_prow(row) so that the 16 lanes
 // of a ds_write_b64 group (4 pixel groups x 4 channel quads) fill one aligned 128-byte window.
-template <int MR, int NR>
+template <int MR, int NR, int NP = 3>
 __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
     constexpr int BM = 64 * MR, BN = 64 * NR;
-    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
@@ -920,18 +1071,28 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
             }
         }
     };
+    int ka = 0, kb = 0;                      // fp16 pairs: scales 2^ka of dy, 2^kb of x
+    if constexpr (NP == 2) {
+        ka = h2_exponent(*p.amax_a);
+        kb = h2_exponent(*p.amax_b);
+    }
+    const float sc = pow2f(isB ? kb : ka);
     auto store_tile = [&](int buf) {
-        char *base = smem + buf * STAGE + (isB ? 3 * PA : 0) + st_off;
+        char *base = smem + buf * STAGE + (isB ? NP * PA : 0) + st_off;
         const int plane = isB ? PB : PA;
         if (q < (isB ? BN : BM) / 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 u32x2 h, m, l;
-                split3(f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]}, h, m, l);
                 char *d = base + e * 128 + (((g >> 1) ^ (e >> 1)) << 4);  // row prow0 + 4 e, 16-byte halves swizzled
+                if constexpr (NP == 2) {
+                    split2h(f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]}, sc, h, m);
+                } else {
+                    split3(f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]}, h, m, l);
+                    *reinterpret_cast<u32x2 *>(d + 2 * plane) = l;
+                }
                 *reinterpret_cast<u32x2 *>(d) = h;
                 *reinterpret_cast<u32x2 *>(d + plane) = m;
-                *reinterpret_cast<u32x2 *>(d + 2 * plane) = l;
             }
         }
     };
@@ -954,15 +1115,16 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
         load_tile(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem + cur * STAGE;
-        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, true, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
         store_tile(cur ^ 1);
         __syncthreads();
     }
     {
         const char *As = smem + ((KT - 1) & 1) * STAGE;
-        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, true, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
+    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const long row_pitch = (long)p.R * p.S * p.Cin;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -979,6 +1141,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_x3_kernel(WgradParams p) {
                 if (co < p.Cout) {
                     float *dst = out + co * row_pitch + (long)rs * p.Cin + c;
                     float v = acc[mr][nr][e];
+                    if constexpr (NP == 2) v = (v * inv_a) * inv_b;
                     if (p.beta && gridDim.z == 1) v += *dst;
                     *dst = v;
                 }
@@ -1000,12 +1163,22 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsig
     l = __builtin_bit_cast(unsigned, lv);
 }
 
+__device__ __forceinline__ void split2h_pair(float a, float b, float s, unsigned &h, unsigned &m) {
+    const f32x2 v = {a * s, b * s};
+    const f16x2 hv = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(hv, f32x2);
+    const f16x2 mv = __builtin_convertvector(r, f16x2);
+    h = __builtin_bit_cast(unsigned, hv);
+    m = __builtin_bit_cast(unsigned, mv);
+}
+
 // 128 x 256 tile of the weight gradient (Cout >= 128, Cin >= 256, whole tensors only): every thread stages one
 // x item (channel quad x 4 pixels, as in igemm_wgrad_x3_kernel) AND half a dy item (channel quad x 2 pixels, one
 // ds_write_b32 per plane), so the loader work is balanced over the four waves; each wave owns 2 x 4 MFMA tiles.
+template <int NP = 3>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams p) {
     constexpr int MR = 2, NR = 4, BM = 128, BN = 256;
-    constexpr int PA = BM * 32, PB = BN * 32, STAGE = 3 * (PA + PB);
+    constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
@@ -1078,25 +1251,39 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams
             }
         }
     };
+    int ka = 0, kb = 0;                      // fp16 pairs: scales 2^ka of dy, 2^kb of x
+    if constexpr (NP == 2) {
+        ka = h2_exponent(*p.amax_a);
+        kb = h2_exponent(*p.amax_b);
+    }
+    const float sa = pow2f(ka), sb = pow2f(kb);
     auto store_tile = [&](int buf) {
-        char *As = smem + buf * STAGE, *Bs = As + 3 * PA;
+        char *As = smem + buf * STAGE, *Bs = As + NP * PA;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsigned h, m, l;
-            split3_pair(ra[0][e], ra[1][e], h, m, l);
             char *d = As + st_a + e * 128 + (((g2 >> 2) ^ (e >> 1)) << 4);     // row prow_a + 4 e
+            if constexpr (NP == 2) {
+                split2h_pair(ra[0][e], ra[1][e], sa, h, m);
+            } else {
+                split3_pair(ra[0][e], ra[1][e], h, m, l);
+                *reinterpret_cast<unsigned *>(d + 2 * PA) = l;
+            }
             *reinterpret_cast<unsigned *>(d) = h;
             *reinterpret_cast<unsigned *>(d + PA) = m;
-            *reinterpret_cast<unsigned *>(d + 2 * PA) = l;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             u32x2 h, m, l;
-            split3(f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]}, h, m, l);
             char *d = Bs + st_b + e * 128 + (((g >> 1) ^ (e >> 1)) << 4);      // row prow_b + 4 e
+            if constexpr (NP == 2) {
+                split2h(f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]}, sb, h, m);
+            } else {
+                split3(f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]}, h, m, l);
+                *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
+            }
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PB) = m;
-            *reinterpret_cast<u32x2 *>(d + 2 * PB) = l;
         }
     };
 
@@ -1118,15 +1305,16 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams
         load_tile(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem + cur * STAGE;
-        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, true, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
         store_tile(cur ^ 1);
         __syncthreads();
     }
     {
         const char *As = smem + ((KT - 1) & 1) * STAGE;
-        mma_x3<MR, NR, PA, PB, true>(As, As + 3 * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, true, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
+    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const long row_pitch = (long)p.R * p.S * p.Cin;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -1142,6 +1330,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams
             for (int nr = 0; nr < NR; ++nr) {
                 if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
                 float v = acc[mr][nr][e];
+                if constexpr (NP == 2) v = (v * inv_a) * inv_b;
                 if (p.beta && gridDim.z == 1) v += drow[nr * 32];
                 drow[nr * 32] = v;
             }
@@ -1213,15 +1402,27 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
 // split-bf16 launch (B always k-contiguous)
 int g_x3_tile = -1;        // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 256x128
 
-template <int MR, int NR, int WM, int WN>
-void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1) {
+template <int MR, int NR, int WM, int WN, int NP, bool PRE = false>
+void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
-    if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true>), grid, dim3(64 * WM * WN), 0, st, p);
-    else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
+}
+
+int g_h2_off = 0;          // rcf_conv_set_variant bit 0x20000: never take the fp16-pair kernels
+
+template <int MR, int NR, int WM, int WN>
+void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1) {
+    if (p.amax_a && p.amax_b && !g_h2_off) {
+        if (p.b_pairs) launch_x3_cfg_np<MR, NR, WM, WN, 2, true>(p, strided, st, batches);
+        else launch_x3_cfg_np<MR, NR, WM, WN, 2>(p, strided, st, batches);
+    } else {
+        launch_x3_cfg_np<MR, NR, WM, WN, 3>(p, strided, st, batches);
+    }
 }
 
 int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
@@ -1315,6 +1516,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
     g_x3_dbg = v >= 0 ? (v >> 15) & 1 : 0;
+    g_h2_off = v >= 0 ? (v >> 17) & 1 : 0;     // 0x20000: bf16 triples even when the operand ranges are given
     g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
     g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
     if (v >= 0) v &= 0xfff;
@@ -1403,9 +1605,31 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
+    p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
     if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
     if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
     return launch_igemm<0>(p, rcf_stream(stream));
+}
+
+extern "C" int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream) {
+    if (!x || !amax || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C || !rcf_aligned16(x)) return RCF_EINVAL;
+    const long items = rows * (C / 4);
+    const long blocks = (items + 1023) / 1024;          // >= 4 float4 per thread
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, rcf_stream(stream), x,
+                       rows, C, pitch, amax);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w,
+                                         void *planes, void *stream) {
+    if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
+    const long n = (long)Cout * R * S * Cin;
+    const long blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(weight_pairs_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                       rcf_stream(stream), w, amax_w, (_Float16 *)planes, Cout, Cin, R * S);
+    RCF_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) {
@@ -1428,6 +1652,7 @@ extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K;
+    p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
     p.stats = (double *)workspace;
     if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
     return rcf_sum_partials_f64((const double *)workspace, p.mtiles, 2 * s->Cout, sums,
@@ -1463,10 +1688,18 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
         const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
         if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
         hipStream_t st = rcf_stream(stream);
-        hipLaunchKernelGGL(weight_transpose_kernel, dim3(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S),
-                           dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin, s->R * s->S);
-        p.Bw = (const float *)workspace;
         p.ldb = p.K;
+        p.amax_a = s->amax_dy; p.amax_b = s->amax_w;
+        const dim3 tgrid(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S);
+        if (p.amax_a && p.amax_b && !g_h2_off) {          // fp16 pairs: transposed AND split, once per launch
+            hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
+                               s->Cout, s->Cin, s->R * s->S);
+            p.b_pairs = workspace;
+        } else {
+            hipLaunchKernelGGL(weight_transpose_kernel, tgrid, dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin,
+                               s->R * s->S);
+            p.Bw = (const float *)workspace;
+        }
         return launch_igemm_x3(p, st);
     }
     if (region) return RCF_EINVAL;
@@ -1517,6 +1750,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     p.rband = region ? region->band : 0; p.rr = region_pixels(region, s->Ho, s->Wo);
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
+    p.amax_a = s->amax_dy; p.amax_b = s->amax_x;
     const bool smallc = s->Cin == 4;
     if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(smallc ? 1 : s->R * s->S), (unsigned)pl.splitk);
@@ -1533,7 +1767,13 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     } while (0)
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
-        if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel, grid, dim3(256), 0, st, p);
+        if (p.amax_a && p.amax_b && !g_h2_off) {            // fp16 pairs
+            if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
+            else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
+            else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, p);
+            else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 1, 2>), grid, dim3(256), 0, st, p);
+        } else if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<3>, grid, dim3(256), 0, st, p);
         else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1>), grid, dim3(256), 0, st, p);
         else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2>), grid, dim3(256), 0, st, p);

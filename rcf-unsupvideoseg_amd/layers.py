@@ -16,22 +16,36 @@ from . import ops
 
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
-    __slots__ = ("t", "grad", "needs_grad", "stats")
+    __slots__ = ("t", "grad", "needs_grad", "stats", "amax", "grad_amax")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
         self.stats = None            # fp64 [2C] column sums | sums of squares, when the producing conv computed them
+        self.amax = None             # int32 [1]: raw bits of max |t| (operand range of the fp16-pair conv kernels)
+        self.grad_amax = None        # the same for `grad`, when its only producer computed it
+
+    def range(self):
+        """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
+        if self.amax is None:
+            self.amax = ops.absmax(self.t)
+        return self.amax
 
     def grad_slot(self):
         """(tensor, beta) for the next gradient producer."""
         if self.grad is None:
             self.grad = torch.empty(tuple(self.t.shape), dtype=torch.float32, device=self.t.device)
             return self.grad, 0
+        self.grad_amax = None        # a second producer accumulates: the first one's range no longer bounds the sum
         return self.grad, 1
 
     def take_grad(self):
         g, self.grad = self.grad, None
         return g
+
+    def take_grad_range(self):
+        """call before take_grad: max |grad| as a device scalar (from the producer when it left one)"""
+        r, self.grad_amax = self.grad_amax, None
+        return r if r is not None else ops.absmax(self.grad)
 
 
 # Weight gradients on a second HIP stream: wgrad and dgrad of a conv both read dy and are independent, so the one's
@@ -40,6 +54,10 @@ class Act:
 OVERLAP_WGRAD = True
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
+# training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
+RELU_BITMASK = True
+# convs on the fp16-pair kernels (3 partial products; operand ranges from ops.absmax) instead of bf16 triples (6)
+FP16_PAIRS = True
 _side_streams = {}
 
 
@@ -147,16 +165,23 @@ class Conv2d(nn.Module):
         """Returns an Act with cout_pad channels (the padded ones are exactly zero).
         stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics."""
         w, b = self._packed_weight(), self._packed_bias()
+        ax = aw = wp = None
+        if FP16_PAIRS:
+            ax, aw = x.range(), ops.absmax(ops.weight_rsck(w))
+            if x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 4096:      # many row tiles would each split the weights
+                wp = ops.weight_pairs(w, aw)
         if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
                 and ops.conv_regions_available():
-            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation)
+            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp)
             ya = Act(y)
             ya.stats = sums
         else:
-            y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out)
+            y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out,
+                               amax=(ax, aw), w_pairs=wp)
             ya = Act(y)
         if tape.enabled:
             def bwd():
+                ady = ya.take_grad_range() if FP16_PAIRS else None    # shared by the data and the weight gradient
                 dy = ya.take_grad()
                 if self.act:
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
@@ -167,15 +192,16 @@ class Conv2d(nn.Module):
                             side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready
                             with torch.cuda.stream(side):
                                 ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                                 self.dilation, beta=1)
+                                                 self.dilation, beta=1, amax=(ax, ady))
                             dy.record_stream(side)
                             x.t.record_stream(side)
                         else:
                             ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                             self.dilation, beta=1)
+                                             self.dilation, beta=1, amax=(ax, ady))
                     else:
                         dwp = torch.empty_like(w)
-                        ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0)
+                        ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0,
+                                         amax=(ax, ady))
                         g = _param_grad(self.weight)
                         if self.cin_pad != self.cin:
                             dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), self.cin)      # [Cout,Cin,R,S]
@@ -192,7 +218,8 @@ class Conv2d(nn.Module):
                         _param_grad(self.bias).add_(db[:self.cout])
                 if x.needs_grad:
                     gx, beta = x.grad_slot()
-                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta)
+                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                     amax=(ady, aw))
             tape.push(bwd)
         return ya
 
@@ -224,16 +251,23 @@ class BatchNorm2d(nn.Module):
         else:
             count = 0
             mean, invstd = self.running_mean, ops.bn_invstd_from_var(self.running_var, self.eps)
+        rmask = None
+        if relu and tape.enabled and RELU_BITMASK:
+            # the backward kernels read this (one byte per 4 channels) instead of y
+            rmask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=xt.device)
+        yamax = ops.new_amax(xt.device) if FP16_PAIRS else None
         y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
-                         residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out)
+                         residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out,
+                         relu_mask=rmask, amax_out=yamax)
         ya = Act(y)
+        ya.amax = yamax
         if tape.enabled:
             if not self.training:
                 raise RuntimeError("tape backward through eval-mode BN is not implemented")
 
             def bwd():
                 dy = ya.take_grad()
-                s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale)
+                s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
                 s2_local = None
                 if dist is not None and dist.on:
                     s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them
@@ -242,10 +276,12 @@ class BatchNorm2d(nn.Module):
                 if residual is not None and residual.needs_grad:
                     dres, rbeta = residual.grad_slot()
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
+                gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS else None
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
-                                 dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale, sums2_local=s2_local)
+                                 dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale, sums2_local=s2_local,
+                                 relu_mask=rmask, amax_out=gamax)
             tape.push(bwd)
         return ya
 
@@ -358,34 +394,43 @@ def commuted_concat_conv(a, b, conv, tape):
     ops.resize_nhwc_fwd(b.t, (h, w), False, out=Uup, frame=bi)
     interior = (bw, bw, h - 2 * bw, w - 2 * bw)
     band = (0, 0, h, w, bw)                      # the border frame of thickness bw, one launch
-    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2)
+    # operand ranges of the fp16-pair kernels: bilinear interpolation is a convex combination (|Uup| <= max |b|),
+    # and one range serves both halves of the weight
+    ra = rb = rw = None
+    if FP16_PAIRS:
+        ra, rb, rw = a.range(), b.range(), ops.absmax(ops.weight_rsck(W))
+    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2, amax=(rb, rw))
     y = ops.resize_nhwc_fwd(Z, (h, w), False)                              # interior: conv_d(up2(b)) = up2(conv_{d/2}(b))
-    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band)    # band: directly
-    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1)                  # a's channels: everywhere
+    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band, amax=(rb, rw))    # band: directly
+    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, amax=(ra, rw))   # a's channels: everywhere
     ya = Act(y)
 
     def bwd():
         dy = ya.take_grad()
         dy_int, dy_band = ops.split_rect(dy, interior)
         g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)                  # adjoint of the interior's up-sampling
+        rdy = rg4 = None
+        if FP16_PAIRS:
+            rdy, rg4 = ops.absmax(dy), ops.absmax(g4)                      # dy_band is a part of dy
         if W.requires_grad:
             gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
             dwa = torch.empty_like(wa)
-            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0)
+            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0, amax=(ra, rdy))
             ops.copy2d(dwa.permute(0, 2, 3, 1), Ca, gW[..., :Ca], C, Co * 9, Ca, beta=1)
             dwb = torch.empty_like(wbt)
-            ops.conv2d_wgrad(b.t, g4, wbt, dwb, 1, d // 2, d // 2, beta=0)
-            ops.conv2d_wgrad(Uup, dy, wbt, dwb, 1, d, d, beta=1, region=band)
+            ops.conv2d_wgrad(b.t, g4, wbt, dwb, 1, d // 2, d // 2, beta=0, amax=(rb, rg4))
+            ops.conv2d_wgrad(Uup, dy, wbt, dwb, 1, d, d, beta=1, region=band, amax=(rb, rdy))
             ops.copy2d(dwb.permute(0, 2, 3, 1), Cb, gW[..., Ca:], C, Co * 9, Cb, beta=1)
         if a.needs_grad:
             ga, beta = a.grad_slot()
-            ops.conv2d_dgrad(dy, wa, a.t.shape, 1, d, d, out=ga, beta=beta)
+            ops.conv2d_dgrad(dy, wa, a.t.shape, 1, d, d, out=ga, beta=beta, amax=(rdy, rw))
         if b.needs_grad:
             gb, beta = b.grad_slot()
             dUup = torch.empty_like(Uup)                                   # written (and read) on the bi-frame only
-            ops.conv2d_dgrad(dy_band, wbt, Uup.shape, 1, d, d, out=dUup, beta=0, region=(0, 0, h, w, bi))
+            ops.conv2d_dgrad(dy_band, wbt, Uup.shape, 1, d, d, out=dUup, beta=0, region=(0, 0, h, w, bi),
+                             amax=(rdy, rw))
             ops.resize_nhwc_bwd(dUup, (hb, wb), False, out=gb, beta=beta, frame=bi)
-            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1)
+            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1, amax=(rg4, rw))
     tape.push(bwd)
     return ya
 

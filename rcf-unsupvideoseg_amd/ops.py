@@ -103,12 +103,64 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None):
+def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None):
+    """amax = (amax_x, amax_w, amax_dy): int32 [1] device tensors from absmax() or None -- the operand ranges that
+    select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h)"""
     N, H, W, Cin = xshape
     Cout, Cin_w, R, S = w.shape
     assert Cin == Cin_w, f"channel mismatch {Cin} vs {Cin_w}"
     Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
-    return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout)
+    ax, aw, ady = amax if amax is not None else (None, None, None)
+    kind = "w" if aw is None else ("d" if ax is None else "f")
+    if kind not in H2_KINDS:                      # debug knob: which launches may take the fp16-pair kernels
+        ax = aw = ady = w_pairs = None
+    return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout,
+                     _addr(ax), _addr(aw), _addr(ady), _addr(w_pairs))
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+_amax_pool = {}
+H2_KINDS = __import__("os").environ.get("RCF_H2_KINDS", "fdw")      # f: forward, d: data gradient, w: weight gradient
+
+
+def new_amax(device):
+    """a zeroed int32 [1] device scalar for a tensor's range.  Slots come from a zero-filled pool and are never handed
+    out twice, so no fill kernel runs per range."""
+    key = torch.device(device).index or 0
+    pool = _amax_pool.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _amax_pool[key] = [torch.zeros(8192, dtype=torch.int32, device=device), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
+def absmax(x, out=None):
+    """int32 [1] on the device: raw fp32 bits of max |x| (x: NHWC activation, possibly a channel slice, or any
+    contiguous fp32 tensor).  `out` accumulates (max with its current content)."""
+    _need_cuda(x)
+    if out is None:
+        out = new_amax(x.device)
+    if x.dim() == 4 and x.stride(3) == 1 and x.shape[3] % 4 == 0 and not x.is_contiguous():
+        rows, C, pitch = _rows(x), x.shape[3], pitch_of(x)
+    else:
+        assert x.is_contiguous() and x.numel() % 4 == 0
+        rows, C, pitch = x.numel() // 4, 4, 4
+    call("rcf_absmax_f32", _p(x), rows, C, pitch, _p(out), _stream())
+    return out
+
+
+def weight_pairs(w, amax_w):
+    """the fp16-pair split of a conv weight (channels_last [Cout,Cin,R,S]) for the forward launches that read it:
+    a uint8 buffer holding two fp16 planes"""
+    _need_cuda(w)
+    Cout, Cin, R, S = w.shape
+    planes = torch.empty(w.numel() * 4, dtype=torch.uint8, device=w.device)
+    call("rcf_conv_weight_pairs_f32", _p(weight_rsck(w)), Cout, Cin, R, S, _p(amax_w), _p(planes), _stream())
+    return planes
 
 
 def conv_regions_available():
@@ -132,10 +184,13 @@ def _region(region):
     return byref(_lib.ConvRegion(*(r + [0] * (5 - len(r)))))
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None):
-    """region = (y0, x0, h, w) in output coordinates: only those pixels of `out` are written"""
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None, amax=None,
+               w_pairs=None):
+    """region = (y0, x0, h, w) in output coordinates: only those pixels of `out` are written.
+    amax = (amax_x, amax_w): operand ranges (absmax) -> fp16-pair kernels; w_pairs: weight_pairs(w, amax_w)"""
     _need_cuda(x, w)
-    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
+                    w_pairs=w_pairs)
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
@@ -149,10 +204,11 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     return out
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1):
+def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None):
     """conv (no bias) whose epilogue also yields the batch-norm statistics of the output: (y, fp64 [2*Cout] sums)"""
     _need_cuda(x, w)
-    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
+                    w_pairs=w_pairs)
     out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     sums = torch.empty(2 * s.Cout, dtype=torch.float64, device=x.device)
@@ -167,12 +223,13 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1):
     return out, sums
 
 
-def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None):
-    """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written"""
+def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None):
+    """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w)"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
-    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
+                    amax=None if amax is None else (None, amax[1], amax[0]))
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
@@ -181,11 +238,12 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     return out
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None):
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None, amax=None):
     """dw (same memory layout as the weight) (+)= wgrad.  region = (y0, x0, h, w) in OUTPUT coordinates: only those
     pixels of dy (and their input patches) contribute."""
     _need_cuda(x, dy, dw)
-    s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy))
+    s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy),
+                    amax=None if amax is None else (amax[0], None, amax[1]))      # amax = (amax_x, amax_dy)
     reg = _region(region)
     need = _lib.load().rcf_conv2d_wgrad_region_workspace_bytes(byref(s), reg)
     ws = workspace(need, x.device) if need else None
@@ -223,37 +281,40 @@ def bn_invstd_from_var(var, eps):
     return out
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None):
+def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None, relu_mask=None,
+             amax_out=None):
+    """relu_mask: uint8 [rows * C/4] to receive the sign bits of the pre-clamp output (for the backward pass)"""
     _need_cuda(x)
     if out is None:
         out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
     rows, C = _rows(x), x.shape[3]
     call("rcf_bn_apply_f32", _p(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
          _p(out), pitch_of(out), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(chan_scale),
-         x.shape[1] * x.shape[2], _stream())
+         x.shape[1] * x.shape[2], _p(relu_mask), _p(amax_out), _stream())
     return out
 
 
-def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None):
+def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None, relu_mask=None):
     rows, C = _rows(x), x.shape[3]
     sums2 = torch.empty(2 * C, dtype=torch.float64, device=x.device)
     need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
     ws = workspace(need, x.device)
     call("rcf_bn_bwd_reduce_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
-         rows, C, _p(mean), _p(invstd), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), _p(ws), need,
-         _stream())
+         rows, C, _p(mean), _p(invstd), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
+         _p(ws), need, _stream())
     return sums2
 
 
 def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbeta, dx=None, dres=None, res_beta=0,
-                 chan_scale=None, sums2_local=None):
+                 chan_scale=None, sums2_local=None, relu_mask=None, amax_out=None):
     rows, C = _rows(x), x.shape[3]
     if dx is None:
         dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
     call("rcf_bn_bwd_apply_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
          _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
-         _p(invstd), _p(gamma), int(relu), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2), _p(sums2_local),
-         float(count), _p(dgamma), _p(dbeta), _stream())
+         _p(invstd), _p(gamma), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
+         _p(sums2_local),
+         float(count), _p(dgamma), _p(dbeta), _p(amax_out), _stream())
     return dx
 
 

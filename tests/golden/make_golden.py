@@ -258,10 +258,20 @@ def main():
         ref32 = dict(loss=[rel(l_ref["loss"].item(), l64["loss"].item())], logits=[rel(logits.numpy(), logits64.numpy())],
                      masks=[float((masks.double() - masks64).abs().max())],
                      gradnorm=[[rel(gn_ref[k], gn64[k]) for k in sorted(gn_ref)]], grad=[[rel(g_ref[k], g64[k]) for k in SAMPLED]])
-        for nthreads, cl in ((1, False), (8, True)):
+        # ... and so does rounding the INPUTS differently: the reference evaluated at parameters moved by one unit in
+        # the last place (each weight times 1 +- 2^-23, random signs) is what any backward-stable fp32
+        # implementation is allowed to return -- the conditioning of each compared quantity, measured
+        for nthreads, cl, ulp_seed in ((1, False, 0), (8, True, 0), (8, False, 1), (8, False, 2), (8, False, 3), (8, False, 4)):
             torch.set_num_threads(nthreads)
             rv = ref_models.RCFModel(args, **copy.deepcopy(kw))
-            rv.load_state_dict(sd)
+            if ulp_seed:
+                gp = torch.Generator().manual_seed(1000 + ulp_seed)
+                sdp = {k: (v * (1 + (torch.randint(0, 2, v.shape, generator=gp).float() * 2 - 1) * 2.0 ** -23)
+                           if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")) else v)
+                       for k, v in sd.items()}
+                rv.load_state_dict(sdp)
+            else:
+                rv.load_state_dict(sd)
             if cl:
                 rv = rv.to(memory_format=torch.channels_last)
             rv.train()

@@ -76,6 +76,49 @@ def test_conv_fwd_dgrad_wgrad(case, report):
     assert e_f < 2e-5 and e_d < 2e-5 and e_w < 2e-5 and e_acc < 2e-5
 
 
+@pytest.mark.parametrize("xs,ws,gs,heavy", [(1.0, 1.0, 1.0, False), (1e-6, 30.0, 1e-9, False), (3e4, 1e-3, 1e5, False),
+                                            (1.0, 1.0, 1e-7, True)])
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 9, 10)] + [(2, 256, 512, 3, 1, 1, 1, 24, 40, False, 0)])
+def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
+    """the fp16-pair kernels (operand ranges given: x*2^k = h + m in fp16, 3 partial products) against float64, over
+    operand magnitudes from 1e-9 to 1e5 and a heavy-tailed gradient; the yardstick is torch's own fp32 conv error"""
+    N, Cin, Cout, k, stride, pad, dil, H, W, _, _ = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case)) + int(heavy))
+    x = torch.randn(N, Cin, H, W, generator=g) * xs
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5 * ws
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yref = F.conv2d(xd, wd, None, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(yref.shape, generator=g) * gs
+    if heavy:                                   # a few entries 1e4 times larger than the rest set the range
+        dy = dy * torch.where(torch.rand(dy.shape, generator=g) < 1e-3, 1e4, 1.0)
+    yref.backward(dy.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = F.conv2d(x32, w32, None, stride=stride, padding=pad, dilation=dil)
+    y32.backward(dy)
+
+    def rms(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float(((a - b) ** 2).mean().sqrt() / ((b ** 2).mean().sqrt() + 1e-300))
+    xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
+    ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
+    assert float(ax.view(torch.float32)) == float(x.abs().max()) and float(ag.view(torch.float32)) == float(dy.abs().max())
+    y = ops.conv2d_fwd(xg, wg, None, stride, pad, dil, amax=(ax, aw))
+    # the weights split once beforehand (two fp16 planes) instead of in every row tile: the same bits
+    assert torch.equal(y, ops.conv2d_fwd(xg, wg, None, stride, pad, dil, amax=(ax, aw), w_pairs=ops.weight_pairs(wg, aw)))
+    dx = ops.conv2d_dgrad(gg, wg, xg.shape, stride, pad, dil, amax=(ag, aw))
+    dw = torch.zeros_like(wg)
+    ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=1, amax=(ax, ag))
+    e = (rms(from_nhwc(y), yref), rms(from_nhwc(dx), xd.grad), rms(dw.cpu(), wd.grad))
+    r = (rms(y32, yref), rms(x32.grad, xd.grad), rms(w32.grad, wd.grad))
+    y6 = ops.conv2d_fwd(xg, wg, None, stride, pad, dil)
+    e6 = rms(from_nhwc(y6), yref)
+    report(f"conv fp16 pairs {case[:9]} scales x{xs:g} w{ws:g} dy{gs:g} heavy={heavy}: rms error vs float64 "
+           f"fwd {e[0]:.2e} dgrad {e[1]:.2e} wgrad {e[2]:.2e} | torch fp32 {r[0]:.2e} {r[1]:.2e} {r[2]:.2e} | "
+           f"bf16 triples fwd {e6:.2e}")
+    for ei, ri in zip(e, r):
+        assert ei < max(4 * ri, 5e-7)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_conv_kernel_variants(variant, report):
     """the tuning variants of the implicit-GEMM kernel (K-step 16/32, K-major / row-major LDS) agree"""
@@ -247,7 +290,8 @@ def test_batchnorm_train(C, relu, res, drop, report):
     gg, bg = gamma.to(DEV), beta.to(DEV)
     rg = to_nhwc(r) if res else None
     kg = keep.to(DEV) if drop else None
-    yg = ops.bn_apply(xg, mean, invstd, gg, bg, relu, residual=rg, chan_scale=kg)
+    rmask = torch.empty(xg.numel() // 4, dtype=torch.uint8, device=DEV) if relu else None
+    yg = ops.bn_apply(xg, mean, invstd, gg, bg, relu, residual=rg, chan_scale=kg, relu_mask=rmask)
     e_y = relerr(from_nhwc(yg), y)
     e_rm, e_rv = relerr(rmean, rm), relerr(rvar, rv)
     dyg = to_nhwc(dy)
@@ -255,6 +299,13 @@ def test_batchnorm_train(C, relu, res, drop, report):
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dres = torch.empty_like(xg) if res else None
     dx = ops.bn_bwd_apply(dyg, xg, yg, mean, invstd, gg, relu, s2, count, dgam, dbet, dres=dres, chan_scale=kg)
+    if relu:
+        # the backward kernels fed the sign-bit mask instead of y: identical results
+        s2m = ops.bn_bwd_reduce(dyg, xg, None, mean, invstd, relu, chan_scale=kg, relu_mask=rmask)
+        dresm = torch.empty_like(xg) if res else None
+        dxm = ops.bn_bwd_apply(dyg, xg, None, mean, invstd, gg, relu, s2m, count, torch.zeros(C, device=DEV),
+                               torch.zeros(C, device=DEV), dres=dresm, chan_scale=kg, relu_mask=rmask)
+        assert torch.equal(s2m, s2) and torch.equal(dxm, dx) and (not res or torch.equal(dresm, dres))
     e_dx, e_dg, e_db = relerr(from_nhwc(dx), xd.grad), relerr(dgam, gd.grad), relerr(dbet, bd.grad)
     e_dr = relerr(from_nhwc(dres), rd.grad) if res else 0.0
     report(f"bn C={C} relu={relu} res={res} drop={drop}: y {e_y:.2e} rm {e_rm:.2e} rv {e_rv:.2e} dx {e_dx:.2e} "
