@@ -51,7 +51,7 @@ class Act:
 # Weight gradients on a second HIP stream: wgrad and dgrad of a conv both read dy and are independent, so the one's
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
-OVERLAP_WGRAD = True
+OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
@@ -396,13 +396,14 @@ def commuted_concat_conv(a, b, conv, tape):
     band = (0, 0, h, w, bw)                      # the border frame of thickness bw, one launch
     # operand ranges of the fp16-pair kernels: bilinear interpolation is a convex combination (|Uup| <= max |b|),
     # and one range serves both halves of the weight
-    ra = rb = rw = None
+    ra = rb = rw = pa = pb = None
     if FP16_PAIRS:
         ra, rb, rw = a.range(), b.range(), ops.absmax(ops.weight_rsck(W))
-    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2, amax=(rb, rw))
+        pa, pb = ops.weight_pairs(wa, rw), ops.weight_pairs(wbt, rw)
+    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2, amax=(rb, rw), w_pairs=pb)
     y = ops.resize_nhwc_fwd(Z, (h, w), False)                              # interior: conv_d(up2(b)) = up2(conv_{d/2}(b))
-    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band, amax=(rb, rw))    # band: directly
-    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, amax=(ra, rw))   # a's channels: everywhere
+    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band, amax=(rb, rw), w_pairs=pb)    # band: directly
+    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, amax=(ra, rw), w_pairs=pa)   # a's channels: everywhere
     ya = Act(y)
 
     def bwd():

