@@ -50,8 +50,9 @@ typedef struct {
     const void *w_pairs;
 } rcf_conv_shape;
 
-/* planes: 4 bytes per weight, 16 per 4 consecutive input channels [Cout][R][S][Cin/4][h0 h1 h2 h3 m0 m1 m2 m3]
- * (fp16 h and m of w * 2^k, k from *amax_w) */
+/* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order
+ * [K/16][Cout][4][h0 h1 h2 h3 m0 m1 m2 m3] with K = R*S*Cin padded to a multiple of 16 */
+size_t rcf_conv_weight_pairs_bytes(int Cout, int Cin, int R, int S);
 int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
                               void *stream);
 
@@ -309,7 +310,9 @@ int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const
 /* fused multi-head attention forward (scores stay on chip): out[b*T+t][h*64+d] = softmax_j(scale q_t.k_j) v_j[d];
  * qkv [B*T][3*nh*64] (q | k | v) as produced by the fused qkv linear (models/dino_vit.py:122-133).  head_dim = 64. */
 int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh, int head_dim,
-                          float scale, void *stream);
+                          float scale, const unsigned *amax_qkv, void *stream);
+/* amax_qkv: max |qkv| (rcf_absmax_f32) -> fp16-pair arithmetic (q, k, v scaled by one power of two, probabilities by
+ * 2^14, 3 partial products); NULL -> bf16 triples (6) */
 int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C, const float *gamma,
                       const float *beta, float eps, void *stream);
 /* in place: row <- softmax(scale * row[0:n]); columns [n, pitch) are zeroed */

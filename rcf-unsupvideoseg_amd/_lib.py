@@ -53,7 +53,7 @@ PROTOS = {
     "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "rcf_gemm_nt_batched_f32": (c_int, [P, c_int, c_long, c_long, P, c_int, c_long, c_long, P, c_int, c_long, c_long, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
-    "rcf_attention_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "rcf_attention_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     "rcf_layernorm_f32": (c_int, [P, c_int, P, c_int, c_long, c_int, P, P, c_float, P]),
     "rcf_softmax_rows_f32": (c_int, [P, c_long, c_long, c_int, c_float, P]),
     "rcf_transpose2d_f32": (c_int, [P, c_long, P, c_long, c_int, c_int, P]),
@@ -65,6 +65,7 @@ PROTOS = {
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_absmax_f32": (c_int, [P, c_long, c_int, c_int, P, P]),
     "rcf_conv_weight_pairs_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rcf_conv_weight_pairs_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),

@@ -35,23 +35,69 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 &h, u32x2 &m, u32x2 
     m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
     l = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
-// eight floats -> three bf16x8 operand fragments
-__device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
-    u32x2 h0, m0, l0, h1, m1, l1;
-    split3(f32x4{v[0], v[1], v[2], v[3]}, h0, m0, l0);
-    split3(f32x4{v[4], v[5], v[6], v[7]}, h1, m1, l1);
-    h = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-    m = __builtin_bit_cast(bf16x8, u32x4{m0[0], m0[1], m1[0], m1[1]});
-    l = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+// ---- fp16 pairs (csrc/igemm_conv.hip): x * 2^k = h + m in fp16, 3 partial products.  One range serves q, k and v
+// (max |qkv|); the softmax probabilities are in [0, 1] and take the fixed scale 2^14.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int h2_exponent(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    if (amax_bits == 0u) return 0;
+    const int k = 14 - (e - 127);
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
 }
-// acc += A B with the six significant partial products (smallest first)
-__device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 &acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+
+__device__ __forceinline__ void split2h(const f32x4 v, float s, u32x2 &h, u32x2 &m) {
+    const f32x2 a = {v[0] * s, v[1] * s}, b = {v[2] * s, v[3] * s};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+    const f16x2 ma = __builtin_convertvector(ra, f16x2), mb = __builtin_convertvector(rb, f16x2);
+    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+}
+
+// operand fragments as raw 16 bytes; NP = 3: bf16 triples (6 products), NP = 2: fp16 pairs (3 products)
+template <int NP>
+__device__ __forceinline__ void split_x8(const float (&v)[8], float s, u32x4 (&f)[NP]) {
+    if constexpr (NP == 2) {
+        u32x2 h0, m0, h1, m1;
+        split2h(f32x4{v[0], v[1], v[2], v[3]}, s, h0, m0);
+        split2h(f32x4{v[4], v[5], v[6], v[7]}, s, h1, m1);
+        f[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        f[1] = u32x4{m0[0], m0[1], m1[0], m1[1]};
+    } else {
+        u32x2 h0, m0, l0, h1, m1, l1;
+        split3(f32x4{v[0], v[1], v[2], v[3]}, h0, m0, l0);
+        split3(f32x4{v[4], v[5], v[6], v[7]}, h1, m1, l1);
+        f[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        f[1] = u32x4{m0[0], m0[1], m1[0], m1[1]};
+        f[2] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void mma_np(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 &acc) {
+    if constexpr (NP == 2) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+    } else {
+        bf16x8 x[3], y[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            x[q] = __builtin_bit_cast(bf16x8, a[q]);
+            y[q] = __builtin_bit_cast(bf16x8, b[q]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], acc, 0, 0, 0);
+    }
 }
 
 constexpr int HD = 64;            // head dimension
@@ -66,11 +112,18 @@ struct AttnParams {
     float *out;         // [B*T][dim]
     int T, nh, ld, ldo; // tokens per image, heads, row pitches of qkv / out
     float scale;
+    const unsigned *amax;   // fp16 pairs: max |qkv| (raw bits); null on the bf16-triple instance
 };
 
+template <int NP>
 __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char kS[3 * KPLANE];
-    __shared__ __attribute__((aligned(16))) char vS[3 * VPLANE];
+    __shared__ __attribute__((aligned(16))) char kS[NP * KPLANE];
+    __shared__ __attribute__((aligned(16))) char vS[NP * VPLANE];
+    int kx = 0;                                                 // fp16 pairs: q, k, v scaled by 2^kx, P by 2^14
+    if constexpr (NP == 2) kx = h2_exponent(*p.amax);
+    const float sx = pow2f(kx);
+    const float s_scale = NP == 2 ? p.scale * pow2f(-kx) * pow2f(-kx) : p.scale;
+    constexpr float P_SCALE = NP == 2 ? 16384.f : 1.f;
     __shared__ float rowv[4][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
     const int q0 = blockIdx.x * BQ + wave * 32;                 // first query of this wavefront
 
     // ---- Q as the B operand of S^T = K Q^T: lane (query l31, half hs) holds dims 16g + 8hs .. +7 of its query
-    bf16x8 qf[4][3];
+    u32x4 qf[4][NP];
     {
         const int q = q0 + l31;
         const bool ok = q < p.T;
@@ -93,7 +146,7 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
             const f32x4 c = ok ? *reinterpret_cast<const f32x4 *>(qr + 16 * g + 8 * hs + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = c[e]; }
-            split3x8(v, qf[g][0], qf[g][1], qf[g][2]);
+            split_x8<NP>(v, sx, qf[g]);
         }
     }
 
@@ -136,20 +189,28 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 h, m, l;
-                split3(kreg[g], h, m, l);
                 char *d = kS + g * (BKEY * 32) + k_st;
+                if constexpr (NP == 2) {
+                    split2h(kreg[g], sx, h, m);
+                } else {
+                    split3(kreg[g], h, m, l);
+                    *reinterpret_cast<u32x2 *>(d + 2 * KPLANE) = l;
+                }
                 *reinterpret_cast<u32x2 *>(d) = h;
                 *reinterpret_cast<u32x2 *>(d + KPLANE) = m;
-                *reinterpret_cast<u32x2 *>(d + 2 * KPLANE) = l;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                       // dim 4vq+e: its 4 keys, k-contiguous
                 u32x2 h, m, l;
-                split3(f32x4{vreg[0][e], vreg[1][e], vreg[2][e], vreg[3][e]}, h, m, l);
                 char *d = vS + (4 * vq + e) * VPITCH + vg * 8;
+                if constexpr (NP == 2) {
+                    split2h(f32x4{vreg[0][e], vreg[1][e], vreg[2][e], vreg[3][e]}, sx, h, m);
+                } else {
+                    split3(f32x4{vreg[0][e], vreg[1][e], vreg[2][e], vreg[3][e]}, h, m, l);
+                    *reinterpret_cast<u32x2 *>(d + 2 * VPLANE) = l;
+                }
                 *reinterpret_cast<u32x2 *>(d) = h;
                 *reinterpret_cast<u32x2 *>(d + VPLANE) = m;
-                *reinterpret_cast<u32x2 *>(d + 2 * VPLANE) = l;
             }
         }
         __syncthreads();
@@ -164,11 +225,11 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
             const int swz = (hs ^ ((l31 >> 3) & 1)) << 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x8 kf[3];
+                u32x4 kf[NP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    kf[q] = *reinterpret_cast<const bf16x8 *>(kS + q * KPLANE + g * (BKEY * 32) + (kt * 32 + l31) * 32 + swz);
-                mma6(kf, qf[g], sacc[kt]);
+                for (int q = 0; q < NP; ++q)
+                    kf[q] = *reinterpret_cast<const u32x4 *>(kS + q * KPLANE + g * (BKEY * 32) + (kt * 32 + l31) * 32 + swz);
+                mma_np<NP>(kf, qf[g], sacc[kt]);
             }
         }
         // ---- online softmax for this lane's query: 32 of the tile's 64 keys live here, 32 on lane^32
@@ -179,7 +240,7 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = key0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hs;
-                const float s = key < p.T ? sacc[kt][e] * p.scale : -INFINITY;
+                const float s = key < p.T ? sacc[kt][e] * s_scale : -INFINITY;
                 pv[kt][e] = s;
                 mx = fmaxf(mx, s);
             }
@@ -211,25 +272,25 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
                 float v8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v8[i] = pv[kt][8 * j + i];
-                bf16x8 pf[3];
-                split3x8(v8, pf[0], pf[1], pf[2]);
+                u32x4 pf[NP];
+                split_x8<NP>(v8, P_SCALE, pf);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    bf16x8 vf[3];
+                    u32x4 vf[NP];
                     const char *vr = vS + (d * 32 + l31) * VPITCH + (kt * 32 + 16 * j + 4 * hs) * 2;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < NP; ++q) {
                         const u32x2 lo = *reinterpret_cast<const u32x2 *>(vr + q * VPLANE);          // keys +0..3
                         const u32x2 hi = *reinterpret_cast<const u32x2 *>(vr + q * VPLANE + 16);     // keys +8..11
-                        vf[q] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                        vf[q] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
-                    mma6(pf, vf, oacc[d]);
+                    mma_np<NP>(pf, vf, oacc[d]);
                 }
             }
     }
     // ---- O / l, store: lane holds dims d*32 + l31 of queries (e&3) + 8(e>>2) + 4hs
     __builtin_amdgcn_wave_barrier();
-    if (hs == 0) rowv[wave][l31] = 1.0f / l_run;
+    if (hs == 0) rowv[wave][l31] = (NP == 2 ? pow2f(-kx - 14) : 1.0f) / l_run;      // undo the scales of P and V
     __builtin_amdgcn_wave_barrier();
     float *ob = p.out + (long)b * p.T * p.ldo + head * HD;
 #pragma unroll
@@ -248,12 +309,14 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
 /* out[b*T + t][h*64 + d] = sum_j softmax_j(scale * q_t . k_j) v_j[d] for every image b and head h; qkv is the output of
  * the fused qkv linear ([B*T][3*nh*64], q | k | v).  Head dimension 64 (every DINO ViT). */
 extern "C" int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh,
-                                     int head_dim, float scale, void *stream) {
+                                     int head_dim, float scale, const unsigned *amax_qkv, void *stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || nh <= 0 || head_dim != HD) return RCF_EINVAL;
     if (ld_qkv % 4 || ld_out % 4 || ld_qkv < 3 * nh * HD || ld_out < nh * HD || !rcf_aligned16(qkv) || !rcf_aligned16(out)) return RCF_EINVAL;
     if ((long)B * nh > 65535) return RCF_EINVAL;
-    AttnParams p{qkv, out, T, nh, ld_qkv, ld_out, scale};
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(rcf_cdiv(T, BQ), B * nh), dim3(256), 0, rcf_stream(stream), p);
+    AttnParams p{qkv, out, T, nh, ld_qkv, ld_out, scale, amax_qkv};
+    const dim3 grid(rcf_cdiv(T, BQ), B * nh);
+    if (amax_qkv) hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(256), 0, rcf_stream(stream), p);   // fp16 pairs
+    else hipLaunchKernelGGL(attention_fwd_kernel<3>, grid, dim3(256), 0, rcf_stream(stream), p);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -564,12 +564,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
         const int j = n0 + arow + ROWS * i;
-        bbase[i] = j < p.Ncol ? (unsigned)j * (unsigned)p.ldb * 4u : X3_OOB;
+        bbase[i] = j < p.Ncol ? (unsigned)j * (pre ? 64u : (unsigned)p.ldb * 4u) : X3_OOB;
     }
     // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets, ping-pong by the parity
     // of the step); B (weights, L2 resident) one step ahead.
     f32x4 ra[2][A_PASS], rb[B_PASS];
-    const unsigned dbg_oob = p.dbg ? X3_OOB : 0u;          // timing experiment: every load out of range
+    const unsigned dbg_oob = p.dbg == 1 ? X3_OOB : 0u;     // timing experiment: every load out of range
+    const unsigned dbg_win = p.dbg == 2 ? 0xfff0u : ~0u;   // timing experiment: activation loads from one 64 KB window
 
     auto load_a = [&](int kt, f32x4 (&dst)[A_PASS]) {
         const int k = kt * BKT + kq * 4;
@@ -595,13 +596,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 off = abase[i] + tapoff;
             }
             // invalid -> offset with bit 31 set (beyond num_records): the load returns zeros without touching memory
-            const unsigned bo = (((unsigned)off * 4u) & ~X3_OOB) | ((unsigned)(v - 1) & X3_OOB) | dbg_oob;
+            const unsigned bo = (((unsigned)off * 4u) & ~X3_OOB & dbg_win) | ((unsigned)(v - 1) & X3_OOB) | dbg_oob;
             dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
     };
     auto load_b = [&](int kt) {
         const int k = kt * BKT + kq * 4;
-        const unsigned k4 = (unsigned)k * 4u, koob = ((unsigned)((int)(k < p.K) - 1) & X3_OOB) | dbg_oob;
+        // pre-split weights: K-step major, 64 bytes per row and step (pairs_index)
+        const unsigned k4 = pre ? (unsigned)kt * (unsigned)p.Ncol * 64u + (unsigned)kq * 16u : (unsigned)k * 4u;
+        const unsigned koob = ((unsigned)((int)(k < p.K) - 1) & X3_OOB) | dbg_oob;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)((bbase[i] + k4) | koob), 0, 0));
@@ -791,9 +794,16 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float *__re
     }
 }
 
-// The weight operand of the fp16-pair kernels, split once per launch instead of once per row tile:
-// element i of the [rows][K] operand -> fp16 h at 2 i + (i & ~3) ... i.e. quads of 4 consecutive k keep their 16 bytes:
-// [h0 h1 h2 h3 m0 m1 m2 m3] of w * 2^k (k from the weights' range).  TRANSPOSE: i runs over wt[c][rs][co].
+// The weight operand of the fp16-pair kernels, split once per launch instead of once per row tile, in the order the
+// kernel reads it: K-step major, [k/16][row][quad of 4 k][h0 h1 h2 h3 m0 m1 m2 m3] (fp16 h, m of w * 2^k, k from the
+// weights' range).  The 64 bytes a row contributes to one K-step sit next to the neighbouring rows' 64 bytes, so a
+// K-step's weight tile is one contiguous run of full cache lines (row-major fp32 weights give half-used lines whose
+// other half is needed a K-step later, after the L1 has been flushed by the activations).
+// Element (row j, k) lives at half-index pairs_index(j, k, rows).  TRANSPOSE: rows = c, k = rs * Cout + co.
+__device__ __forceinline__ long pairs_index(int j, int k, int rows) {
+    return ((((long)(k >> 4) * rows + j) * 4 + ((k >> 2) & 3)) * 8) + (k & 3);
+}
+
 template <bool TRANSPOSE>
 __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restrict__ w, const unsigned *__restrict__ amax,
                                                            _Float16 *__restrict__ planes, int Cout, int Cin, int RS) {
@@ -801,10 +811,12 @@ __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restri
     const long n = (long)Cout * RS * Cin;
     if (!TRANSPOSE) {
         const long step = (long)gridDim.x * blockDim.x;
+        const int K = RS * Cin;
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
             const float v = w[i] * sc;
             const _Float16 h = (_Float16)v;
-            const long q = (i >> 2) * 8 + (i & 3);
+            const int j = (int)(i / K);
+            const long q = pairs_index(j, (int)(i - (long)j * K), Cout);
             planes[q] = h;
             planes[q + 4] = (_Float16)(v - (float)h);
         }
@@ -823,8 +835,7 @@ __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restri
         if (c < Cin && co < Cout) {
             const float v = tile[tx][r] * sc;
             const _Float16 h = (_Float16)v;
-            const long i = ((long)c * RS + rs) * Cout + co;
-            const long q = (i >> 2) * 8 + (i & 3);
+            const long q = pairs_index(c, rs * Cout + co, Cin);
             planes[q] = h;
             planes[q + 4] = (_Float16)(v - (float)h);
         }
@@ -1433,6 +1444,11 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
+    if (p.b_pairs && p.amax_a && p.amax_b && !g_h2_off) {     // K-step-major pairs: K padded to whole steps
+        const long bytes = (long)rcf_cdiv(p.K, 16) * p.Ncol * 64;
+        if (bytes >= (1L << 31)) return RCF_EINVAL;
+        p.b_bytes = (int)bytes;
+    }
     p.dbg = g_x3_dbg;
     const bool strided = p.div > 1;
     int tile = g_x3_tile;
@@ -1515,7 +1531,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
 /* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
-    g_x3_dbg = v >= 0 ? (v >> 15) & 1 : 0;
+    g_x3_dbg = v >= 0 ? ((v >> 15) & 1) | ((v >> 17) & 2) : 0;     // 0x8000: loads off; 0x40000: activation loads from a 64 KB window
     g_h2_off = v >= 0 ? (v >> 17) & 1 : 0;     // 0x20000: bf16 triples even when the operand ranges are given
     g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
     g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
@@ -1621,6 +1637,11 @@ extern "C" int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsig
     return 0;
 }
 
+extern "C" size_t rcf_conv_weight_pairs_bytes(int Cout, int Cin, int R, int S) {
+    if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return 0;
+    return (size_t)rcf_cdiv(R * S * Cin, 16) * Cout * 64;
+}
+
 extern "C" int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w,
                                          void *planes, void *stream) {
     if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
@@ -1661,7 +1682,8 @@ extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y
 
 extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {
     if (check_shape(s) || !use_x3(2)) return 0;
-    return (size_t)s->Cout * s->R * s->S * s->Cin * sizeof(float);
+    // transposed fp32 weights, or their fp16 pairs with K = R*S*Cout padded to whole K-steps
+    return (size_t)rcf_cdiv(s->R * s->S * s->Cout, 16) * 16 * s->Cin * sizeof(float);
 }
 
 extern "C" int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,

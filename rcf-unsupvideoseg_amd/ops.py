@@ -158,7 +158,7 @@ def weight_pairs(w, amax_w):
     a uint8 buffer holding two fp16 planes"""
     _need_cuda(w)
     Cout, Cin, R, S = w.shape
-    planes = torch.empty(w.numel() * 4, dtype=torch.uint8, device=w.device)
+    planes = torch.empty(_lib.load().rcf_conv_weight_pairs_bytes(Cout, Cin, R, S), dtype=torch.uint8, device=w.device)
     call("rcf_conv_weight_pairs_f32", _p(weight_rsck(w)), Cout, Cin, R, S, _p(amax_w), _p(planes), _stream())
     return planes
 
@@ -516,14 +516,15 @@ def gemm_nt_batched(a, lda, a_strides, b, ldb, b_strides, out, ldc, c_strides, b
     return out
 
 
-def attention(qkv, B, T, nh, scale, out=None):
-    """fused softmax(scale q k^T) v for every image and head; qkv [B*T, 3*nh*64] -> [B*T, nh*64]"""
+def attention(qkv, B, T, nh, scale, out=None, amax=None):
+    """fused softmax(scale q k^T) v for every image and head; qkv [B*T, 3*nh*64] -> [B*T, nh*64].
+    amax: absmax(qkv) -> fp16-pair arithmetic (3 partial products instead of 6)"""
     _need_cuda(qkv)
     dim = qkv.shape[1] // 3
     if out is None:
         out = torch.empty((B * T, dim), dtype=torch.float32, device=qkv.device)
     call("rcf_attention_fwd_f32", _p(qkv), _row_pitch(qkv), _p(out), _row_pitch(out), B, T, nh, dim // nh, float(scale),
-         _stream())
+         _p(amax), _stream())
     return out
 
 

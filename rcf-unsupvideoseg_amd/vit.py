@@ -17,6 +17,8 @@ import torch.nn as nn
 from . import ops
 from .layers import Conv2d
 
+FP16_PAIRS = True      # fused attention on the fp16-pair arithmetic (operand range = absmax of qkv)
+
 
 class _Linear(nn.Module):
     """nn.Linear's parameters ([out, in] weight = the B[N][K] operand of rcf_gemm_nt_f32)"""
@@ -130,7 +132,8 @@ class VisionTransformer(nn.Module):
         if keep_qkv:
             self._last_qkv = qkv
         if not want_attn and hd == 64 and self.fused_attention:
-            return ops.attention(qkv, B, T, nh, a.scale), None           # scores never leave the chip (csrc/attention.hip)
+            # scores never leave the chip (csrc/attention.hip); fp16-pair arithmetic with the range of qkv
+            return ops.attention(qkv, B, T, nh, a.scale, amax=ops.absmax(qkv) if FP16_PAIRS else None), None
         Tp = (T + 3) // 4 * 4
         out = torch.empty((B * T, dim), dtype=torch.float32, device=h1.device)
         attn = torch.empty((B, nh, T, T), dtype=torch.float32, device=h1.device) if want_attn else None

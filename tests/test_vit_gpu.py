@@ -51,18 +51,20 @@ def test_gemm_layernorm_softmax_helpers(report):
     assert max(e_g, e_gelu, e_ln, e_sm) < 2e-5 and pad0 == 0.0 and ok_t
 
 
+@pytest.mark.parametrize("pairs,qscale", [(False, 1.5), (True, 1.5), (True, 3e-4), (True, 2e3)])
 @pytest.mark.parametrize("T", [97, 130, 257])
-def test_fused_attention_vs_float64(T, report):
-    """csrc/attention.hip against float64 softmax(q k^T / 8) v on random qkv (tails: T not a multiple of the 64-key /
-    128-query tiles)"""
+def test_fused_attention_vs_float64(T, pairs, qscale, report):
+    """csrc/attention.hip against float64 softmax(q k^T * scale) v on random qkv (tails: T not a multiple of the 64-key /
+    128-query tiles); bf16 triples, and fp16 pairs with operand magnitudes from 3e-4 to 2e3"""
     g = torch.Generator().manual_seed(T)
     B, nh, dim = 2, 6, 384
-    qkv = (torch.randn(B * T, 3 * dim, generator=g) * 1.5).to(DEV)
-    out = ops.attention(qkv, B, T, nh, 0.125).cpu().double()
+    qkv = (torch.randn(B * T, 3 * dim, generator=g) * qscale).to(DEV)
+    sc = 0.125 * (1.5 / qscale) ** 2                      # keeps the logits' spread the same
+    out = ops.attention(qkv, B, T, nh, sc, amax=ops.absmax(qkv) if pairs else None).cpu().double()
     q, k, v = (qkv.cpu().double().view(B, T, 3, nh, 64).permute(2, 0, 3, 1, 4)[i] for i in range(3))
-    ref = (torch.softmax(q @ k.transpose(-2, -1) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(B * T, dim)
+    ref = (torch.softmax(q @ k.transpose(-2, -1) * sc, dim=-1) @ v).transpose(1, 2).reshape(B * T, dim)
     e = float((out - ref).abs().max() / ref.abs().max())
-    report(f"fused attention T={T}: {e:.2e}")
+    report(f"fused attention T={T} {'fp16 pairs' if pairs else 'bf16 triples'} |qkv|~{qscale:g}: {e:.2e}")
     assert e < 2e-5
 
 
