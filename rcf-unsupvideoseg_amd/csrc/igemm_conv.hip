@@ -1354,9 +1354,18 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long step = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += step) {
-        f32x4 a = beta ? reinterpret_cast<const f32x4 *>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < splits; ++s) a += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
-        reinterpret_cast<f32x4 *>(dw)[i] = a;
+        // four independent chains keep four loads in flight; combined in a fixed order (deterministic)
+        f32x4 a0 = beta ? reinterpret_cast<const f32x4 *>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+        int s = 0;
+        for (; s + 3 < splits; s += 4) {
+            a0 += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
+            a1 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 1) * stride)[i];
+            a2 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 2) * stride)[i];
+            a3 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 3) * stride)[i];
+        }
+        for (; s < splits; ++s) a0 += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
+        reinterpret_cast<f32x4 *>(dw)[i] = (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -1808,8 +1817,10 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     RCF_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         const long n4 = p.split_stride / 4;
-        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)workspace, dw, n4,
+        // small weights: one wavefront per workgroup, so that the few thousand float4 spread over all CUs
+        const int bt = n4 < (1 << 17) ? 64 : 256;
+        const int blocks = (int)((n4 + bt - 1) / bt < 4096 ? (n4 + bt - 1) / bt : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(bt), 0, st, (const float *)workspace, dw, n4,
                            p.split_stride, pl.splitk, beta);
         RCF_LAUNCH_CHECK();
     }
