@@ -685,18 +685,58 @@ __device__ __forceinline__ void store_val(void *out, long i, long long a0, long 
     if (MODE == 0) reinterpret_cast<float2 *>(out)[i] = make_float2(fixed_to_float(a0), fixed_to_float(a1));
     else reinterpret_cast<float *>(out)[i] = fixed_to_float(a0);
 }
+// The per-iteration kernels take grid (frames, chunks): with the frame as the FASTEST grid index a frame's workgroups
+// all run on XCD frame % 8 (for 8 k frames per call), so its label values, lattice values and neighbour lists stay in
+// that XCD's 4 MB L2 from the splat through the blurs to the slice instead of being fetched by all eight.
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q, void *__restrict__ out) {
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const long Lf = Lt.L[f];
     const long fb = (long)f * Lt.E;
     const float *Qf = Q + (long)f * Lt.N * MLAB;
     const int wpb = blockDim.x >> 6;
-    // vertices per wavefront: 64 when lists are short (every lane owns one), 8 when they are long (the
-    // wavefront walks them one after another, so fewer per wavefront = more wavefronts in flight)
-    const int chunk = (Lt.E <= 4 * Lf) ? 64 : 8;
-    for (long v0 = ((long)blockIdx.x * wpb + (threadIdx.x >> 6)) * chunk; v0 < Lf; v0 += (long)gridDim.x * wpb * chunk) {
+    if (Lt.E > 4 * Lf) {
+        // Long lists (natural images: ~35 entries per vertex).  A list is two dependent memory round trips (its
+        // entries, then the label values they point to), so the kernel is bound by how many lists are in flight:
+        // four 16-lane groups per wavefront take one list each (lists of more than GROUP_LIST entries are left to
+        // the whole wavefront afterwards).
+        constexpr int GROUP_LIST = 128;
+        const int g = lane >> 4, sl = lane & 15;
+        const long nw = (long)gridDim.y * wpb, w = (long)blockIdx.y * wpb + (threadIdx.x >> 6);
+        for (long vb = w * 4; vb < Lf; vb += nw * 4) {         // vb is wavefront-uniform
+            const long v = vb + g;
+            int beg = 0, n = 0;
+            if (v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
+            const bool big = n > GROUP_LIST;
+            long long a0 = 0, a1 = 0;
+            if (!big) {
+#pragma unroll 2
+                for (int i = sl; i < n; i += 16) acc_entry<MODE>(Lt.csr[fb + beg + i], Qf, a0, a1);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {                   // sums inside the 16-lane group
+                a0 += __shfl_xor(a0, o, 64);
+                if (MODE == 0) a1 += __shfl_xor(a1, o, 64);
+            }
+            if (sl == 0 && v < Lf && !big) store_val<MODE>(out, fb + v, a0, a1);
+            unsigned long long bigm = __ballot(big && sl == 0);
+            while (bigm) {
+                const int j = __ffsll((long long)bigm) - 1;     // lane 16 * group of a long list
+                bigm &= bigm - 1;
+                const int bj = __shfl(beg, j, 64), nj = __shfl(n, j, 64);
+                long long b0 = 0, b1 = 0;
+                for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, b0, b1);
+                b0 = wave_sum_ll(b0);
+                if (MODE == 0) b1 = wave_sum_ll(b1);
+                if (lane == 0) store_val<MODE>(out, fb + vb + (j >> 4), b0, b1);
+            }
+        }
+        return;
+    }
+    // short lists (noise-like images: ~1 entry per vertex): 64 vertices per wavefront, every lane owns one
+    const int chunk = 64;
+    for (long v0 = ((long)blockIdx.y * wpb + (threadIdx.x >> 6)) * chunk; v0 < Lf; v0 += (long)gridDim.y * wpb * chunk) {
         const long v = v0 + lane;
         int beg = 0, n = 0;
         if (lane < chunk && v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
@@ -729,11 +769,11 @@ __device__ __forceinline__ void zero_of(float &v) { v = 0.f; }
 // one blur pass along `axis`: new = 1/4 n+ + 1/2 me + 1/4 n-, missing neighbour = 0.  T = float2 (labels) / float
 template <class T>
 __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T *__restrict__ in, T *__restrict__ out) {
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;
     const int nax2 = 2 * (Lt.pd + 1);
     const long Lf = Lt.L[f];
     const long fb = (long)f * Lt.E;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.x * blockDim.x) {
+    for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x) {
         const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb + v) * nax2 + 2 * axis);
         const T me = in[fb + v];
         T vp, vm;
@@ -747,8 +787,8 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T
 
 // build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
 __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float *__restrict__ z) {
-    const int f = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
     const long fb = (long)f * Lt.E;
     float sw = 0;
@@ -765,8 +805,8 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
                                                     int last, int write_map) {
-    const int f = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
     const int nax = Lt.pd + 1;
     const long fb = (long)f * Lt.E;
@@ -1014,11 +1054,11 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
 
 // homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
 int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
-    const dim3 gp(rcf_cdiv(L.N, 256), F);
+    const dim3 gp(F, rcf_cdiv(L.N, 256));                      // (frames, chunks): see splat_gather_kernel
     float *za = reinterpret_cast<float *>(L.val0), *zb = reinterpret_cast<float *>(L.val1);
-    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(4096, F), dim3(256), 0, st, L, (const float *)nullptr, (void *)za);
+    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(F, 4096), dim3(256), 0, st, L, (const float *)nullptr, (void *)za);
     for (int axis = 0; axis <= L.pd; axis++) {
-        hipLaunchKernelGGL(blur_kernel<float>, dim3(1024, F), dim3(256), 0, st, L, axis, (const float *)za, zb);
+        hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
     }
     hipLaunchKernelGGL(slice_norm_kernel, gp, dim3(256), 0, st, L, (const float *)za);
@@ -1029,9 +1069,9 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
 // tmp-free filter + Potts + softmax epilogue for one potential
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
                   int first, int last, int write_map, hipStream_t st) {
-    const dim3 gv(1024, F), gp(rcf_cdiv(L.N, 256), F);
+    const dim3 gv(F, 1024), gp(F, rcf_cdiv(L.N, 256));         // (frames, chunks): see splat_gather_kernel
     float2 *a = L.val0, *b = L.val1;
-    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(4096, F), dim3(256), 0, st, L, Q, (void *)a);
+    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a);
     for (int axis = 0; axis <= L.pd; axis++) {
         hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
         float2 *t = a; a = b; b = t;
