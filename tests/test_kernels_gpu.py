@@ -119,6 +119,32 @@ def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
         assert ei < max(4 * ri, 5e-7)
 
 
+def test_conv_fp16_pairs_range_edges(report):
+    """operand ranges at the edges: an all-zero tensor (range 0 -> scale 1, exact zeros out), magnitudes spread
+    log-uniformly over 30 binary orders (elements far below the tensor's maximum lose bits, but only at 2^-39 of the
+    maximum: the error relative to the output stays at fp32 level), and a range that is an upper bound 2^10 too large"""
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, H, W = 2, 128, 256, 17, 23
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    wg = cl_weight(w)
+    aw = ops.absmax(ops.weight_rsck(wg))
+    z = torch.zeros(N, H, W, Cin, device=DEV)
+    yz = ops.conv2d_fwd(z, wg, None, 1, 1, 1, amax=(ops.absmax(z), aw))
+    assert float(yz.abs().max()) == 0.0
+    mag = torch.exp2(-30 * torch.rand(N, Cin, H, W, generator=g))
+    x = torch.randn(N, Cin, H, W, generator=g) * mag
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1, 1)
+    xg = to_nhwc(x)
+    y = ops.conv2d_fwd(xg, wg, None, 1, 1, 1, amax=(ops.absmax(xg), aw))
+    e_spread = float(((from_nhwc(y).double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    loose = (ops.absmax(xg).view(torch.float32) * 1024.0).view(torch.int32)          # a valid, needlessly large bound
+    y2 = ops.conv2d_fwd(xg, wg, None, 1, 1, 1, amax=(loose, aw))
+    e_loose = float(((from_nhwc(y2).double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    report(f"conv fp16 pairs range edges: zero tensor exact, 30 binary orders of magnitude rms {e_spread:.2e}, "
+           f"range 2^10 too large rms {e_loose:.2e}")
+    assert e_spread < 1e-6 and e_loose < 1e-6
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_conv_kernel_variants(variant, report):
     """the tuning variants of the implicit-GEMM kernel (K-step 16/32, K-major / row-major LDS) agree"""
