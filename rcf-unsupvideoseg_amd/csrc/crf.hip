@@ -55,7 +55,18 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *slot_vid2;              // [F][2E]  bucket -> dense vertex id (-1 empty)
     int *slot_off;               // [F][2E]  bucket -> CSR offset
     int *blocksum2;              // [F][2][nblk2+1]
+    // The table is first tried with `cap_small` buckets (a natural 480x854 frame has ~7e4 distinct keys: the table
+    // then stays in the frame's L2 and the bucket scans are short); a frame that fills more than half of them, or
+    // needs a probe longer than PK_PROBE_LIMIT, is inserted again into all 2E buckets.
+    int cap_small;
+    int *stat;                   // [F][2]  distinct keys of the small attempt, probe-limit flag
 };
+
+constexpr int PK_PROBE_LIMIT = 256;
+__device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
+    return (long)Lt.cap_small < 2 * Lt.E && (Lt.stat[2 * f] > Lt.cap_small / 2 || Lt.stat[2 * f + 1] != 0);
+}
+__device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : (long)Lt.cap_small; }
 
 __device__ __forceinline__ unsigned key_hash(const short *key, int pd) {
     unsigned k = 0;
@@ -464,12 +475,41 @@ __device__ __forceinline__ void unpack64(unsigned long long k, int pd, short *ke
     for (int i = 0; i < pd; i++) key[i] = (short)((int)((k >> (12 * i)) & 0xfffu) - 2048);
 }
 
+// buckets [0, n) of every frame's table <- empty (phase 0: n = cap_small and the attempt's statistics are reset;
+// phase 1: n = 2E, only for the frames whose small attempt overflowed)
+__global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
+    const int f = blockIdx.x;
+    long n = Lt.cap_small;
+    if (phase == 1) {
+        if (!pk_overflowed(Lt, f)) return;
+        n = 2 * Lt.E;
+    } else if (blockIdx.y == 0 && threadIdx.x < 2) {
+        Lt.stat[2 * f + threadIdx.x] = 0;            // read by nobody before the insert kernel that follows
+    }
+    unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
+    unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
+    for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
+        table[i] = PK_EMPTY;
+        cursor[i] = 0u;
+    }
+}
+
 __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W,
-                                                                   int H, float posdev, float featdev) {
+                                                                   int H, float posdev, float featdev, int phase) {
     __shared__ unsigned long long lkey[LT_SLOTS];
     __shared__ unsigned lcnt[LT_SLOTS], lgs[LT_SLOTS], lbase[LT_SLOTS];
+    __shared__ int newkeys, skip;
     const int pd = Lt.pd, nax = pd + 1;
     const int f = blockIdx.y;
+    const bool small = phase == 0 && (long)Lt.cap_small < 2 * Lt.E;      // an attempt that may overflow
+    if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
+    if (threadIdx.x == 0) {
+        newkeys = 0;
+        // the attempt already failed for this frame: nothing this workgroup inserts will be used
+        skip = small && __hip_atomic_load(Lt.stat + 2 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
+    __syncthreads();
+    if (skip) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < Lt.N;
     for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) { lkey[i] = PK_EMPTY; lcnt[i] = 0u; }
@@ -499,23 +539,36 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     // the block's distinct keys: insert into the frame's table, reserve the block's share of the vertex's list
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
     unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
-    const unsigned nb = (unsigned)(2 * Lt.E);
+    const unsigned nb = phase == 0 ? (unsigned)min((long)Lt.cap_small, 2 * Lt.E) : (unsigned)(2 * Lt.E);
+    int mine = 0;
     for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) {
         const unsigned long long k = lkey[i];
         if (k == PK_EMPTY) continue;
         short key[PD_MAX];
         unpack64(k, pd, key);
         unsigned h = key_hash(key, pd) % nb;
+        int probes = 0;
+        bool placed = true;
         for (;;) {
             unsigned long long cur = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == PK_EMPTY) cur = atomicCAS(table + h, PK_EMPTY, k);
+            if (cur == PK_EMPTY) {
+                cur = atomicCAS(table + h, PK_EMPTY, k);
+                if (cur == PK_EMPTY) ++mine;
+            }
             if (cur == PK_EMPTY || cur == k) break;
             if (++h == nb) h = 0;
+            if (small && ++probes > PK_PROBE_LIMIT) {          // the small table is too full: the frame is redone
+                atomicExch(Lt.stat + 2 * f + 1, 1);
+                placed = false;
+                break;
+            }
         }
         lgs[i] = h;
-        lbase[i] = atomicAdd(cursor + h, lcnt[i]);
+        lbase[i] = placed ? atomicAdd(cursor + h, lcnt[i]) : 0u;
     }
+    if (small && mine) atomicAdd(&newkeys, mine);
     __syncthreads();
+    if (small && threadIdx.x == 0 && newkeys) atomicAdd(Lt.stat + 2 * f, newkeys);
     if (live) {
         const long base = (long)f * Lt.E + p;
         for (int r = 0; r < nax; r++) {
@@ -530,9 +583,17 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
 // exclusive scans over the table's buckets: vertex numbering (occupied flag) and CSR offsets (entry counts)
 __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt) {
     const int f = blockIdx.y;
-    const long S = 2 * Lt.E;
+    const long SS = 2 * Lt.E, S = pk_buckets(Lt, f);          // frame stride of the bucket arrays, buckets in use
+    if ((long)blockIdx.x * SCAN_TILE >= S) {                   // past the table in use: empty tile
+        if (threadIdx.x == 0) {
+            int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
+            bs[blockIdx.x] = 0;
+            bs[gridDim.x + 1 + blockIdx.x] = 0;
+        }
+        return;
+    }
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
-    const unsigned *cursor = Lt.cursor + (long)f * S;
+    const unsigned *cursor = Lt.cursor + (long)f * SS;
     int fl[SCAN_ITEMS], cn[SCAN_ITEMS], sf = 0, sc = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
@@ -545,7 +606,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt) {
     int tf, tc;
     int of = block_exclusive_scan(sf, &tf);
     int oc = block_exclusive_scan(sc, &tc);
-    int *sv = Lt.slot_vid2 + (long)f * S, *so = Lt.slot_off + (long)f * S;
+    int *sv = Lt.slot_vid2 + (long)f * SS, *so = Lt.slot_off + (long)f * SS;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         const long b = base + i;
@@ -586,11 +647,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_blocks_kernel(Lattice Lt, 
 }
 __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
     const int f = blockIdx.y;
-    const long S = 2 * Lt.E;
+    const long SS = 2 * Lt.E, S = pk_buckets(Lt, f);
+    if ((long)blockIdx.x * SCAN_TILE >= S) return;
     const int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
     const int addf = bs[blockIdx.x], addc = bs[gridDim.x + 1 + blockIdx.x];
-    int *sv = Lt.slot_vid2 + (long)f * S, *so = Lt.slot_off + (long)f * S;
-    const unsigned *cursor = Lt.cursor + (long)f * S;
+    int *sv = Lt.slot_vid2 + (long)f * SS, *so = Lt.slot_off + (long)f * SS;
+    const unsigned *cursor = Lt.cursor + (long)f * SS;
     const long fb = (long)f * Lt.E;
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
@@ -610,8 +672,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
 }
 // entry -> (vertex id, CSR slot): a streaming pass, no atomics
 __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
+    const long idx = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
     if (idx >= Lt.E) return;
     const long fb = (long)f * Lt.E, S = 2 * Lt.E;
     const int b = Lt.vid[fb + idx];
@@ -622,15 +684,15 @@ __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
     Lt.vid[fb + idx] = v;
 }
 __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;
     const int pd = Lt.pd, nax = pd + 1;
     const long Lf = Lt.L[f], S = 2 * Lt.E;
     const unsigned long long *table = Lt.table + (long)f * S;
     const int *sv = Lt.slot_vid2 + (long)f * S;
     int *nb = Lt.nb + (long)f * Lt.E * 2 * nax;
-    const unsigned nbk = (unsigned)S;
+    const unsigned nbk = (unsigned)pk_buckets(Lt, f);          // the modulus the insert used
     const long total = Lf * nax;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
         const long v = i / nax;
         const int axis = (int)(i - v * nax);
         short key[8];
@@ -967,6 +1029,8 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
     L.slot_vid2 = c.take<int>(2 * FE);
     L.slot_off = c.take<int>(2 * FE);
     L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
+    L.stat = c.take<int>((size_t)F * 2);
+    L.cap_small = 0;
 }
 
 struct CrfBuffers {
@@ -991,7 +1055,8 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
-int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build
+int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build,
+                           // 2: packed build whose first-attempt table is tiny (exercises the overflow path)
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
 
 // bound on |key coordinate| (see lattice_point): elevated[i] in [-i*cf_i, sum_j cf_j], keys within pd+1 of it
@@ -1009,17 +1074,24 @@ bool keys_fit_12bit(int pd, int W, int H, float posdev, float featdev) {
 
 int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev,
                          hipStream_t st) {
-    const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
+    const dim3 gp(rcf_cdiv(L.N, 256), F), ge(F, rcf_cdiv(L.E, 256));       // ge: (frames, chunks), frame = XCD
     const int nblk2 = scan_blocks(2 * L.E);
-    CK(hipMemsetAsync(L.table, 0xff, (size_t)F * 2 * L.E * sizeof(unsigned long long), st));
-    CK(hipMemsetAsync(L.cursor, 0, (size_t)F * 2 * L.E * sizeof(unsigned), st));
-    hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev);
+    // first attempt: 2^18 - 1 buckets (3 MB of keys + cursors per frame, room for 131 k distinct keys; measured at
+    // 480x854, T=5: 2^21 0.388, 2^19 0.371, 2^18 0.361 ms/frame); g_crf_variant 2 forces a tiny table (tests)
+    const long small = g_crf_variant == 2 ? 1021 : ((1L << 18) - 1);
+    L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
+    hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
+    hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev, 0);
+    if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
+        hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
+        hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev, 1);
+    }
     hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_fill_kernel, ge, dim3(256), 0, st, L);
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
-    hipLaunchKernelGGL(pk_neighbours_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(pk_neighbours_kernel, dim3(F, 2048), dim3(256), 0, st, L);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1029,7 +1101,7 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     L.w = weight;
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
-    if (g_crf_variant == 0 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
+    if (g_crf_variant != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
         if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) return e;
         return build_lattice_norm(L, F, st);
     }

@@ -89,7 +89,8 @@ def test_crf_invariants_fullsize(report):
 
 
 def test_crf_build_variants_identical(report):
-    """the packed 64-bit-key lattice build (default) and the array-of-keys build give the same MAP, Q and vertex count"""
+    """the packed 64-bit-key lattice build (default; small table first, all buckets after an overflow) and the
+    array-of-keys build give the same MAP, Q and vertex count"""
     from rcf_amd import _lib, synth
     from rcf_amd.crf import crf_soft_batched
     H, W = 120, 214
@@ -99,15 +100,16 @@ def test_crf_build_variants_identical(report):
     rgb, unary = head.prepare(imgs, masks)
     out = {}
     try:
-        for v in (0, 1):
+        for v in (0, 1, 2):                      # 2: a 1024-bucket first attempt, so every frame takes the overflow path
             _lib.load().rcf_crf_set_variant(v)
             out[v] = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 5, want_q=True, want_nvert=True)
     finally:
         _lib.load().rcf_crf_set_variant(0)
-    same_map = bool(torch.equal(out[0][0], out[1][0]))
-    dq = float((out[0][1] - out[1][1]).abs().max())
-    report(f"crf build variants: MAP identical {same_map}, max |dQ| {dq:.2e}, vertices {out[0][2][:, 1].tolist()} vs {out[1][2][:, 1].tolist()}")
-    assert same_map and dq == 0.0 and torch.equal(out[0][2], out[1][2])
+    same_map = bool(torch.equal(out[0][0], out[1][0])) and bool(torch.equal(out[0][0], out[2][0]))
+    dq = max(float((out[0][1] - out[1][1]).abs().max()), float((out[0][1] - out[2][1]).abs().max()))
+    report(f"crf build variants: MAP identical {same_map}, max |dQ| {dq:.2e}, vertices {out[0][2][:, 1].tolist()} vs "
+           f"{out[1][2][:, 1].tolist()} vs {out[2][2][:, 1].tolist()} (packed / array-of-keys / packed after a table overflow)")
+    assert same_map and dq == 0.0 and torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out[2][2])
 
 
 def test_offline_callers(report):
