@@ -259,8 +259,8 @@ def vit_bench(torch, rcf_amd, synth, dev, frames=4):
     feats = m.get_last_qkv(x[:1], "k")
     mask = (torch.rand(60, 107, device=dev) > 0.5).float() * 0.8 + 0.1
     t_nc = timeit(lambda: ncut.ncut_refine(feats, mask, steps=10, learning_rate=0.45))
-    return {"workload": f"DINO ViT-S/8 forward at 480x856 ({frames} frames per call, 6421 tokens, 12 blocks, fused attention, "
-                        "fp32 on split-bf16 MFMA) + soft NCut (6420^2 affinity, 10 Adam steps)", "vit_ms_per_frame": round(t_fwd * 1e3, 2),
+    return {"workload": f"DINO ViT-S/8 forward at 480x856 ({frames} frames per call, 6421 tokens, 12 blocks, fused attention and "
+                        "linear layers on fp16 pairs: fp32-level error) + soft NCut (6420^2 affinity, 10 Adam steps)", "vit_ms_per_frame": round(t_fwd * 1e3, 2),
             "vit_gflop_per_frame": round(gf, 1), "vit_tflops": round(gf / 1e3 / t_fwd, 1),
             "ncut_refine_ms_per_frame": round(t_nc * 1e3, 2)}
 

@@ -300,9 +300,13 @@ int rcf_fill_f32(float *p, long n, float v, void *stream);
  * models/dino_vit.py:110-167,176-276 (nn.Linear / attention products, LayerNorm eps 1e-6, softmax, GELU) and
  * tools/SemanticConstraintsAndMAA/semantic_constraints.py:21-75 (soft NCut value, Adam refinement of the mask). */
 /* C[M][N] (pitch ldc) (+)= A[M][K] (pitch lda) . B[N][K]^T (pitch ldb) + bias[N]; act 0 none / 1 LeakyReLU / 2 GELU(erf).
- * Runs on the split-bf16 conv kernel (fp32 accuracy).  K, lda, ldb, ldc multiples of 4. */
+ * Runs on the implicit-GEMM conv kernel (fp32-level error).  K, lda, ldb, ldc multiples of 4.
+ * amax_a / amax_b (both or neither; may be NULL): operand ranges -> fp16 pairs instead of bf16 triples (rcf_conv_shape);
+ * b_pairs (may be NULL): B already split by rcf_conv_weight_pairs_f32(B, N, K, 1, 1, amax_b, ...), needs ldb == K;
+ * amax_out (may be NULL): amax_out[0] = max(amax_out[0], bits(max |C written|)) -- the range of whatever reads C next. */
 int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
-                    int K, int act, float slope, int beta, void *stream);
+                    int K, int act, float slope, int beta, const unsigned *amax_a, const unsigned *amax_b,
+                    const void *b_pairs, unsigned *amax_out, void *stream);
 /* batch0 x batch1 independent products in one launch (attention: images x heads); strides in elements */
 int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const float *B, int ldb, long b_s0, long b_s1,
                             float *C, int ldc, long c_s0, long c_s1, int batch0, int batch1, int M, int N, int K, int act,
@@ -310,11 +314,12 @@ int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long a_s1, const
 /* fused multi-head attention forward (scores stay on chip): out[b*T+t][h*64+d] = softmax_j(scale q_t.k_j) v_j[d];
  * qkv [B*T][3*nh*64] (q | k | v) as produced by the fused qkv linear (models/dino_vit.py:122-133).  head_dim = 64. */
 int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh, int head_dim,
-                          float scale, const unsigned *amax_qkv, void *stream);
-/* amax_qkv: max |qkv| (rcf_absmax_f32) -> fp16-pair arithmetic (q, k, v scaled by one power of two, probabilities by
- * 2^14, 3 partial products); NULL -> bf16 triples (6) */
+                          float scale, const unsigned *amax_qkv, unsigned *amax_out, void *stream);
+/* amax_qkv: max |qkv| (rcf_absmax_f32, or the amax_out of the qkv GEMM) -> fp16-pair arithmetic (q, k, v scaled by one
+ * power of two, probabilities by 2^14, 3 partial products); NULL -> bf16 triples (6).  amax_out (may be NULL): the
+ * range of `out`. */
 int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C, const float *gamma,
-                      const float *beta, float eps, void *stream);
+                      const float *beta, float eps, unsigned *amax_out, void *stream);
 /* in place: row <- softmax(scale * row[0:n]); columns [n, pitch) are zeroed */
 int rcf_softmax_rows_f32(float *s, long pitch, long rows, int n, float scale, void *stream);
 /* dst[c][r] = src[r][c]; dst columns [rows, dpitch) zero-filled */

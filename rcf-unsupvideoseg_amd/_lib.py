@@ -50,11 +50,12 @@ PROTOS = {
     "rcf_conv2d_wgrad_region_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv_regions_available": (c_int, []),
-    "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, P,
+                                P]),
     "rcf_gemm_nt_batched_f32": (c_int, [P, c_int, c_long, c_long, P, c_int, c_long, c_long, P, c_int, c_long, c_long, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
-    "rcf_attention_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
-    "rcf_layernorm_f32": (c_int, [P, c_int, P, c_int, c_long, c_int, P, P, c_float, P]),
+    "rcf_attention_fwd_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P]),
+    "rcf_layernorm_f32": (c_int, [P, c_int, P, c_int, c_long, c_int, P, P, c_float, P, P]),
     "rcf_softmax_rows_f32": (c_int, [P, c_long, c_long, c_int, c_float, P]),
     "rcf_transpose2d_f32": (c_int, [P, c_long, P, c_long, c_int, c_int, P]),
     "rcf_l2_normalize_rows_f32": (c_int, [P, c_long, P, c_long, c_long, c_int, P]),

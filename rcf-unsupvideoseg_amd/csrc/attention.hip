@@ -113,6 +113,7 @@ struct AttnParams {
     int T, nh, ld, ldo; // tokens per image, heads, row pitches of qkv / out
     float scale;
     const unsigned *amax;   // fp16 pairs: max |qkv| (raw bits); null on the bf16-triple instance
+    unsigned *amax_out;     // optional: max |out| (the range of the projection GEMM that reads it)
 };
 
 template <int NP>
@@ -293,14 +294,22 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
     if (hs == 0) rowv[wave][l31] = (NP == 2 ? pow2f(-kx - 14) : 1.0f) / l_run;      // undo the scales of P and V
     __builtin_amdgcn_wave_barrier();
     float *ob = p.out + (long)b * p.T * p.ldo + head * HD;
+    unsigned omax = 0u;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hs;
         const int q = q0 + r;
         if (q >= p.T) continue;
         const float inv = rowv[wave][r];
-        ob[(long)q * p.ldo + l31] = oacc[0][e] * inv;
-        ob[(long)q * p.ldo + 32 + l31] = oacc[1][e] * inv;
+        const float o0 = oacc[0][e] * inv, o1 = oacc[1][e] * inv;
+        ob[(long)q * p.ldo + l31] = o0;
+        ob[(long)q * p.ldo + 32 + l31] = o1;
+        omax = max(omax, max(__float_as_uint(fabsf(o0)), __float_as_uint(fabsf(o1))));
+    }
+    if (p.amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o));
+        if (lane == 0 && omax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, omax);
     }
 }
 
@@ -309,11 +318,12 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
 /* out[b*T + t][h*64 + d] = sum_j softmax_j(scale * q_t . k_j) v_j[d] for every image b and head h; qkv is the output of
  * the fused qkv linear ([B*T][3*nh*64], q | k | v).  Head dimension 64 (every DINO ViT). */
 extern "C" int rcf_attention_fwd_f32(const float *qkv, int ld_qkv, float *out, int ld_out, int B, int T, int nh,
-                                     int head_dim, float scale, const unsigned *amax_qkv, void *stream) {
+                                     int head_dim, float scale, const unsigned *amax_qkv, unsigned *amax_out,
+                                     void *stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || nh <= 0 || head_dim != HD) return RCF_EINVAL;
     if (ld_qkv % 4 || ld_out % 4 || ld_qkv < 3 * nh * HD || ld_out < nh * HD || !rcf_aligned16(qkv) || !rcf_aligned16(out)) return RCF_EINVAL;
     if ((long)B * nh > 65535) return RCF_EINVAL;
-    AttnParams p{qkv, out, T, nh, ld_qkv, ld_out, scale, amax_qkv};
+    AttnParams p{qkv, out, T, nh, ld_qkv, ld_out, scale, amax_qkv, amax_out};
     const dim3 grid(rcf_cdiv(T, BQ), B * nh);
     if (amax_qkv) hipLaunchKernelGGL(attention_fwd_kernel<2>, grid, dim3(256), 0, rcf_stream(stream), p);   // fp16 pairs
     else hipLaunchKernelGGL(attention_fwd_kernel<3>, grid, dim3(256), 0, rcf_stream(stream), p);

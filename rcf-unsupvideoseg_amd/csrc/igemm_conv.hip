@@ -65,6 +65,7 @@ struct IgemmParams {
     // a row [Ncol][ldb/4][h0 h1 h2 h3 m0 m1 m2 m3] (the fp32 layout's addresses); null = fp32 weights in Bw, split on
     // the way into LDS
     const void *b_pairs;
+    unsigned *amax_out;           // optional: max |value written| (raw bits, atomicMax): the range of the next consumer
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -708,6 +709,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const bool want_stats = !DGRAD && p.stats != nullptr;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     float bv[NR];
+    unsigned omax = 0u;          // max |value written| by this lane (p.amax_out)
     float csum[NR], csq[NR];     // this lane's 16 MR values of a column in fp32; everything above that in fp64
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
@@ -741,12 +743,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (erf form)
                 if (p.beta) v += drow[nr * 32];
                 drow[nr * 32] = v;
+                omax = max(omax, __float_as_uint(fabsf(v)));
                 if (want_stats) {
                     csum[nr] += v;
                     csq[nr] = fmaf(v, v, csq[nr]);
                 }
             }
         }
+    }
+    if (p.amax_out) {                                         // block-uniform
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o));
+        // most wavefronts find the scalar already at least as large: a plain load first keeps the atomics few
+        if (lane == 0 && omax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, omax);
     }
     if (want_stats) {                                         // block-uniform
         // column sums of this row tile: lane halves by shuffle, the WM waves of a column through LDS, fixed order
@@ -1572,7 +1581,8 @@ int set_region(IgemmParams &p, const rcf_conv_region *r, int N, int H, int W) {
  * 2 GELU): nn.Linear / attention products of the DINO ViT (models/dino_vit.py:110-134) on the split-bf16 conv
  * kernel -- a 1x1 convolution whose "pixels" are the M rows. */
 extern "C" int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
-                               int M, int N, int K, int act, float slope, int beta, void *stream) {
+                               int M, int N, int K, int act, float slope, int beta, const unsigned *amax_a,
+                               const unsigned *amax_b, const void *b_pairs, unsigned *amax_out, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || ldc % 4) return RCF_EINVAL;
     if (lda < K || ldb < K || ldc < N || !rcf_aligned16(A) || !rcf_aligned16(B) || !rcf_aligned16(C)) return RCF_EINVAL;
     if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29)) return RCF_EINVAL;      // 32-bit descriptor offsets
@@ -1585,6 +1595,10 @@ extern "C" int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb,
     p.a_pitch = lda; p.a_img_stride = (long)M * lda; p.y_pitch = ldc;
     p.ldb = ldb; p.act = act; p.slope = slope; p.beta = beta;
     p.ry0 = 0; p.rx0 = 0; p.rh = M; p.rw = 1; p.rband = 0; p.rr = M;
+    // operand ranges -> fp16-pair kernels; B already split (rcf_conv_weight_pairs_f32 with Cout = N, Cin = K, R = S = 1)
+    // needs the plain layout it was made from (ldb == K)
+    if (b_pairs && ldb != K) return RCF_EINVAL;
+    p.amax_a = amax_a; p.amax_b = amax_b; p.b_pairs = (amax_a && amax_b) ? b_pairs : nullptr; p.amax_out = amax_out;
     return launch_igemm_x3(p, rcf_stream(stream));
 }
 

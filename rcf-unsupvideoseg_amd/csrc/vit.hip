@@ -20,10 +20,12 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // y[r][c] = (x[r][c] - mean_r) * rstd_r * gamma[c] + beta[c]; one wavefront per row, two-pass in registers (C <= 2048)
 __global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict__ x, int x_pitch, float *__restrict__ y,
                                                         int y_pitch, long rows, int C, const float *__restrict__ gamma,
-                                                        const float *__restrict__ beta, float eps) {
+                                                        const float *__restrict__ beta, float eps,
+                                                        unsigned *__restrict__ amax_out) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
+    unsigned omax = 0u;
     const float *xr = x + r * x_pitch;
     const int nq = C / 4;                         // float4 per row; lane handles quads lane, lane+64, ... (<= 8)
     f32x4 q[8];
@@ -50,8 +52,16 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict_
         const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + i * 4), b = *reinterpret_cast<const f32x4 *>(beta + i * 4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (q[k][e] - mean) * rstd * g[e] + b[e];
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (q[k][e] - mean) * rstd * g[e] + b[e];
+            omax = max(omax, __float_as_uint(fabsf(o[e])));
+        }
         *reinterpret_cast<f32x4 *>(yr + i * 4) = o;
+    }
+    if (amax_out) {            // the range of the GEMM that reads y (rcf_gemm_nt_f32's amax_a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o));
+        if (lane == 0 && omax > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, omax);
     }
 }
 
@@ -223,10 +233,10 @@ __global__ void __launch_bounds__(256) clamp01_kernel(float *__restrict__ x, int
 }  // namespace
 
 extern "C" int rcf_layernorm_f32(const float *x, int x_pitch, float *y, int y_pitch, long rows, int C,
-                                 const float *gamma, const float *beta, float eps, void *stream) {
+                                 const float *gamma, const float *beta, float eps, unsigned *amax_out, void *stream) {
     if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 4 || C > 2048 || x_pitch % 4 || y_pitch % 4) return RCF_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)rcf_cdiv(rows, 4)), dim3(256), 0, rcf_stream(stream), x, x_pitch, y,
-                       y_pitch, rows, C, gamma, beta, eps);
+                       y_pitch, rows, C, gamma, beta, eps, amax_out);
     RCF_LAUNCH_CHECK();
     return 0;
 }

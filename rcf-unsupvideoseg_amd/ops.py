@@ -494,17 +494,30 @@ def _row_pitch(t):
     return t.stride(0)
 
 
-def gemm_nt(a, b, bias=None, out=None, act=0, beta=0):
-    """out[M,N] (+)= a[M,K] @ b[N,K]^T + bias, act 0 none / 2 GELU.  a, b, out: row-major 2-D views (rows may be pitched)."""
+def gemm_nt(a, b, bias=None, out=None, act=0, beta=0, amax=None, b_pairs=None, amax_out=None):
+    """out[M,N] (+)= a[M,K] @ b[N,K]^T + bias, act 0 none / 2 GELU.  a, b, out: row-major 2-D views (rows may be pitched).
+    amax = (range of a, range of b) -> fp16-pair arithmetic; b_pairs: b split beforehand (weight_pairs_2d);
+    amax_out: int32 [1] that receives the range of what is written"""
     _need_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K
     if out is None:
         out = torch.empty((M, (N + 3) // 4 * 4), dtype=torch.float32, device=a.device)[:, :N]
+    aa, ab = amax if amax is not None else (None, None)
     call("rcf_gemm_nt_f32", _p(a), _row_pitch(a), _p(b), _row_pitch(b), _p(bias), _p(out), _row_pitch(out), M, N, K,
-         int(act), 0.0, int(beta), _stream())
+         int(act), 0.0, int(beta), _p(aa), _p(ab), _p(b_pairs), _p(amax_out), _stream())
     return out
+
+
+def weight_pairs_2d(w, amax_w):
+    """weight_pairs for an nn.Linear weight [out, in] (contiguous): the B operand of gemm_nt, split once"""
+    _need_cuda(w)
+    N, K = w.shape
+    assert w.is_contiguous() and K % 4 == 0
+    planes = torch.empty(_lib.load().rcf_conv_weight_pairs_bytes(N, K, 1, 1), dtype=torch.uint8, device=w.device)
+    call("rcf_conv_weight_pairs_f32", _p(w), N, K, 1, 1, _p(amax_w), _p(planes), _stream())
+    return planes
 
 
 def gemm_nt_batched(a, lda, a_strides, b, ldb, b_strides, out, ldc, c_strides, batch, M, N, K, beta=0):
@@ -516,7 +529,7 @@ def gemm_nt_batched(a, lda, a_strides, b, ldb, b_strides, out, ldc, c_strides, b
     return out
 
 
-def attention(qkv, B, T, nh, scale, out=None, amax=None):
+def attention(qkv, B, T, nh, scale, out=None, amax=None, amax_out=None):
     """fused softmax(scale q k^T) v for every image and head; qkv [B*T, 3*nh*64] -> [B*T, nh*64].
     amax: absmax(qkv) -> fp16-pair arithmetic (3 partial products instead of 6)"""
     _need_cuda(qkv)
@@ -524,17 +537,17 @@ def attention(qkv, B, T, nh, scale, out=None, amax=None):
     if out is None:
         out = torch.empty((B * T, dim), dtype=torch.float32, device=qkv.device)
     call("rcf_attention_fwd_f32", _p(qkv), _row_pitch(qkv), _p(out), _row_pitch(out), B, T, nh, dim // nh, float(scale),
-         _p(amax), _stream())
+         _p(amax), _p(amax_out), _stream())
     return out
 
 
-def layernorm(x, gamma, beta, eps, out=None):
+def layernorm(x, gamma, beta, eps, out=None, amax_out=None):
     _need_cuda(x)
     rows, C = x.shape
     if out is None:
         out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     call("rcf_layernorm_f32", _p(x), _row_pitch(x), _p(out), _row_pitch(out), rows, C, _p(gamma), _p(beta), float(eps),
-         _stream())
+         _p(amax_out), _stream())
     return out
 
 

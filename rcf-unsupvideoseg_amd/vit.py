@@ -123,17 +123,34 @@ class VisionTransformer(nn.Module):
         torch.add(tok.view(B, npatch, dim), pos[1:], out=X[:, 1:])
         return X.view(B * T, dim), B, T
 
-    def _attention(self, blk, h1, B, T, want_attn=False, keep_qkv=False):
-        """h1 [B*T, dim] (already normalised) -> attention output [B*T, dim] before the projection"""
+    def _linear(self, lin, x, x_range, **kw):
+        """x @ W^T + b on the fp16-pair kernels when the range of x is known: the (frozen) weight's range and its
+        fp16-pair split are made once and kept until the parameter changes"""
+        if not FP16_PAIRS or x_range is None:
+            return ops.gemm_nt(x, lin.weight, lin.bias, **kw)
+        w = lin.weight
+        key = (w.data_ptr(), w._version)
+        c = getattr(lin, "_pairs_cache", None)
+        if c is None or c[0] != key:
+            rw = ops.absmax(w.detach())
+            c = lin._pairs_cache = (key, rw, ops.weight_pairs_2d(w.detach(), rw))
+        return ops.gemm_nt(x, w, lin.bias, amax=(x_range, c[1]), b_pairs=c[2], **kw)
+
+    def _attention(self, blk, h1, B, T, want_attn=False, keep_qkv=False, h1_range=None):
+        """h1 [B*T, dim] (already normalised) -> (attention output [B*T, dim] before the projection, attention maps or
+        None, the output's range or None)"""
         dim, nh = self.embed_dim, self.num_heads
         hd = dim // nh
         a = blk.attn
-        qkv = ops.gemm_nt(h1, a.qkv.weight, a.qkv.bias)                                             # [B*T, 3 dim]
+        r_qkv = ops.new_amax(h1.device) if FP16_PAIRS else None
+        qkv = self._linear(a.qkv, h1, h1_range, amax_out=r_qkv)                                     # [B*T, 3 dim]
         if keep_qkv:
             self._last_qkv = qkv
         if not want_attn and hd == 64 and self.fused_attention:
-            # scores never leave the chip (csrc/attention.hip); fp16-pair arithmetic with the range of qkv
-            return ops.attention(qkv, B, T, nh, a.scale, amax=ops.absmax(qkv) if FP16_PAIRS else None), None
+            # scores never leave the chip (csrc/attention.hip); fp16-pair arithmetic with the range of qkv, which the
+            # qkv GEMM's epilogue left behind
+            r_o = ops.new_amax(h1.device) if FP16_PAIRS else None
+            return ops.attention(qkv, B, T, nh, a.scale, amax=r_qkv, amax_out=r_o), None, r_o
         Tp = (T + 3) // 4 * 4
         out = torch.empty((B * T, dim), dtype=torch.float32, device=h1.device)
         attn = torch.empty((B, nh, T, T), dtype=torch.float32, device=h1.device) if want_attn else None
@@ -151,17 +168,21 @@ class VisionTransformer(nn.Module):
             Vt = torch.stack([ops.transpose2d(rows[i * T:(i + 1) * T, 2 * dim:], Tp) for i in range(nb)])   # [nb, dim, Tp]
             ops.gemm_nt_batched(S, Tp, (nh * T * Tp, T * Tp), Vt, Tp, (dim * Tp, hd * Tp), out[b0 * T:], dim,
                                 (T * dim, hd), (nb, nh), T, hd, Tp)                                 # attn v
-        return out, attn
+        return out, attn, None
 
     def _block(self, blk, X, B, T, last=False, want_attn=False):
-        h1 = ops.layernorm(X, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-        o, attn = self._attention(blk, h1, B, T, want_attn=want_attn, keep_qkv=last)
+        # every GEMM input's range comes out of the kernel that produced it (LayerNorm, attention, the GELU epilogue)
+        new = (lambda: ops.new_amax(X.device)) if FP16_PAIRS else (lambda: None)
+        r1 = new()
+        h1 = ops.layernorm(X, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, amax_out=r1)
+        o, attn, r_o = self._attention(blk, h1, B, T, want_attn=want_attn, keep_qkv=last, h1_range=r1)
         if want_attn:
             return attn
-        ops.gemm_nt(o, blk.attn.proj.weight, blk.attn.proj.bias, out=X, beta=1)                    # x = x + proj(.)
-        h2 = ops.layernorm(X, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        m = ops.gemm_nt(h2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=2)                            # GELU in the epilogue
-        ops.gemm_nt(m, blk.mlp.fc2.weight, blk.mlp.fc2.bias, out=X, beta=1)                         # x = x + mlp(.)
+        self._linear(blk.attn.proj, o, r_o, out=X, beta=1)                                          # x = x + proj(.)
+        r2, rm = new(), new()
+        h2 = ops.layernorm(X, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, amax_out=r2)
+        m = self._linear(blk.mlp.fc1, h2, r2, act=2, amax_out=rm)                                   # GELU in the epilogue
+        self._linear(blk.mlp.fc2, m, rm, out=X, beta=1)                                             # x = x + mlp(.)
         return X
 
     # ---------------------------------------------------------------- reference surfaces

@@ -51,6 +51,26 @@ def test_gemm_layernorm_softmax_helpers(report):
     assert max(e_g, e_gelu, e_ln, e_sm) < 2e-5 and pad0 == 0.0 and ok_t
 
 
+def test_linear_fp16_pairs_with_fused_ranges(report):
+    """nn.Linear on the fp16-pair kernels: LayerNorm leaves the range of its output, the GEMM takes it together with
+    the weight's range and pre-split weights, and its GELU epilogue leaves the range of what it wrote"""
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(301, 384, generator=g) * 3).to(DEV)
+    gam, bet = torch.randn(384, generator=g).to(DEV), torch.randn(384, generator=g).to(DEV)
+    w, b = (torch.randn(1536, 384, generator=g) * 0.05).to(DEV), torch.randn(1536, generator=g).to(DEV)
+    r1, rm = ops.new_amax(DEV), ops.new_amax(DEV)
+    h = ops.layernorm(x, gam, bet, 1e-6, amax_out=r1)
+    assert float(r1.view(torch.float32)) == float(h.abs().max())
+    rw = ops.absmax(w)
+    y = ops.gemm_nt(h, w, b, act=2, amax=(r1, rw), b_pairs=ops.weight_pairs_2d(w, rw), amax_out=rm)
+    assert float(rm.view(torch.float32)) == float(y.abs().max())
+    assert torch.equal(y, ops.gemm_nt(h, w, b, act=2, amax=(r1, rw)))             # pre-split weights: the same bits
+    ref = torch.nn.functional.gelu(h.double() @ w.double().T + b.double())
+    e2, e3 = rel(y.cpu(), ref.cpu()), rel(ops.gemm_nt(h, w, b, act=2).cpu(), ref.cpu())
+    report(f"linear + GELU 384->1536: fp16 pairs {e2:.2e}, bf16 triples {e3:.2e} (max error / max |ref| vs float64)")
+    assert e2 < 2e-6 and e3 < 2e-6
+
+
 @pytest.mark.parametrize("pairs,qscale", [(False, 1.5), (True, 1.5), (True, 3e-4), (True, 2e3)])
 @pytest.mark.parametrize("T", [97, 130, 257])
 def test_fused_attention_vs_float64(T, pairs, qscale, report):
@@ -60,7 +80,10 @@ def test_fused_attention_vs_float64(T, pairs, qscale, report):
     B, nh, dim = 2, 6, 384
     qkv = (torch.randn(B * T, 3 * dim, generator=g) * qscale).to(DEV)
     sc = 0.125 * (1.5 / qscale) ** 2                      # keeps the logits' spread the same
-    out = ops.attention(qkv, B, T, nh, sc, amax=ops.absmax(qkv) if pairs else None).cpu().double()
+    ro = ops.new_amax(DEV)
+    out = ops.attention(qkv, B, T, nh, sc, amax=ops.absmax(qkv) if pairs else None, amax_out=ro)
+    assert float(ro.view(torch.float32)) == float(out.abs().max())
+    out = out.cpu().double()
     q, k, v = (qkv.cpu().double().view(B, T, 3, nh, 64).permute(2, 0, 3, 1, 4)[i] for i in range(3))
     ref = (torch.softmax(q @ k.transpose(-2, -1) * sc, dim=-1) @ v).transpose(1, 2).reshape(B * T, dim)
     e = float((out - ref).abs().max() / ref.abs().max())
