@@ -206,15 +206,35 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__res
         cand_range(yi, sh, align, Ho, ylo, yhi);
         cand_range(xi, sw, align, Wo, xlo, xhi);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int yo = ylo; yo <= yhi; ++yo) {
-            const float wy = tap_weight(yo, yi, sh, align, Hi);
-            if (wy == 0.f) continue;
-            for (int xo = xlo; xo <= xhi; ++xo) {
-                const float wx = tap_weight(xo, xi, sw, align, Wi);
-                if (wx == 0.f) continue;
-                if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) continue;
-                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
-                acc += g * (wy * wx);
+        constexpr int MAXC = 6;                 // candidates per axis handled with weights computed once (2x: 4)
+        if (yhi - ylo < MAXC && xhi - xlo < MAXC) {
+            // the column weights are the same for every candidate row: computed once, not once per (row, column)
+            float wxv[MAXC];
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) wxv[k] = xlo + k <= xhi ? tap_weight(xlo + k, xi, sw, align, Wi) : 0.f;
+            for (int yo = ylo; yo <= yhi; ++yo) {
+                const float wy = tap_weight(yo, yi, sh, align, Hi);
+                if (wy == 0.f) continue;
+                const float *row = dy + (((long)n * Ho + yo) * Wo + xlo) * dy_pitch + cv * 4;
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) {
+                    if (xlo + k > xhi || wxv[k] == 0.f) continue;
+                    if (frame > 0 && !in_frame(yo, xlo + k, Ho, Wo, frame)) continue;
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(row + (long)k * dy_pitch);
+                    acc += g * (wy * wxv[k]);
+                }
+            }
+        } else {
+            for (int yo = ylo; yo <= yhi; ++yo) {
+                const float wy = tap_weight(yo, yi, sh, align, Hi);
+                if (wy == 0.f) continue;
+                for (int xo = xlo; xo <= xhi; ++xo) {
+                    const float wx = tap_weight(xo, xi, sw, align, Wi);
+                    if (wx == 0.f) continue;
+                    if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) continue;
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
+                    acc += g * (wy * wx);
+                }
             }
         }
         f32x4 *dst = reinterpret_cast<f32x4 *>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4);
