@@ -1810,9 +1810,11 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
             else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
         }                                                                                                         \
     } while (0)
-    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region)) {   // narrow tiles: the fp32-MFMA kernel is as fast
+    // narrow tiles: the fp32-MFMA kernel is as fast as the bf16 triples, not as the fp16 pairs
+    const bool h2 = p.amax_a && p.amax_b && !g_h2_off;
+    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
-        if (p.amax_a && p.amax_b && !g_h2_off) {            // fp16 pairs
+        if (h2) {            // fp16 pairs
             if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, p);
