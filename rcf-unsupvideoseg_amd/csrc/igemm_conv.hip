@@ -1810,7 +1810,8 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
             else hipLaunchKernelGGL((igemm_wgrad_kernel<MRv, NRv, false, false>), grid, dim3(256), 0, st, p);     \
         }                                                                                                         \
     } while (0)
-    // narrow tiles: the fp32-MFMA kernel is as fast as the bf16 triples, not as the fp16 pairs
+    // narrow tiles: the fp32-MFMA kernel is as fast as the bf16 triples; with operand ranges they take the fp16 pairs
+    // like every other conv of the step (same-box A/B: no difference in step time either way)
     const bool h2 = p.amax_a && p.amax_b && !g_h2_off;
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
