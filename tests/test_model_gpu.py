@@ -355,3 +355,25 @@ def test_commuted_upsample_conv_matches_plain_path(report):
     e = {k: rel(res[True][k].cpu().numpy(), res[False][k].cpu().numpy()) for k in res[True]}
     report("commuted upsample conv vs plain path: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
     assert max(e.values()) < 5e-5, e
+
+
+def test_train_step_bitwise_reproducible(report):
+    """the same step from the same state twice: identical losses and gradients, bit for bit (no floating-point atomics
+    on the training path: fixed-order split-K and batch-norm reductions, integer max for the operand ranges; the
+    second HIP stream changes the order kernels run in, not what they compute)"""
+    H, W, B = 96, 160, 2
+    out = []
+    for _ in range(2):
+        model = _build(H, W, False, DEV, rcf_amd.RCFModel)
+        tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=DEV)
+        losses = tr.step(_batch(B, H, W, DEV))
+        torch.cuda.synchronize()
+        out.append(({k: float(v) for k, v in losses.items()},
+                    {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                    {n: p.detach().clone() for n, p in model.named_parameters()}))
+    same_loss = out[0][0] == out[1][0]
+    bad_g = [n for n in out[0][1] if not torch.equal(out[0][1][n], out[1][1][n])]
+    bad_p = [n for n in out[0][2] if not torch.equal(out[0][2][n], out[1][2][n])]
+    report(f"two identical steps: losses identical {same_loss}, gradients differing {len(bad_g)} of {len(out[0][1])}, "
+           f"updated parameters differing {len(bad_p)}")
+    assert same_loss and not bad_g and not bad_p, (bad_g[:5], bad_p[:5])
