@@ -445,7 +445,10 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x
 // PERM: tile rows are stored at x3_prow(row) (the weight-gradient loader's conflict-free write pattern).
 __device__ __forceinline__ int x3_prow(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <int MR, int NR, int PA, int PB, bool PERM = false, int NP = 3>
+// SWAP: the MFMA operands change roles, so the accumulator tile is transposed: a lane then owns ONE tile row of A
+// (column lane&31) and, per register quad, FOUR consecutive rows of B -- for the conv kernels one pixel and four
+// consecutive output channels, i.e. a 16-byte store (data-gradient epilogue).
+template <int MR, int NR, int PA, int PB, bool PERM = false, int NP = 3, bool SWAP = false>
 __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *__restrict__ Bs, int arow0, int brow0,
                                        int lane, f32x16 (&acc)[MR][NR]) {
     const int l31 = PERM ? x3_prow(lane & 31) : (lane & 31);
@@ -469,7 +472,8 @@ __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mr][HA[t]], b[nr][HB[t]], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nr][HB[t]], a[mr][HA[t]], acc[mr][nr], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mr][HA[t]], b[nr][HB[t]], acc[mr][nr], 0, 0, 0);
         return;
     }
     bf16x8 a[MR][3], b[NR][3];
@@ -490,7 +494,8 @@ __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr)
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr][QA[t]], b[nr][QB[t]], acc[mr][nr], 0, 0, 0);
+                acc[mr][nr] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nr][QB[t]], a[mr][QA[t]], acc[mr][nr], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr][QA[t]], b[nr][QB[t]], acc[mr][nr], 0, 0, 0);
 }
 
 constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descriptor's num_records: loads return 0
@@ -675,7 +680,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 2, ra[0]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem;
-            mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(1, ra[1]);
             __syncthreads();
         }
@@ -684,7 +689,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 3, ra[1]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem + STAGE;
-            mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(0, ra[0]);
             __syncthreads();
         }
@@ -693,14 +698,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         load_b(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem;
-        mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
         store_tile(1, ra[1]);
         __syncthreads();
         ++kt;
     }
     {
         const char *As = smem + (kt & 1) * STAGE;
-        mma_x3<MR, NR, PA, PB, false, NP>(As, As + NP * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
     // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -708,6 +713,42 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     const bool want_stats = !DGRAD && p.stats != nullptr;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
+    if constexpr (DGRAD) {
+        // transposed accumulators (mma_x3 SWAP): lane = pixel (lane&31) of each row tile, registers 4g..4g+3 = output
+        // channels 8g + 4(lane>>5) .. +3 of each column tile: 16-byte stores, the region walk once per pixel
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int row = m0 + arow0 + mr * 32 + l31;
+            if (row >= p.M) continue;
+            long lin = row;
+            if (!full) {
+                const int n = row / HoWo;
+                int y, x;
+                region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+                lin = ((long)n * p.Ho + y) * p.Wo + x;
+            }
+            float *drow = p.Y + lin * p.y_pitch + n0 + brow0 + 4 * kh;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = n0 + brow0 + nr * 32 + 8 * g + 4 * kh;
+                    if (c >= p.Ncol) continue;                       // Ncol is a multiple of 4: whole quads
+                    f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                    if constexpr (NP == 2) v = (v * inv_a) * inv_b;
+                    if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (p.act == 1) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                        else if (p.act == 2) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+                    }
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(drow + nr * 32 + 8 * g);
+                    if (p.beta) v += *dst;
+                    *dst = v;
+                }
+        }
+        return;
+    }
     float bv[NR];
     unsigned omax = 0u;          // max |value written| by this lane (p.amax_out)
     float csum[NR], csq[NR];     // this lane's 16 MR values of a column in fp32; everything above that in fp64
