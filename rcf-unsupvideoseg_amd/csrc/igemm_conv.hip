@@ -508,7 +508,9 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // the data gradients run beside the weight gradients of a second stream, the forward convs run alone)
 // NP: 3 = bf16 triples (6 partial products), 2 = fp16 pairs (3 partial products, operands scaled by p.amax_a / p.amax_b)
 // PRE (NP == 2 only): the weight operand arrives split (p.b_pairs: two fp16 planes)
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false>
+// TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue -- every launch that does not need the
+// column sums of the fused batch-norm statistics
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD>
 __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 2, ra[0]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem;
-            mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(1, ra[1]);
             __syncthreads();
         }
@@ -689,7 +691,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             load_a(kt + 3, ra[1]);
             __builtin_amdgcn_sched_barrier(0);
             const char *As = smem + STAGE;
-            mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
+            mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
             store_tile(0, ra[0]);
             __syncthreads();
         }
@@ -698,14 +700,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         load_b(kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         const char *As = smem;
-        mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
         store_tile(1, ra[1]);
         __syncthreads();
         ++kt;
     }
     {
         const char *As = smem + (kt & 1) * STAGE;
-        mma_x3<MR, NR, PA, PB, false, NP, DGRAD>(As, As + NP * PA, arow0, brow0, lane, acc);
+        mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
     // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -713,39 +715,123 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     const bool want_stats = !DGRAD && p.stats != nullptr;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
-    if constexpr (DGRAD) {
+    if constexpr (TR) {
+        unsigned tmax = 0u;
         // transposed accumulators (mma_x3 SWAP): lane = pixel (lane&31) of each row tile, registers 4g..4g+3 = output
         // channels 8g + 4(lane>>5) .. +3 of each column tile: 16-byte stores, the region walk once per pixel
+        long lin[MR];
+        bool rowok[MR];
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int row = m0 + arow0 + mr * 32 + l31;
-            if (row >= p.M) continue;
-            long lin = row;
-            if (!full) {
+            rowok[mr] = row < p.M;
+            lin[mr] = row;
+            if (rowok[mr] && !full) {
                 const int n = row / HoWo;
                 int y, x;
                 region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
-                lin = ((long)n * p.Ho + y) * p.Wo + x;
+                lin[mr] = ((long)n * p.Ho + y) * p.Wo + x;
             }
-            float *drow = p.Y + lin * p.y_pitch + n0 + brow0 + 4 * kh;
+        }
+        double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
+        if (want_stats) __syncthreads();                      // every wave is done with the operand stages
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
+        for (int nr = 0; nr < NR; ++nr) {
+            float cs[16], cq[16];                             // this lane's pixels: sums / sums of squares per channel register
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                if (!rowok[mr]) continue;
+                float *drow = p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = n0 + brow0 + nr * 32 + 8 * g + 4 * kh;
-                    if (c >= p.Ncol) continue;                       // Ncol is a multiple of 4: whole quads
+                    if (c >= p.Ncol) continue;
                     f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
                     if constexpr (NP == 2) v = (v * inv_a) * inv_b;
-                    if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + c);
+                    const bool whole = c + 3 < p.Ncol;               // conv channels come in quads; a GEMM's N need not
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        if (p.bias && (whole || c + e < p.Ncol)) v[e] += p.bias[c + e];
                         if (p.act == 1) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
                         else if (p.act == 2) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
                     }
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(drow + nr * 32 + 8 * g);
-                    if (p.beta) v += *dst;
-                    *dst = v;
+                    float *dq = drow + nr * 32 + 8 * g;
+                    if (whole) {
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(dq);
+                        if (p.beta) v += *dst;
+                        *dst = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < p.Ncol) {
+                                if (p.beta) v[e] += dq[e];
+                                dq[e] = v[e];
+                            } else {
+                                v[e] = 0.f;
+                            }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                        cs[4 * g + e] += v[e];
+                        cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                    }
                 }
+            }
+            if (want_stats) {                                 // block-uniform
+                // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly -- at every
+                // step a lane keeps the half of its registers its lane bit selects and adds the partner's copy of them
+                // (16 + 8 + 4 + 2 + 1 values move instead of 5 x 16); bit 0 of the lane ends up redundant.
+                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+                float s8[8], q8[8], s4[4], q4[4], s2[2], q2[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s8[i] = (b4 ? cs[8 + i] : cs[i]) + __shfl_xor(b4 ? cs[i] : cs[8 + i], 16);
+                    q8[i] = (b4 ? cq[8 + i] : cq[i]) + __shfl_xor(b4 ? cq[i] : cq[8 + i], 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s4[i] = (b3 ? s8[4 + i] : s8[i]) + __shfl_xor(b3 ? s8[i] : s8[4 + i], 8);
+                    q4[i] = (b3 ? q8[4 + i] : q8[i]) + __shfl_xor(b3 ? q8[i] : q8[4 + i], 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    s2[i] = (b2 ? s4[2 + i] : s4[i]) + __shfl_xor(b2 ? s4[i] : s4[2 + i], 4);
+                    q2[i] = (b2 ? q4[2 + i] : q4[i]) + __shfl_xor(b2 ? q4[i] : q4[2 + i], 4);
+                }
+                float s1 = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 2);
+                float q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2);
+                s1 += __shfl_xor(s1, 1);
+                q1 += __shfl_xor(q1, 1);
+                if ((lane & 1) == 0) {
+                    const int r = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);     // accumulator register = channel
+                    const int ch = brow0 + nr * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    red[(wm * BN + ch) * 2] = (double)s1;
+                    red[(wm * BN + ch) * 2 + 1] = (double)q1;
+                }
+            }
+        }
+        if (p.amax_out) {                                     // block-uniform
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o));
+            if (lane == 0 && tmax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, tmax);
+        }
+        if (want_stats) {
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                if (n0 + c >= p.Ncol) continue;
+                double sv = 0, qv = 0;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    sv += red[(w * BN + c) * 2];
+                    qv += red[(w * BN + c) * 2 + 1];
+                }
+                double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
+                o[0] = sv;
+                o[p.Ncol] = qv;
+            }
         }
         return;
     }
@@ -1480,7 +1566,7 @@ void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches)
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
     if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false, NP, PRE, true>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 int g_h2_off = 0;          // rcf_conv_set_variant bit 0x20000: never take the fp16-pair kernels
