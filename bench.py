@@ -139,7 +139,7 @@ def main():
             traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
         # The convs run as fp32 contractions on the fp16 matrix cores (each operand scaled and split into 2 fp16
         # parts, 3 partial products, fp32 accumulate): the bound is the dense fp16 MFMA peak / 3 passes.
-        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false,false,2> (implicit-GEMM conv, fp16 pairs, 128x256 tile: the forward launches with > 128 output channels; data gradients are the <...,true,2> instance and overlap the weight gradients of a second stream)",
+        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (implicit-GEMM conv, fp16 pairs, weights split beforehand, transposed 16-byte epilogue, 128x256 tile: the forward launches with > 128 output channels; data gradients are the <...,false,true,2,true,true> instance and overlap the weight gradients of a second stream)",
                            "bound": "mfma", "achieved": round(ach, 2), "peak": round(H2_MFMA_PEAK_TF, 1), "unit": "TFLOP/s",
                            "frac": round(ach / H2_MFMA_PEAK_TF, 4), "traffic": traffic, "launches": n,
                            "avg_launch_ms": round(ms / max(n, 1), 4),

@@ -508,8 +508,8 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // the data gradients run beside the weight gradients of a second stream, the forward convs run alone)
 // NP: 3 = bf16 triples (6 partial products), 2 = fp16 pairs (3 partial products, operands scaled by p.amax_a / p.amax_b)
 // PRE (NP == 2 only): the weight operand arrives split (p.b_pairs: two fp16 planes)
-// TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue -- every launch that does not need the
-// column sums of the fused batch-norm statistics
+// TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue; every instance is launched with TR = true
+// (the batch-norm statistics, column sums, are a butterfly over the pixels = lanes of a half-wavefront there)
 template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD>
 __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
-    // epilogue: lane holds column (lane&31) of each tile, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // epilogue (MFMA C/D layout: column lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5) of each 32 x 32 tile)
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     const bool want_stats = !DGRAD && p.stats != nullptr;
@@ -833,83 +833,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 o[p.Ncol] = qv;
             }
         }
-        return;
-    }
-    float bv[NR];
-    unsigned omax = 0u;          // max |value written| by this lane (p.amax_out)
-    float csum[NR], csq[NR];     // this lane's 16 MR values of a column in fp32; everything above that in fp64
-#pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-        const int col = n0 + brow0 + nr * 32 + l31;
-        bv[nr] = (p.bias && col < p.Ncol) ? p.bias[col] : 0.f;
-        csum[nr] = 0.f;
-        csq[nr] = 0.f;
-    }
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-        const int rbase = m0 + arow0 + mr * 32 + 4 * kh;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = rbase + (e & 3) + 8 * (e >> 2);
-            if (row >= p.M) continue;
-            long lin = row;
-            if (!full) {
-                const int n = row / HoWo;
-                int y, x;
-                region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
-                lin = ((long)n * p.Ho + y) * p.Wo + x;
-            }
-            float *drow = p.Y + lin * p.y_pitch + n0 + brow0 + l31;
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                if (n0 + brow0 + nr * 32 + l31 >= p.Ncol) continue;
-                float v = acc[mr][nr][e];
-                if constexpr (NP == 2) v = (v * inv_a) * inv_b;       // two exact steps: 2^-(ka+kb) may leave fp32's range
-                v += bv[nr];
-                if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (erf form)
-                if (p.beta) v += drow[nr * 32];
-                drow[nr * 32] = v;
-                omax = max(omax, __float_as_uint(fabsf(v)));
-                if (want_stats) {
-                    csum[nr] += v;
-                    csq[nr] = fmaf(v, v, csq[nr]);
-                }
-            }
-        }
-    }
-    if (p.amax_out) {                                         // block-uniform
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o));
-        // most wavefronts find the scalar already at least as large: a plain load first keeps the atomics few
-        if (lane == 0 && omax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, omax);
-    }
-    if (want_stats) {                                         // block-uniform
-        // column sums of this row tile: lane halves by shuffle, the WM waves of a column through LDS, fixed order
-        __syncthreads();                                      // every wave is done with the operand stages
-        double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2]
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-            const double s = (double)csum[nr] + (double)__shfl_xor(csum[nr], 32);
-            const double q = (double)csq[nr] + (double)__shfl_xor(csq[nr], 32);
-            if (kh == 0) {
-                red[(wm * BN + brow0 + nr * 32 + l31) * 2] = s;
-                red[(wm * BN + brow0 + nr * 32 + l31) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            if (n0 + c >= p.Ncol) continue;
-            double s = 0, q = 0;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s += red[(w * BN + c) * 2];
-                q += red[(w * BN + c) * 2 + 1];
-            }
-            double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
-            o[0] = s;
-            o[p.Ncol] = q;
-        }
+    } else {
+        static_assert(TR, "the column-per-lane epilogue was retired: every instance runs transposed");
     }
 }
 

@@ -26,7 +26,7 @@ with open("$R/gpurun_out/pmc_hbm_traffic.txt", "w") as o:
     for tot, k, n, f, w in rows[:40]:
         o.write(f"{k[:120]} | {n} | {f:.1f} | {w:.1f} | {(2*f+w)*1024/1e6:.1f}\n")
 for tot, k, n, f, w in rows:
-    if "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true>" in k:
+    if "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>" in k:
         json.dump({"kernel": k, "launches": n, "hbm_bytes_per_launch": (2 * f + w) * 1024, "note": "all launches of this kernel instance in a step (forward convs with more than 128 output channels)"}, open("$R/gpurun_out/pmc_traffic.json", "w"))
         print(k[:80], n, (2 * f + w) * 1024 / 1e6, "MB/launch")
 PY
