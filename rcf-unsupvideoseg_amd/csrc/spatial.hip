@@ -191,21 +191,34 @@ __device__ __forceinline__ void cand_range(int in_idx, float scale, int align, i
 __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__restrict__ dy, int dy_pitch,
                                                               float *__restrict__ dx, int dx_pitch, int beta, int N,
                                                               int Hi, int Wi, int Ho, int Wo, int C, int align,
-                                                              float sh, float sw, int frame) {
+                                                              float sh, float sw, int frame, int tc) {
+    // tc > 0 (frame > 0 and beta != 0): only the input pixels within tc of the border can receive anything from the
+    // frame -- the walk covers that input frame alone; the interior keeps what it holds
     const int CV = C / 4;
-    const long total = (long)N * Hi * Wi * CV;
+    const long per_img = tc > 0 ? 2L * tc * Wi + 2L * tc * (Hi - 2 * tc) : (long)Hi * Wi;
+    const long total = (long)N * per_img * CV;
     const long step = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const int cv = (int)(i % CV);
         long t = i / CV;
-        const int xi = (int)(t % Wi);
-        t /= Wi;
-        const int yi = (int)(t % Hi);
-        const int n = (int)(t / Hi);
+        const int q = (int)(t % per_img);
+        const int n = (int)(t / per_img);
+        int xi, yi;
+        if (tc > 0) {
+            frame_yx(q, Hi, Wi, tc, yi, xi);
+        } else {
+            yi = q / Wi;
+            xi = q - yi * Wi;
+        }
         int ylo, yhi, xlo, xhi;
         cand_range(yi, sh, align, Ho, ylo, yhi);
         cand_range(xi, sw, align, Wo, xlo, xhi);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (frame > 0 && ylo >= frame && yhi < Ho - frame && xlo >= frame && xhi < Wo - frame) {
+            // no candidate lies on the frame: nothing reaches this pixel (most of the image)
+            if (!beta) *reinterpret_cast<f32x4 *>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4) = acc;
+            continue;
+        }
         constexpr int MAXC = 6;                 // candidates per axis handled with weights computed once (2x: 4)
         if (yhi - ylo < MAXC && xhi - xlo < MAXC) {
             // the column weights are the same for every candidate row: computed once, not once per (row, column)
@@ -386,7 +399,7 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, f
     if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
                        rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0);
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0, 0);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -396,9 +409,16 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_frame_f32(const float *dy, int dy_pi
                                                       int frame, void *stream) {
     if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     if (frame <= 0 || 2 * frame >= Ho || 2 * frame >= Wo) return RCF_EINVAL;
-    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
+    // input pixels that can see the output frame: within tc of the border (conservative: an input pixel's taps lie
+    // within (1 + 1/scale) output pixels of its centre); only when the kernel accumulates (beta), otherwise the
+    // interior must be written (zeros)
+    const float smax = fmaxf((float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    int tc = beta ? (int)ceilf(smax * (float)(frame + 2)) + 2 : 0;
+    if (tc > 0 && (2 * tc >= Hi || 2 * tc >= Wi)) tc = 0;
+    const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks(items)), dim3(256), 0,
                        rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame);
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame, tc);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -430,8 +430,10 @@ def commuted_concat_conv(a, b, conv, tape):
             dUup = torch.empty_like(Uup)                                   # written (and read) on the bi-frame only
             ops.conv2d_dgrad(dy_band, wbt, Uup.shape, 1, d, d, out=dUup, beta=0, region=(0, 0, h, w, bi),
                              amax=(rdy, rw))
-            ops.resize_nhwc_bwd(dUup, (hb, wb), False, out=gb, beta=beta, frame=bi)
-            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=1, amax=(rg4, rw))
+            # the whole-tensor term first, so that the frame term always accumulates (its kernel then only walks the
+            # input pixels that can see the frame)
+            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=beta, amax=(rg4, rw))
+            ops.resize_nhwc_bwd(dUup, (hb, wb), False, out=gb, beta=1, frame=bi)
     tape.push(bwd)
     return ya
 
