@@ -177,6 +177,10 @@ int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N, int C, in
 /* strided 2-D copy: dst[r*dpitch + c] (+)= src[r*spitch + c], c < C (concat / pair-concat / slices) */
 int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
                    void *stream);
+/* n0 x n1 such copies in one launch: copy (i0, i1) reads src + i0*sb0 + i1*sb1 and writes dst + i0*db0 + i1*db1
+ * (element offsets, multiples of 4, may be negative) -- the frames-of-a-pair channel concat of models/rcf_model.py:325 */
+int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, float *dst, long dpitch, long db0, long db1,
+                           long rows, int C, int beta, int n0, int n1, void *stream);
 /* dense NHWC [N,H,W,C]: inside = src on the rectangle (0 elsewhere), outside = src off the rectangle (0 on it);
  * either output may be NULL.  Splits a gradient into its interior / border-band parts (see rcf_conv_region). */
 int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0, int x0,

@@ -97,6 +97,8 @@ PROTOS = {
     "rcf_nchw_to_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_nhwc_to_nchw_f32": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "rcf_copy2d_f32": (c_int, [P, c_long, P, c_long, c_long, c_int, c_int, P]),
+    "rcf_copy2d_batched_f32": (c_int, [P, c_long, c_long, c_long, P, c_long, c_long, c_long, c_long, c_int, c_int, c_int,
+                                       c_int, P]),
     "rcf_colsum_f32": (c_int, [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rcf_flow_warp_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_flow_warp_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

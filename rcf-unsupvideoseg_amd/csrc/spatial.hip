@@ -321,6 +321,26 @@ __global__ void __launch_bounds__(256) copy2d_kernel(const float *__restrict__ s
     }
 }
 
+// n0 x n1 copies in one launch (blockIdx.y = i0 * n1 + i1): copy (i0, i1) starts at src + i0*sb0 + i1*sb1 and
+// dst + i0*db0 + i1*db1 (element offsets, may be negative)
+__global__ void __launch_bounds__(256) copy2d_batched_kernel(const float *__restrict__ src, long spitch, long sb0, long sb1,
+                                                             float *__restrict__ dst, long dpitch, long db0, long db1,
+                                                             long rows, int C, int beta, int n1) {
+    const int i0 = blockIdx.y / n1, i1 = blockIdx.y - i0 * n1;
+    src += i0 * sb0 + i1 * sb1;
+    dst += i0 * db0 + i1 * db1;
+    const int CV = C / 4;
+    const long total = rows * CV;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const long r = i / CV;
+        const int c4 = (int)(i - r * CV) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * spitch + c4);
+        f32x4 *d = reinterpret_cast<f32x4 *>(dst + r * dpitch + c4);
+        *d = beta ? (*d + v) : v;
+    }
+}
+
 // inside[p] = src[p] for pixels in the rectangle, 0 elsewhere; outside[p] = the complement (either may be null)
 __global__ void __launch_bounds__(256) split_rect_kernel(const float *__restrict__ src, float *__restrict__ inside,
                                                          float *__restrict__ outside, long pixels, int H, int W, int C,
@@ -445,6 +465,19 @@ extern "C" int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N
     if (!x || !y || x_pitch < C) return RCF_EINVAL;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((long)N * C * H * W)), dim3(256), 0, rcf_stream(stream), x,
                        x_pitch, y, N, C, (long)H * W);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, float *dst, long dpitch, long db0,
+                                      long db1, long rows, int C, int beta, int n0, int n1, void *stream) {
+    if (!src || !dst || C % 4 || spitch % 4 || dpitch % 4 || sb0 % 4 || sb1 % 4 || db0 % 4 || db1 % 4 || rows <= 0) return RCF_EINVAL;
+    if (n0 <= 0 || n1 <= 0 || (long)n0 * n1 > 65535) return RCF_EINVAL;
+    long blocks = (rows * (C / 4) + 1023) / 1024;
+    const long cap = 4096 / ((long)n0 * n1) > 1 ? 4096 / ((long)n0 * n1) : 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(copy2d_batched_kernel, dim3((unsigned)blocks, (unsigned)(n0 * n1)), dim3(256), 0, rcf_stream(stream),
+                       src, spitch, sb0, sb1, dst, dpitch, db0, db1, rows, C, beta, n1);
     RCF_LAUNCH_CHECK();
     return 0;
 }

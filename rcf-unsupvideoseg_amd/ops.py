@@ -396,6 +396,13 @@ def copy2d(src, spitch, dst, dpitch, rows, C, beta=0):
     call("rcf_copy2d_f32", _p(src), spitch, _p(dst), dpitch, rows, C, beta, _stream())
 
 
+def copy2d_batched(src, spitch, sstrides, dst, dpitch, dstrides, rows, C, batch, beta=0):
+    """batch[0] x batch[1] copies in one launch; src / dst are the base tensors of copy (0, 0) (their data pointers may
+    carry an offset), strides in elements (may be negative)"""
+    call("rcf_copy2d_batched_f32", _p(src), int(spitch), int(sstrides[0]), int(sstrides[1]), _p(dst), int(dpitch),
+         int(dstrides[0]), int(dstrides[1]), int(rows), int(C), int(beta), int(batch[0]), int(batch[1]), _stream())
+
+
 def split_rect(x, rect, want_inside=True, want_outside=True):
     """dense NHWC x -> (x on the rectangle (y0,x0,h,w) else 0, x off the rectangle else 0)"""
     _need_cuda(x)
