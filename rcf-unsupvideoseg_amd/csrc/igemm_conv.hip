@@ -1410,6 +1410,196 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams
     }
 }
 
+// The same 128 x 256 weight-gradient tile with the operands staged in their NATURAL order: LDS holds, per fp16 plane,
+// [16 pixels][channels] (a float4 = 4 channels of a pixel is split once and written with one ds_write_b64 per plane;
+// the global loads of a K-step are whole runs of 512 B / 1 KB per pixel), and the MFMA's k-contiguous fragments come out
+// of gfx950's transposing LDS read: ds_read_b64_tr_b16 gives lane c of a 16-lane group the 4 k-values of channel
+// c0 + c when lane p of the group points at row k0 + p/4, channels c0 + 4 (p%4) .. +3.  No register transposes, no
+// row permutation.  Row pitch = channels * 2 + 32 bytes: the 4 rows a group reads fall into 4 different bank octets.
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ u32x2 lds_tr16(const char *p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) char *)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+
+__global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
+    constexpr int MR = 2, NR = 4, BM = 128, BN = 256;
+    constexpr int PIA = BM * 2 + 32, PIB = BN * 2 + 32;          // row (pixel) pitch of the dy / x planes, bytes
+    constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int rs = (int)blockIdx.y;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+    const int klen = (int)(kend - kbeg);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = p.Ho * p.Wo;
+    const int n_first = (int)(kbeg / HoWo);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.DY + kbeg * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
+
+    // loader roles.  dy: item t + 256 j (j < 2) = pixel (t >> 5) + 8 j, channel quad t & 31.
+    //                x:  item t + 256 j (j < 4) = pixel (t >> 6) + 4 j, channel quad t & 63.
+    const int qa = tid & 31, pa0 = tid >> 5;
+    const int qb = tid & 63, pb0 = tid >> 6;
+    const int cha = i0 + 4 * qa, chb = j0 + 4 * qb;
+    const bool acta = cha < p.Cout, actb = chb < p.Cin;
+    int pn[4], py[4], px_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = kbeg + pb0 + 4 * j;
+        pn[j] = (int)(m / HoWo);
+        const int pix = (int)(m - (long)pn[j] * HoWo);
+        py[j] = pix / p.Wo;
+        px_[j] = pix - py[j] * p.Wo;
+        pn[j] -= n_first;
+    }
+    const bool incr = p.Wo >= BK;
+
+    f32x4 ra[2], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mk = kt * BK + pa0 + 8 * j;
+            const unsigned bo = (acta && mk < klen) ? (unsigned)(mk * p.dy_pitch + cha) * 4u : X3_OOB;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mk = kt * BK + pb0 + 4 * j;
+            const int sy = py[j] * p.stride - p.pad + r * p.dil;
+            const int sx = px_[j] * p.stride - p.pad + s * p.dil;
+            const bool v = actb && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const unsigned bo = v ? (unsigned)(((pn[j] * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 4u : X3_OOB;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+            if (incr) {
+                px_[j] += BK;
+                const bool wx = px_[j] >= p.Wo;
+                px_[j] -= wx ? p.Wo : 0;
+                py[j] += wx ? 1 : 0;
+                const bool wy = py[j] == p.Ho;
+                py[j] = wy ? 0 : py[j];
+                pn[j] += wy ? 1 : 0;
+            } else {
+                const long mn = kbeg + (long)(kt + 1) * BK + pb0 + 4 * j;
+                const int nn = (int)(mn / HoWo);
+                const int pix = (int)(mn - (long)nn * HoWo);
+                pn[j] = nn - n_first;
+                py[j] = pix / p.Wo;
+                px_[j] = pix - py[j] * p.Wo;
+            }
+        }
+    };
+    const int ka = h2_exponent(*p.amax_a), kb = h2_exponent(*p.amax_b);
+    const float sa = pow2f(ka), sb = pow2f(kb);
+    auto store_tile = [&](int buf) {
+        char *As = smem + buf * STAGE, *Bs = As + 2 * PLA;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x2 h, m;
+            split2h(ra[j], sa, h, m);
+            char *d = As + (pa0 + 8 * j) * PIA + qa * 8;
+            *reinterpret_cast<u32x2 *>(d) = h;
+            *reinterpret_cast<u32x2 *>(d + PLA) = m;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x2 h, m;
+            split2h(rb[j], sb, h, m);
+            char *d = Bs + (pb0 + 4 * j) * PIB + qb * 8;
+            *reinterpret_cast<u32x2 *>(d) = h;
+            *reinterpret_cast<u32x2 *>(d + PLB) = m;
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    // fragment addressing: 16-lane group gi = lane >> 4 serves rows 16 (gi & 1) .. +15 of a 32-row tile and the k half
+    // gi >> 1; inside the group lane q points at pixel row 8 (gi >> 1) + q / 4 (+ 4 for the second read), channels 4 (q % 4)
+    const int gi = lane >> 4, q16 = lane & 15;
+    const int fa = (8 * (gi >> 1) + (q16 >> 2)) * PIA + (arow0 + 16 * (gi & 1) + 4 * (q16 & 3)) * 2;
+    const int fb = (8 * (gi >> 1) + (q16 >> 2)) * PIB + (brow0 + 16 * (gi & 1) + 4 * (q16 & 3)) * 2;
+    auto mma = [&](int buf) {
+        const char *As = smem + buf * STAGE, *Bs = As + 2 * PLA;
+        f16x8 a[MR][2], b[NR][2];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u32x2 lo = lds_tr16(As + pl * PLA + fa + mr * 64);
+                const u32x2 hi = lds_tr16(As + pl * PLA + fa + mr * 64 + 4 * PIA);
+                a[mr][pl] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u32x2 lo = lds_tr16(Bs + pl * PLB + fb + nr * 64);
+                const u32x2 hi = lds_tr16(Bs + pl * PLB + fb + nr * 64 + 4 * PIB);
+                b[nr][pl] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mr][HA[t]], b[nr][HB[t]], acc[mr][nr], 0, 0, 0);
+    };
+
+    const int KT = (klen + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(cur);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    mma((KT - 1) & 1);
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const long row_pitch = (long)p.R * p.S * p.Cin;
+    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = rbase + (e & 3) + 8 * (e >> 2);
+            if (co >= p.Cout) continue;
+            float *drow = out + co * row_pitch + (long)rs * p.Cin + j0 + brow0 + l31;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
+                float v = (acc[mr][nr][e] * inv_a) * inv_b;
+                if (p.beta && gridDim.z == 1) v += drow[nr * 32];
+                drow[nr * 32] = v;
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
                                      int splits, int beta) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1446,6 +1636,7 @@ int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 ti
                            // bit3: split-bf16 kernels.  -1: built-in default (= 8)
 int g_x3_dbg = 0;
 int g_wgrad_wide = 1;      // 128 x 256 weight-gradient tile when the operands are wide enough
+int g_wgrad_tr_off = 0;    // rcf_conv_set_variant bit 0x80000: the 128 x 256 fp16-pair tile with register transposes
 int g_x3_off = 0;           // debug mask: 1 forward, 2 dgrad, 4 wgrad stay on the fp32-MFMA kernels
 inline bool use_x3(int kind = 0) { return (g_conv_variant < 0 || (g_conv_variant & 8) != 0) && !(g_x3_off & kind); }
 
@@ -1602,6 +1793,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
     g_x3_dbg = v >= 0 ? ((v >> 15) & 1) | ((v >> 17) & 2) : 0;     // 0x8000: loads off; 0x40000: activation loads from a 64 KB window
+    g_wgrad_tr_off = v >= 0 ? (v >> 19) & 1 : 0;
     g_h2_off = v >= 0 ? (v >> 17) & 1 : 0;     // 0x20000: bf16 triples even when the operand ranges are given
     g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
     g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
@@ -1868,7 +2060,8 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (h2) {            // fp16 pairs
-            if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
+            if (pl.nr == 4 && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel, grid, dim3(256), 0, st, p);
+            else if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, p);
             else if (pl.mr == 1 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<1, 2, 2>), grid, dim3(256), 0, st, p);
