@@ -1423,8 +1423,11 @@ __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
+// NR = 4: 128 x 256 tile; NR = 2: 128 x 128 (operands too narrow for the wide tile)
+template <int NR>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
-    constexpr int MR = 2, NR = 4, BM = 128, BN = 256;
+    constexpr int MR = 2, BM = 128, BN = 64 * NR;
+    constexpr int QB = BN / 4, PBS = 256 / QB, NBP = BK / PBS;      // x loader: channel quads per pixel, pixels per pass, passes
     constexpr int PIA = BM * 2 + 32, PIB = BN * 2 + 32;          // row (pixel) pitch of the dy / x planes, bytes
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -1447,15 +1450,15 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
 
     // loader roles.  dy: item t + 256 j (j < 2) = pixel (t >> 5) + 8 j, channel quad t & 31.
-    //                x:  item t + 256 j (j < 4) = pixel (t >> 6) + 4 j, channel quad t & 63.
+    //                x:  item t + 256 j (j < NBP) = pixel t / QB + PBS j, channel quad t % QB.
     const int qa = tid & 31, pa0 = tid >> 5;
-    const int qb = tid & 63, pb0 = tid >> 6;
+    const int qb = tid % QB, pb0 = tid / QB;
     const int cha = i0 + 4 * qa, chb = j0 + 4 * qb;
     const bool acta = cha < p.Cout, actb = chb < p.Cin;
-    int pn[4], py[4], px_[4];
+    int pn[NBP], py[NBP], px_[NBP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long m = kbeg + pb0 + 4 * j;
+    for (int j = 0; j < NBP; ++j) {
+        const long m = kbeg + pb0 + PBS * j;
         pn[j] = (int)(m / HoWo);
         const int pix = (int)(m - (long)pn[j] * HoWo);
         py[j] = pix / p.Wo;
@@ -1464,7 +1467,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     }
     const bool incr = p.Wo >= BK;
 
-    f32x4 ra[2], rb[4];
+    f32x4 ra[2], rb[NBP];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1473,8 +1476,8 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int mk = kt * BK + pb0 + 4 * j;
+        for (int j = 0; j < NBP; ++j) {
+            const int mk = kt * BK + pb0 + PBS * j;
             const int sy = py[j] * p.stride - p.pad + r * p.dil;
             const int sx = px_[j] * p.stride - p.pad + s * p.dil;
             const bool v = actb && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
@@ -1489,7 +1492,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
                 py[j] = wy ? 0 : py[j];
                 pn[j] += wy ? 1 : 0;
             } else {
-                const long mn = kbeg + (long)(kt + 1) * BK + pb0 + 4 * j;
+                const long mn = kbeg + (long)(kt + 1) * BK + pb0 + PBS * j;
                 const int nn = (int)(mn / HoWo);
                 const int pix = (int)(mn - (long)nn * HoWo);
                 pn[j] = nn - n_first;
@@ -1511,10 +1514,10 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
             *reinterpret_cast<u32x2 *>(d + PLA) = m;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NBP; ++j) {
             u32x2 h, m;
             split2h(rb[j], sb, h, m);
-            char *d = Bs + (pb0 + 4 * j) * PIB + qb * 8;
+            char *d = Bs + (pb0 + PBS * j) * PIB + qb * 8;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PLB) = m;
         }
@@ -2060,7 +2063,8 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (h2) {            // fp16 pairs
-            if (pl.nr == 4 && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel, grid, dim3(256), 0, st, p);
+            if (pl.nr == 4 && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel<4>, grid, dim3(256), 0, st, p);
+            else if (pl.mr == 2 && pl.nr == 2 && !region && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel<2>, grid, dim3(256), 0, st, p);
             else if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, p);
