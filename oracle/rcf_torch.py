@@ -507,12 +507,11 @@ class RCFModel(nn.Module):
         if self.decode_head2_ema is not None:
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
 
-    def train(self, mode=True):
-        super().train(mode)
-        for m in (self.backbone2_ema, self.decode_head2_ema):
-            if m is not None:
-                m.eval()
-        return self
+    # NOTE: like the reference, there is NO train() override: the EMA copies are put in eval mode once, at
+    # construction (models/rcf_model.py:171,187), and a later `model.train()` -- which Lightning issues on the whole
+    # module tree before fitting and after every validation run -- switches them to training mode with everything
+    # else: under main.py the teacher of stage 2.1 normalises with BATCH statistics (and updates its own running
+    # statistics, and draws its own Dropout2d mask).  Pinned by tests/golden/make_golden_stage2.py.
 
     def resize(self, x, shape):
         return resize_bilinear(x, shape, self.align_corners)

@@ -18,7 +18,8 @@ def make_norm(norm_cfg, n):
     t = (norm_cfg or {}).get("type", "BN")
     if t not in ("BN", "SyncBN"):
         raise NotImplementedError(f"norm type {t}")
-    return BatchNorm2d(n, requires_grad=bool((norm_cfg or {}).get("requires_grad", True)))
+    # 'BN' keeps per-rank statistics under data parallelism (torch BatchNorm2d inside DDP), 'SyncBN' exchanges them
+    return BatchNorm2d(n, requires_grad=bool((norm_cfg or {}).get("requires_grad", True)), sync=(t == "SyncBN"))
 
 
 class Downsample(nn.Module):

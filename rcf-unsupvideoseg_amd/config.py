@@ -102,6 +102,16 @@ def stage21_model_kwargs(mask_size=(120, 214), dropout=0.1, norm="SyncBN", refin
     return kw
 
 
+def stage22_model_kwargs(mask_size=(120, 214), dropout=0.1, norm="SyncBN"):
+    """configs/rcf/rcf_stage2.2.yaml:63-78 on top of stage 1: pseudo-label loss (w_seg 0.1, w_pl 2, pos/neg weights 2/1)
+    against the exported stage-2.1 masks; the EMA copies are still created (and updated) but feed no loss"""
+    kw = stage1_model_kwargs(mask_size, dropout=dropout, norm=norm)
+    kw.update(w_seg=0.1, w_entropy=0, w_pl=2.0, pl_pos_weight=2.0, pl_neg_weight=1.0)
+    kw["backbone2"]["create_ema"] = True
+    kw["decode_head2"]["create_ema"] = True
+    return kw
+
+
 def mask_size_for(H, W):
     """spatial size after the 7x7/2 stem and the 3x3/2 max-pool."""
     h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -109,6 +119,8 @@ def mask_size_for(H, W):
 
 
 VARIANTS = ("fbms", "stv2", "sharpen_kl", "sharpen_obj", "joint", "compact_obj", "mask_resize", "freeze")
+# stage 2.1 / 2.2 (models/rcf_model.py:380-408,490-529): these also need pl_masks in the batch / a CRF binding
+STAGE2_VARIANTS = ("stage21", "stage22", "stage22_soft")
 
 
 def variant_model_kwargs(name, H, W, norm="BN"):
@@ -146,6 +158,16 @@ def variant_model_kwargs(name, H, W, norm="BN"):
         small = (ms[0] * 3 // 4, ms[1] * 3 // 4)
         kw = stage1_model_kwargs(small, dropout=0.0, norm=norm)
         kw["allow_mask_resize"] = True
+    elif name == "stage21":
+        # configs/rcf/rcf_stage2.1.yaml: CRF self-labels from the EMA teacher; 5 mean-field iterations (BASELINE configs[3])
+        kw = stage21_model_kwargs(ms, dropout=0.0, norm=norm, refine_iters=5)
+        oc = 1
+    elif name in ("stage22", "stage22_soft"):
+        # configs/rcf/rcf_stage2.2.yaml: pseudo-label loss, thresholded at pl_mask_pos_th (default 0.35) or soft (-1)
+        kw = stage22_model_kwargs(ms, dropout=0.0, norm=norm)
+        if name == "stage22_soft":
+            kw["pl_mask_pos_th"] = -1
+        oc = 2
     elif name == "freeze":
         kw = stage1_model_kwargs(ms, dropout=0.0, norm=norm)                 # freeze_backbone (models/rcf_model.py:107-110)
         kw["freeze_backbone"] = True

@@ -8,15 +8,14 @@ Same constructor keywords / state-dict keys as the reference head.  The training
 (`loss_and_grads`) runs on the hand-written kernels of csrc/flowhead.hip (softmax, segment pooling,
 MLP, fp64 affine least squares, reconstruction + loss, analytic backward) plus the implicit-GEMM conv
 kernels for the two 3x3 flow-feature convs; the sharpen and compactness losses are part of the same
-kernels.  A plain-torch evaluation of the flow maths is kept only for the stand-alone `forward()`
-surface of the reference head (already-softmaxed NCHW masks in, visualisation flows out), which
-RCFModel's training step does not use.
+kernels.  The stand-alone `forward()` surface of the reference head (already-softmaxed NCHW masks in,
+visualisation flows out) runs on the same kernels; there is no second, plain-torch implementation.
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+import torch.nn.functional as F          # softmax of the evaluation masks only
 
 from . import _lib, ops
 from ._lib import FlowHeadCfg
@@ -158,9 +157,11 @@ class FlowAggregationHeadWithResidual(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)    # lives across fwd -> bwd
         return self._ws, need
 
-    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I):
+    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I, want_flows=False):
         """Returns (losses, seed): seed(scale) writes d(scale*loss)/d logits and /d res into the Acts and
-        accumulates this head's parameter gradients."""
+        accumulates this head's parameter gradients.  want_flows: also keep the reconstructed flows (overall,
+        aggregated, residual adjustment, affine; [2B,2,h,w] per direction image) and the softmax masks in
+        `self.last_flows` (the reference head returns them for its visualisations, :370-399)."""
         assert I == 2, "Other im_num not implemented"
         C, (h, w) = self.mask_layer, self.mask_size
         dev = logits.t.device
@@ -193,8 +194,18 @@ class FlowAggregationHeadWithResidual(nn.Module):
         t0 = targets[0][1] if len(targets) > 0 else None
         t1 = targets[1][1] if len(targets) > 1 else None
         l5 = torch.empty(8, dtype=torch.float32, device=dev)
+        fl = {}
+        if want_flows:
+            fl = {k: torch.zeros((B * I, 2, h, w), dtype=torch.float32, device=dev) for k in ("pred", "agg", "adj", "aff")}
+            fl["masks"] = torch.empty((B * I, C, h, w), dtype=torch.float32, device=dev)
         _lib.call("rcf_flowhead_fwd_f32", cfg, _p(logits.t), _p(feat), _p(R), _p(l1.weight), _p(l1.bias), _p(l2.weight),
-                  _p(l2.bias), _p(t0), _p(t1), _p(l5), None, None, None, None, None, _p(ws), need, st)
+                  _p(l2.bias), _p(t0), _p(t1), _p(l5), _p(fl.get("masks")), _p(fl.get("pred")), _p(fl.get("agg")),
+                  _p(fl.get("adj")), _p(fl.get("aff")), _p(ws), need, st)
+        if want_flows:
+            # the clamped ground-truth flows as the kernels saw them: channels 0..1 of the padded conv input
+            fl["gt"] = ops.nhwc_to_nchw(flow4, 2)
+            fl["l5"] = l5
+            self.last_flows = fl
         seg = l5[0] + l5[1]
         losses = {"loss_warp_seg": seg}
         loss = seg * model.w_seg
@@ -235,75 +246,30 @@ class FlowAggregationHeadWithResidual(nn.Module):
             ops.colsum(da1, _param_grad(c1.bias), beta=1)
         return losses, seed
 
-    # ================================================================ plain-torch evaluation (off the hot path)
-    def _coord_map(self, device):
-        H, W = self.mask_size
-        yy, xx = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
-        cols = [yy, xx] + ([yy * yy, xx * xx, yy * xx] if self.quadratic else [])
-        return torch.stack(cols, dim=2).view(H * W, -1).float()
-
-    def _affine(self, mask, flow):
-        B, C, H, W = mask.shape
-        w = (mask / mask.sum(dim=(2, 3), keepdim=True)).flatten(2)
-        Fu = flow.flatten(2).permute(0, 2, 1)
-        om = self._coord_map(mask.device)
-        mu_F, mu_o = torch.bmm(w, Fu), w @ om
-        Fd, od = Fu[:, None] - mu_F[:, :, None], om[None, None] - mu_o[:, :, None]
-        S_Fo = torch.einsum("bcp,bcpk,bcpl->bckl", w, Fd, od)
-        S_oo = torch.einsum("bcp,bcpk,bcpl->bckl", w, od, od)
-        A = torch.linalg.solve(S_oo.float(), S_Fo.permute(0, 1, 3, 2).float()).permute(0, 1, 3, 2)
-        pred = torch.einsum("bcjk,bclk->bclj", A, od).view(B, C, H, W, 2)
-        return torch.einsum("bchw,bchwl->blhw", mask, pred)
-
-    def _features_torch(self, flow):
-        c1, c2 = self.flow_feat_before_agg[0], self.flow_feat_before_agg[2]
-        x = F.leaky_relu(F.conv2d(flow, c1.weight, c1.bias, padding=c1.padding), 0.1)
-        return F.leaky_relu(F.conv2d(x, c2.weight, c2.bias, padding=c2.padding), 0.1)
-
-    def _aggregate(self, mask, flow, residual):
-        B, C, H, W = mask.shape
-        mhat = mask / mask.flatten(2).sum(dim=2).view(B, C, 1, 1)
-        feat = self._features_torch(flow)
-        assert feat.shape[2:] == mask.shape[2:], f"{feat.shape[2:]} != {mask.shape[2:]}"
-        l1, l2 = self.flow_feat_after_agg[0], self.flow_feat_after_agg[2]
-        pooled = torch.einsum("bkhw,bchw->bkc", feat, mhat)
-        u = F.conv1d(F.leaky_relu(F.conv1d(pooled, l1.weight, l1.bias), 0.1), l2.weight, l2.bias)
-        agg = torch.einsum("bdc,bchw->bdhw", u, mask)
-        affine = self._affine(mask, flow) if self.free_residual_with_affine else None
-        if self.allow_residual_resize and tuple(residual.shape[-2:]) != self.mask_size:
-            residual = F.interpolate(residual, self.mask_size, mode="bilinear")
-        r = residual.unflatten(1, (2, self.mask_layer))
-        if self.free_residual_with_affine or self.residual_adjustment_scale != -1.:
-            adj = (torch.tanh(r / self.pred_div_coeff) * mask[:, None]).sum(dim=2) * self.residual_adjustment_scale
-        else:
-            adj = (r * mask[:, None]).sum(dim=2)
-        overall = agg + adj if affine is None else agg + affine + adj
-        return overall, agg, adj, affine
-
-    def _flow_loss(self, gt, pred):
-        d = (gt - pred).abs().view(-1)
-        return ((d + self.eps) ** self.q).mean() if self.outlier_robust_loss else d.mean()
-
-    def flow_losses(self, masks, gfw, gbw, res_fw, res_bw):
-        clamp = (lambda f: f.clamp(min=-self.clamp_flow_t, max=self.clamp_flow_t)) if self.clamp_flow_t is not None \
-            else (lambda f: f)
-        gt_fw, gt_bw = clamp(gfw[:, 0]), clamp(gbw[:, 0])
-        fw = self._aggregate(masks[:, 0], gt_fw, res_fw)
-        bw = self._aggregate(masks[:, 1], gt_bw, res_bw)
-        l_fw, l_bw = self._flow_loss(gt_fw, fw[0]), self._flow_loss(gt_bw, bw[0])
-        return {"seg_fw": l_fw, "seg_bw": l_bw, "seg": l_fw + l_bw}, (fw, bw, gt_fw, gt_bw)
-
+    # ================================================================ stand-alone nn.Module surface
     def forward(self, imgs, masks, gt_fw_flows, gt_bw_flows, res_fw, res_bw):
-        """nn.Module surface of the reference head (NCHW tensors, masks already softmaxed):
-        (flows dict, loss dict).  Plain torch, differentiable; not used by RCFModel's training step."""
+        """nn.Module surface of the reference head (models/flow_aggregation_head_with_residual.py:312-399; NCHW
+        tensors, masks ALREADY softmaxed [B,2,C,h,w]): (flows dict of normalised [B,4,h,w] visualisation flows,
+        loss dict seg / seg_fw / seg_bw).  Runs on the same HIP kernels as the training step (softmax(log p) = p);
+        inference only -- the training step differentiates through loss_and_grads, not through this."""
+        import types
+        from .layers import Act
         assert imgs.shape[1] == 2, "Other im_num not implemented"
-        loss, (fw, bw, gt_fw, gt_bw) = self.flow_losses(masks, gt_fw_flows, gt_bw_flows, res_fw, res_bw)
+        B, I, C, h, w = masks.shape
+        lg = torch.log(masks.detach().float().clamp_min(1e-30)).reshape(B * I, C, h, w).contiguous()
+        logits = Act(ops.nchw_to_nhwc(lg), needs_grad=False)
+        res = Act(ops.nchw_to_nhwc(torch.cat([res_fw, res_bw], dim=1).detach().float().contiguous()), needs_grad=False)
+        model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.0, w_pl=0, w_crf=0, compactness_head=None, w_sharpen=0,
+                                      t_sharpen=0.25, object_aware_sharpening=False,
+                                      args=types.SimpleNamespace(object_channel=None))
+        losses, _ = self.loss_and_grads(model, logits, res, gt_fw_flows.float(), gt_bw_flows.float(), {}, B, I,
+                                        want_flows=True)
+        f = self.last_flows
+        s = torch.tensor([h / 2.0, w / 2.0], dtype=torch.float32, device=masks.device).view(1, 1, 2, 1, 1)
 
-        def vis(a, b):                               # get_norm_flow :18-30
-            h, w = a.shape[-2:]
-            s = torch.tensor([h / 2.0, w / 2.0], dtype=a.dtype, device=a.device).view(1, 2, 1, 1)
-            return torch.cat([a / s, b / s], dim=1)
-        flows = {"gt_flow": [vis(gt_fw, gt_bw)], "pred_flow": [vis(fw[0], bw[0])], "agg_flow": [vis(fw[1], bw[1])],
-                 "residual_adj": [vis(fw[2], bw[2])],
-                 "affine_flow": [vis(fw[3], bw[3])] if fw[3] is not None else []}
-        return flows, loss
+        def vis(t):                                   # get_norm_flow :18-30; direction images n = 2b + d -> [B,4,h,w]
+            return (t.view(B, 2, 2, h, w) / s).reshape(B, 4, h, w)
+        flows = {"gt_flow": [vis(f["gt"])], "pred_flow": [vis(f["pred"])], "agg_flow": [vis(f["agg"])],
+                 "residual_adj": [vis(f["adj"])],
+                 "affine_flow": [vis(f["aff"])] if self.free_residual_with_affine else []}
+        return flows, {"seg_fw": f["l5"][0], "seg_bw": f["l5"][1], "seg": f["l5"][0] + f["l5"][1]}

@@ -228,9 +228,10 @@ class BatchNorm2d(nn.Module):
     """(Sync)BatchNorm2d, eps 1e-5, momentum 0.1, with fused ReLU / residual add / Dropout2d scale.
     Same parameter and buffer names as torch's (state-dict compatible)."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1, requires_grad=True):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, requires_grad=True, sync=True):
         super().__init__()
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.sync = sync                 # SyncBN: statistics over the global batch (every rank holds the same number of rows)
         self.weight = nn.Parameter(torch.ones(num_features), requires_grad=requires_grad)
         self.bias = nn.Parameter(torch.zeros(num_features), requires_grad=requires_grad)
         self.register_buffer("running_mean", torch.zeros(num_features))
@@ -239,6 +240,8 @@ class BatchNorm2d(nn.Module):
 
     def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None):
         xt = x.t
+        if not self.sync:
+            dist = None
         if self.training:
             local_rows = xt.shape[0] * xt.shape[1] * xt.shape[2]
             sums = x.stats if x.stats is not None else ops.bn_stats(xt)

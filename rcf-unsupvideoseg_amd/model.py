@@ -36,17 +36,46 @@ def _item(v):
 
 
 class _TapeBackward(torch.autograd.Function):
-    """Bridges `losses['loss'].backward()` (what main.py / Lightning call) to the HIP tape."""
+    """Bridges `losses['loss'].backward()` (what main.py / Lightning call) to the HIP tape.
+
+    The trainable parameters are INPUTS of this node and their gradients are its outputs, so autograd's own
+    AccumulateGrad nodes run for every parameter -- which is where torch's DistributedDataParallel hangs its
+    bucket hooks (Lightning strategy `ddp_find_unused_parameters_false`, main.py:453-455): under the unchanged
+    main.py the gradients are all-reduced by DDP, every parameter receives one every step, and
+    torch.optim.Adam (main.py:299-307) sees ordinary `.grad` tensors."""
 
     @staticmethod
-    def forward(ctx, anchor, loss_value, model):
-        ctx.model = model
+    def forward(ctx, loss_value, model, *params):
+        ctx.model, ctx.n = model, len(params)
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.model.run_backward(grad_out)
-        return None, None, None
+        model = ctx.model
+        params = [p for p in model.parameters() if p.requires_grad]
+        assert len(params) == ctx.n, "the set of trainable parameters changed between forward and backward"
+        # the tape accumulates into p.grad: point every p.grad at a view of one fresh zero-filled flat buffer for the
+        # duration of the tape, hand those views to autograd, and put the user's .grad tensors back
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=params[0].device)
+        saved, views, off = [], [], 0
+        for p, n in zip(params, sizes):
+            chunk = flat[off:off + p.numel()]
+            if p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous():      # channels_last conv weight
+                co, ci, r, s = p.shape
+                v = chunk.view(co, r, s, ci).permute(0, 3, 1, 2)
+            else:
+                v = chunk.view(p.shape)
+            saved.append(p.grad)
+            p.grad = v
+            views.append(v)
+            off += n
+        try:
+            model.run_backward(grad_out)
+        finally:
+            for p, g in zip(params, saved):
+                p.grad = g
+        return (None, None) + tuple(views)
 
 
 @torch.no_grad()
@@ -136,17 +165,14 @@ class RCFModel(nn.Module):
             copy_param_and_buffer(self.backbone2, self.backbone2_ema)
         if self.decode_head2_ema is not None:
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
-        self._tape, self._root_grads, self._anchor = None, None, None
+        self._tape = None
         self.dist = None
         self.grad_ready_hook = None      # callable(group) set by the trainer: "heads", "layer4" ... "layer1", "stem"
 
     # ------------------------------------------------------------------ plumbing
-    def train(self, mode=True):
-        super().train(mode)
-        for m in (self.backbone2_ema, self.decode_head2_ema):
-            if m is not None:
-                m.eval()
-        return self
+    # No train() override, like the reference: the EMA copies are set to eval mode once, at construction
+    # (models/rcf_model.py:171,187); `model.train()` -- Lightning calls it on the whole module tree -- switches them to
+    # training mode with everything else, so under main.py the stage-2.1 teacher runs with batch statistics.
 
     def _dist(self):
         if self.dist is None:
@@ -180,6 +206,9 @@ class RCFModel(nn.Module):
             # the EMA teacher's forward + CRF need only the images: run them on the second stream beside the student's
             # forward (its HBM-bound BN passes and the teacher's MFMA-bound convs fill each other's gaps)
             crf_side = layers._side_stream(img.t.device)
+            if layers.FP16_PAIRS:
+                img.range()      # on THIS stream, before the fork: teacher and student stems share the cached range
+            ops.reserve_amax(img.t.device, 512)     # the teacher's range slots: zero-filled before the fork as well
             crf_side.wait_stream(torch.cuda.current_stream(img.t.device))
             with torch.cuda.stream(crf_side):
                 crf_early = self._crf_targets(img, imgs, None, B, I)
@@ -221,15 +250,14 @@ class RCFModel(nn.Module):
             self, logits, res, gfw.view(B, nf, 2, *self.mask_size), gbw.view(B, nf, 2, *self.mask_size), extra, B, I)
         self._seed_backward = seed
         self._tape = tape
+        self.last_targets = extra        # the pl / crf targets at mask size that entered the loss (tests look at them)
         if self.backbone2_ema is not None:
             momentum_update_param_and_buffer(self.backbone2, self.backbone2_ema, self.ema_m)
         if self.decode_head2_ema is not None:
             momentum_update_param_and_buffer(self.decode_head2, self.decode_head2_ema, self.ema_m)
         self.train_iter += 1
         if torch.is_grad_enabled():
-            if self._anchor is None or self._anchor.device != losses["loss"].device:
-                self._anchor = torch.zeros((), device=losses["loss"].device, requires_grad=True)
-            losses["loss"] = _TapeBackward.apply(self._anchor, losses["loss"], self)
+            losses["loss"] = _TapeBackward.apply(losses["loss"], self, *[p for p in self.parameters() if p.requires_grad])
         return losses
 
     @torch.no_grad()
@@ -238,7 +266,8 @@ class RCFModel(nn.Module):
         oc = self.args.object_channel
         if self.crf_use_ema:
             t = Tape(enabled=False)
-            le = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img_act, t), t)
+            d = self._dist()             # in training mode (after model.train()) the teacher's SyncBN exchanges statistics too
+            le = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img_act, t, d), t, d)
         else:
             le = logits
         h, w = le.t.shape[1:3]

@@ -138,6 +138,15 @@ def new_amax(device):
     return pool[0][i:i + 1]
 
 
+def reserve_amax(device, n):
+    """make sure the next `n` new_amax slots come from a pool that was zero-filled on the CURRENT stream (call before
+    forking work to another stream: a pool refilled over there would be zeroed in that stream's order only)"""
+    key = torch.device(device).index or 0
+    pool = _amax_pool.get(key)
+    if pool is None or pool[1] + n > pool[0].numel():
+        _amax_pool[key] = [torch.zeros(8192, dtype=torch.int32, device=device), 0]
+
+
 def absmax(x, out=None):
     """int32 [1] on the device: raw fp32 bits of max |x| (x: NHWC activation, possibly a channel slice, or any
     contiguous fp32 tensor).  `out` accumulates (max with its current content)."""

@@ -116,6 +116,12 @@ def soft_blob_mask(H, W, seed):
     return (1.0 / (1.0 + np.exp((d - 1.0) * 6.0))).astype(np.float32)
 
 
+def make_pl_masks(B, H, W, config_id=1, first_index=0):
+    """batch['pl_masks'] of stage 2.2 (dataset/data.py:137-151): one soft mask in [0,1] per frame, 2 x [B,H,W]"""
+    return [np.stack([soft_blob_mask(H, W, 1000 * config_id + first_index + i + 7000 * (f + 1)) for i in range(B)])
+            for f in range(2)]
+
+
 def fill_state_dict(shapes, seed=7, bn3_gamma=0.5, seg_scale=10.0):
     """Seeded weights for every entry of a state-dict `shapes` mapping name -> shape.
 

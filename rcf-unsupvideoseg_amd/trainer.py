@@ -81,7 +81,7 @@ class FlatParams:
 
 class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, epochs=200, power=0.9, min_lr=1e-6, device="cuda:0",
-                 betas=(0.9, 0.999), eps=1e-8):
+                 betas=(0.9, 0.999), eps=1e-8, force_group=False):
         self.model = model.to(device)
         self.device = torch.device(device)
         self.fp = FlatParams(self.model, self.device)
@@ -91,7 +91,14 @@ class Trainer:
         self.betas, self.eps = betas, eps
         self.epoch, self.step_count = 0, 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.ranges = self.fp.group_ranges(self.model) if self.world > 1 else None
+        # force_group: run the chunked asynchronous all-reduce path even with one rank (a dry run of the RCCL code path
+        # on a single GPU: tests/test_dist_gpu.py)
+        self.chunked = self.world > 1 or (force_group and dist.is_available() and dist.is_initialized())
+        self.ranges = self.fp.group_ranges(self.model) if self.chunked else None
+        # The gradient chunks travel on their OWN communicator: with one process group the asynchronous 10-60 MB chunk
+        # all-reduces and the small synchronous SyncBN all-reduces of the layers still in backward would share one
+        # RCCL stream in issue order, and every statistics exchange would queue behind the chunk before it.
+        self.grad_group = dist.new_group() if self.chunked else None
         self._pending, self._done = [], set()
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
             self.model.grad_ready_hook = self._grads_ready
@@ -102,7 +109,8 @@ class Trainer:
         if r is None or group in self._done:
             return
         self._done.add(group)
-        self._pending.append(dist.all_reduce(self.fp.grad[r[0]:r[1]], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append(dist.all_reduce(self.fp.grad[r[0]:r[1]], op=dist.ReduceOp.SUM, group=self.grad_group,
+                                             async_op=True))
 
     def lr(self):
         return self.base_lr * poly_lr_factor(self.epoch, self.epochs, self.power, self.base_lr, self.min_lr)
@@ -116,9 +124,9 @@ class Trainer:
             losses = self.model(batch)
         self._pending, self._done = [], set()
         self.model.run_backward()
-        if self.world > 1:
+        if self.chunked:
             if self.ranges is None or not hasattr(self.model, "grad_ready_hook"):
-                dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
+                dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.grad_group)
             else:
                 for g in self.ranges:                           # groups whose mark did not fire (e.g. a frozen path)
                     self._grads_ready(g)

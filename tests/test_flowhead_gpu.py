@@ -45,9 +45,19 @@ def test_flow_head_vs_reference_golden(tag, golden_dir, report):
     gfw, gbw = torch.from_numpy(fx["gfw"]).to(DEV), torch.from_numpy(fx["gbw"]).to(DEV)
     for p in head.parameters():
         p.grad = None
-    losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {}, B, 2)
+    losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {}, B, 2, want_flows=True)
     seed(1.0)
     e = {"seg": rel(float(losses["loss_warp_seg"]), float(fx["seg"]))}
+    # the head's outputs themselves (reference: flows dict of models/flow_aggregation_head_with_residual.py:370-399,
+    # normalised [B,4,h,w]) through the nn.Module surface, which runs the same kernels on softmax(log p) = p
+    masks = torch.softmax(torch.from_numpy(fx["logits"]), dim=2).to(DEV)
+    flows, lf = head(torch.zeros(B, 2, 3, 4, 4, device=DEV), masks, gfw, gbw, torch.from_numpy(fx["rfw"]).to(DEV),
+                     torch.from_numpy(fx["rbw"]).to(DEV))
+    for k in ("pred_flow", "agg_flow", "residual_adj", "affine_flow"):
+        if "flow_" + k in fx:
+            e["flow." + k] = rel(flows[k][0].cpu().numpy(), fx["flow_" + k])
+    e["seg_surface"] = rel(float(lf["seg"]), float(fx["seg"]))
+    e["masks"] = rel(head.last_flows["masks"].cpu().numpy().reshape(B, 2, C, h, w), masks.cpu().numpy())
     e["dlogits"] = rel(ops.nhwc_to_nchw(logits.grad, C).cpu().numpy().reshape(B, 2, C, h, w), fx["dlogits"])
     dres = ops.nhwc_to_nchw(res.grad).cpu().numpy()
     e["dres_fw"], e["dres_bw"] = rel(dres[:, :2 * C], fx["dres_fw"]), rel(dres[:, 2 * C:], fx["dres_bw"])
@@ -61,7 +71,7 @@ def test_flow_head_vs_reference_golden(tag, golden_dir, report):
 
 
 def test_flow_head_entropy_and_targets_vs_torch(report):
-    """entropy (double softmax) and pl / crf target terms: HIP tail vs torch autograd of the same formulas"""
+    """entropy (double softmax) and pl / crf target terms with an upstream gradient scale: HIP tail vs the oracle head"""
     import torch.nn.functional as F
     g = np.random.Generator(np.random.PCG64(5))
     B, C, h, w = 2, 4, 20, 28
@@ -83,14 +93,20 @@ def test_flow_head_entropy_and_targets_vs_torch(report):
         p.grad = None
     losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {"pl_masks": pl, "crf_masks": crf}, B, 2)
     seed(0.5)                                           # an upstream scale, like loss.backward(gradient=0.5)
-    # torch reference of the same tail
-    l = torch.from_numpy(lg).to(DEV).requires_grad_(True)
-    r = torch.from_numpy(rs).to(DEV).requires_grad_(True)
+    # reference of the same tail: the ORACLE head (pinned to the reference, tests/test_oracle_cpu.py) on the CPU with this
+    # head's weights, torch autograd
+    import rcf_torch as orc
+    ohead = orc.FlowAggregationHeadWithResidual(args=None, create_flownet=True, mask_layer=C, mask_size=(h, w),
+                                                clamp_flow_t=20., free_residual=True, allow_residual_resize=True)
+    ohead.load_state_dict({k: v.detach().cpu().contiguous() for k, v in head.state_dict().items()})
+    l = torch.from_numpy(lg).requires_grad_(True)
+    r = torch.from_numpy(rs).requires_grad_(True)
     p = F.softmax(l.view(B, 2, C, h, w), dim=2)
-    lf, _ = head.flow_losses(p, gfw, gbw, r[:, :2 * C], r[:, 2 * C:])
+    _, lf = ohead(torch.zeros(B, 2, 3, 4, 4), p, gfw.cpu(), gbw.cpu(), r[:, :2 * C], r[:, 2 * C:])
     ent = -(p * F.log_softmax(p, dim=2)).sum(dim=2).mean()
+    pl, crf = pl.cpu(), crf.cpu()
 
-    def asym(t, pred, wp, wn):
+    def asym(t, pred, wp, wn):                          # models/rcf_model.py:380-408 (pinned by the stage-2 goldens)
         d = t - pred
         return (d.clamp(min=0) ** 2).mean() * wp + (d.clamp(max=0) ** 2).mean() * wn
     lpl = asym((pl > 0.35).float(), p[:, :, 2], 2.0, 1.0)

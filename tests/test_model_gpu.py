@@ -129,12 +129,17 @@ def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
         # evaluations whose parameters differ by one unit in the last place -- tools/h2_lottery.py).  Backward
         # stability is the criterion: the result must be the float64 truth's, to the limit, for SOME input within one
         # ulp of the given one, and within 10x the limit for all of them.
-        worst = dict(e_grad)
+        worst, first = dict(e_grad), dict(e_grad)
         for seed in (1, 2, 3, 4):
             e_s = _sampled_grad_errors_ulp(H, W, affine, B, fx, seed)
             e_grad = {k: min(e_grad[k], e_s[k]) for k in e_grad}
             worst = {k: max(worst[k], e_s[k]) for k in worst}
-        report(f"{tag}: sampled gradients over 1-ulp parameter perturbations: best {e_grad} worst {worst}")
+        import warnings
+        marker = (f"ONE-ULP-CRITERION USED [{tag}]: the plain run missed the sampled-gradient limit on "
+                  f"{[k for k in worst if not first[k] < lim_grad[k]]}; best of 5 one-ulp-perturbed runs {e_grad}, worst {worst}")
+        report(marker)
+        warnings.warn(marker)
+        print(marker)
         assert all(worst[k] < 10 * lim_grad[k] for k in worst), (worst, lim_grad)
     assert all(e_grad[k] < lim_grad[k] for k in e_grad), (e_grad, lim_grad)
     # the first Adam step is sign-like (g / (|g| + 1e-8)): fp32 noise on near-zero gradients flips +-lr updates,

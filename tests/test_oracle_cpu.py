@@ -108,3 +108,55 @@ def test_oracle_crf_head_prefix_lr_table_ema(golden_dir):
     orc.momentum_update_param_and_buffer(src, dst, 0.999)
     for k, v in dst.state_dict().items():
         assert np.array_equal(v.numpy(), ema[k.replace(".", "_")]), k    # incl. the int64 truncation quirk
+
+
+@pytest.mark.parametrize("variant", list(config.STAGE2_VARIANTS))
+def test_oracle_stage2_vs_reference_golden(variant, golden_dir):
+    """stage 2.1 (EMA teacher -> CRF self-labels) and 2.2 (pseudo labels) against the numbers the REFERENCE produced
+    (tests/golden/make_golden_stage2.py; torchcrf_cpp.crf_soft bound to oracle/crf_ref.c on both sides): losses,
+    the FFI operands, the CRF / pl targets fed to the loss, gradient norms, the EMA copies after the update.
+    Note the teacher runs in TRAINING mode after model.train(), as in the reference (no train() override there)."""
+    import crf_oracle
+    fx = json.load(open(os.path.join(golden_dir, "stage2.json")))[variant]
+    arr = np.load(os.path.join(golden_dir, "stage2.npz"))
+    H, W, B = fx["H"], fx["W"], fx["B"]
+    kw, oc = config.variant_model_kwargs(variant, H, W)
+    assert oc == fx["object_channel"]
+    calls = []
+
+    def crf_soft(img, UU, *rest):
+        m = crf_oracle.crf_soft_torch(img, UU, *rest)
+        calls.append((img.numpy().copy(), UU.numpy().copy(), m.numpy().copy()))
+        return m
+    if "crf_head" in kw:
+        kw["crf_head"]["crf_soft"] = crf_soft
+    args = _args()
+    args.object_channel = oc
+    m = orc.RCFModel(args, **copy.deepcopy(kw))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=fx["weight_seed"]).items()})
+    nb = synth.make_batch(B, H, W, config_id=fx["config_id"])
+    batch = {k: [torch.from_numpy(np.ascontiguousarray(x)) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+    batch["pl_masks"] = [torch.from_numpy(a) for a in synth.make_pl_masks(B, H, W, config_id=fx["config_id"])]
+    m.train()
+    assert m.backbone2_ema.training and m.decode_head2_ema.training
+    losses = m(batch)
+    losses["loss"].backward()
+    assert sorted(k for k in losses if "loss" in k) == sorted(fx["loss"])
+    for k, v in fx["loss"].items():
+        assert rel(losses[k].item(), v) < 1e-5, k
+    if fx["crf_calls"]:
+        assert len(calls) == fx["crf_calls"]
+        assert np.array_equal(np.stack([c[0] for c in calls]), arr[variant + "_crf_img_u8"])
+        assert rel(np.stack([c[1] for c in calls]), arr[variant + "_crf_unary"]) < 1e-6
+        assert np.array_equal(np.stack([c[2] for c in calls]).astype(np.uint8), arr[variant + "_crf_map"])
+        assert rel(losses["_crf_masks"].numpy(), arr[variant + "_crf_target"]) < 1e-6
+    gn = {}
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in fx["gradnorm"].items():
+        assert rel(np.sqrt(gn[k]), v) < 1e-4, k
+    sd = m.state_dict()
+    for k in fx["ema_keys"]:
+        assert np.array_equal(sd[k].numpy(), arr[variant + "_ema_" + k.replace(".", "_")]), k
