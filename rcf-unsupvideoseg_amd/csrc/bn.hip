@@ -153,11 +153,12 @@ __device__ __forceinline__ void block_amax(unsigned mx, unsigned *__restrict__ a
     if (threadIdx.x == 0) atomicMax(amax, max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3])));
 }
 
+template <typename XT>
 struct StatsOp {
-    const float *x;
+    const XT *x;
     int pitch;
     __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * pitch + c4);
+        const f32x4 v = ld4(x + r * pitch + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             a[e] = v[e];
@@ -166,14 +167,19 @@ struct StatsOp {
     }
 };
 
+// XT: storage type of the conv-output side (x, dx); YT: of the activation side (y, dy, residual, dres)
+template <typename XT, typename YT>
 struct BwdOp {
-    const float *dy, *x, *y, *mean, *invstd, *scale;
+    const YT *dy;
+    const XT *x;
+    const YT *y;
+    const float *mean, *invstd, *scale;
     int dy_pitch, x_pitch, y_pitch, relu, C;
     long rows_per_image;
     const unsigned char *mask;     // [rows][C/4]: bit e = output c4+e was positive (replaces the read of y)
     __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        f32x4 g = ld4(dy + r * dy_pitch + c4);
+        const f32x4 xv = ld4(x + r * x_pitch + c4);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
         if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
@@ -182,7 +188,7 @@ struct BwdOp {
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
         } else if (relu) {
-            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
+            const f32x4 yv = ld4(y + r * y_pitch + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
         }
@@ -216,9 +222,10 @@ __global__ void invstd_from_var_kernel(const float *__restrict__ var, int C, flo
     if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__ x, int x_pitch,
-                                                       const float *__restrict__ res, int r_pitch,
-                                                       float *__restrict__ y, int y_pitch, long rows, int C,
+template <typename XT, typename YT>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x, int x_pitch,
+                                                       const YT *__restrict__ res, int r_pitch,
+                                                       YT *__restrict__ y, int y_pitch, long rows, int C,
                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int relu, const float *__restrict__ scale, long rows_per_image,
@@ -231,7 +238,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        const f32x4 xv = ld4(x + r * x_pitch + c4);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
@@ -239,14 +246,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
-        if (res) o += *reinterpret_cast<const f32x4 *>(res + r * r_pitch + c4);
+        if (res) o += ld4(res + r * r_pitch + c4);
         if (relu) {
             if (mask) mask[i] = (unsigned char)((o[0] > 0.f) | ((o[1] > 0.f) << 1) | ((o[2] > 0.f) << 2) | ((o[3] > 0.f) << 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
         }
         if (scale) o *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
-        *reinterpret_cast<f32x4 *>(y + r * y_pitch + c4) = o;
+        st4(y + r * y_pitch + c4, o);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float f = o[e];
@@ -256,9 +263,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *__restrict__
     if (amax) block_amax(mx, amax);
 }
 
+template <typename XT, typename YT>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
-    const float *__restrict__ dy, int dy_pitch, const float *__restrict__ x, int x_pitch, const float *__restrict__ y,
-    int y_pitch, float *__restrict__ dx, int dx_pitch, float *__restrict__ dres, int dres_pitch, int res_beta,
+    const YT *__restrict__ dy, int dy_pitch, const XT *__restrict__ x, int x_pitch, const YT *__restrict__ y,
+    int y_pitch, XT *__restrict__ dx, int dx_pitch, YT *__restrict__ dres, int dres_pitch, int res_beta,
     long rows, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
@@ -279,18 +287,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
-        f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_pitch + c4);
+        f32x4 g = ld4(dy + r * dy_pitch + c4);
         if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
         if (relu && mask) {
             const unsigned m = mask[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
         } else if (relu) {
-            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * y_pitch + c4);
+            const f32x4 yv = ld4(y + r * y_pitch + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + r * x_pitch + c4);
+        const f32x4 xv = ld4(x + r * x_pitch + c4);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
@@ -302,25 +310,26 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
             const float sgx = (float)sums2[C + c4 + e] * inv_count;
             o[e] = ga[e] * is[e] * (g[e] - sg - xh * sgx);
         }
-        *reinterpret_cast<f32x4 *>(dx + r * dx_pitch + c4) = o;
+        st4(dx + r * dx_pitch + c4, o);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float f = o[e];
             mx = max(mx, __float_as_uint(fabsf(f)));
         }
         if (dres) {
-            f32x4 *dr = reinterpret_cast<f32x4 *>(dres + r * dres_pitch + c4);
-            *dr = res_beta ? (*dr + g) : g;
+            YT *dr = dres + r * dres_pitch + c4;
+            st4(dr, res_beta ? (ld4(dr) + g) : g);
         }
     }
     if (amax) block_amax(mx, amax);
 }
 
+template <typename XT>
 struct ColsumOp {
-    const float *x;
+    const XT *x;
     int pitch;
     __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * pitch + c4);
+        const f32x4 v = ld4(x + r * pitch + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             a[e] = v[e];
@@ -360,20 +369,28 @@ extern "C" size_t rcf_bn_stats_workspace_bytes(long rows, int C) {
     return (size_t)g.chunks * 2 * C * sizeof(double);
 }
 
-extern "C" int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, double *sums, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+extern "C" int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pitch, double *sums, void *workspace,
+                               size_t workspace_bytes, void *stream) {
     if (!x || !sums || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
     const ColGeom g = col_geom(rows, C);
     hipStream_t st = rcf_stream(stream);
-    StatsOp op{x, pitch};
-    hipLaunchKernelGGL(colreduce2_kernel<StatsOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
-                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+#define RCF_CALL(XT)                                                                                                   \
+    StatsOp<XT> op{(const XT *)x, pitch};                                                                              \
+    hipLaunchKernelGGL(colreduce2_kernel<StatsOp<XT>>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, \
+                       C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+    RCF_DISPATCH1(xdt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums);
     RCF_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int rcf_bn_stats_f32(const float *x, long rows, int C, int pitch, double *sums, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return rcf_bn_stats_mp(x, RCF_F32, rows, C, pitch, sums, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rcf_sum_partials_f64(const double *partial, int chunks, int n, double *out, double *scratch,
@@ -411,16 +428,53 @@ extern "C" int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, fl
     return 0;
 }
 
+extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch, void *y, int ydt,
+                               int y_pitch, long rows, int C, const float *mean, const float *invstd,
+                               const float *gamma, const float *beta, int relu, const float *chan_scale,
+                               long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
+    if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
+#define RCF_CALL(XT, YT)                                                                                              \
+    hipLaunchKernelGGL((bn_apply_kernel<XT, YT>), dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), \
+                       (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, mean,        \
+                       invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,     \
+                       amax_out)
+    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+#undef RCF_CALL
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residual, int r_pitch, float *y,
                                 int y_pitch, long rows, int C, const float *mean, const float *invstd,
                                 const float *gamma, const float *beta, int relu, const float *chan_scale,
                                 long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *stream) {
-    if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
-    if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
-    if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), x, x_pitch,
-                       residual, r_pitch, y, y_pitch, rows, C, mean, invstd, gamma, beta, relu, chan_scale,
-                       rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out);
+    return rcf_bn_apply_mp(x, RCF_F32, x_pitch, residual, r_pitch, y, RCF_F32, y_pitch, rows, C, mean, invstd, gamma, beta,
+                           relu, chan_scale, rows_per_image, relu_mask, amax_out, stream);
+}
+
+extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch,
+                                    const void *y, int y_pitch, long rows, int C, const float *mean,
+                                    const float *invstd, int relu, const unsigned char *relu_mask,
+                                    const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    if (!dy || !x || !mean || !invstd || !sums2 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (relu && !y && !relu_mask) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || (relu && !relu_mask && y_pitch % 4)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const ColGeom g = col_geom(rows, C);
+    hipStream_t st = rcf_stream(stream);
+#define RCF_CALL(XT, YT)                                                                                                 \
+    BwdOp<XT, YT> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
+                     relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask};                                       \
+    hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT>>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,     \
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+#undef RCF_CALL
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, 2 * C, sums2);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -429,19 +483,29 @@ extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float 
                                      int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
                                      const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
                                      double *sums2, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!dy || !x || !mean || !invstd || !sums2 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    return rcf_bn_bwd_reduce_mp(dy, RCF_F32, dy_pitch, x, RCF_F32, x_pitch, y, y_pitch, rows, C, mean, invstd, relu,
+                                relu_mask, chan_scale, rows_per_image, sums2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch,
+                                   const void *y, int y_pitch, void *dx, int dx_pitch, void *dres, int dres_pitch,
+                                   int res_beta, long rows, int C, const float *mean, const float *invstd,
+                                   const float *gamma, int relu, const unsigned char *relu_mask,
+                                   const float *chan_scale, long rows_per_image, const double *sums2,
+                                   const double *sums2_local, double count, float *dgamma, float *dbeta,
+                                   unsigned *amax_out, void *stream) {
+    if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
+        return RCF_EINVAL;
     if (relu && !y && !relu_mask) return RCF_EINVAL;
-    if (dy_pitch % 4 || x_pitch % 4 || (relu && !relu_mask && y_pitch % 4)) return RCF_EINVAL;
-    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
-    const ColGeom g = col_geom(rows, C);
-    hipStream_t st = rcf_stream(stream);
-    BwdOp op{dy, x, y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, relu, C,
-             rows_per_image > 0 ? rows_per_image : 1, relu_mask};
-    hipLaunchKernelGGL(colreduce2_kernel<BwdOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
-                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
-    RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, 2 * C, sums2);
+    if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
+#define RCF_CALL(XT, YT)                                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<XT, YT>), dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), \
+                       (const YT *)dy, dy_pitch, (const XT *)x, x_pitch, (const YT *)y, y_pitch, (XT *)dx, dx_pitch,      \
+                       (YT *)dres, dres_pitch, res_beta, rows, C, mean, invstd, gamma, relu, chan_scale,                  \
+                       rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma,  \
+                       dbeta, relu_mask, amax_out)
+    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -452,30 +516,31 @@ extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *
                                     int relu, const unsigned char *relu_mask, const float *chan_scale,
                                     long rows_per_image, const double *sums2, const double *sums2_local, double count,
                                     float *dgamma, float *dbeta, unsigned *amax_out, void *stream) {
-    if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
-        return RCF_EINVAL;
-    if (relu && !y && !relu_mask) return RCF_EINVAL;
-    if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), dy,
-                       dy_pitch, x, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch, res_beta, rows, C, mean,
-                       invstd, gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
-                       sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out);
+    return rcf_bn_bwd_apply_mp(dy, RCF_F32, dy_pitch, x, RCF_F32, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch,
+                               res_beta, rows, C, mean, invstd, gamma, relu, relu_mask, chan_scale, rows_per_image, sums2,
+                               sums2_local, count, dgamma, dbeta, amax_out, stream);
+}
+
+extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch, float *out, int beta, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const ColGeom g = col_geom(rows, C);
+    hipStream_t st = rcf_stream(stream);
+#define RCF_CALL(XT)                                                                                                    \
+    ColsumOp<XT> op{(const XT *)x, pitch};                                                                              \
+    hipLaunchKernelGGL(colreduce2_kernel<ColsumOp<XT>>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, \
+                       C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+    RCF_DISPATCH1(xdt, RCF_CALL);
+#undef RCF_CALL
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(rcf_cdiv(C, 32)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, C, out, beta);
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
                               size_t workspace_bytes, void *stream) {
-    if (!x || !out || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
-    if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
-    const ColGeom g = col_geom(rows, C);
-    hipStream_t st = rcf_stream(stream);
-    ColsumOp op{x, pitch};
-    hipLaunchKernelGGL(colreduce2_kernel<ColsumOp>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, C,
-                       g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
-    RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(rcf_cdiv(C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, C, out, beta);
-    RCF_LAUNCH_CHECK();
-    return 0;
+    return rcf_colsum_mp(x, RCF_F32, rows, C, pitch, out, beta, workspace, workspace_bytes, stream);
 }

@@ -88,12 +88,27 @@ def main():
             return {k: float(v) for k, v in l.items() if "loss" in k}, mg.grad_norms(m)
         l_ref, g_ref = step(ref, tag="ref")
         ref_calls = list(calls)
+        ref_targets = dict(targets)
         l_ora, g_ora = step(ora, tag="ora")
         o64 = orc.RCFModel(args, **copy.deepcopy(okw))
         o64.load_state_dict(sd)
         if o64.crf_head is not None:                       # CRFHead constants are plain tensors, not buffers
             o64.crf_head.mean, o64.crf_head.std = o64.crf_head.mean.double(), o64.crf_head.std.double()
         l64, g64 = step(o64.double(), dbl=True)
+        # the yardstick of make_golden_variants.py: the reference's own fp32 deviation from the float64 truth under other,
+        # equally valid reduction orders (1 thread; channels_last convolutions)
+        e_l = [{k: mg.rel(l_ref[k], l64[k]) for k in l_ref}]
+        e_g = [{k: mg.rel(g_ref[k], g64[k]) for k in g_ref}]
+        for nthreads, cl in ((1, False), (8, True)):
+            torch.set_num_threads(nthreads)
+            rv = ref_models.RCFModel(args, **copy.deepcopy(kw))
+            rv.load_state_dict(sd)
+            if cl:
+                rv = rv.to(memory_format=torch.channels_last)
+            lv, gv = step(rv)
+            e_l.append({k: mg.rel(lv[k], l64[k]) for k in l_ref})
+            e_g.append({k: mg.rel(gv[k], g64[k]) for k in g_ref})
+            torch.set_num_threads(8)
         chk = {k: mg.rel(l_ora[k], l_ref[k]) for k in l_ref}
         chk.update({"gradnorm." + k: mg.rel(g_ora[k], g_ref[k]) for k in g_ref})
         # the EMA copies after the momentum update (incl. the int64 num_batches_tracked truncation)
@@ -105,18 +120,18 @@ def main():
         assert max(v for k, v in chk.items() if "gradnorm" in k) < 2e-3, name
         out[name] = dict(H=H, W=W, B=B, weight_seed=7, config_id=1, object_channel=oc,
                          loss=l_ref, gradnorm=g_ref, truth_loss=l64, truth_gradnorm=g64,
-                         ref32_err_loss={k: mg.rel(l_ref[k], l64[k]) for k in l_ref},
-                         ref32_err_gradnorm={k: mg.rel(g_ref[k], g64[k]) for k in g_ref},
+                         ref32_err_loss={k: max(e[k] for e in e_l) for k in l_ref},
+                         ref32_err_gradnorm={k: max(e[k] for e in e_g) for k in g_ref},
                          oracle_vs_reference=chk, crf_calls=len(ref_calls))
         if ref_calls:
             arrays[name + "_crf_img_u8"] = np.stack([c[0].numpy() for c in ref_calls])
             arrays[name + "_crf_unary"] = np.stack([c[1].numpy() for c in ref_calls])
             arrays[name + "_crf_map"] = np.stack([c[2].numpy().astype(np.uint8) for c in ref_calls])
             out[name]["crf_params"] = ref_calls[0][3]
-            assert torch.equal(targets["get_crf_loss"], extras["ora"]["_crf_masks"]), "oracle's CRF targets differ"
-            arrays[name + "_crf_target"] = targets["get_crf_loss"].numpy()
-        if "get_pl_loss" in targets:
-            arrays[name + "_pl_target"] = targets["get_pl_loss"].numpy()
+            assert torch.equal(ref_targets["get_crf_loss"], extras["ora"]["_crf_masks"]), "oracle's CRF targets differ"
+            arrays[name + "_crf_target"] = ref_targets["get_crf_loss"].numpy()
+        if "get_pl_loss" in ref_targets:
+            arrays[name + "_pl_target"] = ref_targets["get_pl_loss"].numpy()
         ema_keys = ["backbone2_ema.layer1.0.conv1.weight", "backbone2_ema.bn1.running_mean",
                     "backbone2_ema.bn1.num_batches_tracked", "decode_head2_ema.conv_seg.bias"]
         for k in ema_keys:
