@@ -24,6 +24,12 @@ extern "C" {
 #define RCF_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
 #define RCF_EWORKSPACE (-2) /* workspace too small */
 
+/* storage type codes of the mixed-precision (`*_mp`, `*_bf16`) entry points: activations and activation gradients may
+ * be held as bf16 between layers (BASELINE configs[2]: bf16 forward / fp32 gradients); every kernel computes in fp32.
+ * Pitches are in ELEMENTS of the tensor's own type. */
+#define RCF_F32 0
+#define RCF_BF16 1
+
 /* library identity: "rcf_hip <version> gfx950" */
 const char *rcf_version(void);
 
@@ -103,6 +109,34 @@ int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, float *dw, cons
                                 const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
+/* ---- the same three operators with bf16 OPERANDS and fp32 accumulation (csrc/igemm_bf16.hip) -----------------------
+ * The mixed-precision training step (BASELINE configs[2]; the reference's AMP configs configs/rcf_stv2/rcf_stage1.yaml:57-60):
+ * x, dy, dx are NHWC bf16 (channel counts and pitches multiples of 8, pitches in bf16 elements), weights stay fp32
+ * master copies ([Cout][R][S][Cin]) and are cast per launch, dw is fp32.  One MFMA pass (v_mfma_f32_32x32x16_bf16).
+ * rcf_conv_shape's amax / w_pairs members are ignored.
+ * rcf_conv_weight_bf16: the kernels' weight operand, K-step major [K/32][rows][32] bf16 (K zero-padded to a multiple of
+ * 32); transpose = 0: rows = Cout, k = (r, s, cin) -- forward; transpose = 1: rows = Cin, k = (r, s, cout) -- data gradient. */
+size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, int transpose);
+int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, void *stream);
+/* y (ydt: RCF_BF16 or RCF_F32, pitch s->y_pitch in its own elements) (+)= conv(x, w) + bias, act 0 none / 1 LeakyReLU.
+ * w_bf16 = rcf_conv_weight_bf16(w, ..., transpose 0).  region: as rcf_conv2d_fwd_region_f32 (NULL = whole tensor).
+ * sums != NULL (needs region == NULL, bias == NULL, act == beta == 0 and the workspace): the batch-norm statistics of the
+ * fp32 accumulators [sum | sumsq] per output channel from the epilogue, like rcf_conv2d_fwd_stats_f32. */
+size_t rcf_conv2d_fwd_stats_bf16_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, void *y, int ydt, const rcf_conv_shape *s,
+                        const rcf_conv_region *region, int act, float slope, int beta, double *sums, void *workspace,
+                        size_t workspace_bytes, void *stream);
+/* dx (bf16) (+)= conv_transpose(dy (bf16), w (fp32 master)); the workspace receives the transposed bf16 weights */
+size_t rcf_conv2d_dgrad_bf16_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_conv_shape *s, const rcf_conv_region *region,
+                          int beta, void *workspace, size_t workspace_bytes, void *stream);
+/* dw (fp32, [Cout][R][S][Cin]) (+)= sum over pixels of dy (bf16) * x (bf16); deterministic split-K through the workspace */
+size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region);
+int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, const rcf_conv_shape *s, const rcf_conv_region *region,
+                          int beta, void *workspace, size_t workspace_bytes, void *stream);
+/* tile of the bf16 forward / data-gradient kernel for A/B measurements: -1 heuristic, 0 128x128, 1 128x256, 2 256x256, 3 128x64 */
+int rcf_conv_bf16_set_tile(int tile);
+
 /* tuning knob for A/B measurements of the conv kernels: bit0 K-step 32, bit1 row-major LDS tiles;
  * -1 restores the built-in default.  Results are identical up to fp32 summation order. */
 int rcf_conv_set_variant(int variant);
@@ -149,6 +183,29 @@ int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pi
                          const double *sums2_local, double count, float *dgamma, float *dbeta,
                          unsigned *amax_out, void *stream);
 
+/* Mixed-precision forms of the batch-norm family (the `_f32` entry points above are these with every code RCF_F32).
+ * xdt: storage type of the conv-output side (x, dx); ydt: of the activation side (y, residual, dy, dres).
+ * Supported (xdt, ydt): (F32, F32), (BF16, BF16), (F32, BF16) -- an fp32 conv output (the stem) normalised into bf16
+ * activations.  The reference runs these layers under torch autocast (configs/rcf_stv2/rcf_stage1.yaml:57-60). */
+int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pitch, double *sums, void *workspace,
+                    size_t workspace_bytes, void *stream);
+int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch, void *y, int ydt, int y_pitch,
+                    long rows, int C, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                    int relu, const float *chan_scale, long rows_per_image, unsigned char *relu_mask,
+                    unsigned *amax_out, void *stream);
+int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
+                         int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
+                         const unsigned char *relu_mask, const float *chan_scale, long rows_per_image, double *sums2,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
+                        int y_pitch, void *dx, int dx_pitch, void *dres, int dres_pitch, int res_beta, long rows, int C,
+                        const float *mean, const float *invstd, const float *gamma, int relu,
+                        const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
+                        const double *sums2, const double *sums2_local, double count, float *dgamma, float *dbeta,
+                        unsigned *amax_out, void *stream);
+int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch, float *out, int beta, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
 /* ---- pooling / resize / layout ------------------------------------------------------------------
  * MaxPool2d(3,2,1): models/resnet.py:577.  argmax: uint8 window position (r*3+s), first max wins. */
 int rcf_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho,
@@ -185,6 +242,22 @@ int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, fl
  * either output may be NULL.  Splits a gradient into its interior / border-band parts (see rcf_conv_region). */
 int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0, int x0,
                        int h, int w, void *stream);
+/* Mixed-precision forms (dt = RCF_F32 / RCF_BF16 storage of every tensor argument; `frame` 0 = the whole tensor) */
+int rcf_maxpool3x3s2_fwd_mp(const void *x, void *y, int dt, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo,
+                            void *stream);
+int rcf_maxpool3x3s2_bwd_mp(const void *dy, const uint8_t *argmax, void *dx, int dt, int N, int H, int W, int C, int Ho,
+                            int Wo, void *stream);
+int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void *y, int y_pitch, int dt, int N, int Hi, int Wi, int Ho,
+                                    int Wo, int C, int align_corners, int frame, void *stream);
+int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, void *dx, int dx_pitch, int dt, int beta, int N, int Hi,
+                                    int Wi, int Ho, int Wo, int C, int align_corners, int frame, void *stream);
+int rcf_copy2d_batched_mp(const void *src, long spitch, long sb0, long sb1, void *dst, long dpitch, long db0, long db1, int dt,
+                          long rows, int C, int beta, int n0, int n1, void *stream);
+/* source and destination in their own storage types: strided copy, or the fp32 <-> bf16 cast */
+int rcf_copy2d_mp(const void *src, int sdt, long spitch, void *dst, int ddt, long dpitch, long rows, int C, int beta,
+                  void *stream);
+int rcf_split_rect_mp(const void *src, void *inside, void *outside, int dt, int N, int H, int W, int C, int y0, int x0, int h,
+                      int w, void *stream);
 /* column sums of [rows][C] (pitch) in fp64 -> out[C] (+)= (bias gradients of conv_seg) */
 int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
                    size_t workspace_bytes, void *stream);

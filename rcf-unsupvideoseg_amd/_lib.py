@@ -120,7 +120,36 @@ PROTOS = {
     "rcf_adam_step_f32": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "rcf_ema_update_f32": (c_int, [P, P, c_long, c_float, P]),
     "rcf_fill_f32": (c_int, [P, c_long, c_float, P]),
+    # mixed-precision (bf16 storage) forms
+    "rcf_bn_stats_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, P, c_size_t, P]),
+    "rcf_bn_apply_mp": (c_int, [P, c_int, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,
+                                P, P]),
+    "rcf_bn_bwd_reduce_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, c_int, P, P, c_long,
+                                     P, P, c_size_t, P]),
+    "rcf_bn_bwd_apply_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P,
+                                    P, P, c_int, P, P, c_long, P, P, c_double, P, P, P, P]),
+    "rcf_colsum_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, P, c_size_t, P]),
+    "rcf_maxpool3x3s2_fwd_mp": (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_maxpool3x3s2_bwd_mp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_resize_bilinear_nhwc_fwd_mp": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, P]),
+    "rcf_resize_bilinear_nhwc_bwd_mp": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, c_int, P]),
+    "rcf_copy2d_batched_mp": (c_int, [P, c_long, c_long, c_long, P, c_long, c_long, c_long, c_int, c_long, c_int, c_int,
+                                      c_int, c_int, P]),
+    "rcf_copy2d_mp": (c_int, [P, c_int, c_long, P, c_int, c_long, c_long, c_int, c_int, P]),
+    "rcf_split_rect_mp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "rcf_conv_weight_bf16_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rcf_conv_weight_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "rcf_conv2d_fwd_stats_bf16_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_fwd_bf16": (c_int, [P, P, P, P, c_int, _CS, _CR, c_int, c_float, c_int, P, P, c_size_t, P]),
+    "rcf_conv2d_dgrad_bf16_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_dgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
+    "rcf_conv2d_wgrad_bf16_workspace_bytes": (c_size_t, [_CS, _CR]),
+    "rcf_conv2d_wgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
+    "rcf_conv_bf16_set_tile": (c_int, [c_int]),
 }
+F32, BF16 = 0, 1          # storage type codes (RCF_F32 / RCF_BF16)
 
 _lib = None
 

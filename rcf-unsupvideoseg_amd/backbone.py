@@ -167,6 +167,7 @@ class FCNHead(nn.Module):
         self.in_channels, self.channels, self.num_classes = in_channels, channels, num_classes
         self.align_corners, self.transform_scale, self.dropout_ratio = align_corners, transform_scale, dropout_ratio
         self.conv_seg = Conv2d(channels, num_classes, 1, bias=True)
+        self.conv_seg.out_fp32 = True       # the logits feed the fp32 loss tail also in the bf16 step
         nn.init.kaiming_uniform_(self.conv_seg.weight, a=5 ** 0.5)      # torch Conv2d default: never re-initialised
         nn.init.uniform_(self.conv_seg.bias, -1 / channels ** 0.5, 1 / channels ** 0.5)   # 
         if input_dilation is None:

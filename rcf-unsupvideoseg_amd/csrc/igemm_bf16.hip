@@ -1,0 +1,864 @@
+// Convolution forward / data gradient / weight gradient with bf16 OPERANDS and fp32 accumulation -- the
+// mixed-precision training step (BASELINE configs[2]: bf16 forward / fp32 gradients; the reference trains STv2 and
+// FBMS under torch autocast, configs/rcf_stv2/rcf_stage1.yaml:57-60, configs/rcf_fbms59/rcf_stage1.yaml:61).
+// Same implicit-GEMM view and reference call sites as igemm_conv.hip (models/resnet.py:164-203, models/res_layer.py:54-60,
+// models/fcn_head.py:100-130); what changes is the storage: activations and activation gradients live in HBM as bf16
+// NHWC (half the bytes of every pass), weights are cast once per launch from the fp32 master copy, weight gradients
+// come out in fp32.  One MFMA pass (v_mfma_f32_32x32x16_bf16) instead of the three of the fp16-pair kernels: the
+// roofline is the dense bf16 peak, 2.5 PF/s.
+//
+// K-step = 32 (64 B of one source pixel per GEMM row).  LDS tile [row][4 chunks of 16 B]; chunk c of row r is stored at
+// chunk position c ^ ((r >> 2) & 3), which makes both the loader's ds_write_b128 and the MFMA operand fetch
+// (ds_read_b128: lane = row, lane >> 5 = which half of a 16-k substep) bank-conflict free without padding.
+#include "rcf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0x80000000u;      // byte offset beyond every descriptor's num_records: loads return 0
+constexpr int BKT = 32;                    // K-step (bf16 elements)
+
+struct ConvParams {
+    const bf16_t *A;      // source activations (x for fwd, dy for dgrad), NHWC bf16
+    const bf16_t *Bw;     // weights, K-step major: [K/32][Ncol][32] (rcf_conv_weight_bf16)
+    const float *bias;    // per output column or null
+    void *Y;              // bf16 or fp32, NHWC
+    int M, Ncol, K;
+    int Ho, Wo;           // spatial dims of the GEMM-row tensor
+    int Hs, Ws;           // spatial dims of the source tensor
+    int Cs;               // source channels per tap (multiple of 8)
+    int S;                // kernel width
+    int up, off, step, div;   // source coord t = y*up + off + r*step, valid iff t>=0, t%div==0, t/div<Hs
+    int a_pitch;
+    long a_img_stride;
+    int y_pitch;
+    int act;
+    float slope;
+    int beta;
+    int mtiles, ntiles;
+    unsigned cs_magic, s_magic;
+    int b_bytes;
+    int ry0, rx0, rh, rw, rband, rr;      // region of the GEMM-row tensor (see igemm_conv.hip)
+    double *stats;                        // forward only: per row tile, fp64 column sums | sums of squares
+};
+
+__device__ __forceinline__ void region_yx(int pix, int ry0, int rx0, int rh, int rw, int t, int &y, int &x) {
+    if (t <= 0) {
+        const int yr = pix / rw;
+        y = yr + ry0;
+        x = pix - yr * rw + rx0;
+        return;
+    }
+    const int strip = t * rw;
+    if (pix < 2 * strip) {
+        const int bottom = pix >= strip;
+        const int q = pix - (bottom ? strip : 0);
+        const int yr = q / rw;
+        y = ry0 + yr + (bottom ? rh - t : 0);
+        x = rx0 + q - yr * rw;
+    } else {
+        int q = pix - 2 * strip;
+        const int side = t * (rh - 2 * t);
+        const int right = q >= side;
+        q -= right ? side : 0;
+        const int yr = q / t;
+        y = ry0 + t + yr;
+        x = rx0 + q - yr * t + (right ? rw - t : 0);
+    }
+}
+
+__device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
+
+__device__ __forceinline__ u32x2 pack4(const f32x4 v) {
+    const bf16x2 a = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), b = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
+    return u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+
+// one K-step of 32: two 16-k substeps of MR x NR MFMAs.  SWAP'd operands: the accumulator tile is transposed, a lane owns
+// ONE tile row of A (one pixel) and, per register quad, four consecutive rows of B (output channels).
+template <int MR, int NR>
+__device__ __forceinline__ void mma_step(const char *__restrict__ As, const char *__restrict__ Bs, int arow0, int brow0,
+                                         int lane, f32x16 (&acc)[MR][NR]) {
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int coff = (((2 * j + kh) ^ sw) << 4);
+        bf16x8 a[MR], b[NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a[mr] = *reinterpret_cast<const bf16x8 *>(As + (arow0 + mr * 32 + l31) * 64 + coff);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) b[nr] = *reinterpret_cast<const bf16x8 *>(Bs + (brow0 + nr * 32 + l31) * 64 + coff);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nr], a[mr], acc[mr][nr], 0, 0, 0);
+    }
+}
+
+// forward / data gradient.  Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32.
+// DGRAD only names the instantiation (profiles tell forward and data-gradient launches apart).
+// OBF: bf16 output (16-byte stores after a half-wave exchange), else fp32 output.
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
+    constexpr int PA = BM * 64, PB = BN * 64, STAGE = PA + PB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * p.ntiles);
+    const int rem = bid - grp * 8 * p.ntiles;
+    const int tile_n = rem >> 3;
+    const int tile_m = grp * 8 + (rem & 7);          // XCD aware: ids b, b+8, .. walk the column tiles of one row tile
+    if (tile_m >= p.mtiles) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    constexpr int ROWS = NT / 4;                      // 4 threads x 16 B per 64-byte row
+    constexpr int A_PASS = BM / ROWS, B_PASS = BN / ROWS;
+    static_assert(A_PASS >= 1 && B_PASS >= 1, "tile smaller than one loader pass");
+    const int kq = tid & 3, arow = tid >> 2;
+    const int st_off = arow * 64 + ((kq ^ ((arow >> 2) & 3)) << 4);      // + ROWS*64 per pass (ROWS % 16 == 0)
+
+    const int HoWo = p.rr;
+    const int n_first = m0 / HoWo;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.A + (long)n_first * p.a_img_stride), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.Bw), 0, p.b_bytes, 0x00020000);
+
+    int abase[A_PASS], ay[A_PASS], ax[A_PASS];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+        const int m = m0 + arow + ROWS * i;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            int y, x;
+            region_yx(m - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+            ay[i] = y * p.up + p.off;
+            ax[i] = x * p.up + p.off;
+            abase[i] = (n - n_first) * (int)p.a_img_stride + (STRIDED ? 0 : (ay[i] * p.Ws + ax[i]) * p.a_pitch);
+        } else {
+            abase[i] = 0;
+            ay[i] = -(1 << 28);
+            ax[i] = -(1 << 28);
+        }
+    }
+    unsigned bbase[B_PASS];   // byte offset of the weight row inside a K-step's block (out of range for columns past Ncol)
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+        const int j = n0 + arow + ROWS * i;
+        bbase[i] = j < p.Ncol ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
+    }
+    // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets); B (weights, L2) one step ahead
+    u32x4 ra[2][A_PASS], rb[B_PASS];
+
+    auto load_a = [&](int kt, u32x4 (&dst)[A_PASS]) {
+        const int k = kt * BKT + kq * 8;
+        const bool kv = k < p.K;
+        const int rs = fast_div(k, p.cs_magic);
+        const int c = k - rs * p.Cs;
+        const int r = fast_div(rs, p.s_magic);
+        const int s = rs - r * p.S;
+        const int dy = r * p.step, dx = s * p.step;
+        const int tapoff = (dy * p.Ws + dx) * p.a_pitch + c;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            int ty = ay[i] + dy, tx = ax[i] + dx;
+            int v, off;
+            if (STRIDED) {
+                v = (int)kv & (int)(ty >= 0) & (int)(tx >= 0) & (int)(ty % p.div == 0) & (int)(tx % p.div == 0);
+                ty /= p.div;
+                tx /= p.div;
+                v &= (int)(ty < p.Hs) & (int)(tx < p.Ws);
+                off = abase[i] + (ty * p.Ws + tx) * p.a_pitch + c;
+            } else {
+                v = (int)kv & (int)((unsigned)ty < (unsigned)p.Hs) & (int)((unsigned)tx < (unsigned)p.Ws);
+                off = abase[i] + tapoff;
+            }
+            const unsigned bo = (((unsigned)off * 2u) & ~OOB) | ((unsigned)(v - 1) & OOB);
+            dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0);
+        }
+    };
+    auto load_b = [&](int kt) {
+        const unsigned kb = (unsigned)kt * (unsigned)p.Ncol * 64u;
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(bbase[i] + kb), 0, 0);
+    };
+    auto store_tile = [&](int buf, const u32x4 (&src)[A_PASS]) {
+        char *As = smem + buf * STAGE;
+        char *Bs = As + PA;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<u32x4 *>(As + st_off + i * ROWS * 64) = src[i];
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<u32x4 *>(Bs + st_off + i * ROWS * 64) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    const int KT = (p.K + BKT - 1) / BKT;
+    load_a(0, ra[0]);
+    load_b(0);
+    load_a(1, ra[1]);                        // past the end of K: out-of-range offsets, zeros
+    store_tile(0, ra[0]);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 <= KT - 1; kt += 2) {
+        {
+            load_b(kt + 1);
+            load_a(kt + 2, ra[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const char *As = smem;
+            mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+            store_tile(1, ra[1]);
+            __syncthreads();
+        }
+        {
+            load_b(kt + 2);
+            load_a(kt + 3, ra[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const char *As = smem + STAGE;
+            mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+            store_tile(0, ra[0]);
+            __syncthreads();
+        }
+    }
+    if (kt < KT - 1) {
+        load_b(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *As = smem;
+        mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+        store_tile(1, ra[1]);
+        __syncthreads();
+        ++kt;
+    }
+    {
+        const char *As = smem + (kt & 1) * STAGE;
+        mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+    }
+
+    // epilogue.  Transposed accumulators: lane = pixel (lane & 31) of each row tile, registers 4g..4g+3 = output channels
+    // 8g + 4(lane>>5) .. +3 of each column tile.
+    const int l31 = lane & 31, kh = lane >> 5;
+    const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;
+    const bool want_stats = !DGRAD && p.stats != nullptr;
+    long lin[MR];
+    bool rowok[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int row = m0 + arow0 + mr * 32 + l31;
+        rowok[mr] = row < p.M;
+        lin[mr] = row;
+        if (rowok[mr] && !full) {
+            const int n = row / HoWo;
+            int y, x;
+            region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+            lin[mr] = ((long)n * p.Ho + y) * p.Wo + x;
+        }
+    }
+    double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
+    if (want_stats) __syncthreads();                      // every wave is done with the operand stages
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        float cs[16], cq[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+        const int cb = n0 + brow0 + nr * 32;              // first channel of this column tile
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            // lanes of rows past M keep zeros and take part in the half-wave exchange (no divergence around it)
+            f32x4 q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cb + 8 * g + 4 * kh;
+                f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                const bool ok = rowok[mr] && c < p.Ncol;  // Ncol % 4 == 0: a quad is in or out as a whole
+                if (ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (p.bias) v[e] += p.bias[c + e];
+                        if (p.act == 1) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                    }
+                    if (p.beta) {
+                        if constexpr (OBF) v += ld4(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + c);
+                        else v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c);
+                    }
+                } else {
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                q[g] = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[4 * g + e] += v[e];
+                    cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                }
+            }
+            if constexpr (OBF) {
+                // half-wave exchange (v_permlane32_swap): lanes 0-31 end up with channels 8g..8g+7 of group pair (g, g+1)'s
+                // first group, lanes 32-63 with those of the second -> one 16-byte store per pair
+                bf16_t *yrow = reinterpret_cast<bf16_t *>(p.Y) + lin[mr] * p.y_pitch;
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    u32x2 a = pack4(q[g]), b = pack4(q[g + 1]);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    const int c8 = cb + 8 * (g + kh);
+                    if (rowok[mr] && c8 < p.Ncol)
+                        *reinterpret_cast<u32x4 *>(yrow + c8) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+            } else {
+                float *yrow = reinterpret_cast<float *>(p.Y) + lin[mr] * p.y_pitch;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cb + 8 * g + 4 * kh;
+                    if (rowok[mr] && c < p.Ncol) *reinterpret_cast<f32x4 *>(yrow + c) = q[g];
+                }
+            }
+        }
+        if (want_stats) {                                 // block-uniform
+            // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly (igemm_conv.hip)
+            const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+            float s8[8], q8[8], s4[4], q4[4], s2[2], q2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s8[i] = (b4 ? cs[8 + i] : cs[i]) + __shfl_xor(b4 ? cs[i] : cs[8 + i], 16);
+                q8[i] = (b4 ? cq[8 + i] : cq[i]) + __shfl_xor(b4 ? cq[i] : cq[8 + i], 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s4[i] = (b3 ? s8[4 + i] : s8[i]) + __shfl_xor(b3 ? s8[i] : s8[4 + i], 8);
+                q4[i] = (b3 ? q8[4 + i] : q8[i]) + __shfl_xor(b3 ? q8[i] : q8[4 + i], 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                s2[i] = (b2 ? s4[2 + i] : s4[i]) + __shfl_xor(b2 ? s4[i] : s4[2 + i], 4);
+                q2[i] = (b2 ? q4[2 + i] : q4[i]) + __shfl_xor(b2 ? q4[i] : q4[2 + i], 4);
+            }
+            float s1 = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 2);
+            float q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2);
+            s1 += __shfl_xor(s1, 1);
+            q1 += __shfl_xor(q1, 1);
+            if ((lane & 1) == 0) {
+                const int r = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);     // accumulator register = channel
+                const int ch = brow0 + nr * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                red[(wm * BN + ch) * 2] = (double)s1;
+                red[(wm * BN + ch) * 2 + 1] = (double)q1;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            if (n0 + c >= p.Ncol) continue;
+            double sv = 0, qv = 0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                sv += red[(w * BN + c) * 2];
+                qv += red[(w * BN + c) * 2 + 1];
+            }
+            double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
+            o[0] = sv;
+            o[p.Ncol] = qv;
+        }
+    }
+}
+
+// fp32 master weights -> the bf16 operand of the kernels above, K-step major: element (row j, k) at
+// ((k >> 5) * rows + j) * 32 + (k & 31), K padded with zeros to a multiple of 32.
+// TRANSPOSE (data gradient): rows = c (Cin), k = rs * Cout + co of w[co][rs][c].
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(256) weight_bf16_kernel(const float *__restrict__ w, bf16_t *__restrict__ out, int Cout,
+                                                          int Cin, int RS) {
+    const int rows = TRANSPOSE ? Cin : Cout;
+    const int K = TRANSPOSE ? RS * Cout : RS * Cin;
+    const int KT = (K + 31) >> 5;
+    const long n = (long)KT * rows * 32;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const int kl = (int)(i & 31);
+        const long t = i >> 5;
+        const int j = (int)(t % rows);
+        const int k = (int)(t / rows) * 32 + kl;
+        float v = 0.f;
+        if (k < K) {
+            if (!TRANSPOSE) {
+                v = w[(long)j * K + k];
+            } else {
+                const int rs = k / Cout, co = k - rs * Cout;
+                v = w[((long)co * RS + rs) * Cin + j];
+            }
+        }
+        out[i] = (bf16_t)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- weight gradient
+struct WgradParams {
+    const bf16_t *X, *DY;
+    float *OUT;
+    int Cout, Cin, R, S;
+    int H, W, Ho, Wo, stride, pad, dil;
+    int x_pitch, dy_pitch;
+    long M;            // N * rr
+    long chunk;        // pixels per K-split (multiple of 32)
+    int itiles, jtiles;
+    long split_stride; // Cout*R*S*Cin
+    int beta;          // only honoured when gridDim.z == 1
+    int ry0, rx0, rh, rw, rband, rr;
+};
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ u32x2 lds_tr16(const char *p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) char *)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+
+// dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c]: rows i = co (128), cols j = c (64 NR), K = pixels (32 per step).
+// Both operands are staged in their NATURAL order -- LDS holds [32 pixels][channels] bf16 (16-byte global loads of 8
+// channels of a pixel, one ds_write_b128 each) -- and the MFMA's k-contiguous fragments come out of gfx950's transposing
+// LDS read (ds_read_b64_tr_b16), as in igemm_wgrad_h2t_kernel.  Row pitch = channels * 2 + 32 bytes.
+// REGION: the contributing output pixels are a rectangle / frame of every image (general pixel walk).
+template <int NR, bool REGION>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
+    constexpr int MR = 2, BM = 128, BN = 64 * NR, BK = 32;
+    constexpr int QA = BM / 8, PAS = 256 / QA, NAP = BK / PAS;   // dy loader: 16-byte chunks per pixel, pixels per pass, passes
+    constexpr int QB = BN / 8, PBS = 256 / QB, NBP = BK / PBS;   // x loader
+    // row pitch = channels * 2 + 64 bytes: the 4 pixel rows a 16-lane group reads are 64 B apart in bank space and the
+    // second group of a 32-lane half (channels + 16 = + 32 B) falls into the gaps: 256 distinct bytes per LDS cycle
+    constexpr int PIA = BM * 2 + 64, PIB = BN * 2 + 64;
+    constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = PLA + PLB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int rs = (int)blockIdx.y;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+    const int klen = (int)(kend - kbeg);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = p.rr;
+    const int n_first = (int)(kbeg / HoWo);
+    // whole tensors: the contributing pixels are the rows of dy in order, no walk needed
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.DY + (REGION ? (long)n_first * p.Ho * p.Wo : kbeg) * p.dy_pitch), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)OOB, 0x00020000);
+
+    const int qa = tid % QA, pa0 = tid / QA;
+    const int qb = tid % QB, pb0 = tid / QB;
+    const int cha = i0 + 8 * qa, chb = j0 + 8 * qb;
+    const bool acta = cha < p.Cout, actb = chb < p.Cin;
+    // pixel walkers (image-relative to n_first), advanced by BK per K-step
+    int an[NAP], ay[NAP], ax[NAP], apix[NAP];
+    int bn[NBP], by[NBP], bx[NBP], bpix[NBP];
+    auto init_px = [&](long m, int &n, int &y, int &x, int &pix) {
+        n = (int)(m / HoWo);
+        pix = (int)(m - (long)n * HoWo);
+        if (REGION) region_yx(pix, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+        else { y = pix / p.Wo; x = pix - y * p.Wo; }
+        n -= n_first;
+    };
+    if (REGION) {
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) init_px(kbeg + pa0 + PAS * j, an[j], ay[j], ax[j], apix[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) init_px(kbeg + pb0 + PBS * j, bn[j], by[j], bx[j], bpix[j]);
+    const bool incr = !REGION && p.Wo >= BK;
+    auto advance = [&](int &n, int &y, int &x, int &pix) {
+        if (incr) {                              // Wo >= BK: at most one row wrap per K-step
+            x += BK;
+            const bool wx = x >= p.Wo;
+            x -= wx ? p.Wo : 0;
+            y += wx ? 1 : 0;
+            const bool wy = y == p.Ho;
+            y = wy ? 0 : y;
+            n += wy ? 1 : 0;
+        } else {
+            pix += BK;
+            while (pix >= HoWo) { pix -= HoWo; ++n; }
+            if (REGION) region_yx(pix, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+            else { y = pix / p.Wo; x = pix - y * p.Wo; }
+        }
+    };
+
+    u32x4 ra[NAP], rb[NBP];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) {
+            const int mk = kt * BK + pa0 + PAS * j;
+            const bool v = acta && mk < klen;
+            unsigned bo;
+            if (REGION) {
+                bo = v ? (unsigned)(((an[j] * p.Ho + ay[j]) * p.Wo + ax[j]) * p.dy_pitch + cha) * 2u : OOB;
+                advance(an[j], ay[j], ax[j], apix[j]);
+            } else {
+                bo = v ? (unsigned)(mk * p.dy_pitch + cha) * 2u : OOB;
+            }
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NBP; ++j) {
+            const int mk = kt * BK + pb0 + PBS * j;
+            const int sy = by[j] * p.stride - p.pad + r * p.dil;
+            const int sx = bx[j] * p.stride - p.pad + s * p.dil;
+            const bool v = actb && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const unsigned bo = v ? (unsigned)(((bn[j] * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 2u : OOB;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0);
+            advance(bn[j], by[j], bx[j], bpix[j]);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *As = smem + buf * STAGE, *Bs = As + PLA;
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) *reinterpret_cast<u32x4 *>(As + (pa0 + PAS * j) * PIA + qa * 16) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NBP; ++j) *reinterpret_cast<u32x4 *>(Bs + (pb0 + PBS * j) * PIB + qb * 16) = rb[j];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    // fragment addressing (see igemm_wgrad_h2t_kernel): 16-lane group gi serves tile rows 16 (gi & 1) .. +15 and the k
+    // half gi >> 1; lane q of the group points at pixel row 8 (gi >> 1) + q / 4 (+ 4 for the second read), channels 4 (q % 4)
+    const int gi = lane >> 4, q16 = lane & 15;
+    const int fa = (8 * (gi >> 1) + (q16 >> 2)) * PIA + (arow0 + 16 * (gi & 1) + 4 * (q16 & 3)) * 2;
+    const int fb = (8 * (gi >> 1) + (q16 >> 2)) * PIB + (brow0 + 16 * (gi & 1) + 4 * (q16 & 3)) * 2;
+    auto mma = [&](int buf) {
+        const char *As = smem + buf * STAGE, *Bs = As + PLA;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                     // two 16-pixel substeps
+            bf16x8 a[MR], b[NR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                const u32x2 lo = lds_tr16(As + fa + 16 * j * PIA + mr * 64);
+                const u32x2 hi = lds_tr16(As + fa + 16 * j * PIA + mr * 64 + 4 * PIA);
+                a[mr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const u32x2 lo = lds_tr16(Bs + fb + 16 * j * PIB + nr * 64);
+                const u32x2 hi = lds_tr16(Bs + fb + 16 * j * PIB + nr * 64 + 4 * PIB);
+                b[nr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+        }
+    };
+
+    const int KT = (klen + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(cur);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    mma((KT - 1) & 1);
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const long row_pitch = (long)p.R * p.S * p.Cin;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = rbase + (e & 3) + 8 * (e >> 2);
+            if (co >= p.Cout) continue;
+            float *drow = out + co * row_pitch + (long)rs * p.Cin + j0 + brow0 + l31;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
+                float v = acc[mr][nr][e];
+                if (p.beta && gridDim.z == 1) v += drow[nr * 32];
+                drow[nr * 32] = v;
+            }
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
+                                     int splits, int beta) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += step) {
+        f32x4 a0 = beta ? reinterpret_cast<const f32x4 *>(dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+        int s = 0;
+        for (; s + 3 < splits; s += 4) {
+            a0 += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
+            a1 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 1) * stride)[i];
+            a2 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 2) * stride)[i];
+            a3 += reinterpret_cast<const f32x4 *>(ws + (long)(s + 3) * stride)[i];
+        }
+        for (; s < splits; ++s) a0 += reinterpret_cast<const f32x4 *>(ws + (long)s * stride)[i];
+        reinterpret_cast<f32x4 *>(dw)[i] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- host side
+int check_shape(const rcf_conv_shape *s) {
+    if (!s) return RCF_EINVAL;
+    if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->R <= 0 || s->S <= 0) return RCF_EINVAL;
+    // 16-byte loads of 8 bf16 channels: channel counts and pitches in multiples of 8
+    if (s->Cin % 8 || s->Cout % 8 || s->x_pitch % 8 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
+    if (s->stride <= 0 || s->dil <= 0 || s->pad < 0) return RCF_EINVAL;
+    const int ho = (s->H + 2 * s->pad - s->dil * (s->R - 1) - 1) / s->stride + 1;
+    const int wo = (s->W + 2 * s->pad - s->dil * (s->S - 1) - 1) / s->stride + 1;
+    if (ho != s->Ho || wo != s->Wo) return RCF_EINVAL;
+    if ((long)s->N * s->Ho * s->Wo >= (1L << 31) || (long)s->N * s->H * s->W >= (1L << 31)) return RCF_EINVAL;
+    return 0;
+}
+
+inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+
+inline int region_pixels(const rcf_conv_region *r, int H, int W) {
+    if (!r) return H * W;
+    return r->band > 0 ? 2 * r->band * r->w + 2 * r->band * (r->h - 2 * r->band) : r->h * r->w;
+}
+
+int set_region(ConvParams &p, const rcf_conv_region *r, int N, int H, int W) {
+    p.ry0 = r ? r->y0 : 0; p.rx0 = r ? r->x0 : 0; p.rh = r ? r->h : H; p.rw = r ? r->w : W;
+    p.rband = r ? r->band : 0;
+    if (p.ry0 < 0 || p.rx0 < 0 || p.rh <= 0 || p.rw <= 0 || p.ry0 + p.rh > H || p.rx0 + p.rw > W) return RCF_EINVAL;
+    if (p.rband < 0 || (p.rband > 0 && (2 * p.rband >= p.rh || 2 * p.rband >= p.rw))) return RCF_EINVAL;
+    p.rr = region_pixels(r, H, W);
+    p.M = N * p.rr;
+    return 0;
+}
+
+int g_bf16_tile = -1;      // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 128x64
+
+template <int MR, int NR, int WM, int WN, bool OBF>
+void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
+    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
+    p.mtiles = rcf_cdiv(p.M, BM);
+    p.ntiles = rcf_cdiv(p.Ncol, BN);
+    const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
+    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
+}
+
+template <bool OBF>
+int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
+    p.cs_magic = magic_of(p.Cs);
+    p.s_magic = magic_of(p.S);
+    if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
+    const long per_tile_imgs = 256 / (long)p.rr + 2;
+    if (per_tile_imgs * p.a_img_stride * 2 >= (1L << 31)) return RCF_EINVAL;
+    const long bbytes = (long)rcf_cdiv(p.K, BKT) * p.Ncol * 64;
+    if (bbytes >= (1L << 31)) return RCF_EINVAL;
+    p.b_bytes = (int)bbytes;
+    const bool strided = p.div > 1;
+    int tile = g_bf16_tile;
+    if (tile < 0) tile = p.Ncol <= 64 ? 3 : (p.Ncol <= 128 ? 0 : 1);
+    if (tile == 3 || p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (tile == 0 || p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (tile == 2) launch_cfg<2, 4, 4, 2, OBF>(p, strided, dgrad, st);
+    else launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+struct WgradPlan {
+    int nr, itiles, jtiles, splitk;
+    long chunk;
+};
+WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
+    WgradPlan pl;
+    pl.nr = (s->Cin >= 256 && s->Cout >= 128) ? 4 : 2;
+    pl.itiles = rcf_cdiv(s->Cout, 128);
+    pl.jtiles = rcf_cdiv(s->Cin, 64 * pl.nr);
+    const long RR = region_pixels(reg, s->Ho, s->Wo);
+    const long M = (long)s->N * RR;
+    const long tiles = (long)pl.itiles * pl.jtiles * s->R * s->S;
+    // 2 workgroups per CU = 512 slots: pick the split whose last round is fullest (time ~ rounds / split; the fixed-order
+    // reduction costs ~ split)
+    const long maxsk = M / 2048 > 1 ? M / 2048 : 1;
+    const long slots = 512, hi = maxsk < 96 ? maxsk : 96;
+    double best = 1e30;
+    long sk = 1;
+    for (long c = 1; c <= hi; ++c) {
+        const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
+        if (cost < best - 1e-12) { best = cost; sk = c; }
+    }
+    long chunk = (M + sk - 1) / sk;
+    chunk = (chunk + 31) / 32 * 32;
+    const long img_bytes = (long)s->H * s->W * s->x_pitch * 2, dy_bytes = (long)s->Ho * s->Wo * s->y_pitch * 2;
+    while (chunk > 32 && ((chunk / RR + 2) * img_bytes >= (1L << 31) || (chunk / RR + 2) * dy_bytes >= (1L << 31)))
+        chunk = (chunk / 2 + 31) / 32 * 32;
+    pl.splitk = (int)((M + chunk - 1) / chunk);
+    pl.chunk = chunk;
+    return pl;
+}
+
+bool region_ok(const rcf_conv_region *r, int H, int W) {
+    return !r || (r->y0 >= 0 && r->x0 >= 0 && r->h > 0 && r->w > 0 && r->y0 + r->h <= H && r->x0 + r->w <= W &&
+                  r->band >= 0 && (r->band == 0 || (2 * r->band < r->h && 2 * r->band < r->w)));
+}
+
+}  // namespace
+
+extern "C" int rcf_conv_bf16_set_tile(int tile) {
+    g_bf16_tile = tile;
+    return 0;
+}
+
+extern "C" size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, int transpose) {
+    if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return 0;
+    const long rows = transpose ? Cin : Cout, K = (long)R * S * (transpose ? Cout : Cin);
+    return (size_t)((K + 31) / 32) * rows * 64;
+}
+
+extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, void *stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(out)) return RCF_EINVAL;
+    const long n = (long)rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, transpose) / 2;
+    const long blocks = (n + 1023) / 1024;
+    const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
+    if (transpose) hipLaunchKernelGGL(weight_bf16_kernel<true>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S);
+    else hipLaunchKernelGGL(weight_bf16_kernel<false>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t rcf_conv2d_fwd_stats_bf16_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s)) return 0;
+    return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 128) + 64) * 2 * s->Cout * sizeof(double);
+}
+
+extern "C" int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, void *y, int ydt,
+                                   const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope, int beta,
+                                   double *sums, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !w_bf16 || !y || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y)) return RCF_EINVAL;
+    if (ydt == RCF_BF16 ? (s->y_pitch % 8) : (s->y_pitch % 4)) return RCF_EINVAL;
+    if (ydt != RCF_BF16 && ydt != RCF_F32) return RCF_EINVAL;
+    ConvParams p{};
+    p.A = (const bf16_t *)x; p.Bw = (const bf16_t *)w_bf16; p.bias = bias; p.Y = y;
+    p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
+    p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
+    if (int e = set_region(p, region, s->N, s->Ho, s->Wo)) return e;
+    p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
+    p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
+    p.act = act; p.slope = slope; p.beta = beta;
+    hipStream_t st = rcf_stream(stream);
+    if (sums) {                                       // batch-norm statistics of the output from the epilogue
+        if (region || bias || act || beta) return RCF_EINVAL;
+        if (!workspace || workspace_bytes < rcf_conv2d_fwd_stats_bf16_workspace_bytes(s)) return RCF_EWORKSPACE;
+        p.stats = (double *)workspace;
+    }
+    const int e = ydt == RCF_BF16 ? launch_conv<true>(p, false, st) : launch_conv<false>(p, false, st);
+    if (e || !sums) return e;
+    return rcf_sum_partials_f64((const double *)workspace, p.mtiles, 2 * s->Cout, sums,
+                                (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, stream);
+}
+
+extern "C" size_t rcf_conv2d_dgrad_bf16_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s)) return 0;
+    return rcf_conv_weight_bf16_bytes(s->Cout, s->Cin, s->R, s->S, 1);
+}
+
+extern "C" int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_conv_shape *s,
+                                     const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    if (s->y_pitch % 8) return RCF_EINVAL;
+    const size_t need = rcf_conv2d_dgrad_bf16_workspace_bytes(s);
+    if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+    if (int e = rcf_conv_weight_bf16(w, s->Cout, s->Cin, s->R, s->S, 1, workspace, stream)) return e;
+    ConvParams p{};
+    p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)workspace; p.bias = nullptr; p.Y = dx;
+    p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
+    p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
+    if (int e = set_region(p, region, s->N, s->H, s->W)) return e;
+    p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
+    p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
+    p.act = 0; p.slope = 0.f; p.beta = beta;
+    return launch_conv<true>(p, true, rcf_stream(stream));
+}
+
+extern "C" size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region) {
+    if (check_shape(s) || !region_ok(region, s->Ho, s->Wo)) return 0;
+    const WgradPlan pl = plan_wgrad(s, region);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * s->Cout * s->R * s->S * s->Cin * sizeof(float);
+}
+
+extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, const rcf_conv_shape *s,
+                                     const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !dy || !dw || !rcf_aligned16(x) || !rcf_aligned16(dy) || !rcf_aligned16(dw)) return RCF_EINVAL;
+    if (s->y_pitch % 8 || !region_ok(region, s->Ho, s->Wo)) return RCF_EINVAL;
+    const WgradPlan pl = plan_wgrad(s, region);
+    const size_t need = rcf_conv2d_wgrad_bf16_workspace_bytes(s, region);
+    if (need > 0 && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
+    hipStream_t st = rcf_stream(stream);
+    WgradParams p{};
+    p.X = (const bf16_t *)x; p.DY = (const bf16_t *)dy;
+    p.OUT = pl.splitk > 1 ? (float *)workspace : dw;
+    p.Cout = s->Cout; p.Cin = s->Cin; p.R = s->R; p.S = s->S;
+    p.H = s->H; p.W = s->W; p.Ho = s->Ho; p.Wo = s->Wo; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
+    p.x_pitch = s->x_pitch; p.dy_pitch = s->y_pitch;
+    p.ry0 = region ? region->y0 : 0; p.rx0 = region ? region->x0 : 0;
+    p.rh = region ? region->h : s->Ho; p.rw = region ? region->w : s->Wo;
+    p.rband = region ? region->band : 0; p.rr = region_pixels(region, s->Ho, s->Wo);
+    p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
+    p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
+    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(s->R * s->S), (unsigned)pl.splitk);
+    if (region) {
+        if (pl.nr == 4) hipLaunchKernelGGL((wgrad_bf16_kernel<4, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (pl.nr == 4) hipLaunchKernelGGL((wgrad_bf16_kernel<4, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, false>), grid, dim3(256), 0, st, p);
+    }
+    RCF_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        const long n4 = p.split_stride / 4;
+        const int bt = n4 < (1 << 17) ? 64 : 256;
+        const int blocks = (int)((n4 + bt - 1) / bt < 4096 ? (n4 + bt - 1) / bt : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(bt), 0, st, (const float *)workspace, dw, n4,
+                           p.split_stride, pl.splitk, beta);
+        RCF_LAUNCH_CHECK();
+    }
+    return 0;
+}

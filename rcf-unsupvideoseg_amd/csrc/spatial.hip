@@ -13,7 +13,8 @@ inline int ew_blocks(long total) {
 }
 
 // ------------------------------------------------------------------------------------------ maxpool
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                           uint8_t *__restrict__ am, int N, int H, int W, int C,
                                                           int Ho, int Wo) {
     const int CV = C / 4;
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restric
             for (int s = 0; s < 3; ++s) {
                 const int xi = xo * 2 - 1 + s;
                 if (xi < 0 || xi >= W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + yi) * W + xi) * C + cv * 4);
+                const f32x4 v = ld4(x + (((long)n * H + yi) * W + xi) * C + cv * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // torch max_pool2d: index starts at the first valid tap; later taps win on
@@ -48,14 +49,15 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restric
                 }
             }
         }
-        *reinterpret_cast<f32x4 *>(y + i * 4) = best;
+        st4(y + i * 4, best);
         uchar4 code = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
         *reinterpret_cast<uchar4 *>(am + i * 4) = code;
     }
 }
 
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ am,
-                                                          float *__restrict__ dx, int N, int H, int W, int C, int Ho,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ dy, const uint8_t *__restrict__ am,
+                                                          T *__restrict__ dx, int N, int H, int W, int C, int Ho,
                                                           int Wo) {
     const int CV = C / 4;
     const long total = (long)N * H * W * CV;
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restric
                 if (xo >= Wo) continue;
                 const long o = ((((long)n * Ho + yo) * Wo + xo) * CV + cv) * 4;
                 const uchar4 code = *reinterpret_cast<const uchar4 *>(am + o);
-                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + o);
+                const f32x4 g = ld4(dy + o);
                 const int want = r * 3 + s;
                 if (code.x == want) acc[0] += g[0];
                 if (code.y == want) acc[1] += g[1];
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restric
                 if (code.w == want) acc[3] += g[3];
             }
         }
-        *reinterpret_cast<f32x4 *>(dx + i * 4) = acc;
+        st4(dx + i * 4, acc);
     }
 }
 
@@ -131,8 +133,9 @@ __device__ __forceinline__ bool in_frame(int y, int x, int H, int W, int t) {
 }
 
 // frame > 0: only the output pixels within `frame` of the border are written
-__global__ void __launch_bounds__(256) resize_nhwc_fwd_kernel(const float *__restrict__ x, int x_pitch,
-                                                              float *__restrict__ y, int y_pitch, int N, int Hi,
+template <typename T>
+__global__ void __launch_bounds__(256) resize_nhwc_fwd_kernel(const T *__restrict__ x, int x_pitch,
+                                                              T *__restrict__ y, int y_pitch, int N, int Hi,
                                                               int Wi, int Ho, int Wo, int C, int align, float sh,
                                                               float sw, int frame) {
     const int CV = C / 4;
@@ -151,16 +154,16 @@ __global__ void __launch_bounds__(256) resize_nhwc_fwd_kernel(const float *__res
         float ly, lx;
         src_index(yo, sh, align, Hi, y0, y1, ly);
         src_index(xo, sw, align, Wi, x0, x1, lx);
-        const float *base = x + (long)n * Hi * Wi * x_pitch + cv * 4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(base + ((long)y0 * Wi + x0) * x_pitch);
-        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(base + ((long)y0 * Wi + x1) * x_pitch);
-        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(base + ((long)y1 * Wi + x0) * x_pitch);
-        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(base + ((long)y1 * Wi + x1) * x_pitch);
+        const T *base = x + (long)n * Hi * Wi * x_pitch + cv * 4;
+        const f32x4 v00 = ld4(base + ((long)y0 * Wi + x0) * x_pitch);
+        const f32x4 v01 = ld4(base + ((long)y0 * Wi + x1) * x_pitch);
+        const f32x4 v10 = ld4(base + ((long)y1 * Wi + x0) * x_pitch);
+        const f32x4 v11 = ld4(base + ((long)y1 * Wi + x1) * x_pitch);
         const float hy = 1.f - ly, hx = 1.f - lx;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
-        *reinterpret_cast<f32x4 *>(y + (((long)n * Ho + yo) * Wo + xo) * y_pitch + cv * 4) = o;
+        st4(y + (((long)n * Ho + yo) * Wo + xo) * y_pitch + cv * 4, o);
     }
 }
 
@@ -188,8 +191,9 @@ __device__ __forceinline__ void cand_range(int in_idx, float scale, int align, i
 }
 
 // frame > 0: dy is taken as zero outside the border frame of that thickness (and not read there)
-__global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__restrict__ dy, int dy_pitch,
-                                                              float *__restrict__ dx, int dx_pitch, int beta, int N,
+template <typename T>
+__global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const T *__restrict__ dy, int dy_pitch,
+                                                              T *__restrict__ dx, int dx_pitch, int beta, int N,
                                                               int Hi, int Wi, int Ho, int Wo, int C, int align,
                                                               float sh, float sw, int frame, int tc) {
     // tc > 0 (frame > 0 and beta != 0): only the input pixels within tc of the border can receive anything from the
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__res
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (frame > 0 && ylo >= frame && yhi < Ho - frame && xlo >= frame && xhi < Wo - frame) {
             // no candidate lies on the frame: nothing reaches this pixel (most of the image)
-            if (!beta) *reinterpret_cast<f32x4 *>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4) = acc;
+            if (!beta) st4(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4, acc);
             continue;
         }
         constexpr int MAXC = 6;                 // candidates per axis handled with weights computed once (2x: 4)
@@ -228,12 +232,12 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__res
             for (int yo = ylo; yo <= yhi; ++yo) {
                 const float wy = tap_weight(yo, yi, sh, align, Hi);
                 if (wy == 0.f) continue;
-                const float *row = dy + (((long)n * Ho + yo) * Wo + xlo) * dy_pitch + cv * 4;
+                const T *row = dy + (((long)n * Ho + yo) * Wo + xlo) * dy_pitch + cv * 4;
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) {
                     if (xlo + k > xhi || wxv[k] == 0.f) continue;
                     if (frame > 0 && !in_frame(yo, xlo + k, Ho, Wo, frame)) continue;
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(row + (long)k * dy_pitch);
+                    const f32x4 g = ld4(row + (long)k * dy_pitch);
                     acc += g * (wy * wxv[k]);
                 }
             }
@@ -245,13 +249,13 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const float *__res
                     const float wx = tap_weight(xo, xi, sw, align, Wi);
                     if (wx == 0.f) continue;
                     if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) continue;
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
+                    const f32x4 g = ld4(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * 4);
                     acc += g * (wy * wx);
                 }
             }
         }
-        f32x4 *dst = reinterpret_cast<f32x4 *>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4);
-        *dst = beta ? (*dst + acc) : acc;
+        T *dst = dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * 4;
+        st4(dst, beta ? (ld4(dst) + acc) : acc);
     }
 }
 
@@ -307,24 +311,27 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float *__restri
     }
 }
 
-__global__ void __launch_bounds__(256) copy2d_kernel(const float *__restrict__ src, long spitch,
-                                                     float *__restrict__ dst, long dpitch, long rows, int C, int beta) {
+// ST -> DT: the same kernel is the fp32 <-> bf16 cast
+template <typename ST, typename DT>
+__global__ void __launch_bounds__(256) copy2d_kernel(const ST *__restrict__ src, long spitch,
+                                                     DT *__restrict__ dst, long dpitch, long rows, int C, int beta) {
     const int CV = C / 4;
     const long total = rows * CV;
     const long step = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * spitch + c4);
-        f32x4 *d = reinterpret_cast<f32x4 *>(dst + r * dpitch + c4);
-        *d = beta ? (*d + v) : v;
+        const f32x4 v = ld4(src + r * spitch + c4);
+        DT *d = dst + r * dpitch + c4;
+        st4(d, beta ? (ld4(d) + v) : v);
     }
 }
 
 // n0 x n1 copies in one launch (blockIdx.y = i0 * n1 + i1): copy (i0, i1) starts at src + i0*sb0 + i1*sb1 and
 // dst + i0*db0 + i1*db1 (element offsets, may be negative)
-__global__ void __launch_bounds__(256) copy2d_batched_kernel(const float *__restrict__ src, long spitch, long sb0, long sb1,
-                                                             float *__restrict__ dst, long dpitch, long db0, long db1,
+template <typename T>
+__global__ void __launch_bounds__(256) copy2d_batched_kernel(const T *__restrict__ src, long spitch, long sb0, long sb1,
+                                                             T *__restrict__ dst, long dpitch, long db0, long db1,
                                                              long rows, int C, int beta, int n1) {
     const int i0 = blockIdx.y / n1, i1 = blockIdx.y - i0 * n1;
     src += i0 * sb0 + i1 * sb1;
@@ -335,15 +342,16 @@ __global__ void __launch_bounds__(256) copy2d_batched_kernel(const float *__rest
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const long r = i / CV;
         const int c4 = (int)(i - r * CV) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * spitch + c4);
-        f32x4 *d = reinterpret_cast<f32x4 *>(dst + r * dpitch + c4);
-        *d = beta ? (*d + v) : v;
+        const f32x4 v = ld4(src + r * spitch + c4);
+        T *d = dst + r * dpitch + c4;
+        st4(d, beta ? (ld4(d) + v) : v);
     }
 }
 
 // inside[p] = src[p] for pixels in the rectangle, 0 elsewhere; outside[p] = the complement (either may be null)
-__global__ void __launch_bounds__(256) split_rect_kernel(const float *__restrict__ src, float *__restrict__ inside,
-                                                         float *__restrict__ outside, long pixels, int H, int W, int C,
+template <typename T>
+__global__ void __launch_bounds__(256) split_rect_kernel(const T *__restrict__ src, T *__restrict__ inside,
+                                                         T *__restrict__ outside, long pixels, int H, int W, int C,
                                                          int y0, int x0, int h, int w) {
     const int CV = C / 4;
     const long total = pixels * CV;
@@ -353,94 +361,127 @@ __global__ void __launch_bounds__(256) split_rect_kernel(const float *__restrict
         const long p = i / CV;
         const int x = (int)(p % W), y = (int)((p / W) % H);
         const bool in = y >= y0 && y < y0 + h && x >= x0 && x < x0 + w;
-        const f32x4 v = reinterpret_cast<const f32x4 *>(src)[i];
-        if (inside) reinterpret_cast<f32x4 *>(inside)[i] = in ? v : z;
-        if (outside) reinterpret_cast<f32x4 *>(outside)[i] = in ? z : v;
+        const f32x4 v = ld4(src + i * 4);
+        if (inside) st4(inside + i * 4, in ? v : z);
+        if (outside) st4(outside + i * 4, in ? z : v);
     }
 }
 
 }  // namespace
 
-extern "C" int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0,
-                                  int x0, int h, int w, void *stream) {
+extern "C" int rcf_split_rect_mp(const void *src, void *inside, void *outside, int dt, int N, int H, int W, int C, int y0,
+                                 int x0, int h, int w, void *stream) {
     if (!src || (!inside && !outside) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (y0 < 0 || x0 < 0 || h <= 0 || w <= 0 || y0 + h > H || x0 + w > W) return RCF_EINVAL;
     const long pixels = (long)N * H * W;
-    hipLaunchKernelGGL(split_rect_kernel, dim3(ew_blocks(pixels * (C / 4))), dim3(256), 0, rcf_stream(stream), src, inside,
-                       outside, pixels, H, W, C, y0, x0, h, w);
+#define RCF_CALL(T)                                                                                                    \
+    hipLaunchKernelGGL(split_rect_kernel<T>, dim3(ew_blocks(pixels * (C / 4))), dim3(256), 0, rcf_stream(stream),     \
+                       (const T *)src, (T *)inside, (T *)outside, pixels, H, W, C, y0, x0, h, w)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0,
+                                  int x0, int h, int w, void *stream) {
+    return rcf_split_rect_mp(src, inside, outside, RCF_F32, N, H, W, C, y0, x0, h, w, stream);
+}
 
+extern "C" int rcf_maxpool3x3s2_fwd_mp(const void *x, void *y, int dt, uint8_t *argmax, int N, int H, int W, int C, int Ho,
+                                       int Wo, void *stream) {
+    if (!x || !y || !argmax || C % 4 || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RCF_EINVAL;
+#define RCF_CALL(T)                                                                                               \
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,        \
+                       rcf_stream(stream), (const T *)x, (T *)y, argmax, N, H, W, C, Ho, Wo)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int rcf_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int N, int H, int W, int C, int Ho,
                                         int Wo, void *stream) {
-    if (!x || !y || !argmax || C % 4 || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RCF_EINVAL;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
-                       rcf_stream(stream), x, y, argmax, N, H, W, C, Ho, Wo);
+    return rcf_maxpool3x3s2_fwd_mp(x, y, RCF_F32, argmax, N, H, W, C, Ho, Wo, stream);
+}
+
+extern "C" int rcf_maxpool3x3s2_bwd_mp(const void *dy, const uint8_t *argmax, void *dx, int dt, int N, int H, int W, int C,
+                                       int Ho, int Wo, void *stream) {
+    if (!dy || !dx || !argmax || C % 4) return RCF_EINVAL;
+#define RCF_CALL(T)                                                                                                       \
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, rcf_stream(stream), \
+                       (const T *)dy, argmax, (T *)dx, N, H, W, C, Ho, Wo)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
-
 extern "C" int rcf_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, float *dx, int N, int H, int W, int C,
                                         int Ho, int Wo, void *stream) {
-    if (!dy || !dx || !argmax || C % 4) return RCF_EINVAL;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, rcf_stream(stream),
-                       dy, argmax, dx, N, H, W, C, Ho, Wo);
+    return rcf_maxpool3x3s2_bwd_mp(dy, argmax, dx, RCF_F32, N, H, W, C, Ho, Wo, stream);
+}
+
+/* frame == 0: the whole tensor */
+extern "C" int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void *y, int y_pitch, int dt, int N, int Hi,
+                                               int Wi, int Ho, int Wo, int C, int align_corners, int frame, void *stream) {
+    if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
+    const long px = frame > 0 ? (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame)) : (long)N * Ho * Wo;
+#define RCF_CALL(T)                                                                                                    \
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel<T>, dim3(ew_blocks(px * (C / 4))), dim3(256), 0, rcf_stream(stream),     \
+                       (const T *)x, x_pitch, (T *)y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners,                    \
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
-
 extern "C" int rcf_resize_bilinear_nhwc_fwd_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi,
                                                 int Wi, int Ho, int Wo, int C, int align_corners, void *stream) {
-    if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
-    hipLaunchKernelGGL(resize_nhwc_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
-                       rcf_stream(stream), x, x_pitch, y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0);
-    RCF_LAUNCH_CHECK();
-    return 0;
+    return rcf_resize_bilinear_nhwc_fwd_mp(x, x_pitch, y, y_pitch, RCF_F32, N, Hi, Wi, Ho, Wo, C, align_corners, 0, stream);
 }
-
 extern "C" int rcf_resize_bilinear_nhwc_fwd_frame_f32(const float *x, int x_pitch, float *y, int y_pitch, int N, int Hi,
                                                       int Wi, int Ho, int Wo, int C, int align_corners, int frame,
                                                       void *stream) {
-    if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
-    if (frame <= 0 || 2 * frame >= Ho || 2 * frame >= Wo) return RCF_EINVAL;
-    const long px = (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame));
-    hipLaunchKernelGGL(resize_nhwc_fwd_kernel, dim3(ew_blocks(px * (C / 4))), dim3(256), 0, rcf_stream(stream), x, x_pitch,
-                       y, y_pitch, N, Hi, Wi, Ho, Wo, C, align_corners, host_scale(Hi, Ho, align_corners),
-                       host_scale(Wi, Wo, align_corners), frame);
+    if (frame <= 0) return RCF_EINVAL;
+    return rcf_resize_bilinear_nhwc_fwd_mp(x, x_pitch, y, y_pitch, RCF_F32, N, Hi, Wi, Ho, Wo, C, align_corners, frame,
+                                           stream);
+}
+
+extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, void *dx, int dx_pitch, int dt, int beta,
+                                               int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                                               int frame, void *stream) {
+    if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
+    // frame > 0: input pixels that can see the output frame lie within tc of the border (conservative: an input pixel's
+    // taps lie within (1 + 1/scale) output pixels of its centre); only when the kernel accumulates (beta), otherwise
+    // the interior must be written (zeros)
+    int tc = 0;
+    if (frame > 0 && beta) {
+        const float smax = fmaxf((float)Hi / (float)Ho, (float)Wi / (float)Wo);
+        tc = (int)ceilf(smax * (float)(frame + 2)) + 2;
+        if (2 * tc >= Hi || 2 * tc >= Wi) tc = 0;
+    }
+    const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
+#define RCF_CALL(T)                                                                                                  \
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel<T>, dim3(ew_blocks(items)), dim3(256), 0, rcf_stream(stream),          \
+                       (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,        \
+                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame, tc)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
-
 extern "C" int rcf_resize_bilinear_nhwc_bwd_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta,
                                                 int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
                                                 void *stream) {
-    if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
-    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks((long)N * Hi * Wi * (C / 4))), dim3(256), 0,
-                       rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), 0, 0);
-    RCF_LAUNCH_CHECK();
-    return 0;
+    return rcf_resize_bilinear_nhwc_bwd_mp(dy, dy_pitch, dx, dx_pitch, RCF_F32, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
+                                           0, stream);
 }
-
 extern "C" int rcf_resize_bilinear_nhwc_bwd_frame_f32(const float *dy, int dy_pitch, float *dx, int dx_pitch, int beta,
                                                       int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
                                                       int frame, void *stream) {
-    if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
-    if (frame <= 0 || 2 * frame >= Ho || 2 * frame >= Wo) return RCF_EINVAL;
-    // input pixels that can see the output frame: within tc of the border (conservative: an input pixel's taps lie
-    // within (1 + 1/scale) output pixels of its centre); only when the kernel accumulates (beta), otherwise the
-    // interior must be written (zeros)
-    const float smax = fmaxf((float)Hi / (float)Ho, (float)Wi / (float)Wo);
-    int tc = beta ? (int)ceilf(smax * (float)(frame + 2)) + 2 : 0;
-    if (tc > 0 && (2 * tc >= Hi || 2 * tc >= Wi)) tc = 0;
-    const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
-    hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(ew_blocks(items)), dim3(256), 0,
-                       rcf_stream(stream), dy, dy_pitch, dx, dx_pitch, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
-                       host_scale(Hi, Ho, align_corners), host_scale(Wi, Wo, align_corners), frame, tc);
-    RCF_LAUNCH_CHECK();
-    return 0;
+    if (frame <= 0) return RCF_EINVAL;
+    return rcf_resize_bilinear_nhwc_bwd_mp(dy, dy_pitch, dx, dx_pitch, RCF_F32, beta, N, Hi, Wi, Ho, Wo, C, align_corners,
+                                           frame, stream);
 }
 
 extern "C" int rcf_resize_bilinear_nchw_f32(const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
@@ -469,24 +510,46 @@ extern "C" int rcf_nhwc_to_nchw_f32(const float *x, int x_pitch, float *y, int N
     return 0;
 }
 
-extern "C" int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, float *dst, long dpitch, long db0,
-                                      long db1, long rows, int C, int beta, int n0, int n1, void *stream) {
+extern "C" int rcf_copy2d_batched_mp(const void *src, long spitch, long sb0, long sb1, void *dst, long dpitch, long db0,
+                                     long db1, int dt, long rows, int C, int beta, int n0, int n1, void *stream) {
     if (!src || !dst || C % 4 || spitch % 4 || dpitch % 4 || sb0 % 4 || sb1 % 4 || db0 % 4 || db1 % 4 || rows <= 0) return RCF_EINVAL;
     if (n0 <= 0 || n1 <= 0 || (long)n0 * n1 > 65535) return RCF_EINVAL;
     long blocks = (rows * (C / 4) + 1023) / 1024;
     const long cap = 4096 / ((long)n0 * n1) > 1 ? 4096 / ((long)n0 * n1) : 1;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(copy2d_batched_kernel, dim3((unsigned)blocks, (unsigned)(n0 * n1)), dim3(256), 0, rcf_stream(stream),
-                       src, spitch, sb0, sb1, dst, dpitch, db0, db1, rows, C, beta, n1);
+#define RCF_CALL(T)                                                                                                     \
+    hipLaunchKernelGGL(copy2d_batched_kernel<T>, dim3((unsigned)blocks, (unsigned)(n0 * n1)), dim3(256), 0,             \
+                       rcf_stream(stream), (const T *)src, spitch, sb0, sb1, (T *)dst, dpitch, db0, db1, rows, C, beta, n1)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
     RCF_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, float *dst, long dpitch, long db0,
+                                      long db1, long rows, int C, int beta, int n0, int n1, void *stream) {
+    return rcf_copy2d_batched_mp(src, spitch, sb0, sb1, dst, dpitch, db0, db1, RCF_F32, rows, C, beta, n0, n1, stream);
+}
 
-extern "C" int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
-                              void *stream) {
+/* dst[r][c] (+)= src[r][c] with the two sides in their own storage types: strided copy, or the fp32 <-> bf16 cast */
+extern "C" int rcf_copy2d_mp(const void *src, int sdt, long spitch, void *dst, int ddt, long dpitch, long rows, int C,
+                             int beta, void *stream) {
     if (!src || !dst || C % 4 || spitch % 4 || dpitch % 4 || rows <= 0) return RCF_EINVAL;
-    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), src, spitch,
-                       dst, dpitch, rows, C, beta);
+    const dim3 grid(ew_blocks(rows * (C / 4)));
+    hipStream_t st = rcf_stream(stream);
+    if (sdt == RCF_F32 && ddt == RCF_F32)
+        hipLaunchKernelGGL((copy2d_kernel<float, float>), grid, dim3(256), 0, st, (const float *)src, spitch, (float *)dst, dpitch, rows, C, beta);
+    else if (sdt == RCF_BF16 && ddt == RCF_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t *)src, spitch, (bf16_t *)dst, dpitch, rows, C, beta);
+    else if (sdt == RCF_F32 && ddt == RCF_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float *)src, spitch, (bf16_t *)dst, dpitch, rows, C, beta);
+    else if (sdt == RCF_BF16 && ddt == RCF_F32)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t *)src, spitch, (float *)dst, dpitch, rows, C, beta);
+    else
+        return RCF_EINVAL;
     RCF_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int rcf_copy2d_f32(const float *src, long spitch, float *dst, long dpitch, long rows, int C, int beta,
+                              void *stream) {
+    return rcf_copy2d_mp(src, RCF_F32, spitch, dst, RCF_F32, dpitch, rows, C, beta, stream);
 }

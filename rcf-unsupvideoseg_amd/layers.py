@@ -14,6 +14,25 @@ import torch.nn as nn
 from . import ops
 
 
+# Storage type of the activations (and their gradients) between layers: torch.float32, or torch.bfloat16 for the
+# mixed-precision step (BASELINE configs[2]: bf16 forward / fp32 gradients -- what the reference's AMP configs do under
+# torch autocast, configs/rcf_stv2/rcf_stage1.yaml:57-60).  In bf16 mode the stem conv (fp32 image, Cin = 3) and the loss
+# tail stay fp32: the first batch norm turns the stem's fp32 output into bf16 activations, every conv after it runs on
+# the bf16-operand kernels (csrc/igemm_bf16.hip) with fp32 accumulation, the heads' final 1x1 convs write fp32 logits,
+# parameter gradients are fp32.  Set by RCFModel at the start of each forward.
+ACT_DTYPE = torch.float32
+
+
+def set_act_dtype(dtype):
+    global ACT_DTYPE
+    assert dtype in (torch.float32, torch.bfloat16)
+    ACT_DTYPE = dtype
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "amax", "grad_amax")
@@ -33,7 +52,7 @@ class Act:
     def grad_slot(self):
         """(tensor, beta) for the next gradient producer."""
         if self.grad is None:
-            self.grad = torch.empty(tuple(self.t.shape), dtype=torch.float32, device=self.t.device)
+            self.grad = torch.empty(tuple(self.t.shape), dtype=self.t.dtype, device=self.t.device)
             return self.grad, 0
         self.grad_amax = None        # a second producer accumulates: the first one's range no longer bounds the sum
         return self.grad, 1
@@ -139,17 +158,19 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
         nn.init.kaiming_normal_(self.weight, a=0, mode="fan_out", nonlinearity="relu")   # mmcv kaiming_init
 
-    def _packed_weight(self):
-        """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded."""
-        if self.cin_pad == self.cin and self.cout_pad == self.cout:
+    def _packed_weight(self, cout_mult=4):
+        """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded
+        (Cout_pad = Cout rounded up to `cout_mult`)."""
+        cp = _round_up(self.cout, cout_mult)
+        if self.cin_pad == self.cin and cp == self.cout:
             return self.weight
         if self.cin_pad != self.cin:
             # [Cout,Cin,R,S] contiguous is an "NCHW" tensor with N=Cout: the layout kernel pads C to 4
-            assert self.cout_pad == self.cout
+            assert cp == self.cout
             w = ops.nchw_to_nhwc(self.weight.detach().contiguous(), self.cin_pad)      # [Cout,R,S,4]
             return w.permute(0, 3, 1, 2)
-        # Cout not a multiple of 4 (e.g. 3 segments): rows are contiguous, so padding = prefix copy + zero rows
-        w = torch.zeros((self.cout_pad, self.k, self.k, self.cin), dtype=torch.float32, device=self.weight.device)
+        # Cout not a multiple (e.g. 3 segments): rows are contiguous, so padding = prefix copy + zero rows
+        w = torch.zeros((cp, self.k, self.k, self.cin), dtype=torch.float32, device=self.weight.device)
         n = self.weight.numel()
         ops.copy2d(self.weight.detach().permute(0, 2, 3, 1), n, w, n, 1, n)
         return w.permute(0, 3, 1, 2)
@@ -161,9 +182,74 @@ class Conv2d(nn.Module):
         b[:self.cout].copy_(self.bias.detach())
         return b
 
+    def _fwd_bf16(self, x, tape, out=None, stats=False):
+        """bf16 activations in; bf16 out -- or fp32 out for the heads' final convs (`out_fp32`, or Cout % 8 != 0), whose
+        results feed the fp32 loss tail.  Weights: fp32 master copy cast per launch; weight gradient fp32."""
+        if self.cin % 8:
+            raise ops._lib.RcfHipError("the bf16-operand conv kernels need Cin % 8 == 0")
+        if self.act:
+            raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
+        out_f32 = getattr(self, "out_fp32", False) or self.cout % 8 != 0
+        if out_f32:
+            w, b = self._packed_weight(), self._packed_bias()          # Cout padded to a multiple of 4: fp32 quads
+            y = ops.conv2d_fwd_bf16(x.t, w, None, b, self.stride, self.padding, self.dilation, out=out,
+                                    out_dtype=torch.float32)
+            ya = Act(y)
+        else:
+            w, b = self.weight, self.bias
+            if stats and FUSE_BN_STATS and b is None and out is None:
+                y, sums = ops.conv2d_fwd_bf16(x.t, w, None, None, self.stride, self.padding, self.dilation, stats=True)
+                ya = Act(y)
+                ya.stats = sums
+            else:
+                ya = Act(ops.conv2d_fwd_bf16(x.t, w, None, b, self.stride, self.padding, self.dilation, out=out))
+        if tape.enabled:
+            def bwd():
+                dy = ya.take_grad()
+                if self.bias is not None and self.bias.requires_grad:
+                    if dy.shape[3] == self.cout:
+                        ops.colsum(dy, _param_grad(self.bias), beta=1)
+                    else:
+                        db = torch.zeros(dy.shape[3], dtype=torch.float32, device=dy.device)
+                        ops.colsum(dy, db, beta=0)
+                        _param_grad(self.bias).add_(db[:self.cout])
+                wk = self.weight
+                if dy.dtype != torch.bfloat16:
+                    # fp32 gradient of an fp32 output: as bf16 with the channels zero-padded to a multiple of 8
+                    c8 = _round_up(dy.shape[3], 8)
+                    d16 = (torch.zeros if c8 != dy.shape[3] else torch.empty)(tuple(dy.shape[:3]) + (c8,),
+                                                                                dtype=torch.bfloat16, device=dy.device)
+                    ops.cast(dy, torch.bfloat16, out=d16[..., :dy.shape[3]])
+                    dy = d16
+                    wk = self._packed_weight(8)
+                if self.weight.requires_grad:
+                    padded = wk is not self.weight
+                    dw = torch.empty_like(wk) if padded else _param_grad(self.weight)
+                    if OVERLAP_WGRAD and x.needs_grad and not padded:
+                        side = _side_stream(dy.device)
+                        side.wait_stream(torch.cuda.current_stream(dy.device))
+                        with torch.cuda.stream(side):
+                            ops.conv2d_wgrad_bf16(x.t, dy, wk, dw, self.stride, self.padding, self.dilation, beta=1)
+                        dy.record_stream(side)
+                        x.t.record_stream(side)
+                    else:
+                        ops.conv2d_wgrad_bf16(x.t, dy, wk, dw, self.stride, self.padding, self.dilation,
+                                              beta=0 if padded else 1)
+                    if padded:                                           # prefix = the real rows
+                        g = _param_grad(self.weight)
+                        n = g.numel()
+                        ops.copy2d(dw.permute(0, 2, 3, 1), n, g.permute(0, 2, 3, 1), n, 1, n, beta=1)
+                if x.needs_grad:
+                    gx, beta = x.grad_slot()
+                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta)
+            tape.push(bwd)
+        return ya
+
     def fwd(self, x, tape, out=None, stats=False):
         """Returns an Act with cout_pad channels (the padded ones are exactly zero).
         stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics."""
+        if x.t.dtype == torch.bfloat16:
+            return self._fwd_bf16(x, tape, out, stats)
         w, b = self._packed_weight(), self._packed_bias()
         ax = aw = wp = None
         if FP16_PAIRS:
@@ -258,10 +344,11 @@ class BatchNorm2d(nn.Module):
         if relu and tape.enabled and RELU_BITMASK:
             # the backward kernels read this (one byte per 4 channels) instead of y
             rmask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=xt.device)
-        yamax = ops.new_amax(xt.device) if FP16_PAIRS else None
+        ydt = out.dtype if out is not None else (ACT_DTYPE if xt.dtype == torch.float32 else xt.dtype)
+        yamax = ops.new_amax(xt.device) if FP16_PAIRS and ydt == torch.float32 else None
         y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
                          residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out,
-                         relu_mask=rmask, amax_out=yamax)
+                         relu_mask=rmask, amax_out=yamax, out_dtype=ydt)
         ya = Act(y)
         ya.amax = yamax
         if tape.enabled:
@@ -279,7 +366,7 @@ class BatchNorm2d(nn.Module):
                 if residual is not None and residual.needs_grad:
                     dres, rbeta = residual.grad_slot()
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
-                gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS else None
+                gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS and xt.dtype == torch.float32 else None
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
@@ -331,7 +418,7 @@ def concat_channels(parts, tape, size=None, align_corners=False, widths=None):
         H, W = size
     widths = [p.t.shape[3] for p in parts] if widths is None else list(widths)
     ctot = sum(widths)
-    buf = torch.empty((N, H, W, ctot), dtype=torch.float32, device=parts[0].t.device)
+    buf = torch.empty((N, H, W, ctot), dtype=parts[0].t.dtype, device=parts[0].t.device)
     offs, o = [], 0
     for p, c in zip(parts, widths):
         sl = buf[..., o:o + c]
@@ -368,7 +455,8 @@ def commuted_concat_conv_ok(a, b, conv, align_corners):
     return (conv.k == 3 and conv.stride == 1 and d % 2 == 0 and d >= 2 and conv.padding == d and conv.bias is None
             and not align_corners and (h, w) == (2 * b.t.shape[1], 2 * b.t.shape[2])
             and conv.cin == a.t.shape[3] + b.t.shape[3] and conv.cout_pad == conv.cout and conv.cin_pad == conv.cin
-            and min(h, w) > 2 * (2 * d + 1) and a.t.is_contiguous() and b.t.is_contiguous() and ops.conv_regions_available())
+            and min(h, w) > 2 * (2 * d + 1) and a.t.is_contiguous() and b.t.is_contiguous() and ops.conv_regions_available()
+            and (a.t.dtype == torch.float32 or (a.t.shape[3] % 8 == 0 and b.t.shape[3] % 8 == 0 and conv.cout % 8 == 0)))
 
 
 def commuted_concat_conv(a, b, conv, tape):
@@ -390,23 +478,45 @@ def commuted_concat_conv(a, b, conv, tape):
     bw = d + 1                                   # border band (output pixels computed directly)
     bi = bw + d                                  # input pixels the band's gradient reaches
     W = conv.weight
+    dt = a.t.dtype
+    bf = dt == torch.bfloat16                    # bf16-operand kernels (mixed-precision step), else fp32-level kernels
+    assert b.t.dtype == dt
     wa = W[:, :Ca].contiguous(memory_format=torch.channels_last)
     wbt = W[:, Ca:].contiguous(memory_format=torch.channels_last)
     # the up-sampled channels are only ever needed on the frame the band's taps reach (bi = bw + d pixels)
-    Uup = torch.empty((N, h, w, Cb), dtype=torch.float32, device=a.t.device)
+    Uup = torch.empty((N, h, w, Cb), dtype=dt, device=a.t.device)
     ops.resize_nhwc_fwd(b.t, (h, w), False, out=Uup, frame=bi)
     interior = (bw, bw, h - 2 * bw, w - 2 * bw)
     band = (0, 0, h, w, bw)                      # the border frame of thickness bw, one launch
     # operand ranges of the fp16-pair kernels: bilinear interpolation is a convex combination (|Uup| <= max |b|),
     # and one range serves both halves of the weight
     ra = rb = rw = pa = pb = None
-    if FP16_PAIRS:
+    h2 = FP16_PAIRS and not bf
+    if h2:
         ra, rb, rw = a.range(), b.range(), ops.absmax(ops.weight_rsck(W))
         pa, pb = ops.weight_pairs(wa, rw), ops.weight_pairs(wbt, rw)
-    Z = ops.conv2d_fwd(b.t, wbt, None, 1, d // 2, d // 2, amax=(rb, rw), w_pairs=pb)
+    if bf:
+        pa, pb = ops.weight_bf16(wa), ops.weight_bf16(wbt)
+
+    def cfwd(x, wt, wpre, dil, rx, out=None, beta=0, region=None):
+        if bf:
+            return ops.conv2d_fwd_bf16(x, wt, wpre, None, 1, dil, dil, out=out, beta=beta, region=region)
+        return ops.conv2d_fwd(x, wt, None, 1, dil, dil, out=out, beta=beta, region=region, amax=(rx, rw), w_pairs=wpre)
+
+    def cwgrad(x, dy, wt, dw, dil, beta, rx, rdy, region=None):
+        if bf:
+            return ops.conv2d_wgrad_bf16(x, dy, wt, dw, 1, dil, dil, beta=beta, region=region)
+        return ops.conv2d_wgrad(x, dy, wt, dw, 1, dil, dil, beta=beta, region=region, amax=(rx, rdy))
+
+    def cdgrad(dy, wt, xshape, dil, out, beta, rdy, region=None):
+        if bf:
+            return ops.conv2d_dgrad_bf16(dy, wt, xshape, 1, dil, dil, out=out, beta=beta, region=region)
+        return ops.conv2d_dgrad(dy, wt, xshape, 1, dil, dil, out=out, beta=beta, region=region, amax=(rdy, rw))
+
+    Z = cfwd(b.t, wbt, pb, d // 2, rb)
     y = ops.resize_nhwc_fwd(Z, (h, w), False)                              # interior: conv_d(up2(b)) = up2(conv_{d/2}(b))
-    ops.conv2d_fwd(Uup, wbt, None, 1, d, d, out=y, beta=0, region=band, amax=(rb, rw), w_pairs=pb)    # band: directly
-    ops.conv2d_fwd(a.t, wa, None, 1, d, d, out=y, beta=1, amax=(ra, rw), w_pairs=pa)   # a's channels: everywhere
+    cfwd(Uup, wbt, pb, d, rb, out=y, beta=0, region=band)                  # band: directly
+    cfwd(a.t, wa, pa, d, ra, out=y, beta=1)                                # a's channels: everywhere
     ya = Act(y)
 
     def bwd():
@@ -414,28 +524,27 @@ def commuted_concat_conv(a, b, conv, tape):
         dy_int, dy_band = ops.split_rect(dy, interior)
         g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)                  # adjoint of the interior's up-sampling
         rdy = rg4 = None
-        if FP16_PAIRS:
+        if h2:
             rdy, rg4 = ops.absmax(dy), ops.absmax(g4)                      # dy_band is a part of dy
         if W.requires_grad:
             gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
             dwa = torch.empty_like(wa)
-            ops.conv2d_wgrad(a.t, dy, wa, dwa, 1, d, d, beta=0, amax=(ra, rdy))
+            cwgrad(a.t, dy, wa, dwa, d, 0, ra, rdy)
             ops.copy2d(dwa.permute(0, 2, 3, 1), Ca, gW[..., :Ca], C, Co * 9, Ca, beta=1)
             dwb = torch.empty_like(wbt)
-            ops.conv2d_wgrad(b.t, g4, wbt, dwb, 1, d // 2, d // 2, beta=0, amax=(rb, rg4))
-            ops.conv2d_wgrad(Uup, dy, wbt, dwb, 1, d, d, beta=1, region=band, amax=(rb, rdy))
+            cwgrad(b.t, g4, wbt, dwb, d // 2, 0, rb, rg4)
+            cwgrad(Uup, dy, wbt, dwb, d, 1, rb, rdy, region=band)
             ops.copy2d(dwb.permute(0, 2, 3, 1), Cb, gW[..., Ca:], C, Co * 9, Cb, beta=1)
         if a.needs_grad:
             ga, beta = a.grad_slot()
-            ops.conv2d_dgrad(dy, wa, a.t.shape, 1, d, d, out=ga, beta=beta, amax=(rdy, rw))
+            cdgrad(dy, wa, a.t.shape, d, ga, beta, rdy)
         if b.needs_grad:
             gb, beta = b.grad_slot()
             dUup = torch.empty_like(Uup)                                   # written (and read) on the bi-frame only
-            ops.conv2d_dgrad(dy_band, wbt, Uup.shape, 1, d, d, out=dUup, beta=0, region=(0, 0, h, w, bi),
-                             amax=(rdy, rw))
+            cdgrad(dy_band, wbt, Uup.shape, d, dUup, 0, rdy, region=(0, 0, h, w, bi))
             # the whole-tensor term first, so that the frame term always accumulates (its kernel then only walks the
             # input pixels that can see the frame)
-            ops.conv2d_dgrad(g4, wbt, b.t.shape, 1, d // 2, d // 2, out=gb, beta=beta, amax=(rg4, rw))
+            cdgrad(g4, wbt, b.t.shape, d // 2, gb, beta, rg4)
             ops.resize_nhwc_bwd(dUup, (hb, wb), False, out=gb, beta=1, frame=bi)
     tape.push(bwd)
     return ya
@@ -448,7 +557,7 @@ def pair_concat(x, tape, B, I, order=None):
     N, H, W, C = x.t.shape
     assert N == B * I and x.t.is_contiguous()
     order = list(range(I)) if order is None else list(order)
-    out = torch.empty((B, H, W, I * C), dtype=torch.float32, device=x.t.device)
+    out = torch.empty((B, H, W, I * C), dtype=x.t.dtype, device=x.t.device)
     HW = H * W
     # one launch for the B x I copies when the frame order is an arithmetic progression (identity, or the swap of a pair)
     step = order[1] - order[0] if I > 1 else 1

@@ -166,6 +166,9 @@ class RCFModel(nn.Module):
         if self.decode_head2_ema is not None:
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
         self._tape = None
+        # "fp32" | "bf16" | None.  None = follow torch autocast: the reference's AMP configs (configs/rcf_stv2/rcf_stage1.yaml:57-60,
+        # Lightning `precision: 16`) call the model inside torch.autocast -- that selects the bf16 step here.
+        self.precision = None
         self.dist = None
         self.grad_ready_hook = None      # callable(group) set by the trainer: "heads", "layer4" ... "layer1", "stem"
 
@@ -178,6 +181,15 @@ class RCFModel(nn.Module):
         if self.dist is None:
             self.dist = DistCtx()
         return self.dist
+
+    def _select_precision(self):
+        p = self.precision
+        if p is None:
+            p = "bf16" if torch.is_autocast_enabled() else "fp32"
+        if p not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
+        layers.set_act_dtype(torch.bfloat16 if p == "bf16" else torch.float32)
+        return p
 
     def _images_nhwc(self, imgs):
         B, I, C3, H, W = imgs.shape
@@ -199,6 +211,7 @@ class RCFModel(nn.Module):
     def forward_train(self, imgs, gt_fw_flows, gt_bw_flows, pl_masks=None):
         B, I = imgs.shape[:2]
         dist = self._dist()
+        self._select_precision()
         tape = Tape(on_mark=self.grad_ready_hook)
         img = self._images_nhwc(imgs)
         crf_side = None
@@ -316,6 +329,7 @@ class RCFModel(nn.Module):
         """rcf_model.py:275-320: softmax masks of the current frame [B,C,h,w]; with args.eval_save the 2x
         visualisation grid (and with args.eval_export the object-channel / all-channel PNGs) are written."""
         B, I = imgs.shape[:2]
+        self._select_precision()
         t = Tape(enabled=False)
         img = self._images_nhwc(imgs)
         if self.eval_on_ema:

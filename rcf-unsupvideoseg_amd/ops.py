@@ -22,6 +22,23 @@ def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+def _dt(t):
+    """storage type code of an activation tensor (RCF_F32 / RCF_BF16 of include/rcf_hip.h)"""
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    raise _lib.RcfHipError(f"unsupported activation dtype {t.dtype}")
+
+
+def _same_dt(*ts):
+    d = _dt(ts[0])
+    for t in ts[1:]:
+        if t is not None and _dt(t) != d:
+            raise _lib.RcfHipError("tensors of one call must share their storage type")
+    return d
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -260,6 +277,91 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
     return dw
 
 
+# ------------------------------------------------------------------------------- bf16-operand convs (csrc/igemm_bf16.hip)
+def weight_bf16(w, transpose=False):
+    """fp32 master weight (channels_last [Cout,Cin,R,S]) -> the bf16 operand of the bf16 conv kernels (uint8 buffer)"""
+    _need_cuda(w)
+    Cout, Cin, R, S = w.shape
+    out = torch.empty(_lib.load().rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, int(transpose)), dtype=torch.uint8,
+                      device=w.device)
+    call("rcf_conv_weight_bf16", _p(weight_rsck(w)), Cout, Cin, R, S, int(transpose), _p(out), _stream())
+    return out
+
+
+def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None,
+                    out_dtype=torch.bfloat16, stats=False):
+    """x: NHWC bf16; w: the fp32 master weight (shape only, unless w_bf16 is None); returns y (bf16 or fp32) and, with
+    stats, the fp64 [2*Cout] batch-norm sums of the fp32 accumulators"""
+    _need_cuda(x, w)
+    assert x.dtype == torch.bfloat16
+    if w_bf16 is None:
+        w_bf16 = weight_bf16(w)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    if out is None:
+        out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=out_dtype, device=x.device)
+    s.y_pitch = pitch_of(out)
+    sums = ws = None
+    need = 0
+    if stats:
+        sums = torch.empty(2 * s.Cout, dtype=torch.float64, device=x.device)
+        need = _lib.load().rcf_conv2d_fwd_stats_bf16_workspace_bytes(byref(s))
+        ws = workspace(need, x.device)
+    end = None
+    if PROFILE.which is not None and s.Cout > 128:
+        end = PROFILE.bracket("conv_bf16_fwd", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+    call("rcf_conv2d_fwd_bf16", _p(x), _p(w_bf16), _p(bias), _p(out), _dt(out), byref(s), _region(region), act, slope, beta,
+         _p(sums), _p(ws), need, _stream())
+    if end is not None:
+        end.record()
+    return (out, sums) if stats else out
+
+
+def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None):
+    """dy: NHWC bf16, w: fp32 master weight -> dx bf16 (region in INPUT coordinates)"""
+    _need_cuda(dy, w)
+    assert dy.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(tuple(xshape), dtype=torch.bfloat16, device=dy.device)
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
+    need = _lib.load().rcf_conv2d_dgrad_bf16_workspace_bytes(byref(s))
+    ws = workspace(need, dy.device)
+    end = None
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_bf16_dgrad", 2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
+    call("rcf_conv2d_dgrad_bf16", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws), need,
+         _stream())
+    if end is not None:
+        end.record()
+    return out
+
+
+def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None):
+    """dw (fp32, the weight's memory layout) (+)= wgrad of bf16 x / dy (region in OUTPUT coordinates)"""
+    _need_cuda(x, dy, dw)
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy))
+    reg = _region(region)
+    need = _lib.load().rcf_conv2d_wgrad_bf16_workspace_bytes(byref(s), reg)
+    ws = workspace(need, x.device) if need else None
+    end = None
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_bf16_wgrad", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+    call("rcf_conv2d_wgrad_bf16", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
+    if end is not None:
+        end.record()
+    return dw
+
+
+def cast(x, dtype, out=None):
+    """NHWC activation (possibly a channel slice) -> the same values in `dtype` (fp32 <-> bf16)"""
+    _need_cuda(x)
+    if out is None:
+        out = torch.empty(tuple(x.shape), dtype=dtype, device=x.device)
+    call("rcf_copy2d_mp", _p(x), _dt(x), pitch_of(x), _p(out), _dt(out), pitch_of(out), _rows(x), x.shape[3], 0, _stream())
+    return out
+
+
 def _rows(x):
     return x.shape[0] * x.shape[1] * x.shape[2]
 
@@ -271,7 +373,7 @@ def bn_stats(x):
     sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
     need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
     ws = workspace(need, x.device)
-    call("rcf_bn_stats_f32", _p(x), rows, C, pitch_of(x), _p(sums), _p(ws), need, _stream())
+    call("rcf_bn_stats_mp", _p(x), _dt(x), rows, C, pitch_of(x), _p(sums), _p(ws), need, _stream())
     return sums
 
 
@@ -291,14 +393,16 @@ def bn_invstd_from_var(var, eps):
 
 
 def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None, relu_mask=None,
-             amax_out=None):
-    """relu_mask: uint8 [rows * C/4] to receive the sign bits of the pre-clamp output (for the backward pass)"""
+             amax_out=None, out_dtype=None):
+    """relu_mask: uint8 [rows * C/4] to receive the sign bits of the pre-clamp output (for the backward pass).
+    out_dtype: storage type of y (default: x's); an fp32 x may be normalised into bf16 activations"""
     _need_cuda(x)
     if out is None:
-        out = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+        out = torch.empty(tuple(x.shape), dtype=out_dtype or x.dtype, device=x.device)
     rows, C = _rows(x), x.shape[3]
-    call("rcf_bn_apply_f32", _p(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
-         _p(out), pitch_of(out), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(chan_scale),
+    ydt = _same_dt(out, residual)
+    call("rcf_bn_apply_mp", _p(x), _dt(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
+         _p(out), ydt, pitch_of(out), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(chan_scale),
          x.shape[1] * x.shape[2], _p(relu_mask), _p(amax_out), _stream())
     return out
 
@@ -308,8 +412,8 @@ def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None, relu_mask=None)
     sums2 = torch.empty(2 * C, dtype=torch.float64, device=x.device)
     need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
     ws = workspace(need, x.device)
-    call("rcf_bn_bwd_reduce_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
-         rows, C, _p(mean), _p(invstd), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
+    call("rcf_bn_bwd_reduce_mp", _p(dy), _same_dt(dy, y), pitch_of(dy), _p(x), _dt(x), pitch_of(x), _p(y),
+         pitch_of(y) if y is not None else 0, rows, C, _p(mean), _p(invstd), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
          _p(ws), need, _stream())
     return sums2
 
@@ -318,9 +422,9 @@ def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbet
                  chan_scale=None, sums2_local=None, relu_mask=None, amax_out=None):
     rows, C = _rows(x), x.shape[3]
     if dx is None:
-        dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
-    call("rcf_bn_bwd_apply_f32", _p(dy), pitch_of(dy), _p(x), pitch_of(x), _p(y), pitch_of(y) if y is not None else 0,
-         _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
+        dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+    call("rcf_bn_bwd_apply_mp", _p(dy), _same_dt(dy, y, dres), pitch_of(dy), _p(x), _same_dt(x, dx), pitch_of(x), _p(y),
+         pitch_of(y) if y is not None else 0, _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
          _p(invstd), _p(gamma), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
          _p(sums2_local),
          float(count), _p(dgamma), _p(dbeta), _p(amax_out), _stream())
@@ -331,17 +435,17 @@ def maxpool_fwd(x):
     N, H, W, C = x.shape
     assert x.is_contiguous()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     am = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
-    call("rcf_maxpool3x3s2_fwd_f32", _p(x), _p(y), _p(am), N, H, W, C, Ho, Wo, _stream())
+    call("rcf_maxpool3x3s2_fwd_mp", _p(x), _p(y), _dt(x), _p(am), N, H, W, C, Ho, Wo, _stream())
     return y, am
 
 
 def maxpool_bwd(dy, am, xshape):
     N, H, W, C = xshape
     assert dy.is_contiguous()
-    dx = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
-    call("rcf_maxpool3x3s2_bwd_f32", _p(dy), _p(am), _p(dx), N, H, W, C, dy.shape[1], dy.shape[2], _stream())
+    dx = torch.empty(tuple(xshape), dtype=dy.dtype, device=dy.device)
+    call("rcf_maxpool3x3s2_bwd_mp", _p(dy), _p(am), _p(dx), _dt(dy), N, H, W, C, dy.shape[1], dy.shape[2], _stream())
     return dx
 
 
@@ -350,13 +454,9 @@ def resize_nhwc_fwd(x, size, align_corners=False, out=None, frame=0):
     N, Hi, Wi, C = x.shape
     Ho, Wo = size
     if out is None:
-        out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    if frame > 0:
-        call("rcf_resize_bilinear_nhwc_fwd_frame_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
-             int(align_corners), int(frame), _stream())
-    else:
-        call("rcf_resize_bilinear_nhwc_fwd_f32", _p(x), pitch_of(x), _p(out), pitch_of(out), N, Hi, Wi, Ho, Wo, C,
-             int(align_corners), _stream())
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    call("rcf_resize_bilinear_nhwc_fwd_mp", _p(x), pitch_of(x), _p(out), pitch_of(out), _same_dt(x, out), N, Hi, Wi, Ho, Wo,
+         C, int(align_corners), int(frame), _stream())
     return out
 
 
@@ -365,13 +465,9 @@ def resize_nhwc_bwd(dy, in_size, align_corners=False, out=None, beta=0, frame=0)
     N, Ho, Wo, C = dy.shape
     Hi, Wi = in_size
     if out is None:
-        out = torch.empty((N, Hi, Wi, C), dtype=torch.float32, device=dy.device)
-    if frame > 0:
-        call("rcf_resize_bilinear_nhwc_bwd_frame_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho,
-             Wo, C, int(align_corners), int(frame), _stream())
-    else:
-        call("rcf_resize_bilinear_nhwc_bwd_f32", _p(dy), pitch_of(dy), _p(out), pitch_of(out), beta, N, Hi, Wi, Ho, Wo, C,
-             int(align_corners), _stream())
+        out = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+    call("rcf_resize_bilinear_nhwc_bwd_mp", _p(dy), pitch_of(dy), _p(out), pitch_of(out), _same_dt(dy, out), beta, N, Hi, Wi,
+         Ho, Wo, C, int(align_corners), int(frame), _stream())
     return out
 
 
@@ -394,6 +490,8 @@ def nchw_to_nhwc(x, cpad=None):
 
 
 def nhwc_to_nchw(x, C=None):
+    if x.dtype == torch.bfloat16:
+        x = cast(x, torch.float32)
     N, H, W, Cx = x.shape
     C = C or Cx
     out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
@@ -402,14 +500,15 @@ def nhwc_to_nchw(x, C=None):
 
 
 def copy2d(src, spitch, dst, dpitch, rows, C, beta=0):
-    call("rcf_copy2d_f32", _p(src), spitch, _p(dst), dpitch, rows, C, beta, _stream())
+    call("rcf_copy2d_mp", _p(src), _dt(src), spitch, _p(dst), _dt(dst), dpitch, rows, C, beta, _stream())
 
 
 def copy2d_batched(src, spitch, sstrides, dst, dpitch, dstrides, rows, C, batch, beta=0):
     """batch[0] x batch[1] copies in one launch; src / dst are the base tensors of copy (0, 0) (their data pointers may
     carry an offset), strides in elements (may be negative)"""
-    call("rcf_copy2d_batched_f32", _p(src), int(spitch), int(sstrides[0]), int(sstrides[1]), _p(dst), int(dpitch),
-         int(dstrides[0]), int(dstrides[1]), int(rows), int(C), int(beta), int(batch[0]), int(batch[1]), _stream())
+    call("rcf_copy2d_batched_mp", _p(src), int(spitch), int(sstrides[0]), int(sstrides[1]), _p(dst), int(dpitch),
+         int(dstrides[0]), int(dstrides[1]), _same_dt(src, dst), int(rows), int(C), int(beta), int(batch[0]), int(batch[1]),
+         _stream())
 
 
 def split_rect(x, rect, want_inside=True, want_outside=True):
@@ -419,7 +518,7 @@ def split_rect(x, rect, want_inside=True, want_outside=True):
     N, H, W, C = x.shape
     ins = torch.empty_like(x) if want_inside else None
     outs = torch.empty_like(x) if want_outside else None
-    call("rcf_split_rect_f32", _p(x), _p(ins), _p(outs), N, H, W, C, *[int(v) for v in rect], _stream())
+    call("rcf_split_rect_mp", _p(x), _p(ins), _p(outs), _dt(x), N, H, W, C, *[int(v) for v in rect], _stream())
     return ins, outs
 
 
@@ -427,7 +526,7 @@ def colsum(x, out, beta=1):
     rows, C = _rows(x), x.shape[3]
     need = _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
     ws = workspace(need, x.device)
-    call("rcf_colsum_f32", _p(x), rows, C, pitch_of(x), _p(out), beta, _p(ws), need, _stream())
+    call("rcf_colsum_mp", _p(x), _dt(x), rows, C, pitch_of(x), _p(out), beta, _p(ws), need, _stream())
     return out
 
 

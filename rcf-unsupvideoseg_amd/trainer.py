@@ -81,8 +81,10 @@ class FlatParams:
 
 class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, epochs=200, power=0.9, min_lr=1e-6, device="cuda:0",
-                 betas=(0.9, 0.999), eps=1e-8, force_group=False):
+                 betas=(0.9, 0.999), eps=1e-8, force_group=False, precision=None):
         self.model = model.to(device)
+        if precision is not None:           # "bf16": bf16 activations / operands, fp32 master weights and gradients
+            self.model.precision = precision
         self.device = torch.device(device)
         self.fp = FlatParams(self.model, self.device)
         self.exp_avg = torch.zeros_like(self.fp.flat)

@@ -1,0 +1,265 @@
+"""GPU: the mixed-precision (bf16 storage / bf16 operands / fp32 accumulation) kernels of BASELINE configs[2]
+against float64 torch references evaluated on the SAME bf16-representable inputs -- products of bf16 numbers are exact in
+fp32, so the only errors are fp32 accumulation (1e-6 class) and, for bf16 outputs, the final rounding (2^-9 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rcf_amd
+from rcf_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def q(t):
+    """round to bf16-representable values (kept in the original dtype)"""
+    return t.to(BF).to(t.dtype)
+
+
+def nhwc(x_nchw, dtype=BF):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def conv_ref(x, w, stride, pad, dil):
+    return F.conv2d(x.double(), w.double(), None, stride, pad, dil)
+
+
+CASES = [  # N, Cin, Cout, k, stride, pad, dil, H, W
+    (2, 64, 64, 1, 1, 0, 1, 17, 23),
+    (2, 64, 256, 3, 1, 1, 1, 19, 21),
+    (1, 256, 512, 3, 1, 2, 2, 24, 31),
+    (2, 128, 128, 3, 2, 1, 1, 33, 37),       # strided (layer2.0.conv2)
+    (2, 256, 512, 1, 2, 0, 1, 30, 41),       # strided 1x1 (downsample)
+    (1, 512, 256, 3, 1, 6, 6, 30, 27),       # decode head dilation
+    (2, 72, 40, 3, 1, 1, 1, 15, 18),         # channel counts that are only multiples of 8
+    (1, 2304, 256, 3, 1, 6, 6, 26, 30),      # long K (wide concat)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16_fwd_dgrad_wgrad(case, report):
+    N, Cin, Cout, k, stride, pad, dil, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = q(torch.randn(N, Cin, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    y64 = conv_ref(x, w, stride, pad, dil)
+    dy = q(torch.randn(y64.shape, generator=g))
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    yr.backward(dy.double())
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    xd, dyd = nhwc(x), nhwc(dy)
+    # forward: bf16 out (rounding 2^-9) and fp32 out (accumulation error only); fused BN statistics
+    yb, sums = ops.conv2d_fwd_bf16(xd, wd, stride=stride, pad=pad, dil=dil, stats=True)
+    yf = ops.conv2d_fwd_bf16(xd, wd, stride=stride, pad=pad, dil=dil, out_dtype=torch.float32)
+    ref_nhwc = y64.permute(0, 2, 3, 1)
+    e_f32 = relerr(yf, ref_nhwc)
+    e_bf = relerr(yb.float(), ref_nhwc)
+    exact_round = float((yb.float().cpu() - yf.cpu().to(BF).float()).abs().max())      # bf16 out == RNE(fp32 out)
+    s_ref = torch.cat([y64.sum(dim=(0, 2, 3)), (y64 * y64).sum(dim=(0, 2, 3))])
+    e_stats = relerr(sums, s_ref)
+    # accumulate (beta = 1) into an existing bf16 tensor
+    base = q(torch.randn(ref_nhwc.shape, generator=g))
+    yacc = base.to(BF).to(DEV).clone()
+    ops.conv2d_fwd_bf16(xd, wd, stride=stride, pad=pad, dil=dil, out=yacc, beta=1)
+    e_acc = relerr(yacc.float(), ref_nhwc + base.double())
+    # data gradient (bf16 out) and weight gradient (fp32 out)
+    dx = ops.conv2d_dgrad_bf16(dyd, wd, xd.shape, stride, pad, dil)
+    e_dx = relerr(dx.float(), xr.grad.permute(0, 2, 3, 1))
+    dw = torch.zeros_like(wd)
+    ops.conv2d_wgrad_bf16(xd, dyd, wd, dw, stride, pad, dil, beta=1)
+    e_dw = relerr(dw, wr.grad)
+    dw2 = dw.clone()
+    ops.conv2d_wgrad_bf16(xd, dyd, wd, dw2, stride, pad, dil, beta=1)           # accumulates
+    e_dw2 = relerr(dw2, 2 * wr.grad)
+    report(f"conv bf16 {case}: fwd fp32-out {e_f32:.2e} bf16-out {e_bf:.2e} (vs RNE of fp32-out {exact_round:.1e}) "
+           f"stats {e_stats:.2e} acc {e_acc:.2e} dgrad {e_dx:.2e} wgrad {e_dw:.2e} / {e_dw2:.2e}")
+    assert e_f32 < 2e-5 and e_dw < 2e-5 and e_dw2 < 2e-5 and e_stats < 1e-5
+    assert e_bf < 5e-3 and e_dx < 5e-3 and e_acc < 8e-3
+    assert exact_round == 0.0
+
+
+def test_conv_bf16_narrow_heads_and_bias(report):
+    """the heads' final 1x1 convs: bf16 in, fp32 logits out with bias, Cout padded to 4 (3 segments) / 8 / 16"""
+    g = torch.Generator().manual_seed(5)
+    for Cout in (4, 8, 12, 16):
+        N, Cin, H, W = 2, 256, 21, 25
+        x = q(torch.randn(N, Cin, H, W, generator=g))
+        w = q(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05)
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x.double(), w.double(), b.double()).permute(0, 2, 3, 1)
+        y = ops.conv2d_fwd_bf16(nhwc(x), w.to(DEV).contiguous(memory_format=torch.channels_last), bias=b.to(DEV),
+                                out_dtype=torch.float32)
+        e = relerr(y, ref)
+        ya = ops.conv2d_fwd_bf16(nhwc(x), w.to(DEV).contiguous(memory_format=torch.channels_last), bias=b.to(DEV),
+                                 act=1, slope=0.1, out_dtype=torch.float32)
+        e_act = relerr(ya, F.leaky_relu(ref, 0.1))
+        report(f"conv bf16 head Cout={Cout}: {e:.2e} lrelu {e_act:.2e}")
+        assert e < 1e-5 and e_act < 1e-5
+
+
+def test_conv_bf16_regions(report):
+    """rectangle / border-frame restricted launches (the commuted decode-head conv)"""
+    g = torch.Generator().manual_seed(9)
+    N, Cin, Cout, H, W, d = 2, 64, 64, 40, 46, 6
+    x = q(torch.randn(N, Cin, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05)
+    dy = q(torch.randn(N, Cout, H, W, generator=g))
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    xd, dyd = nhwc(x), nhwc(dy)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, d, d)
+    for name, reg in (("rect", (7, 7, H - 14, W - 14)), ("band", (0, 0, H, W, 7))):
+        mask = torch.zeros(H, W, dtype=torch.bool)
+        if len(reg) == 4:
+            mask[reg[0]:reg[0] + reg[2], reg[1]:reg[1] + reg[3]] = True
+        else:
+            t = reg[4]
+            mask[:] = True
+            mask[t:H - t, t:W - t] = False
+        y = torch.full((N, H, W, Cout), 7.0, dtype=BF, device=DEV)
+        ops.conv2d_fwd_bf16(xd, wd, pad=d, dil=d, out=y, region=reg)
+        want = torch.where(mask[None, :, :, None], yr.detach().permute(0, 2, 3, 1), torch.tensor(7.0, dtype=torch.float64))
+        e_f = relerr(y.float(), want)
+        # wgrad restricted to the region's output pixels; dgrad restricted to input pixels
+        gy = dy.double() * mask[None, None]
+        gx, gw = torch.autograd.grad(yr, [xr, wr], gy, retain_graph=True)
+        dw = torch.zeros_like(wd)
+        ops.conv2d_wgrad_bf16(xd, dyd, wd, dw, 1, d, d, beta=0, region=reg)
+        e_w = relerr(dw, gw)
+        gx_full = torch.autograd.grad(yr, xr, dy.double(), retain_graph=True)[0].permute(0, 2, 3, 1)
+        dx = torch.full((N, H, W, Cin), 3.0, dtype=BF, device=DEV)
+        ops.conv2d_dgrad_bf16(dyd, wd, xd.shape, 1, d, d, out=dx, region=reg)
+        want_dx = torch.where(mask[None, :, :, None], gx_full, torch.tensor(3.0, dtype=torch.float64))
+        e_d = relerr(dx.float(), want_dx)
+        report(f"conv bf16 region {name}: fwd {e_f:.2e} wgrad {e_w:.2e} dgrad {e_d:.2e}")
+        assert e_f < 5e-3 and e_w < 2e-5 and e_d < 5e-3
+
+
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, BF), (BF, BF)])
+@pytest.mark.parametrize("relu,res,drop", [(True, False, False), (True, True, False), (False, False, False), (True, False, True)])
+def test_batchnorm_mixed_precision(xdt, ydt, relu, res, drop, report):
+    """bn stats / apply / backward with bf16 storage == the fp32 kernels on the same (bf16-representable) values, up to
+    the rounding of what is stored"""
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 3, 9, 11, 64
+    x = q(torch.randn(N, H, W, C, generator=g) * 2 + 0.5)
+    r = q(torch.randn(N, H, W, C, generator=g)) if res else None
+    dy = q(torch.randn(N, H, W, C, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    cs = (torch.bernoulli(torch.full((N, C), 0.8), generator=g) / 0.8).to(DEV) if drop else None
+    out = {}
+    for tag, xd, yd in (("f32", torch.float32, torch.float32), ("mp", xdt, ydt)):
+        xt = x.to(xd).to(DEV)
+        sums = ops.bn_stats(xt)
+        mean, invstd = ops.bn_finalize(sums, N * H * W, 1e-5, 0.1)
+        mask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=DEV) if relu else None
+        y = ops.bn_apply(xt, mean, invstd, gamma.to(DEV), beta.to(DEV), relu, residual=r.to(yd).to(DEV) if res else None,
+                         chan_scale=cs, relu_mask=mask, out_dtype=yd)
+        dyt = dy.to(yd).to(DEV)
+        s2 = ops.bn_bwd_reduce(dyt, xt, y, mean, invstd, relu, chan_scale=cs, relu_mask=mask)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dres = torch.empty((N, H, W, C), dtype=yd, device=DEV) if res else None
+        dx = ops.bn_bwd_apply(dyt, xt, y, mean, invstd, gamma.to(DEV), relu, s2, N * H * W, dg, db, dres=dres,
+                              chan_scale=cs, relu_mask=mask)
+        assert y.dtype == yd and dx.dtype == xd
+        out[tag] = dict(sums=sums, y=y.float(), s2=s2, dx=dx.float(), dg=dg, db=db, dres=dres.float() if res else None)
+    e = {k: relerr(out["mp"][k], out["f32"][k]) for k in out["f32"] if out["f32"][k] is not None}
+    report(f"bn mixed precision x:{xdt} y:{ydt} relu={relu} res={res} drop={drop}: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert e["sums"] < 1e-12
+    # the stored y is rounded to bf16 (2^-9); with ReLU the backward reads the sign bits, not y: the sums agree closely
+    assert e["y"] < 5e-3 and e["s2"] < 1e-6 and e["dg"] < 1e-6 and e["db"] < 1e-6
+    assert e["dx"] < (5e-3 if xdt == BF else 1e-6)
+    if res:
+        assert e["dres"] < 5e-3
+
+
+def test_spatial_mixed_precision(report):
+    g = torch.Generator().manual_seed(13)
+    N, H, W, C = 2, 21, 27, 32
+    x = q(torch.randn(N, H, W, C, generator=g))
+    xf, xb = x.to(DEV), x.to(BF).to(DEV)
+    e = {}
+    yf, amf = ops.maxpool_fwd(xf)
+    yb, amb = ops.maxpool_fwd(xb)
+    e["maxpool"] = relerr(yb.float(), yf)
+    assert torch.equal(amf, amb) and yb.dtype == BF
+    dy = q(torch.randn(yf.shape, generator=g))
+    e["maxpool_bwd"] = relerr(ops.maxpool_bwd(dy.to(BF).to(DEV), amb, x.shape).float(), ops.maxpool_bwd(dy.to(DEV), amf, x.shape))
+    for frame in (0, 5):
+        size = (2 * H, 2 * W)
+        of = torch.zeros((N,) + size + (C,), device=DEV)
+        ob = torch.zeros((N,) + size + (C,), dtype=BF, device=DEV)
+        ops.resize_nhwc_fwd(xf, size, False, out=of, frame=frame)
+        ops.resize_nhwc_fwd(xb, size, False, out=ob, frame=frame)
+        e[f"resize_fwd_f{frame}"] = relerr(ob.float(), of)
+        gy = q(torch.randn(of.shape, generator=g))
+        bf_ = ops.resize_nhwc_bwd(gy.to(DEV), (H, W), False, frame=frame)
+        bb = ops.resize_nhwc_bwd(gy.to(BF).to(DEV), (H, W), False, frame=frame)
+        e[f"resize_bwd_f{frame}"] = relerr(bb.float(), bf_)
+    # copies (with accumulate), casts, split
+    dst_f, dst_b = torch.ones(N, H, W, 2 * C, device=DEV), torch.ones(N, H, W, 2 * C, dtype=BF, device=DEV)
+    ops.copy2d(xf, C, dst_f[..., C:], 2 * C, N * H * W, C, beta=1)
+    ops.copy2d(xb, C, dst_b[..., C:], 2 * C, N * H * W, C, beta=1)
+    e["copy_acc"] = relerr(dst_b.float(), dst_f)
+    e["cast"] = relerr(ops.cast(ops.cast(xf, BF), torch.float32), xf)
+    a_f, b_f = ops.split_rect(xf, (3, 4, 10, 12))
+    a_b, b_b = ops.split_rect(xb, (3, 4, 10, 12))
+    e["split"] = max(relerr(a_b.float(), a_f), relerr(b_b.float(), b_f))
+    out_f = torch.zeros(C, device=DEV)
+    out_b = torch.zeros(C, device=DEV)
+    ops.colsum(xf, out_f, beta=0)
+    ops.colsum(xb, out_b, beta=0)
+    e["colsum"] = relerr(out_b, out_f)
+    report("spatial mixed precision: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert e["maxpool"] == 0 and e["cast"] == 0 and e["split"] == 0 and e["colsum"] < 1e-7
+    assert max(e.values()) < 6e-3
+
+
+def _model_and_batch(H, W, B, variant=None):
+    import copy
+    import types
+    from rcf_amd import config, synth
+    if variant is None:
+        kw, oc = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN"), None
+    else:
+        kw, oc = config.variant_model_kwargs(variant, H, W)
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bf16", object_channel=oc)
+    m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    nb = synth.make_batch(B, H, W, config_id=1)
+    batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).to(DEV) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+    return m, batch
+
+
+@pytest.mark.parametrize("variant", [None, "fbms", "joint"])
+def test_bf16_step_runs_and_tracks_fp32(variant, report):
+    """plumbing + sanity of the mixed-precision step: same model / batch in fp32 and in bf16 mode"""
+    H, W, B = 64, 96, 2
+    res = {}
+    for prec in ("fp32", "bf16"):
+        m, batch = _model_and_batch(H, W, B, variant)
+        tr = rcf_amd.Trainer(m, device=DEV, precision=prec)
+        losses = tr.step(batch)
+        gn = {}
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                assert p.grad.dtype == torch.float32
+                gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+        res[prec] = ({k: float(v) for k, v in losses.items()}, {k: v ** 0.5 for k, v in gn.items()})
+    e_l = {k: abs(res["bf16"][0][k] - v) / abs(v) for k, v in res["fp32"][0].items()}
+    e_g = {k: abs(res["bf16"][1][k] - v) / abs(v) for k, v in res["fp32"][1].items()}
+    report(f"bf16 step vs fp32 step [{variant}] {H}x{W}: loss " + " ".join(f"{k} {v:.2e}" for k, v in e_l.items()) +
+           " | gradnorm " + " ".join(f"{k} {v:.2e}" for k, v in e_g.items()))
+    assert all(np.isfinite(v) for v in res["bf16"][0].values())
+    assert max(e_l.values()) < 5e-2 and max(e_g.values()) < 0.3
