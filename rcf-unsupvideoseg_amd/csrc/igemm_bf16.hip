@@ -632,11 +632,12 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
 }
 
 // ------------------------------------------------------------------------------------------- host side
-int check_shape(const rcf_conv_shape *s) {
+// cout_mult: 8 where Cout is read or written as bf16 (16-byte accesses), 4 for the forward with fp32 output
+int check_shape(const rcf_conv_shape *s, int cout_mult = 8) {
     if (!s) return RCF_EINVAL;
     if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->R <= 0 || s->S <= 0) return RCF_EINVAL;
     // 16-byte loads of 8 bf16 channels: channel counts and pitches in multiples of 8
-    if (s->Cin % 8 || s->Cout % 8 || s->x_pitch % 8 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
+    if (s->Cin % 8 || s->Cout % cout_mult || s->x_pitch % 8 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
     if (s->stride <= 0 || s->dil <= 0 || s->pad < 0) return RCF_EINVAL;
     const int ho = (s->H + 2 * s->pad - s->dil * (s->R - 1) - 1) / s->stride + 1;
     const int wo = (s->W + 2 * s->pad - s->dil * (s->S - 1) - 1) / s->stride + 1;
@@ -759,17 +760,17 @@ extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, in
 }
 
 extern "C" size_t rcf_conv2d_fwd_stats_bf16_workspace_bytes(const rcf_conv_shape *s) {
-    if (check_shape(s)) return 0;
+    if (check_shape(s, 4)) return 0;
     return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 128) + 64) * 2 * s->Cout * sizeof(double);
 }
 
 extern "C" int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, void *y, int ydt,
                                    const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope, int beta,
                                    double *sums, void *workspace, size_t workspace_bytes, void *stream) {
-    if (int e = check_shape(s)) return e;
+    if (ydt != RCF_BF16 && ydt != RCF_F32) return RCF_EINVAL;
+    if (int e = check_shape(s, ydt == RCF_BF16 ? 8 : 4)) return e;
     if (!x || !w_bf16 || !y || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y)) return RCF_EINVAL;
     if (ydt == RCF_BF16 ? (s->y_pitch % 8) : (s->y_pitch % 4)) return RCF_EINVAL;
-    if (ydt != RCF_BF16 && ydt != RCF_F32) return RCF_EINVAL;
     ConvParams p{};
     p.A = (const bf16_t *)x; p.Bw = (const bf16_t *)w_bf16; p.bias = bias; p.Y = y;
     p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
