@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--crf-iters", type=int, default=5)
     ap.add_argument("--no-stage2", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true")
     a = ap.parse_args()
 
     import numpy as np
@@ -75,10 +76,6 @@ def main():
     mask = config.mask_size_for(H, W)
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=None, eval_save=False,
                                  eval_export=False)
-    model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(mask, dropout=0.1, norm="SyncBN"))
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
-    trainer = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev)
     nb = synth.make_batch(B, H, W, config_id=2, first_index=rank * B)      # weak scaling: B pairs per rank
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     batch = {"imgs": [t(x) for x in nb["imgs"]], "gt_fw_flows": [t(x) for x in nb["gt_fw_flows"]],
@@ -90,28 +87,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not measurement: two priming steps let the caching allocator and the second stream's scratch reach their
-    # steady state (the first steps hipMalloc); then the W untimed warm-up steps and the K timed ones of the contract
-    for _ in range(PRIMING_STEPS):
-        trainer.step(batch)
-    for _ in range(a.warmup):
-        trainer.step(batch)
-    barrier()
-    ops.PROFILE.start("conv_x3_128x256")
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = trainer.step(batch)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ops.PROFILE.stop()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-    loss_val = float(losses["loss"])
-    if loss_val != loss_val:
-        raise SystemExit("loss is NaN")
+    def step_leg(precision, family, steps, warmup):
+        """One training configuration: PRIMING_STEPS + warmup untimed steps, then `steps` timed ones between barriers
+        (max over ranks), `family` bracketed live inside the timed region; then two more steps with EVERY conv family
+        bracketed (roofline_by_kernel)."""
+        model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(mask, dropout=0.1, norm="SyncBN"))
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+        trainer = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=precision)
+        # set-up, not measurement: priming steps let the caching allocator and the second stream's scratch reach their
+        # steady state (the first steps hipMalloc); then the W untimed warm-up steps and the K timed ones of the contract
+        for _ in range(PRIMING_STEPS + warmup):
+            trainer.step(batch)
+        barrier()
+        ops.PROFILE.start(family)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses = trainer.step(batch)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = ops.PROFILE.stop()
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0])
+        loss_val = float(losses["loss"])
+        if loss_val != loss_val:
+            raise SystemExit("loss is NaN")
+        fams = FAMILIES_BF16 if precision == "bf16" else FAMILIES_F32
+        ops.PROFILE.start(list(fams))
+        for _ in range(2):
+            trainer.step(batch)
+        by = ops.PROFILE.stop()
+        barrier()
+        del trainer, model
+        torch.cuda.empty_cache()
+        return dt, loss_val, prof, by
 
+    def roofline_of(prof, name, kernel, peak, by=None, traffic=None):
+        n, flops, ms = prof["launches"], prof["flops"], prof["ms"]
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"kernel": kernel, "family": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "launches": n,
+                "avg_launch_ms": round(ms / max(n, 1), 4), "flops_per_launch": round(flops / max(n, 1), 1)}
+
+    def by_kernel(by, fams, peak, nsteps=2):
+        out = {}
+        for name, kernel in fams.items():
+            r = by.get(name)
+            if not r or not r["launches"]:
+                continue
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            out[name] = {"kernel": kernel, "launches_per_step": r["launches"] // nsteps,
+                         "ms_per_step": round(r["ms"] / nsteps, 3), "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+                         "flops_per_launch": round(r["flops"] / r["launches"], 1), "achieved": round(ach, 1),
+                         "frac": round(ach / peak, 4)}
+        return out
+
+    # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel with the largest share of
+    # the step's kernel time, the 128x256 weight-gradient tile (it runs on the second stream beside the data gradients,
+    # so its live duration includes what the overlap costs it)
+    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_wgrad_h2t4")
+    dt, loss_val, prof, by32 = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
     value = frames / dt
     out = {
@@ -119,9 +156,10 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "priming_steps": PRIMING_STEPS,
-        "arithmetic": "fp32 conv operands scaled by a power of two into fp16's range and split into 2 fp16 parts "
-                      "(22 significand bits), 3 partial products on fp16 MFMA, fp32 accumulate; error vs float64 at "
-                      "the level of torch's fp32 conv (tests/test_kernels_gpu.py::test_conv_fp16_pairs)",
+        "arithmetic": "fp32 step, emulated on the fp16 matrix cores: every conv operand is scaled by a power of two into "
+                      "fp16's range and split into 2 fp16 parts (22 significand bits), 3 partial products on fp16 MFMA, fp32 "
+                      "accumulate (the m*m' term is dropped); error vs float64 at the level of torch's own fp32 conv, rms AND "
+                      "max (tests/test_kernels_gpu.py::test_conv_fp16_pairs)",
         "config": {"workload": f"RCF stage-1 ResNet50+FCN train step, {B} pairs/GPU of {H}x{W} RGB+flow, "
                                f"mask {mask[0]}x{mask[1]}, fp32, SyncBN, Adam (BASELINE configs[1])",
                    "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}"},
@@ -130,27 +168,43 @@ def main():
         "frac_of_fp32_mfma_roofline": round(value / world * GF_PER_FRAME / 1e3 / FP32_MFMA_PEAK_TF, 4),
         "frac_of_fp16_pair_mfma_roofline": round(value / world * GF_PER_FRAME / 1e3 / H2_MFMA_PEAK_TF, 4),
     }
+    # ---- BASELINE configs[2]: the same step with bf16 activations / operands, fp32 master weights and gradients
+    bf = None
+    if not a.no_bf16:
+        fam16 = os.environ.get("RCF_BENCH_FAMILY_BF16", "conv_bf16_wgrad4")
+        dt16, loss16, prof16, by16 = step_leg("bf16", fam16, a.steps, a.warmup)
+        v16 = frames / dt16
+        bf = {"workload": f"the same step in mixed precision (BASELINE configs[2]): bf16 activations and MFMA operands, fp32 "
+                          f"accumulation, fp32 master weights / gradients / Adam; {B} pairs/GPU, dp{world}",
+              "dtype": "bf16", "frames_per_s": round(v16, 3), "ms_per_step": round(dt16 / a.steps * 1e3, 3),
+              "vs_fp32_step": round(v16 / value, 3), "loss": round(loss16, 6),
+              "step_tflops_per_gpu": round(v16 / world * GF_PER_FRAME / 1e3, 2),
+              "frac_of_bf16_mfma_roofline": round(v16 / world * GF_PER_FRAME / 1e3 / BF16_MFMA_PEAK_TF, 4)}
     if rank == 0:
-        n, flops, ms = prof["launches"], prof["flops"], prof["ms"]
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (B, H, W) == (8, 480, 854):
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+            tj = json.load(open(tpath))
+            if tj.get("family") == fam32:
+                traffic = round(tj["hbm_bytes_per_launch"])
         # The convs run as fp32 contractions on the fp16 matrix cores (each operand scaled and split into 2 fp16
         # parts, 3 partial products, fp32 accumulate): the bound is the dense fp16 MFMA peak / 3 passes.
-        out["roofline"] = {"kernel": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (implicit-GEMM conv, fp16 pairs, weights split beforehand, transposed 16-byte epilogue, 128x256 tile: the forward launches with > 128 output channels; data gradients are the <...,false,true,2,true,true> instance and overlap the weight gradients of a second stream)",
-                           "bound": "mfma", "achieved": round(ach, 2), "peak": round(H2_MFMA_PEAK_TF, 1), "unit": "TFLOP/s",
-                           "frac": round(ach / H2_MFMA_PEAK_TF, 4), "traffic": traffic, "launches": n,
-                           "avg_launch_ms": round(ms / max(n, 1), 4),
-                           "flops_per_launch": round(flops / max(n, 1), 1),
-                           "executed_fp16_mfma_tflops": round(3 * ach, 1), "fp16_mfma_peak": BF16_MFMA_PEAK_TF,
-                           "fp32_mfma_peak": FP32_MFMA_PEAK_TF, "vs_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4)}
+        out["roofline"] = roofline_of(prof, fam32, FAMILIES_F32.get(fam32, fam32), H2_MFMA_PEAK_TF, traffic=traffic)
+        out["roofline"].update({"executed_fp16_mfma_tflops": round(3 * out["roofline"]["achieved"], 1),
+                                "fp16_mfma_peak": BF16_MFMA_PEAK_TF, "fp32_mfma_peak": FP32_MFMA_PEAK_TF,
+                                "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload), not measured in this run"})
+        out["roofline_by_kernel"] = by_kernel(by32, FAMILIES_F32, H2_MFMA_PEAK_TF)
+        if bf is not None:
+            bf["roofline"] = roofline_of(prof16, fam16, FAMILIES_BF16.get(fam16, fam16), BF16_MFMA_PEAK_TF)
+            bf["roofline_by_kernel"] = by_kernel(by16, FAMILIES_BF16, BF16_MFMA_PEAK_TF)
+            out["bf16_step"] = bf
         # CRF ms/frame (second half of BASELINE's metric) -- 480x854, T iterations, batch of 8 frames
         try:
             out["crf_ms_per_frame"] = crf_bench(torch, rcf_amd, synth, dev, H, W, a.crf_iters)
             if world == 1:                                      # the reference's default iteration count (crf_head.py:16)
                 out["crf_ms_per_frame_T50"] = crf_bench(torch, rcf_amd, synth, dev, H, W, 50)
+                # worst case for the lattice (SURVEY.md §8d "reported separately"): uniform-noise frames, L/N ~ 5.5
+                out["crf_ms_per_frame_noise"] = crf_bench(torch, rcf_amd, synth, dev, H, W, a.crf_iters, noise=True)
         except Exception as e:                                  # noqa: BLE001 -- reported, not hidden
             out["crf_ms_per_frame"] = None
             out["crf_error"] = str(e)[:200]
@@ -164,8 +218,6 @@ def main():
         # CRF, T=5) and the EMA teacher forward + update in the loop
         if not a.no_stage2 and world == 1:
             try:
-                del trainer, model
-                torch.cuda.empty_cache()
                 out["stage2_step"] = stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, a.crf_iters)
             except Exception as e:                              # noqa: BLE001
                 out["stage2_step"] = None
@@ -185,13 +237,36 @@ def main():
         dist.destroy_process_group()
 
 
-def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8):
+# bracket families (rcf_amd/ops.py) -> the kernel instance behind each
+FAMILIES_F32 = {
+    "conv_x3_128x256": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (forward, fp16 pairs, 128x256 tile; incl. the two kernels that sum its fused BN statistics)",
+    "conv_fwd_narrow": "igemm_conv_x3_kernel<2,{1,2},2,2,...> / fp32-MFMA stem (forward, <= 128 output channels)",
+    "conv_dgrad_wide": "igemm_conv_x3_kernel<2,4,2,2,false,true,2,true,true> (data gradient, fp16 pairs, 128x256 tile; incl. the weight transpose+split pre-pass)",
+    "conv_dgrad_other": "igemm_conv_x3_kernel<...,true,...> (data gradient: strided / narrow tiles)",
+    "conv_wgrad_h2t4": "igemm_wgrad_h2t_kernel<4> (weight gradient, fp16 pairs, 128x256 tile, transposing LDS reads; incl. the split-K reduction)",
+    "conv_wgrad_other": "igemm_wgrad_h2t_kernel<2> / igemm_wgrad_x3_kernel / igemm_wgrad_kernel (weight gradient: narrow tiles, regions, stem)",
+}
+FAMILIES_BF16 = {
+    "conv_bf16_fwd": "conv_bf16_kernel<2,4,2,2,false,false,true> (forward, bf16 operands, 128x256 tile; incl. the fused BN statistics sums)",
+    "conv_bf16_fwd_narrow": "conv_bf16_kernel<2,{1,2},2,2,...> (forward, <= 128 output channels)",
+    "conv_bf16_dgrad_wide": "conv_bf16_kernel<2,4,2,2,false,true,true> (data gradient, 128x256 tile; incl. the bf16 weight transpose)",
+    "conv_bf16_dgrad_other": "conv_bf16_kernel<...> (data gradient: strided / narrow tiles)",
+    "conv_bf16_wgrad4": "wgrad_bf16_kernel<2,4,false> (weight gradient, bf16 operands, 128x256 tile over (tap, channel) columns; incl. the split-K reduction)",
+    "conv_bf16_wgrad_other": "wgrad_bf16_kernel<1,*,*> / <2,{1,2},*> / <2,4,true> (weight gradient: narrow tiles, regions)",
+    # the fp32 stem and the flow head's two small convs keep the fp32 kernels in the bf16 step
+    "conv_x3_128x256": FAMILIES_F32["conv_x3_128x256"], "conv_fwd_narrow": FAMILIES_F32["conv_fwd_narrow"],
+    "conv_dgrad_other": FAMILIES_F32["conv_dgrad_other"], "conv_wgrad_other": FAMILIES_F32["conv_wgrad_other"],
+}
+
+
+def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8, noise=False):
     """CRFHead on `nframes` 480x854 frames per call.  Roofline: algorithmic bytes per frame =
     T*(192 N + 348 L) + build (68 N + 70 L), N pixels, L lattice vertices (measured, data dependent)."""
     import numpy as np
     from rcf_amd.crf import crf_soft_batched
     head = rcf_amd.CRFHead(None, refine_iters=iters)
-    imgs = torch.from_numpy(np.stack([synth.normalize_rgb(synth.smooth_rgb(H, W, 4000 + i)) for i in range(nframes)])).to(dev)
+    make = synth.noise_rgb if noise else synth.smooth_rgb
+    imgs = torch.from_numpy(np.stack([synth.normalize_rgb(make(H, W, 4000 + i)) for i in range(nframes)])).to(dev)
     masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4000 + i) for i in range(nframes)])).to(dev)
     head(imgs, masks)
     torch.cuda.synchronize()
@@ -208,7 +283,8 @@ def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8):
     N, L = H * W, float(nv[:, 1].float().mean())
     alg = iters * (192.0 * N + 348.0 * L) + 68.0 * N + 70.0 * L
     ach = alg / (ms * 1e-3) / 1e9
-    return {"iters": iters, "frames_per_call": nframes, "value": round(ms, 4), "pixels": N, "lattice_vertices": round(L),
+    return {"iters": iters, "frames_per_call": nframes, "frames": "uniform noise (worst case)" if noise else "smooth synthetic",
+            "value": round(ms, 4), "pixels": N, "lattice_vertices": round(L),
             "algorithmic_bytes_per_frame": round(alg),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4)}}
@@ -296,36 +372,85 @@ def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):
             "flow_warp_GBps": round(px * 32.0 / t_w / 1e9, 1), "flow_warp_us_per_frame": round(t_w / nframes * 1e6, 2)}
 
 
+def _cpu_info():
+    """(model name, logical CPUs available to this process, physical cores among them)"""
+    model, phys = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in allowed:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = [x.strip() for x in line.split(":", 1)]
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if cur and int(cur.get("processor", -1)) in allowed:
+            phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+        return model, len(allowed), max(len(phys), 1)
+    except Exception:                                           # noqa: BLE001
+        return model, os.cpu_count() or 1, os.cpu_count() or 1
+
+
 def cpu_baseline(H, W):
-    """The oracle (CPU restatement of the reference, validated against it in the build container) on a
-    bounded sample of the same workload: ONE pair, one full training step (fwd+bwd+Adam)."""
+    """BASELINE.md section 4 / configs[0]: the oracle (CPU restatement of the reference, pinned to it in the build
+    container) on the GPU box's host cores -- one full training step (fwd + bwd + Adam) on 4 pairs of 480x854 after one
+    untimed warm-up step on 1 pair (thread pool, allocator, first-call overheads), plus the sequential C restatement of
+    tools/torchCRF (oracle/crf_ref.c) on one 480x854 frame at T = 5 and T = 50."""
     import copy
     import types
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import crf_oracle
     import rcf_torch as orc
     from rcf_amd import config, synth
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    model_name, logical, physical = _cpu_info()
+    cores = min(physical, 64)
     torch.set_num_threads(cores)
+    avail_gb = 0.0
+    try:
+        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+    except Exception:                                           # noqa: BLE001
+        pass
+    pairs = 4 if avail_gb >= 48 else (2 if avail_gb >= 28 else 1)       # the B=4 step peaks at ~20 GB resident
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=None)
     m = orc.RCFModel(args, **copy.deepcopy(config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN")))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
     m.train()
     opt = orc.make_optimizer(m, 1e-4, 1e-4)
-    nb = synth.make_batch(1, H, W, config_id=2)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
-    batch = {"imgs": [t(x) for x in nb["imgs"]], "gt_fw_flows": [t(x) for x in nb["gt_fw_flows"]],
-             "gt_bw_flows": [t(x) for x in nb["gt_bw_flows"]]}
-    t0 = time.perf_counter()
-    losses = m(batch)
-    opt.zero_grad()
-    losses["loss"].backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": round(2.0 / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 pair (2 frames) {H}x{W}, one fwd+bwd+Adam step of oracle/rcf_torch.py, {dt:.1f} s"}
+
+    def step(n):
+        nb = synth.make_batch(n, H, W, config_id=2)
+        batch = {"imgs": [t(x) for x in nb["imgs"]], "gt_fw_flows": [t(x) for x in nb["gt_fw_flows"]],
+                 "gt_bw_flows": [t(x) for x in nb["gt_bw_flows"]]}
+        t0 = time.perf_counter()
+        losses = m(batch)
+        opt.zero_grad()
+        losses["loss"].backward()
+        opt.step()
+        return time.perf_counter() - t0
+    warm = step(1)
+    dt = step(pairs)
+    # CPU CRF: the restatement of tools/torchCRF is sequential C (1 core)
+    rgb, msk = synth.smooth_rgb(H, W, 4000), synth.soft_blob_mask(H, W, 4000)
+    img = torch.from_numpy(synth.normalize_rgb(rgb))[None]
+    crf = {}
+    for iters in (5, 50):
+        head = orc.CRFHead(None, refine_iters=iters, crf_soft=crf_oracle.crf_soft_torch)
+        t0 = time.perf_counter()
+        head(img, torch.from_numpy(msk)[None])
+        crf[f"crf_ms_per_frame_T{iters}"] = round((time.perf_counter() - t0) * 1e3, 1)
+    return {"value": round(2.0 * pairs / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "cpu_model": model_name, "logical_cpus": logical, "physical_cores": physical,
+            "sample": f"{pairs} pairs ({2 * pairs} frames) {H}x{W} (BASELINE configs[0]), one fwd+bwd+Adam step of "
+                      f"oracle/rcf_torch.py in {dt:.1f} s after an untimed 1-pair warm-up step ({warm:.1f} s)",
+            **crf, "crf_cores": 1, "crf_kind": "port (oracle/crf_ref.c, sequential C restatement of tools/torchCRF)"}
 
 
 if __name__ == "__main__":

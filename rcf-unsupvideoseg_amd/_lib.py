@@ -168,6 +168,8 @@ def load():
                 continue            # reported by missing_symbols(); calling it raises
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("RCF_BF16_TILE"):          # A/B knob of the bf16 forward / data-gradient tile (tools/bench_conv_bf16.py)
+            lib.rcf_conv_bf16_set_tile(int(os.environ["RCF_BF16_TILE"]))
         _lib = lib
     return _lib
 

@@ -422,6 +422,7 @@ struct WgradParams {
     long split_stride; // Cout*R*S*Cin
     int beta;          // only honoured when gridDim.z == 1
     int ry0, rx0, rh, rw, rband, rr;
+    int Ktot;          // R*S*Cin: the GEMM columns are (tap, input channel) pairs
 };
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -431,14 +432,16 @@ __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-// dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c]: rows i = co (128), cols j = c (64 NR), K = pixels (32 per step).
+// dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c]: rows i = co (64 MR), cols j = (rs, c) (64 NR), K = pixels (32 per
+// step).  The taps are GEMM COLUMNS (j = rs * Cin + c, the weight's own memory order), not grid rows: a tile of a
+// narrow layer (Cin = 64: 576 columns) spans several taps, so dy is read once per 256 columns instead of once per tap.
 // Both operands are staged in their NATURAL order -- LDS holds [32 pixels][channels] bf16 (16-byte global loads of 8
 // channels of a pixel, one ds_write_b128 each) -- and the MFMA's k-contiguous fragments come out of gfx950's transposing
-// LDS read (ds_read_b64_tr_b16), as in igemm_wgrad_h2t_kernel.  Row pitch = channels * 2 + 32 bytes.
+// LDS read (ds_read_b64_tr_b16), as in igemm_wgrad_h2t_kernel.
 // REGION: the contributing output pixels are a rectangle / frame of every image (general pixel walk).
-template <int NR, bool REGION>
+template <int MR, int NR, bool REGION>
 __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
-    constexpr int MR = 2, BM = 128, BN = 64 * NR, BK = 32;
+    constexpr int BM = 64 * MR, BN = 64 * NR, BK = 32;
     constexpr int QA = BM / 8, PAS = 256 / QA, NAP = BK / PAS;   // dy loader: 16-byte chunks per pixel, pixels per pass, passes
     constexpr int QB = BN / 8, PBS = 256 / QB, NBP = BK / PBS;   // x loader
     // row pitch = channels * 2 + 64 bytes: the 4 pixel rows a 16-lane group reads are 64 B apart in bank space and the
@@ -449,8 +452,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
 
     const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
-    const int rs = (int)blockIdx.y;
-    const int r = rs / p.S, s = rs - r * p.S;
     const long kbeg = (long)blockIdx.z * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
     const int klen = (int)(kend - kbeg);
@@ -467,8 +468,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
 
     const int qa = tid % QA, pa0 = tid / QA;
     const int qb = tid % QB, pb0 = tid / QB;
-    const int cha = i0 + 8 * qa, chb = j0 + 8 * qb;
-    const bool acta = cha < p.Cout, actb = chb < p.Cin;
+    const int cha = i0 + 8 * qa, jc = j0 + 8 * qb;          // this thread's dy channels / GEMM columns (one tap: Cin % 8 == 0)
+    const int rs = jc / p.Cin, chb = jc - rs * p.Cin;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const bool acta = cha < p.Cout, actb = jc < p.Ktot;
     // pixel walkers (image-relative to n_first), advanced by BK per K-step
     int an[NAP], ay[NAP], ax[NAP], apix[NAP];
     int bn[NBP], by[NBP], bx[NBP], bpix[NBP];
@@ -591,7 +594,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
     mma((KT - 1) & 1);
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
-    const long row_pitch = (long)p.R * p.S * p.Cin;
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
@@ -600,10 +602,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
         for (int e = 0; e < 16; ++e) {
             const int co = rbase + (e & 3) + 8 * (e >> 2);
             if (co >= p.Cout) continue;
-            float *drow = out + co * row_pitch + (long)rs * p.Cin + j0 + brow0 + l31;
+            float *drow = out + (long)co * p.Ktot + j0 + brow0 + l31;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
-                if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
+                if (j0 + brow0 + nr * 32 + l31 >= p.Ktot) continue;
                 float v = acc[mr][nr][e];
                 if (p.beta && gridDim.z == 1) v += drow[nr * 32];
                 drow[nr * 32] = v;
@@ -699,17 +701,19 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
 }
 
 struct WgradPlan {
-    int nr, itiles, jtiles, splitk;
+    int mr, nr, itiles, jtiles, splitk;
     long chunk;
 };
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     WgradPlan pl;
-    pl.nr = (s->Cin >= 256 && s->Cout >= 128) ? 4 : 2;
-    pl.itiles = rcf_cdiv(s->Cout, 128);
-    pl.jtiles = rcf_cdiv(s->Cin, 64 * pl.nr);
+    const int ktot = s->R * s->S * s->Cin;
+    pl.mr = s->Cout > 64 ? 2 : 1;
+    pl.nr = ktot >= 256 ? 4 : (ktot >= 128 ? 2 : 1);
+    pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
+    pl.jtiles = rcf_cdiv(ktot, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);
     const long M = (long)s->N * RR;
-    const long tiles = (long)pl.itiles * pl.jtiles * s->R * s->S;
+    const long tiles = (long)pl.itiles * pl.jtiles;
     // 2 workgroups per CU = 512 slots: pick the split whose last round is fullest (time ~ rounds / split; the fixed-order
     // reduction costs ~ split)
     const long maxsk = M / 2048 > 1 ? M / 2048 : 1;
@@ -844,14 +848,20 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
     p.rband = region ? region->band : 0; p.rr = region_pixels(region, s->Ho, s->Wo);
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
-    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(s->R * s->S), (unsigned)pl.splitk);
-    if (region) {
-        if (pl.nr == 4) hipLaunchKernelGGL((wgrad_bf16_kernel<4, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, true>), grid, dim3(256), 0, st, p);
-    } else {
-        if (pl.nr == 4) hipLaunchKernelGGL((wgrad_bf16_kernel<4, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, false>), grid, dim3(256), 0, st, p);
-    }
+    p.Ktot = s->R * s->S * s->Cin;
+    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), 1u, (unsigned)pl.splitk);
+#define RCF_WG(MRv, NRv)                                                                              \
+    do {                                                                                              \
+        if (region) hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, true>), grid, dim3(256), 0, st, p);  \
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, false>), grid, dim3(256), 0, st, p);        \
+    } while (0)
+    if (pl.mr == 2 && pl.nr == 4) RCF_WG(2, 4);
+    else if (pl.mr == 2 && pl.nr == 2) RCF_WG(2, 2);
+    else if (pl.mr == 2) RCF_WG(2, 1);
+    else if (pl.nr == 4) RCF_WG(1, 4);
+    else if (pl.nr == 2) RCF_WG(1, 2);
+    else RCF_WG(1, 1);
+#undef RCF_WG
     RCF_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         const long n4 = p.split_stride / 4;

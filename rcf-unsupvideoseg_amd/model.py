@@ -264,6 +264,7 @@ class RCFModel(nn.Module):
         self._seed_backward = seed
         self._tape = tape
         self.last_targets = extra        # the pl / crf targets at mask size that entered the loss (tests look at them)
+        self.last_logits = logits.t      # NHWC fp32 logits of decode_head2 (kept alive by the tape anyway)
         if self.backbone2_ema is not None:
             momentum_update_param_and_buffer(self.backbone2, self.backbone2_ema, self.ema_m)
         if self.decode_head2_ema is not None:

@@ -69,29 +69,35 @@ def pitch_of(x):
 
 
 class _Profile:
-    """Live per-kernel timing with HIP events on the launch stream (bench.py's `roofline` leg).
-    Only the selected kernel family is bracketed, so the timed region is barely perturbed."""
+    """Live per-kernel timing with HIP events on the launch stream (bench.py's `roofline` legs): every launch of a
+    selected kernel family is bracketed by two events recorded on the stream it is launched on (weight gradients: the
+    second stream).  bench.py selects ONE family inside the timed region, so the timed steps are barely perturbed, and
+    all of them in a short separate pass (`roofline_by_kernel`)."""
 
     def __init__(self):
-        self.which, self.records = None, []
+        self.which, self.records = None, {}
 
     def start(self, which):
-        self.which, self.records = which, []
+        """which: a family name, or a collection of names"""
+        self.which = {which} if isinstance(which, str) else set(which)
+        self.records = {w: [] for w in self.which}
 
     def bracket(self, which, flops):
-        if self.which != which:
+        if self.which is None or which not in self.which:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((flops, e0, e1))
+        self.records[which].append((flops, e0, e1))
         e0.record()
         return e1
 
     def stop(self):
+        """{family: {launches, flops, ms}}; a single selected family is returned directly"""
         torch.cuda.synchronize()
-        out = {"launches": len(self.records), "flops": float(sum(r[0] for r in self.records)),
-               "ms": float(sum(r[1].elapsed_time(r[2]) for r in self.records))}
-        self.which, self.records = None, []
-        return out
+        out = {w: {"launches": len(r), "flops": float(sum(x[0] for x in r)),
+                   "ms": float(sum(x[1].elapsed_time(x[2]) for x in r))} for w, r in self.records.items()}
+        single = len(self.which) == 1
+        self.which, self.records = None, {}
+        return next(iter(out.values())) if single else out
 
 
 PROFILE = _Profile()
@@ -221,8 +227,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
-    if PROFILE.which is not None and s.Cout > 128:       # forward launches of the 128x256-tile kernel instance
-        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None:       # forward launches of the 128x256-tile kernel instance / of the narrower tiles
+        end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
     if end is not None:
@@ -241,8 +248,9 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None):
     need = _lib.load().rcf_conv2d_fwd_stats_workspace_bytes(byref(s))
     ws = workspace(need, x.device)
     end = None
-    if PROFILE.which is not None and s.Cout > 128:
-        end = PROFILE.bracket("conv_x3_128x256", 2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+                              2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
     if end is not None:
         end.record()
@@ -259,8 +267,14 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
+    end = None
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
+                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
     call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
          need, _stream())
+    if end is not None:
+        end.record()
     return out
 
 
@@ -273,7 +287,14 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
     reg = _region(region)
     need = _lib.load().rcf_conv2d_wgrad_region_workspace_bytes(byref(s), reg)
     ws = workspace(need, x.device) if need else None
+    end = None
+    if PROFILE.which is not None:
+        wide = region is None and s.Cout >= 128 and s.Cin >= 256 and amax is not None          # plan_wgrad (csrc/igemm_conv.hip)
+        end = PROFILE.bracket("conv_wgrad_h2t4" if wide else "conv_wgrad_other",
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
+    if end is not None:
+        end.record()
     return dw
 
 
@@ -307,8 +328,9 @@ def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0,
         need = _lib.load().rcf_conv2d_fwd_stats_bf16_workspace_bytes(byref(s))
         ws = workspace(need, x.device)
     end = None
-    if PROFILE.which is not None and s.Cout > 128:
-        end = PROFILE.bracket("conv_bf16_fwd", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_bf16_fwd" if s.Cout > 128 else "conv_bf16_fwd_narrow",
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_fwd_bf16", _p(x), _p(w_bf16), _p(bias), _p(out), _dt(out), byref(s), _region(region), act, slope, beta,
          _p(sums), _p(ws), need, _stream())
     if end is not None:
@@ -328,7 +350,8 @@ def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, r
     ws = workspace(need, dy.device)
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_bf16_dgrad", 2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
+        end = PROFILE.bracket("conv_bf16_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_bf16_dgrad_other",
+                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
     call("rcf_conv2d_dgrad_bf16", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws), need,
          _stream())
     if end is not None:
@@ -346,7 +369,9 @@ def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=
     ws = workspace(need, x.device) if need else None
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_bf16_wgrad", 2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+        wide = region is None and s.Cout > 64 and s.R * s.S * s.Cin >= 256                      # plan_wgrad (csrc/igemm_bf16.hip)
+        end = PROFILE.bracket("conv_bf16_wgrad4" if wide else "conv_bf16_wgrad_other",
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_wgrad_bf16", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     if end is not None:
         end.record()
