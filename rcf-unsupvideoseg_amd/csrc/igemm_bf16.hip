@@ -714,15 +714,21 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     const long RR = region_pixels(reg, s->Ho, s->Wo);
     const long M = (long)s->N * RR;
     const long tiles = (long)pl.itiles * pl.jtiles;
-    // 2 workgroups per CU = 512 slots: pick the split whose last round is fullest (time ~ rounds / split; the fixed-order
-    // reduction costs ~ split)
-    const long maxsk = M / 2048 > 1 ? M / 2048 : 1;
-    const long slots = 512, hi = maxsk < 96 ? maxsk : 96;
+    // Split K (the pixels) over `c` workgroups per tile; 2 workgroups per CU = 512 slots.  Cost model in microseconds:
+    // rounds(c) x pixels per workgroup x time per pixel (0.025 us for the 128x256 tile at the measured ~30 % of the MFMA
+    // peak, proportionally less for smaller tiles down to the load-bound floor) + the fixed-order reduction, which reads
+    // c copies of the weight gradient (~2 bytes/us/1e6 effective).  Small weights on many pixels (layer1) want hundreds
+    // of splits, large weights on few pixels (layer4) a handful.
+    const double px_us = 0.025 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
+    const double wbytes = (double)s->Cout * ktot * 4.0;
+    const long maxsk = M / 512 > 1 ? M / 512 : 1;
+    const long slots = 512, hi = maxsk < 256 ? maxsk : 256;
     double best = 1e30;
     long sk = 1;
     for (long c = 1; c <= hi; ++c) {
-        const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
-        if (cost < best - 1e-12) { best = cost; sk = c; }
+        const double rounds = (double)((tiles * c + slots - 1) / slots);
+        const double cost = rounds * (double)((M + c - 1) / c) * px_us + (c > 1 ? (double)c * wbytes / 2.0e6 + 3.0 : 0.0);
+        if (cost < best - 1e-9) { best = cost; sk = c; }
     }
     long chunk = (M + sk - 1) / sk;
     chunk = (chunk + 31) / 32 * 32;

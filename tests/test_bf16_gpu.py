@@ -271,8 +271,11 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     torch.autocast(bf16) (tests/golden/make_golden_bf16.py).  bf16 moves this randomly initialised network a lot -- the
     reference's own autocast run changes 9-11 % of the argmax decisions and the logits by 11-19 % of their range -- so the
     yardstick is the reference's own bf16-vs-fp32 deviation: the HIP bf16 step must stay within 3x of it on losses and
-    gradient norms, within 2x on the mean mask deviation, and decide every pixel like the fp32 reference wherever the
-    fp32 top-2 logit margin exceeds 1.5x the margin up to which the reference's autocast run itself flips pixels."""
+    gradient norms (floor 10 %: CPU autocast keeps batch norm, ReLU and the residual adds -- and their gradients -- in
+    fp32, while this path, like CUDA autocast, STORES activations and their gradients as bf16 between all layers; the
+    backbone's gradient norm moved by 14 % in the reference's own 64x96 autocast run), within 2x on the mean mask
+    deviation, and decide every pixel like the fp32 reference wherever the fp32 top-2 logit margin exceeds 1.5x the margin
+    up to which the reference's autocast run itself flips pixels."""
     import json
     import os
     fx = json.load(open(os.path.join(golden_dir, "bf16.json")))[tag]
@@ -309,6 +312,6 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
         assert d_h < 2 * d_r + 1e-3
     report(msg)
     assert all(e_l[k] < max(3 * ref["loss"][k], 5e-3) for k in e_l), e_l
-    assert all(e_g[k] < max(3 * ref["gradnorm"][k], 5e-2) for k in e_g), e_g
+    assert all(e_g[k] < max(3 * ref["gradnorm"][k], 0.10) for k in e_g), e_g
     assert float(mism.float().mean()) < 2 * ref["argmax_mismatch_frac"] + 0.01
     assert n_sure_bad == 0
