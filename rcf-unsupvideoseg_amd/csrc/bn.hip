@@ -15,16 +15,16 @@ namespace {
 constexpr int RED_THREADS = 256;
 
 struct ColGeom {
-    int cvB;      // float4 columns handled per block (<= 64)
+    int cvB;      // channel vectors (V channels each) handled per block (<= 64)
     int RG;       // row groups per block = 256 / cvB
     int cgroups;  // blocks along C
     int chunks;   // blocks along rows
     long rows_per_chunk;
 };
 
-ColGeom col_geom(long rows, int C) {
+ColGeom col_geom(long rows, int C, int V = 4) {
     ColGeom g;
-    const int CV = C / 4;
+    const int CV = C / V;
     g.cvB = CV < 64 ? CV : 64;
     g.RG = RED_THREADS / g.cvB;
     g.cgroups = (CV + g.cvB - 1) / g.cvB;
@@ -37,47 +37,50 @@ ColGeom col_geom(long rows, int C) {
     return g;
 }
 
-// Generic two-value column reduction.  F(row, c4, out a[4], out b[4]) produces the two addends.
-template <class F>
+// Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
+template <class F, int V>
 __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows, int C, int cvB, int RG,
                                                                  long rows_per_chunk, double *__restrict__ partial) {
-    __shared__ double red[RED_THREADS * 8];
+    __shared__ double red[RED_THREADS * 2 * V];
     const int tid = threadIdx.x;
     const int cv = tid % cvB, rg = tid / cvB;
-    const int c4 = (blockIdx.y * cvB + cv) * 4;
+    const int c0 = (blockIdx.y * cvB + cv) * V;
     const long r0 = (long)blockIdx.x * rows_per_chunk;
     const long r1 = min(rows, r0 + rows_per_chunk);
-    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-    if (rg < RG && c4 < C) {
-        for (long r = r0 + rg; r < r1; r += RG) {
-            float a[4], b[4];
-            f(r, c4, a, b);
+    double sa[V], sb[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < V; ++e) { sa[e] = 0; sb[e] = 0; }
+    if (rg < RG && c0 < C) {
+        f.init(c0);                      // per-channel constants into registers, once per thread
+        for (long r = r0 + rg; r < r1; r += RG) {
+            float a[V], b[V];
+            f(r, c0, a, b);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
                 sa[e] += (double)a[e];
                 sb[e] += (double)b[e];
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        red[tid * 8 + e] = sa[e];
-        red[tid * 8 + 4 + e] = sb[e];
+    for (int e = 0; e < V; ++e) {
+        red[tid * 2 * V + e] = sa[e];
+        red[tid * 2 * V + V + e] = sb[e];
     }
     __syncthreads();
-    if (rg == 0 && c4 < C) {
+    if (rg == 0 && c0 < C) {
         for (int g = 1; g < RG; ++g) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sa[e] += red[(g * cvB + cv) * 8 + e];
-                sb[e] += red[(g * cvB + cv) * 8 + 4 + e];
+            for (int e = 0; e < V; ++e) {
+                sa[e] += red[(g * cvB + cv) * 2 * V + e];
+                sb[e] += red[(g * cvB + cv) * 2 * V + V + e];
             }
         }
         double *dst = partial + (long)blockIdx.x * 2 * C;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            dst[c4 + e] = sa[e];
-            dst[C + c4 + e] = sb[e];
+        for (int e = 0; e < V; ++e) {
+            dst[c0 + e] = sa[e];
+            dst[C + c0 + e] = sb[e];
         }
     }
 }
@@ -153,22 +156,23 @@ __device__ __forceinline__ void block_amax(unsigned mx, unsigned *__restrict__ a
     if (threadIdx.x == 0) atomicMax(amax, max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3])));
 }
 
-template <typename XT>
+template <typename XT, int V>
 struct StatsOp {
     const XT *x;
     int pitch;
-    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        const f32x4 v = ld4(x + r * pitch + c4);
+    __device__ void init(int) {}
+    __device__ void operator()(long r, int c0, float (&a)[V], float (&b)[V]) const {
+        const fvec<V> v = ldv<XT, V>(x + r * pitch + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = v[e];
-            b[e] = v[e] * v[e];
+        for (int e = 0; e < V; ++e) {
+            a[e] = v.q[e >> 2][e & 3];
+            b[e] = a[e] * a[e];
         }
     }
 };
 
 // XT: storage type of the conv-output side (x, dx); YT: of the activation side (y, dy, residual, dres)
-template <typename XT, typename YT>
+template <typename XT, typename YT, int V>
 struct BwdOp {
     const YT *dy;
     const XT *x;
@@ -176,26 +180,38 @@ struct BwdOp {
     const float *mean, *invstd, *scale;
     int dy_pitch, x_pitch, y_pitch, relu, C;
     long rows_per_image;
-    const unsigned char *mask;     // [rows][C/4]: bit e = output c4+e was positive (replaces the read of y)
-    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        f32x4 g = ld4(dy + r * dy_pitch + c4);
-        const f32x4 xv = ld4(x + r * x_pitch + c4);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
-        if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
+    const unsigned char *mask;     // [rows][C/4]: bit e = output 4j+e was positive (replaces the read of y)
+    fvec<V> mu, is;                // this thread's channels (init)
+    __device__ void init(int c0) {
+        mu = ldv<float, V>(mean + c0);
+        is = ldv<float, V>(invstd + c0);
+    }
+    __device__ void operator()(long r, int c0, float (&a)[V], float (&b)[V]) const {
+        fvec<V> g = ldv<YT, V>(dy + r * dy_pitch + c0);
+        const fvec<V> xv = ldv<XT, V>(x + r * x_pitch + c0);
+        if (scale) {
+            const fvec<V> sc = ldv<float, V>(scale + (r / rows_per_image) * C + c0);
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) g.q[h] *= sc.q[h];
+        }
         if (relu && mask) {
-            const unsigned m = mask[r * (C >> 2) + (c4 >> 2)];
+            const unsigned char *mp = mask + r * (C >> 2) + (c0 >> 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+            for (int h = 0; h < V / 4; ++h) {
+                const unsigned m = mp[h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g.q[h][e] = (m >> e) & 1u ? g.q[h][e] : 0.f;
+            }
         } else if (relu) {
-            const f32x4 yv = ld4(y + r * y_pitch + c4);
+            const fvec<V> yv = ldv<YT, V>(y + r * y_pitch + c0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < V; ++e) g.q[e >> 2][e & 3] = yv.q[e >> 2][e & 3] > 0.f ? g.q[e >> 2][e & 3] : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = g[e];
-            b[e] = g[e] * ((xv[e] - mu[e]) * is[e]);
+        for (int e = 0; e < V; ++e) {
+            const int h = e >> 2, k = e & 3;
+            a[e] = g.q[h][k];
+            b[e] = g.q[h][k] * ((xv.q[h][k] - mu.q[h][k]) * is.q[h][k]);
         }
     }
 };
@@ -222,117 +238,191 @@ __global__ void invstd_from_var_kernel(const float *__restrict__ var, int C, flo
     if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-template <typename XT, typename YT>
+// Element-wise passes.  A thread keeps ONE vector of V channels for the whole kernel (its per-channel constants live in
+// registers: no reloads, no index divisions in the loop) and walks the rows with a grid stride, two rows in flight.
+// Thread layout: cvt = min(CV, 256) threads across the channels, 256 / cvt rows per block; layers wider than 256
+// vectors loop over channel chunks (grid.y).
+struct EwGeom {
+    int cvt, rpb;      // threads across channels, rows per block
+    dim3 grid;
+};
+EwGeom ew_geom(long rows, int CV) {
+    EwGeom g;
+    g.cvt = CV < 256 ? CV : 256;
+    g.rpb = 256 / g.cvt;
+    const int cchunks = (CV + g.cvt - 1) / g.cvt;
+    long rb = (rows + g.rpb - 1) / g.rpb;              // row blocks if every block took one group of rows
+    long bx = rb / 8 > 0 ? rb / 8 : 1;                  // >= 8 row groups per block (2 in flight at a time)
+    const long cap = 4096 / cchunks > 0 ? 4096 / cchunks : 1;
+    if (bx > cap) bx = cap;
+    g.grid = dim3((unsigned)bx, (unsigned)cchunks);
+    return g;
+}
+
+template <typename XT, typename YT, int V>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x, int x_pitch,
                                                        const YT *__restrict__ res, int r_pitch,
-                                                       YT *__restrict__ y, int y_pitch, long rows, int C,
+                                                       YT *__restrict__ y, int y_pitch, long rows, int C, int cvt, int rpb,
                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int relu, const float *__restrict__ scale, long rows_per_image,
                                                        unsigned char *__restrict__ mask,
                                                        unsigned *__restrict__ amax) {
-    const int CV = C / 4;
-    const long total = rows * CV;
-    const long step = (long)gridDim.x * blockDim.x;
+    const int CV = C / V;
+    const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
+    const int cv = blockIdx.y * cvt + cx;
+    const bool active = ry < rpb && cv < CV;
+    const int c0 = cv * V;
     unsigned mx = 0u;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const long r = i / CV;
-        const int c4 = (int)(i - r * CV) * 4;
-        const f32x4 xv = ld4(x + r * x_pitch + c4);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
-        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c4);
-        f32x4 o;
+    if (active) {
+        const fvec<V> mu = ldv<float, V>(mean + c0), is = ldv<float, V>(invstd + c0);
+        const fvec<V> ga = ldv<float, V>(gamma + c0), be = ldv<float, V>(beta + c0);
+        const long rstep = (long)gridDim.x * rpb;
+        auto finish = [&](long r, const fvec<V> &xv, const fvec<V> &rv) {
+            fvec<V> o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
-        if (res) o += ld4(res + r * r_pitch + c4);
-        if (relu) {
-            if (mask) mask[i] = (unsigned char)((o[0] > 0.f) | ((o[1] > 0.f) << 1) | ((o[2] > 0.f) << 2) | ((o[3] > 0.f) << 3));
+            for (int e = 0; e < V; ++e) {
+                const int h = e >> 2, k = e & 3;
+                // (x - mean) * invstd * gamma + beta, evaluated in the reference's order
+                o.q[h][k] = (xv.q[h][k] - mu.q[h][k]) * is.q[h][k] * ga.q[h][k] + be.q[h][k];
+            }
+            if (res) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+                for (int h = 0; h < V / 4; ++h) o.q[h] += rv.q[h];
+            }
+            if (relu) {
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) {
+                    if (mask)
+                        mask[r * (C >> 2) + (c0 >> 2) + h] = (unsigned char)((o.q[h][0] > 0.f) | ((o.q[h][1] > 0.f) << 1) |
+                                                                             ((o.q[h][2] > 0.f) << 2) | ((o.q[h][3] > 0.f) << 3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.q[h][e] = o.q[h][e] > 0.f ? o.q[h][e] : 0.f;
+                }
+            }
+            if (scale) {
+                const fvec<V> sc = ldv<float, V>(scale + (r / rows_per_image) * C + c0);
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) o.q[h] *= sc.q[h];
+            }
+            stv<YT, V>(y + r * y_pitch + c0, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+        };
+        long r = (long)blockIdx.x * rpb + ry;
+        for (; r + rstep < rows; r += 2 * rstep) {      // two rows in flight
+            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0), x1 = ldv<XT, V>(x + (r + rstep) * x_pitch + c0);
+            fvec<V> r0{}, r1{};
+            if (res) {
+                r0 = ldv<YT, V>(res + r * r_pitch + c0);
+                r1 = ldv<YT, V>(res + (r + rstep) * r_pitch + c0);
+            }
+            finish(r, x0, r0);
+            finish(r + rstep, x1, r1);
         }
-        if (scale) o *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
-        st4(y + r * y_pitch + c4, o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float f = o[e];
-            mx = max(mx, __float_as_uint(fabsf(f)));
+        if (r < rows) {
+            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0);
+            fvec<V> r0{};
+            if (res) r0 = ldv<YT, V>(res + r * r_pitch + c0);
+            finish(r, x0, r0);
         }
     }
     if (amax) block_amax(mx, amax);
 }
 
-template <typename XT, typename YT>
+template <typename XT, typename YT, int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const YT *__restrict__ dy, int dy_pitch, const XT *__restrict__ x, int x_pitch, const YT *__restrict__ y,
     int y_pitch, XT *__restrict__ dx, int dx_pitch, YT *__restrict__ dres, int dres_pitch, int res_beta,
-    long rows, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+    long rows, int C, int cvt, int rpb, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
     float *__restrict__ dgamma, float *__restrict__ dbeta, const unsigned char *__restrict__ mask,
     unsigned *__restrict__ amax) {
-    const int CV = C / 4;
-    const long total = rows * CV;
-    const long step = (long)gridDim.x * blockDim.x;
-    if (blockIdx.x == 0) {
+    const int CV = C / V;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         // parameter gradients come from THIS rank's sums: the data-parallel gradient all-reduce adds the ranks
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (dgamma) dgamma[c] += (float)sums2_param[C + c];
             if (dbeta) dbeta[c] += (float)sums2_param[c];
         }
     }
-    const float inv_count = (float)(1.0 / count);
+    const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
+    const int cv = blockIdx.y * cvt + cx;
+    const bool active = ry < rpb && cv < CV;
+    const int c0 = cv * V;
     unsigned mx = 0u;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const long r = i / CV;
-        const int c4 = (int)(i - r * CV) * 4;
-        f32x4 g = ld4(dy + r * dy_pitch + c4);
-        if (scale) g *= *reinterpret_cast<const f32x4 *>(scale + (r / rows_per_image) * C + c4);
-        if (relu && mask) {
-            const unsigned m = mask[i];
+    if (active) {
+        const float inv_count = (float)(1.0 / count);
+        const fvec<V> mu = ldv<float, V>(mean + c0), is = ldv<float, V>(invstd + c0), ga = ldv<float, V>(gamma + c0);
+        fvec<V> sg, sgx;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
-        } else if (relu) {
-            const f32x4 yv = ld4(y + r * y_pitch + c4);
+        for (int e = 0; e < V; ++e) {
+            sg.q[e >> 2][e & 3] = (float)sums2[c0 + e] * inv_count;
+            sgx.q[e >> 2][e & 3] = (float)sums2[C + c0 + e] * inv_count;
+        }
+        const long rstep = (long)gridDim.x * rpb;
+        auto finish = [&](long r, fvec<V> g, const fvec<V> &xv) {
+            if (scale) {
+                const fvec<V> sc = ldv<float, V>(scale + (r / rows_per_image) * C + c0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
-        }
-        const f32x4 xv = ld4(x + r * x_pitch + c4);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + c4);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c4);
-        f32x4 o;
+                for (int h = 0; h < V / 4; ++h) g.q[h] *= sc.q[h];
+            }
+            if (relu && mask) {
+                const unsigned char *mp = mask + r * (C >> 2) + (c0 >> 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float xh = (xv[e] - mu[e]) * is[e];
-            const float sg = (float)sums2[c4 + e] * inv_count;
-            const float sgx = (float)sums2[C + c4 + e] * inv_count;
-            o[e] = ga[e] * is[e] * (g[e] - sg - xh * sgx);
-        }
-        st4(dx + r * dx_pitch + c4, o);
+                for (int h = 0; h < V / 4; ++h) {
+                    const unsigned m = mp[h];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float f = o[e];
-            mx = max(mx, __float_as_uint(fabsf(f)));
+                    for (int e = 0; e < 4; ++e) g.q[h][e] = (m >> e) & 1u ? g.q[h][e] : 0.f;
+                }
+            } else if (relu) {
+                const fvec<V> yv = ldv<YT, V>(y + r * y_pitch + c0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) g.q[e >> 2][e & 3] = yv.q[e >> 2][e & 3] > 0.f ? g.q[e >> 2][e & 3] : 0.f;
+            }
+            fvec<V> o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int h = e >> 2, k = e & 3;
+                const float xh = (xv.q[h][k] - mu.q[h][k]) * is.q[h][k];
+                o.q[h][k] = ga.q[h][k] * is.q[h][k] * (g.q[h][k] - sg.q[h][k] - xh * sgx.q[h][k]);
+            }
+            stv<XT, V>(dx + r * dx_pitch + c0, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+            if (dres) {
+                YT *dr = dres + r * dres_pitch + c0;
+                if (res_beta) {
+                    const fvec<V> old = ldv<YT, V>(dr);
+#pragma unroll
+                    for (int h = 0; h < V / 4; ++h) g.q[h] += old.q[h];
+                }
+                stv<YT, V>(dr, g);
+            }
+        };
+        long r = (long)blockIdx.x * rpb + ry;
+        for (; r + rstep < rows; r += 2 * rstep) {      // two rows in flight
+            const fvec<V> g0 = ldv<YT, V>(dy + r * dy_pitch + c0), g1 = ldv<YT, V>(dy + (r + rstep) * dy_pitch + c0);
+            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0), x1 = ldv<XT, V>(x + (r + rstep) * x_pitch + c0);
+            finish(r, g0, x0);
+            finish(r + rstep, g1, x1);
         }
-        if (dres) {
-            YT *dr = dres + r * dres_pitch + c4;
-            st4(dr, res_beta ? (ld4(dr) + g) : g);
-        }
+        if (r < rows) finish(r, ldv<YT, V>(dy + r * dy_pitch + c0), ldv<XT, V>(x + r * x_pitch + c0));
     }
     if (amax) block_amax(mx, amax);
 }
 
-template <typename XT>
+template <typename XT, int V>
 struct ColsumOp {
     const XT *x;
     int pitch;
-    __device__ void operator()(long r, int c4, float (&a)[4], float (&b)[4]) const {
-        const f32x4 v = ld4(x + r * pitch + c4);
+    __device__ void init(int) {}
+    __device__ void operator()(long r, int c0, float (&a)[V], float (&b)[V]) const {
+        const fvec<V> v = ldv<XT, V>(x + r * pitch + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = v[e];
+        for (int e = 0; e < V; ++e) {
+            a[e] = v.q[e >> 2][e & 3];
             b[e] = 0.f;
         }
     }
@@ -366,21 +456,40 @@ inline int ew_blocks(long total) {
 extern "C" size_t rcf_bn_stats_workspace_bytes(long rows, int C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
     const ColGeom g = col_geom(rows, C);
-    return (size_t)g.chunks * 2 * C * sizeof(double);
+    int chunks = g.chunks;
+    if (C % 8 == 0) {                                   // the 8-channel (bf16) geometry may cut the rows into more chunks
+        const ColGeom g8 = col_geom(rows, C, 8);
+        chunks = g8.chunks > chunks ? g8.chunks : chunks;
+    }
+    return (size_t)chunks * 2 * C * sizeof(double);
 }
+
+namespace {
+// bf16 on both sides and C % 8 == 0: 8 channels (one 16-byte access) per thread
+inline int vec_width(int xdt, int ydt, int C, int pa, int pb, int pc, int pd) {
+    return (xdt == RCF_BF16 && ydt == RCF_BF16 && C % 8 == 0 && pa % 8 == 0 && pb % 8 == 0 && pc % 8 == 0 && pd % 8 == 0) ? 8 : 4;
+}
+}  // namespace
 
 extern "C" int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pitch, double *sums, void *workspace,
                                size_t workspace_bytes, void *stream) {
     if (!x || !sums || rows <= 0 || C <= 0 || C % 4 || pitch % 4 || pitch < C) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
-    const ColGeom g = col_geom(rows, C);
+    const int V = vec_width(xdt, xdt, C, pitch, 8, 8, 8);
+    const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
-#define RCF_CALL(XT)                                                                                                   \
-    StatsOp<XT> op{(const XT *)x, pitch};                                                                              \
-    hipLaunchKernelGGL(colreduce2_kernel<StatsOp<XT>>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, \
-                       C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
-    RCF_DISPATCH1(xdt, RCF_CALL);
+    if (V == 8) {
+        StatsOp<bf16_t, 8> op{(const bf16_t *)x, pitch};
+        hipLaunchKernelGGL((colreduce2_kernel<StatsOp<bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st,
+                           op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+    } else {
+#define RCF_CALL(XT)                                                                                                     \
+    StatsOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
+    hipLaunchKernelGGL((colreduce2_kernel<StatsOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+        RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
+    }
     RCF_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums);
@@ -435,13 +544,22 @@ extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *
     if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
     if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
-#define RCF_CALL(XT, YT)                                                                                              \
-    hipLaunchKernelGGL((bn_apply_kernel<XT, YT>), dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), \
-                       (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, mean,        \
-                       invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,     \
+    if (vec_width(xdt, ydt, C, x_pitch, y_pitch, residual ? r_pitch : 8, 8) == 8) {
+        const EwGeom g = ew_geom(rows, C / 8);
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 8>), g.grid, dim3(256), 0,
+                           rcf_stream(stream), (const bf16_t *)x, x_pitch, (const bf16_t *)residual, r_pitch, (bf16_t *)y,
+                           y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, chan_scale,
+                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out);
+    } else {
+        const EwGeom g = ew_geom(rows, C / 4);
+#define RCF_CALL(XT, YT)                                                                                                 \
+    hipLaunchKernelGGL((bn_apply_kernel<XT, YT, 4>), g.grid, dim3(256), 0, rcf_stream(stream),                          \
+                       (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, g.cvt, g.rpb,   \
+                       mean, invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,  \
                        amax_out)
-    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+        RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
+    }
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -463,15 +581,23 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
     if (relu && !y && !relu_mask) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || (relu && !relu_mask && y_pitch % 4)) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
-    const ColGeom g = col_geom(rows, C);
+    const int V = vec_width(xdt, ydt, C, dy_pitch, x_pitch, (relu && !relu_mask) ? y_pitch : 8, 8);
+    const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
-#define RCF_CALL(XT, YT)                                                                                                 \
-    BwdOp<XT, YT> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
-                     relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask};                                       \
-    hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT>>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,     \
+    if (V == 8) {
+        BwdOp<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)y, mean, invstd, chan_scale,
+                                    dy_pitch, x_pitch, y_pitch, relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};
+        hipLaunchKernelGGL((colreduce2_kernel<BwdOp<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0,
+                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+    } else {
+#define RCF_CALL(XT, YT)                                                                                                    \
+    BwdOp<XT, YT, 4> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
+                        relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};                               \
+    hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,  \
                        rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
-    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+        RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
+    }
     RCF_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
                        g.chunks, 2 * C, sums2);
@@ -498,14 +624,25 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
         return RCF_EINVAL;
     if (relu && !y && !relu_mask) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
-#define RCF_CALL(XT, YT)                                                                                                  \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<XT, YT>), dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, rcf_stream(stream), \
-                       (const YT *)dy, dy_pitch, (const XT *)x, x_pitch, (const YT *)y, y_pitch, (XT *)dx, dx_pitch,      \
-                       (YT *)dres, dres_pitch, res_beta, rows, C, mean, invstd, gamma, relu, chan_scale,                  \
-                       rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma,  \
+    if (vec_width(xdt, ydt, C, dy_pitch, x_pitch, dx_pitch, dres ? dres_pitch : 8) == 8 &&
+        (!(relu && !relu_mask) || y_pitch % 8 == 0)) {
+        const EwGeom g = ew_geom(rows, C / 8);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t, 8>), g.grid, dim3(256), 0,
+                           rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (const bf16_t *)x, x_pitch, (const bf16_t *)y,
+                           y_pitch, (bf16_t *)dx, dx_pitch, (bf16_t *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd,
+                           gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
+                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out);
+    } else {
+        const EwGeom g = ew_geom(rows, C / 4);
+#define RCF_CALL(XT, YT)                                                                                                     \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<XT, YT, 4>), g.grid, dim3(256), 0, rcf_stream(stream),                          \
+                       (const YT *)dy, dy_pitch, (const XT *)x, x_pitch, (const YT *)y, y_pitch, (XT *)dx, dx_pitch,         \
+                       (YT *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, chan_scale,       \
+                       rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma,     \
                        dbeta, relu_mask, amax_out)
-    RCF_DISPATCH2(xdt, ydt, RCF_CALL);
+        RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
+    }
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -527,10 +664,10 @@ extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch
     if (!workspace || workspace_bytes < rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
     const ColGeom g = col_geom(rows, C);
     hipStream_t st = rcf_stream(stream);
-#define RCF_CALL(XT)                                                                                                    \
-    ColsumOp<XT> op{(const XT *)x, pitch};                                                                              \
-    hipLaunchKernelGGL(colreduce2_kernel<ColsumOp<XT>>, dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, rows, \
-                       C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+#define RCF_CALL(XT)                                                                                                      \
+    ColsumOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
+    hipLaunchKernelGGL((colreduce2_kernel<ColsumOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
     RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
     RCF_LAUNCH_CHECK();

@@ -52,6 +52,35 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, f32x4 v) {
 template <typename T> __device__ __forceinline__ float ld1(const T *p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void st1(T *p, float v) { *p = (T)v; }
 
+// V consecutive channels (V = 4 or 8) as fp32: one 16-byte access moves 8 bf16 channels
+template <int V> struct fvec { f32x4 q[V / 4]; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <typename T, int V> __device__ __forceinline__ fvec<V> ldv(const T *p) {
+    fvec<V> r;
+    if constexpr (V == 8 && sizeof(T) == 2) {
+        const u32x4_t w = *reinterpret_cast<const u32x4_t *>(p);
+        r.q[0] = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
+                       __uint_as_float(w[1] & 0xffff0000u)};
+        r.q[1] = f32x4{__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16),
+                       __uint_as_float(w[3] & 0xffff0000u)};
+    } else {
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h) r.q[h] = ld4(p + 4 * h);
+    }
+    return r;
+}
+template <typename T, int V> __device__ __forceinline__ void stv(T *p, const fvec<V> &v) {
+    if constexpr (V == 8 && sizeof(T) == 2) {
+        const bf16x4_t a = __builtin_convertvector(v.q[0], bf16x4_t), b = __builtin_convertvector(v.q[1], bf16x4_t);
+        const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+        *reinterpret_cast<u32x4_t *>(p) = u32x4_t{ua[0], ua[1], ub[0], ub[1]};
+    } else {
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h) st4(p + 4 * h, v.q[h]);
+    }
+}
+
 // dtype-code dispatch for the *_mp entry points: expands `CALL(T)` with T = float / bf16_t
 #define RCF_DISPATCH1(dt, CALL)                          \
     do {                                                 \
