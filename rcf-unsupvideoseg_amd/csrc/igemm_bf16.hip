@@ -105,12 +105,17 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
 // forward / data gradient.  Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32.
 // DGRAD only names the instantiation (profiles tell forward and data-gradient launches apart).
 // OBF: bf16 output (16-byte stores after a half-wave exchange), else fp32 output.
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF>
+// DMA: both operands go from global memory STRAIGHT into LDS (buffer_load ... lds, 16 bytes per lane: no staging
+// registers, no ds_write pass); three LDS stages, the loads of K-step t+2 are issued before the MFMAs of step t and
+// stay in flight across the one barrier per step (counted s_waitcnt vmcnt).  The LDS image of a wave instruction is
+// lane-linear (1 KB = 16 rows x 64 B), so the XOR swizzle of the 16-byte chunks is applied to the SOURCE address.
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     constexpr int PA = BM * 64, PB = BN * 64, STAGE = PA + PB;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int NSTAGE = DMA ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
     const int bid = blockIdx.x;
     const int grp = bid / (8 * p.ntiles);
@@ -127,7 +132,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
     constexpr int ROWS = NT / 4;                      // 4 threads x 16 B per 64-byte row
     constexpr int A_PASS = BM / ROWS, B_PASS = BN / ROWS;
     static_assert(A_PASS >= 1 && B_PASS >= 1, "tile smaller than one loader pass");
-    const int kq = tid & 3, arow = tid >> 2;
+    const int arow = tid >> 2;
+    // register-staged path: this thread loads source chunk kq and stores it at position kq ^ swizzle; DMA path: the
+    // thread's LDS position IS tid & 3, so it loads source chunk (tid & 3) ^ swizzle
+    const int kq = DMA ? ((tid & 3) ^ ((arow >> 2) & 3)) : (tid & 3);
     const int st_off = arow * 64 + ((kq ^ ((arow >> 2) & 3)) << 4);      // + ROWS*64 per pass (ROWS % 16 == 0)
 
     const int HoWo = p.rr;
@@ -160,6 +168,76 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
         const int j = n0 + arow + ROWS * i;
         bbase[i] = j < p.Ncol ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
     }
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    const int KT = (p.K + BKT - 1) / BKT;
+
+    // byte offset of this thread's 16-byte chunk of A for K-step kt, row pass i (bit 31 set = out of range: zeros)
+    auto a_offset = [&](int kt, int i, int tapoff, int c, bool kv, int dy, int dx) -> unsigned {
+        int ty = ay[i] + dy, tx = ax[i] + dx;
+        int v, off;
+        if (STRIDED) {
+            v = (int)kv & (int)(ty >= 0) & (int)(tx >= 0) & (int)(ty % p.div == 0) & (int)(tx % p.div == 0);
+            ty /= p.div;
+            tx /= p.div;
+            v &= (int)(ty < p.Hs) & (int)(tx < p.Ws);
+            off = abase[i] + (ty * p.Ws + tx) * p.a_pitch + c;
+        } else {
+            v = (int)kv & (int)((unsigned)ty < (unsigned)p.Hs) & (int)((unsigned)tx < (unsigned)p.Ws);
+            off = abase[i] + tapoff;
+        }
+        return (((unsigned)off * 2u) & ~OOB) | ((unsigned)(v - 1) & OOB);
+    };
+
+    if constexpr (DMA) {
+        // wave-uniform LDS destinations: pass i of wave w covers rows [ROWS i + 16 w, + 16) = 1 KB
+        const int wrow = __builtin_amdgcn_readfirstlane(wave) * 16 * 64;
+        auto issue = [&](int kt, int stage) {
+            char *As = smem + stage * STAGE + wrow;
+            char *Bs = As + PA;
+            const int k = kt * BKT + kq * 8;
+            const bool kv = k < p.K;
+            const int rs = fast_div(k, p.cs_magic);
+            const int c = k - rs * p.Cs;
+            const int r = fast_div(rs, p.s_magic);
+            const int s = rs - r * p.S;
+            const int dy = r * p.step, dx = s * p.step;
+            const int tapoff = (dy * p.Ws + dx) * p.a_pitch + c;
+            const unsigned kb = (unsigned)kt * (unsigned)p.Ncol * 64u;
+#pragma unroll
+            for (int i = 0; i < B_PASS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(Bs + i * ROWS * 64), 16,
+                                                         (int)(bbase[i] + kb), 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < A_PASS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(As + i * ROWS * 64), 16,
+                                                         (int)a_offset(kt, i, tapoff, c, kv, dy, dx), 0, 0, 0);
+        };
+        constexpr int NLD = A_PASS + B_PASS;              // LDS-DMA instructions per thread per K-step
+        issue(0, 0);
+        if (KT > 1) issue(1, 1);
+        if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st = 0;                                       // stage of K-step kt
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st2 = st >= 1 ? st - 1 : 2;         // (st + 2) % 3: the stage read a step ago, free since the last barrier
+            if (kt + 2 < KT) issue(kt + 2, st2);
+            const char *As = smem + st * STAGE;
+            mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+            // the loads of step kt + 1 (issued a step ago) must have landed; those of kt + 2 stay in flight
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else {
     // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets); B (weights, L2) one step ahead
     u32x4 ra[2][A_PASS], rb[B_PASS];
 
@@ -173,22 +251,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
         const int dy = r * p.step, dx = s * p.step;
         const int tapoff = (dy * p.Ws + dx) * p.a_pitch + c;
 #pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            int ty = ay[i] + dy, tx = ax[i] + dx;
-            int v, off;
-            if (STRIDED) {
-                v = (int)kv & (int)(ty >= 0) & (int)(tx >= 0) & (int)(ty % p.div == 0) & (int)(tx % p.div == 0);
-                ty /= p.div;
-                tx /= p.div;
-                v &= (int)(ty < p.Hs) & (int)(tx < p.Ws);
-                off = abase[i] + (ty * p.Ws + tx) * p.a_pitch + c;
-            } else {
-                v = (int)kv & (int)((unsigned)ty < (unsigned)p.Hs) & (int)((unsigned)tx < (unsigned)p.Ws);
-                off = abase[i] + tapoff;
-            }
-            const unsigned bo = (((unsigned)off * 2u) & ~OOB) | ((unsigned)(v - 1) & OOB);
-            dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0);
-        }
+        for (int i = 0; i < A_PASS; ++i)
+            dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_offset(kt, i, tapoff, c, kv, dy, dx), 0, 0);
     };
     auto load_b = [&](int kt) {
         const unsigned kb = (unsigned)kt * (unsigned)p.Ncol * 64u;
@@ -204,16 +268,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
         for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<u32x4 *>(Bs + st_off + i * ROWS * 64) = rb[i];
     };
 
-    f32x16 acc[MR][NR];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
-
-    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
-    const int KT = (p.K + BKT - 1) / BKT;
     load_a(0, ra[0]);
     load_b(0);
     load_a(1, ra[1]);                        // past the end of K: out-of-range offsets, zeros
@@ -252,6 +306,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
     {
         const char *As = smem + (kt & 1) * STAGE;
         mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+    }
     }
 
     // epilogue.  Transposed accumulators: lane = pixel (lane & 31) of each row tile, registers 4g..4g+3 = output channels
@@ -665,17 +720,18 @@ int set_region(ConvParams &p, const rcf_conv_region *r, int N, int H, int W) {
     return 0;
 }
 
-int g_bf16_tile = -1;      // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 128x64
+int g_bf16_tile = -1;      // -1 / 4: LDS-DMA kernels (128x64 / 128x128 / 128x256 by width), 5: LDS-DMA 256x256 (512 threads);
+                           // register-staged A/B references: 0 128x128, 1 128x256, 2 256x256, 3 128x64
 
-template <int MR, int NR, int WM, int WN, bool OBF>
+template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false>
 void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
-    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
-    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 template <bool OBF>
@@ -690,12 +746,16 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     if (bbytes >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)bbytes;
     const bool strided = p.div > 1;
-    int tile = g_bf16_tile;
-    if (tile < 0) tile = p.Ncol <= 64 ? 3 : (p.Ncol <= 128 ? 0 : 1);
-    if (tile == 3 || p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (tile == 0 || p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
+    const int tile = g_bf16_tile;
+    // tiles 0-3: register-staged loads (A/B reference); default: LDS-DMA loads with three stages
+    if (tile == 3) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (tile == 0) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
     else if (tile == 2) launch_cfg<2, 4, 4, 2, OBF>(p, strided, dgrad, st);
-    else launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (tile == 1) launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true>(p, strided, dgrad, st);
+    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true>(p, strided, dgrad, st);
+    else if (tile == 5) launch_cfg<2, 4, 4, 2, OBF, true>(p, strided, dgrad, st);       // 256x256, 8 waves
+    else launch_cfg<2, 4, 2, 2, OBF, true>(p, strided, dgrad, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -18,6 +18,6 @@ for i in range(1, 5):
             k = r["Kernel_Name"][:60]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
         for k, d in agg.items():
-            if "igemm" in k or "wgrad" in k:
+            if "igemm" in k or "wgrad" in k or "conv_bf16" in k:
                 print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
 PY
