@@ -122,6 +122,32 @@ def make_pl_masks(B, H, W, config_id=1, first_index=0):
             for f in range(2)]
 
 
+def eval_inputs(seed, N=6, C=4, h=30, w=54, H=120, W=214):
+    """Inputs of the evaluation-metric fixtures (tests/golden/make_golden_eval.py): smooth soft masks [N,C,h,w] (softmax
+    of low-frequency logits), annotations [N,H,W] u8 in {0, 128 (ignore), 255}, sequence names (two frames each)."""
+    g = _rng(seed)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    logits = np.zeros((N, C, h, w), dtype=np.float32)
+    for n in range(N):
+        for c in range(C):
+            for _ in range(3):
+                fy, fx = g.uniform(0.5, 2.5, size=2) * 2 * np.pi / np.array([h, w])
+                logits[n, c] += g.uniform(1.0, 3.0) * np.sin(fy * yy + fx * xx + g.uniform(0, 2 * np.pi)).astype(np.float32)
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    masks = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    YY, XX = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    ann = np.zeros((N, H, W), dtype=np.uint8)
+    for n in range(N):
+        cy, cx = g.uniform(0.3, 0.7) * H, g.uniform(0.3, 0.7) * W
+        ry, rx = g.uniform(0.15, 0.35) * H, g.uniform(0.15, 0.35) * W
+        d = ((YY - cy) / ry) ** 2 + ((XX - cx) / rx) ** 2
+        ann[n][d < 1.0] = 255
+        ann[n][(d >= 1.0) & (d < 1.15)] = 128                  # a ring of "ignore" pixels around the object
+    ann[N - 1] = 0                                             # an empty annotation
+    names = [f"seq{n // 2}" for n in range(N)]
+    return masks, ann, names
+
+
 def fill_state_dict(shapes, seed=7, bn3_gamma=0.5, seg_scale=10.0):
     """Seeded weights for every entry of a state-dict `shapes` mapping name -> shape.
 
