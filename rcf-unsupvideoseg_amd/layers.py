@@ -71,6 +71,9 @@ class Act:
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
 OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
+# ... in the bf16 step the convs are as load/LDS-bound as the batch-norm passes and running two of them side by side gains
+# nothing (same-box A/B: 57.8 vs 58.1 ms/step, against 129.7 vs 140.6 in fp32): its weight gradients stay on the main stream
+OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "0") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
@@ -225,7 +228,7 @@ class Conv2d(nn.Module):
                 if self.weight.requires_grad:
                     padded = wk is not self.weight
                     dw = torch.empty_like(wk) if padded else _param_grad(self.weight)
-                    if OVERLAP_WGRAD and x.needs_grad and not padded:
+                    if OVERLAP_WGRAD and OVERLAP_WGRAD_BF16 and x.needs_grad and not padded:
                         side = _side_stream(dy.device)
                         side.wait_stream(torch.cuda.current_stream(dy.device))
                         with torch.cuda.stream(side):
