@@ -297,6 +297,12 @@ size_t rcf_crf_workspace_bytes(int W, int H, int batch);
 int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
                  float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map,
                  float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream);
+/* normalization 0 = rcf_crf_soft; 1 = the symmetric kernel normalisation N^1/2 K N^1/2, N = diag(1 / (K 1 + 1e-20)), of
+ * pydensecrf's DenseCRF2D (NORMALIZE_SYMMETRIC, the default of addPairwiseBilateral): the CPU post-processor
+ * tools/pydenseCRF/crf.py:58-89 and models/crf_head.py:62-91.  Exactly one potential may be active with 1. */
+int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
+                    float scomp_app, float sxy_app, float srgb_app, int iters, int normalization, int16_t *out_map,
+                    float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream);
 int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,
                  float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence, int iters,
                  int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,

@@ -41,6 +41,23 @@ def crf_soft_np(rgb, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, 
     return out, q, (int(nv[0]), int(nv[1]))
 
 
+def dcrf_soft_np(rgb, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters):
+    """DenseCRF2D semantics (symmetric kernel normalisation, pydensecrf's default): see crf_ref.c lattice_filter.
+    Parity-unpinned: restated from the published algorithm, pydensecrf itself is not available here."""
+    rgbf = np.ascontiguousarray(rgb, dtype=np.float32)
+    un = np.ascontiguousarray(unary, dtype=np.float32)
+    assert rgbf.shape == (H, W, 3) and un.shape == (H * W, 2)
+    out = np.empty((H, W), dtype=np.int16)
+    q = np.empty((H * W, 2), dtype=np.float32)
+    nv = np.zeros(2, dtype=np.int32)
+    rc = lib().crf_ref_soft_symmetric(_p(rgbf, ctypes.c_float), _p(un, ctypes.c_float), int(W), int(H),
+                                      ctypes.c_float(scomp_smooth), ctypes.c_float(sxy_smooth), ctypes.c_float(scomp_app),
+                                      ctypes.c_float(sxy_app), ctypes.c_float(srgb_app), int(iters),
+                                      _p(out, ctypes.c_int16), _p(q, ctypes.c_float), _p(nv, ctypes.c_int32))
+    assert rc == 0
+    return out, q, (int(nv[0]), int(nv[1]))
+
+
 def crf_hard_np(rgb, label, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, confidence, iters):
     rgbf = np.ascontiguousarray(rgb, dtype=np.float32)
     lab = np.ascontiguousarray(label, dtype=np.int16)

@@ -42,6 +42,7 @@ typedef struct {
     int *nb_plus, *nb_minus; /* per canonical slot and axis: neighbour slot or -1 (computed once) */
     float *values, *new_values;
     float w;              /* Potts weight */
+    float *norm;          /* symmetric mode only: 1 / sqrt(filter(1) + 1e-20) per pixel (see lattice_filter) */
 } lattice_t;
 
 static unsigned int key_hash(const int16_t *key, int pd) {
@@ -78,7 +79,7 @@ static int table_retrieve(const lattice_t *L, const int16_t *key) {
 
 static void lattice_free(lattice_t *L) {
     free(L->entries); free(L->keys); free(L->mat_index); free(L->mat_weight); free(L->canon);
-    free(L->nb_plus); free(L->nb_minus); free(L->values); free(L->new_values);
+    free(L->nb_plus); free(L->nb_minus); free(L->values); free(L->new_values); free(L->norm);
     memset(L, 0, sizeof(*L));
 }
 
@@ -172,9 +173,20 @@ static int lattice_build(lattice_t *L, const float *feat, int n, int pd, float w
     return 0;
 }
 
-/* out[n*M] = filter(in[n*M])  (permutohedral_gpu.cu:551-573) */
+/* out[n*M] = filter(in[n*M])  (permutohedral_gpu.cu:551-573): normalised by the filtered homogeneous channel.
+ *
+ * L->norm != NULL selects the OTHER normalisation this repo needs: the symmetric one of Kraehenbuehl & Koltun's
+ * DenseCRF (densecrf/src/pairwise.cpp, DenseKernel::filter with NORMALIZE_SYMMETRIC -- the default of
+ * pydensecrf's DenseCRF2D.addPairwiseBilateral, which tools/pydenseCRF/crf.py:73 and models/crf_head.py:82 call):
+ *     out = N^(1/2) K N^(1/2) in,   N = diag(1 / (K 1 + 1e-20)),   K = the unnormalised lattice filter
+ * (DenseKernel::initLattice: norm_ = lattice_.compute(ones); norm_[i] = 1 / sqrt(norm_[i] + 1e-20);
+ *  filter: out = in * norm_; lattice_.compute(out, out); out = out * norm_).  Constant factors of K (blur taps
+ * 1/4-1/2-1/4 here against 1/2-1-1/2 and the slice's alpha there) cancel between K and N.  pydensecrf is not
+ * vendored in the reference (requirements.txt:8, unpinned git HEAD): this branch restates the published algorithm and
+ * is PARITY-UNPINNED (no reference vectors exist for it). */
 static void lattice_filter(lattice_t *L, float *out, const float *in) {
     const int pd = L->pd, n = L->n;
+    const float *nrm = L->norm;
     float *val = L->values, *nv = L->new_values;
     memset(val, 0, sizeof(float) * (size_t)L->capacity * VD);
     for (int p = 0; p < n; p++) {                          /* splat :303-378 */
@@ -182,7 +194,7 @@ static void lattice_filter(lattice_t *L, float *out, const float *in) {
             const int e = p * (pd + 1) + r;
             float wgt = L->mat_weight[e];
             float *v = val + (size_t)L->mat_index[e] * VD;
-            for (int j = 0; j < MLAB; j++) v[j] += in[(size_t)p * MLAB + j] * wgt;
+            for (int j = 0; j < MLAB; j++) v[j] += (nrm ? in[(size_t)p * MLAB + j] * nrm[p] : in[(size_t)p * MLAB + j]) * wgt;
             v[VD - 1] += wgt;
         }
     }
@@ -208,9 +220,29 @@ static void lattice_filter(lattice_t *L, float *out, const float *in) {
             for (int j = 0; j < MLAB; j++) acc[j] += L->mat_weight[e] * v[j];
             wsum += L->mat_weight[e] * v[VD - 1];
         }
-        wsum = (float)(1.0 / wsum);
+        wsum = nrm ? nrm[p] : (float)(1.0 / wsum);
         for (int j = 0; j < MLAB; j++) out[(size_t)p * MLAB + j] = acc[j] * wsum;
     }
+}
+
+/* symmetric mode: norm[p] = 1 / sqrt((K 1)[p] + 1e-20), from the homogeneous channel of one plain filter pass */
+static int lattice_make_symmetric(lattice_t *L) {
+    const int pd = L->pd, n = L->n;
+    float *zeros = (float *)calloc((size_t)n * MLAB, sizeof(float)), *tmp = (float *)malloc(sizeof(float) * (size_t)n * MLAB);
+    float *norm = (float *)malloc(sizeof(float) * (size_t)n);
+    if (!zeros || !tmp || !norm) { free(zeros); free(tmp); free(norm); return -1; }
+    lattice_filter(L, tmp, zeros);                       /* leaves the blurred homogeneous channel in L->values */
+    for (int p = 0; p < n; p++) {
+        float wsum = 0;
+        for (int r = 0; r <= pd; r++) {
+            const int e = p * (pd + 1) + r;
+            wsum += L->mat_weight[e] * L->values[(size_t)L->mat_index[e] * VD + (VD - 1)];
+        }
+        norm[p] = (float)(1.0 / sqrt((double)wsum + 1e-20));
+    }
+    L->norm = norm;
+    free(zeros); free(tmp);
+    return 0;
 }
 
 static void exp_normalize(float *out, const float *in, int n, float scale) {
@@ -236,6 +268,7 @@ static void image_features(float *out, int pd, int W, int H, const float *rgb, f
 
 /* Shared inference. unary: n*2 energies.  Optional outputs may be NULL.
  * num_vertices[0] = smoothness lattice size (0 if off), [1] = appearance lattice size. */
+static int g_symmetric = 0;     /* set around a call by crf_ref_soft_symmetric */
 static int crf_run(const float *rgbf, const float *unary, int W, int H, float scomp_smooth, float sxy_smooth,
                    float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *out_q,
                    int *num_vertices) {
@@ -251,11 +284,13 @@ static int crf_run(const float *rgbf, const float *unary, int W, int H, float sc
         image_features(feat, 2, W, H, NULL, sxy_smooth, 1.0f);
         if (lattice_build(&Ls, feat, n, 2, scomp_smooth)) { rc = -1; goto done; }
         has_s = 1;
+        if (g_symmetric && lattice_make_symmetric(&Ls)) { rc = -1; goto done; }
     }
     if (scomp_app > 0.0f && sxy_app > 0.0f) {              /* torchcrf.cu:39-51 */
         image_features(feat, 5, W, H, rgbf, sxy_app, srgb_app);
         if (lattice_build(&La, feat, n, 5, scomp_app)) { rc = -1; goto done; }
         has_a = 1;
+        if (g_symmetric && lattice_make_symmetric(&La)) { rc = -1; goto done; }
     }
     if (num_vertices) { num_vertices[0] = has_s ? Ls.ncanon : 0; num_vertices[1] = has_a ? La.ncanon : 0; }
     exp_normalize(cur, unary, n, -1.0f);                   /* densecrf_base.cpp:31-34 */
@@ -285,6 +320,19 @@ int crf_ref_soft(const float *rgb, const float *unary, int W, int H, float scomp
                  int *num_vertices) {
     return crf_run(rgb, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
                    out_q, num_vertices);
+}
+
+/* DenseCRF2D(W, H, 2) + setUnaryEnergy + addPairwiseGaussian / addPairwiseBilateral (symmetric normalisation, the
+ * pydensecrf default) + inference(iters): Q <- softmax(-U + sum_k w_k * Ksym_k Q)  (densecrf.cpp DenseCRF::inference,
+ * pairwise.cpp PottsCompatibility::apply).  Same argument meaning as crf_ref_soft.  See lattice_filter. */
+int crf_ref_soft_symmetric(const float *rgb, const float *unary, int W, int H, float scomp_smooth, float sxy_smooth,
+                           float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *out_q,
+                           int *num_vertices) {
+    g_symmetric = 1;
+    int rc = crf_run(rgb, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map, out_q,
+                     num_vertices);
+    g_symmetric = 0;
+    return rc;
 }
 
 /* torchcrfHard (torchcrf.cu:106-124) with setUnaryEnergyFromLabel (densecrf_gpu.cu:84-143). */

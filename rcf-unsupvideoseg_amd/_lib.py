@@ -109,6 +109,8 @@ PROTOS = {
     "rcf_crf_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rcf_crf_soft": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P, P, P,
                              P, c_size_t, P]),
+    "rcf_crf_soft_ex": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P,
+                                P, c_size_t, P]),
     "rcf_crf_hard": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                              P, P, P, P, c_size_t, P]),
     "rcf_crf_prepare": (c_int, [P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),

@@ -18,8 +18,9 @@ def _check(t, name):
 
 
 def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
-                     want_q=False, want_nvert=False):
-    """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2])."""
+                     want_q=False, want_nvert=False, symmetric=False):
+    """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2]).
+    symmetric: pydensecrf's DenseCRF2D kernel normalisation (NORMALIZE_SYMMETRIC) instead of tools/torchCRF's."""
     _check(rgb_u8, "rgbFeat")
     _check(unary, "unaryEnergy")
     n = rgb_u8.shape[0]
@@ -31,8 +32,8 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
     nv = torch.zeros((n, 2), dtype=torch.int32, device=dev) if want_nvert else None
     need = _lib.load().rcf_crf_workspace_bytes(W, H, n)
     ws = workspace(need, dev)
-    _lib.call("rcf_crf_soft", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
-              int(iters), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
+    _lib.call("rcf_crf_soft_ex", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
+              int(iters), int(bool(symmetric)), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
     res = (out,)
     if want_q:
         res += (q,)
@@ -100,10 +101,12 @@ class CRFHead(nn.Module):
         return rgb, unary
 
     @torch.no_grad()
-    def forward(self, imgs, masks, unstandardize=True):
-        """imgs [N,3,H,W] normalised, masks [N,H,W] in [0,1] -> refined masks [N,H,W] float 0/1."""
+    def forward(self, imgs, masks, unstandardize=True, symmetric=False):
+        """imgs [N,3,H,W] normalised, masks [N,H,W] in [0,1] -> refined masks [N,H,W] float 0/1.
+        symmetric=True: the arithmetic of the reference's `crf_cpu` (models/crf_head.py:62-91: pydensecrf DenseCRF2D,
+        symmetric kernel normalisation) instead of `crf` (torchcrf_cpp), batched on the GPU all the same."""
         rgb, unary = self.prepare(imgs, masks, unstandardize)
         N, H, W, _ = rgb.shape
         m = crf_soft_batched(rgb, unary, W, H, self.scomp_smooth, self.sxy_smooth, self.scomp, self.sxy, self.srgb,
-                             self.refine_iters)
+                             self.refine_iters, symmetric=symmetric)
         return m.float()

@@ -848,7 +848,8 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T
 }
 
 // build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
-__global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float *__restrict__ z) {
+// sym: inv[p] = 1 / sqrt(that + 1e-20), the symmetric normalisation of DenseCRF2D (see rcf_crf_soft_ex)
+__global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float *__restrict__ z, int sym) {
     const int f = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
@@ -858,7 +859,7 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
         const long pe = fb + (long)r * Lt.N + p;
         sw += Lt.weight[pe] * z[fb + Lt.vid[pe]];
     }
-    Lt.inv[(long)f * Lt.N + p] = (float)(1.0 / sw);
+    Lt.inv[(long)f * Lt.N + p] = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
 }
 
 // slice + Potts weight + (optionally) softmax and MAP.
@@ -866,7 +867,7 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
 __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__restrict__ val,
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
-                                                    int last, int write_map) {
+                                                    int last, int write_map, int sym) {
     const int f = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
@@ -892,9 +893,20 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const float e0 = __expf(n0 - mx), e1 = __expf(n1 - mx);
     const float tt = e0 + e1;
     const float q0 = e0 / tt, q1 = e1 / tt;
-    Q[qi] = q0;
-    Q[qi + 1] = q1;
+    // symmetric normalisation: what the next iteration splats is Q * norm (inv holds norm = 1/sqrt(K 1) there); the final
+    // iteration (write_map) leaves the marginals themselves
+    const float sc = (sym && !write_map) ? inv : 1.f;
+    Q[qi] = q0 * sc;
+    Q[qi + 1] = q1 * sc;
     if (write_map) map[(long)f * Lt.N + p] = (q0 < q1) ? 1 : 0;
+}
+
+// symmetric normalisation: Q *= norm before the first splat
+__global__ void __launch_bounds__(256) scale_q_kernel(float *__restrict__ Q, const float *__restrict__ nrm, long n) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    Q[p * 2] *= nrm[p];
+    Q[p * 2 + 1] *= nrm[p];
 }
 
 // Q = softmax(scale * in)  (startInference: scale -1 on the unary; also T=0 MAP)
@@ -1057,6 +1069,7 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
 
 int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build,
                            // 2: packed build whose first-attempt table is tiny (exercises the overflow path)
+int g_crf_sym = 0;         // 1 while rcf_crf_soft_ex runs with the symmetric normalisation
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
 
 // bound on |key coordinate| (see lattice_point): elevated[i] in [-i*cf_i, sum_j cf_j], keys within pd+1 of it
@@ -1133,7 +1146,7 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
         hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
     }
-    hipLaunchKernelGGL(slice_norm_kernel, gp, dim3(256), 0, st, L, (const float *)za);
+    hipLaunchKernelGGL(slice_norm_kernel, gp, dim3(256), 0, st, L, (const float *)za, g_crf_sym);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1149,7 +1162,7 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
         float2 *t = a; a = b; b = t;
     }
     hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last,
-                       write_map);
+                       write_map, g_crf_sym);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1170,6 +1183,11 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
     if (npot == 0 && iters > 0) {
         // no pairwise term: every step is softmax(-U) again
         iters = 0;
+    }
+    if (g_crf_sym && iters > 0) {
+        if (npot != 1) return RCF_EINVAL;                // the scaled marginals belong to ONE kernel's normaliser
+        hipLaunchKernelGGL(scale_q_kernel, dim3(rcf_cdiv(n, 256)), dim3(256), 0, st, b.cur, (has_a ? b.app : b.smooth).inv, n);
+        RCF_LAUNCH_CHECK();
     }
     for (int it = 0; it < iters; it++) {
         const int wm = (it == iters - 1) ? 1 : 0;
@@ -1214,6 +1232,22 @@ extern "C" int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H
     carve_all((char *)workspace, W, H, batch, b);
     return crf_infer(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
                      q_out, nvert, b, rcf_stream(stream));
+}
+
+/* normalization 0: rcf_crf_soft.  normalization 1: the symmetric kernel normalisation of Kraehenbuehl & Koltun's DenseCRF
+ * (pydensecrf DenseCRF2D.addPairwiseBilateral / addPairwiseGaussian defaults, NORMALIZE_SYMMETRIC): the filter is
+ * N^1/2 K N^1/2 with N = diag(1 / (K 1 + 1e-20)) instead of diag(1 / K 1) K -- what tools/pydenseCRF/crf.py:58-89 and
+ * models/crf_head.py:62-91 (crf_cpu) compute.  Exactly one potential may be active in that mode. */
+extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
+                               float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
+                               int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    if (normalization != 0 && normalization != 1) return RCF_EINVAL;
+    g_crf_sym = normalization;
+    const int rc = rcf_crf_soft(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
+                                out_map, q_out, nvert, workspace, workspace_bytes, stream);
+    g_crf_sym = 0;
+    return rc;
 }
 
 extern "C" int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,

@@ -669,6 +669,203 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
     }
 }
 
+// The 128-row tiles again with LDS-DMA loads (buffer_load ... lds), three LDS stages and one barrier per K-step, like
+// conv_bf16_kernel<..., DMA>.  LDS image per operand: [channel group of 64][32 pixels][128 B] -- a DMA instruction (1 KB,
+// lane-linear) is 8 pixel rows of ONE channel group, so every thread serves ONE pixel (8 wave + lane / 8) in all of its
+// instructions: one pixel walk and one bounds test per K-step instead of one per load (the register-staged kernel spends
+// 9.5 VALU instructions per MFMA, mostly on that).  The 16-byte chunks of pixel row p are XOR-swizzled by
+// ((p >> 1) & 1) << 2 (source address and fragment address alike): the 4 rows x 4 chunks a 32-lane half reads through
+// ds_read_b64_tr_b16 cover all 16 chunk positions of the 256-byte bank space (SQ_LDS_BANK_CONFLICT = 0).
+// ONETAP: Cin is a multiple of the tile width, so a tile's columns belong to one filter tap.
+template <int NR, bool REGION, bool ONETAP>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
+    constexpr int MR = 2, BM = 128, BN = 64 * NR, BK = 32;
+    constexpr int GA = BM / 64, GB = BN / 64;                  // channel groups = DMA instructions per wave and K-step
+    constexpr int GSZ = BK * 128;                              // bytes of one group: 32 pixels x 128 B
+    constexpr int PLA = GA * GSZ, PLB = GB * GSZ, STAGE = PLA + PLB;
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kend = min(p.M, kbeg + p.chunk);
+    const int klen = (int)(kend - kbeg);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HoWo = p.rr;
+    const int n_first = (int)(kbeg / HoWo);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.DY + (REGION ? (long)n_first * p.Ho * p.Wo : kbeg) * p.dy_pitch), 0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)OOB, 0x00020000);
+
+    // this thread's pixel row of the K-step and its chunk position inside a 128-byte group row
+    const int prow = 8 * wave + (lane >> 3), qpos = lane & 7;
+    const int qsrc = qpos ^ (((prow >> 1) & 1) << 2);          // source chunk of that position
+    int pn, py, px, ppix;                                      // the pixel walk (image index relative to n_first)
+    {
+        const long m = kbeg + prow;
+        pn = (int)(m / HoWo);
+        ppix = (int)(m - (long)pn * HoWo);
+        if (REGION) region_yx(ppix, p.ry0, p.rx0, p.rh, p.rw, p.rband, py, px);
+        else { py = ppix / p.Wo; px = ppix - py * p.Wo; }
+        pn -= n_first;
+    }
+    const bool incr = !REGION && p.Wo >= BK;
+    int cha[GA], chb[GB], tr[GB], ts[GB];
+    bool acta[GA], actb[GB];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+        cha[g] = i0 + 64 * g + 8 * qsrc;
+        acta[g] = cha[g] < p.Cout;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int jc = j0 + 64 * g + 8 * qsrc;                 // GEMM column = (tap, channel)
+        const int rs = (ONETAP ? j0 : jc) / p.Cin;
+        chb[g] = jc - rs * p.Cin;
+        tr[g] = rs / p.S;
+        ts[g] = rs - tr[g] * p.S;
+        actb[g] = jc < p.Ktot;
+    }
+    const int wb = __builtin_amdgcn_readfirstlane(wave) * 1024;    // 8 pixel rows x 128 B of each group
+    auto issue = [&](int kt, int stage) {                  // K-steps are issued in order: the walk advances by BK each time
+        char *As = smem + stage * STAGE + wb;
+        char *Bs = smem + stage * STAGE + PLA + wb;
+        const int mk = kt * BK + prow;
+        const bool inb = mk < klen;
+        const int dyoff = REGION ? ((pn * p.Ho + py) * p.Wo + px) * p.dy_pitch : mk * p.dy_pitch;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+            const unsigned bo = (inb && acta[g]) ? (unsigned)(dyoff + cha[g]) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(As + g * GSZ), 16, (int)bo, 0, 0, 0);
+        }
+        if constexpr (ONETAP) {
+            const int sy = py * p.stride - p.pad + tr[0] * p.dil, sx = px * p.stride - p.pad + ts[0] * p.dil;
+            const bool v = inb && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const int xoff = ((pn * p.H + sy) * p.W + sx) * p.x_pitch;
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const unsigned bo = (v && actb[g]) ? (unsigned)(xoff + chb[g]) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(Bs + g * GSZ), 16, (int)bo, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int sy = py * p.stride - p.pad + tr[g] * p.dil, sx = px * p.stride - p.pad + ts[g] * p.dil;
+                const bool v = inb && actb[g] && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+                const unsigned bo = v ? (unsigned)(((pn * p.H + sy) * p.W + sx) * p.x_pitch + chb[g]) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(Bs + g * GSZ), 16, (int)bo, 0, 0, 0);
+            }
+        }
+        if (incr) {                              // Wo >= BK: at most one row wrap per K-step
+            px += BK;
+            const bool wx = px >= p.Wo;
+            px -= wx ? p.Wo : 0;
+            py += wx ? 1 : 0;
+            const bool wy = py == p.Ho;
+            py = wy ? 0 : py;
+            pn += wy ? 1 : 0;
+        } else {
+            ppix += BK;
+            while (ppix >= HoWo) { ppix -= HoWo; ++pn; }
+            if (REGION) region_yx(ppix, p.ry0, p.rx0, p.rh, p.rw, p.rband, py, px);
+            else { py = ppix / p.Wo; px = ppix - py * p.Wo; }
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
+
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    // fragment addressing: 16-lane group gi serves tile rows (channels) 16 (gi & 1) .. +15 and the k half gi >> 1; lane q of
+    // the group points at pixel row 8 (gi >> 1) + q / 4 (+ 4 for the second read), channels 4 (q % 4) .. + 3 of its 16
+    const int gi = lane >> 4, q16 = lane & 15;
+    const int fprow = 8 * (gi >> 1) + (q16 >> 2);
+    const int swz = ((fprow >> 1) & 1) << 2;                              // (+4, +16 j leave bit 1 of the pixel row alone)
+    const int cin = 16 * (gi & 1) + 4 * (q16 & 3);                         // channel inside a 32-channel tile
+    const int wi = (cin & 7) * 2;
+    int fa[MR], fb[NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int c = arow0 + mr * 32 + cin;
+        fa[mr] = (c >> 6) * GSZ + fprow * 128 + ((((c >> 3) & 7) ^ swz) << 4) + wi;
+    }
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int c = brow0 + nr * 32 + cin;
+        fb[nr] = (c >> 6) * GSZ + fprow * 128 + ((((c >> 3) & 7) ^ swz) << 4) + wi;
+    }
+    auto mma = [&](int stage) {
+        const char *As = smem + stage * STAGE, *Bs = As + PLA;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                     // two 16-pixel substeps
+            bf16x8 a[MR], b[NR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                const u32x2 lo = lds_tr16(As + fa[mr] + 16 * j * 128);
+                const u32x2 hi = lds_tr16(As + fa[mr] + 16 * j * 128 + 4 * 128);
+                a[mr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const u32x2 lo = lds_tr16(Bs + fb[nr] + 16 * j * 128);
+                const u32x2 hi = lds_tr16(Bs + fb[nr] + 16 * j * 128 + 4 * 128);
+                b[nr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+        }
+    };
+
+    constexpr int NLD = GA + GB;
+    const int KT = (klen + BK - 1) / BK;
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int st2 = st >= 1 ? st - 1 : 2;             // (st + 2) % 3
+        if (kt + 2 < KT) issue(kt + 2, st2);
+        mma(st);
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st = st == 2 ? 0 : st + 1;
+    }
+
+    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = rbase + (e & 3) + 8 * (e >> 2);
+            if (co >= p.Cout) continue;
+            float *drow = out + (long)co * p.Ktot + j0 + brow0 + l31;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (j0 + brow0 + nr * 32 + l31 >= p.Ktot) continue;
+                float v = acc[mr][nr][e];
+                if (p.beta && gridDim.z == 1) v += drow[nr * 32];
+                drow[nr * 32] = v;
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
                                      int splits, int beta) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -921,13 +1118,25 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
         if (region) hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, true>), grid, dim3(256), 0, st, p);  \
         else hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, false>), grid, dim3(256), 0, st, p);        \
     } while (0)
-    if (pl.mr == 2 && pl.nr == 4) RCF_WG(2, 4);
+    const bool onetap = s->Cin % (64 * pl.nr) == 0;
+#define RCF_WGD(NRv)                                                                                              \
+    do {                                                                                                          \
+        if (region && onetap) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);   \
+        else if (region) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, true, false>), grid, dim3(256), 0, st, p);       \
+        else if (onetap) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, false, true>), grid, dim3(256), 0, st, p);       \
+        else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, false, false>), grid, dim3(256), 0, st, p);                  \
+    } while (0)
+    const bool dma = g_bf16_tile < 0 || g_bf16_tile >= 4;      // tiles 0-3 select the register-staged references
+    if (pl.mr == 2 && pl.nr == 4 && dma) RCF_WGD(4);
+    else if (pl.mr == 2 && pl.nr == 2 && dma) RCF_WGD(2);
+    else if (pl.mr == 2 && pl.nr == 4) RCF_WG(2, 4);
     else if (pl.mr == 2 && pl.nr == 2) RCF_WG(2, 2);
     else if (pl.mr == 2) RCF_WG(2, 1);
     else if (pl.nr == 4) RCF_WG(1, 4);
     else if (pl.nr == 2) RCF_WG(1, 2);
     else RCF_WG(1, 1);
 #undef RCF_WG
+#undef RCF_WGD
     RCF_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         const long n4 = p.split_stride / 4;

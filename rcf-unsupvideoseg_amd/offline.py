@@ -6,9 +6,11 @@
   (`crf_head_single`, crf_scale 0.7, on the input mask; `crf_head`, crf_scale 0.5, on the refined mask; product, or
   the single-CRF mask when the two disagree by more than `umi_th`).
 
-The mean-field arithmetic is the reference's GPU CRF (tools/torchCRF: normalisation by the sliced homogeneous
-channel), not pydensecrf's symmetric normalisation; pydensecrf is not importable in this environment, so `refine` is
-unpinned against it -- it is pinned against the C restatement of tools/torchCRF instead (tests/test_crf_gpu.py).
+`refine` reproduces pydensecrf's arithmetic: DenseCRF2D.addPairwiseBilateral's default SYMMETRIC kernel normalisation
+(N^1/2 K N^1/2, Kraehenbuehl & Koltun's densecrf), selected in the HIP kernel by rcf_crf_soft_ex(normalization=1); the
+merge uses tools/torchCRF's (the reference's `CRFHead.crf`).  pydensecrf is not importable in this environment and is not
+vendored by the reference: the symmetric mode is checked against oracle/crf_ref.c's restatement of the published
+algorithm (parity-unpinned; tests/test_crf_gpu.py, tests/test_crf_oracle_cpu.py).
 """
 import numpy as np
 import torch
@@ -28,19 +30,21 @@ def _unary_from_u8(mask, gk):
     return np.float32(UU).reshape(-1, 2)
 
 
-def refine_batch(masks, images, gk=0.1, sxy=60.0, srgb=5.0, compat=5.0, iters=50, device="cuda:0"):
-    """masks u8 [n,H,W] (0..255), images u8 [n,H,W,3] -> float32 [n,H,W] of 0/1 (one library call for all frames)"""
+def refine_batch(masks, images, gk=0.1, sxy=60.0, srgb=5.0, compat=5.0, iters=50, device="cuda:0", symmetric=True):
+    """masks u8 [n,H,W] (0..255), images u8 [n,H,W,3] -> float32 [n,H,W] of 0/1 (one library call for all frames).
+    symmetric=True is pydensecrf's normalisation (what tools/pydenseCRF/crf.py runs); False is tools/torchCRF's."""
     masks, images = np.asarray(masks), np.ascontiguousarray(images)
     n, H, W = masks.shape
     unary = torch.from_numpy(np.stack([_unary_from_u8(m, gk) for m in masks])).to(device)
     rgb = torch.from_numpy(images).to(device)
-    out = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, float(compat), float(sxy), float(srgb), int(iters))
+    out = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, float(compat), float(sxy), float(srgb), int(iters),
+                           symmetric=symmetric)
     return out.float().cpu().numpy()
 
 
-def refine(mask, image, gk, sxy, srgb, compat, gtmask, iters=50, device="cuda:0"):
+def refine(mask, image, gk, sxy, srgb, compat, gtmask, iters=50, device="cuda:0", symmetric=True):
     """tools/pydenseCRF/crf.py:57 `refine(mask, image, gk, sxy, srgb, compat, gtmask)`"""
-    new_mask = refine_batch(mask[None], image[None], gk, sxy, srgb, compat, iters, device)[0]
+    new_mask = refine_batch(mask[None], image[None], gk, sxy, srgb, compat, iters, device, symmetric)[0]
     if gtmask is not None:
         gt, bm = gtmask > 0.1, new_mask > 0.1
         return new_mask, np.float32(np.sum(gt & bm)) / np.float32(np.sum(gt | bm))

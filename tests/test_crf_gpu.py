@@ -122,8 +122,12 @@ def test_offline_callers(report):
     mask_u8 = (np.asarray(soft) * 255 / 0.8).clip(0, 255).astype(np.uint8)   # tools/pydenseCRF/crf.py:174
     got = offline.refine(mask_u8, img, 0.1, 60.0, 5.0, 5.0, None, iters=10)
     unary = offline._unary_from_u8(mask_u8, 0.1)
-    ref = crf_oracle.crf_soft_np(img, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 10)[0]
+    # `refine` runs pydensecrf's symmetric kernel normalisation: checked against the restatement of that algorithm
+    ref = crf_oracle.dcrf_soft_np(img, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 10)[0]
     agree = float((got == ref.astype(np.float32)).mean())
+    got_row = offline.refine(mask_u8, img, 0.1, 60.0, 5.0, 5.0, None, iters=10, symmetric=False)
+    ref_row = crf_oracle.crf_soft_np(img, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 10)[0]
+    assert float((got_row == ref_row.astype(np.float32)).mean()) > 0.999
     new_mask, iou = offline.refine(mask_u8, img, 0.1, 60.0, 5.0, 5.0, (np.asarray(soft) > 0.5).astype(np.float32), iters=10)
     # double CRF merge: equals the product of the two heads run separately
     head_a = rcf_amd.CRFHead(None, refine_iters=5, crf_scale=0.7)
@@ -137,6 +141,27 @@ def test_offline_callers(report):
     e_merge = float((merged - prod).abs().max()) + (0.0 if same_u8 else 1.0)
     report(f"offline refine vs C restatement: pixel agreement {agree:.5f}, iou vs blob {iou:.3f}; double-CRF merge |d| {e_merge}")
     assert agree > 0.999 and 0.0 < iou <= 1.0 and e_merge == 0.0
+
+
+@pytest.mark.parametrize("H,W,iters", [(64, 96, 5), (96, 130, 50), (480, 854, 5)])
+def test_crf_symmetric_normalisation_vs_oracle(H, W, iters, report):
+    """rcf_crf_soft_ex(normalization=1) -- DenseCRF2D's symmetric kernel normalisation (pydensecrf default; the CPU
+    post-processor tools/pydenseCRF/crf.py:58-89) -- against oracle/crf_ref.c's restatement of it (parity-unpinned)"""
+    from rcf_amd.crf import crf_soft_batched
+    rgb = synth.smooth_rgb(H, W, 4300)
+    soft = np.clip(synth.soft_blob_mask(H, W, 4300), 1e-6, 1 - 1e-6)
+    unary = np.stack([-np.log(1 - soft), -np.log(soft)], -1).reshape(-1, 2).astype(np.float32)
+    m, q, nv = crf_soft_batched(torch.from_numpy(rgb)[None].to(DEV), torch.from_numpy(unary)[None].to(DEV), W, H, 0.0, 0.0,
+                                5.0, 60.0, 5.0, iters, want_q=True, want_nvert=True, symmetric=True)
+    mo, qo, nvo = crf_oracle.dcrf_soft_np(rgb, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, iters)
+    agree = float((m[0].cpu().numpy() == mo).mean())
+    dq = float(np.abs(q[0].cpu().numpy() - qo).max())
+    m_row = crf_soft_batched(torch.from_numpy(rgb)[None].to(DEV), torch.from_numpy(unary)[None].to(DEV), W, H, 0.0, 0.0, 5.0,
+                             60.0, 5.0, iters)
+    differs = float((m_row[0].cpu().numpy() != m[0].cpu().numpy()).mean())
+    report(f"crf symmetric normalisation {H}x{W} T={iters}: MAP agreement with the oracle {agree:.6f}, max |dQ| {dq:.2e}, "
+           f"vertices {int(nv[0, 1])} vs {nvo[1]}; differs from the row-normalised MAP on {differs:.4f} of the pixels")
+    assert agree > 0.9995 and dq < 5e-4 and int(nv[0, 1]) == nvo[1]
 
 
 def test_crf_hard_vs_oracle(report):

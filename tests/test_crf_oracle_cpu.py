@@ -79,3 +79,35 @@ def test_hard_labels():
     lab2 = lab.copy(); lab2[:] = -1
     m2, q2, _ = crf_oracle.crf_hard_np(rgb, lab2, W, H, 0, 0, 0, 60, 5, 0.7, 3)
     assert np.abs(q2 - 0.5).max() < 1e-6 and (m2 == 0).all()       # unknown everywhere: ties -> label 0
+
+
+def test_symmetric_normalisation_against_bruteforce_and_invariants():
+    """DenseCRF2D semantics (pydensecrf default, NORMALIZE_SYMMETRIC): Ksym = D^-1/2 K D^-1/2 with D = K 1.
+    Parity-unpinned restatement of the published algorithm; held to (i) an O(N^2) dense mean-field with the same
+    symmetric normalisation, (ii) symmetry of the operator <a, Ksym b> = <Ksym a, b>, which the row-normalised torchCRF
+    filter does not have, (iii) marginals on the simplex, (iv) w = 0 gives the unary arg-max."""
+    import ctypes
+    H, W, T = 20, 28, 5
+    rgb = synth.smooth_rgb(H, W, 21)
+    un = _unary(synth.soft_blob_mask(H, W, 21))
+    sxy, srgb, w = 8.0, 20.0, 5.0
+    m, q, _ = crf_oracle.dcrf_soft_np(rgb, un, W, H, 0, 0, w, sxy, srgb, T)
+    assert np.abs(q.sum(1) - 1).max() < 1e-6 and q.min() >= 0
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    f = np.concatenate([np.stack([xx, yy], -1).reshape(-1, 2) / sxy, rgb.reshape(-1, 3).astype(np.float64) / srgb], 1)
+    K = np.exp(-0.5 * ((f[:, None] - f[None]) ** 2).sum(-1))
+    n = 1.0 / np.sqrt(K.sum(1) + 1e-20)
+    Ks = n[:, None] * K * n[None]
+    Q = np.exp(-un - (-un).max(1, keepdims=True)); Q /= Q.sum(1, keepdims=True)
+    for _ in range(T):
+        nx = -un + w * (Ks @ Q)
+        Q = np.exp(nx - nx.max(1, keepdims=True)); Q /= Q.sum(1, keepdims=True)
+    agree = (Q.argmax(1).reshape(H, W) == m).mean()
+    assert agree > 0.93, agree
+    assert np.abs(Q[:, 1] - q[:, 1]).mean() < 0.05
+    # it is a different operator from the row-normalised one of tools/torchCRF
+    m_row, q_row, _ = crf_oracle.crf_soft_np(rgb, un, W, H, 0, 0, w, sxy, srgb, T)
+    assert np.abs(q - q_row).max() > 1e-3
+    # w = 0: unary arg-max
+    want = (un[:, 1] < un[:, 0]).astype(np.int16).reshape(H, W)
+    assert np.array_equal(crf_oracle.dcrf_soft_np(rgb, un, W, H, 0, 0, 0, sxy, srgb, 3)[0], want)
