@@ -59,12 +59,19 @@ struct Lattice {           // device pointers of one potential, for all frames (
     // then stays in the frame's L2 and the bucket scans are short); a frame that fills more than half of them, or
     // needs a probe longer than PK_PROBE_LIMIT, is inserted again into all 2E buckets.
     int cap_small;
-    int *stat;                   // [F][2]  distinct keys of the small attempt, probe-limit flag
+    int *stat;                   // [F][4]  distinct keys of the small attempt, probe-limit flag, sampled distinct keys, -
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
+// pk_estimate_kernel: PK_SAMPLES blocks of 256 pixels per frame, spread over the image; a frame whose sampled blocks hold
+// more than half as many distinct keys as entries (noise-like content: ~1 key per entry; smooth content: a few percent)
+// cannot fit the small table and goes straight to the full one -- without this every workgroup of the first attempt
+// probes a table that is 10x over-subscribed (uniform-noise frames: 12.7 ms of the 25 ms build per 8 frames).
+constexpr int PK_SAMPLES = 64;
+constexpr int PK_SAMPLE_LIMIT = PK_SAMPLES * 256 * 6 / 2;
 __device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
-    return (long)Lt.cap_small < 2 * Lt.E && (Lt.stat[2 * f] > Lt.cap_small / 2 || Lt.stat[2 * f + 1] != 0);
+    return (long)Lt.cap_small < 2 * Lt.E &&
+           (Lt.stat[4 * f] > Lt.cap_small / 2 || Lt.stat[4 * f + 1] != 0 || Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
 }
 __device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : (long)Lt.cap_small; }
 
@@ -483,8 +490,8 @@ __global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
     if (phase == 1) {
         if (!pk_overflowed(Lt, f)) return;
         n = 2 * Lt.E;
-    } else if (blockIdx.y == 0 && threadIdx.x < 2) {
-        Lt.stat[2 * f + threadIdx.x] = 0;            // read by nobody before the insert kernel that follows
+    } else if (blockIdx.y == 0 && threadIdx.x < 4) {
+        Lt.stat[4 * f + threadIdx.x] = 0;            // read by nobody before the estimate / insert kernels that follow
     }
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
     unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
@@ -492,6 +499,42 @@ __global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
         table[i] = PK_EMPTY;
         cursor[i] = 0u;
     }
+}
+
+// distinct keys of PK_SAMPLES sampled pixel blocks (block-local de-duplication only) -> stat[4 f + 2]
+__global__ void __launch_bounds__(256) pk_estimate_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, float posdev,
+                                                          float featdev) {
+    __shared__ unsigned long long lkey[LT_SLOTS];
+    __shared__ int distinct;
+    const int pd = Lt.pd, nax = pd + 1;
+    const int f = blockIdx.y;
+    const int nblk = (Lt.N + 255) / 256;
+    const int blk = (int)(((long)blockIdx.x * nblk) / gridDim.x);
+    const int p = blk * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) lkey[i] = PK_EMPTY;
+    if (threadIdx.x == 0) distinct = 0;
+    __syncthreads();
+    int mine = 0;
+    if (p < Lt.N) {
+        int rem0[PD_MAX + 1], rank[PD_MAX + 1];
+        float bary[PD_MAX + 2];
+        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+        for (int r = 0; r < nax; r++) {
+            short key[PD_MAX];
+            lattice_key(pd, r, rem0, rank, key);
+            const unsigned long long k = pack64(key, pd);
+            unsigned h = key_hash(key, pd) & (LT_SLOTS - 1);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&lkey[h], PK_EMPTY, k);
+                if (prev == PK_EMPTY) ++mine;
+                if (prev == PK_EMPTY || prev == k) break;
+                h = (h + 1) & (LT_SLOTS - 1);
+            }
+        }
+    }
+    if (mine) atomicAdd(&distinct, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(Lt.stat + 4 * f + 2, distinct);
 }
 
 __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W,
@@ -506,7 +549,8 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     if (threadIdx.x == 0) {
         newkeys = 0;
         // the attempt already failed for this frame: nothing this workgroup inserts will be used
-        skip = small && __hip_atomic_load(Lt.stat + 2 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        skip = small && (__hip_atomic_load(Lt.stat + 4 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                         Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
     }
     __syncthreads();
     if (skip) return;
@@ -558,7 +602,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
             if (cur == PK_EMPTY || cur == k) break;
             if (++h == nb) h = 0;
             if (small && ++probes > PK_PROBE_LIMIT) {          // the small table is too full: the frame is redone
-                atomicExch(Lt.stat + 2 * f + 1, 1);
+                atomicExch(Lt.stat + 4 * f + 1, 1);
                 placed = false;
                 break;
             }
@@ -568,7 +612,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     }
     if (small && mine) atomicAdd(&newkeys, mine);
     __syncthreads();
-    if (small && threadIdx.x == 0 && newkeys) atomicAdd(Lt.stat + 2 * f, newkeys);
+    if (small && threadIdx.x == 0 && newkeys) atomicAdd(Lt.stat + 4 * f, newkeys);
     if (live) {
         const long base = (long)f * Lt.E + p;
         for (int r = 0; r < nax; r++) {
@@ -1041,7 +1085,7 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
     L.slot_vid2 = c.take<int>(2 * FE);
     L.slot_off = c.take<int>(2 * FE);
     L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
-    L.stat = c.take<int>((size_t)F * 2);
+    L.stat = c.take<int>((size_t)F * 4);
     L.cap_small = 0;
 }
 
@@ -1094,6 +1138,8 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     const long small = g_crf_variant == 2 ? 1021 : ((1L << 18) - 1);
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
+    if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
+        hipLaunchKernelGGL(pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), 0, st, L, rgb, W, posdev, featdev);
     hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
         hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
