@@ -389,6 +389,32 @@ int rcf_fill_f32(float *p, long n, float v, void *stream);
 int rcf_eval_iou_counts_f32(const float *masks, const uint8_t *ann, int B, int C, int h, int w, int H, int W, float pos_th,
                             unsigned long long *counts, void *stream);
 
+/* ---- data transform on the device ------------------------------------------------------
+ * dataset/transforms.py:884-924 `Transform` (Resize :170-237 -> RandomCrop :442-508 -> RandomFlip :249-306 ->
+ * PhotoMetricDistortion :557-687 -> FlowTransform :825-848 / PLTransform :865-876 -> NumpyToTensor :793-808 ->
+ * TorchNormalize :850-863) as one gather per output tensor.  The random decisions are drawn by the host in the
+ * reference's order and passed per sample: */
+typedef struct rcf_aug_params {
+    int32_t rw, rh;            /* size of the resized frame (mmcv.rescale_size of the drawn scale) */
+    int32_t crop_x, crop_y;    /* RandomCrop offset inside the resized frame (0,0 and out = resized size: no crop) */
+    int32_t flip;              /* horizontal flip of the crop */
+    int32_t ops;               /* bit 0 brightness, 1 contrast, 2 saturation, 3 hue, 4 contrast applied last (mode 0) */
+    float beta;                /* brightness offset */
+    float alpha_c, alpha_s;    /* contrast / saturation gains */
+    float flow_sx, flow_sy;    /* FlowTransform(scale_flow): factors on (u, v); 1 when off */
+    double hue_delta;          /* python float in the reference: the hue arithmetic is fp64 */
+} rcf_aug_params;
+/* frames u8 [B][I][H][W][3] (decoded RGB) -> out fp32 [I][B][3][oh][ow]: (u8/255 - mean)/std of the bilinearly resized
+ * (cv2 8-bit fixed point), cropped, flipped, distorted frame.  params: device array [B]; mean3/std3: host arrays. */
+int rcf_aug_frames_u8(const uint8_t *frames, int B, int I, int H, int W, const rcf_aug_params *params, float *out, int oh,
+                      int ow, const float *mean3, const float *std3, void *stream);
+/* seg fields (nearest resize, crop, flip -- the reference does not negate u under a flip): flows fp32 [B][K][H][W][2] ->
+ * [K][B][2][oh][ow];  pseudo-label masks u8 [B][K][H][W] -> fp32 [K][B][oh][ow] = u8/255 */
+int rcf_aug_flows_f32(const float *flows, int B, int K, int H, int W, const rcf_aug_params *params, float *out, int oh,
+                      int ow, void *stream);
+int rcf_aug_masks_u8(const uint8_t *masks, int B, int K, int H, int W, const rcf_aug_params *params, float *out, int oh,
+                     int ow, void *stream);
+
 /* ---- DINO ViT forward + soft NCut -----------------------------------------
  * models/dino_vit.py:110-167,176-276 (nn.Linear / attention products, LayerNorm eps 1e-6, softmax, GELU) and
  * tools/SemanticConstraintsAndMAA/semantic_constraints.py:21-75 (soft NCut value, Adam refinement of the mask). */

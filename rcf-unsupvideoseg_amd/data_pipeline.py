@@ -1,0 +1,159 @@
+"""The reference's data transform (dataset/transforms.py:884-924 `Transform`, selected by `get_transform` :926-929) over
+the HIP gather kernels of csrc/datapipe.hip.
+
+The reference transforms ONE sample at a time on a DataLoader worker (numpy / cv2) and collates afterwards; here the
+loader hands over the DECODED arrays of a whole batch -- frames u8 [B,I,H,W,3], flows fp32 [B,H,W,2] per direction,
+pseudo-label masks u8 [B,I,H,W] -- and one launch per output tensor produces the collated, normalised batch in HBM.
+JPEG / PNG decoding and `.npy` reading stay with the loader (dataset/data.py:62-70,122-128: file I/O, out of scope).
+
+`sample_params` consumes the random stream exactly as the reference's pipeline does (same generator, same calls, same
+order: Resize.random_sample_ratio :130, RandomCrop.get_crop_bbox :447-448, RandomFlip :281, PhotoMetricDistortion
+:599-679), so that under `np.random.seed(s)` a sample gets the decisions the reference would give it.
+
+No CPU path: the tensors must live on the GPU, and the extension must load.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+MEAN = (0.485, 0.456, 0.406)                              # dataset/transforms.py:893
+STD = (0.229, 0.224, 0.225)
+
+# mirrors `struct rcf_aug_params` of include/rcf_hip.h (C layout, natural alignment)
+PARAMS_DTYPE = np.dtype([("rw", "<i4"), ("rh", "<i4"), ("crop_x", "<i4"), ("crop_y", "<i4"), ("flip", "<i4"), ("ops", "<i4"),
+                         ("beta", "<f4"), ("alpha_c", "<f4"), ("alpha_s", "<f4"), ("flow_sx", "<f4"), ("flow_sy", "<f4"),
+                         ("hue_delta", "<f8")], align=True)
+OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION, OP_HUE, OP_CONTRAST_LAST = 1, 2, 4, 8, 16
+
+
+def rescale_size(w, h, scale):
+    """mmcv.imrescale's size rule for a (long edge, short edge) bound: factor = min(long/max(h,w), short/min(h,w)),
+    size = int(edge * factor + 0.5)"""
+    max_long, max_short = max(scale), min(scale)
+    f = min(max_long / max(h, w), max_short / min(h, w))
+    return int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+
+
+class Transform:
+    """Same constructor as the reference's (`training`, `strong_aug`, `has_flow`, `has_attn`, `has_pl`, `scale_flow`).
+    `has_attn` (AttnTransform, the AMD baseline's attention maps) is not on the RCF path and is refused."""
+
+    img_scale = (9999, 400)                               # :897, :911
+    crop_size = (384, 384)                                # :898
+    brightness_delta, contrast_range, saturation_range, hue_delta = 32, (0.5, 1.5), (0.5, 1.5), 18     # :580-584
+
+    def __init__(self, training, strong_aug=False, has_flow=True, has_attn=False, has_pl=False, scale_flow=False):
+        if has_attn:
+            raise NotImplementedError("has_attn belongs to the AMD baseline's loader, not to the RCF path")
+        self.training, self.strong_aug, self.has_flow, self.has_pl, self.scale_flow = training, strong_aug, has_flow, has_pl, scale_flow
+        self.ratio_range = (0.96, 1.0) if training else (0.98, 0.98)
+
+    # -- host: the random decisions, in the reference's order -------------------------------------------------------------
+    def sample_params(self, H, W, rng=np.random):
+        """one sample's decisions as a PARAMS_DTYPE record; `rng` is numpy's global generator (what the reference
+        draws from) or any RandomState"""
+        p = np.zeros((), dtype=PARAMS_DTYPE)
+        lo, hi = self.ratio_range
+        ratio = rng.random_sample() * (hi - lo) + lo                                          # :130
+        scale = int(self.img_scale[0] * ratio), int(self.img_scale[1] * ratio)                # :131
+        rw, rh = rescale_size(W, H, scale)
+        p["rw"], p["rh"] = rw, rh
+        p["flow_sx"], p["flow_sy"] = 1.0, 1.0
+        if self.training:
+            ch, cw = self.crop_size
+            if rh < ch or rw < cw:
+                raise ValueError(f"resized frame {rh}x{rw} is smaller than the crop {ch}x{cw}: the reference rescales such "
+                                 f"frames again (transforms.py:487-493); not supported on the device path")
+            p["crop_y"] = rng.randint(0, max(rh - ch, 0) + 1)                                 # :447
+            p["crop_x"] = rng.randint(0, max(rw - cw, 0) + 1)                                 # :448
+            if self.strong_aug:
+                p["flip"] = 1 if rng.rand() < 0.5 else 0                                      # :281
+                ops = 0
+                if rng.randint(2):                                                            # brightness :601
+                    ops |= OP_BRIGHTNESS
+                    p["beta"] = rng.uniform(-self.brightness_delta, self.brightness_delta)
+                mode = rng.randint(2)                                                         # :664
+
+                def contrast():
+                    nonlocal ops
+                    if rng.randint(2):                                                        # :610
+                        ops |= OP_CONTRAST
+                        p["alpha_c"] = rng.uniform(*self.contrast_range)
+                if mode == 1:
+                    contrast()
+                if rng.randint(2):                                                            # saturation :626
+                    ops |= OP_SATURATION
+                    p["alpha_s"] = rng.uniform(*self.saturation_range)
+                if rng.randint(2):                                                            # hue :643
+                    ops |= OP_HUE
+                    p["hue_delta"] = rng.uniform(-self.hue_delta, self.hue_delta)
+                if mode == 0:
+                    ops |= OP_CONTRAST_LAST
+                    contrast()
+                p["ops"] = ops
+            if self.has_flow and self.scale_flow:                                             # :838-843, :208-209
+                p["flow_sx"], p["flow_sy"] = np.float32(rw / W), np.float32(rh / H)
+        return p
+
+    def output_size(self, params):
+        if self.training:
+            return self.crop_size
+        sizes = {(int(p["rh"]), int(p["rw"])) for p in params}
+        assert len(sizes) == 1, "evaluation batches hold frames of one size"
+        return sizes.pop()
+
+    # -- device ---------------------------------------------------------------------------------------------------------
+    def __call__(self, data, params=None, rng=np.random):
+        """data: {'imgs': u8 [B,I,H,W,3], 'gt_fw_flows' / 'gt_bw_flows': fp32 [B,H,W,2] (has_flow, training),
+        'pl_masks': u8 [B,I,H,W] (has_pl, training), 'ann': passed through} as CUDA tensors -> the collated batch the
+        reference's loader yields: 'imgs' = I tensors [B,3,h,w], 'gt_fw_flows' / 'gt_bw_flows' = [tensor [B,2,h,w]],
+        'pl_masks' = I tensors [B,h,w]; other keys are kept."""
+        frames = data["imgs"]
+        if not frames.is_cuda:
+            raise _lib.RcfHipError("rcf_amd.data_pipeline needs CUDA (HIP) tensors: there is no CPU fallback")
+        assert frames.dtype == torch.uint8 and frames.dim() == 5 and frames.shape[-1] == 3, "frames: u8 [B,I,H,W,3]"
+        frames = frames.contiguous()
+        B, I, H, W, _ = frames.shape
+        if params is None:
+            params = np.stack([self.sample_params(H, W, rng) for _ in range(B)])
+        params = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
+        assert params.shape == (B,)
+        oh, ow = self.output_size(params)
+        dev = frames.device
+        prm = torch.from_numpy(params.view(np.uint8).reshape(B, -1)).to(dev, non_blocking=True)
+        mean = np.asarray(MEAN, dtype=np.float32)
+        std = np.asarray(STD, dtype=np.float32)
+        out = dict(data)
+        imgs = torch.empty((I, B, 3, oh, ow), dtype=torch.float32, device=dev)
+        _lib.call("rcf_aug_frames_u8", _p(frames), B, I, H, W, _p(prm), _p(imgs), oh, ow, mean.ctypes.data, std.ctypes.data,
+                  _stream())
+        out["imgs"] = list(imgs.unbind(0))
+        if self.training and self.has_flow:
+            fl = torch.stack([data["gt_fw_flows"], data["gt_bw_flows"]], dim=1).contiguous()      # [B,2,H,W,2]
+            assert fl.dtype == torch.float32 and fl.shape == (B, 2, H, W, 2), "flows: fp32 [B,H,W,2] per direction"
+            fo = torch.empty((2, B, 2, oh, ow), dtype=torch.float32, device=dev)
+            _lib.call("rcf_aug_flows_f32", _p(fl), B, 2, H, W, _p(prm), _p(fo), oh, ow, _stream())
+            out["gt_fw_flows"], out["gt_bw_flows"] = [fo[0]], [fo[1]]
+        if self.training and self.has_pl:
+            pl = data["pl_masks"].contiguous()
+            assert pl.dtype == torch.uint8 and pl.shape == (B, I, H, W), "pl_masks: u8 [B,I,H,W]"
+            po = torch.empty((I, B, oh, ow), dtype=torch.float32, device=dev)
+            _lib.call("rcf_aug_masks_u8", _p(pl), B, I, H, W, _p(prm), _p(po), oh, ow, _stream())
+            out["pl_masks"] = list(po.unbind(0))
+        out["aug_params"] = params
+        return out
+
+    def __repr__(self):
+        return (f"Transform(training={self.training}, strong_aug={self.strong_aug}, has_flow={self.has_flow}, "
+                f"has_pl={self.has_pl}, scale_flow={self.scale_flow})")
+
+
+def get_transform(args, training):
+    """dataset/transforms.py:926-929"""
+    kw = args.train_transform_kwargs if training else args.test_transform_kwargs
+    cls = getattr(args, "transform_cls", "Transform")
+    if cls != "Transform":
+        raise NotImplementedError(cls)
+    return Transform(training=training, **kw)

@@ -122,6 +122,19 @@ def make_pl_masks(B, H, W, config_id=1, first_index=0):
             for f in range(2)]
 
 
+def loader_sample(seed, H=480, W=854):
+    """What dataset/data.py:73-151 hands to the transform for one training sample, decoded: frames u8 [2,H,W,3] (smooth
+    content; the right quarter is uniform noise so that every hue sector / saturation extreme occurs), forward / backward
+    flow fp32 [H,W,2] (the `.npy` layout, :122-128) and pseudo-label masks u8 [2,H,W] (:137-150)."""
+    frames = np.stack([smooth_rgb(H, W, seed + 31 * i) for i in range(2)])
+    for i in range(2):
+        frames[i, :, W - W // 4:] = noise_rgb(H, W // 4, seed + 77 + i)
+    fw, _ = voronoi_affine_flow(H, W, seed + 500000)
+    bw, _ = voronoi_affine_flow(H, W, seed + 600000)
+    pl = np.stack([np.round(soft_blob_mask(H, W, seed + 7000 * (i + 1)) * 255.0).astype(np.uint8) for i in range(2)])
+    return dict(frames=frames, fw=np.ascontiguousarray(fw.transpose(1, 2, 0)), bw=np.ascontiguousarray(bw.transpose(1, 2, 0)), pl=pl)
+
+
 def eval_inputs(seed, N=6, C=4, h=30, w=54, H=120, W=214):
     """Inputs of the evaluation-metric fixtures (tests/golden/make_golden_eval.py): smooth soft masks [N,C,h,w] (softmax
     of low-frequency logits), annotations [N,H,W] u8 in {0, 128 (ignore), 255}, sequence names (two frames each)."""
