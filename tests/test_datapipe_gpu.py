@@ -122,5 +122,6 @@ def test_output_feeds_the_model_batch_layout_and_refuses_host_tensors():
     assert out["imgs"][0].is_contiguous() and out["gt_bw_flows"][0].is_contiguous()
     with pytest.raises(_lib.RcfHipError):
         tf({"imgs": torch.zeros((1, 2, 400, 520, 3), dtype=torch.uint8)})
+    tf.crop_size = (500, 500)                                  # cannot happen with the reference's 400 / 384 constants
     with pytest.raises(ValueError):                            # the reference rescales too-small frames again; refused here
         tf.sample_params(300, 520, np.random.RandomState(0))
