@@ -6,8 +6,9 @@ helpers of utils/warp_utils.py and a `torchcrf_cpp`-shaped `crf_soft` / `crf_har
 """
 __version__ = "0.1.0"
 
-from . import _lib, ncut, offline, ops, synth, vit  # noqa: F401
+from . import _lib, data_pipeline, evaluate, ncut, offline, ops, synth, vit  # noqa: F401
 from .backbone import FCNHead, ResNet  # noqa: F401
+from .evaluate import Evaluator  # noqa: F401
 from .crf import CRFHead, crf_hard, crf_soft  # noqa: F401
 from .flow_head import CompactnessHead, FlowAggregationHeadWithResidual  # noqa: F401
 from .model import RCFModel  # noqa: F401
