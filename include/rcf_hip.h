@@ -268,6 +268,9 @@ int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int 
  * utils/warp_utils.py:84-94 (flow_warp; pad 0 = 'border', 1 = 'zeros'), :107-113 + :27-81
  * (get_occu_mask_backward), :97-104 (get_occu_mask_bidirection), models/amd/flow_loss.py:15-29 with
  * models/amd/loss_blocks.py:46-65 (L1 + SSIM photometric loss).  Planar NCHW fp32 as the reference. */
+/* 1 (default): RGB / border-mode calls take the tile kernels (lane = x, dword taps; bit-identical results);
+ * 0: the per-pixel kernels every other call takes */
+int rcf_warp_set_variant(int variant);
 int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W, int pad_mode,
                       void *stream);
 /* grads of flow_warp w.r.t. x (atomic scatter; dx must be zero-filled or hold a running sum) and flow */

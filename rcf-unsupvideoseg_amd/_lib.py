@@ -151,6 +151,7 @@ PROTOS = {
     "rcf_conv2d_wgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv_bf16_set_tile": (c_int, [c_int]),
     "rcf_eval_iou_counts_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
+    "rcf_warp_set_variant": (c_int, [c_int]),
     "rcf_aug_frames_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     "rcf_aug_flows_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
     "rcf_aug_masks_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),

@@ -296,6 +296,150 @@ __global__ void __launch_bounds__(256) warp_l1_kernel(const float *__restrict__ 
     block_add2(s, so, out);
 }
 
+// ---- RGB / border fast path ---------------------------------------------------------------------------------------------
+// PMC on the per-pixel kernels above (profiles/r02_pmc_warp.txt): HBM delivers 1.03x the algorithmic bytes, yet the waves
+// spend 41 % of their cycles in issue stalls with the vector ALU 51 % busy (182 VALU instructions per pixel: an integer
+// division for (y, x), two IEEE divisions in the normalise round trip, selects for taps outside the image) and every
+// CU's vector cache handles 0.67 accesses per clock: a 4-byte-aligned 8-byte pair load costs 35-40 cache accesses per
+// wave instruction, a dword load of (nearly) consecutive lane addresses 4.  The fast path keeps every float operation of
+// the sample position and of the blend -- results are bit-identical (tools/bench_warp.py, tests/test_kernels_gpu.py) -- and
+//   * maps lanes to x inside 64x16 tiles (no per-pixel division), four independent pixels (rows) per thread;
+//   * loads every tap as its own dword;
+//   * computes x / (W-1) as  q = x*r;  q += fma(-q, d, x) * r  with r = RN(1/d) from the host -- correctly rounded
+//     (Markstein: q is within 1 ulp and the residual is exact), 3 operations instead of the IEEE sequence's 10;
+//   * uses that border mode clamps the position into [0, W-1] x [0, H-1]: the only tap outside is x0+1 = W (y0+1 = H) at
+//     weight exactly 0, and folding it to (x0 = W-2, wx = 1) gives the same value with no masks and no selects;
+//   * sends x and y through the position arithmetic as one float2 (v_pk_mul / v_pk_add / v_pk_fma).
+// Measured on 64 frames of 480x854 (fused warp + L1): 262 -> 210 us, 3.6 -> 4.5 TB/s of algorithmic bytes.  Tried and
+// slower: four consecutive pixels per thread with 16-byte stream loads (249 us; the strided pair gathers cost more cache
+// accesses), staging the tile's source window in LDS (56 KB, two workgroups per CU, two barriers per tile: 421 us),
+// non-temporal loads / stores on the streamed operands (+2 %), 2 or 8 rows per thread (223 / 211 us).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct WarpGeom {
+    float dx, dy, rx, ry;       // W-1, H-1 and their correctly rounded reciprocals
+};
+
+struct Tap4 {
+    int off;                    // offset of the (y0, x0) pair inside a plane; the (y0+1) pair is W further
+    v2f w0, w1;                 // weights of (row y0: x0, x0+1), (row y0+1: x0, x0+1)
+};
+
+__device__ __forceinline__ Tap4 border_tap(int x, int y, float fx, float fy, const WarpGeom &g, int W, int H) {
+    const v2f d = {g.dx, g.dy}, r = {g.rx, g.ry};
+    const v2f p = {(float)x + fx, (float)y + fy};
+    // norm_grid: 2*p/(size-1) - 1;  grid_sampler_unnormalize(align_corners=True): ((g+1)/2)*(size-1)
+    const v2f t = 2.0f * p;
+    v2f q = t * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, d, t), r, q);        // == t / d, correctly rounded
+    const v2f gn = q - 1.0f;
+    v2f i = ((gn + 1.f) * 0.5f) * d;
+    // clip_coordinates: below 0 (or NaN) -> 0, above size-1 -> size-1
+    i.x = fminf(fmaxf(i.x, 0.f), g.dx);
+    i.y = fminf(fmaxf(i.y, 0.f), g.dy);
+    v2f f = {floorf(i.x), floorf(i.y)};
+    v2f w = i - f;
+    int x0 = (int)f.x, y0 = (int)f.y;
+    if (x0 > W - 2) { x0 = W - 2; w.x = 1.f; }                 // tap x0+1 = W carried weight 0: same value from (W-2, 1)
+    if (y0 > H - 2) { y0 = H - 2; w.y = 1.f; }
+    const v2f e = 1.f - w;
+    Tap4 tp;
+    tp.off = y0 * W + x0;
+    const v2f ew = {e.x, w.x};
+    tp.w0 = e.y * ew;
+    tp.w1 = w.y * ew;
+    return tp;
+}
+
+__device__ __forceinline__ float blend(v2f a, v2f b, const Tap4 &tp) {
+    const v2f ta = a * tp.w0, tb = b * tp.w1;
+    return (ta.x + ta.y) + (tb.x + tb.y);
+}
+
+// XCD k (workgroup ids k mod 8) walks the k-th eighth of the row-major tile list of every image, so the source rows that
+// neighbouring tiles share stay in one L2.  lane = x, wavefront wv takes rows wv, wv+4, ... of the tile.
+constexpr int TILE_W = 64;
+template <bool L1, int PX>
+__global__ void __launch_bounds__(256) warp_rows_kernel(const float *__restrict__ im1, const float *__restrict__ im2,
+                                                        const float *__restrict__ flow, const float *__restrict__ occ,
+                                                        void *__restrict__ out_, int B, int H, int W, WarpGeom gm,
+                                                        int tiles_x, int tiles_y) {
+    const int HW = H * W;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, Q = gridDim.x >> 3;
+    const int ntiles = tiles_x * tiles_y;
+    const int t0 = (int)((long)ntiles * xcd / 8), t1 = (int)((long)ntiles * (xcd + 1) / 8);
+    const int per = t1 - t0, R = B * per;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double s = 0, so = 0;
+    for (int r = j; r < R; r += Q) {
+        const int b = r / per, t = t0 + (r - b * per);
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const float *fl = flow + (long)b * 2 * HW, *src = im2 + (long)b * 3 * HW;
+        const int x = tx * TILE_W + lane;
+        const int xc = min(x, W - 1);
+        Tap4 tp[PX];
+        int g[PX];
+        bool ok[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const int y = ty * (4 * PX) + wv + 4 * k;
+            ok[k] = x < W && y < H;
+            const int yc = min(y, H - 1);
+            g[k] = yc * W + xc;
+            tp[k] = border_tap(xc, yc, fl[g[k]], fl[HW + g[k]], gm, W, H);
+        }
+        float v[3][PX];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *pl = src + c * HW;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const float *q = pl + tp[k].off;
+                v[c][k] = blend(v2f{q[0], q[1]}, v2f{q[W], q[W + 1]}, tp[k]);
+            }
+        }
+        if (L1) {
+            const float *tgt = im1 + (long)b * 3 * HW;
+            const float *oc = occ ? occ + (long)b * HW : nullptr;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc += fabsf(tgt[c * HW + g[k]] - v[c][k]);
+                const float o = oc ? oc[g[k]] : 1.f;
+                if (ok[k]) {
+                    s += (double)(acc * o);
+                    so += (double)o;
+                }
+            }
+        } else {
+            float *ob = (float *)out_ + (long)b * 3 * HW;
+#pragma unroll
+            for (int k = 0; k < PX; ++k)
+                if (ok[k])
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ob[c * HW + g[k]] = v[c][k];
+        }
+    }
+    if (L1) block_add2(s, so, (double *)out_);
+}
+
+int g_warp_variant = 1;       // 1: tile kernels for RGB / border calls; 0: per-pixel kernels everywhere
+
+inline bool warp_tile_applies(int C, int H, int W, int pad_mode) {
+    return g_warp_variant == 1 && C == 3 && pad_mode == 0 && W >= 2 && H >= 2;
+}
+
+inline WarpGeom warp_geom(int H, int W) {
+    WarpGeom g;
+    g.dx = (float)(W - 1);
+    g.dy = (float)(H - 1);
+    g.rx = 1.0f / g.dx;
+    g.ry = 1.0f / g.dy;
+    return g;
+}
+
 // sums[0] = sum |im-recon|*occ, sums[1] = sum occ, sums[2] = sum SSIM distance, sums[3] unused
 __global__ void __launch_bounds__(256) photometric_kernel(const float *__restrict__ im, const float *__restrict__ rec,
                                                           const float *__restrict__ occ, double *__restrict__ sums,
@@ -346,10 +490,26 @@ __global__ void photometric_final_kernel(const double *__restrict__ sums, float 
 
 }  // namespace
 
+extern "C" int rcf_warp_set_variant(int v) {
+    if (v != 0 && v != 1) return RCF_EINVAL;
+    g_warp_variant = v;
+    return 0;
+}
+
 extern "C" int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W,
                                  int pad_mode, void *stream) {
     if (!x || !flow || !out || B <= 0 || C <= 0 || H < 2 || W < 2 || (pad_mode != 0 && pad_mode != 1)) return RCF_EINVAL;
     if ((long)H * W >= (1L << 30)) return RCF_EINVAL;
+    if (warp_tile_applies(C, H, W, pad_mode) && W >= 256) {     // narrow images: the flat 512-pixel runs fill the lanes better
+        const int tx = rcf_cdiv(W, TILE_W), ty = rcf_cdiv(H, 16);
+        const long R = (long)B * rcf_cdiv((long)tx * ty, 8);
+        const int Q = (int)(R < 1024 ? R : 1024);               // up to 8192 workgroups, each walking its share of the tiles
+        hipLaunchKernelGGL((warp_rows_kernel<false, 4>), dim3((unsigned)(8 * Q)), dim3(256), 0, rcf_stream(stream),
+                           (const float *)nullptr, x, flow, (const float *)nullptr, (void *)out, B, H, W, warp_geom(H, W), tx,
+                           ty);
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     const int runs = rcf_cdiv((long)((H + 7) / 8) * W, 512);          // 512-pixel runs per band
     if ((long)8 * B * runs >= (1L << 31)) return RCF_EINVAL;
     hipLaunchKernelGGL(flow_warp_kernel, dim3((unsigned)(8 * B * runs)), dim3(256), 0, rcf_stream(stream), x, flow, out, B,
@@ -396,6 +556,16 @@ extern "C" int rcf_warp_l1_residual_f32(const float *im1, const float *im2, cons
     hipStream_t st = rcf_stream(stream);
     hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
+    if (warp_tile_applies(C, H, W, pad_mode)) {
+        const int tx = rcf_cdiv(W, TILE_W), ty = rcf_cdiv(H, 16);
+        const long R = (long)B * rcf_cdiv((long)tx * ty, 8);
+        // 2048 workgroups at most, and at least four tiles each: every workgroup ends in two fp64 atomics on one address
+        const int Q = (int)(R < 4 ? 1 : (R / 4 < 256 ? R / 4 : 256));
+        hipLaunchKernelGGL((warp_rows_kernel<true, 4>), dim3((unsigned)(8 * Q)), dim3(256), 0, st, im1, im2, flow, occ,
+                           (void *)out, B, H, W, warp_geom(H, W), tx, ty);
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     // 8 bands x 256 workgroups (2048 in total: each ends in two fp64 atomics), fewer when there is less work
     const int runs = rcf_cdiv((long)((H + 7) / 8) * W, 512);          // 512-pixel runs per band
     const long R = (long)B * runs;

@@ -490,6 +490,37 @@ def test_warp_odd_shapes_vs_oracle(H, W, report):
         assert e < 2e-5 and e1 < 1e-5 and float(l1[1]) == float(occ.sum())
 
 
+@pytest.mark.parametrize("H,W", [(33, 300), (16, 256), (50, 857), (7, 9)])
+def test_warp_tile_kernels_are_bit_identical_to_the_per_pixel_kernels(H, W, report):
+    """the RGB / border tile kernels (exact 3-operation division, folded border taps, packed position arithmetic) against
+    the per-pixel kernels: same bits, including positions far outside the image, NaN flows and exact-integer positions"""
+    from rcf_amd import _lib
+    g = torch.Generator().manual_seed(H * 7 + W)
+    B = 3
+    x, y = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    fl = torch.randn(B, 2, H, W, generator=g) * 6.0
+    fl[0, :, :3, :5] = 1e9
+    fl[1, :, -3:, -5:] = -1e9
+    fl[2, 0, 2, 2] = float("nan")
+    fl[2, :, 4:6] = fl[2, :, 4:6].round()                          # integer positions: weights exactly 0 / 1
+    fl[2, 0, :, -1] = 0.0                                          # x = W-1 exactly: the folded tap
+    fl[2, 1, -1, :] = 0.0
+    fl = fl.to(DEV)
+    occ = (torch.rand(B, 1, H, W, generator=g) > 0.3).float().to(DEV)
+    res = {}
+    try:
+        for v in (0, 1):
+            _lib.call("rcf_warp_set_variant", v)
+            res[v] = (ops.flow_warp(x, fl, "border").cpu(), ops.warp_l1_residual(y, x, fl, occ, "border").cpu(),
+                      ops.warp_l1_residual(y, x, fl, None, "border").cpu())
+    finally:
+        _lib.call("rcf_warp_set_variant", 1)
+    same_w = torch.equal(res[0][0], res[1][0])
+    rel = [abs(float(res[0][k][0]) - float(res[1][k][0])) / abs(float(res[0][k][0])) for k in (1, 2)]
+    report(f"warp tile vs per-pixel {H}x{W}: warped identical {same_w}, fused L1 rel diff {rel[0]:.1e} / {rel[1]:.1e} (fp64 sums, order differs)")
+    assert same_w and max(rel) < 1e-12 and float(res[0][1][1]) == float(res[1][1][1])
+
+
 def test_warp_backward(report):
     g = torch.Generator().manual_seed(21)
     B, C, H, W = 2, 3, 17, 23

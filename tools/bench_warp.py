@@ -1,36 +1,49 @@
-"""HBM roofline of the warp family at 480x854: algorithmic bytes 4*(2+2C) per pixel (flow + source + output)."""
-import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python3
+"""A/B of the warp kernels (bench.py's warp leg shapes): per-pixel kernels (variant 0) against the RGB / border tile kernels
+(variant 1); checks that both give the same bits."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
 import rcf_amd
-from rcf_amd import ops
+from rcf_amd import _lib, ops, synth
 
-def timeit(fn, iters=20):
+
+def timeit(fn, n=5 if "big" in sys.argv else 20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): fn()
+    for _ in range(n):
+        fn()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / n * 1e-3
 
-B, C, H, W = 64, 3, 480, 854
-x = torch.rand(B, C, H, W, device="cuda:0"); y = torch.rand(B, C, H, W, device="cuda:0")
-# representative flow: the piecewise-affine synthetic field of SURVEY.md §8(d) (per-pixel N(0,0.5) jitter), tiled
-import numpy as np
-from rcf_amd import synth
-base = np.stack([synth.voronoi_affine_flow(H, W, 7000 + i)[0] for i in range(8)])
-fl = torch.from_numpy(np.tile(base, (B // 8, 1, 1, 1))).to("cuda:0")
-if len(sys.argv) > 1 and sys.argv[1] == "random":
-    fl = torch.randn(B, 2, H, W, device="cuda:0") * 4     # adversarial: every lane samples its own cache line
-occ = torch.ones(B, 1, H, W, device="cuda:0")
-px = B * H * W
-t = timeit(lambda: ops.flow_warp(x, fl, "border"))
-print(f"flow_warp        B={B}: {t*1e3:.3f} ms  {px*4*(2+2*C)/t/1e12:.2f} TB/s algorithmic ({t/B*1e6:.1f} us/frame)")
-t = timeit(lambda: ops.warp_l1_residual(y, x, fl, occ, "border"))
-print(f"warp+L1 fused    B={B}: {t*1e3:.3f} ms  {px*4*(2+2*C+1)/t/1e12:.2f} TB/s algorithmic ({t/B*1e6:.1f} us/frame)")
-t = timeit(lambda: ops.occu_mask_bidirection(fl, -fl))
-print(f"occ bidirection  B={B}: {t*1e3:.3f} ms  {px*4*(4+1)/t/1e12:.2f} TB/s algorithmic")
-t = timeit(lambda: ops.occu_mask_backward(fl))
-print(f"occ backward     B={B}: {t*1e3:.3f} ms  {px*4*(2+1)/t/1e12:.2f} TB/s algorithmic (4 float atomics / px)")
-wb = ops.flow_warp(x, fl)
-t = timeit(lambda: ops.photometric_loss(y, wb, occ))
-print(f"photometric      B={B}: {t*1e3:.3f} ms  {px*4*(2*C+1)/t/1e12:.2f} TB/s algorithmic")
+
+def main():
+    dev = "cuda:0"
+    shapes = [(480, 854, 64)] if "big" in sys.argv else [(480, 854, 64), (96, 160, 64), (384, 384, 16)]
+    for (H, W, nframes) in shapes:
+        base = np.stack([synth.voronoi_affine_flow(H, W, 7000 + i)[0] for i in range(8)])
+        fl = torch.from_numpy(np.tile(base, (nframes // 8, 1, 1, 1))).to(dev)
+        fl[0, :, :4, :4] = 1e9; fl[1, :, :4, :4] = -1e9; fl[2, 0, 5, 5] = float("nan")
+        x = torch.rand(nframes, 3, H, W, device=dev); y = torch.rand(nframes, 3, H, W, device=dev)
+        occ = (torch.rand(nframes, 1, H, W, device=dev) > 0.2).float()
+        px = nframes * H * W
+        res = {}
+        for v in (0, 1):
+            _lib.call("rcf_warp_set_variant", v)
+            w = ops.flow_warp(x, fl, "border")
+            l1 = ops.warp_l1_residual(y, x, fl, occ, "border")
+            t_l1 = timeit(lambda: ops.warp_l1_residual(y, x, fl, occ, "border"))
+            t_w = timeit(lambda: ops.flow_warp(x, fl, "border"))
+            res[v] = (w, l1)
+            print(f"{H}x{W}x{nframes} variant {v:#x}: warp_l1 {t_l1*1e6:8.1f} us  {px*36/t_l1/1e9:7.1f} GB/s ({px*36/t_l1/8e12:.3f})   "
+                  f"flow_warp {t_w*1e6:8.1f} us {px*32/t_w/1e9:7.1f} GB/s ({px*32/t_w/8e12:.3f})", flush=True)
+        for v in (1,):
+            print(f"   variant {v} vs 0: warped identical {torch.equal(res[0][0], res[v][0])}; l1 sums",
+                  [float(a) for a in res[0][1]], [float(a) for a in res[v][1]])
+    _lib.call("rcf_warp_set_variant", 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,19 +1,30 @@
 #!/bin/bash
-# HBM-side fetch/write bytes of the warp kernels (tools/bench_warp.py): separate FETCH_SIZE / WRITE_SIZE passes
+# usage: tools/pmc_warp.sh   -> counter passes over tools/bench_warp.py (big shape only), per-kernel averages
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_$c -- python3 $R/tools/bench_warp.py > $R/gpurun_out/pmcw_$c.log 2>&1
+rocprofv3 -L > $R/gpurun_out/counters_list.txt 2>&1
+i=0
+for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM" \
+            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+            "TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+            "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_warp_$i -- python3 $R/tools/bench_warp.py big > $R/gpurun_out/pmc_warp_$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob("$R/gpurun_out/pmcw_%s/**/*counter_collection.csv" % c, recursive=True):
+for i in range(1, 7):
+    fs = glob.glob("$R/gpurun_out/pmc_warp_%d/**/*counter_collection.csv" % i, recursive=True)
+    if not fs:
+        print("pass", i, "no output:", open("$R/gpurun_out/pmc_warp_%d.log" % i).read()[-300:])
+    for f in fs:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == c:
-                agg[r["Kernel_Name"]][c] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]][c] += 1
-for k, d in agg.items():
-    f = d.get("FETCH_SIZE", 0) / max(cnt[k]["FETCH_SIZE"], 1); w = d.get("WRITE_SIZE", 0) / max(cnt[k]["WRITE_SIZE"], 1)
-    print(f"{k[:70]:70s} launches {max(cnt[k].values()):4d} FETCH_SIZE {f:12.1f} KiB WRITE_SIZE {w:12.1f} KiB -> (2F+W) {(2*f+w)*1024/1e6:9.1f} MB, (F+W) {(f+w)*1024/1e6:9.1f} MB")
+            k = r["Kernel_Name"][:48]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        for k, d in agg.items():
+            if "warp" in k:
+                print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
 PY
