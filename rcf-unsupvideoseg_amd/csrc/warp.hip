@@ -299,12 +299,12 @@ __global__ void __launch_bounds__(256) warp_l1_kernel(const float *__restrict__ 
 // ---- RGB / border fast path ---------------------------------------------------------------------------------------------
 // PMC on the per-pixel kernels above (profiles/r02_pmc_warp.txt): HBM delivers 1.03x the algorithmic bytes, yet the waves
 // spend 41 % of their cycles in issue stalls with the vector ALU 51 % busy (182 VALU instructions per pixel: an integer
-// division for (y, x), two IEEE divisions in the normalise round trip, selects for taps outside the image) and every
-// CU's vector cache handles 0.67 accesses per clock: a 4-byte-aligned 8-byte pair load costs 35-40 cache accesses per
-// wave instruction, a dword load of (nearly) consecutive lane addresses 4.  The fast path keeps every float operation of
-// the sample position and of the blend -- results are bit-identical (tools/bench_warp.py, tests/test_kernels_gpu.py) -- and
+// division for (y, x), two IEEE divisions in the normalise round trip, selects for taps outside the image) and the
+// texture addresser is the busiest unit (a 64-lane load costs ~20 of its cycles whether the lanes ask for 4 or for
+// 4-byte-aligned 8 bytes).  The fast path keeps every float operation of the sample position and of the blend --
+// results are bit-identical (tools/bench_warp.py, tests/test_kernels_gpu.py) -- and
 //   * maps lanes to x inside 64x16 tiles (no per-pixel division), four independent pixels (rows) per thread;
-//   * loads every tap as its own dword;
+//   * loads every tap as its own dword (lane addresses nearly consecutive: the 2-D tiles cut L2 requests by 20 %);
 //   * computes x / (W-1) as  q = x*r;  q += fma(-q, d, x) * r  with r = RN(1/d) from the host -- correctly rounded
 //     (Markstein: q is within 1 ulp and the residual is exact), 3 operations instead of the IEEE sequence's 10;
 //   * uses that border mode clamps the position into [0, W-1] x [0, H-1]: the only tap outside is x0+1 = W (y0+1 = H) at
@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(256) warp_l1_kernel(const float *__restrict__ 
 // Measured on 64 frames of 480x854 (fused warp + L1): 262 -> 210 us, 3.6 -> 4.5 TB/s of algorithmic bytes.  Tried and
 // slower: four consecutive pixels per thread with 16-byte stream loads (249 us; the strided pair gathers cost more cache
 // accesses), staging the tile's source window in LDS (56 KB, two workgroups per CU, two barriers per tile: 421 us),
-// non-temporal loads / stores on the streamed operands (+2 %), 2 or 8 rows per thread (223 / 211 us).
+// non-temporal loads / stores on the streamed operands (+2 %), 2 or 8 rows per thread (223 / 211 us).  What bounds it
+// now: the texture addresser, 88 % busy (18 dword loads per pixel = 72 requested bytes per 36 algorithmic ones).
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
