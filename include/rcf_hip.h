@@ -87,6 +87,23 @@ int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias,
 size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* What a training-mode batch norm derives from its statistics (the per-channel constants of the normalisation, the
+ * running statistics with momentum, torch's num_batches_tracked): handed to a statistics-producing entry point, the
+ * final reduction kernel writes these too and no separate finalize launch is needed.  All pointers are device memory;
+ * running_mean / running_var / num_batches_tracked may be NULL. */
+typedef struct rcf_bn_finalize {
+    double count;                 /* rows the statistics cover (N*H*W) */
+    float eps, momentum;
+    float *mean, *invstd;         /* out [C] */
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;
+} rcf_bn_finalize;
+/* rcf_conv2d_fwd_stats_f32 / the statistics form of rcf_conv2d_fwd_bf16 with the batch norm finalized by the same
+ * reduction launch (fin != NULL; sums may then be NULL).  fin == NULL: as the plain entry points. */
+int rcf_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
+                               const rcf_bn_finalize *fin, void *workspace, size_t workspace_bytes, void *stream);
+int rcf_conv2d_fwd_bnstats_bf16(const void *x, const void *w_bf16, void *y, int ydt, const rcf_conv_shape *s, double *sums,
+                                const rcf_bn_finalize *fin, void *workspace, size_t workspace_bytes, void *stream);
 /* out[i] = sum_k partial[k][i], k < chunks, i < n, in a fixed order; scratch (64 * n doubles, may be NULL) lets a
  * long list of partial rows be summed in two levels */
 int rcf_sum_partials_f64(const double *partial, int chunks, int n, double *out, double *scratch, void *stream);

@@ -21,6 +21,13 @@ class ConvShape(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ("amax_x", "amax_w", "amax_dy", "w_pairs")]
 
 
+class BnFinalize(ctypes.Structure):
+    """struct rcf_bn_finalize of include/rcf_hip.h"""
+    _fields_ = [("count", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("running_mean", ctypes.c_void_p),
+                ("running_var", ctypes.c_void_p), ("num_batches_tracked", ctypes.c_void_p)]
+
+
 class ConvRegion(ctypes.Structure):
     """mirror of rcf_conv_region"""
     _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w", "band")]
@@ -40,6 +47,7 @@ P = c_void_p
 _CS = ctypes.POINTER(ConvShape)
 _FH = ctypes.POINTER(FlowHeadCfg)
 _CR = ctypes.POINTER(ConvRegion)
+_BF = ctypes.POINTER(BnFinalize)
 
 # name -> (restype, argtypes); every int-returning entry point is status-checked by `call`
 PROTOS = {
@@ -70,6 +78,8 @@ PROTOS = {
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
+    "rcf_conv2d_fwd_bnstats_f32": (c_int, [P, P, P, _CS, P, _BF, P, c_size_t, P]),
+    "rcf_conv2d_fwd_bnstats_bf16": (c_int, [P, P, P, c_int, _CS, P, _BF, P, c_size_t, P]),
     "rcf_sum_partials_f64": (c_int, [P, c_int, c_int, P, P, P]),
     "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
     "rcf_conv_set_variant": (c_int, [c_int]),

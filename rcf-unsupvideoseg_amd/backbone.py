@@ -31,7 +31,7 @@ class Downsample(nn.Module):
         self.add_module("1", norm)
 
     def fwd(self, x, tape, dist):
-        return getattr(self, "1").fwd(getattr(self, "0").fwd(x, tape, stats=getattr(self, "1").training), tape, relu=False,
+        return getattr(self, "1").fwd(getattr(self, "0").fwd(x, tape, stats=getattr(self, "1").stats_request(dist)), tape, relu=False,
                                     dist=dist)
 
 
@@ -49,9 +49,9 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def fwd(self, x, tape, dist):
-        o = self.bn1.fwd(self.conv1.fwd(x, tape, stats=self.bn1.training), tape, relu=True, dist=dist)
-        o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.training), tape, relu=True, dist=dist)
-        o = self.conv3.fwd(o, tape, stats=self.bn3.training)
+        o = self.bn1.fwd(self.conv1.fwd(x, tape, stats=self.bn1.stats_request(dist)), tape, relu=True, dist=dist)
+        o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist)
+        o = self.conv3.fwd(o, tape, stats=self.bn3.stats_request(dist))
         idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
         return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist)   # relu(bn3 + identity)
 
@@ -116,7 +116,7 @@ class ResNet(nn.Module):
     def fwd(self, img, tape, dist=None):
         """img: Act of the NHWC image zero-padded to 4 channels; returns the list of stage outputs."""
         tape.mark("stem")
-        x = self.bn1.fwd(self.conv1.fwd(img, tape, stats=self.bn1.training), tape, relu=True, dist=dist)
+        x = self.bn1.fwd(self.conv1.fwd(img, tape, stats=self.bn1.stats_request(dist)), tape, relu=True, dist=dist)
         x = maxpool3x3s2(x, tape)
         outs = []
         for i in range(self.num_stages):
@@ -145,7 +145,7 @@ class ConvModule(nn.Module):
         self.bn = make_norm(norm_cfg, cout)
 
     def fwd(self, x, tape, dist, chan_scale=None):
-        return self.bn.fwd(self.conv.fwd(x, tape, stats=self.bn.training), tape, relu=True, chan_scale=chan_scale, dist=dist)
+        return self.bn.fwd(self.conv.fwd(x, tape, stats=self.bn.stats_request(dist)), tape, relu=True, chan_scale=chan_scale, dist=dist)
 
 
 class FCNHead(nn.Module):

@@ -10,6 +10,8 @@
 // data-parallel run all-reduces (SyncBN).
 #include "rcf_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int RED_THREADS = 256;
@@ -38,9 +40,33 @@ ColGeom col_geom(long rows, int C, int V = 4) {
 }
 
 // Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
+// The workgroup that finishes LAST in its channel group (a ticket per group) sums the group's partial rows in a fixed
+// order into sums[2C]: the sum is deterministic whoever is last, and the second launch the partials used to need is gone.
+// Tickets live in zero-initialised device storage and are reset by their last taker.  Kernels on different streams may
+// run side by side (the EMA teacher's forward beside the student's, models/rcf_model.py:380-408), so every stream gets its
+// own row of tickets (ticket_row below: static storage, nothing is allocated); a ninth stream falls back to the second
+// launch.
+constexpr int TICKET_STREAMS = 8, TICKET_COLS = 256;
+__device__ unsigned g_tickets[TICKET_STREAMS][TICKET_COLS];
+
+__device__ __forceinline__ bool last_block_of(unsigned *ticket, unsigned participants) {
+    __shared__ unsigned last;
+    __threadfence();                                   // this block's partial row is visible before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        last = t == participants - 1 ? 1u : 0u;
+        if (last) *ticket = 0u;                        // every participant has drawn: ready for the next launch
+    }
+    __syncthreads();
+    if (last) __threadfence();
+    return last != 0u;
+}
+
 template <class F, int V>
 __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows, int C, int cvB, int RG,
-                                                                 long rows_per_chunk, double *__restrict__ partial) {
+                                                                 long rows_per_chunk, double *__restrict__ partial,
+                                                                 double *__restrict__ sums, unsigned *__restrict__ tickets) {
     __shared__ double red[RED_THREADS * 2 * V];
     const int tid = threadIdx.x;
     const int cv = tid % cvB, rg = tid / cvB;
@@ -81,6 +107,47 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
         for (int e = 0; e < V; ++e) {
             dst[c0 + e] = sa[e];
             dst[C + c0 + e] = sb[e];
+        }
+    }
+    if (!tickets) return;                               // the caller sums the partial rows with a second launch
+    if (gridDim.x == 1) {                               // one chunk: its partial row is the result
+        if (rg == 0 && c0 < C) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                sums[c0 + e] = sa[e];
+                sums[C + c0 + e] = sb[e];
+            }
+        }
+        return;
+    }
+    if (!last_block_of(tickets + blockIdx.y, gridDim.x)) return;
+    // 2 * cvB * V columns of this group over gridDim.x rows: thread -> (column, slice of rows), slices combined in LDS
+    const int cols = 2 * cvB * V, S = RED_THREADS / cols > 0 ? RED_THREADS / cols : 1;
+    for (int base = 0; base < cols; base += RED_THREADS / S) {
+        const int j = base + tid / S, sl = tid % S;
+        double acc = 0;
+        int col = -1;
+        if (j < cols && tid / S < RED_THREADS / S) {
+            const int half = j / (cvB * V), cc = blockIdx.y * cvB * V + (j - half * cvB * V);
+            if (cc < C) {
+                col = half * C + cc;
+                double a0 = 0, a1 = 0;
+                int k = sl;
+                for (; k + S < (int)gridDim.x; k += 2 * S) {
+                    a0 += partial[(long)k * 2 * C + col];
+                    a1 += partial[(long)(k + S) * 2 * C + col];
+                }
+                if (k < (int)gridDim.x) a0 += partial[(long)k * 2 * C + col];
+                acc = a0 + a1;
+            }
+        }
+        __syncthreads();
+        red[tid] = acc;
+        __syncthreads();
+        if (sl == 0 && col >= 0) {
+            double t = 0;
+            for (int q = 0; q < S; ++q) t += red[tid + q];
+            sums[col] = t;
         }
     }
 }
@@ -230,6 +297,94 @@ __global__ void bn_finalize_kernel(const double *__restrict__ sums, double count
     if (rvar) {
         const double unbiased = count > 1 ? var * (count / (count - 1.0)) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+// partial [chunks][2C] (sum | sum of squares per conv row tile) -> sums[2C] and, with fin.on, the batch-norm constants of
+// bn_finalize_kernel plus `num_batches_tracked += 1`, in ONE launch: blockIdx.y cuts the rows into G groups; the group sums
+// go to scratch[G][2C]; the workgroup that draws the last ticket of its 32 channels adds the G rows in a fixed order.
+struct FinArgs {
+    double count;
+    float eps, momentum;
+    float *mean, *invstd, *rmean, *rvar;
+    long long *nbt;
+    int on;
+};
+
+__global__ void __launch_bounds__(256) sum_finalize_kernel(const double *__restrict__ partial, int chunks, int per, int C,
+                                                           double *__restrict__ scratch, double *__restrict__ out,
+                                                           unsigned *__restrict__ tickets, FinArgs fin) {
+    __shared__ double sh[2][256];
+    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + j, G = gridDim.y;
+    const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
+    const long n = 2L * C;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double acc = 0;
+        if (c < C) {
+            const long col = (long)h * C + c;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;        // four independent chains, combined in a fixed order
+            int k = k0 + sl;
+            for (; k + 24 < k1; k += 32) {
+                a0 += partial[(long)k * n + col];
+                a1 += partial[(long)(k + 8) * n + col];
+                a2 += partial[(long)(k + 16) * n + col];
+                a3 += partial[(long)(k + 24) * n + col];
+            }
+            for (; k < k1; k += 8) a0 += partial[(long)k * n + col];
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        sh[h][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    double t[2] = {0, 0};
+    if (sl == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[h] += sh[h][q * 32 + j];
+    }
+    if (G > 1) {
+        if (sl == 0 && c < C) {
+            scratch[(long)blockIdx.y * n + c] = t[0];
+            scratch[(long)blockIdx.y * n + C + c] = t[1];
+        }
+        if (!last_block_of(tickets + blockIdx.x, G)) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double acc = 0;
+            if (c < C)
+                for (int g = sl; g < G; g += 8) acc += scratch[(long)g * n + (long)h * C + c];
+            sh[h][threadIdx.x] = acc;
+        }
+        __syncthreads();
+        if (sl == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                t[h] = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[h] += sh[h][q * 32 + j];
+            }
+        }
+    }
+    if (sl != 0 || c >= C) return;
+    if (out) {
+        out[c] = t[0];
+        out[C + c] = t[1];
+    }
+    if (fin.on) {                                          // bn_finalize_kernel's arithmetic
+        const double m = t[0] / fin.count;
+        double var = t[1] / fin.count - m * m;
+        if (var < 0) var = 0;
+        fin.mean[c] = (float)m;
+        fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+        if (fin.rmean) fin.rmean[c] = (1.f - fin.momentum) * fin.rmean[c] + fin.momentum * (float)m;
+        if (fin.rvar) {
+            const double unbiased = fin.count > 1 ? var * (fin.count / (fin.count - 1.0)) : var;
+            fin.rvar[c] = (1.f - fin.momentum) * fin.rvar[c] + fin.momentum * (float)unbiased;
+        }
+        if (c == 0 && fin.nbt) fin.nbt[0] += 1;
     }
 }
 
@@ -453,6 +608,45 @@ inline int ew_blocks(long total) {
 
 }  // namespace
 
+// every stream that issues statistics kernels gets one row of the static ticket storage (up to TICKET_STREAMS)
+static unsigned *ticket_row(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owners[TICKET_STREAMS];
+    static int used = 0;
+    static unsigned *base = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base && hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+    for (int i = 0; i < used; ++i)
+        if (owners[i] == st) return base + i * TICKET_COLS;
+    if (used == TICKET_STREAMS) return nullptr;
+    owners[used] = st;
+    return base + (used++) * TICKET_COLS;
+}
+
+// partial [chunks][2C] -> sums[2C] (may be NULL with fin) and, with fin, the batch-norm constants; one launch
+int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, double *scratch,
+                        const rcf_bn_finalize *fin, void *stream) {
+    if (!partial || chunks <= 0 || C <= 0 || (!sums && !fin)) return RCF_EINVAL;
+    if (fin && (!fin->mean || !fin->invstd || !(fin->count > 0))) return RCF_EINVAL;
+    hipStream_t st = rcf_stream(stream);
+    FinArgs fa{};
+    if (fin) {
+        fa.count = fin->count; fa.eps = fin->eps; fa.momentum = fin->momentum;
+        fa.mean = fin->mean; fa.invstd = fin->invstd; fa.rmean = fin->running_mean; fa.rvar = fin->running_var;
+        fa.nbt = fin->num_batches_tracked; fa.on = 1;
+    }
+    int G = 1;
+    unsigned *tickets = nullptr;
+    if (scratch && chunks >= 256 && rcf_cdiv(C, 32) <= TICKET_COLS) {
+        tickets = ticket_row(st);
+        if (tickets) G = chunks >= 2048 ? 64 : 16;      // many row tiles: more than C/32 workgroups read
+    }
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32), G), dim3(256), 0, st, partial, chunks, rcf_cdiv(chunks, G),
+                       C, scratch, sums, tickets, fa);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t rcf_bn_stats_workspace_bytes(long rows, int C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
     const ColGeom g = col_geom(rows, C);
@@ -478,22 +672,25 @@ extern "C" int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pit
     const int V = vec_width(xdt, xdt, C, pitch, 8, 8, 8);
     const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
+    unsigned *tickets = g.cgroups <= TICKET_COLS ? ticket_row(st) : nullptr;   // the last workgroup sums the partial rows
     if (V == 8) {
         StatsOp<bf16_t, 8> op{(const bf16_t *)x, pitch};
         hipLaunchKernelGGL((colreduce2_kernel<StatsOp<bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st,
-                           op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+                           op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums, tickets);
     } else {
 #define RCF_CALL(XT)                                                                                                     \
     StatsOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
     hipLaunchKernelGGL((colreduce2_kernel<StatsOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums, tickets)
         RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, 2 * C, sums);
-    RCF_LAUNCH_CHECK();
+    if (!tickets) {
+        hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
+                           g.chunks, 2 * C, sums);
+        RCF_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -584,24 +781,27 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
     const int V = vec_width(xdt, ydt, C, dy_pitch, x_pitch, (relu && !relu_mask) ? y_pitch : 8, 8);
     const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
+    unsigned *tickets = g.cgroups <= TICKET_COLS ? ticket_row(st) : nullptr;   // the last workgroup sums the partial rows
     if (V == 8) {
         BwdOp<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)y, mean, invstd, chan_scale,
                                     dy_pitch, x_pitch, y_pitch, relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};
         hipLaunchKernelGGL((colreduce2_kernel<BwdOp<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0,
-                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums2, tickets);
     } else {
 #define RCF_CALL(XT, YT)                                                                                                    \
     BwdOp<XT, YT, 4> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
                         relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};                               \
     hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,  \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums2, tickets)
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, 2 * C, sums2);
-    RCF_LAUNCH_CHECK();
+    if (!tickets) {
+        hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
+                           g.chunks, 2 * C, sums2);
+        RCF_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -667,7 +867,7 @@ extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch
 #define RCF_CALL(XT)                                                                                                      \
     ColsumOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
     hipLaunchKernelGGL((colreduce2_kernel<ColsumOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, (double *)nullptr, (unsigned *)nullptr)
     RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
     RCF_LAUNCH_CHECK();

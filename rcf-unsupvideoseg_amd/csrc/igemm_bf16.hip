@@ -1031,9 +1031,10 @@ extern "C" size_t rcf_conv2d_fwd_stats_bf16_workspace_bytes(const rcf_conv_shape
     return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 128) + 64) * 2 * s->Cout * sizeof(double);
 }
 
-extern "C" int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, void *y, int ydt,
-                                   const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope, int beta,
-                                   double *sums, void *workspace, size_t workspace_bytes, void *stream) {
+static int conv2d_fwd_bf16_impl(const void *x, const void *w_bf16, const float *bias, void *y, int ydt,
+                               const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope, int beta,
+                               double *sums, const rcf_bn_finalize *fin, void *workspace, size_t workspace_bytes,
+                               void *stream) {
     if (ydt != RCF_BF16 && ydt != RCF_F32) return RCF_EINVAL;
     if (int e = check_shape(s, ydt == RCF_BF16 ? 8 : 4)) return e;
     if (!x || !w_bf16 || !y || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y)) return RCF_EINVAL;
@@ -1047,15 +1048,31 @@ extern "C" int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const floa
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.act = act; p.slope = slope; p.beta = beta;
     hipStream_t st = rcf_stream(stream);
-    if (sums) {                                       // batch-norm statistics of the output from the epilogue
+    const bool stats = sums || fin;
+    if (stats) {                                      // batch-norm statistics of the output from the epilogue
         if (region || bias || act || beta) return RCF_EINVAL;
         if (!workspace || workspace_bytes < rcf_conv2d_fwd_stats_bf16_workspace_bytes(s)) return RCF_EWORKSPACE;
         p.stats = (double *)workspace;
     }
     const int e = ydt == RCF_BF16 ? launch_conv<true>(p, false, st) : launch_conv<false>(p, false, st);
-    if (e || !sums) return e;
-    return rcf_sum_partials_f64((const double *)workspace, p.mtiles, 2 * s->Cout, sums,
-                                (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, stream);
+    if (e || !stats) return e;
+    return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cout, sums,
+                               (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, fin, stream);
+}
+
+extern "C" int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, void *y, int ydt,
+                                   const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope, int beta,
+                                   double *sums, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv2d_fwd_bf16_impl(x, w_bf16, bias, y, ydt, s, region, act, slope, beta, sums, nullptr, workspace,
+                                workspace_bytes, stream);
+}
+
+extern "C" int rcf_conv2d_fwd_bnstats_bf16(const void *x, const void *w_bf16, void *y, int ydt, const rcf_conv_shape *s,
+                                           double *sums, const rcf_bn_finalize *fin, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+    if (!sums && !fin) return RCF_EINVAL;
+    return conv2d_fwd_bf16_impl(x, w_bf16, nullptr, y, ydt, s, nullptr, 0, 0.f, 0, sums, fin, workspace, workspace_bytes,
+                                stream);
 }
 
 extern "C" size_t rcf_conv2d_dgrad_bf16_workspace_bytes(const rcf_conv_shape *s) {

@@ -1929,10 +1929,11 @@ extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) 
     return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 64) + 64) * 2 * s->Cout * sizeof(double);
 }
 
-extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int rcf_conv2d_fwd_bnstats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
+                                          const rcf_bn_finalize *fin, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
     if (int e = check_shape(s)) return e;
-    if (!x || !w || !y || !sums || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+    if (!x || !w || !y || (!sums && !fin) || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
     if (!use_x3(1)) return RCF_EINVAL;                    // the statistics epilogue exists on the split-bf16 kernels only
     if (!workspace || workspace_bytes < rcf_conv2d_fwd_stats_workspace_bytes(s)) return RCF_EWORKSPACE;
     IgemmParams p{};
@@ -1946,8 +1947,13 @@ extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
     p.stats = (double *)workspace;
     if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
-    return rcf_sum_partials_f64((const double *)workspace, p.mtiles, 2 * s->Cout, sums,
-                                (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, stream);
+    return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cout, sums,
+                               (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, fin, stream);
+}
+
+extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    return rcf_conv2d_fwd_bnstats_f32(x, w, y, s, sums, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {

@@ -14,6 +14,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 static inline hipStream_t rcf_stream(void *s) { return (hipStream_t)s; }
+// bn.hip: partial [chunks][2C] (per conv row tile: sum | sum of squares) -> sums[2C] (may be NULL with fin) and, with fin,
+// the batch-norm constants + running statistics + num_batches_tracked, in one launch.  scratch: 64 rows of 2C doubles.
+int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, double *scratch,
+                        const rcf_bn_finalize *fin, void *stream);
+
 static inline int rcf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool rcf_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 

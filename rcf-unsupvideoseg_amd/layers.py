@@ -35,11 +35,12 @@ def _round_up(n, m):
 
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
-    __slots__ = ("t", "grad", "needs_grad", "stats", "amax", "grad_amax")
+    __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
         self.stats = None            # fp64 [2C] column sums | sums of squares, when the producing conv computed them
+        self.bn = None               # (mean, invstd, count) when the producing conv's reduction also finalized the norm
         self.amax = None             # int32 [1]: raw bits of max |t| (operand range of the fp16-pair conv kernels)
         self.grad_amax = None        # the same for `grad`, when its only producer computed it
 
@@ -76,6 +77,7 @@ OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
 OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "0") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
+FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
 # convs on the fp16-pair kernels (3 partial products; operand ranges from ops.absmax) instead of bf16 triples (6)
@@ -201,9 +203,13 @@ class Conv2d(nn.Module):
         else:
             w, b = self.weight, self.bias
             if stats and FUSE_BN_STATS and b is None and out is None:
-                y, sums = ops.conv2d_fwd_bf16(x.t, w, None, None, self.stride, self.padding, self.dilation, stats=True)
+                bn = stats if isinstance(stats, BatchNorm2d) else None
+                y, sums = ops.conv2d_fwd_bf16(x.t, w, None, None, self.stride, self.padding, self.dilation, stats=True, bn=bn)
                 ya = Act(y)
-                ya.stats = sums
+                if bn is not None:
+                    ya.bn = sums
+                else:
+                    ya.stats = sums
             else:
                 ya = Act(ops.conv2d_fwd_bf16(x.t, w, None, b, self.stride, self.padding, self.dilation, out=out))
         if tape.enabled:
@@ -250,7 +256,8 @@ class Conv2d(nn.Module):
 
     def fwd(self, x, tape, out=None, stats=False):
         """Returns an Act with cout_pad channels (the padded ones are exactly zero).
-        stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics."""
+        stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics.  Pass the
+        BatchNorm2d itself (`bn.stats_request(dist)`) and the reduction of those statistics finalizes it in the same launch."""
         if x.t.dtype == torch.bfloat16:
             return self._fwd_bf16(x, tape, out, stats)
         w, b = self._packed_weight(), self._packed_bias()
@@ -261,9 +268,13 @@ class Conv2d(nn.Module):
                 wp = ops.weight_pairs(w, aw)
         if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
                 and ops.conv_regions_available():
-            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp)
+            bn = stats if isinstance(stats, BatchNorm2d) else None
+            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp, bn=bn)
             ya = Act(y)
-            ya.stats = sums
+            if bn is not None:
+                ya.bn = sums
+            else:
+                ya.stats = sums
         else:
             y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out,
                                amax=(ax, aw), w_pairs=wp)
@@ -327,11 +338,22 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
+    def stats_request(self, dist=None):
+        """what to hand the producing conv as `stats`: False in eval mode; True when the statistics must be all-reduced
+        first (SyncBN in a distributed run); otherwise this module -- the conv's reduction finalizes it"""
+        if not self.training:
+            return False
+        if self.sync and dist is not None and dist.on:
+            return True
+        return self if FUSE_BN_FINALIZE else True
+
     def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None):
         xt = x.t
         if not self.sync:
             dist = None
-        if self.training:
+        if self.training and x.bn is not None:            # finalized by the producing conv's statistics reduction
+            mean, invstd, count = x.bn
+        elif self.training:
             local_rows = xt.shape[0] * xt.shape[1] * xt.shape[2]
             sums = x.stats if x.stats is not None else ops.bn_stats(xt)
             count = local_rows

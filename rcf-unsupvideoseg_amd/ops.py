@@ -237,8 +237,20 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     return out
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None):
-    """conv (no bias) whose epilogue also yields the batch-norm statistics of the output: (y, fp64 [2*Cout] sums)"""
+def _bn_fin(bn, count, device):
+    """(struct rcf_bn_finalize, mean, invstd) for a training-mode batch norm whose statistics the next launch produces:
+    its final reduction also writes the normalisation constants, the running statistics and num_batches_tracked"""
+    C = bn.num_features
+    mean = torch.empty(C, dtype=torch.float32, device=device)
+    invstd = torch.empty(C, dtype=torch.float32, device=device)
+    fin = _lib.BnFinalize(float(count), bn.eps, bn.momentum, mean.data_ptr(), invstd.data_ptr(), bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr())
+    return fin, mean, invstd
+
+
+def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=None):
+    """conv (no bias) whose epilogue also yields the batch-norm statistics of the output: (y, fp64 [2*Cout] sums); with
+    `bn` (a training-mode BatchNorm2d whose statistics are local) the same reduction finalizes it: (y, (mean, invstd, count))"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
                     w_pairs=w_pairs)
@@ -251,7 +263,13 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None):
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
                               2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
-    call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
+    if bn is not None:
+        count = s.N * s.Ho * s.Wo
+        fin, mean, invstd = _bn_fin(bn, count, x.device)
+        call("rcf_conv2d_fwd_bnstats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), None, byref(fin), _p(ws), need, _stream())
+        sums = (mean, invstd, count)
+    else:
+        call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
     if end is not None:
         end.record()
     return out, sums
@@ -310,7 +328,7 @@ def weight_bf16(w, transpose=False):
 
 
 def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None,
-                    out_dtype=torch.bfloat16, stats=False):
+                    out_dtype=torch.bfloat16, stats=False, bn=None):
     """x: NHWC bf16; w: the fp32 master weight (shape only, unless w_bf16 is None); returns y (bf16 or fp32) and, with
     stats, the fp64 [2*Cout] batch-norm sums of the fp32 accumulators"""
     _need_cuda(x, w)
@@ -331,8 +349,15 @@ def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0,
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_fwd" if s.Cout > 128 else "conv_bf16_fwd_narrow",
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
-    call("rcf_conv2d_fwd_bf16", _p(x), _p(w_bf16), _p(bias), _p(out), _dt(out), byref(s), _region(region), act, slope, beta,
-         _p(sums), _p(ws), need, _stream())
+    if stats and bn is not None:                     # the statistics reduction also finalizes the batch norm
+        count = s.N * s.Ho * s.Wo
+        fin, mean, invstd = _bn_fin(bn, count, x.device)
+        call("rcf_conv2d_fwd_bnstats_bf16", _p(x), _p(w_bf16), _p(out), _dt(out), byref(s), None, byref(fin), _p(ws), need,
+             _stream())
+        sums = (mean, invstd, count)
+    else:
+        call("rcf_conv2d_fwd_bf16", _p(x), _p(w_bf16), _p(bias), _p(out), _dt(out), byref(s), _region(region), act, slope, beta,
+             _p(sums), _p(ws), need, _stream())
     if end is not None:
         end.record()
     return (out, sums) if stats else out
