@@ -39,9 +39,10 @@ ColGeom col_geom(long rows, int C, int V = 4) {
     return g;
 }
 
-// Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
-// The workgroup that finishes LAST in its channel group (a ticket per group) sums the group's partial rows in a fixed
-// order into sums[2C]: the sum is deterministic whoever is last, and the second launch the partials used to need is gone.
+// "The last one sums" (sum_finalize_kernel): the workgroup that draws the last ticket of its channels adds the group rows
+// in a fixed order -- deterministic whoever is last.  Tried for colreduce2_kernel too (one or two levels of tails instead
+// of the partial_sum_kernel launch): the serial tail costs as much as the launch it saves (bf16 step 57 -> 68 ms with
+// one level, a wash with two), so the column reductions keep their second launch.
 // Tickets live in zero-initialised device storage and are reset by their last taker.  Kernels on different streams may
 // run side by side (the EMA teacher's forward beside the student's, models/rcf_model.py:380-408), so every stream gets its
 // own row of tickets (ticket_row below: static storage, nothing is allocated); a ninth stream falls back to the second
@@ -63,10 +64,10 @@ __device__ __forceinline__ bool last_block_of(unsigned *ticket, unsigned partici
     return last != 0u;
 }
 
+// Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
 template <class F, int V>
 __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows, int C, int cvB, int RG,
-                                                                 long rows_per_chunk, double *__restrict__ partial,
-                                                                 double *__restrict__ sums, unsigned *__restrict__ tickets) {
+                                                                 long rows_per_chunk, double *__restrict__ partial) {
     __shared__ double red[RED_THREADS * 2 * V];
     const int tid = threadIdx.x;
     const int cv = tid % cvB, rg = tid / cvB;
@@ -107,47 +108,6 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
         for (int e = 0; e < V; ++e) {
             dst[c0 + e] = sa[e];
             dst[C + c0 + e] = sb[e];
-        }
-    }
-    if (!tickets) return;                               // the caller sums the partial rows with a second launch
-    if (gridDim.x == 1) {                               // one chunk: its partial row is the result
-        if (rg == 0 && c0 < C) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                sums[c0 + e] = sa[e];
-                sums[C + c0 + e] = sb[e];
-            }
-        }
-        return;
-    }
-    if (!last_block_of(tickets + blockIdx.y, gridDim.x)) return;
-    // 2 * cvB * V columns of this group over gridDim.x rows: thread -> (column, slice of rows), slices combined in LDS
-    const int cols = 2 * cvB * V, S = RED_THREADS / cols > 0 ? RED_THREADS / cols : 1;
-    for (int base = 0; base < cols; base += RED_THREADS / S) {
-        const int j = base + tid / S, sl = tid % S;
-        double acc = 0;
-        int col = -1;
-        if (j < cols && tid / S < RED_THREADS / S) {
-            const int half = j / (cvB * V), cc = blockIdx.y * cvB * V + (j - half * cvB * V);
-            if (cc < C) {
-                col = half * C + cc;
-                double a0 = 0, a1 = 0;
-                int k = sl;
-                for (; k + S < (int)gridDim.x; k += 2 * S) {
-                    a0 += partial[(long)k * 2 * C + col];
-                    a1 += partial[(long)(k + S) * 2 * C + col];
-                }
-                if (k < (int)gridDim.x) a0 += partial[(long)k * 2 * C + col];
-                acc = a0 + a1;
-            }
-        }
-        __syncthreads();
-        red[tid] = acc;
-        __syncthreads();
-        if (sl == 0 && col >= 0) {
-            double t = 0;
-            for (int q = 0; q < S; ++q) t += red[tid + q];
-            sums[col] = t;
         }
     }
 }
@@ -672,25 +632,22 @@ extern "C" int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pit
     const int V = vec_width(xdt, xdt, C, pitch, 8, 8, 8);
     const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
-    unsigned *tickets = g.cgroups <= TICKET_COLS ? ticket_row(st) : nullptr;   // the last workgroup sums the partial rows
     if (V == 8) {
         StatsOp<bf16_t, 8> op{(const bf16_t *)x, pitch};
         hipLaunchKernelGGL((colreduce2_kernel<StatsOp<bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st,
-                           op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums, tickets);
+                           op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     } else {
 #define RCF_CALL(XT)                                                                                                     \
     StatsOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
     hipLaunchKernelGGL((colreduce2_kernel<StatsOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums, tickets)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
         RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    if (!tickets) {
-        hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                           g.chunks, 2 * C, sums);
-        RCF_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, 2 * C, sums);
+    RCF_LAUNCH_CHECK();
     return 0;
 }
 
@@ -781,27 +738,24 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
     const int V = vec_width(xdt, ydt, C, dy_pitch, x_pitch, (relu && !relu_mask) ? y_pitch : 8, 8);
     const ColGeom g = col_geom(rows, C, V);
     hipStream_t st = rcf_stream(stream);
-    unsigned *tickets = g.cgroups <= TICKET_COLS ? ticket_row(st) : nullptr;   // the last workgroup sums the partial rows
     if (V == 8) {
         BwdOp<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)y, mean, invstd, chan_scale,
                                     dy_pitch, x_pitch, y_pitch, relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};
         hipLaunchKernelGGL((colreduce2_kernel<BwdOp<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0,
-                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums2, tickets);
+                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
     } else {
 #define RCF_CALL(XT, YT)                                                                                                    \
     BwdOp<XT, YT, 4> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
                         relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};                               \
     hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,  \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, sums2, tickets)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    if (!tickets) {
-        hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                           g.chunks, 2 * C, sums2);
-        RCF_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
+                       g.chunks, 2 * C, sums2);
+    RCF_LAUNCH_CHECK();
     return 0;
 }
 
@@ -867,7 +821,7 @@ extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch
 #define RCF_CALL(XT)                                                                                                      \
     ColsumOp<XT, 4> op{(const XT *)x, pitch};                                                                             \
     hipLaunchKernelGGL((colreduce2_kernel<ColsumOp<XT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op, \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, (double *)nullptr, (unsigned *)nullptr)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
     RCF_DISPATCH1(xdt, RCF_CALL);
 #undef RCF_CALL
     RCF_LAUNCH_CHECK();

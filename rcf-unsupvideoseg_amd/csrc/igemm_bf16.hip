@@ -109,12 +109,12 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
 // registers, no ds_write pass); three LDS stages, the loads of K-step t+2 are issued before the MFMAs of step t and
 // stay in flight across the one barrier per step (counted s_waitcnt vmcnt).  The LDS image of a wave instruction is
 // lane-linear (1 KB = 16 rows x 64 B), so the XOR swizzle of the 16-byte chunks is applied to the SOURCE address.
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false, int NST = 3>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     constexpr int PA = BM * 64, PB = BN * 64, STAGE = PA + PB;
-    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr int NSTAGE = DMA ? NST : 2;
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
     const int bid = blockIdx.x;
@@ -220,22 +220,29 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) conv_bf1
                                                          (int)a_offset(kt, i, tapoff, c, kv, dy, dx), 0, 0, 0);
         };
         constexpr int NLD = A_PASS + B_PASS;              // LDS-DMA instructions per thread per K-step
-        issue(0, 0);
-        if (KT > 1) issue(1, 1);
-        if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int AHEAD = NST - 1;                    // K-steps in flight beyond the one being multiplied
+        // wait until the loads of step `kt + 1` have landed: those of the later steps already issued stay in flight
+        auto wait_next = [&](int kt) {
+            const int later = min(KT - 1, kt + AHEAD) - (kt + 1);       // steps issued beyond kt + 1
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < KT) issue(i, i);
+        wait_next(-1);
         __builtin_amdgcn_s_barrier();
         int st = 0;                                       // stage of K-step kt
         for (int kt = 0; kt < KT; ++kt) {
-            const int st2 = st >= 1 ? st - 1 : 2;         // (st + 2) % 3: the stage read a step ago, free since the last barrier
-            if (kt + 2 < KT) issue(kt + 2, st2);
+            // stage (st + AHEAD) % NST was read a step ago: free since the last barrier
+            const int stn = st + AHEAD >= NST ? st + AHEAD - NST : st + AHEAD;
+            if (kt + AHEAD < KT) issue(kt + AHEAD, stn);
             const char *As = smem + st * STAGE;
             mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
-            // the loads of step kt + 1 (issued a step ago) must have landed; those of kt + 2 stay in flight
-            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_next(kt);
             __builtin_amdgcn_s_barrier();
-            st = st == 2 ? 0 : st + 1;
+            st = st == NST - 1 ? 0 : st + 1;
         }
     } else {
     // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets); B (weights, L2) one step ahead
@@ -920,15 +927,15 @@ int set_region(ConvParams &p, const rcf_conv_region *r, int N, int H, int W) {
 int g_bf16_tile = -1;      // -1 / 4: LDS-DMA kernels (128x64 / 128x128 / 128x256 by width), 5: LDS-DMA 256x256 (512 threads);
                            // register-staged A/B references: 0 128x128, 1 128x256, 2 256x256, 3 128x64
 
-template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false>
+template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false, int NST = 3>
 void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
-    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
-    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 template <bool OBF>
@@ -952,6 +959,8 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     else if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true>(p, strided, dgrad, st);
     else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true>(p, strided, dgrad, st);
     else if (tile == 5) launch_cfg<2, 4, 4, 2, OBF, true>(p, strided, dgrad, st);       // 256x256, 8 waves
+    else if (tile == 6) launch_cfg<2, 4, 4, 2, OBF, true, 4>(p, strided, dgrad, st);    // 256x256, four LDS stages (128 KB)
+    else if (tile == 7) launch_cfg<2, 4, 2, 2, OBF, true, 4>(p, strided, dgrad, st);    // 128x256, four stages: one workgroup per CU
     else launch_cfg<2, 4, 2, 2, OBF, true>(p, strided, dgrad, st);
     RCF_LAUNCH_CHECK();
     return 0;
