@@ -54,6 +54,10 @@ typedef struct {
     /* Optional, forward launches of the fp16-pair kernels: w already split by rcf_conv_weight_pairs_f32 with the
      * range amax_w points to (the kernel then reads the two fp16 planes instead of splitting w in every row tile) */
     const void *w_pairs;
+    /* Optional, data-gradient launches: the transposed weight operand prepared ONCE per weight update instead of per
+     * launch -- fp32 entry points: rcf_conv_weight_pairs_t_f32 (fp16 planes of the transposed weights, with amax_w);
+     * bf16 entry points: rcf_conv_weight_bf16(..., transpose = 1).  The workspace of the launch may then be NULL. */
+    const void *w_pairs_t;
 } rcf_conv_shape;
 
 /* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order
@@ -85,6 +89,10 @@ int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias,
  * models/resnet.py:268-300 and mmcv ConvModule without the statistics pass re-reading y.  Split-bf16 kernels only
  * (RCF_EINVAL otherwise: the caller then runs rcf_bn_stats_f32). */
 size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s);
+/* the transposed ([Cin][R][S][Cout], K padded to whole K-steps) fp16-pair planes the data gradient contracts against;
+ * rcf_conv2d_dgrad_workspace_bytes(s) bytes */
+int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
+                                void *stream);
 int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
                              void *workspace, size_t workspace_bytes, void *stream);
 /* What a training-mode batch norm derives from its statistics (the per-channel constants of the normalisation, the

@@ -1095,11 +1095,17 @@ extern "C" int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, c
     if (int e = check_shape(s)) return e;
     if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
     if (s->y_pitch % 8) return RCF_EINVAL;
-    const size_t need = rcf_conv2d_dgrad_bf16_workspace_bytes(s);
-    if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
-    if (int e = rcf_conv_weight_bf16(w, s->Cout, s->Cin, s->R, s->S, 1, workspace, stream)) return e;
+    const void *wt = s->w_pairs_t;                        // the transposed bf16 weights, prepared once per weight update
+    if (!wt) {
+        const size_t need = rcf_conv2d_dgrad_bf16_workspace_bytes(s);
+        if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+        if (int e = rcf_conv_weight_bf16(w, s->Cout, s->Cin, s->R, s->S, 1, workspace, stream)) return e;
+        wt = workspace;
+    } else if (!rcf_aligned16(wt)) {
+        return RCF_EINVAL;
+    }
     ConvParams p{};
-    p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)workspace; p.bias = nullptr; p.Y = dx;
+    p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)wt; p.bias = nullptr; p.Y = dx;
     p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
     p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
     if (int e = set_region(p, region, s->N, s->H, s->W)) return e;

@@ -1923,6 +1923,16 @@ extern "C" int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int 
     return 0;
 }
 
+extern "C" int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w,
+                                           void *planes, void *stream) {
+    if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
+    const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
+    hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)planes,
+                       Cout, Cin, R * S);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) {
     if (check_shape(s) || !use_x3(1)) return 0;
     // one row of partial sums per row tile (smallest tile: 64 rows) + the 64 rows of the two-level reduction
@@ -1984,12 +1994,15 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
     if (use_x3(2)) {
         // k-contiguous weights for the bf16 operand fetch: wt[c][rs][co] (one small transpose per call)
         const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
-        if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+        const bool prepared = s->w_pairs_t && s->amax_dy && s->amax_w && !g_h2_off;
+        if (!prepared && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
         hipStream_t st = rcf_stream(stream);
         p.ldb = p.K;
         p.amax_a = s->amax_dy; p.amax_b = s->amax_w;
         const dim3 tgrid(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S);
-        if (p.amax_a && p.amax_b && !g_h2_off) {          // fp16 pairs: transposed AND split, once per launch
+        if (p.amax_a && p.amax_b && !g_h2_off && s->w_pairs_t) {
+            p.b_pairs = s->w_pairs_t;                      // prepared once per weight update by the caller
+        } else if (p.amax_a && p.amax_b && !g_h2_off) {   // fp16 pairs: transposed AND split, once per launch
             hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
                                s->Cout, s->Cin, s->R * s->S);
             p.b_pairs = workspace;

@@ -77,6 +77,7 @@ OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
 OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "0") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
+CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once per weight update, not per launch
 FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
@@ -163,6 +164,20 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
         nn.init.kaiming_normal_(self.weight, a=0, mode="fan_out", nonlinearity="relu")   # mmcv kaiming_init
 
+    def _derived(self, kind, make):
+        """an operand derived from self.weight (its range, its fp16 planes, its bf16 copies), made once per weight update
+        instead of once per launch: valid while the weight's storage, torch version and the library's weight epoch stand"""
+        if not CACHE_WEIGHT_OPERANDS:
+            return make()
+        key = ops.weight_key(self.weight)
+        cache = self.__dict__.setdefault("_wcache", {})
+        hit = cache.get(kind)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        v = make()
+        cache[kind] = (key, v)
+        return v
+
     def _packed_weight(self, cout_mult=4):
         """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded
         (Cout_pad = Cout rounded up to `cout_mult`)."""
@@ -204,14 +219,16 @@ class Conv2d(nn.Module):
             w, b = self.weight, self.bias
             if stats and FUSE_BN_STATS and b is None and out is None:
                 bn = stats if isinstance(stats, BatchNorm2d) else None
-                y, sums = ops.conv2d_fwd_bf16(x.t, w, None, None, self.stride, self.padding, self.dilation, stats=True, bn=bn)
+                y, sums = ops.conv2d_fwd_bf16(x.t, w, self._derived("bf16", lambda: ops.weight_bf16(w)), None, self.stride,
+                                              self.padding, self.dilation, stats=True, bn=bn)
                 ya = Act(y)
                 if bn is not None:
                     ya.bn = sums
                 else:
                     ya.stats = sums
             else:
-                ya = Act(ops.conv2d_fwd_bf16(x.t, w, None, b, self.stride, self.padding, self.dilation, out=out))
+                ya = Act(ops.conv2d_fwd_bf16(x.t, w, self._derived("bf16", lambda: ops.weight_bf16(w)), b, self.stride,
+                                             self.padding, self.dilation, out=out))
         if tape.enabled:
             def bwd():
                 dy = ya.take_grad()
@@ -250,7 +267,9 @@ class Conv2d(nn.Module):
                         ops.copy2d(dw.permute(0, 2, 3, 1), n, g.permute(0, 2, 3, 1), n, 1, n, beta=1)
                 if x.needs_grad:
                     gx, beta = x.grad_slot()
-                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta)
+                    wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
+                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                          w_t_bf16=wt)
             tape.push(bwd)
         return ya
 
@@ -263,9 +282,11 @@ class Conv2d(nn.Module):
         w, b = self._packed_weight(), self._packed_bias()
         ax = aw = wp = None
         if FP16_PAIRS:
-            ax, aw = x.range(), ops.absmax(ops.weight_rsck(w))
+            own = w is self.weight                                       # padded copies are rebuilt per call: not cached
+            ax = x.range()
+            aw = self._derived("amax", lambda: ops.absmax(ops.weight_rsck(w))) if own else ops.absmax(ops.weight_rsck(w))
             if x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 4096:      # many row tiles would each split the weights
-                wp = ops.weight_pairs(w, aw)
+                wp = self._derived("pairs", lambda: ops.weight_pairs(w, aw)) if own else ops.weight_pairs(w, aw)
         if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
                 and ops.conv_regions_available():
             bn = stats if isinstance(stats, BatchNorm2d) else None
@@ -318,8 +339,11 @@ class Conv2d(nn.Module):
                         _param_grad(self.bias).add_(db[:self.cout])
                 if x.needs_grad:
                     gx, beta = x.grad_slot()
+                    wpt = None
+                    if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
+                        wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
                     ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                     amax=(ady, aw))
+                                     amax=(ady, aw), w_pairs_t=wpt)
             tape.push(bwd)
         return ya
 

@@ -126,7 +126,7 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None):
+def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None):
     """amax = (amax_x, amax_w, amax_dy): int32 [1] device tensors from absmax() or None -- the operand ranges that
     select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h)"""
     N, H, W, Cin = xshape
@@ -138,7 +138,7 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w
     if kind not in H2_KINDS:                      # debug knob: which launches may take the fp16-pair kernels
         ax = aw = ady = w_pairs = None
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout,
-                     _addr(ax), _addr(aw), _addr(ady), _addr(w_pairs))
+                     _addr(ax), _addr(aw), _addr(ady), _addr(w_pairs), _addr(w_pairs_t))
 
 
 def _addr(t):
@@ -183,6 +183,30 @@ def absmax(x, out=None):
         rows, C, pitch = x.numel() // 4, 4, 4
     call("rcf_absmax_f32", _p(x), rows, C, pitch, _p(out), _stream())
     return out
+
+
+# Operands derived from a weight (its range, fp16 planes, bf16 copies) are cached by the layers between weight updates.
+# Updates made through torch (optimizers, copy_, load_state_dict) bump the tensor's `_version`; the kernels of this
+# library write through raw pointers, so their wrappers bump this epoch instead.
+WEIGHT_EPOCH = [0]
+
+
+def weights_changed():
+    WEIGHT_EPOCH[0] += 1
+
+
+def weight_key(w):
+    return (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+
+
+def weight_pairs_t(w, amax_w):
+    """the transposed fp16-pair planes the data gradient contracts against (once per weight update, not per launch)"""
+    _need_cuda(w)
+    Cout, Cin, R, S = w.shape
+    nbytes = ((R * S * Cout + 15) // 16) * 16 * Cin * 4          # rcf_conv2d_dgrad_workspace_bytes
+    planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call("rcf_conv_weight_pairs_t_f32", _p(weight_rsck(w)), Cout, Cin, R, S, _p(amax_w), _p(planes), _stream())
+    return planes
 
 
 def weight_pairs(w, amax_w):
@@ -275,15 +299,18 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
     return out, sums
 
 
-def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None):
-    """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w)"""
+def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None, w_pairs_t=None):
+    """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w);
+    w_pairs_t = weight_pairs_t(w, amax_w), prepared once per weight update"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
+    if amax is None or amax[0] is None or amax[1] is None or "d" not in H2_KINDS:
+        w_pairs_t = None
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
-                    amax=None if amax is None else (None, amax[1], amax[0]))
+                    amax=None if amax is None else (None, amax[1], amax[0]), w_pairs_t=w_pairs_t)
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
-    need = _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
+    need = 0 if w_pairs_t is not None else _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
@@ -363,16 +390,17 @@ def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0,
     return (out, sums) if stats else out
 
 
-def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None):
-    """dy: NHWC bf16, w: fp32 master weight -> dx bf16 (region in INPUT coordinates)"""
+def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, w_t_bf16=None):
+    """dy: NHWC bf16, w: fp32 master weight -> dx bf16 (region in INPUT coordinates).  w_t_bf16 = weight_bf16(w, True),
+    prepared once per weight update (otherwise the launch casts into its workspace)"""
     _need_cuda(dy, w)
     assert dy.dtype == torch.bfloat16
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.bfloat16, device=dy.device)
-    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy), w_pairs_t=w_t_bf16)
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
-    need = _lib.load().rcf_conv2d_dgrad_bf16_workspace_bytes(byref(s))
-    ws = workspace(need, dy.device)
+    need = 0 if w_t_bf16 is not None else _lib.load().rcf_conv2d_dgrad_bf16_workspace_bytes(byref(s))
+    ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_bf16_dgrad_other",
@@ -641,15 +669,18 @@ def photometric_loss(im, recon, occ, w_l1=0.15, w_ssim=0.85):
 # ------------------------------------------------------------------------------- optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
               grad_scale=1.0):
+    weights_changed()
     call("rcf_adam_step_f32", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
          eps, weight_decay, step, grad_scale, _stream())
 
 
 def ema_update(dest, src, m):
+    weights_changed()
     call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
 
 
 def fill(t, v):
+    weights_changed()
     call("rcf_fill_f32", _p(t), t.numel(), float(v), _stream())
 
 
