@@ -794,6 +794,10 @@ __device__ __forceinline__ void store_val(void *out, long i, long long a0, long 
 // The per-iteration kernels take grid (frames, chunks): with the frame as the FASTEST grid index a frame's workgroups
 // all run on XCD frame % 8 (for 8 k frames per call), so its label values, lattice values and neighbour lists stay in
 // that XCD's 4 MB L2 from the splat through the blurs to the slice instead of being fetched by all eight.
+// Tried in round 2 and rejected: a position-parallel splat (one lane per CSR position or per four, segmented scan over the
+// wavefront, 64-bit integer atomics into per-vertex accumulators, bit-identical sums): 0.344-0.360 ms/frame against this
+// kernel's 0.353-0.359 on smooth frames, slower on mixed batches -- the ~0.6 M 64-bit L2 atomics per frame and iteration
+// cost what the list walk costs.
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q, void *__restrict__ out) {
     const int f = blockIdx.x;
@@ -999,18 +1003,38 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
     if (p4 < HW) {
         const bool full = (p4 + 3 < HW) && (HW % 4 == 0);
         unsigned bytes[12];
-        for (int j = 0; j < 4; j++) {
-            const int p = p4 + j;
-            if (p >= HW) { bytes[3 * j] = bytes[3 * j + 1] = bytes[3 * j + 2] = 0; continue; }
+        if (full) {                                    // 16-byte loads: (f*3 + c)*HW + p4 is a multiple of 4 floats
+            float4 pl[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float v = img[((long)f * 3 + c) * HW + p];
-                if (unstd) v = v * std3[c] + mean3[c];
-                bytes[3 * j + c] = to_u8(v);
+            for (int c = 0; c < 3; c++) pl[c] = *reinterpret_cast<const float4 *>(img + ((long)f * 3 + c) * HW + p4);
+            const float4 mk = *reinterpret_cast<const float4 *>(mask + (long)f * HW + p4);
+            const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float v = j == 0 ? pl[c].x : (j == 1 ? pl[c].y : (j == 2 ? pl[c].z : pl[c].w));
+                    if (unstd) v = v * std3[c] + mean3[c];
+                    bytes[3 * j + c] = to_u8(v);
+                }
+                float m = mv[j] * 255.f / crf_scale;
+                m = fminf(fmaxf(m, 0.f), 255.f);
+                q = max(q, (unsigned)(uint8_t)m);
             }
-            float m = mask[(long)f * HW + p] * 255.f / crf_scale;
-            m = fminf(fmaxf(m, 0.f), 255.f);
-            q = max(q, (unsigned)(uint8_t)m);
+        } else {
+            for (int j = 0; j < 4; j++) {
+                const int p = p4 + j;
+                if (p >= HW) { bytes[3 * j] = bytes[3 * j + 1] = bytes[3 * j + 2] = 0; continue; }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float v = img[((long)f * 3 + c) * HW + p];
+                    if (unstd) v = v * std3[c] + mean3[c];
+                    bytes[3 * j + c] = to_u8(v);
+                }
+                float m = mask[(long)f * HW + p] * 255.f / crf_scale;
+                m = fminf(fmaxf(m, 0.f), 255.f);
+                q = max(q, (unsigned)(uint8_t)m);
+            }
         }
         uint8_t *dst = rgb + ((long)f * HW + p4) * 3;
         if (full) {
