@@ -249,6 +249,12 @@ def main():
             except Exception as e:                              # noqa: BLE001
                 out["vit_s8_ncut"] = None
                 out["vit_error"] = str(e)[:200]
+        # the reference's data transform on the device: decoded u8 batch -> collated, normalised batch
+        try:
+            out["data_transform"] = datapipe_bench(torch, rcf_amd, synth, dev, H, W, B)
+        except Exception as e:                                  # noqa: BLE001
+            out["data_transform"] = None
+            out["data_transform_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(out), flush=True)
@@ -392,6 +398,42 @@ def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):
             "flow_warp_GBps": round(px * 32.0 / t_w / 1e9, 1), "flow_warp_us_per_frame": round(t_w / nframes * 1e6, 2)}
 
 
+def datapipe_bench(torch, rcf_amd, synth, dev, H, W, B):
+    """rcf_amd.data_pipeline.Transform(training, strong_aug, has_pl) on a batch of B decoded samples (2 frames, 2 flows,
+    2 pseudo-label masks of HxW each) resident in HBM -> 2 x [B,3,384,384] + flows + masks.  Algorithmic bytes: what is
+    written plus the source pixels the crops cover once (frames 3 B, flows 8 B, masks 1 B per source pixel)."""
+    import numpy as np
+    from rcf_amd.data_pipeline import Transform
+    base = [synth.loader_sample(9000 + i, H, W) for i in range(2)]
+    samples = [base[i % 2] for i in range(B)]
+    tf = Transform(training=True, strong_aug=True, has_pl=True)
+    rng = np.random.RandomState(5)
+    params = np.stack([tf.sample_params(H, W, rng) for _ in range(B)])
+    params["ops"] |= 15                                       # every photometric stage on: the most arithmetic per pixel
+    data = {"imgs": torch.from_numpy(np.stack([s["frames"] for s in samples])).to(dev),
+            "gt_fw_flows": torch.from_numpy(np.stack([s["fw"] for s in samples])).to(dev),
+            "gt_bw_flows": torch.from_numpy(np.stack([s["bw"] for s in samples])).to(dev),
+            "pl_masks": torch.from_numpy(np.stack([s["pl"] for s in samples])).to(dev)}
+    tf(data, params=params)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        tf(data, params=params)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    out_b = B * 384 * 384 * (2 * 3 * 4 + 2 * 2 * 4 + 2 * 4)
+    src_b = sum(384.0 * 384.0 * (H / float(p["rh"])) * (W / float(p["rw"])) * (2 * 3 + 2 * 8 + 2 * 1) for p in params)
+    ach = (out_b + src_b) / (ms * 1e-3) / 1e9
+    return {"workload": f"Transform(training, strong_aug, has_pl) on {B} samples of 2 frames {H}x{W} (+2 flows, 2 masks), "
+                        f"every photometric stage on", "ms_per_batch": round(ms, 4), "samples_per_s": round(B / (ms * 1e-3), 1),
+            "launches_per_batch": 3, "algorithmic_bytes_per_batch": round(out_b + src_b),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4)}}
+
+
 def _cpu_info():
     """(model name, logical CPUs available to this process, physical cores among them)"""
     model, phys = "unknown", set()
@@ -466,11 +508,22 @@ def cpu_baseline(H, W):
         t0 = time.perf_counter()
         head(img, torch.from_numpy(msk)[None])
         crf[f"crf_ms_per_frame_T{iters}"] = round((time.perf_counter() - t0) * 1e3, 1)
+    # CPU data transform: the numpy restatement of the reference's per-sample pipeline (oracle/transforms_np.py), 1 core
+    from oracle import transforms_np as T_np
+    from rcf_amd.data_pipeline import Transform
+    tfm = Transform(training=True, strong_aug=True, has_pl=True)
+    smp = synth.loader_sample(9000, H, W)
+    prm = tfm.sample_params(H, W, np.random.RandomState(5))
+    prm["ops"] |= 15
+    t0 = time.perf_counter()
+    T_np.apply_params(smp, prm, 384, 384)
+    crf["data_transform_ms_per_sample"] = round((time.perf_counter() - t0) * 1e3, 1)
     return {"value": round(2.0 * pairs / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "cpu_model": model_name, "logical_cpus": logical, "physical_cores": physical,
             "sample": f"{pairs} pairs ({2 * pairs} frames) {H}x{W} (BASELINE configs[0]), one fwd+bwd+Adam step of "
                       f"oracle/rcf_torch.py in {dt:.1f} s after an untimed 1-pair warm-up step ({warm:.1f} s)",
-            **crf, "crf_cores": 1, "crf_kind": "port (oracle/crf_ref.c, sequential C restatement of tools/torchCRF)"}
+            **crf, "crf_cores": 1, "crf_kind": "port (oracle/crf_ref.c, sequential C restatement of tools/torchCRF)",
+            "data_transform_kind": "port (oracle/transforms_np.py: numpy restatement of dataset/transforms.py's per-sample pipeline, 1 core)"}
 
 
 if __name__ == "__main__":
