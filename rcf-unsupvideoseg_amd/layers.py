@@ -89,7 +89,9 @@ _side_streams = {}
 def _side_stream(device):
     s = _side_streams.get(device.index)
     if s is None:
-        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+        # RCF_SIDE_PRIORITY: -1 = high priority for the second stream (experiment knob; default: the same priority)
+        prio = int(__import__("os").environ.get("RCF_SIDE_PRIORITY", "0"))
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device, priority=prio)
     return s
 
 
