@@ -154,9 +154,10 @@ __device__ __forceinline__ void lattice_key(int pd, int r, const int (&rem0)[PD_
     }
 }
 
+template <int PD>      // 2 / 5: the key arithmetic unrolls with a compile-time dimension; 0: Lt.pd at run time
 __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, int H,
                                                            float posdev, float featdev) {
-    const int pd = Lt.pd;
+    const int pd = PD ? PD : Lt.pd;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
     if (p >= Lt.N) return;
@@ -502,11 +503,12 @@ __global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
 }
 
 // distinct keys of PK_SAMPLES sampled pixel blocks (block-local de-duplication only) -> stat[4 f + 2]
+template <int PD>      // 2 / 5: the key arithmetic unrolls with a compile-time dimension; 0: Lt.pd at run time
 __global__ void __launch_bounds__(256) pk_estimate_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, float posdev,
                                                           float featdev) {
     __shared__ unsigned long long lkey[LT_SLOTS];
     __shared__ int distinct;
-    const int pd = Lt.pd, nax = pd + 1;
+    const int pd = PD ? PD : Lt.pd, nax = pd + 1;
     const int f = blockIdx.y;
     const int nblk = (Lt.N + 255) / 256;
     const int blk = (int)(((long)blockIdx.x * nblk) / gridDim.x);
@@ -537,12 +539,13 @@ __global__ void __launch_bounds__(256) pk_estimate_kernel(Lattice Lt, const uint
     if (threadIdx.x == 0) atomicAdd(Lt.stat + 4 * f + 2, distinct);
 }
 
+template <int PD>      // 2 / 5: the key arithmetic unrolls with a compile-time dimension; 0: Lt.pd at run time
 __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W,
                                                                    int H, float posdev, float featdev, int phase) {
     __shared__ unsigned long long lkey[LT_SLOTS];
     __shared__ unsigned lcnt[LT_SLOTS], lgs[LT_SLOTS], lbase[LT_SLOTS];
     __shared__ int newkeys, skip;
-    const int pd = Lt.pd, nax = pd + 1;
+    const int pd = PD ? PD : Lt.pd, nax = pd + 1;
     const int f = blockIdx.y;
     const bool small = phase == 0 && (long)Lt.cap_small < 2 * Lt.E;      // an attempt that may overflow
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
@@ -727,9 +730,10 @@ __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
     Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));
     Lt.vid[fb + idx] = v;
 }
+template <int PD>      // 2 / 5: the key arithmetic unrolls with a compile-time dimension; 0: Lt.pd at run time
 __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
     const int f = blockIdx.x;
-    const int pd = Lt.pd, nax = pd + 1;
+    const int pd = PD ? PD : Lt.pd, nax = pd + 1;
     const long Lf = Lt.L[f], S = 2 * Lt.E;
     const unsigned long long *table = Lt.table + (long)f * S;
     const int *sv = Lt.slot_vid2 + (long)f * S;
@@ -897,13 +901,16 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T
 
 // build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
 // sym: inv[p] = 1 / sqrt(that + 1e-20), the symmetric normalisation of DenseCRF2D (see rcf_crf_soft_ex)
+template <int PD>
 __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float *__restrict__ z, int sym) {
     const int f = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
     const long fb = (long)f * Lt.E;
+    const int pd = PD ? PD : Lt.pd;
     float sw = 0;
-    for (int r = 0; r <= Lt.pd; r++) {
+#pragma unroll
+    for (int r = 0; r <= pd; r++) {
         const long pe = fb + (long)r * Lt.N + p;
         sw += Lt.weight[pe] * z[fb + Lt.vid[pe]];
     }
@@ -912,6 +919,7 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
 
 // slice + Potts weight + (optionally) softmax and MAP.
 //   first: next = -U, else next = next_in;  next += w * slice;  last: Q = softmax(next) (+ MAP)
+template <int PD>      // compile-time dimension: the pd + 1 (weight, vertex, value) chains of a pixel are all in flight at once
 __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__restrict__ val,
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
@@ -919,9 +927,10 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const int f = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
     if (p >= Lt.N) return;
-    const int nax = Lt.pd + 1;
+    const int nax = (PD ? PD : Lt.pd) + 1;
     const long fb = (long)f * Lt.E;
     float s0 = 0, s1 = 0;
+#pragma unroll
     for (int r = 0; r < nax; r++) {
         const long pe = fb + (long)r * Lt.N + p;
         const float wgt = Lt.weight[pe];
@@ -1047,10 +1056,16 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
                 for (int c = 0; c < 3; c++) dst[3 * j + c] = (uint8_t)bytes[3 * j + c];
         }
     }
+    // Same-address atomics serialise (~75 ns each here): one per wavefront cost 100+ of this kernel's 150 us.  One per
+    // workgroup, and only while it would raise the running maximum (it saturates after a few workgroups).
+    __shared__ unsigned wq[4];
     for (int o = 32; o > 0; o >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, o, 64));
-    // one same-address atomic per wavefront cost 130 of this kernel's 150 us (12.8 k serialised atomics per frame): the
-    // running maximum saturates after a few workgroups, so look before asking for the atomic
-    if ((threadIdx.x & 63) == 0 && q > __hip_atomic_load(qmax + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qmax + f, q);
+    if ((threadIdx.x & 63) == 0) wq[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q = max(max(wq[0], wq[1]), max(wq[2], wq[3]));
+        if (q > __hip_atomic_load(qmax + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qmax + f, q);
+    }
 }
 
 __global__ void __launch_bounds__(256) prepare_unary_kernel(const float *__restrict__ mask, float crf_scale,
@@ -1142,6 +1157,14 @@ int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the a
 int g_crf_sym = 0;         // 1 while rcf_crf_soft_ex runs with the symmetric normalisation
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
 
+// kernels templated on the lattice dimension: the two potentials of the reference are pd = 2 and pd = 5
+#define PD_LAUNCH(pd_, kern, grid, block, st_, ...)                                              \
+    do {                                                                                        \
+        if ((pd_) == 5) hipLaunchKernelGGL(kern<5>, grid, block, 0, st_, __VA_ARGS__);          \
+        else if ((pd_) == 2) hipLaunchKernelGGL(kern<2>, grid, block, 0, st_, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(kern<0>, grid, block, 0, st_, __VA_ARGS__);                     \
+    } while (0)
+
 // bound on |key coordinate| (see lattice_point): elevated[i] in [-i*cf_i, sum_j cf_j], keys within pd+1 of it
 bool keys_fit_12bit(int pd, int W, int H, float posdev, float featdev) {
     double posmax[PD_MAX] = {(double)W / posdev, (double)H / posdev, 255.0 / featdev, 255.0 / featdev, 255.0 / featdev};
@@ -1165,18 +1188,18 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
-        hipLaunchKernelGGL(pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), 0, st, L, rgb, W, posdev, featdev);
-    hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev, 0);
+        PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
+    PD_LAUNCH(L.pd, lattice_build_packed_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
         hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
-        hipLaunchKernelGGL(lattice_build_packed_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev, 1);
+        PD_LAUNCH(L.pd, lattice_build_packed_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
     }
     hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_fill_kernel, ge, dim3(256), 0, st, L);
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
-    hipLaunchKernelGGL(pk_neighbours_kernel, dim3(F, 2048), dim3(256), 0, st, L);
+    PD_LAUNCH(L.pd, pk_neighbours_kernel, dim3(F, 2048), dim3(256), st, L);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1191,7 +1214,7 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
         return build_lattice_norm(L, F, st);
     }
     CK(hipMemsetAsync(L.entries, 0xff, (size_t)F * 2 * L.E * sizeof(int), st));
-    hipLaunchKernelGGL(lattice_keys_kernel, gp, dim3(256), 0, st, L, rgb, W, H, posdev, featdev);
+    PD_LAUNCH(L.pd, lattice_keys_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev);
     hipLaunchKernelGGL(lattice_insert_kernel, ge, dim3(256), 0, st, L);
     hipLaunchKernelGGL(lattice_scan_local_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(lattice_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk);
@@ -1218,7 +1241,7 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
         hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
     }
-    hipLaunchKernelGGL(slice_norm_kernel, gp, dim3(256), 0, st, L, (const float *)za, g_crf_sym);
+    PD_LAUNCH(L.pd, slice_norm_kernel, gp, dim3(256), st, L, (const float *)za, g_crf_sym);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1233,7 +1256,7 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
         hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
         float2 *t = a; a = b; b = t;
     }
-    hipLaunchKernelGGL(slice_kernel, gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last,
+    PD_LAUNCH(L.pd, slice_kernel, gp, dim3(256), st, L, (const float2 *)a, unary, next, Qout, map, first, last,
                        write_map, g_crf_sym);
     RCF_LAUNCH_CHECK();
     return 0;
