@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     __shared__ unsigned lcnt[LT_SLOTS], lgs[LT_SLOTS], lbase[LT_SLOTS];
     __shared__ int newkeys, skip;
     const int pd = PD ? PD : Lt.pd, nax = pd + 1;
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;                             // frame fastest: with 8 frames per call a frame's workgroups share one XCD
     const bool small = phase == 0 && (long)Lt.cap_small < 2 * Lt.E;      // an attempt that may overflow
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
     if (threadIdx.x == 0) {
@@ -557,8 +557,14 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     }
     __syncthreads();
     if (skip) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = p < Lt.N;
+    // A workgroup takes a 16 x 16 pixel tile, not 256 pixels of one row: neighbours in BOTH directions share lattice
+    // vertices, so the tile's 1 536 entries collapse to fewer distinct keys and fewer of them go to the global table
+    // (the global inserts -- dependent device-scope atomics -- are what this kernel waits for).
+    const int tiles_x = (W + 15) >> 4;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
+    const bool live = py < H && px < W;
+    const int p = live ? py * W + px : 0;
     for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) { lkey[i] = PK_EMPTY; lcnt[i] = 0u; }
     __syncthreads();
     float wgt[PD_MAX + 1];
@@ -1181,6 +1187,7 @@ bool keys_fit_12bit(int pd, int W, int H, float posdev, float featdev) {
 int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev,
                          hipStream_t st) {
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(F, rcf_cdiv(L.E, 256));       // ge: (frames, chunks), frame = XCD
+    const dim3 gpf(F, rcf_cdiv(W, 16) * rcf_cdiv(H, 16));        // (frames, 16 x 16 pixel tiles)
     const int nblk2 = scan_blocks(2 * L.E);
     // first attempt: 2^18 - 1 buckets (3 MB of keys + cursors per frame, room for 131 k distinct keys; measured at
     // 480x854, T=5: 2^21 0.388, 2^19 0.371, 2^18 0.361 ms/frame); g_crf_variant 2 forces a tiny table (tests)
@@ -1189,10 +1196,10 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
         PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
-    PD_LAUNCH(L.pd, lattice_build_packed_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
+    PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
         hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
-        PD_LAUNCH(L.pd, lattice_build_packed_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
+        PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
     }
     hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
