@@ -32,6 +32,7 @@ constexpr float FIX_INV = 1.0f / 1099511627776.0f;
 struct Lattice {           // device pointers of one potential, for all frames (frame stride in elements)
     int pd;
     int N;                 // pixels per frame
+    int W;                 // image width (N = W * H): the per-pixel kernels walk 16 x 16 tiles
     long E;                // entries per frame = N*(pd+1)
     float w;               // Potts weight
     uint4 *keys;           // [F][E]   5 x int16 packed, zero padded
@@ -821,7 +822,7 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
         // entries, then the label values they point to), so the kernel is bound by how many lists are in flight:
         // four 16-lane groups per wavefront take one list each (lists of more than GROUP_LIST entries are left to
         // the whole wavefront afterwards).
-        constexpr int GROUP_LIST = 128;
+        constexpr int GROUP_LIST = 64;
         const int g = lane >> 4, sl = lane & 15;
         const long nw = (long)gridDim.y * wpb, w = (long)blockIdx.y * wpb + (threadIdx.x >> 6);
         for (long vb = w * 4; vb < Lf; vb += nw * 4) {         // vb is wavefront-uniform
@@ -831,8 +832,17 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
             const bool big = n > GROUP_LIST;
             long long a0 = 0, a1 = 0;
             if (!big) {
-#pragma unroll 2
-                for (int i = sl; i < n; i += 16) acc_entry<MODE>(Lt.csr[fb + beg + i], Qf, a0, a1);
+                // up to GROUP_LIST / 16 records per lane, all loaded before the first label value is asked for: the list
+                // costs three dependent round trips (its extent, its records, their labels) whatever its length
+                int2 pw[GROUP_LIST / 16];
+#pragma unroll
+                for (int k = 0; k < GROUP_LIST / 16; ++k) {
+                    const int i = sl + 16 * k;
+                    pw[k] = i < n ? Lt.csr[fb + beg + i] : make_int2(-1, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < GROUP_LIST / 16; ++k)
+                    if (pw[k].x >= 0) acc_entry<MODE>(pw[k], Qf, a0, a1);
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) {                   // sums inside the 16-lane group
@@ -931,8 +941,12 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
                                                     int last, int write_map, int sym) {
     const int f = blockIdx.x;
-    const int p = blockIdx.y * blockDim.x + threadIdx.x;
-    if (p >= Lt.N) return;
+    // 16 x 16 pixel tiles: the pixels of a tile share most of their lattice vertices (the values stay in the CU's L1)
+    const int W = Lt.W, H = Lt.N / Lt.W, tiles_x = (W + 15) >> 4;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
+    if (py >= H || px >= W) return;
+    const int p = py * W + px;
     const int nax = (PD ? PD : Lt.pd) + 1;
     const long fb = (long)f * Lt.E;
     float s0 = 0, s1 = 0;
@@ -1106,9 +1120,10 @@ struct Carver {
 
 inline int scan_blocks(long E) { return (int)((E + SCAN_TILE - 1) / SCAN_TILE); }
 
-void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F) {
+void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.pd = pd;
     L.N = N;
+    L.W = W;
     L.E = (long)N * (pd + 1);
     const size_t FE = (size_t)F * L.E;
     L.keys = c.take<uint4>(FE);
@@ -1144,8 +1159,8 @@ struct CrfBuffers {
 size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
     Carver c{base, 0};
     const int N = W * H;
-    carve_lattice(c, b.smooth, 2, N, F);
-    carve_lattice(c, b.app, 5, N, F);
+    carve_lattice(c, b.smooth, 2, N, F, W);
+    carve_lattice(c, b.app, 5, N, F, W);
     b.cur = c.take<float>((size_t)F * N * MLAB);
     b.next = c.take<float>((size_t)F * N * MLAB);
     b.unary_own = c.take<float>((size_t)F * N * MLAB);
@@ -1256,7 +1271,7 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
 // tmp-free filter + Potts + softmax epilogue for one potential
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
                   int first, int last, int write_map, hipStream_t st) {
-    const dim3 gv(F, 1024), gp(F, rcf_cdiv(L.N, 256));         // (frames, chunks): see splat_gather_kernel
+    const dim3 gv(F, 1024), gp(F, rcf_cdiv(L.W, 16) * rcf_cdiv(L.N / L.W, 16));     // (frames, 16 x 16 tiles): see splat_gather_kernel
     float2 *a = L.val0, *b = L.val1;
     hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a);
     for (int axis = 0; axis <= L.pd; axis++) {
