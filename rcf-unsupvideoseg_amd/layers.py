@@ -77,6 +77,7 @@ OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
 OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "0") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
+BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels), as torch autocast does
 CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once per weight update, not per launch
 FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
@@ -204,13 +205,45 @@ class Conv2d(nn.Module):
         b[:self.cout].copy_(self.bias.detach())
         return b
 
+    def _fwd_bf16_padded_cin(self, x, tape, out, stats):
+        """the stem (3 input channels) on the bf16 kernels: the image arrives as bf16 NHWC zero-padded to 8 channels
+        (`BF16_STEM`), the [Cout,Cin,R,S] parameter is re-packed to [Cout][R][S][8] once per weight update.  No data
+        gradient (the input is the image)."""
+        c8 = _round_up(self.cin, 8)
+        if x.t.shape[3] != c8 or x.needs_grad or self.bias is not None or out is not None or self.cout % 8:
+            raise ops._lib.RcfHipError("bf16 conv with Cin % 8 != 0: bias-free stem on an 8-channel-padded input only")
+        wpad = self._derived("w_cin8", lambda: ops.nchw_to_nhwc(self.weight.detach().contiguous(), c8).permute(0, 3, 1, 2))
+        wb = self._derived("bf16_cin8", lambda: ops.weight_bf16(wpad))
+        want = bool(stats) and FUSE_BN_STATS
+        bn = stats if isinstance(stats, BatchNorm2d) else None
+        res = ops.conv2d_fwd_bf16(x.t, wpad, wb, None, self.stride, self.padding, self.dilation, stats=want, bn=bn if want else None)
+        if want:
+            ya = Act(res[0])
+            if bn is not None:
+                ya.bn = res[1]
+            else:
+                ya.stats = res[1]
+        else:
+            ya = Act(res)
+        if tape.enabled:
+            def bwd():
+                dy = ya.take_grad()
+                if self.weight.requires_grad:
+                    dwp = torch.empty_like(wpad)
+                    ops.conv2d_wgrad_bf16(x.t, dy, wpad, dwp, self.stride, self.padding, self.dilation, beta=0)
+                    g = _param_grad(self.weight)
+                    dw = ops.nhwc_to_nchw(dwp.permute(0, 2, 3, 1), self.cin)          # [Cout,Cin,R,S]
+                    ops.copy2d(dw, dw.numel(), g, g.numel(), 1, dw.numel(), beta=1)
+            tape.push(bwd)
+        return ya
+
     def _fwd_bf16(self, x, tape, out=None, stats=False):
         """bf16 activations in; bf16 out -- or fp32 out for the heads' final convs (`out_fp32`, or Cout % 8 != 0), whose
         results feed the fp32 loss tail.  Weights: fp32 master copy cast per launch; weight gradient fp32."""
-        if self.cin % 8:
-            raise ops._lib.RcfHipError("the bf16-operand conv kernels need Cin % 8 == 0")
         if self.act:
             raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
+        if self.cin % 8:
+            return self._fwd_bf16_padded_cin(x, tape, out, stats)
         out_f32 = getattr(self, "out_fp32", False) or self.cout % 8 != 0
         if out_f32:
             w, b = self._packed_weight(), self._packed_bias()          # Cout padded to a multiple of 4: fp32 quads

@@ -196,6 +196,9 @@ class RCFModel(nn.Module):
         x = imgs.reshape(B * I, C3, H, W).contiguous().float()
         if not x.is_cuda:
             raise RuntimeError("RCFModel (HIP) needs the batch on the GPU: there is no CPU fallback")
+        if layers.ACT_DTYPE == torch.bfloat16 and layers.BF16_STEM:
+            # bf16 step: the stem conv takes bf16 operands like every other conv (torch autocast casts conv1's input too)
+            return Act(ops.cast(ops.nchw_to_nhwc(x, 8), torch.bfloat16), needs_grad=False)
         return Act(ops.nchw_to_nhwc(x, 4), needs_grad=False)
 
     def run_backward(self, grad_out=None):
@@ -219,7 +222,7 @@ class RCFModel(nn.Module):
             # the EMA teacher's forward + CRF need only the images: run them on the second stream beside the student's
             # forward (its HBM-bound BN passes and the teacher's MFMA-bound convs fill each other's gaps)
             crf_side = layers._side_stream(img.t.device)
-            if layers.FP16_PAIRS:
+            if layers.FP16_PAIRS and img.t.dtype == torch.float32:
                 img.range()      # on THIS stream, before the fork: teacher and student stems share the cached range
             ops.reserve_amax(img.t.device, 512)     # the teacher's range slots: zero-filled before the fork as well
             crf_side.wait_stream(torch.cuda.current_stream(img.t.device))

@@ -21,13 +21,14 @@ nb = synth.make_batch(B, H, W, config_id=2)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
 configs = {"all on": {}, "no operand cache": {"CACHE_WEIGHT_OPERANDS": False}, "no fused finalize": {"FUSE_BN_FINALIZE": False},
-           "both off": {"CACHE_WEIGHT_OPERANDS": False, "FUSE_BN_FINALIZE": False}}
+           "fp32 stem": {"BF16_STEM": False}}
+FLAGS = ("CACHE_WEIGHT_OPERANDS", "FUSE_BN_FINALIZE", "BF16_STEM")
 for _ in range(3):
     tr.step(batch)
 res = {k: [] for k in configs}
 for r in range(rounds):
     for name, flags in configs.items():
-        for k in ("CACHE_WEIGHT_OPERANDS", "FUSE_BN_FINALIZE"):
+        for k in FLAGS:
             setattr(layers, k, flags.get(k, True))
         tr.step(batch)
         torch.cuda.synchronize()
