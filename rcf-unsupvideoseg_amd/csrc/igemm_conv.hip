@@ -21,6 +21,8 @@
 // same row tile: the activation tile is re-read from that XCD's own L2.
 #include "rcf_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BK = 16;   // K-step of the weight-gradient kernel
@@ -1747,7 +1749,10 @@ struct WgradPlan {
     int mr, nr, itiles, jtiles, splitk;
     long chunk;
 };
+int g_wgrad_plan_us = 1;      // 1: split-K by the microsecond cost model (same-box A/B: -0.5 ms per fp32 step); RCF_WGRAD_PLAN_US=0: round-1 model
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullptr) {
+    static const int env_plan = getenv("RCF_WGRAD_PLAN_US") ? atoi(getenv("RCF_WGRAD_PLAN_US")) : -1;
+    if (env_plan >= 0) g_wgrad_plan_us = env_plan;
     WgradPlan pl;
     const bool smallc = s->Cin == 4;
     const int ncols = smallc ? s->R * s->S * 4 : s->Cin;
@@ -1769,11 +1774,25 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr >= 2) {
         // the split-bf16 kernel runs 3 workgroups per CU (768 slots): pick the split whose last round is fullest
         // (time ~ rounds / split; the fixed-order reduction costs ~ split)
-        const long slots = pl.nr == 4 ? 512 : 768, hi = maxsk < 96 ? maxsk : 96;     // (the 128 x 256 kernel: 2 per CU = 512)
+        const long slots = pl.nr == 4 ? 512 : 768, hi = maxsk < 256 ? maxsk : 256;   // (the 128 x 256 kernel: 2 per CU = 512)
         double best = 1e30;
-        for (long c = 1; c <= hi; ++c) {
-            const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
-            if (cost < best - 1e-12) { best = cost; sk = c; }
+        if (g_wgrad_plan_us) {
+            // the cost model of the bf16 weight gradient (csrc/igemm_bf16.hip), in microseconds: rounds x pixels per
+            // workgroup x time per pixel (three partial products: 3 x the bf16 figure) + the fixed-order reduction, which
+            // reads c copies of the weight gradient
+            const double px_us = 0.075 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
+            const double wbytes = (double)s->Cout * s->R * s->S * s->Cin * 4.0;
+            for (long c = 1; c <= hi; ++c) {
+                const double rounds = (double)((tiles * c + slots - 1) / slots);
+                const double cost = rounds * (double)((M + c - 1) / c) * px_us + (c > 1 ? (double)c * wbytes / 2.0e6 + 3.0 : 0.0);
+                if (cost < best - 1e-9) { best = cost; sk = c; }
+            }
+        } else {
+            const long hi0 = hi < 96 ? hi : 96;
+            for (long c = 1; c <= hi0; ++c) {
+                const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
+                if (cost < best - 1e-12) { best = cost; sk = c; }
+            }
         }
     }
     long chunk = (M + sk - 1) / sk;
