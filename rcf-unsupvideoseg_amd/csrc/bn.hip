@@ -10,8 +10,6 @@
 // data-parallel run all-reduces (SyncBN).
 #include "rcf_common.h"
 
-#include <mutex>
-
 namespace {
 
 constexpr int RED_THREADS = 256;
@@ -37,31 +35,6 @@ ColGeom col_geom(long rows, int C, int V = 4) {
     g.rows_per_chunk = (rows + chunks - 1) / chunks;
     g.chunks = (int)((rows + g.rows_per_chunk - 1) / g.rows_per_chunk);
     return g;
-}
-
-// "The last one sums" (sum_finalize_kernel): the workgroup that draws the last ticket of its channels adds the group rows
-// in a fixed order -- deterministic whoever is last.  Tried for colreduce2_kernel too (one or two levels of tails instead
-// of the partial_sum_kernel launch): the serial tail costs as much as the launch it saves (bf16 step 57 -> 68 ms with
-// one level, a wash with two), so the column reductions keep their second launch.
-// Tickets live in zero-initialised device storage and are reset by their last taker.  Kernels on different streams may
-// run side by side (the EMA teacher's forward beside the student's, models/rcf_model.py:380-408), so every stream gets its
-// own row of tickets (ticket_row below: static storage, nothing is allocated); a ninth stream falls back to the second
-// launch.
-constexpr int TICKET_STREAMS = 8, TICKET_COLS = 256;
-__device__ unsigned g_tickets[TICKET_STREAMS][TICKET_COLS];
-
-__device__ __forceinline__ bool last_block_of(unsigned *ticket, unsigned participants) {
-    __shared__ unsigned last;
-    __threadfence();                                   // this block's partial row is visible before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(ticket, 1u);
-        last = t == participants - 1 ? 1u : 0u;
-        if (last) *ticket = 0u;                        // every participant has drawn: ready for the next launch
-    }
-    __syncthreads();
-    if (last) __threadfence();
-    return last != 0u;
 }
 
 // Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
@@ -261,8 +234,11 @@ __global__ void bn_finalize_kernel(const double *__restrict__ sums, double count
 }
 
 // partial [chunks][2C] (sum | sum of squares per conv row tile) -> sums[2C] and, with fin.on, the batch-norm constants of
-// bn_finalize_kernel plus `num_batches_tracked += 1`, in ONE launch: blockIdx.y cuts the rows into G groups; the group sums
-// go to scratch[G][2C]; the workgroup that draws the last ticket of its 32 channels adds the G rows in a fixed order.
+// bn_finalize_kernel plus `num_batches_tracked += 1`, in the launch that finishes the reduction.  Long lists of row tiles
+// are first cut into G groups by partial_sum_groups_kernel (more workgroups than C/32 read), this kernel then adds the G
+// group rows.  (A single-launch form -- the workgroup that draws the last ticket of its channels adds the group rows --
+// was measured at 37 us per call against 20 for the two launches: the agent-scope release fence every workgroup needs
+// before its ticket writes back an L2 full of the conv's dirty output.)
 struct FinArgs {
     double count;
     float eps, momentum;
@@ -271,16 +247,16 @@ struct FinArgs {
     int on;
 };
 
-__global__ void __launch_bounds__(256) sum_finalize_kernel(const double *__restrict__ partial, int chunks, int per, int C,
-                                                           double *__restrict__ scratch, double *__restrict__ out,
-                                                           unsigned *__restrict__ tickets, FinArgs fin) {
+__global__ void __launch_bounds__(512) sum_finalize_kernel(const double *__restrict__ partial, int chunks, int C,
+                                                           double *__restrict__ out, FinArgs fin) {
+    // 512 threads: threads 0-255 add the sums, 256-511 the sums of squares of the block's 32 channels (8 row slices each)
     __shared__ double sh[2][256];
-    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + j, G = gridDim.y;
-    const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
+    const int h = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int j = tid & 31, sl = tid >> 5;
+    const int c = blockIdx.x * 32 + j;
+    const int k0 = 0, k1 = chunks;
     const long n = 2L * C;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    {
         double acc = 0;
         if (c < C) {
             const long col = (long)h * C + c;
@@ -295,47 +271,26 @@ __global__ void __launch_bounds__(256) sum_finalize_kernel(const double *__restr
             for (; k < k1; k += 8) a0 += partial[(long)k * n + col];
             acc = (a0 + a1) + (a2 + a3);
         }
-        sh[h][threadIdx.x] = acc;
+        sh[h][tid] = acc;
     }
     __syncthreads();
-    double t[2] = {0, 0};
+    double t = 0;                                          // threads with sl == 0: the block's sum for (half h, channel c)
     if (sl == 0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[h] += sh[h][q * 32 + j];
+        for (int q = 0; q < 8; ++q) t += sh[h][q * 32 + j];
     }
-    if (G > 1) {
-        if (sl == 0 && c < C) {
-            scratch[(long)blockIdx.y * n + c] = t[0];
-            scratch[(long)blockIdx.y * n + C + c] = t[1];
-        }
-        if (!last_block_of(tickets + blockIdx.x, G)) return;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double acc = 0;
-            if (c < C)
-                for (int g = sl; g < G; g += 8) acc += scratch[(long)g * n + (long)h * C + c];
-            sh[h][threadIdx.x] = acc;
-        }
-        __syncthreads();
-        if (sl == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                t[h] = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) t[h] += sh[h][q * 32 + j];
-            }
-        }
-    }
-    if (sl != 0 || c >= C) return;
+    __syncthreads();
+    if (sl == 0) sh[h][j] = t;                             // hand both halves to the thread that finalizes the channel
+    __syncthreads();
+    if (h != 0 || sl != 0 || c >= C) return;
+    const double t0 = sh[0][j], t1 = sh[1][j];
     if (out) {
-        out[c] = t[0];
-        out[C + c] = t[1];
+        out[c] = t0;
+        out[C + c] = t1;
     }
     if (fin.on) {                                          // bn_finalize_kernel's arithmetic
-        const double m = t[0] / fin.count;
-        double var = t[1] / fin.count - m * m;
+        const double m = t0 / fin.count;
+        double var = t1 / fin.count - m * m;
         if (var < 0) var = 0;
         fin.mean[c] = (float)m;
         fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
@@ -568,22 +523,7 @@ inline int ew_blocks(long total) {
 
 }  // namespace
 
-// every stream that issues statistics kernels gets one row of the static ticket storage (up to TICKET_STREAMS)
-static unsigned *ticket_row(hipStream_t st) {
-    static std::mutex mu;
-    static hipStream_t owners[TICKET_STREAMS];
-    static int used = 0;
-    static unsigned *base = nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!base && hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
-    for (int i = 0; i < used; ++i)
-        if (owners[i] == st) return base + i * TICKET_COLS;
-    if (used == TICKET_STREAMS) return nullptr;
-    owners[used] = st;
-    return base + (used++) * TICKET_COLS;
-}
-
-// partial [chunks][2C] -> sums[2C] (may be NULL with fin) and, with fin, the batch-norm constants; one launch
+// partial [chunks][2C] -> sums[2C] (may be NULL with fin) and, with fin, the batch-norm constants; one or two launches
 int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, double *scratch,
                         const rcf_bn_finalize *fin, void *stream) {
     if (!partial || chunks <= 0 || C <= 0 || (!sums && !fin)) return RCF_EINVAL;
@@ -595,14 +535,16 @@ int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, 
         fa.mean = fin->mean; fa.invstd = fin->invstd; fa.rmean = fin->running_mean; fa.rvar = fin->running_var;
         fa.nbt = fin->num_batches_tracked; fa.on = 1;
     }
-    int G = 1;
-    unsigned *tickets = nullptr;
-    if (scratch && chunks >= 256 && rcf_cdiv(C, 32) <= TICKET_COLS) {
-        tickets = ticket_row(st);
-        if (tickets) G = chunks >= 2048 ? 64 : 16;      // many row tiles: more than C/32 workgroups read
+    if (scratch && chunks >= 256) {
+        // many row tiles: G groups of rows first, so that more than C/32 workgroups read
+        const int G = chunks >= 2048 ? 64 : 16, per = rcf_cdiv(chunks, G);
+        hipLaunchKernelGGL(partial_sum_groups_kernel, dim3(rcf_cdiv(2 * C, 32), G), dim3(256), 0, st, partial, chunks, per,
+                           2 * C, scratch);
+        RCF_LAUNCH_CHECK();
+        partial = scratch;
+        chunks = G;
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32), G), dim3(256), 0, st, partial, chunks, rcf_cdiv(chunks, G),
-                       C, scratch, sums, tickets, fa);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32)), dim3(512), 0, st, partial, chunks, C, sums, fa);
     RCF_LAUNCH_CHECK();
     return 0;
 }
