@@ -1780,7 +1780,8 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
             // the cost model of the bf16 weight gradient (csrc/igemm_bf16.hip), in microseconds: rounds x pixels per
             // workgroup x time per pixel (three partial products: 3 x the bf16 figure) + the fixed-order reduction, which
             // reads c copies of the weight gradient
-            const double px_us = 0.075 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
+            static const double px_base = getenv("RCF_WGRAD_PX_US") ? atof(getenv("RCF_WGRAD_PX_US")) : 0.075;
+            const double px_us = px_base * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
             const double wbytes = (double)s->Cout * s->R * s->S * s->Cin * 4.0;
             for (long c = 1; c <= hi; ++c) {
                 const double rounds = (double)((tiles * c + slots - 1) / slots);
