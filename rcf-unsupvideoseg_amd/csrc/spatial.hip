@@ -266,12 +266,13 @@ __global__ void __launch_bounds__(256) resize_nhwc_bwd_kernel(const T *__restric
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize_rows_fwd_kernel(const T *__restrict__ x, int x_pitch, T *__restrict__ y,
                                                               int y_pitch, int Hi, int Wi, int Ho, int Wo, int C, int align,
-                                                              float sh, float sw) {
+                                                              float sh, float sw, int frame) {
     const int CV = C / V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int xo = idx / CV, cv = idx - xo * CV;
     if (xo >= Wo) return;
     const int n = blockIdx.y / Ho, yo = blockIdx.y - n * Ho;
+    if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) return;      // only the border frame is written
     int y0, y1, x0, x1;
     float ly, lx;
     src_index(yo, sh, align, Hi, y0, y1, ly);
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(256) resize_rows_fwd_kernel(const T *__restric
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restrict__ dy, int dy_pitch, T *__restrict__ dx,
                                                               int dx_pitch, int beta, int Hi, int Wi, int Ho, int Wo, int C,
-                                                              int align, float sh, float sw) {
+                                                              int align, float sh, float sw, int frame) {
     const int CV = C / V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int xi = idx / CV, cv = idx - xi * CV;
@@ -304,6 +305,11 @@ __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restric
     fvec<V> acc;
 #pragma unroll
     for (int h = 0; h < V / 4; ++h) acc.q[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (frame > 0 && ylo >= frame && yhi < Ho - frame && xlo >= frame && xhi < Wo - frame) {
+        // frame > 0: dy counts as zero off the border frame; no candidate of this pixel lies on it (most of the image)
+        if (!beta) stv<T, V>(dx + (((long)n * Hi + yi) * Wi + xi) * dx_pitch + cv * V, acc);
+        return;
+    }
     constexpr int MAXC = 6;
     if (yhi - ylo < MAXC && xhi - xlo < MAXC) {
         float wxv[MAXC];
@@ -316,6 +322,7 @@ __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restric
 #pragma unroll
             for (int k = 0; k < MAXC; ++k) {
                 if (xlo + k > xhi || wxv[k] == 0.f) continue;
+                if (frame > 0 && !in_frame(yo, xlo + k, Ho, Wo, frame)) continue;
                 const fvec<V> g = ldv<T, V>(row + (long)k * dy_pitch);
                 const float w = wy * wxv[k];
 #pragma unroll
@@ -329,6 +336,7 @@ __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restric
             for (int xo = xlo; xo <= xhi; ++xo) {
                 const float wx = tap_weight(xo, xi, sw, align, Wi);
                 if (wx == 0.f) continue;
+                if (frame > 0 && !in_frame(yo, xo, Ho, Wo, frame)) continue;
                 const fvec<V> g = ldv<T, V>(dy + (((long)n * Ho + yo) * Wo + xo) * dy_pitch + cv * V);
                 const float w = wy * wx;
 #pragma unroll
@@ -511,16 +519,16 @@ extern "C" int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void 
     if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
     const long px = frame > 0 ? (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame)) : (long)N * Ho * Wo;
-    if (frame == 0 && (long)N * Ho <= 65535 && (long)Wo * (C / 4) < (1L << 30)) {
+    if ((long)N * Ho <= 65535 && (long)Wo * (C / 4) < (1L << 30)) {
         const float sh = host_scale(Hi, Ho, align_corners), sw = host_scale(Wi, Wo, align_corners);
         if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {
             hipLaunchKernelGGL((resize_rows_fwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wo * (C / 8), 256), N * Ho), dim3(256), 0,
                                rcf_stream(stream), (const bf16_t *)x, x_pitch, (bf16_t *)y, y_pitch, Hi, Wi, Ho, Wo, C,
-                               align_corners, sh, sw);
+                               align_corners, sh, sw, frame);
         } else {
 #define RCF_CALL(T)                                                                                                       \
     hipLaunchKernelGGL((resize_rows_fwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wo * (C / 4), 256), N * Ho), dim3(256), 0,      \
-                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, Ho, Wo, C, align_corners, sh, sw)
+                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, Ho, Wo, C, align_corners, sh, sw, frame)
             RCF_DISPATCH1(dt, RCF_CALL);
 #undef RCF_CALL
         }
@@ -563,17 +571,17 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, voi
         if (2 * tc >= Hi || 2 * tc >= Wi) tc = 0;
     }
     const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
-    if (frame == 0 && (long)N * Hi <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
+    if ((long)N * Hi <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
         const float sh = host_scale(Hi, Ho, align_corners), sw = host_scale(Wi, Wo, align_corners);
         if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {
             hipLaunchKernelGGL((resize_rows_bwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wi * (C / 8), 256), N * Hi), dim3(256), 0,
                                rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (bf16_t *)dx, dx_pitch, beta, Hi, Wi, Ho, Wo, C,
-                               align_corners, sh, sw);
+                               align_corners, sh, sw, frame);
         } else {
 #define RCF_CALL(T)                                                                                                       \
     hipLaunchKernelGGL((resize_rows_bwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wi * (C / 4), 256), N * Hi), dim3(256), 0,      \
                        rcf_stream(stream), (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, Hi, Wi, Ho, Wo, C,             \
-                       align_corners, sh, sw)
+                       align_corners, sh, sw, frame)
             RCF_DISPATCH1(dt, RCF_CALL);
 #undef RCF_CALL
         }

@@ -31,3 +31,14 @@ for dt in (torch.bfloat16, torch.float32):
     gb = ops.resize_nhwc_bwd(g, (60, 107), False).float()
     print(f"{dt}: fwd {tf*1e6:7.1f} us {nb/tf/1e12:.2f} TB/s | bwd {tb*1e6:7.1f} us {nb/tb/1e12:.2f} TB/s | "
           f"fwd err {float((y-ref).abs().max()):.2e} bwd err {float((gb-xg.grad).abs().max()):.2e}")
+
+# frame-restricted forms (the commuted up-sampling of the decode head's dilated conv): only the border frame is written / read
+for dt in (torch.bfloat16, torch.float32):
+    x = torch.randn(16, 60, 107, 256, device="cuda:0").to(dt)
+    g = torch.randn(16, 120, 214, 256, device="cuda:0").to(dt)
+    out = torch.zeros(16, 120, 214, 256, device="cuda:0").to(dt)
+    gx = torch.zeros(16, 60, 107, 256, device="cuda:0").to(dt)
+    for fr in (6, 12):
+        tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False, out=out, frame=fr))
+        tb = timeit(lambda: ops.resize_nhwc_bwd(g, (60, 107), False, out=gx, beta=1, frame=fr))
+        print(f"{dt} frame {fr}: fwd {tf*1e6:7.1f} us | bwd (beta=1) {tb*1e6:7.1f} us")
