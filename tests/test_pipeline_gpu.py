@@ -1,0 +1,58 @@
+"""GPU: the pieces either side of the hot path composed the way a maintainer would wire them: decoded
+u8 batch -> rcf_amd.data_pipeline.Transform on the device -> RCFModel / Trainer step (stage 2.2: pseudo-label loss on the
+transformed masks) -> evaluation transform -> forward_eval -> Evaluator.  No parity claim of its own (each piece has its
+fixtures); this checks the interfaces fit: shapes, dtypes, list-of-tensors batch layout, finite losses that move."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import rcf_amd
+from rcf_amd import config, evaluate, synth
+from rcf_amd.data_pipeline import Transform
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _raw_batch(seeds, H, W):
+    s = [synth.loader_sample(k, H, W) for k in seeds]
+    return {"imgs": torch.from_numpy(np.stack([x["frames"] for x in s])).to(DEV),
+            "gt_fw_flows": torch.from_numpy(np.stack([x["fw"] for x in s])).to(DEV),
+            "gt_bw_flows": torch.from_numpy(np.stack([x["bw"] for x in s])).to(DEV),
+            "pl_masks": torch.from_numpy(np.stack([x["pl"] for x in s])).to(DEV),
+            "seq_names": [f"synth{k}" for k in seeds]}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_transform_feeds_the_training_step_and_the_evaluator(precision, report):
+    H, W = 400, 520
+    tf = Transform(training=True, strong_aug=True, has_pl=True)
+    raw = _raw_batch([501, 502], H, W)
+    batch = tf(raw, rng=np.random.RandomState(11))
+    assert [tuple(t.shape) for t in batch["imgs"]] == [(2, 3, 384, 384)] * 2 and len(batch["pl_masks"]) == 2
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_pipe", object_channel=1, eval_save=False, eval_export=False,
+                                 eval_pos_th=0.35, rank=-1, set_object_channel_after_epoch=1)
+    mask = config.mask_size_for(384, 384)
+    model = rcf_amd.RCFModel(args, **config.stage22_model_kwargs(mask, dropout=0.0, norm="BN"))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=torch.device(DEV), precision=precision)
+    losses = [tr.step(batch) for _ in range(2)]
+    vals = [{k: float(v) for k, v in l.items()} for l in losses]
+    assert all(np.isfinite(list(v.values())).all() for v in vals) and "loss_pl" in vals[0]
+    assert vals[0]["loss"] != vals[1]["loss"], "the second step runs on updated weights"
+    # evaluation: single frames, resized (ratio 0.98) and normalised on the device, masks against a 0/128/255 annotation
+    etf = Transform(training=False)
+    eraw = {"imgs": raw["imgs"][:, :1].contiguous()}
+    ebatch = etf(eraw)
+    assert tuple(ebatch["imgs"][0].shape) == (2, 3, 392, int(W * (392 / H) + 0.5))
+    ann = torch.from_numpy(np.stack([np.where(synth.soft_blob_mask(H, W, 9 + i) > 0.5, 255, 0).astype(np.uint8) for i in range(2)])).to(DEV)
+    ebatch.update(ann=ann, seq_names=["a", "b"])
+    ev = evaluate.Evaluator(args, mask_layer=model.mask_layer if hasattr(model, "mask_layer") else 4)
+    ious = ev.test_step(model, ebatch)
+    assert ious.shape[0] == 2 and np.all((ious >= 0) & (ious <= 1) | np.isnan(ious))
+    miou, frame_avg, per_seq = ev.test_epoch_end(current_epoch=0, testing=True)
+    report(f"pipeline [{precision}]: transform -> 2 train steps (loss {vals[0]['loss']:.4f} -> {vals[1]['loss']:.4f}, loss_pl "
+           f"{vals[0]['loss_pl']:.4f}) -> eval transform -> Evaluator mIoU {float(miou):.4f}")
