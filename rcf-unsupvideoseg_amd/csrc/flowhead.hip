@@ -206,7 +206,14 @@ __global__ void __launch_bounds__(RB) softmax_kernel(Cfg c, Ws w, const float *_
 __global__ void softmax_final_kernel(Cfg c, Ws w) {
     // one block; S[n][c] and the scalar losses
     const int t = threadIdx.x;
-    if (t < c.NB * c.C) w.S[t] = w.red[(long)(t / c.C) * PARTW + (t % c.C)];
+    // A segment whose softmax mass is EXACTLY zero in a frame (logits hundreds apart: exp underflows on every pixel) makes
+    // the reference divide 0 by 0 (mask / mask.sum, flow_aggregation_head_with_residual.py:242-243) and the whole step NaN.
+    // Here such a segment is absent from the frame: its mass is stored as +inf, so every x / S below is 0 -- its pooled flow,
+    // its weights p / S and the gradient through them.  Any non-zero mass is used as it is (results unchanged).
+    if (t < c.NB * c.C) {
+        const double m = w.red[(long)(t / c.C) * PARTW + (t % c.C)];
+        w.S[t] = m > 0.0 ? m : (double)INFINITY;
+    }
     if (c.w_compact != 0.f && t < c.NB * 2)
         w.cen[t] = w.red[(long)(t >> 1) * PARTW + c.C + 3 + (t & 1)] / w.red[(long)(t >> 1) * PARTW + c.comp_ch];
     if (t == 0) {
@@ -333,6 +340,12 @@ __global__ void affine_solve_kernel(Cfg c, Ws w, int cc) {
     const int D = c.D;
     const double S = w.S[(long)n * c.C + cc];
     const double *r = w.red + (long)n * PARTW;
+    if (isinf(S)) {                                        // segment absent from this frame (see softmax_final_kernel)
+        double *Qi0 = w.Qinv + ((long)n * c.C + cc) * D * D, *A0 = w.A + ((long)n * c.C + cc) * 2 * D;
+        for (int j = 0; j < D * D; j++) Qi0[j] = 0.0;
+        for (int j = 0; j < 2 * D; j++) A0[j] = 0.0;
+        return;
+    }
     double M[2][DMAX], Q[DMAX][2 * DMAX];
     int q = 2 * D;
     for (int j = 0; j < D; j++) {

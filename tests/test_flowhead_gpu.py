@@ -119,3 +119,45 @@ def test_flow_head_entropy_and_targets_vs_torch(report):
          "dres": rel(ops.nhwc_to_nchw(res.grad).cpu().numpy(), gr.cpu().numpy())}
     report("flow head entropy/targets: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
     assert max(e.values()) < 2e-4, e
+
+
+@pytest.mark.parametrize("tag", ["head_free", "head_affine"])
+def test_flow_head_zero_mass_segment_is_absent_not_nan(tag, golden_dir, report):
+    """A segment whose softmax mass is exactly 0 in a frame (logits hundreds apart) makes the reference's
+    `mask / mask.sum(...)` 0/0 and the step NaN (flow_aggregation_head_with_residual.py:242-243).  Deliberate deviation:
+    the segment is treated as absent from that frame -- loss and gradients stay finite, and they equal what the head
+    gives for the same frame with that channel removed from the softmax altogether (the other frames are untouched)."""
+    fx = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, C, h, w = (int(fx[k]) for k in ("B", "C", "h", "w"))
+
+    def run(logits_np, nchan):
+        head = rcf_amd.FlowAggregationHeadWithResidual(
+            args=None, create_flownet=True, mask_layer=nchan, mask_size=(h, w), clamp_flow_t=20.,
+            free_residual=not bool(fx["affine"]), free_residual_with_affine=bool(fx["affine"]),
+            free_residual_with_affine_quadratic=bool(fx["quadratic"]), allow_residual_resize=True,
+            outlier_robust_loss=bool(fx["robust"]))
+        shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+        head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=11).items()})
+        head = head.to(DEV)
+        model = types.SimpleNamespace(w_seg=1.0, w_entropy=0.0, w_pl=0, w_crf=0, compactness_head=None, w_sharpen=0,
+                                      t_sharpen=0.25, object_aware_sharpening=False,
+                                      args=types.SimpleNamespace(object_channel=None))
+        logits = Act(to_nhwc(logits_np.reshape(B * 2, nchan, h, w)))
+        hr, wr = fx["rfw"].shape[2:]                               # residual maps (half resolution): [B, (x|y) x C, hr, wr]
+        rfw, rbw = fx["rfw"].reshape(B, 2, C, hr, wr)[:, :, :nchan], fx["rbw"].reshape(B, 2, C, hr, wr)[:, :, :nchan]
+        res = Act(to_nhwc(np.concatenate([rfw.reshape(B, 2 * nchan, hr, wr), rbw.reshape(B, 2 * nchan, hr, wr)], axis=1)))
+        gfw, gbw = torch.from_numpy(fx["gfw"]).to(DEV), torch.from_numpy(fx["gbw"]).to(DEV)
+        losses, seed = head.loss_and_grads(model, logits, res, gfw, gbw, {}, B, 2)
+        seed(1.0)
+        return float(losses["loss_warp_seg"]), ops.nhwc_to_nchw(logits.grad, nchan).cpu().numpy().reshape(B, 2, nchan, h, w)
+
+    lg = fx["logits"].copy()                                   # [B, 2, C, h, w]
+    lg[:, :, C - 1] = -1.0e4                                   # the last segment: exp underflows on every pixel of every frame
+    loss_dead, g_dead = run(lg, C)
+    loss_ref, g_ref = run(np.ascontiguousarray(lg[:, :, :C - 1]), C - 1)
+    e_loss = abs(loss_dead - loss_ref) / abs(loss_ref)
+    e_g = rel(g_dead[:, :, :C - 1], g_ref)
+    report(f"flow head {tag}, segment of zero mass: loss {loss_dead:.6f} vs the head without that segment {loss_ref:.6f} "
+           f"({e_loss:.1e}); dlogits of the live segments {e_g:.1e}; dead segment's dlogits max {np.abs(g_dead[:, :, C - 1]).max():.1e}")
+    assert np.isfinite(loss_dead) and np.isfinite(g_dead).all()
+    assert e_loss < 1e-5 and e_g < 2e-4 and np.abs(g_dead[:, :, C - 1]).max() == 0.0
