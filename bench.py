@@ -257,7 +257,7 @@ def main():
             out["data_transform_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(_finite(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -396,6 +396,17 @@ def warp_bench(torch, rcf_amd, synth, dev, H, W, nframes=64):
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "us_per_frame": round(t_l1 / nframes * 1e6, 2),
             "flow_warp_GBps": round(px * 32.0 / t_w / 1e9, 1), "flow_warp_us_per_frame": round(t_w / nframes * 1e6, 2)}
+
+
+def _finite(o):
+    """strict JSON: a non-finite float (a diverged loss) becomes null instead of NaN / Infinity"""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
 
 
 def datapipe_bench(torch, rcf_amd, synth, dev, H, W, B):
