@@ -56,3 +56,29 @@ def test_transform_feeds_the_training_step_and_the_evaluator(precision, report):
     miou, frame_avg, per_seq = ev.test_epoch_end(current_epoch=0, testing=True)
     report(f"pipeline [{precision}]: transform -> 2 train steps (loss {vals[0]['loss']:.4f} -> {vals[1]['loss']:.4f}, loss_pl "
            f"{vals[0]['loss_pl']:.4f}) -> eval transform -> Evaluator mIoU {float(miou):.4f}")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_steps_are_bit_reproducible(precision, report):
+    """two runs of three steps from the same weights and batch (Dropout2d off): identical losses, gradients and parameters,
+    bit for bit -- fixed-order reductions everywhere (split-K, batch-norm sums, loss sums), no floating-point atomics"""
+    H, W, B = 96, 160, 2
+
+    def run():
+        args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_rep", object_channel=None, eval_save=False, eval_export=False)
+        model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN"))
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+        tr = rcf_amd.Trainer(model, device=torch.device(DEV), precision=precision)
+        nb = synth.make_batch(B, H, W, config_id=2)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+        batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+        out = []
+        for _ in range(3):
+            loss = float(tr.step(batch)["loss"])
+            out.append((loss, tr.fp.grad.clone(), tr.fp.flat.clone()))
+        return out
+    a, b = run(), run()
+    for (la, ga, pa), (lb, gb, pb) in zip(a, b):
+        assert la == lb and torch.equal(ga, gb) and torch.equal(pa, pb)
+    report(f"reproducibility [{precision}]: 3 steps twice, losses {[round(x[0], 5) for x in a]}, gradients and parameters bit-identical")
