@@ -382,3 +382,35 @@ def test_train_step_bitwise_reproducible(report):
     report(f"two identical steps: losses identical {same_loss}, gradients differing {len(bad_g)} of {len(out[0][1])}, "
            f"updated parameters differing {len(bad_p)}")
     assert same_loss and not bad_g and not bad_p, (bad_g[:5], bad_p[:5])
+
+
+def test_bn_buffers_after_two_steps_vs_oracle(report):
+    """running_mean / running_var / num_batches_tracked of every batch norm after two optimiser steps: the conv's statistics
+    reduction finalizes the norm on the device (rcf_conv2d_fwd_bnstats_*) -- against the oracle model taking the same two
+    steps with torch's BatchNorm2d and Adam"""
+    import rcf_torch as orc
+    H, W, B = 96, 160, 2
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    ora = _build(H, W, False, "cpu", orc.RCFModel)
+    tr = rcf_amd.Trainer(hip, lr=1e-4, weight_decay=1e-4, device=DEV)
+    opt = orc.make_optimizer(ora, 1e-4, 1e-4)
+    ora.train()
+    for i in range(2):
+        tr.step(_batch(B, H, W, DEV))
+        losses = ora(_batch(B, H, W, "cpu"))
+        opt.zero_grad()
+        losses["loss"].backward()
+        opt.step()
+    hs, os_ = hip.state_dict(), ora.state_dict()
+    worst_m = worst_v = 0.0
+    n = 0
+    for k, v in os_.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(hs[k]) == int(v) == 2, (k, int(hs[k]), int(v))
+            n += 1
+        elif k.endswith("running_mean"):
+            worst_m = max(worst_m, float((hs[k].cpu() - v).abs().max() / (v.abs().max() + 1e-6)))
+        elif k.endswith("running_var"):
+            worst_v = max(worst_v, rel(hs[k].cpu().numpy(), v.numpy()))
+    report(f"batch-norm buffers after 2 steps ({n} norms): running_mean {worst_m:.2e} running_var {worst_v:.2e}, num_batches_tracked exact")
+    assert n >= 50 and worst_m < 2e-3 and worst_v < 2e-3
