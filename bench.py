@@ -158,9 +158,10 @@ def main():
         return out
 
     # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel with the largest share of
-    # the step's kernel time, the 128x256 weight-gradient tile (it runs on the second stream beside the data gradients,
-    # so its live duration includes what the overlap costs it)
-    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_wgrad_h2t4")
+    # the step's kernel time -- since the weight gradient's split-K plan changed (round 2) that is the 128x256 data-gradient
+    # tile on the main stream (28.2 ms per step; forward 28.0, weight gradient 27.3 with one stream); while it runs, the
+    # weight gradients of the layer above share the chip from the second stream
+    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_dgrad_wide")
     dt, loss_val, prof, by32, by32s = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
     value = frames / dt
@@ -198,7 +199,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (B, H, W) == (8, 480, 854):
             tj = json.load(open(tpath))
-            if tj.get("family") == fam32:
+            if fam32 in tj.get("by_family", {}):
+                traffic = round(tj["by_family"][fam32]["hbm_bytes_per_launch"])
+            elif tj.get("family") == fam32:
                 traffic = round(tj["hbm_bytes_per_launch"])
         # The convs run as fp32 contractions on the fp16 matrix cores (each operand scaled and split into 2 fp16
         # parts, 3 partial products, fp32 accumulate): the bound is the dense fp16 MFMA peak / 3 passes.
@@ -206,8 +209,8 @@ def main():
         out["roofline"].update({"executed_fp16_mfma_tflops": round(3 * out["roofline"]["achieved"], 1),
                                 "fp16_mfma_peak": BF16_MFMA_PEAK_TF, "fp32_mfma_peak": FP32_MFMA_PEAK_TF,
                                 "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload), not measured in this run"})
-        out["roofline"]["note"] = ("this kernel runs on the second HIP stream beside the data gradients of the main stream (+8 % "
-                                   "frames/s): its live duration includes what sharing the chip costs it; "
+        out["roofline"]["note"] = ("the weight gradients run on a second HIP stream beside the data gradients of the main stream (+8 % "
+                                   "frames/s): a kernel's live duration includes what sharing the chip costs it; "
                                    "roofline_by_kernel_one_stream holds the same brackets with everything on one stream")
         if fam32 in by32s and by32s[fam32]["ms"] > 0:
             out["roofline"]["achieved_one_stream"] = round(by32s[fam32]["flops"] / (by32s[fam32]["ms"] * 1e-3) / 1e12, 2)
