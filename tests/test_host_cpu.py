@@ -140,3 +140,19 @@ def test_vit_state_dict_schema_matches_reference(golden_dir):
     fx = np.load(os.path.join(golden_dir, "vit_small8.npz"))
     mine = [f"{k}:{'x'.join(map(str, v.shape))}" for k, v in vit.vit_small(patch_size=8).state_dict().items()]
     assert mine == [str(s) for s in fx["schema"]]
+
+
+def test_bench_line_helpers():
+    """bench.py's host-side pieces that need no GPU: strict JSON (a diverged loss must not print NaN), the bracket families
+    the default headline names exist, flags parse"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("rcf_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    dirty = {"loss": float("nan"), "x": [1.0, float("inf"), {"y": -float("inf"), "z": 2}], "s": "ok", "n": None, "i": 3}
+    clean = b._finite(dirty)
+    assert clean == {"loss": None, "x": [1.0, None, {"y": None, "z": 2}], "s": "ok", "n": None, "i": 3}
+    json.loads(json.dumps(clean, allow_nan=False))
+    assert "conv_dgrad_wide" in b.FAMILIES_F32 and "conv_wgrad_h2t4" in b.FAMILIES_F32 and "conv_bf16_wgrad4" in b.FAMILIES_BF16
+    assert b.HBM_PEAK_GBS == 8000.0 and b.BF16_MFMA_PEAK_TF == 2500.0
