@@ -414,3 +414,21 @@ def test_bn_buffers_after_two_steps_vs_oracle(report):
             worst_v = max(worst_v, rel(hs[k].cpu().numpy(), v.numpy()))
     report(f"batch-norm buffers after 2 steps ({n} norms): running_mean {worst_m:.2e} running_var {worst_v:.2e}, num_batches_tracked exact")
     assert n >= 50 and worst_m < 2e-3 and worst_v < 2e-3
+
+
+def test_fullsize_b8_losses_vs_oracle(report):
+    """BASELINE configs[1] at its real batch: 8 pairs of 480x854 (16 frames through the backbone, SyncBN statistics over all
+    of them) -- every loss term of one training-mode forward against the oracle on the host (the reference-generated fixture
+    of this geometry holds one pair; the oracle is pinned to the reference on the small cases and on that pair)"""
+    import rcf_torch as orc
+    H, W, B = 480, 854, 8
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    ora = _build(H, W, False, "cpu", orc.RCFModel)
+    hip.train()
+    ora.train()
+    with torch.no_grad():
+        lh = hip(_batch(B, H, W, DEV))
+        lo = ora(_batch(B, H, W, "cpu"))
+    e = {k: rel(float(lh[k]), float(lo[k])) for k in lo}
+    report(f"480x854 b8 (16 frames): " + " ".join(f"{k} hip {float(lh[k]):.6f} oracle {float(lo[k]):.6f} ({e[k]:.1e})" for k in lo))
+    assert all(np.isfinite(float(v)) for v in lh.values()) and max(e.values()) < TOL
