@@ -117,3 +117,32 @@ def test_soft_ncut_vs_reference_golden(golden_dir, report):
     # Adam's first steps are sign-like (g / (|g| + 1e-8)); with lr 0.45 and the clamp the mask saturates, so the
     # comparison is on the final mask: every cell within 1e-3
     assert e_v < 1e-5 and d.max() < 1e-3
+
+
+def test_vit_small8_fullsize_vs_float64(golden_dir, report):
+    """480 x 856 (6 421 tokens: the size the semantic-constraint tools run, models/dino_vit.py on a 480p frame): the twelve
+    blocks and the final norm of the HIP model against the same arithmetic in float64 torch on the prepared tokens
+    (models/dino_vit.py:110-167: pre-norm attention + MLP blocks, softmax(q k^T / 8), GELU(erf), LayerNorm eps 1e-6).  The
+    reference fixture pins the small size end to end; this pins the attention / linear kernels at the real token count."""
+    fx = np.load(os.path.join(golden_dir, "vit_small8.npz"))
+    m = _model(fx)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, 480, 856, generator=g).to(DEV)
+    X0, B, T = m.prepare_tokens(x)
+    assert T == 60 * 107 + 1
+    out = m(x)[0].double()
+    X = X0.clone().double()
+    F = torch.nn.functional
+    nh = m.blocks[0].attn.num_heads
+    for blk in m.blocks:
+        h = F.layer_norm(X, (X.shape[1],), blk.norm1.weight.double(), blk.norm1.bias.double(), blk.norm1.eps)
+        qkv = (h @ blk.attn.qkv.weight.double().T + blk.attn.qkv.bias.double()).view(T, 3, nh, -1).permute(1, 2, 0, 3)
+        a = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * (qkv.shape[-1] ** -0.5), dim=-1) @ qkv[2]      # [nh, T, 64]
+        X = X + a.transpose(0, 1).reshape(T, -1) @ blk.attn.proj.weight.double().T + blk.attn.proj.bias.double()
+        h = F.layer_norm(X, (X.shape[1],), blk.norm2.weight.double(), blk.norm2.bias.double(), blk.norm2.eps)
+        X = X + F.gelu(h @ blk.mlp.fc1.weight.double().T + blk.mlp.fc1.bias.double()) @ blk.mlp.fc2.weight.double().T + blk.mlp.fc2.bias.double()
+    with torch.no_grad():
+        ref = F.layer_norm(X, (X.shape[1],), m.norm.weight.double(), m.norm.bias.double(), m.norm.eps)
+    e = float((out.detach() - ref.detach()).abs().max() / ref.detach().abs().max())
+    report(f"ViT-S/8 at 480x856 ({T} tokens), 12 blocks vs float64: max error / max |ref| {e:.2e}")
+    assert e < TOL
