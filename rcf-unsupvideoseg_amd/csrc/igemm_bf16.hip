@@ -73,6 +73,10 @@ __device__ __forceinline__ void region_yx(int pix, int ry0, int rx0, int rh, int
 }
 
 __device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
+// the same without a branch on the (uniform) divisor-is-one case: keeps a K-step's address arithmetic in one basic block
+__device__ __forceinline__ int fast_div_nb(int k, unsigned magic) {
+    return (int)(__umulhi((unsigned)k, magic) + ((unsigned)k & (magic ? 0u : ~0u)));
+}
 
 __device__ __forceinline__ u32x2 pack4(const f32x4 v) {
     const bf16x2 a = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), b = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
@@ -109,7 +113,7 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
 // registers, no ds_write pass); three LDS stages, the loads of K-step t+2 are issued before the MFMAs of step t and
 // stay in flight across the one barrier per step (counted s_waitcnt vmcnt).  The LDS image of a wave instruction is
 // lane-linear (1 KB = 16 rows x 64 B), so the XOR swizzle of the 16-byte chunks is applied to the SOURCE address.
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false, int NST = 3>
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false, int NST = 3, int SCHED = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
@@ -203,9 +207,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
             char *Bs = As + PA;
             const int k = kt * BKT + kq * 8;
             const bool kv = k < p.K;
-            const int rs = fast_div(k, p.cs_magic);
+            const int rs = SCHED != 0 ? fast_div_nb(k, p.cs_magic) : fast_div(k, p.cs_magic);
             const int c = k - rs * p.Cs;
-            const int r = fast_div(rs, p.s_magic);
+            const int r = SCHED != 0 ? fast_div_nb(rs, p.s_magic) : fast_div(rs, p.s_magic);
             const int s = rs - r * p.S;
             const int dy = r * p.step, dx = s * p.step;
             const int tapoff = (dy * p.Ws + dx) * p.a_pitch + c;
@@ -234,6 +238,40 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
         wait_next(-1);
         __builtin_amdgcn_s_barrier();
         int st = 0;                                       // stage of K-step kt
+        if constexpr (SCHED != 0) {
+            // steady state as ONE basic block (unconditional issue, constant wait count) so that the scheduler may place
+            // the LDS-DMA pieces among the MFMAs; the last AHEAD steps, which issue nothing, follow
+            int kt = 0;
+            for (; kt + AHEAD < KT; ++kt) {
+                const int stn = st + AHEAD >= NST ? st + AHEAD - NST : st + AHEAD;
+                const char *As = smem + st * STAGE;
+                mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+                issue(kt + AHEAD, stn);       // in program order BEHIND the fragment reads (LDS write after LDS reads)
+                if constexpr (SCHED == 1) {
+                    // both halves' fragments first, then one LDS-DMA piece behind each of the first MFMAs: a piece's issue
+                    // (tens of cycles) runs under the matrix pipe's work instead of ahead of it
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR - NLD, 0);
+                }
+                // the MFMAs may sink below the barrier (registers only); the fragment reads may not: the next step's
+                // pieces overwrite this stage
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * NLD) : "memory");
+                __builtin_amdgcn_s_barrier();
+                st = st == NST - 1 ? 0 : st + 1;
+            }
+            for (; kt < KT; ++kt) {
+                const char *As = smem + st * STAGE;
+                mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
+                wait_next(kt);
+                __builtin_amdgcn_s_barrier();
+                st = st == NST - 1 ? 0 : st + 1;
+            }
+        } else {
         for (int kt = 0; kt < KT; ++kt) {
             // stage (st + AHEAD) % NST was read a step ago: free since the last barrier
             const int stn = st + AHEAD >= NST ? st + AHEAD - NST : st + AHEAD;
@@ -243,6 +281,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
             wait_next(kt);
             __builtin_amdgcn_s_barrier();
             st = st == NST - 1 ? 0 : st + 1;
+        }
         }
     } else {
     // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets); B (weights, L2) one step ahead
@@ -485,7 +524,12 @@ struct WgradParams {
     int beta;          // only honoured when gridDim.z == 1
     int ry0, rx0, rh, rw, rband, rr;
     int Ktot;          // R*S*Cin: the GEMM columns are (tap, input channel) pairs
+    int sched;         // LDS-DMA kernel: 1 = pieces interleaved with the MFMAs (default), 0 = ahead of them (A/B reference)
 };
+
+// byte offset `off` if ok == 1, an out-of-range offset (the load returns zeros) if ok == 0 -- arithmetic, so that a
+// K-step's loads stay in one basic block
+__device__ __forceinline__ unsigned oob_unless(unsigned off, int ok) { return (off & ~OOB) | ((unsigned)(ok - 1) & OOB); }
 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
@@ -676,6 +720,36 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
     }
 }
 
+// one K-step of the LDS-DMA weight-gradient kernel: two 16-pixel substeps, fragments through the transposing reads.
+// `As` / `Bs` are __restrict__ on purpose: inlined, the reads carry no-alias scopes against the kernel's LDS-DMA writes --
+// without them the compiler puts `s_waitcnt vmcnt(0)` in front of the first read of every K-step (it must assume the
+// pieces in flight, which target ANOTHER stage, could alias) and the loads of later steps no longer stay in flight.
+template <int MR, int NR>
+__device__ __forceinline__ void wgrad_tr_step(const char *__restrict__ As, const char *__restrict__ Bs, const int (&fa)[MR],
+                                              const int (&fb)[NR], f32x16 (&acc)[MR][NR]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bf16x8 a[MR], b[NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const u32x2 lo = lds_tr16(As + fa[mr] + 16 * j * 128);
+            const u32x2 hi = lds_tr16(As + fa[mr] + 16 * j * 128 + 4 * 128);
+            a[mr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const u32x2 lo = lds_tr16(Bs + fb[nr] + 16 * j * 128);
+            const u32x2 hi = lds_tr16(Bs + fb[nr] + 16 * j * 128 + 4 * 128);
+            b[nr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        }
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+    }
+}
+
 // The 128-row tiles again with LDS-DMA loads (buffer_load ... lds), three LDS stages and one barrier per K-step, like
 // conv_bf16_kernel<..., DMA>.  LDS image per operand: [channel group of 64][32 pixels][128 B] -- a DMA instruction (1 KB,
 // lane-linear) is 8 pixel rows of ONE channel group, so every thread serves ONE pixel (8 wave + lane / 8) in all of its
@@ -737,7 +811,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
         actb[g] = jc < p.Ktot;
     }
     const int wb = __builtin_amdgcn_readfirstlane(wave) * 1024;    // 8 pixel rows x 128 B of each group
-    auto issue = [&](int kt, int stage) {                  // K-steps are issued in order: the walk advances by BK each time
+    auto loads = [&](int kt, int stage) {                  // K-steps are issued in order: the walk advances by BK each time
         char *As = smem + stage * STAGE + wb;
         char *Bs = smem + stage * STAGE + PLA + wb;
         const int mk = kt * BK + prow;
@@ -745,35 +819,41 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
         const int dyoff = REGION ? ((pn * p.Ho + py) * p.Wo + px) * p.dy_pitch : mk * p.dy_pitch;
 #pragma unroll
         for (int g = 0; g < GA; ++g) {
-            const unsigned bo = (inb && acta[g]) ? (unsigned)(dyoff + cha[g]) * 2u : OOB;
+            const unsigned bo = oob_unless((unsigned)(dyoff + cha[g]) * 2u, (int)inb & (int)acta[g]);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(As + g * GSZ), 16, (int)bo, 0, 0, 0);
         }
         if constexpr (ONETAP) {
             const int sy = py * p.stride - p.pad + tr[0] * p.dil, sx = px * p.stride - p.pad + ts[0] * p.dil;
-            const bool v = inb && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const int v = (int)inb & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
             const int xoff = ((pn * p.H + sy) * p.W + sx) * p.x_pitch;
 #pragma unroll
             for (int g = 0; g < GB; ++g) {
-                const unsigned bo = (v && actb[g]) ? (unsigned)(xoff + chb[g]) * 2u : OOB;
+                const unsigned bo = oob_unless((unsigned)(xoff + chb[g]) * 2u, (int)v & (int)actb[g]);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(Bs + g * GSZ), 16, (int)bo, 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int g = 0; g < GB; ++g) {
                 const int sy = py * p.stride - p.pad + tr[g] * p.dil, sx = px * p.stride - p.pad + ts[g] * p.dil;
-                const bool v = inb && actb[g] && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
-                const unsigned bo = v ? (unsigned)(((pn * p.H + sy) * p.W + sx) * p.x_pitch + chb[g]) * 2u : OOB;
+                const int v = (int)inb & (int)actb[g] & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
+                const unsigned bo = oob_unless((unsigned)(((pn * p.H + sy) * p.W + sx) * p.x_pitch + chb[g]) * 2u, v);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void *)(Bs + g * GSZ), 16, (int)bo, 0, 0, 0);
             }
         }
-        if (incr) {                              // Wo >= BK: at most one row wrap per K-step
-            px += BK;
-            const bool wx = px >= p.Wo;
-            px -= wx ? p.Wo : 0;
-            py += wx ? 1 : 0;
-            const bool wy = py == p.Ho;
-            py = wy ? 0 : py;
-            pn += wy ? 1 : 0;
+    };
+    auto advance_rows = [&]() {                  // Wo >= BK: at most one row wrap per K-step (no branches)
+        px += BK;
+        const bool wx = px >= p.Wo;
+        px -= wx ? p.Wo : 0;
+        py += wx ? 1 : 0;
+        const bool wy = py == p.Ho;
+        py = wy ? 0 : py;
+        pn += wy ? 1 : 0;
+    };
+    auto issue = [&](int kt, int stage) {
+        loads(kt, stage);
+        if (incr) {
+            advance_rows();
         } else {
             ppix += BK;
             while (ppix >= HoWo) { ppix -= HoWo; ++pn; }
@@ -810,28 +890,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
         fb[nr] = (c >> 6) * GSZ + fprow * 128 + ((((c >> 3) & 7) ^ swz) << 4) + wi;
     }
     auto mma = [&](int stage) {
-        const char *As = smem + stage * STAGE, *Bs = As + PLA;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                     // two 16-pixel substeps
-            bf16x8 a[MR], b[NR];
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                const u32x2 lo = lds_tr16(As + fa[mr] + 16 * j * 128);
-                const u32x2 hi = lds_tr16(As + fa[mr] + 16 * j * 128 + 4 * 128);
-                a[mr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-            }
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                const u32x2 lo = lds_tr16(Bs + fb[nr] + 16 * j * 128);
-                const u32x2 hi = lds_tr16(Bs + fb[nr] + 16 * j * 128 + 4 * 128);
-                b[nr] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-            }
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < NR; ++nr)
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
-        }
+        const char *As = smem + stage * STAGE;
+        wgrad_tr_step<MR, NR>(As, As + PLA, fa, fb, acc);
     };
 
     constexpr int NLD = GA + GB;
@@ -841,9 +901,29 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
     if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int st = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int st2 = st >= 1 ? st - 1 : 2;             // (st + 2) % 3
+    int st = 0, kt = 0;
+    if (incr && p.sched) {
+        // steady state as ONE basic block (conv_bf16_kernel<..., SCHED = 1>): fragment reads, then one LDS-DMA piece behind
+        // each of the first MFMAs
+        for (; kt + 2 < KT; ++kt) {
+            const int st2 = st >= 1 ? st - 1 : 2;         // (st + 2) % 3
+            mma(st);
+            loads(kt + 2, st2);
+            advance_rows();
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MR + NR), 0);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR - NLD, 0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
+            __builtin_amdgcn_s_barrier();
+            st = st == 2 ? 0 : st + 1;
+        }
+    }
+    for (; kt < KT; ++kt) {
+        const int st2 = st >= 1 ? st - 1 : 2;
         if (kt + 2 < KT) issue(kt + 2, st2);
         mma(st);
         if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
@@ -924,18 +1004,19 @@ int set_region(ConvParams &p, const rcf_conv_region *r, int N, int H, int W) {
     return 0;
 }
 
-int g_bf16_tile = -1;      // -1 / 4: LDS-DMA kernels (128x64 / 128x128 / 128x256 by width), 5: LDS-DMA 256x256 (512 threads);
+int g_bf16_tile = -1;      // -1: LDS-DMA kernels (128x64 / 128x128 / 128x256 by width), pieces interleaved with the MFMAs;
+                           // 4: the same with the pieces ahead of the MFMAs; 5: LDS-DMA 256x256 (512 threads);
                            // register-staged A/B references: 0 128x128, 1 128x256, 2 256x256, 3 128x64
 
-template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false, int NST = 3>
+template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false, int NST = 3, int SCHED = 0>
 void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
-    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
-    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA, NST>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 template <bool OBF>
@@ -956,12 +1037,17 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     else if (tile == 0) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
     else if (tile == 2) launch_cfg<2, 4, 4, 2, OBF>(p, strided, dgrad, st);
     else if (tile == 1) launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true>(p, strided, dgrad, st);
-    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true>(p, strided, dgrad, st);
+    else if (tile == 4) {     // LDS-DMA, pieces issued ahead of the K-step's MFMAs (A/B reference of the interleaved form)
+        if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true>(p, strided, dgrad, st);
+        else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true>(p, strided, dgrad, st);
+        else launch_cfg<2, 4, 2, 2, OBF, true>(p, strided, dgrad, st);
+    }
     else if (tile == 5) launch_cfg<2, 4, 4, 2, OBF, true>(p, strided, dgrad, st);       // 256x256, 8 waves
     else if (tile == 6) launch_cfg<2, 4, 4, 2, OBF, true, 4>(p, strided, dgrad, st);    // 256x256, four LDS stages (128 KB)
     else if (tile == 7) launch_cfg<2, 4, 2, 2, OBF, true, 4>(p, strided, dgrad, st);    // 128x256, four stages: one workgroup per CU
-    else launch_cfg<2, 4, 2, 2, OBF, true>(p, strided, dgrad, st);
+    else if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
+    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
+    else launch_cfg<2, 4, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1144,6 +1230,7 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     p.Ktot = s->R * s->S * s->Cin;
+    p.sched = g_bf16_tile == 4 ? 0 : 1;
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), 1u, (unsigned)pl.splitk);
 #define RCF_WG(MRv, NRv)                                                                              \
     do {                                                                                              \
