@@ -276,11 +276,11 @@ FAMILIES_F32 = {
     "conv_wgrad_other": "igemm_wgrad_h2t_kernel<2> / igemm_wgrad_x3_kernel / igemm_wgrad_kernel (weight gradient: narrow tiles, regions, stem)",
 }
 FAMILIES_BF16 = {
-    "conv_bf16_fwd": "conv_bf16_kernel<2,4,2,2,false,false,true> (forward, bf16 operands, 128x256 tile; incl. the fused BN statistics sums)",
+    "conv_bf16_fwd": "conv_bf16_kernel<2,4,2,2,false,false,true,true,3,1> (forward, bf16 operands, 128x256 tile, LDS-DMA loads interleaved with the MFMAs; incl. the fused BN statistics sums)",
     "conv_bf16_fwd_narrow": "conv_bf16_kernel<2,{1,2},2,2,...> (forward, <= 128 output channels)",
-    "conv_bf16_dgrad_wide": "conv_bf16_kernel<2,4,2,2,false,true,true> (data gradient, 128x256 tile; incl. the bf16 weight transpose)",
+    "conv_bf16_dgrad_wide": "conv_bf16_kernel<2,4,2,2,false,true,true,true,3,1> (data gradient, 128x256 tile, LDS-DMA loads; incl. the bf16 weight transpose)",
     "conv_bf16_dgrad_other": "conv_bf16_kernel<...> (data gradient: strided / narrow tiles)",
-    "conv_bf16_wgrad4": "wgrad_bf16_kernel<2,4,false> (weight gradient, bf16 operands, 128x256 tile over (tap, channel) columns; incl. the split-K reduction)",
+    "conv_bf16_wgrad4": "wgrad_bf16_dma_kernel<4,false,*> (weight gradient, bf16 operands, 128x256 tile over (tap, channel) columns, LDS-DMA loads, transposing LDS reads; incl. the split-K reduction)",
     "conv_bf16_wgrad_other": "wgrad_bf16_kernel<1,*,*> / <2,{1,2},*> / <2,4,true> (weight gradient: narrow tiles, regions)",
     # the fp32 stem and the flow head's two small convs keep the fp32 kernels in the bf16 step
     "conv_x3_128x256": FAMILIES_F32["conv_x3_128x256"], "conv_fwd_narrow": FAMILIES_F32["conv_fwd_narrow"],

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                 const char *As = smem + st * STAGE;
                 mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
                 issue(kt + AHEAD, stn);       // in program order BEHIND the fragment reads (LDS write after LDS reads)
-                if constexpr (SCHED == 1) {
+                if constexpr (SCHED >= 1) {
                     // both halves' fragments first, then one LDS-DMA piece behind each of the first MFMAs: a piece's issue
                     // (tens of cycles) runs under the matrix pipe's work instead of ahead of it
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);

@@ -19,6 +19,7 @@
 // Block -> tile mapping is XCD aware: workgroup b runs on XCD b%8 (MI355X_MICROARCH.md), so the
 // 8 consecutive ids take 8 different row tiles and ids b, b+8, b+16.. walk the column tiles of the
 // same row tile: the activation tile is re-read from that XCD's own L2.
+#include <type_traits>
 #include "rcf_common.h"
 
 #include <cstdlib>
@@ -408,13 +409,26 @@ __device__ __forceinline__ int h2_exponent(unsigned amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
 
+// x * s = h + m + (rest below 2^-22 |x s|), h and m in fp16: h = fp16(x s) (s is a power of two: the product is exact),
+// m = fp16(x s - h) (the difference is exact in fp32).  Two values per register pair through gfx950's mixed-precision FMAs:
+// v_fma_mix{lo,hi}_f16 evaluate fma(fp32, fp32, fp32-or-fp16) in fp32 and round the result once to fp16 into the low /
+// high half of the destination -- 8 instructions per four values where multiply / convert / convert back / subtract /
+// convert took 14 (the weight-gradient kernel, which splits both operands, spent 10 VALU instructions per MFMA).
+// `- 0.0` as the addend keeps the sign of a zero product.
+__device__ __forceinline__ unsigned split2h_pair(float a, float b, float s, unsigned &m) {
+    unsigned h;
+    const float nz = -0.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(h) : "v"(a), "v"(s), "v"(nz));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(h) : "v"(b), "v"(s), "v"(nz));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(b), "v"(s), "v"(h));
+    return h;
+}
 __device__ __forceinline__ void split2h(const f32x4 v, float s, u32x2 &h, u32x2 &m) {
-    const f32x2 a = {v[0] * s, v[1] * s}, b = {v[2] * s, v[3] * s};
-    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
-    const f16x2 ma = __builtin_convertvector(ra, f16x2), mb = __builtin_convertvector(rb, f16x2);
-    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    unsigned m0, m1;
+    const unsigned h0 = split2h_pair(v[0], v[1], s, m0), h1 = split2h_pair(v[2], v[3], s, m1);
+    h = u32x2{h0, h1};
+    m = u32x2{m0, m1};
 }
 
 // amax[0] = max(amax[0], bits(max |x|)) over a [rows][C] matrix with row pitch `pitch`: for non-negative floats the
@@ -501,6 +515,8 @@ __device__ __forceinline__ void mma_x3(const char *__restrict__ As, const char *
 }
 
 constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descriptor's num_records: loads return 0
+// `off` if ok == 1, an out-of-range offset if ok == 0: arithmetic (a select on a load's address tends to become a branch)
+__device__ __forceinline__ unsigned x3_oob_unless(unsigned off, int ok) { return (off & ~X3_OOB) | ((unsigned)(ok - 1) & X3_OOB); }
 
 // forward / dgrad with k-contiguous weights B[j][k] (dgrad: the [Cin][R][S][Cout] transposed copy).
 // Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32: tile (32 MR WM) x (32 NR WN).
@@ -1417,7 +1433,9 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_wide_kernel(WgradParams
 // the global loads of a K-step are whole runs of 512 B / 1 KB per pixel), and the MFMA's k-contiguous fragments come out
 // of gfx950's transposing LDS read: ds_read_b64_tr_b16 gives lane c of a 16-lane group the 4 k-values of channel
 // c0 + c when lane p of the group points at row k0 + p/4, channels c0 + 4 (p%4) .. +3.  No register transposes, no
-// row permutation.  Row pitch = channels * 2 + 32 bytes: the 4 rows a group reads fall into 4 different bank octets.
+// row permutation.  Row pitch = channels * 2 + 64 bytes: the 64-byte runs that a 32-lane half reads from 4 rows tile the
+// 256-byte bank space (a pitch of 32 mod 256 made neighbouring rows overlap by half: SQ_LDS_BANK_CONFLICT 33 % of the
+// LDS cycles).
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -1430,7 +1448,7 @@ template <int NR>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
     constexpr int MR = 2, BM = 128, BN = 64 * NR;
     constexpr int QB = BN / 4, PBS = 256 / QB, NBP = BK / PBS;      // x loader: channel quads per pixel, pixels per pass, passes
-    constexpr int PIA = BM * 2 + 32, PIB = BN * 2 + 32;          // row (pixel) pitch of the dy / x planes, bytes
+    constexpr int PIA = BM * 2 + 64, PIB = BN * 2 + 64;          // row (pixel) pitch of the dy / x planes, bytes (= 64 mod 256)
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -1457,55 +1475,68 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     const int qb = tid % QB, pb0 = tid / QB;
     const int cha = i0 + 4 * qa, chb = j0 + 4 * qb;
     const bool acta = cha < p.Cout, actb = chb < p.Cin;
-    int pn[NBP], py[NBP], px_[NBP];
-#pragma unroll
-    for (int j = 0; j < NBP; ++j) {
-        const long m = kbeg + pb0 + PBS * j;
-        pn[j] = (int)(m / HoWo);
-        const int pix = (int)(m - (long)pn[j] * HoWo);
-        py[j] = pix / p.Wo;
-        px_[j] = pix - py[j] * p.Wo;
-        pn[j] -= n_first;
+    // pixel walk of the x loader: the position of the thread's FIRST pixel (pb0) of the current K-step; its other pixels
+    // (+ PBS j < BK) are derived from it (Wo >= BK: at most one row wrap on the way), which keeps the state at three
+    // registers.  Images narrower than a K-step take the division path.
+    int pn, py, px_;
+    {
+        const long m = kbeg + pb0;
+        pn = (int)(m / HoWo);
+        const int pix = (int)(m - (long)pn * HoWo);
+        py = pix / p.Wo;
+        px_ = pix - py * p.Wo;
+        pn -= n_first;
     }
     const bool incr = p.Wo >= BK;
 
-    f32x4 ra[2], rb[NBP];
-    auto load_tile = [&](int kt) {
+    // both operands come from HBM: their loads run TWO K-steps ahead (two register sets, ping-pong by the parity of the step)
+    f32x4 ra[2][2], rb[2][NBP];
+    auto load_tile = [&](auto INCR, int kt, f32x4 (&ra)[2], f32x4 (&rb)[NBP]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int mk = kt * BK + pa0 + 8 * j;
-            const unsigned bo = (acta && mk < klen) ? (unsigned)(mk * p.dy_pitch + cha) * 4u : X3_OOB;
+            const unsigned bo = x3_oob_unless((unsigned)(mk * p.dy_pitch + cha) * 4u, (int)acta & (int)(mk < klen));
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < NBP; ++j) {
             const int mk = kt * BK + pb0 + PBS * j;
-            const int sy = py[j] * p.stride - p.pad + r * p.dil;
-            const int sx = px_[j] * p.stride - p.pad + s * p.dil;
-            const bool v = actb && mk < klen && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
-            const unsigned bo = v ? (unsigned)(((pn[j] * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 4u : X3_OOB;
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
-            if (incr) {
-                px_[j] += BK;
-                const bool wx = px_[j] >= p.Wo;
-                px_[j] -= wx ? p.Wo : 0;
-                py[j] += wx ? 1 : 0;
-                const bool wy = py[j] == p.Ho;
-                py[j] = wy ? 0 : py[j];
-                pn[j] += wy ? 1 : 0;
+            int n, y, x;
+            if constexpr (decltype(INCR)::value) {
+                x = px_ + PBS * j;
+                const bool wx = x >= p.Wo;
+                x -= wx ? p.Wo : 0;
+                y = py + (wx ? 1 : 0);
+                const bool wy = y == p.Ho;
+                y = wy ? 0 : y;
+                n = pn + (wy ? 1 : 0);
             } else {
-                const long mn = kbeg + (long)(kt + 1) * BK + pb0 + PBS * j;
-                const int nn = (int)(mn / HoWo);
-                const int pix = (int)(mn - (long)nn * HoWo);
-                pn[j] = nn - n_first;
-                py[j] = pix / p.Wo;
-                px_[j] = pix - py[j] * p.Wo;
+                const long m = kbeg + mk;
+                const int nn = (int)(m / HoWo);
+                const int pix = (int)(m - (long)nn * HoWo);
+                n = nn - n_first;
+                y = pix / p.Wo;
+                x = pix - y * p.Wo;
             }
+            const int sy = y * p.stride - p.pad + r * p.dil;
+            const int sx = x * p.stride - p.pad + s * p.dil;
+            const int v = (int)actb & (int)(mk < klen) & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
+            const unsigned bo = x3_oob_unless((unsigned)(((n * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 4u, v);
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+        }
+        if constexpr (decltype(INCR)::value) {       // K-steps are loaded in order: advance the first pixel by BK
+            px_ += BK;
+            const bool wx = px_ >= p.Wo;
+            px_ -= wx ? p.Wo : 0;
+            py += wx ? 1 : 0;
+            const bool wy = py == p.Ho;
+            py = wy ? 0 : py;
+            pn += wy ? 1 : 0;
         }
     };
     const int ka = h2_exponent(*p.amax_a), kb = h2_exponent(*p.amax_b);
     const float sa = pow2f(ka), sb = pow2f(kb);
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[NBP]) {
         char *As = smem + buf * STAGE, *Bs = As + 2 * PLA;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1569,18 +1600,35 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     };
 
     const int KT = (klen + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt + 1 < KT; ++kt) {
-        const int cur = kt & 1;
-        load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(cur);
-        store_tile(cur ^ 1);
+    // K-step kt: MFMAs on stage kt & 1 while the tiles of steps kt + 1 (loaded a step ago) and kt + 2 are in flight; then
+    // tile kt + 1 is split into the other stage
+    auto k_loop = [&](auto INCR) {
+        load_tile(INCR, 0, ra[0], rb[0]);
+        load_tile(INCR, 1, ra[1], rb[1]);    // past the end of the chunk: out-of-range offsets, zeros
+        store_tile(0, ra[0], rb[0]);
         __syncthreads();
-    }
-    mma((KT - 1) & 1);
+        int kt = 0;
+        for (; kt + 2 < KT; kt += 2) {
+            load_tile(INCR, kt + 2, ra[0], rb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            store_tile(1, ra[1], rb[1]);
+            __syncthreads();
+            load_tile(INCR, kt + 3, ra[1], rb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            store_tile(0, ra[0], rb[0]);
+            __syncthreads();
+        }
+        mma(0);
+        if (kt + 1 < KT) {
+            store_tile(1, ra[1], rb[1]);
+            __syncthreads();
+            mma(1);
+        }
+    };
+    if (incr) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const long row_pitch = (long)p.R * p.S * p.Cin;
