@@ -1447,7 +1447,7 @@ __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
 template <int NR>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
     constexpr int MR = 2, BM = 128, BN = 64 * NR;
-    constexpr int QB = BN / 4, PBS = 256 / QB, NBP = BK / PBS;      // x loader: channel quads per pixel, pixels per pass, passes
+    constexpr int QB = BN / 4, NBP = QB / 16;                       // x loader: channel quads per pixel, quads per thread
     constexpr int PIA = BM * 2 + 64, PIB = BN * 2 + 64;          // row (pixel) pitch of the dy / x planes, bytes (= 64 mod 256)
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -1470,14 +1470,15 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
 
     // loader roles.  dy: item t + 256 j (j < 2) = pixel (t >> 5) + 8 j, channel quad t & 31.
-    //                x:  item t + 256 j (j < NBP) = pixel t / QB + PBS j, channel quad t % QB.
+    //                x:  thread t serves ONE pixel (t >> 4) of the K-step and the channel quads (t & 15) + 16 j (j < NBP): one
+    //                    pixel walk and one bounds test per K-step (the kernel spent as many VALU instructions on addresses as
+    //                    on splitting); 16 lanes x 16 B = 256 contiguous bytes per pixel and instruction
     const int qa = tid & 31, pa0 = tid >> 5;
-    const int qb = tid % QB, pb0 = tid / QB;
+    const int qb = tid & 15, pb0 = tid >> 4;
     const int cha = i0 + 4 * qa, chb = j0 + 4 * qb;
-    const bool acta = cha < p.Cout, actb = chb < p.Cin;
-    // pixel walk of the x loader: the position of the thread's FIRST pixel (pb0) of the current K-step; its other pixels
-    // (+ PBS j < BK) are derived from it (Wo >= BK: at most one row wrap on the way), which keeps the state at three
-    // registers.  Images narrower than a K-step take the division path.
+    const bool acta = cha < p.Cout;
+    // pixel walk of the x loader: the position of the thread's pixel (pb0) of the current K-step, advanced by BK per step
+    // (Wo >= BK: at most one row wrap).  Images narrower than a K-step take the division path.
     int pn, py, px_;
     {
         const long m = kbeg + pb0;
@@ -1498,18 +1499,11 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
             const unsigned bo = x3_oob_unless((unsigned)(mk * p.dy_pitch + cha) * 4u, (int)acta & (int)(mk < klen));
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
-#pragma unroll
-        for (int j = 0; j < NBP; ++j) {
-            const int mk = kt * BK + pb0 + PBS * j;
+        {
+            const int mk = kt * BK + pb0;
             int n, y, x;
             if constexpr (decltype(INCR)::value) {
-                x = px_ + PBS * j;
-                const bool wx = x >= p.Wo;
-                x -= wx ? p.Wo : 0;
-                y = py + (wx ? 1 : 0);
-                const bool wy = y == p.Ho;
-                y = wy ? 0 : y;
-                n = pn + (wy ? 1 : 0);
+                n = pn; y = py; x = px_;
             } else {
                 const long m = kbeg + mk;
                 const int nn = (int)(m / HoWo);
@@ -1520,9 +1514,13 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
             }
             const int sy = y * p.stride - p.pad + r * p.dil;
             const int sx = x * p.stride - p.pad + s * p.dil;
-            const int v = (int)actb & (int)(mk < klen) & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
-            const unsigned bo = x3_oob_unless((unsigned)(((n * p.H + sy) * p.W + sx) * p.x_pitch + chb) * 4u, v);
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+            const int v = (int)(mk < klen) & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
+            const int xoff = ((n * p.H + sy) * p.W + sx) * p.x_pitch + chb;
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) {
+                const unsigned bo = x3_oob_unless((unsigned)(xoff + 64 * j) * 4u, v & (int)(chb + 64 * j < p.Cin));
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+            }
         }
         if constexpr (decltype(INCR)::value) {       // K-steps are loaded in order: advance the first pixel by BK
             px_ += BK;
@@ -1550,7 +1548,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         for (int j = 0; j < NBP; ++j) {
             u32x2 h, m;
             split2h(rb[j], sb, h, m);
-            char *d = Bs + (pb0 + PBS * j) * PIB + qb * 8;
+            char *d = Bs + pb0 * PIB + (qb + 16 * j) * 8;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PLB) = m;
         }
