@@ -1443,42 +1443,54 @@ __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-// NR = 4: 128 x 256 tile; NR = 2: 128 x 128 (operands too narrow for the wide tile)
-template <int NR>
+// NR = 4: 128 x 256 tile; NR = 2: 128 x 128 (operands too narrow for the wide tile).
+// The GEMM columns are (tap, input channel) pairs, j = rs * Cin + c -- the weight's own memory order -- and not grid rows:
+// a tile of a narrow layer (Cin = 64: 576 columns of a 3x3 filter) spans several taps, so dy is read once per 256 columns
+// instead of once per tap.  Cin % 64 == 0: each of a thread's 64-channel groups lies in ONE tap, which is block-uniform
+// (scalar registers).  ONETAP: Cin % BN == 0, the whole tile belongs to one tap.
+// REGION: only the pixels of p's rectangle / frame contribute (M = N * rr); the pixel walk divides.
+template <int NR, bool REGION, bool ONETAP>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
     constexpr int MR = 2, BM = 128, BN = 64 * NR;
-    constexpr int QB = BN / 4, NBP = QB / 16;                       // x loader: channel quads per pixel, quads per thread
+    constexpr int NAP = BM / 64, NBP = BN / 64;                  // 64-channel groups per thread: dy, x
     constexpr int PIA = BM * 2 + 64, PIB = BN * 2 + 64;          // row (pixel) pitch of the dy / x planes, bytes (= 64 mod 256)
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
-    const int rs = (int)blockIdx.y;
-    const int r = rs / p.S, s = rs - r * p.S;
+    const int Ktot = p.R * p.S * p.Cin;
     const long kbeg = (long)blockIdx.z * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
     const int klen = (int)(kend - kbeg);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int HoWo = p.Ho * p.Wo;
+    const int HoWo = p.rr;                                    // contributing pixels per image
     const int n_first = (int)(kbeg / HoWo);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.DY + kbeg * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
+        const_cast<float *>(p.DY + (REGION ? (long)n_first * p.Ho * p.Wo : kbeg) * p.dy_pitch), 0, (int)X3_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.X + (long)n_first * p.H * p.W * p.x_pitch), 0, (int)X3_OOB, 0x00020000);
 
-    // loader roles.  dy: item t + 256 j (j < 2) = pixel (t >> 5) + 8 j, channel quad t & 31.
-    //                x:  thread t serves ONE pixel (t >> 4) of the K-step and the channel quads (t & 15) + 16 j (j < NBP): one
-    //                    pixel walk and one bounds test per K-step (the kernel spent as many VALU instructions on addresses as
-    //                    on splitting); 16 lanes x 16 B = 256 contiguous bytes per pixel and instruction
-    const int qa = tid & 31, pa0 = tid >> 5;
-    const int qb = tid & 15, pb0 = tid >> 4;
-    const int cha = i0 + 4 * qa, chb = j0 + 4 * qb;
-    const bool acta = cha < p.Cout;
-    // pixel walk of the x loader: the position of the thread's pixel (pb0) of the current K-step, advanced by BK per step
-    // (Wo >= BK: at most one row wrap).  Images narrower than a K-step take the division path.
+    // loader roles: thread t serves ONE pixel (t >> 4) of the K-step in both operands -- channel quads (t & 15) + 16 j of dy
+    // (j < NAP) and of x (j < NBP): one pixel walk and one bounds test per K-step (the kernel used to spend as many VALU
+    // instructions on addresses as on splitting); 16 lanes x 16 B = 256 contiguous bytes per pixel and instruction
+    const int q0 = tid & 15, pb0 = tid >> 4;
+    const int cha = i0 + 4 * q0;
+    // block-uniform taps of the 64-column groups (scalar)
+    int tdy[NBP], tdx[NBP], cb[NBP];
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) {
+        const int jc = j0 + (ONETAP ? 0 : 64 * j);
+        const int rs = jc / p.Cin;
+        const int r = rs / p.S;
+        tdy[j] = r * p.dil - p.pad;
+        tdx[j] = (rs - r * p.S) * p.dil - p.pad;
+        cb[j] = j0 + 64 * j - rs * p.Cin;                     // first channel of the group inside its tap
+    }
+    // pixel walk: the position of the thread's pixel of the current K-step, advanced by BK per step (Wo >= BK: at most one
+    // row wrap).  Narrow images and regions take the division path.
     int pn, py, px_;
     {
         const long m = kbeg + pb0;
@@ -1488,41 +1500,55 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         px_ = pix - py * p.Wo;
         pn -= n_first;
     }
-    const bool incr = p.Wo >= BK;
+    const bool incr = !REGION && p.Wo >= BK;
 
     // both operands come from HBM: their loads run TWO K-steps ahead (two register sets, ping-pong by the parity of the step)
-    f32x4 ra[2][2], rb[2][NBP];
-    auto load_tile = [&](auto INCR, int kt, f32x4 (&ra)[2], f32x4 (&rb)[NBP]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int mk = kt * BK + pa0 + 8 * j;
-            const unsigned bo = x3_oob_unless((unsigned)(mk * p.dy_pitch + cha) * 4u, (int)acta & (int)(mk < klen));
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
-        }
-        {
-            const int mk = kt * BK + pb0;
-            int n, y, x;
-            if constexpr (decltype(INCR)::value) {
-                n = pn; y = py; x = px_;
+    f32x4 ra[2][NAP], rb[2][NBP];
+    auto load_tile = [&](auto INCR, int kt, f32x4 (&ra)[NAP], f32x4 (&rb)[NBP]) {
+        const int mk = kt * BK + pb0;
+        int n, y, x;
+        if constexpr (decltype(INCR)::value) {
+            n = pn; y = py; x = px_;
+        } else {
+            const long m = kbeg + mk;
+            const int nn = (int)(m / HoWo);
+            const int pix = (int)(m - (long)nn * HoWo);
+            n = nn - n_first;
+            if constexpr (REGION) {
+                region_yx(pix, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
             } else {
-                const long m = kbeg + mk;
-                const int nn = (int)(m / HoWo);
-                const int pix = (int)(m - (long)nn * HoWo);
-                n = nn - n_first;
                 y = pix / p.Wo;
                 x = pix - y * p.Wo;
             }
-            const int sy = y * p.stride - p.pad + r * p.dil;
-            const int sx = x * p.stride - p.pad + s * p.dil;
-            const int v = (int)(mk < klen) & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
-            const int xoff = ((n * p.H + sy) * p.W + sx) * p.x_pitch + chb;
+        }
+        const int inb = (int)(mk < klen);
+        const int dyoff = (REGION ? ((n * p.Ho + y) * p.Wo + x) * p.dy_pitch : mk * p.dy_pitch) + cha;
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) {
+            const unsigned bo = x3_oob_unless((unsigned)(dyoff + 64 * j) * 4u, inb & (int)(cha + 64 * j < p.Cout));
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
+        }
+        const int ys = y * p.stride, xs = x * p.stride;
+        if constexpr (ONETAP) {
+            const int sy = ys + tdy[0], sx = xs + tdx[0];
+            const int v = inb & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W);
+            const int xoff = ((n * p.H + sy) * p.W + sx) * p.x_pitch + cb[0] + 4 * q0;
 #pragma unroll
             for (int j = 0; j < NBP; ++j) {
-                const unsigned bo = x3_oob_unless((unsigned)(xoff + 64 * j) * 4u, v & (int)(chb + 64 * j < p.Cin));
+                const unsigned bo = x3_oob_unless((unsigned)(xoff + 64 * j) * 4u, v & (int)(j0 + 64 * j + 4 * q0 < Ktot));
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) {
+                const int sy = ys + tdy[j], sx = xs + tdx[j];
+                const int v = inb & (int)((unsigned)sy < (unsigned)p.H) & (int)((unsigned)sx < (unsigned)p.W) &
+                              (int)(j0 + 64 * j + 4 * q0 < Ktot);
+                const unsigned bo = x3_oob_unless((unsigned)(((n * p.H + sy) * p.W + sx) * p.x_pitch + cb[j] + 4 * q0) * 4u, v);
                 rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bo, 0, 0));
             }
         }
-        if constexpr (decltype(INCR)::value) {       // K-steps are loaded in order: advance the first pixel by BK
+        if constexpr (decltype(INCR)::value) {       // K-steps are loaded in order: advance the pixel by BK
             px_ += BK;
             const bool wx = px_ >= p.Wo;
             px_ -= wx ? p.Wo : 0;
@@ -1534,13 +1560,13 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     };
     const int ka = h2_exponent(*p.amax_a), kb = h2_exponent(*p.amax_b);
     const float sa = pow2f(ka), sb = pow2f(kb);
-    auto store_tile = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[NBP]) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[NAP], const f32x4 (&rb)[NBP]) {
         char *As = smem + buf * STAGE, *Bs = As + 2 * PLA;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NAP; ++j) {
             u32x2 h, m;
             split2h(ra[j], sa, h, m);
-            char *d = As + (pa0 + 8 * j) * PIA + qa * 8;
+            char *d = As + pb0 * PIA + (q0 + 16 * j) * 8;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PLA) = m;
         }
@@ -1548,7 +1574,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         for (int j = 0; j < NBP; ++j) {
             u32x2 h, m;
             split2h(rb[j], sb, h, m);
-            char *d = Bs + pb0 * PIB + (qb + 16 * j) * 8;
+            char *d = Bs + pb0 * PIB + (q0 + 16 * j) * 8;
             *reinterpret_cast<u32x2 *>(d) = h;
             *reinterpret_cast<u32x2 *>(d + PLB) = m;
         }
@@ -1629,7 +1655,6 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     else k_loop(std::false_type{});
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
-    const long row_pitch = (long)p.R * p.S * p.Cin;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
@@ -1639,10 +1664,10 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
         for (int e = 0; e < 16; ++e) {
             const int co = rbase + (e & 3) + 8 * (e >> 2);
             if (co >= p.Cout) continue;
-            float *drow = out + co * row_pitch + (long)rs * p.Cin + j0 + brow0 + l31;
+            float *drow = out + (long)co * Ktot + j0 + brow0 + l31;
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
-                if (j0 + brow0 + nr * 32 + l31 >= p.Cin) continue;
+                if (j0 + brow0 + nr * 32 + l31 >= Ktot) continue;
                 float v = (acc[mr][nr][e] * inv_a) * inv_b;
                 if (p.beta && gridDim.z == 1) v += drow[nr * 32];
                 drow[nr * 32] = v;
@@ -1794,6 +1819,7 @@ inline int region_pixels(const rcf_conv_region *r, int H, int W) {
 struct WgradPlan {
     int mr, nr, itiles, jtiles, splitk;
     long chunk;
+    bool cols;      // igemm_wgrad_h2t_kernel: the taps are GEMM columns (grid.y = 1)
 };
 int g_wgrad_plan_us = 1;      // 1: split-K by the microsecond cost model (same-box A/B: -0.5 ms per fp32 step); RCF_WGRAD_PLAN_US=0: round-1 model
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullptr) {
@@ -1807,11 +1833,21 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     // 128 x 256 tile (igemm_wgrad_x3_wide_kernel): whole tensors, wide enough operands
     const bool wide = use_x3(4) && g_wgrad_wide && !smallc && !reg && s->Cout >= 128 && s->Cin >= 256;
     if (wide) pl.nr = 4;
+    // fp16 pairs with the (tap, channel) pairs as GEMM columns (igemm_wgrad_h2t_kernel): 128 x 256 tiles over R*S*Cin
+    // columns (128 x 128 for 128 ... 255 columns), whole tensors and regions.  Layers with 64 output channels only when
+    // they have several taps (bound by re-reading dy per tap otherwise, not by the half-empty tile rows).
+    const int ktot = s->R * s->S * s->Cin;
+    pl.cols = s->amax_dy && s->amax_x && !g_h2_off && use_x3(4) && g_wgrad_wide && !g_wgrad_tr_off && !smallc &&
+              s->Cin % 64 == 0 && ktot >= 128 && (s->Cout >= 128 || s->R * s->S > 1) && !(reg && ktot < 256);
+    if (pl.cols) {
+        pl.mr = 2;
+        pl.nr = ktot >= 256 ? 4 : 2;
+    }
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
-    pl.jtiles = rcf_cdiv(ncols, 64 * pl.nr);
+    pl.jtiles = pl.cols ? rcf_cdiv(ktot, 64 * pl.nr) : rcf_cdiv(ncols, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);                       // contributing pixels per image
     const long M = (long)s->N * RR;
-    const long tiles = (long)pl.itiles * pl.jtiles * (smallc ? 1 : s->R * s->S);
+    const long tiles = (long)pl.itiles * pl.jtiles * ((smallc || pl.cols) ? 1 : s->R * s->S);
     long sk = (1536 + tiles - 1) / tiles;
     const long maxsk = M / 1024 > 1 ? M / 1024 : 1;
     if (sk > maxsk) sk = maxsk;
@@ -2130,7 +2166,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     p.amax_a = s->amax_dy; p.amax_b = s->amax_x;
     const bool smallc = s->Cin == 4;
     if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
-    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)(smallc ? 1 : s->R * s->S), (unsigned)pl.splitk);
+    const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)((smallc || pl.cols) ? 1 : s->R * s->S), (unsigned)pl.splitk);
     const bool incr = s->Wo >= BK;
 #define RCF_WGRAD_LAUNCH(MRv, NRv)                                                                                \
     do {                                                                                                          \
@@ -2148,8 +2184,16 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (h2) {            // fp16 pairs
-            if (pl.nr == 4 && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel<4>, grid, dim3(256), 0, st, p);
-            else if (pl.mr == 2 && pl.nr == 2 && !region && !g_wgrad_tr_off) hipLaunchKernelGGL(igemm_wgrad_h2t_kernel<2>, grid, dim3(256), 0, st, p);
+            if (pl.cols) {
+                const bool onetap = s->Cin % (64 * pl.nr) == 0;
+                if (pl.nr == 4) {
+                    if (region && onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, true>), grid, dim3(256), 0, st, p);
+                    else if (region) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, false>), grid, dim3(256), 0, st, p);
+                    else if (onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, false, true>), grid, dim3(256), 0, st, p);
+                    else hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, false, false>), grid, dim3(256), 0, st, p);
+                } else if (onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<2, false, true>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<2, false, false>), grid, dim3(256), 0, st, p);
+            }
             else if (pl.nr == 4) hipLaunchKernelGGL(igemm_wgrad_x3_wide_kernel<2>, grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 2) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
             else if (pl.mr == 2 && pl.nr == 1) hipLaunchKernelGGL((igemm_wgrad_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, p);
