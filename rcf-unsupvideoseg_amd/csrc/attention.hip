@@ -48,13 +48,21 @@ __device__ __forceinline__ int h2_exponent(unsigned amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
 
+// the fp16-pair split of csrc/igemm_conv.hip (split2h there): h = fp16(x s), m = fp16(x s - h), through v_fma_mix{lo,hi}_f16
+__device__ __forceinline__ unsigned split2h_pair(float a, float b, float s, unsigned &m) {
+    unsigned h;
+    const float nz = -0.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(h) : "v"(a), "v"(s), "v"(nz));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(h) : "v"(b), "v"(s), "v"(nz));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(b), "v"(s), "v"(h));
+    return h;
+}
 __device__ __forceinline__ void split2h(const f32x4 v, float s, u32x2 &h, u32x2 &m) {
-    const f32x2 a = {v[0] * s, v[1] * s}, b = {v[2] * s, v[3] * s};
-    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-    const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
-    const f16x2 ma = __builtin_convertvector(ra, f16x2), mb = __builtin_convertvector(rb, f16x2);
-    h = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-    m = u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+    unsigned m0, m1;
+    const unsigned h0 = split2h_pair(v[0], v[1], s, m0), h1 = split2h_pair(v[2], v[3], s, m1);
+    h = u32x2{h0, h1};
+    m = u32x2{m0, m1};
 }
 
 // operand fragments as raw 16 bytes; NP = 3: bf16 triples (6 products), NP = 2: fp16 pairs (3 products)
