@@ -222,6 +222,54 @@ def test_conv_region(case, report):
     assert e_f < 2e-5 and e_w < 2e-5 and e_d < 2e-5 and outside == 0.0 and outside_d == 0.0
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, stride, pad, dil, H, W, region in output coordinates or None
+    (2, 256, 256, 1, 1, 0, 1, 9, 14, (1, 2, 5, 9)),          # region, one tap per 256-column tile
+    (2, 256, 136, 3, 1, 3, 3, 19, 23, (0, 0, 19, 23, 5)),    # frame of the whole image (the commuted decode-head conv's shape)
+    (3, 64, 136, 3, 1, 3, 3, 11, 23, (1, 2, 9, 20, 2)),      # region, a 256-column tile spans four taps
+    (3, 64, 64, 3, 1, 1, 1, 11, 23, (2, 20, 9, 3)),          # 3-pixel-wide strip, 64 output channels (half-empty tile rows)
+    (2, 128, 200, 1, 1, 0, 1, 17, 19, None),                 # 128 columns: the 128 x 128 tile, one tap
+    (2, 192, 136, 1, 1, 0, 1, 17, 19, None),                 # 192 columns: the 128 x 128 tile, ragged second column tile
+    (2, 128, 72, 3, 2, 1, 1, 21, 37, None),                  # stride 2, two taps per 256-column tile, ragged last tile (1152 columns)
+    (1, 320, 136, 3, 1, 2, 2, 13, 16, None),                 # Cin = 5 x 64: column tiles straddle taps at a 64-channel boundary
+])
+def test_conv_wgrad_fp16_pairs_columns(case, report):
+    """the fp16-pair weight gradient with (tap, channel) pairs as GEMM columns (igemm_wgrad_h2t_kernel: whole tensors and
+    regions, one tap or several per column tile, both tile widths) against float64; yardstick: torch's own fp32 conv"""
+    N, Cin, Cout, k, stride, pad, dil, H, W, reg = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:9])))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    xd, wd = x.double(), w.double().requires_grad_(True)
+    yref = F.conv2d(xd, wd, None, stride, pad, dil)
+    dy = torch.randn(yref.shape, generator=g)
+    mask = torch.ones(dy.shape)
+    if reg is not None:
+        y0, x0, rh, rw = reg[:4]
+        t = reg[4] if len(reg) > 4 else 0
+        mask = torch.zeros(dy.shape)
+        mask[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+        if t:
+            mask[:, :, y0 + t:y0 + rh - t, x0 + t:x0 + rw - t] = 0
+    yref.backward((dy * mask).double())
+    w32 = w.clone().requires_grad_(True)
+    F.conv2d(x, w32, None, stride, pad, dil).backward(dy * mask)
+
+    def rms(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float(((a - b) ** 2).mean().sqrt() / ((b ** 2).mean().sqrt() + 1e-300))
+    xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
+    ax, ag = ops.absmax(xg), ops.absmax(gg)
+    dw = torch.full_like(wg, 3.0)
+    ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=0, region=reg, amax=(ax, ag))
+    e0 = rms(dw.cpu(), wd.grad)
+    ops.conv2d_wgrad(xg, gg, wg, dw, stride, pad, dil, beta=1, region=reg, amax=(ax, ag))      # accumulate: 2 x
+    e1 = rms(dw.cpu(), 2 * wd.grad)
+    r = rms(w32.grad, wd.grad)
+    report(f"conv wgrad fp16 pairs, columns {case}: rms error vs float64 {e0:.2e} (accumulated {e1:.2e}) | torch fp32 {r:.2e}")
+    assert e0 < max(4 * r, 5e-7) and e1 < max(4 * r, 5e-7)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,k,stride,pad,dil,H,W", [
     (2, 64, 64, 1, 1, 0, 1, 31, 45),           # 64-wide tiles, ragged last row tile
     (2, 4, 64, 7, 2, 3, 1, 60, 107),           # stem
