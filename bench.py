@@ -219,7 +219,14 @@ def main():
         out["roofline_by_kernel_one_stream"] = by_kernel(by32s, FAMILIES_F32, H2_MFMA_PEAK_TF)
         if bf is not None:
             bf["roofline"] = roofline_of(prof16, fam16, FAMILIES_BF16.get(fam16, fam16), BF16_MFMA_PEAK_TF)
+            bf["roofline"]["note"] = ("weight gradients on a second HIP stream beside the main stream's data gradients and batch-norm "
+                                      "passes (-2 % step time): live durations include the sharing; roofline_by_kernel_one_stream "
+                                      "holds the same brackets with everything on one stream")
+            if fam16 in by16s and by16s[fam16]["ms"] > 0:
+                bf["roofline"]["achieved_one_stream"] = round(by16s[fam16]["flops"] / (by16s[fam16]["ms"] * 1e-3) / 1e12, 2)
+                bf["roofline"]["frac_one_stream"] = round(bf["roofline"]["achieved_one_stream"] / BF16_MFMA_PEAK_TF, 4)
             bf["roofline_by_kernel"] = by_kernel(by16, FAMILIES_BF16, BF16_MFMA_PEAK_TF)
+            bf["roofline_by_kernel_one_stream"] = by_kernel(by16s, FAMILIES_BF16, BF16_MFMA_PEAK_TF)
             out["bf16_step"] = bf
         # CRF ms/frame (second half of BASELINE's metric) -- 480x854, T iterations, batch of 8 frames
         try:

@@ -72,9 +72,9 @@ class Act:
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
 OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
-# ... in the bf16 step the convs are as load/LDS-bound as the batch-norm passes and running two of them side by side gains
-# nothing (same-box A/B: 57.8 vs 58.1 ms/step, against 129.7 vs 140.6 in fp32): its weight gradients stay on the main stream
-OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "0") != "0"
+# ... in the bf16 step the gain is smaller (same process, interleaved: 50.96 vs 51.98 ms/step, against 129.7 vs 140.6 in fp32;
+# before the bf16 weight gradient's prefetch worked, csrc/igemm_bf16.hip wgrad_tr_step, there was none: 57.8 vs 58.1)
+OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "1") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
 BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels), as torch autocast does

@@ -21,7 +21,8 @@ nb = synth.make_batch(B, H, W, config_id=2)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
 configs = {"all on": {}, "no operand cache": {"CACHE_WEIGHT_OPERANDS": False}, "no fused finalize": {"FUSE_BN_FINALIZE": False},
-           "fp32 stem": {"BF16_STEM": False}, "dma pieces ahead": {"tile": 4}}
+           "fp32 stem": {"BF16_STEM": False}, "dma pieces ahead": {"tile": 4},
+           "bf16 wgrad on 2nd stream": {"OVERLAP_WGRAD_BF16": True}}
 if os.environ.get("AB_ONLY"):
     configs = {k: v for k, v in configs.items() if k == "all on" or k in os.environ["AB_ONLY"].split(",")}
 FLAGS = ("CACHE_WEIGHT_OPERANDS", "FUSE_BN_FINALIZE", "BF16_STEM")
@@ -33,6 +34,7 @@ for r in range(rounds):
         for k in FLAGS:
             setattr(layers, k, flags.get(k, True))
         rcf_amd._lib.load().rcf_conv_bf16_set_tile(flags.get("tile", -1))
+        layers.OVERLAP_WGRAD_BF16 = flags.get("OVERLAP_WGRAD_BF16", False)
         tr.step(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
