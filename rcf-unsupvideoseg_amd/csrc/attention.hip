@@ -131,7 +131,10 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
     int kx = 0;                                                 // fp16 pairs: q, k, v scaled by 2^kx, P by 2^14
     if constexpr (NP == 2) kx = h2_exponent(*p.amax);
     const float sx = pow2f(kx);
-    const float s_scale = NP == 2 ? p.scale * pow2f(-kx) * pow2f(-kx) : p.scale;
+    // scores in the log2 domain: the softmax is exp2(s2 - max) with s2 = s log2(e) -- one v_exp_f32 per probability instead of
+    // expf's range reduction (the kernel ran 20 VALU instructions per MFMA, a third of them inside expf); the probabilities
+    // are the same numbers, so O and the running sum need nothing else
+    const float s_scale = (NP == 2 ? p.scale * pow2f(-kx) * pow2f(-kx) : p.scale) * 1.4426950408889634f;
     constexpr float P_SCALE = NP == 2 ? 16384.f : 1.f;
     __shared__ float rowv[4][32];
 
@@ -255,12 +258,12 @@ __global__ void __launch_bounds__(256, 2) attention_fwd_kernel(AttnParams p) {
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                   // finite: every tile holds at least one real key
-        const float alpha = expf(m_run - m_new);                // 0 on the first tile (m_run = -inf)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { pv[kt][e] = expf(pv[kt][e] - m_new); rs += pv[kt][e]; }
+            for (int e = 0; e < 16; ++e) { pv[kt][e] = __builtin_amdgcn_exp2f(pv[kt][e] - m_new); rs += pv[kt][e]; }
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
         m_run = m_new;
