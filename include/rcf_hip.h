@@ -159,9 +159,10 @@ int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_co
 size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region);
 int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, const rcf_conv_shape *s, const rcf_conv_region *region,
                           int beta, void *workspace, size_t workspace_bytes, void *stream);
-/* variant of the bf16 forward / data-gradient kernel for A/B measurements: -1 default (global -> LDS DMA loads, three LDS
- * stages, tile by output width), 5 the same on a 256x256 tile; 0..3 register-staged loads on 128x128 / 128x256 / 256x256 /
- * 128x64 tiles.  Results are identical. */
+/* variant of the bf16 forward / data-gradient kernel for A/B measurements: -1 default (global -> LDS DMA loads placed among
+ * the MFMAs of a K-step, three LDS stages, tile by output width), 4 the same with the loads issued ahead of the K-step's
+ * MFMAs (also the weight gradient's), 5 DMA loads on a 256x256 tile, 6 / 7 four LDS stages on 256x256 / 128x256; 0..3
+ * register-staged loads on 128x128 / 128x256 / 256x256 / 128x64 tiles.  Results are identical. */
 int rcf_conv_bf16_set_tile(int tile);
 
 /* tuning knob for A/B measurements of the conv kernels: bit0 K-step 32, bit1 row-major LDS tiles;

@@ -109,6 +109,8 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
 // forward / data gradient.  Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32.
 // DGRAD only names the instantiation (profiles tell forward and data-gradient launches apart).
 // OBF: bf16 output (16-byte stores after a half-wave exchange), else fp32 output.
+// SCHED (DMA only): 1 = the steady-state K-step is one basic block with the LDS-DMA pieces placed among the MFMAs (the
+// default), 0 = pieces issued ahead of the K-step's MFMAs (A/B reference, rcf_conv_bf16_set_tile(4)).
 // DMA: both operands go from global memory STRAIGHT into LDS (buffer_load ... lds, 16 bytes per lane: no staging
 // registers, no ds_write pass); three LDS stages, the loads of K-step t+2 are issued before the MFMAs of step t and
 // stay in flight across the one barrier per step (counted s_waitcnt vmcnt).  The LDS image of a wave instruction is
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                 const char *As = smem + st * STAGE;
                 mma_step<MR, NR>(As, As + PA, arow0, brow0, lane, acc);
                 issue(kt + AHEAD, stn);       // in program order BEHIND the fragment reads (LDS write after LDS reads)
-                if constexpr (SCHED >= 1) {
+                {
                     // both halves' fragments first, then one LDS-DMA piece behind each of the first MFMAs: a piece's issue
                     // (tens of cycles) runs under the matrix pipe's work instead of ahead of it
                     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);

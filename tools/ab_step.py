@@ -22,7 +22,8 @@ t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
 configs = {"all on": {}, "no operand cache": {"CACHE_WEIGHT_OPERANDS": False}, "no fused finalize": {"FUSE_BN_FINALIZE": False},
            "fp32 stem": {"BF16_STEM": False}, "dma pieces ahead": {"tile": 4},
-           "bf16 wgrad on 2nd stream": {"OVERLAP_WGRAD_BF16": True}}
+           "bf16 wgrad on 1 stream": {"OVERLAP_WGRAD_BF16": False}, "main stream high priority": {"hp": True}}
+HP = torch.cuda.Stream(device=dev, priority=-1)
 if os.environ.get("AB_ONLY"):
     configs = {k: v for k, v in configs.items() if k == "all on" or k in os.environ["AB_ONLY"].split(",")}
 FLAGS = ("CACHE_WEIGHT_OPERANDS", "FUSE_BN_FINALIZE", "BF16_STEM")
@@ -34,7 +35,10 @@ for r in range(rounds):
         for k in FLAGS:
             setattr(layers, k, flags.get(k, True))
         rcf_amd._lib.load().rcf_conv_bf16_set_tile(flags.get("tile", -1))
-        layers.OVERLAP_WGRAD_BF16 = flags.get("OVERLAP_WGRAD_BF16", False)
+        layers.OVERLAP_WGRAD_BF16 = flags.get("OVERLAP_WGRAD_BF16", True)
+        ctx = torch.cuda.stream(HP) if flags.get("hp") else __import__("contextlib").nullcontext()
+        torch.cuda.synchronize()
+        ctx.__enter__()
         tr.step(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -47,6 +51,8 @@ for r in range(rounds):
         ops.PROFILE.start(fams)
         tr.step(batch)
         by = ops.PROFILE.stop()
+        torch.cuda.synchronize()
+        ctx.__exit__(None, None, None)
         print(f"   round {r} {name:20s} {res[name][-1]:7.2f} ms/step | " + " ".join(f"{k.replace('conv_', '')} {v['ms']:6.2f}" for k, v in by.items()),
               f"| reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB", flush=True)
 for name, v in res.items():
