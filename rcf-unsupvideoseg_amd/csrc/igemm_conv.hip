@@ -1834,11 +1834,12 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     const bool wide = use_x3(4) && g_wgrad_wide && !smallc && !reg && s->Cout >= 128 && s->Cin >= 256;
     if (wide) pl.nr = 4;
     // fp16 pairs with the (tap, channel) pairs as GEMM columns (igemm_wgrad_h2t_kernel): 128 x 256 tiles over R*S*Cin
-    // columns (128 x 128 for 128 ... 255 columns), whole tensors and regions.  Layers with 64 output channels only when
-    // they have several taps (bound by re-reading dy per tap otherwise, not by the half-empty tile rows).
+    // columns (128 x 128 below 256 columns), whole tensors and regions, from 64 output channels and 64 columns up: the
+    // narrow layers are bound by memory, not by the half-empty tiles (1x1 64->256 and 256->64 at 120x214: 0.19 -> 0.12 ms
+    // against the 64-wide kernels).
     const int ktot = s->R * s->S * s->Cin;
     pl.cols = s->amax_dy && s->amax_x && !g_h2_off && use_x3(4) && g_wgrad_wide && !g_wgrad_tr_off && !smallc &&
-              s->Cin % 64 == 0 && ktot >= 128 && (s->Cout >= 128 || s->R * s->S > 1) && !(reg && ktot < 256);
+              s->Cin % 64 == 0 && s->Cout >= 64 && !(reg && ktot < 256);
     if (pl.cols) {
         pl.mr = 2;
         pl.nr = ktot >= 256 ? 4 : 2;

@@ -335,7 +335,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
     end = None
     if PROFILE.which is not None:
         ktot = s.R * s.S * s.Cin                                   # plan_wgrad (csrc/igemm_conv.hip): the 128 x 256 fp16-pair tile
-        wide = amax is not None and s.Cin % 64 == 0 and ktot >= 256 and (s.Cout >= 128 or s.R * s.S > 1)
+        wide = amax is not None and s.Cin % 64 == 0 and ktot >= 256 and s.Cout >= 64
         end = PROFILE.bracket("conv_wgrad_h2t4" if wide else "conv_wgrad_other",
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())

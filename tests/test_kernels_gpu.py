@@ -232,6 +232,9 @@ def test_conv_region(case, report):
     (2, 192, 136, 1, 1, 0, 1, 17, 19, None),                 # 192 columns: the 128 x 128 tile, ragged second column tile
     (2, 128, 72, 3, 2, 1, 1, 21, 37, None),                  # stride 2, two taps per 256-column tile, ragged last tile (1152 columns)
     (1, 320, 136, 3, 1, 2, 2, 13, 16, None),                 # Cin = 5 x 64: column tiles straddle taps at a 64-channel boundary
+    (2, 64, 256, 1, 1, 0, 1, 17, 19, None),                  # 64 columns: half of a 128-column tile
+    (2, 256, 64, 1, 1, 0, 1, 17, 19, None),                  # 64 output channels: half of the tile's rows
+    (2, 64, 72, 1, 2, 0, 1, 21, 23, None),                   # both, stride 2
 ])
 def test_conv_wgrad_fp16_pairs_columns(case, report):
     """the fp16-pair weight gradient with (tap, channel) pairs as GEMM columns (igemm_wgrad_h2t_kernel: whole tensors and

@@ -18,6 +18,8 @@ SHAPES = [
     ("layer3.conv2 3x3d2 256->256 @60x107", 256, 256, 3, 1, 2, 2, 60, 107),
     ("layer1.conv2 3x3 64->64 @120x214", 64, 64, 3, 1, 1, 1, 120, 214),
     ("layer1.conv3 1x1 64->256 @120x214", 64, 256, 1, 1, 0, 1, 120, 214),
+    ("layer1.conv1 1x1 256->64 @120x214", 256, 64, 1, 1, 0, 1, 120, 214),
+    ("layer2.conv3 1x1 128->512 @60x107", 128, 512, 1, 1, 0, 1, 60, 107),
     ("stem 7x7s2 4->64 @480x854", 4, 64, 7, 2, 3, 1, 480, 854),
 ]
 
