@@ -10,6 +10,7 @@
 // K-step = 32 (64 B of one source pixel per GEMM row).  LDS tile [row][4 chunks of 16 B]; chunk c of row r is stored at
 // chunk position c ^ ((r >> 2) & 3), which makes both the loader's ds_write_b128 and the MFMA operand fetch
 // (ds_read_b128: lane = row, lane >> 5 = which half of a 16-k substep) bank-conflict free without padding.
+#include <cstdlib>
 #include "rcf_common.h"
 
 namespace {
@@ -1061,8 +1062,10 @@ struct WgradPlan {
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     WgradPlan pl;
     const int ktot = s->R * s->S * s->Cin;
-    pl.mr = s->Cout > 64 ? 2 : 1;
     pl.nr = ktot >= 256 ? 4 : (ktot >= 128 ? 2 : 1);
+    // 64 output channels take the 128-row LDS-DMA kernel too when the columns allow it: these layers are bound by memory,
+    // not by the half-empty tile rows (layer1 3x3 64->64: 0.104 -> 0.093 ms, 1x1 256->64: 0.089 -> 0.068)
+    pl.mr = (s->Cout > 64 || (s->Cout == 64 && pl.nr >= 2)) ? 2 : 1;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ktot, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);

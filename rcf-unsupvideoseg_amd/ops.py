@@ -423,7 +423,7 @@ def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=
     ws = workspace(need, x.device) if need else None
     end = None
     if PROFILE.which is not None:
-        wide = region is None and s.Cout > 64 and s.R * s.S * s.Cin >= 256                      # plan_wgrad (csrc/igemm_bf16.hip)
+        wide = region is None and s.Cout >= 64 and s.R * s.S * s.Cin >= 256                     # plan_wgrad (csrc/igemm_bf16.hip)
         end = PROFILE.bracket("conv_bf16_wgrad4" if wide else "conv_bf16_wgrad_other",
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
     call("rcf_conv2d_wgrad_bf16", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
