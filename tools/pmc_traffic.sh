@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stage2 > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stage2 > $R/gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -27,10 +27,10 @@ with open("$R/gpurun_out/pmc_hbm_traffic.txt", "w") as o:
         o.write(f"{k[:120]} | {n} | {f:.1f} | {w:.1f} | {(2*f+w)*1024/1e6:.1f}\n")
 out = {}
 for tot, k, n, f, w in rows:
-    for fam, pat in (("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4>"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
+    for fam, pat in (("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true>"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
                      ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true>"),
-                     ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true>"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true>"),
-                     ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true>")):
+                     ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true>"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
+                     ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
         if pat in k:
             out[fam] = {"kernel": k, "launches": n, "hbm_bytes_per_launch": (2 * f + w) * 1024}
             print(fam, n, round((2 * f + w) * 1024 / 1e6, 1), "MB/launch")
