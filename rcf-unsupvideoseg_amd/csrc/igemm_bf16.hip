@@ -42,6 +42,7 @@ struct ConvParams {
     float slope;
     int beta;
     int mtiles, ntiles;
+    int mtiles8;                  // ceil(mtiles / 8): XCD x (block id % 8) walks the contiguous row tiles [x mtiles8, (x + 1) mtiles8)
     unsigned cs_magic, s_magic;
     int b_bytes;
     int ry0, rx0, rh, rw, rband, rr;      // region of the GEMM-row tensor (see igemm_conv.hip)
@@ -128,7 +129,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     const int grp = bid / (8 * p.ntiles);
     const int rem = bid - grp * 8 * p.ntiles;
     const int tile_n = rem >> 3;
-    const int tile_m = grp * 8 + (rem & 7);          // XCD aware: ids b, b+8, .. walk the column tiles of one row tile
+    // XCD aware (as igemm_conv_x3_kernel): ids b, b + 8, .. walk the column tiles of one row tile, each XCD its own contiguous
+    // range of row tiles
+    const int tile_m = (rem & 7) * p.mtiles8 + grp;
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -1015,6 +1018,7 @@ template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false, int NST = 
 void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
+    p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
     if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);

@@ -2,7 +2,7 @@
 # HBM traffic of the dominant conv kernel: separate FETCH_SIZE / WRITE_SIZE passes over bench.py (MI355X_MICROARCH.md §HBM)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE; do   # RCF_XCD_RANGES etc. pass through the environment
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stage2 > $R/gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<PY
