@@ -279,8 +279,8 @@ FAMILIES_F32 = {
     "conv_fwd_narrow": "igemm_conv_x3_kernel<2,{1,2},2,2,...> / fp32-MFMA stem (forward, <= 128 output channels)",
     "conv_dgrad_wide": "igemm_conv_x3_kernel<2,4,2,2,false,true,2,true,true> (data gradient, fp16 pairs, 128x256 tile; incl. the weight transpose+split pre-pass)",
     "conv_dgrad_other": "igemm_conv_x3_kernel<...,true,...> (data gradient: strided / narrow tiles)",
-    "conv_wgrad_h2t4": "igemm_wgrad_h2t_kernel<4> (weight gradient, fp16 pairs, 128x256 tile, transposing LDS reads; incl. the split-K reduction)",
-    "conv_wgrad_other": "igemm_wgrad_h2t_kernel<2> / igemm_wgrad_x3_kernel / igemm_wgrad_kernel (weight gradient: narrow tiles, regions, stem)",
+    "conv_wgrad_h2t4": "igemm_wgrad_h2t_kernel<4,*,*> (weight gradient, fp16 pairs, 128x256 tile over (tap, channel) columns, transposing LDS reads, whole tensors and regions; incl. the split-K reduction)",
+    "conv_wgrad_other": "igemm_wgrad_h2t_kernel<2,*,*> / igemm_wgrad_x3_kernel / igemm_wgrad_kernel (weight gradient: fewer than 256 columns, odd channel counts, stem)",
 }
 FAMILIES_BF16 = {
     "conv_bf16_fwd": "conv_bf16_kernel<2,4,2,2,false,false,true,true,3,1> (forward, bf16 operands, 128x256 tile, LDS-DMA loads interleaved with the MFMAs; incl. the fused BN statistics sums)",
