@@ -412,7 +412,7 @@ int rcf_fill_f32(float *p, long n, float v, void *stream);
 
 /* ---- evaluation metric ---------------------------------------------------------------
  * main.py:200-235 + utils/eval_utils.py:5-52,120-123: masks [B,C,h,w] (fp32 softmax) are resized to the annotation size
- * [H,W] (bilinear, align_corners=True), binarised (> pos_th; pos_th < 0: one-hot of the channel argmax) and compared with
+ * [H,W] (bilinear, align_corners=True), binarised (> pos_th; pos_th == -1 exactly: one-hot of the channel argmax) and compared with
  * the u8 annotation (255 foreground, 128 ignored, else background).  counts [B][C][3] uint64, zero-filled by the caller:
  * intersection, prediction area, label area of the foreground over the valid pixels; IoU = I / (P + L - I). */
 int rcf_eval_iou_counts_f32(const float *masks, const uint8_t *ann, int B, int C, int h, int w, int H, int W, float pos_th,

@@ -61,6 +61,7 @@ struct Lattice {           // device pointers of one potential, for all frames (
     // needs a probe longer than PK_PROBE_LIMIT, is inserted again into all 2E buckets.
     int cap_small;
     int *stat;                   // [F][4]  distinct keys of the small attempt, probe-limit flag, sampled distinct keys, -
+    int sym;                     // 1: DenseCRF2D's symmetric kernel normalisation (rcf_crf_soft_ex), set per call by crf_infer
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
@@ -1175,7 +1176,6 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
 
 int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build,
                            // 2: packed build whose first-attempt table is tiny (exercises the overflow path)
-int g_crf_sym = 0;         // 1 while rcf_crf_soft_ex runs with the symmetric normalisation
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
 
 // kernels templated on the lattice dimension: the two potentials of the reference are pd = 2 and pd = 5
@@ -1263,7 +1263,7 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
         hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
     }
-    PD_LAUNCH(L.pd, slice_norm_kernel, gp, dim3(256), st, L, (const float *)za, g_crf_sym);
+    PD_LAUNCH(L.pd, slice_norm_kernel, gp, dim3(256), st, L, (const float *)za, L.sym);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1279,14 +1279,15 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
         float2 *t = a; a = b; b = t;
     }
     PD_LAUNCH(L.pd, slice_kernel, gp, dim3(256), st, L, (const float2 *)a, unary, next, Qout, map, first, last,
-                       write_map, g_crf_sym);
+                       write_map, L.sym);
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
 int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float scomp_smooth, float sxy_smooth,
               float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *q_out,
-              int32_t *nvert, CrfBuffers &b, hipStream_t st) {
+              int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0) {
+    b.smooth.sym = b.app.sym = sym;                                // per call, not per process: concurrent callers differ
     const bool has_s = scomp_smooth > 0.f && sxy_smooth > 0.f;     // torchcrf.cu:28
     const bool has_a = scomp_app > 0.f && sxy_app > 0.f;           // torchcrf.cu:41
     const long n = (long)F * W * H;
@@ -1301,7 +1302,7 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
         // no pairwise term: every step is softmax(-U) again
         iters = 0;
     }
-    if (g_crf_sym && iters > 0) {
+    if (sym && iters > 0) {
         if (npot != 1) return RCF_EINVAL;                // the scaled marginals belong to ONE kernel's normaliser
         hipLaunchKernelGGL(scale_q_kernel, dim3(rcf_cdiv(n, 256)), dim3(256), 0, st, b.cur, (has_a ? b.app : b.smooth).inv, n);
         RCF_LAUNCH_CHECK();
@@ -1338,33 +1339,40 @@ extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
     return carve_all(nullptr, W, H, batch, b);
 }
 
-extern "C" int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
-                            float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
-                            int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
-                            void *stream) {
+namespace {
+int crf_soft_impl(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
+                  float scomp_app, float sxy_app, float srgb_app, int iters, int sym, int16_t *out_map, float *q_out,
+                  int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream) {
     if (!rgb || !unary || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
     if ((long)W * H * 6 >= (1L << 30)) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_crf_workspace_bytes(W, H, batch) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
     CrfBuffers b;
     carve_all((char *)workspace, W, H, batch, b);
     return crf_infer(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
-                     q_out, nvert, b, rcf_stream(stream));
+                     q_out, nvert, b, rcf_stream(stream), sym);
+}
+}  // namespace
+
+extern "C" int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
+                            float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
+                            int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, 0, out_map,
+                         q_out, nvert, workspace, workspace_bytes, stream);
 }
 
 /* normalization 0: rcf_crf_soft.  normalization 1: the symmetric kernel normalisation of Kraehenbuehl & Koltun's DenseCRF
  * (pydensecrf DenseCRF2D.addPairwiseBilateral / addPairwiseGaussian defaults, NORMALIZE_SYMMETRIC): the filter is
  * N^1/2 K N^1/2 with N = diag(1 / (K 1 + 1e-20)) instead of diag(1 / K 1) K -- what tools/pydenseCRF/crf.py:58-89 and
- * models/crf_head.py:62-91 (crf_cpu) compute.  Exactly one potential may be active in that mode. */
+ * models/crf_head.py:62-91 (crf_cpu) compute.  Exactly one potential may be active in that mode.  The mode travels as a
+ * parameter (no process-wide state): calls with different normalisations may run concurrently from several threads. */
 extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth,
                                float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
                                int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
                                size_t workspace_bytes, void *stream) {
     if (normalization != 0 && normalization != 1) return RCF_EINVAL;
-    g_crf_sym = normalization;
-    const int rc = rcf_crf_soft(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
-                                out_map, q_out, nvert, workspace, workspace_bytes, stream);
-    g_crf_sym = 0;
-    return rc;
+    return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
+                         normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,

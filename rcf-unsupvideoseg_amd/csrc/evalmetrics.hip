@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) eval_counts_kernel(const float *__restric
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
             if (c >= C) break;
-            const unsigned on = pos_th >= 0.f ? (v[c] > pos_th ? 1u : 0u) : (c == best ? 1u : 0u);
+            const unsigned on = pos_th != -1.f ? (v[c] > pos_th ? 1u : 0u) : (c == best ? 1u : 0u);
             pred[c] += on;
             inter[c] += on & l;
         }
@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(256) eval_counts_kernel(const float *__restric
 }  // namespace
 
 /* counts [B][C][3] (uint64, zero-filled by the caller): intersection, prediction area, label area of the foreground
- * class over the non-ignored pixels.  pos_th < 0: one-hot of the channel argmax instead of the threshold. */
+ * class over the non-ignored pixels.  pos_th == -1 exactly (main.py:209 `eval_pos_th != -1`): one-hot of the channel argmax
+ * instead of the threshold; any other value, negative ones included, thresholds like the reference. */
 extern "C" int rcf_eval_iou_counts_f32(const float *masks, const uint8_t *ann, int B, int C, int h, int w, int H, int W,
                                        float pos_th, unsigned long long *counts, void *stream) {
     if (!masks || !ann || !counts || B <= 0 || C <= 0 || C > CMAX || h <= 0 || w <= 0 || H <= 0 || W <= 0) return RCF_EINVAL;

@@ -176,9 +176,12 @@ class Conv2d(nn.Module):
         cache = self.__dict__.setdefault("_wcache", {})
         hit = cache.get(kind)
         if hit is not None and hit[0] == key:
+            if ops.DEBUG_WEIGHT_CACHE and hit[2] != ops.weight_checksum(self.weight):
+                raise ops._lib.RcfHipError(f"stale cached weight operand '{kind}': the weight was written through .data / a raw "
+                                           "pointer without rcf_amd.ops.weights_changed()")
             return hit[1]
         v = make()
-        cache[kind] = (key, v)
+        cache[kind] = (key, v, ops.weight_checksum(self.weight) if ops.DEBUG_WEIGHT_CACHE else None)
         return v
 
     def _packed_weight(self, cout_mult=4):

@@ -85,6 +85,7 @@ def copy_param_and_buffer(src, dest):
     assert list(s.keys()) == list(d.keys())
     for k in s:
         d[k].data.copy_(s[k])
+    ops.weights_changed()            # `.data` writes do not bump `_version`: drop every cached weight operand
 
 
 @torch.no_grad()
@@ -100,6 +101,7 @@ def momentum_update_param_and_buffer(src, dest, m):
             ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m)
         else:
             d[k].data.copy_(d[k].data * m + s[k].data * (1.0 - m))
+    ops.weights_changed()
 
 
 class RCFModel(nn.Module):
@@ -166,6 +168,7 @@ class RCFModel(nn.Module):
         if self.decode_head2_ema is not None:
             copy_param_and_buffer(self.decode_head2, self.decode_head2_ema)
         self._tape = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: ops.weights_changed())
         # "fp32" | "bf16" | None.  None = follow torch autocast: the reference's AMP configs (configs/rcf_stv2/rcf_stage1.yaml:57-60,
         # Lightning `precision: 16`) call the model inside torch.autocast -- that selects the bf16 step here.
         self.precision = None
@@ -173,9 +176,17 @@ class RCFModel(nn.Module):
         self.grad_ready_hook = None      # callable(group) set by the trainer: "heads", "layer4" ... "layer1", "stem"
 
     # ------------------------------------------------------------------ plumbing
-    # No train() override, like the reference: the EMA copies are set to eval mode once, at construction
-    # (models/rcf_model.py:171,187); `model.train()` -- Lightning calls it on the whole module tree -- switches them to
-    # training mode with everything else, so under main.py the stage-2.1 teacher runs with batch statistics.
+    # train() keeps the reference's semantics (it has no override): the EMA copies are set to eval mode once, at
+    # construction (models/rcf_model.py:171,187); `model.train()` -- Lightning calls it on the whole module tree --
+    # switches them to training mode with everything else, so under main.py the stage-2.1 teacher runs with batch
+    # statistics.  The override below only invalidates the cached weight operands (fp16 planes, bf16 copies, ranges):
+    # they are keyed by (data_ptr, _version, epoch) and an in-place write through `.data` bumps none of those, so every
+    # mode switch and every load_state_dict starts from fresh operands.  Anything else that writes parameters through
+    # `.data` / raw pointers after a forward must call `rcf_amd.ops.weights_changed()` itself.
+
+    def train(self, mode=True):
+        ops.weights_changed()
+        return super().train(mode)
 
     def _dist(self):
         if self.dist is None:

@@ -10,6 +10,7 @@ Conv weights: torch shape [Cout,Cin,R,S] in channels_last memory format, i.e. [C
 in memory.
 """
 import ctypes
+import os
 from ctypes import c_void_p, byref
 
 import torch
@@ -186,9 +187,13 @@ def absmax(x, out=None):
 
 
 # Operands derived from a weight (its range, fp16 planes, bf16 copies) are cached by the layers between weight updates.
-# Updates made through torch (optimizers, copy_, load_state_dict) bump the tensor's `_version`; the kernels of this
-# library write through raw pointers, so their wrappers bump this epoch instead.
+# In-place updates made through torch on the parameter itself (optimizers, `p.copy_`, `p.mul_`) bump the tensor's
+# `_version`; writes through `p.data` / `p.detach()` views do NOT, and neither do the kernels of this library (raw
+# pointers) -- those writers bump this epoch instead: the library's own wrappers (Adam, EMA), `copy_param_and_buffer`,
+# `RCFModel.train()/eval()` and its load_state_dict hook do; an external `.data` writer must call `weights_changed()`.
+# RCF_DEBUG_WEIGHT_CACHE=1 re-validates every cache hit against a checksum of the weight (two reductions per launch).
 WEIGHT_EPOCH = [0]
+DEBUG_WEIGHT_CACHE = os.environ.get("RCF_DEBUG_WEIGHT_CACHE", "0") == "1"
 
 
 def weights_changed():
@@ -197,6 +202,12 @@ def weights_changed():
 
 def weight_key(w):
     return (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+
+
+def weight_checksum(w):
+    """debug mode only: (max |w|, sum w) as Python floats -- a stale cache entry shows up as a changed checksum"""
+    d = w.detach()
+    return (float(d.abs().max()), float(d.double().sum()))
 
 
 def weight_pairs_t(w, amax_w):

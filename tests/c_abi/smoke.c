@@ -10,6 +10,157 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 2; } } while (0)
 
+/* 4. rcf_conv2d_fwd_f32 on a 4x4 known-answer case (torch.nn.Conv2d, models/resnet.py:164-203): one image, 4 -> 8 channels,
+ * 3x3, pad 1, small-integer data, so every product and sum is exact in any fp32 arithmetic and the comparison with the
+ * plain C loops below is ==.  Run twice: without operand ranges (bf16-triple kernels) and with ranges from
+ * rcf_absmax_f32 plus pre-split weights (fp16-pair kernels, the training step's path).  Then the data gradient
+ * (rcf_conv2d_dgrad_f32) and the weight gradient (rcf_conv2d_wgrad_f32) of the same layer against their definitions. */
+static int conv_known_answer(void) {
+    enum { H = 4, W = 4, CI = 4, CO = 8, R = 3 };
+    float hx[H * W * CI], hw[CO * R * R * CI], hb[CO], hy[H * W * CO], ref[H * W * CO], hdx[H * W * CI], rdx[H * W * CI];
+    float hdw[CO * R * R * CI], rdw[CO * R * R * CI];
+    for (int i = 0; i < H * W * CI; i++) hx[i] = (float)((i * 7 + 3) % 11 - 5);              /* NHWC */
+    for (int i = 0; i < CO * R * R * CI; i++) hw[i] = (float)((i * 5 + 1) % 7 - 3);          /* [Cout][R][S][Cin] */
+    for (int i = 0; i < CO; i++) hb[i] = (float)(i - 2);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int co = 0; co < CO; co++) {
+        float acc = hb[co];
+        for (int r = 0; r < R; r++) for (int q = 0; q < R; q++) {
+            const int sy = y + r - 1, sx = x + q - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            for (int c = 0; c < CI; c++) acc += hx[(sy * W + sx) * CI + c] * hw[((co * R + r) * R + q) * CI + c];
+        }
+        ref[(y * W + x) * CO + co] = acc;
+    }
+    float *dx, *dw, *db, *dy, *ddx, *ddw;
+    unsigned *amax;
+    void *planes, *ws;
+    CK(hipMalloc((void **)&dx, sizeof hx)); CK(hipMalloc((void **)&dw, sizeof hw)); CK(hipMalloc((void **)&db, sizeof hb));
+    CK(hipMalloc((void **)&dy, sizeof hy)); CK(hipMalloc((void **)&ddx, sizeof hdx)); CK(hipMalloc((void **)&ddw, sizeof hdw));
+    CK(hipMalloc((void **)&amax, 3 * sizeof(unsigned)));
+    CK(hipMemcpy(dx, hx, sizeof hx, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw, sizeof hw, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb, sizeof hb, hipMemcpyHostToDevice));
+    rcf_conv_shape s;
+    memset(&s, 0, sizeof s);
+    s.N = 1; s.H = H; s.W = W; s.Cin = CI; s.Ho = H; s.Wo = W; s.Cout = CO; s.R = R; s.S = R; s.stride = 1; s.pad = 1; s.dil = 1;
+    s.x_pitch = CI; s.y_pitch = CO;
+    const size_t pbytes = rcf_conv_weight_pairs_bytes(CO, CI, R, R);
+    CK(hipMalloc(&planes, pbytes));
+    size_t wsb = rcf_conv2d_dgrad_workspace_bytes(&s), wsw = rcf_conv2d_wgrad_workspace_bytes(&s);
+    if (wsw > wsb) wsb = wsw;
+    CK(hipMalloc(&ws, wsb + 256));
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {                         /* operand ranges -> fp16-pair kernels, weights split once */
+            CK(hipMemset(amax, 0, 3 * sizeof(unsigned)));
+            if (rcf_absmax_f32(dx, H * W, CI, CI, amax, NULL) != 0) return 10;
+            if (rcf_absmax_f32(dw, CO * R * R, CI, CI, amax + 1, NULL) != 0) return 10;
+            if (rcf_conv_weight_pairs_f32(dw, CO, CI, R, R, amax + 1, planes, NULL) != 0) return 10;
+            s.amax_x = amax; s.amax_w = amax + 1; s.w_pairs = planes;
+        }
+        CK(hipMemset(dy, 0xff, sizeof hy));
+        const int rc = rcf_conv2d_fwd_f32(dx, dw, db, dy, &s, 0, 0.f, 0, NULL);
+        if (rc != 0) { printf("rcf_conv2d_fwd_f32 returned %d\n", rc); return 10; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hy, dy, sizeof hy, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < H * W * CO; i++) bad += hy[i] != ref[i];
+        printf("conv2d_fwd 4x4x4->8 3x3 (%s): %d of %d outputs differ from the C loops\n", pass ? "fp16 pairs" : "bf16 triples", bad, H * W * CO);
+        if (bad) return 11;
+    }
+    /* data gradient with dy := ref - bias (integers): dx[sy][sx][c] = sum over taps / co of dy * w */
+    for (int i = 0; i < H * W * CO; i++) hy[i] = (float)(((int)ref[i] % 5));
+    CK(hipMemcpy(dy, hy, sizeof hy, hipMemcpyHostToDevice));
+    memset(rdx, 0, sizeof rdx); memset(rdw, 0, sizeof rdw);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int co = 0; co < CO; co++)
+        for (int r = 0; r < R; r++) for (int q = 0; q < R; q++) {
+            const int sy = y + r - 1, sx = x + q - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            for (int c = 0; c < CI; c++) {
+                rdx[(sy * W + sx) * CI + c] += hy[(y * W + x) * CO + co] * hw[((co * R + r) * R + q) * CI + c];
+                rdw[((co * R + r) * R + q) * CI + c] += hy[(y * W + x) * CO + co] * hx[(sy * W + sx) * CI + c];
+            }
+        }
+    CK(hipMemset(amax + 2, 0, sizeof(unsigned)));
+    if (rcf_absmax_f32(dy, H * W, CO, CO, amax + 2, NULL) != 0) return 10;
+    s.amax_dy = amax + 2;
+    if (rcf_conv2d_dgrad_f32(dy, dw, ddx, &s, 0, ws, wsb, NULL) != 0) return 12;
+    if (rcf_conv2d_wgrad_f32(dx, dy, ddw, &s, 0, ws, wsb, NULL) != 0) return 12;
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hdx, ddx, sizeof hdx, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdw, ddw, sizeof hdw, hipMemcpyDeviceToHost));
+    int badx = 0, badw = 0;
+    for (int i = 0; i < H * W * CI; i++) badx += hdx[i] != rdx[i];
+    for (int i = 0; i < CO * R * R * CI; i++) badw += hdw[i] != rdw[i];
+    printf("conv2d_dgrad: %d of %d differ; conv2d_wgrad: %d of %d differ\n", badx, H * W * CI, badw, CO * R * R * CI);
+    if (badx || badw) return 13;
+    /* error codes, not crashes */
+    if (rcf_conv2d_fwd_f32(NULL, dw, db, dy, &s, 0, 0.f, 0, NULL) != RCF_EINVAL) return 14;
+    s.Cin = 3;
+    if (rcf_conv2d_fwd_f32(dx, dw, db, dy, &s, 0, 0.f, 0, NULL) != RCF_EINVAL) return 14;
+    hipFree(dx); hipFree(dw); hipFree(db); hipFree(dy); hipFree(ddx); hipFree(ddw); hipFree(amax); hipFree(planes); hipFree(ws);
+    return 0;
+}
+
+/* 5. rcf_crf_soft (torchcrf_cpp.crf_soft, tools/torchCRF/src/torchcrf.cu:106-126) with caller-owned hipMalloc'd buffers.
+ * (a) both potentials' weights 0: no pairwise term, the MAP is the arg-min of the unary energies on every pixel and the
+ * marginals are softmax(-U) (torchcrf.cu:28,41: inactive potentials).  (b) the training configuration's potentials
+ * (crf_head.py:13-20: weights 3 / 10, sxy 3 / 60, srgb 5 -> scaled for a small frame), 5 iterations, on a two-colour
+ * frame whose unary energies already agree with the colour regions: the filter can only reinforce them, MAP unchanged;
+ * the lattice vertex counts come back positive.  (c) bad arguments return codes. */
+static int crf_known_answer(void) {
+    enum { H = 24, W = 40, F = 2 };
+    const size_t npx = (size_t)F * H * W;
+    unsigned char *hrgb = (unsigned char *)malloc(npx * 3);
+    float *hun = (float *)malloc(npx * 2 * sizeof(float)), *hq = (float *)malloc(npx * 2 * sizeof(float));
+    short *hmap = (short *)malloc(npx * sizeof(short));
+    int hnv[2 * F];
+    for (size_t i = 0; i < npx; i++) {
+        const int x = (int)(i % W), f = (int)(i / ((size_t)H * W));
+        const int fg = f == 0 ? x >= W / 2 : x < W / 3;                  /* the colour regions */
+        hrgb[3 * i] = fg ? 200 : 30; hrgb[3 * i + 1] = fg ? 180 : 40; hrgb[3 * i + 2] = fg ? 20 : 90;
+        const float conf = 0.6f + 0.3f * (float)((i * 2654435761u) % 97u) / 97.0f;   /* P(label = region) in [0.6, 0.9] */
+        hun[2 * i + fg] = -logf(conf);
+        hun[2 * i + 1 - fg] = -logf(1.0f - conf);
+    }
+    unsigned char *drgb; float *dun, *dq; short *dmap; int *dnv; void *ws;
+    const size_t wsb = rcf_crf_workspace_bytes(W, H, F);
+    CK(hipMalloc((void **)&drgb, npx * 3)); CK(hipMalloc((void **)&dun, npx * 2 * sizeof(float)));
+    CK(hipMalloc((void **)&dq, npx * 2 * sizeof(float))); CK(hipMalloc((void **)&dmap, npx * sizeof(short)));
+    CK(hipMalloc((void **)&dnv, sizeof hnv)); CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(drgb, hrgb, npx * 3, hipMemcpyHostToDevice)); CK(hipMemcpy(dun, hun, npx * 2 * sizeof(float), hipMemcpyHostToDevice));
+    for (int pass = 0; pass < 2; pass++) {
+        const float w_s = pass ? 3.f : 0.f, w_a = pass ? 10.f : 0.f;
+        CK(hipMemset(dmap, 0xff, npx * sizeof(short)));
+        const int rc = rcf_crf_soft(drgb, dun, W, H, F, w_s, 3.f, w_a, 20.f, 5.f, 5, (int16_t *)dmap, dq, dnv, ws, wsb, NULL);
+        if (rc != 0) { printf("rcf_crf_soft returned %d\n", rc); return 20; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hmap, dmap, npx * sizeof(short), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hq, dq, npx * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hnv, dnv, sizeof hnv, hipMemcpyDeviceToHost));
+        size_t bad = 0; double worst = 0, sum_err = 0;
+        for (size_t i = 0; i < npx; i++) {
+            const int want = hun[2 * i + 1] < hun[2 * i];
+            bad += hmap[i] != want;
+            const double s1 = fabs((double)hq[2 * i] + (double)hq[2 * i + 1] - 1.0);
+            if (s1 > sum_err) sum_err = s1;
+            if (!pass) {                                                  /* softmax(-U) = the confidences themselves */
+                const double e0 = exp(-(double)hun[2 * i]), e1 = exp(-(double)hun[2 * i + 1]);
+                const double d = fabs((double)hq[2 * i] - e0 / (e0 + e1));
+                if (d > worst) worst = d;
+            }
+        }
+        printf("crf_soft %s: %zu of %zu MAP labels differ from the unary arg-min; max |q0+q1-1| = %.2g%s; vertices %d/%d, %d/%d\n",
+               pass ? "weights 3 / 10, T=5" : "weights 0", bad, npx, sum_err, pass ? "" : "; q = softmax(-U)", hnv[0], hnv[1], hnv[2], hnv[3]);
+        if (bad || !(sum_err < 1e-5) || (!pass && !(worst < 1e-6))) return 21;
+        if (pass && (hnv[0] <= 0 || hnv[1] <= 0 || hnv[2] <= 0 || hnv[3] <= 0)) return 22;
+        if (!pass && (hnv[0] || hnv[1])) return 22;
+    }
+    if (rcf_crf_soft(drgb, dun, W, H, F, 3.f, 3.f, 10.f, 20.f, 5.f, 5, (int16_t *)dmap, dq, dnv, ws, wsb / 2, NULL) != RCF_EWORKSPACE) return 23;
+    if (rcf_crf_soft(NULL, dun, W, H, F, 3.f, 3.f, 10.f, 20.f, 5.f, 5, (int16_t *)dmap, dq, dnv, ws, wsb, NULL) != RCF_EINVAL) return 23;
+    if (rcf_crf_soft_ex(drgb, dun, W, H, F, 3.f, 3.f, 10.f, 20.f, 5.f, 5, 2, (int16_t *)dmap, dq, dnv, ws, wsb, NULL) != RCF_EINVAL) return 23;
+    hipFree(drgb); hipFree(dun); hipFree(dq); hipFree(dmap); hipFree(dnv); hipFree(ws);
+    free(hrgb); free(hun); free(hq); free(hmap);
+    return 0;
+}
+
 int main(void) {
     const int B = 2, C = 3, H = 37, W = 53;
     const size_t n = (size_t)B * C * H * W, nf = (size_t)B * 2 * H * W;
@@ -59,6 +210,8 @@ int main(void) {
     if (ws == 0 || rcf_crf_workspace_bytes(0, H, B) != 0) return 7;
     hipFree(dx); hipFree(dy); hipFree(df);
     free(hx); free(hy); free(hf);
+    { const int rc = conv_known_answer(); if (rc) return rc; }
+    { const int rc = crf_known_answer(); if (rc) return rc; }
     printf("C ABI smoke: OK\n");
     return 0;
 }

@@ -202,3 +202,22 @@ def test_bench_two_ranks_end_to_end(report):
     report(f"bench.py --gpus 2 (gloo, shared GPU): {d['value']} frames/s, {d['ms_per_step']} ms/step")
     assert d["n_gpus"] == 2 and d["config"]["global_pairs"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+def test_bench_self_launches_its_ranks(report):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the parent starts the two ranks through
+    torch.distributed.run as a child process, never touches the GPU itself and relays rank 0's ONE JSON line"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["RCF_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pairs", "1", "--height", "64", "--width", "96", "--no-stage2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    report(f"python bench.py --gpus 2 (self-launched, gloo, shared GPU): {d['value']} frames/s; "
+           f"bf16 {d.get('bf16_frames_per_s')} frames/s")
+    assert d["n_gpus"] == 2 and d["config"]["global_pairs"] == 2 and d["value"] > 0
+    assert d["bf16_frames_per_s"] > 0 and d["roofline"]["bf16_step_frames_per_s"] == d["bf16_frames_per_s"]

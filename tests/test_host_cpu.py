@@ -156,3 +156,43 @@ def test_bench_line_helpers():
     json.loads(json.dumps(clean, allow_nan=False))
     assert "conv_dgrad_wide" in b.FAMILIES_F32 and "conv_wgrad_h2t4" in b.FAMILIES_F32 and "conv_bf16_wgrad4" in b.FAMILIES_BF16
     assert b.HBM_PEAK_GBS == 8000.0 and b.BF16_MFMA_PEAK_TF == 2500.0
+
+
+def test_weight_operand_cache_invalidation(monkeypatch):
+    """operands derived from a conv weight are cached by (data_ptr, _version, epoch): an in-place write on the parameter
+    bumps `_version`, a write through `.data` bumps nothing -- the library's own `.data` writers (copy_param_and_buffer,
+    the EMA update, model.train() / load_state_dict) bump the epoch, and the debug mode catches a writer that does not"""
+    from rcf_amd import layers, ops
+    conv = layers.Conv2d(4, 8, 3)
+    made = []
+
+    def make():
+        made.append(float(conv.weight.detach().abs().max()))
+        return made[-1]
+    assert conv._derived("amax", make) == conv._derived("amax", make) and len(made) == 1      # hit
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                           # torch in-place op on the parameter: _version changes
+    conv._derived("amax", make)
+    assert len(made) == 2
+    conv.weight.data.mul_(2.0)                          # .data write: invisible to the key ...
+    assert conv._derived("amax", make) == made[1] and len(made) == 2
+    ops.weights_changed()                               # ... until the writer says so
+    assert conv._derived("amax", make) == 2 * made[1] and len(made) == 3
+    # the repo's own .data writers bump the epoch
+    src, dst = layers.Conv2d(4, 8, 3), layers.Conv2d(4, 8, 3)
+    e0 = ops.WEIGHT_EPOCH[0]
+    rcf_amd.model.copy_param_and_buffer(src, dst)
+    assert ops.WEIGHT_EPOCH[0] > e0 and torch.equal(src.weight, dst.weight)
+    kw = config.stage1_model_kwargs((24, 40), dropout=0.0, norm="BN")
+    m = rcf_amd.RCFModel(types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None), **kw)
+    for fn in (lambda: m.train(), lambda: m.eval(), lambda: m.load_state_dict(m.state_dict())):
+        e0 = ops.WEIGHT_EPOCH[0]
+        fn()
+        assert ops.WEIGHT_EPOCH[0] > e0
+    # debug mode: a stale hit raises instead of being used
+    monkeypatch.setattr(ops, "DEBUG_WEIGHT_CACHE", True)
+    conv2 = layers.Conv2d(4, 8, 3)
+    conv2._derived("amax", lambda: 1)
+    conv2.weight.data.mul_(3.0)
+    with pytest.raises(ops._lib.RcfHipError):
+        conv2._derived("amax", lambda: 1)

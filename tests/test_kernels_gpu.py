@@ -99,6 +99,11 @@ def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
     def rms(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return float(((a - b) ** 2).mean().sqrt() / ((b ** 2).mean().sqrt() + 1e-300))
+
+    def mxe(a, b):
+        """largest element error in units of the result's rms value"""
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).abs().max() / ((b ** 2).mean().sqrt() + 1e-300))
     xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
     ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
     assert float(ax.view(torch.float32)) == float(x.abs().max()) and float(ag.view(torch.float32)) == float(dy.abs().max())
@@ -117,6 +122,14 @@ def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
            f"bf16 triples fwd {e6:.2e}")
     for ei, ri in zip(e, r):
         assert ei < max(4 * ri, 5e-7)
+    # ... and the LARGEST element error (in units of the result's rms), against the same yardstick: a kernel that is right
+    # on average and wrong on a few elements (a dropped partial product on one tile edge, an overflowing part) fails here
+    em = (mxe(from_nhwc(y), yref), mxe(from_nhwc(dx), xd.grad), mxe(dw.cpu(), wd.grad))
+    rm = (mxe(y32, yref), mxe(x32.grad, xd.grad), mxe(w32.grad, wd.grad))
+    report(f"   max element error / rms(result): fwd {em[0]:.2e} dgrad {em[1]:.2e} wgrad {em[2]:.2e} | torch fp32 "
+           f"{rm[0]:.2e} {rm[1]:.2e} {rm[2]:.2e}")
+    for ei, ri in zip(em, rm):
+        assert ei < max(4 * ri, 4e-6)
 
 
 def test_conv_fp16_pairs_range_edges(report):

@@ -45,9 +45,10 @@ def test_stage21_step_vs_oracle(report):
     lo = ora(mk("cpu"))
     lo["loss"].backward()
     e = {k: rel(lh[k], lo[k]) for k in ("loss", "loss_warp_seg", "loss_crf")}
-    # CRF targets themselves: recompute on both sides from the (identical) teacher
+    # the oracle's CRF targets (resized MAPs: in [0, 1], both labels present) -- the HIP side's are compared bit for bit
+    # against the reference's in test_stage2_vs_reference_golden; here they enter through loss_crf
     crf_o = lo["_crf_masks"].numpy()
-    assert set(np.unique(crf_o)) - {0.0, 1.0} != set() or True       # resized to mask size: not binary
+    assert crf_o.min() >= 0.0 and crf_o.max() <= 1.0 and 0.0 < float(crf_o.mean()) < 1.0
     # EMA teacher after the momentum update, incl. the int64 num_batches_tracked quirk
     hs, os_ = hip.state_dict(), ora.state_dict()
     e_ema = max(float((hs[k].cpu().float() - os_[k].float()).abs().max() / (os_[k].float().abs().max() + 1e-12))
