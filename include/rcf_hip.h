@@ -58,6 +58,10 @@ typedef struct {
      * launch -- fp32 entry points: rcf_conv_weight_pairs_t_f32 (fp16 planes of the transposed weights, with amax_w);
      * bf16 entry points: rcf_conv_weight_bf16(..., transpose = 1).  The workspace of the launch may then be NULL. */
     const void *w_pairs_t;
+    /* Optional, preferred over w_pairs / w_pairs_t: rcf_conv_weight_pairs2_f32 buffers (transpose 0 / 1) holding the split
+     * weights in BOTH reading orders; the wide, deep convs then run on the persistent LDS-DMA kernel (conv_h2p_kernel,
+     * csrc/igemm_h2p.inc), the others on the kernels that read w_pairs / w_pairs_t.  Results are identical. */
+    const void *w_pairs2, *w_pairs2_t;
 } rcf_conv_shape;
 
 /* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order
@@ -65,6 +69,13 @@ typedef struct {
 size_t rcf_conv_weight_pairs_bytes(int Cout, int Cin, int R, int S);
 int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
                               void *stream);
+
+size_t rcf_conv_weight_pairs2_bytes(int Cout, int Cin, int R, int S, int transpose);
+int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int R, int S, int transpose, const unsigned *amax_w,
+                               void *planes, void *stream);
+/* A/B switch of the persistent kernel: mode -1 built-in rule (taken when K >= min_k), 0 never, 1 whenever eligible
+ * (non-strided, no bias / activation, Cout-side % 256 == 0, K % 16 == 0, >= 32768 rows); min_k <= 0 keeps the current one */
+int rcf_conv_set_h2p(int mode, int min_k);
 
 /* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
 int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);

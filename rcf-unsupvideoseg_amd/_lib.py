@@ -18,7 +18,8 @@ class ConvShape(ctypes.Structure):
     """mirror of rcf_conv_shape"""
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad", "dil",
                                      "x_pitch", "y_pitch")] + \
-               [(n, ctypes.c_void_p) for n in ("amax_x", "amax_w", "amax_dy", "w_pairs", "w_pairs_t")]
+               [(n, ctypes.c_void_p) for n in ("amax_x", "amax_w", "amax_dy", "w_pairs", "w_pairs_t", "w_pairs2",
+                                                "w_pairs2_t")]
 
 
 class BnFinalize(ctypes.Structure):
@@ -79,6 +80,9 @@ PROTOS = {
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
     "rcf_conv_weight_pairs_t_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rcf_conv_weight_pairs2_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "rcf_conv_weight_pairs2_f32": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "rcf_conv_set_h2p": (c_int, [c_int, c_int]),
     "rcf_conv2d_fwd_bnstats_f32": (c_int, [P, P, P, _CS, P, _BF, P, c_size_t, P]),
     "rcf_conv2d_fwd_bnstats_bf16": (c_int, [P, P, P, c_int, _CS, P, _BF, P, c_size_t, P]),
     "rcf_sum_partials_f64": (c_int, [P, c_int, c_int, P, P, P]),

@@ -14,11 +14,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def headers():
+    """everything a source may include: csrc/*.h, csrc/*.inc, the public header"""
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        [os.path.join(HERE, "..", "include", "rcf_hip.h")]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "rcf_hip.h")]
+    deps = sources() + headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -33,8 +39,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "rcf_hip.h"))):
+                os.path.getmtime(src), *(os.path.getmtime(h) for h in headers())):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -69,6 +69,10 @@ struct IgemmParams {
     // a row [Ncol][ldb/4][h0 h1 h2 h3 m0 m1 m2 m3] (the fp32 layout's addresses); null = fp32 weights in Bw, split on
     // the way into LDS
     const void *b_pairs;
+    // conv_h2p_kernel (igemm_h2p.inc): the same split weights as plane-separated K-step blocks [K/16][2][Ncol][32 B, halves
+    // swizzled like the LDS tile], fetched global -> LDS by DMA; null = that kernel is not eligible
+    const void *b_pairs2;
+    int h2p_gn;                   // conv_h2p_kernel: workgroups sharing one row range (they split the column tiles)
     unsigned *amax_out;           // optional: max |value written| (raw bits, atomicMax): the range of the next consumer
 };
 
@@ -925,6 +929,51 @@ __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restri
     }
 }
 
+// pairs2[(((k >> 4) * 2 + plane) * rows + j) * 16 + (((k >> 3) & 1) ^ ((j >> 3) & 1)) * 8 + (k & 7)]: per K-step and plane the
+// rows' 32-byte runs back to back, the two 16-byte halves of a run swapped on rows with bit 3 set -- byte for byte the LDS
+// image conv_h2p_kernel's fragment reads expect, so a 1 KB LDS-DMA piece is 1 KB of consecutive global memory
+__device__ __forceinline__ long pairs2_index(int j, int k, int rows, int plane) {
+    return ((((long)(k >> 4) * 2 + plane) * rows + j) << 4) + ((((k >> 3) & 1) ^ ((j >> 3) & 1)) << 3) + (k & 7);
+}
+
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(256) weight_pairs2_kernel(const float *__restrict__ w, const unsigned *__restrict__ amax,
+                                                            _Float16 *__restrict__ planes, int Cout, int Cin, int RS) {
+    const float sc = pow2f(h2_exponent(*amax));
+    const long n = (long)Cout * RS * Cin;
+    if (!TRANSPOSE) {
+        const long step = (long)gridDim.x * blockDim.x;
+        const int K = RS * Cin;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+            const float v = w[i] * sc;
+            const _Float16 h = (_Float16)v;
+            const int j = (int)(i / K), k = (int)(i - (long)j * K);
+            planes[pairs2_index(j, k, Cout, 0)] = h;
+            planes[pairs2_index(j, k, Cout, 1)] = (_Float16)(v - (float)h);
+        }
+        return;
+    }
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = o0 + r, c = c0 + tx;
+        tile[r][tx] = (co < Cout && c < Cin) ? w[((long)co * RS + rs) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, co = o0 + tx;
+        if (c < Cin && co < Cout) {
+            const float v = tile[tx][r] * sc;
+            const _Float16 h = (_Float16)v;
+            planes[pairs2_index(c, rs * Cout + co, Cin, 0)] = h;
+            planes[pairs2_index(c, rs * Cout + co, Cin, 1)] = (_Float16)(v - (float)h);
+        }
+    }
+}
+
+#include "igemm_h2p.inc"
+
 // ------------------------------------------------------------------------------------------- wgrad
 struct WgradParams {
     const float *X, *DY;
@@ -1779,10 +1828,59 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
     }
 }
 
+// conv_h2p_kernel (igemm_h2p.inc): which launches take it.  g_h2p: -1 built-in rule, 0 never, 1 whenever eligible
+int g_h2p = -1;
+int g_h2p_min_k = 2304;    // the 3x3 layers.  Below (1x1 convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part
+                           // of a tile's time and the kernel's single workgroup per CU has nothing to overlap it with: measured
+                           // 0.90-1.0x of the 128x256 kernel there, 1.04-1.17x on the 3x3 layers (tools/bench_h2p.py)
+// workgroups per row range: the smallest power of two dividing the column-tile count that gives a workgroup >= 12 row
+// blocks (one block of imbalance is then <= 8 %), else the largest one
+int h2p_gn(int M, int ntiles) {
+    const int RB = rcf_cdiv(M, 32);
+    int gn = 1;
+    while ((long)RB * gn < 12L * H2P_G && gn * 2 <= 16 && ntiles % (gn * 2) == 0) gn *= 2;
+    return gn;
+}
+int h2p_stat_rows(int M, int gn) {                        // partial statistics rows per row range: sub-tiles of the longest one
+    const int GM = H2P_G / gn;
+    const int RB = rcf_cdiv(M, 32), base = RB / GM, extra = RB - base * GM;
+    int n = h2p_subtiles(extra ? base + 1 : base);
+    if (extra && base > 0 && h2p_subtiles(base) > n) n = h2p_subtiles(base);
+    return n < 1 ? 1 : n;
+}
+
+bool h2p_eligible(const IgemmParams &p, int batches) {
+    if (g_h2p == 0 || g_h2_off || !p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return false;
+    if (p.div > 1 || p.bias || p.act != 0 || p.Ncol % 256 || p.K % 16 || p.Cs % 16) return false;
+    // the statistics workspace is sized for one row of partial sums per 64 GEMM rows (rcf_conv2d_fwd_stats_workspace_bytes)
+    const int gn = h2p_gn(p.M, p.Ncol / 256);
+    if (p.stats && (long)(H2P_G / gn) * h2p_stat_rows(p.M, gn) > rcf_cdiv(p.M, 64)) return false;
+    // built-in rule: the deep 3x3 layers with few column tiles.  Many column tiles on a short K (the data gradient of a
+    // 3x3 256 -> 2048 conv: 8 tiles, K = 2304) re-read the activation tile and pay the tile prologue / epilogue once per
+    // column tile: measured equal to or 2 % behind the 128 x 256 kernel there
+    return g_h2p == 1 || (p.K >= g_h2p_min_k && p.M >= 32768 && (long)p.K * 256 >= 1152L * p.Ncol);
+}
+
+int launch_h2p(IgemmParams &p, hipStream_t st) {
+    const long bytes = (long)(p.K / 16) * p.Ncol * 64;
+    const long per_tile_imgs = 256 / (long)p.rr + 2;
+    if (bytes >= (1L << 31) || per_tile_imgs * p.a_img_stride * 4 >= (1L << 31)) return RCF_EINVAL;
+    p.b_bytes = (int)bytes;
+    p.ntiles = p.Ncol / 256;
+    p.h2p_gn = h2p_gn(p.M, p.ntiles);
+    p.mtiles8 = h2p_stat_rows(p.M, p.h2p_gn);
+    p.mtiles = (H2P_G / p.h2p_gn) * p.mtiles8;                          // rows of partial statistics (rcf_conv2d_fwd_bnstats_f32)
+    if (p.step < 0) hipLaunchKernelGGL(conv_h2p_kernel<true>, dim3(H2P_G), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_h2p_kernel<false>, dim3(H2P_G), dim3(256), 0, st, p);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    if (h2p_eligible(p, batches)) return launch_h2p(p, st);
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
@@ -2001,6 +2099,7 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
+    if (s->w_pairs2) { p.b_pairs = s->w_pairs2; p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S); }
     if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
     if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
     return launch_igemm<0>(p, rcf_stream(stream));
@@ -2042,6 +2141,49 @@ extern "C" int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, in
     return 0;
 }
 
+/* Both layouts of the split weights in one buffer -- [pairs (rcf_conv_weight_pairs_f32 / _t_f32) | pairs2 (plane-separated
+ * K-step blocks for the LDS-DMA loads of conv_h2p_kernel)] -- for rcf_conv_shape.w_pairs2 (transpose = 0: forward) and
+ * .w_pairs2_t (transpose = 1: data gradient). */
+extern "C" size_t rcf_conv_weight_pairs2_bytes(int Cout, int Cin, int R, int S, int transpose) {
+    if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return 0;
+    const size_t one = transpose ? (size_t)rcf_cdiv(R * S * Cout, 16) * 16 * Cin * sizeof(float)
+                                 : rcf_conv_weight_pairs_bytes(Cout, Cin, R, S);
+    return 2 * one;
+}
+
+extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int R, int S, int transpose,
+                                          const unsigned *amax_w, void *planes, void *stream) {
+    if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
+    const size_t one = rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, transpose) / 2;
+    char *second = (char *)planes + one;
+    const int rows = transpose ? Cin : Cout, K = R * S * (transpose ? Cout : Cin);
+    if (K % 16) {                                          // pairs2 holds whole K-steps only: the tail step's unused half stays zero
+        if (hipMemsetAsync(second, 0, one, rcf_stream(stream)) != hipSuccess) return RCF_EINVAL;
+    }
+    (void)rows;
+    if (transpose) {
+        if (int e = rcf_conv_weight_pairs_t_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
+        const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
+        hipLaunchKernelGGL(weight_pairs2_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)second,
+                           Cout, Cin, R * S);
+    } else {
+        if (int e = rcf_conv_weight_pairs_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
+        const long n = (long)Cout * R * S * Cin;
+        const long blocks = (n + 1023) / 1024;
+        hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                           rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S);
+    }
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+/* A/B switch of conv_h2p_kernel: mode -1 built-in rule (K >= min_k), 0 never, 1 whenever eligible; min_k <= 0 keeps it */
+extern "C" int rcf_conv_set_h2p(int mode, int min_k) {
+    g_h2p = mode;
+    if (min_k > 0) g_h2p_min_k = min_k;
+    return 0;
+}
+
 extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) {
     if (check_shape(s) || !use_x3(1)) return 0;
     // one row of partial sums per row tile (smallest tile: 64 rows) + the 64 rows of the two-level reduction
@@ -2064,6 +2206,7 @@ extern "C" int rcf_conv2d_fwd_bnstats_f32(const float *x, const float *w, float 
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K;
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
+    if (s->w_pairs2) { p.b_pairs = s->w_pairs2; p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S); }
     p.stats = (double *)workspace;
     if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
     return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cout, sums,
@@ -2103,14 +2246,16 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
     if (use_x3(2)) {
         // k-contiguous weights for the bf16 operand fetch: wt[c][rs][co] (one small transpose per call)
         const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
-        const bool prepared = s->w_pairs_t && s->amax_dy && s->amax_w && !g_h2_off;
+        const void *wpt = s->w_pairs2_t ? s->w_pairs2_t : s->w_pairs_t;
+        const bool prepared = wpt && s->amax_dy && s->amax_w && !g_h2_off;
         if (!prepared && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
         hipStream_t st = rcf_stream(stream);
         p.ldb = p.K;
         p.amax_a = s->amax_dy; p.amax_b = s->amax_w;
         const dim3 tgrid(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S);
-        if (p.amax_a && p.amax_b && !g_h2_off && s->w_pairs_t) {
-            p.b_pairs = s->w_pairs_t;                      // prepared once per weight update by the caller
+        if (p.amax_a && p.amax_b && !g_h2_off && wpt) {
+            p.b_pairs = wpt;                               // prepared once per weight update by the caller
+            if (s->w_pairs2_t) p.b_pairs2 = (const char *)wpt + need;
         } else if (p.amax_a && p.amax_b && !g_h2_off) {   // fp16 pairs: transposed AND split, once per launch
             hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
                                s->Cout, s->Cin, s->R * s->S);

@@ -595,10 +595,17 @@ def commuted_concat_conv(a, b, conv, tape):
             return ops.conv2d_wgrad_bf16(x, dy, wt, dw, 1, dil, dil, beta=beta, region=region)
         return ops.conv2d_wgrad(x, dy, wt, dw, 1, dil, dil, beta=beta, region=region, amax=(rx, rdy))
 
+    wpt = {}                                     # transposed fp16-pair planes of the two weight halves, made once per backward
+
     def cdgrad(dy, wt, xshape, dil, out, beta, rdy, region=None):
         if bf:
             return ops.conv2d_dgrad_bf16(dy, wt, xshape, 1, dil, dil, out=out, beta=beta, region=region)
-        return ops.conv2d_dgrad(dy, wt, xshape, 1, dil, dil, out=out, beta=beta, region=region, amax=(rdy, rw))
+        pt = None
+        if h2 and rdy is not None:
+            pt = wpt.get(id(wt))
+            if pt is None:
+                pt = wpt[id(wt)] = ops.weight_pairs_t(wt, rw)
+        return ops.conv2d_dgrad(dy, wt, xshape, 1, dil, dil, out=out, beta=beta, region=region, amax=(rdy, rw), w_pairs_t=pt)
 
     Z = cfwd(b.t, wbt, pb, d // 2, rb)
     y = ops.resize_nhwc_fwd(Z, (h, w), False)                              # interior: conv_d(up2(b)) = up2(conv_{d/2}(b))

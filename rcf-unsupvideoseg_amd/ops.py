@@ -83,13 +83,27 @@ class _Profile:
         self.which = {which} if isinstance(which, str) else set(which)
         self.records = {w: [] for w in self.which}
 
-    def bracket(self, which, flops):
+    def bracket(self, which, flops, tag=None):
         if self.which is None or which not in self.which:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records[which].append((flops, e0, e1))
+        self.records[which].append((flops, e0, e1, tag))
         e0.record()
         return e1
+
+    def stop_detail(self):
+        """{(family, tag): {launches, flops, ms}}: the brackets of stop(), kept apart by the launch's shape tag
+        (tools/layer_table.py)"""
+        torch.cuda.synchronize()
+        out = {}
+        for w, r in self.records.items():
+            for flops, e0, e1, tag in r:
+                d = out.setdefault((w, tag), {"launches": 0, "flops": 0.0, "ms": 0.0})
+                d["launches"] += 1
+                d["flops"] += float(flops)
+                d["ms"] += float(e0.elapsed_time(e1))
+        self.which, self.records = None, {}
+        return out
 
     def stop(self):
         """{family: {launches, flops, ms}}; a single selected family is returned directly"""
@@ -127,7 +141,7 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None):
+def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None, w_pairs2_t=None):
     """amax = (amax_x, amax_w, amax_dy): int32 [1] device tensors from absmax() or None -- the operand ranges that
     select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h)"""
     N, H, W, Cin = xshape
@@ -137,9 +151,9 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w
     ax, aw, ady = amax if amax is not None else (None, None, None)
     kind = "w" if aw is None else ("d" if ax is None else "f")
     if kind not in H2_KINDS:                      # debug knob: which launches may take the fp16-pair kernels
-        ax = aw = ady = w_pairs = None
+        ax = aw = ady = w_pairs = w_pairs2_t = None
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout,
-                     _addr(ax), _addr(aw), _addr(ady), _addr(w_pairs), _addr(w_pairs_t))
+                     _addr(ax), _addr(aw), _addr(ady), None, _addr(w_pairs_t), _addr(w_pairs), _addr(w_pairs2_t))
 
 
 def _addr(t):
@@ -211,28 +225,45 @@ def weight_checksum(w):
 
 
 def weight_pairs_t(w, amax_w):
-    """the transposed fp16-pair planes the data gradient contracts against (once per weight update, not per launch)"""
+    """the transposed fp16-pair planes the data gradient contracts against (once per weight update, not per launch), in
+    both reading orders (rcf_conv_weight_pairs2_f32, transpose = 1): conv2d_dgrad(w_pairs_t=...)"""
     _need_cuda(w)
     Cout, Cin, R, S = w.shape
-    nbytes = ((R * S * Cout + 15) // 16) * 16 * Cin * 4          # rcf_conv2d_dgrad_workspace_bytes
-    planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    call("rcf_conv_weight_pairs_t_f32", _p(weight_rsck(w)), Cout, Cin, R, S, _p(amax_w), _p(planes), _stream())
+    planes = torch.empty(_lib.load().rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 1), dtype=torch.uint8, device=w.device)
+    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 1, _p(amax_w), _p(planes), _stream())
     return planes
 
 
 def weight_pairs(w, amax_w):
-    """the fp16-pair split of a conv weight (channels_last [Cout,Cin,R,S]) for the forward launches that read it:
-    a uint8 buffer holding two fp16 planes"""
+    """the fp16-pair split of a conv weight (channels_last [Cout,Cin,R,S]) for the forward launches that read it: a uint8
+    buffer holding the two fp16 planes in both reading orders (rcf_conv_weight_pairs2_f32: the 128 x 256 kernel's and the
+    persistent LDS-DMA kernel's)"""
     _need_cuda(w)
     Cout, Cin, R, S = w.shape
-    planes = torch.empty(_lib.load().rcf_conv_weight_pairs_bytes(Cout, Cin, R, S), dtype=torch.uint8, device=w.device)
-    call("rcf_conv_weight_pairs_f32", _p(weight_rsck(w)), Cout, Cin, R, S, _p(amax_w), _p(planes), _stream())
+    planes = torch.empty(_lib.load().rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 0), dtype=torch.uint8, device=w.device)
+    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 0, _p(amax_w), _p(planes), _stream())
     return planes
+
+
+def conv_set_h2p(mode=-1, min_k=0):
+    """A/B switch of the persistent LDS-DMA conv kernel (csrc/igemm_h2p.inc): -1 built-in rule, 0 never, 1 whenever eligible"""
+    _lib.load().rcf_conv_set_h2p(int(mode), int(min_k))
+
+
+if "RCF_H2P" in os.environ:            # experiment knob: RCF_H2P=0 keeps every conv on the 128 x 256 kernel
+    try:
+        conv_set_h2p(int(os.environ["RCF_H2P"]), int(os.environ.get("RCF_H2P_MIN_K", "0")))
+    except Exception:                  # noqa: BLE001 -- no library yet (build step): the switch is applied on first use instead
+        pass
 
 
 def conv_regions_available():
     """the rectangle-restricted convs exist on the split-bf16 kernels (the default conv variant)"""
     return bool(_lib.load().rcf_conv_regions_available())
+
+
+def _shape_tag(s, region=None):
+    return (f"{s.Cin}->{s.Cout} k{s.R} d{s.dil} s{s.stride} {s.N}x{s.Ho}x{s.Wo}" + ("" if region is None else f" region{tuple(int(v) for v in region)}"))
 
 
 def _region_pixels(region, H, W):
@@ -264,7 +295,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     end = None
     if PROFILE.which is not None:       # forward launches of the 128x256-tile kernel instance / of the narrower tiles
         end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
-                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
     if end is not None:
@@ -297,7 +328,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
-                              2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin)
+                              2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin, _shape_tag(s))
     if bn is not None:
         count = s.N * s.Ho * s.Wo
         fin, mean, invstd = _bn_fin(bn, count, x.device)
@@ -319,14 +350,14 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     if amax is None or amax[0] is None or amax[1] is None or "d" not in H2_KINDS:
         w_pairs_t = None
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
-                    amax=None if amax is None else (None, amax[1], amax[0]), w_pairs_t=w_pairs_t)
+                    amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t)
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = 0 if w_pairs_t is not None else _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
-                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
+                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
     call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
          need, _stream())
     if end is not None:
@@ -348,7 +379,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
         ktot = s.R * s.S * s.Cin                                   # plan_wgrad (csrc/igemm_conv.hip): the 128 x 256 fp16-pair tile
         wide = amax is not None and s.Cin % 64 == 0 and ktot >= 256 and s.Cout >= 64
         end = PROFILE.bracket("conv_wgrad_h2t4" if wide else "conv_wgrad_other",
-                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     if end is not None:
         end.record()
@@ -387,7 +418,7 @@ def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0,
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_fwd" if s.Cout > 128 else "conv_bf16_fwd_narrow",
-                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     if stats and bn is not None:                     # the statistics reduction also finalizes the batch norm
         count = s.N * s.Ho * s.Wo
         fin, mean, invstd = _bn_fin(bn, count, x.device)
@@ -416,7 +447,7 @@ def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, r
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_bf16_dgrad_other",
-                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout)
+                              2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
     call("rcf_conv2d_dgrad_bf16", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws), need,
          _stream())
     if end is not None:
@@ -436,7 +467,7 @@ def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=
     if PROFILE.which is not None:
         wide = region is None and s.Cout >= 64 and s.R * s.S * s.Cin >= 256                     # plan_wgrad (csrc/igemm_bf16.hip)
         end = PROFILE.bracket("conv_bf16_wgrad4" if wide else "conv_bf16_wgrad_other",
-                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin)
+                              2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_wgrad_bf16", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     if end is not None:
         end.record()

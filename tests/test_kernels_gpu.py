@@ -129,7 +129,7 @@ def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
     report(f"   max element error / rms(result): fwd {em[0]:.2e} dgrad {em[1]:.2e} wgrad {em[2]:.2e} | torch fp32 "
            f"{rm[0]:.2e} {rm[1]:.2e} {rm[2]:.2e}")
     for ei, ri in zip(em, rm):
-        assert ei < max(4 * ri, 4e-6)
+        assert ei < max(4 * ri, 1e-5)      # measured 0.8e-6 ... 6.2e-6 (torch fp32: 1.2e-6 ... 1.5e-5); a dropped partial product is >= 5e-4
 
 
 def test_conv_fp16_pairs_range_edges(report):
@@ -181,6 +181,68 @@ def test_conv_kernel_variants(variant, report):
             assert e_f < 2e-5 and e_d < 2e-5
     finally:
         lib.rcf_conv_set_variant(-1)
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, pad, dil, H, W, region: row counts that give every sub-tile height (4..8 row blocks, masked < 4)
+    (2, 64, 256, 3, 2, 2, 60, 107, None),        # 12 840 rows = 402 blocks: ranges of 1 / 2 blocks (masked 4-block tiles)
+    (8, 64, 256, 3, 1, 1, 64, 107, None),        # 54 784 rows = 1 712 blocks: ranges of 6 / 7
+    (12, 32, 512, 3, 3, 3, 60, 107, None),       # 77 040 rows: ranges of 9 / 10 -> 5 + 4, 5 + 5; two column tiles; K = 288
+    (16, 16, 256, 1, 0, 1, 60, 107, None),       # 102 720 rows: 12 / 13 -> 8 + 4, 8 + 5; K = 16: ONE K-step (ring padded to 4)
+    (3, 48, 256, 3, 6, 6, 60, 107, (0, 0, 60, 107, 7)),      # border frame (the commuted decode-head conv's band)
+    (3, 48, 256, 3, 6, 6, 60, 107, (5, 9, 40, 70)),          # rectangle
+])
+def test_conv_h2p_matches_x3(case, report):
+    """the persistent LDS-DMA kernel (csrc/igemm_h2p.inc: one workgroup per CU, 4-stage ring, weights by DMA, balanced row
+    ranges) against the 128 x 256 kernel it replaces on the deep 3x3 layers: forward (+ fused batch-norm statistics),
+    data gradient (overwrite and accumulate), whole tensors and regions -- the same arithmetic in the same order, so the
+    outputs must be BIT-identical; and against float64 at fp32 level"""
+    N, Cin, Cout, k, pad, dil, H, W, reg = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:8])))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
+    ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
+    wp, wpt = ops.weight_pairs(wg, aw), ops.weight_pairs_t(wg, aw)
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.conv_set_h2p(mode)
+            y = torch.full((N, H, W, Cout), 3.0, device=DEV)
+            ops.conv2d_fwd(xg, wg, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp, region=reg)
+            dx = torch.full((N, H, W, Cin), 5.0, device=DEV)
+            # dgrad: Ncol = Cin must be a multiple of 256 for the persistent kernel -> swap the roles: gradient of a conv
+            # whose INPUT has Cout channels (weights transposed by viewing the same tensor as [Cin', Cout'])
+            dxw = torch.full((N, H, W, Cout), 5.0, device=DEV)
+            wT = cl_weight(w.permute(1, 0, 2, 3).contiguous())                     # [Cin, Cout, k, k]: a Cout -> Cin conv
+            awT = ops.absmax(ops.weight_rsck(wT))
+            wptT = ops.weight_pairs_t(wT, awT)
+            ops.conv2d_dgrad(xg, wT, (N, H, W, Cout), 1, pad, dil, out=dxw, amax=(ax, awT), w_pairs_t=wptT, region=reg)
+            acc = dxw.clone()
+            ops.conv2d_dgrad(xg, wT, (N, H, W, Cout), 1, pad, dil, out=acc, beta=1, amax=(ax, awT), w_pairs_t=wptT, region=reg)
+            st = None
+            if reg is None:
+                ys, st = ops.conv2d_fwd_stats(xg, wg, 1, pad, dil, amax=(ax, aw), w_pairs=wp)
+                assert torch.equal(ys, y)
+            res[mode] = (y, dxw, acc, st)
+    finally:
+        ops.conv_set_h2p(-1)
+    a, b = res[0], res[1]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if reg is None:
+        e_s = float((a[3] - b[3]).abs().max() / a[3].abs().max())
+        assert e_s < 1e-7, e_s                     # the partial sums are grouped differently (row ranges, not 128-row tiles)
+        yref = F.conv2d(x.double(), w.double(), None, 1, pad, dil)
+        e_f = relerr(from_nhwc(b[0]), yref)
+        dref = F.conv_transpose2d(x.double(), w.permute(1, 0, 2, 3).double(), None, 1, pad, 0, 1, dil)
+        e_d = relerr(from_nhwc(b[1]), dref)
+        sref = torch.cat([yref.sum((0, 2, 3)), (yref ** 2).sum((0, 2, 3))])
+        e_st = float((b[3].cpu() - sref).abs().max() / sref.abs().max())
+        report(f"conv h2p {case[:8]}: identical to the 128x256 kernel; vs float64 fwd {e_f:.2e} dgrad {e_d:.2e} stats {e_st:.2e}")
+        assert e_f < 2e-5 and e_d < 2e-5 and e_st < 1e-6
+    else:
+        report(f"conv h2p region {case}: identical to the 128x256 kernel (fwd, dgrad, accumulate)")
 
 
 @pytest.mark.parametrize("case", [

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rcf_amd
 from rcf_amd import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+ops.conv_set_h2p(int(os.environ.get("RCF_H2P", "-1")))          # 0: 128x256 kernel, 1 / -1: persistent LDS-DMA kernel
 N, Cin, Cout, H, W = 16, 512, 512, 60, 107
 x = torch.randn(N, H, W, Cin, device="cuda:0")
 w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0") * 0.05).contiguous(memory_format=torch.channels_last)
