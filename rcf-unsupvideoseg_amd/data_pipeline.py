@@ -4,7 +4,9 @@ the HIP gather kernels of csrc/datapipe.hip.
 The reference transforms ONE sample at a time on a DataLoader worker (numpy / cv2) and collates afterwards; here the
 loader hands over the DECODED arrays of a whole batch -- frames u8 [B,I,H,W,3], flows fp32 [B,H,W,2] per direction,
 pseudo-label masks u8 [B,I,H,W] -- and one launch per output tensor produces the collated, normalised batch in HBM.
-JPEG / PNG decoding and `.npy` reading stay with the loader (dataset/data.py:62-70,122-128: file I/O, out of scope).
+JPEG / PNG decoding stays with the loader (dataset/data.py:62-70: no decoder library on the device in this image, see the
+note above `BatchUploader`); `.npy` flows are read straight into pinned staging buffers and the decoded batch is uploaded
+on a copy stream (`load_flow_npy_into`, `BatchUploader`: dataset/data.py:122-128 and the DataLoader's collate / pin / copy).
 
 `sample_params` consumes the random stream exactly as the reference's pipeline does (same generator, same calls, same
 order: Resize.random_sample_ratio :130, RandomCrop.get_crop_bbox :447-448, RandomFlip :281, PhotoMetricDistortion
@@ -143,6 +145,9 @@ class Transform:
             _lib.call("rcf_aug_masks_u8", _p(pl), B, I, H, W, _p(prm), _p(po), oh, ow, _stream())
             out["pl_masks"] = list(po.unbind(0))
         out["aug_params"] = params
+        release = out.pop("_release", None)                 # BatchUploader: every kernel reading its buffers is enqueued now
+        if release is not None:
+            release()
         return out
 
     def __repr__(self):
@@ -157,3 +162,88 @@ def get_transform(args, training):
     if cls != "Transform":
         raise NotImplementedError(cls)
     return Transform(training=training, **kw)
+
+
+# ---- decoded batch -> HBM (dataset/data.py:70-151 hands PIL images and np.load'ed flows to the transform) ---------------
+# JPEG / PNG decoding stays on the host: this image has no hardware or device decoder library, a software Huffman + IDCT
+# decoder on the GPU would be a second project, and the bytes are small (a 480x854 JPEG pair is ~0.2 MB against 2.5 MB
+# decoded).  What IS on this path is everything after the decoder: the decoded arrays of a batch are written once into
+# page-locked staging buffers (np.load reads the `.npy` flows straight into them: no intermediate array), uploaded on a
+# copy stream while the previous batch trains, and handed to `Transform.__call__` in the layout it gathers from.
+def load_flow_npy_into(path, out):
+    """dataset/data.py:122-128: `np.load(path)` of a RAFT flow [H,W,2] float32 -- read into `out` (a numpy view of pinned
+    memory).  `.npy` v1/v2 headers are parsed by numpy itself; the payload is read without a temporary array."""
+    with open(path, "rb") as f:
+        major, minor = np.lib.format.read_magic(f)
+        shape, fortran, dtype = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(f)
+        if fortran or tuple(shape) != tuple(out.shape) or np.dtype(dtype) != out.dtype:
+            out[...] = np.load(path).astype(out.dtype, copy=False).reshape(out.shape)     # odd file: the slow, general way
+            return out
+        n = f.readinto(memoryview(out).cast("B"))
+        if n != out.nbytes:
+            raise IOError(f"{path}: {n} of {out.nbytes} payload bytes")
+    return out
+
+
+class BatchUploader:
+    """Double-buffered host -> device path for decoded batches.
+
+        up = BatchUploader(B, I, H, W, has_pl=..., device="cuda:0")
+        stage = up.stage()                 # dict of numpy views on pinned memory: fill them (decoder / np.load workers)
+        ...  stage["imgs"][b, i] = np.asarray(pil_image);  load_flow_npy_into(path, stage["gt_fw_flows"][b])
+        data = up.upload()                 # async copies on the copy stream; returns device tensors for Transform(data)
+
+    `upload` makes the compute stream wait for the copies (an event, no host sync) and flips to the other staging set, so
+    the loader may fill batch t+1 while batch t is copied and transformed.  Pageable -> pinned copies, `torch.stack`
+    collation and per-sample `.cuda()` calls of a default DataLoader path do not exist here."""
+
+    def __init__(self, B, I, H, W, has_flow=True, has_pl=False, device="cuda:0", sets=2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchUploader stages batches for the GPU: there is no CPU path")
+        shapes = {"imgs": ((B, I, H, W, 3), torch.uint8)}
+        if has_flow:
+            shapes["gt_fw_flows"] = ((B, H, W, 2), torch.float32)
+            shapes["gt_bw_flows"] = ((B, H, W, 2), torch.float32)
+        if has_pl:
+            shapes["pl_masks"] = ((B, I, H, W), torch.uint8)
+        self.host = [{k: torch.empty(s, dtype=dt).pin_memory() for k, (s, dt) in shapes.items()} for _ in range(sets)]
+        self.dev = [{k: torch.empty(s, dtype=dt, device=self.device) for k, (s, dt) in shapes.items()} for _ in range(sets)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.done = [None] * sets            # event: set i's device tensors were last read (compute stream)
+        self.cur = 0
+        self.nbytes = sum(t.numel() * t.element_size() for t in self.host[0].values())
+
+    def stage(self):
+        """numpy views of the current pinned staging set (host memory the loader writes)"""
+        return {k: t.numpy() for k, t in self.host[self.cur].items()}
+
+    def upload(self):
+        i = self.cur
+        comp = torch.cuda.current_stream(self.device)
+        if self.done[i] is not None:
+            self.copy_stream.wait_event(self.done[i])          # the batch that used these device buffers has been consumed
+        with torch.cuda.stream(self.copy_stream):
+            for k, t in self.host[i].items():
+                self.dev[i][k].copy_(t, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        comp.wait_event(ready)
+        self.cur = (i + 1) % len(self.host)
+        out = dict(self.dev[i])
+        out["_release"] = lambda: self._release(i)
+        self._host_busy = (i, ready)
+        return out
+
+    def _release(self, i):
+        """call after the last kernel that reads the returned tensors was enqueued (Transform.__call__ is the only reader:
+        it writes fresh output tensors)"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.done[i] = ev
+
+    def wait_host(self):
+        """block until the last upload has left its pinned buffers (before the loader overwrites THAT staging set; with two
+        sets this is the upload before last, which has long finished)"""
+        if getattr(self, "_host_busy", None) is not None:
+            self._host_busy[1].synchronize()

@@ -82,6 +82,9 @@ CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once 
 FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
+# test hook (tests/test_model_gpu.py::test_train_step_all_grads_at_fixed_relu_pattern): a list that receives, in forward
+# order, the boolean map `output > 0` of every batch norm + ReLU -- the activation pattern of this evaluation
+RELU_TRACE = None
 # convs on the fp16-pair kernels (3 partial products; operand ranges from ops.absmax) instead of bf16 triples (6)
 FP16_PAIRS = True
 _side_streams = {}
@@ -128,19 +131,39 @@ class Tape:
 
 
 class DistCtx:
-    """Data-parallel context for SyncBN statistics (torch.distributed over RCCL, or gloo in tests)."""
+    """Data-parallel context for SyncBN statistics (torch.distributed over RCCL, or gloo in tests).
+    One all-reduce per batch norm and direction: forward the fp64 vector [sum x | sum x^2] (2C doubles), backward
+    [sum g | sum g xhat] -- never two.  `count` / `profile` let a test or a dry run see how many collectives a step issues
+    and what one costs on the stream it runs on (tests/test_dist_gpu.py)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.group = group
         self.world = dist.get_world_size(group) if self.on else 1
+        self.count, self.bytes = 0, 0
+        self.profile = False
+        self.events = []                 # profile mode: (start, end) event pairs around each collective
 
     def allreduce_sum(self, t):
         if self.on:
             import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.count += 1
+            self.bytes += t.numel() * t.element_size()
+            if self.profile:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                e1.record()
+                self.events.append((e0, e1))
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def profile_ms(self):
+        """profile mode: per-collective device time between the events around it (ms), after a synchronize"""
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.events]
 
 
 def _param_grad(p):
@@ -438,6 +461,8 @@ class BatchNorm2d(nn.Module):
                          relu_mask=rmask, amax_out=yamax, out_dtype=ydt)
         ya = Act(y)
         ya.amax = yamax
+        if RELU_TRACE is not None and relu:
+            RELU_TRACE.append(y > 0)
         if tape.enabled:
             if not self.training:
                 raise RuntimeError("tape backward through eval-mode BN is not implemented")

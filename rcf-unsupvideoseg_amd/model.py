@@ -193,6 +193,19 @@ class RCFModel(nn.Module):
             self.dist = DistCtx()
         return self.dist
 
+    def _teacher_dist(self):
+        """the EMA teacher's SyncBN exchanges on their OWN communicator: its forward is enqueued (on the side stream)
+        ahead of the student's, and on one communicator every statistics all-reduce of the student would queue behind
+        all of the teacher's -- the two forwards would serialise across ranks.  RCF_TEACHER_GROUP=0 keeps the default
+        group (a fallback should two more concurrent RCCL communicators misbehave on a given system)."""
+        d = self._dist()
+        if not d.on or os.environ.get("RCF_TEACHER_GROUP", "1") == "0":
+            return d
+        if getattr(self, "_tdist", None) is None:
+            import torch.distributed as tdist
+            self._tdist = DistCtx(group=tdist.new_group())
+        return self._tdist
+
     def _select_precision(self):
         p = self.precision
         if p is None:
@@ -294,7 +307,7 @@ class RCFModel(nn.Module):
         oc = self.args.object_channel
         if self.crf_use_ema:
             t = Tape(enabled=False)
-            d = self._dist()             # in training mode (after model.train()) the teacher's SyncBN exchanges statistics too
+            d = self._teacher_dist()     # in training mode (after model.train()) the teacher's SyncBN exchanges statistics too
             le = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img_act, t, d), t, d)
         else:
             le = logits

@@ -100,7 +100,10 @@ class Trainer:
         # The gradient chunks travel on their OWN communicator: with one process group the asynchronous 10-60 MB chunk
         # all-reduces and the small synchronous SyncBN all-reduces of the layers still in backward would share one
         # RCCL stream in issue order, and every statistics exchange would queue behind the chunk before it.
-        self.grad_group = dist.new_group() if self.chunked else None
+        # RCF_GRAD_GROUP=0: the chunks share the default group (fallback: two RCCL communicators in flight at once is the
+        # configuration no multi-GPU box has exercised yet)
+        own_group = __import__("os").environ.get("RCF_GRAD_GROUP", "1") != "0"
+        self.grad_group = dist.new_group() if (self.chunked and own_group) else None
         self._pending, self._done = [], set()
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
             self.model.grad_ready_hook = self._grads_ready

@@ -92,6 +92,12 @@ def main():
         meta[tag] = dict(H=H, W=W, B=B, C=C, weight_seed=7, config_id=1, loss_fp32=l32, loss_bf16=l16, gradnorm_fp32=g32,
                          gradnorm_bf16=g16, ref_bf16_vs_fp32=dev, oracle_vs_reference_autocast=chk)
         arrays[tag + "_argmax_fp32"] = z32.argmax(1).numpy().astype(np.uint8)
+        # the reference's own autocast decisions, pixel by pixel: the flip RATE as a function of the fp32 margin is the
+        # yardstick that covers every pixel (the `sure` threshold above is a max statistic: one far-out flip of the
+        # reference leaves 8-23 % of the pixels to check).  Scaling conv_seg x10 as SURVEY section 7 proposed does NOT
+        # separate the logits: signal and bf16 noise scale together (measured: identical flip maps, 56 % gradient-norm
+        # deviation from the saturated softmax) -- tried and dropped.
+        arrays[tag + "_argmax_bf16"] = z16.argmax(1).numpy().astype(np.uint8)
         arrays[tag + "_margin_fp32"] = margin.numpy().astype(np.float16)
         if tag == "small":
             arrays[tag + "_masks_fp32"] = p32.numpy()

@@ -335,8 +335,21 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
         d_h, d_r = float((ph - p32).abs().mean()), float((p16 - p32).abs().mean())
         msg += f" | mean |mask - fp32 mask| {d_h:.3e} (ref autocast {d_r:.3e})"
         assert d_h < 2 * d_r + 1e-3
+    # ... and EVERY pixel, statistically: pixels binned by their fp32 top-2 margin (ten equally filled bins); in each bin
+    # the fraction this step decides differently from the fp32 reference against the fraction the reference's own autocast
+    # run decides differently.  A path that is only right where the decision is easy shows up in the low-margin bins, one
+    # with a systematic error in the high-margin ones (where the reference flips nothing).
+    am16 = torch.from_numpy(arr[tag + "_argmax_bf16"].astype(np.int64))
+    ref_mism = am16 != am32
+    order = margin.flatten().argsort()
+    bins = [order[i * order.numel() // 10:(i + 1) * order.numel() // 10] for i in range(10)]
+    rate_h = [float(mism.flatten()[b].float().mean()) for b in bins]
+    rate_r = [float(ref_mism.flatten()[b].float().mean()) for b in bins]
+    msg += (" | flip rate by fp32-margin decile (all px), HIP: " + " ".join(f"{v:.3f}" for v in rate_h) +
+            " ref autocast: " + " ".join(f"{v:.3f}" for v in rate_r))
     report(msg)
     assert all(e_l[k] < max(3 * ref["loss"][k], 5e-3) for k in e_l), e_l
     assert all(e_g[k] < max(3 * ref["gradnorm"][k], 0.10) for k in e_g), e_g
     assert float(mism.float().mean()) < 2 * ref["argmax_mismatch_frac"] + 0.01
     assert n_sure_bad == 0
+    assert all(h < 1.5 * r + 0.02 for h, r in zip(rate_h, rate_r)), (rate_h, rate_r)

@@ -107,3 +107,27 @@ def test_hsv_restatement_round_trip():
     assert np.all(hsv[..., 0] == 0) and np.all(hsv[..., 1] == 0) and np.array_equal(T.hsv2rgb(hsv), gray)
     prim = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], dtype=np.uint8)
     assert T.rgb2hsv(prim)[0, :, 0].tolist() == [0, 60, 120]
+
+
+def test_npy_flow_reader_fills_a_given_buffer(tmp_path):
+    """dataset/data.py:122-128 `np.load(flow_path)`: the payload of a v1 / v2 `.npy` file lands in the caller's (pinned)
+    buffer without a temporary; files of another dtype / order take numpy's general path"""
+    from rcf_amd.data_pipeline import load_flow_npy_into
+    g = np.random.RandomState(3)
+    a = g.randn(13, 17, 2).astype(np.float32)
+    for name, arr in (("v1.npy", a), ("f64.npy", a.astype(np.float64)), ("fortran.npy", np.asfortranarray(a))):
+        np.save(tmp_path / name, arr)
+        out = np.full(a.shape, 7, np.float32)
+        load_flow_npy_into(str(tmp_path / name), out)
+        assert np.array_equal(out, a), name
+    with open(tmp_path / "v2.npy", "wb") as f:
+        np.lib.format.write_array(f, a, version=(2, 0))
+    out = np.empty_like(a)
+    load_flow_npy_into(str(tmp_path / "v2.npy"), out)
+    assert np.array_equal(out, a)
+    np.save(tmp_path / "short.npy", a)
+    data = open(tmp_path / "short.npy", "rb").read()
+    open(tmp_path / "short.npy", "wb").write(data[:-100])
+    import pytest
+    with pytest.raises((IOError, ValueError)):
+        load_flow_npy_into(str(tmp_path / "short.npy"), np.empty_like(a))

@@ -125,3 +125,36 @@ def test_output_feeds_the_model_batch_layout_and_refuses_host_tensors():
     tf.crop_size = (500, 500)                                  # cannot happen with the reference's 400 / 384 constants
     with pytest.raises(ValueError):                            # the reference rescales too-small frames again; refused here
         tf.sample_params(300, 520, np.random.RandomState(0))
+
+
+def test_batch_uploader_pinned_double_buffer(tmp_path):
+    """decoded batch -> pinned staging (flows np.load'ed straight into it) -> copy stream -> Transform: the same tensors as
+    the plain `torch.from_numpy(...).to(device)` path, over more batches than staging sets (buffers are recycled)"""
+    import torch
+    from rcf_amd.data_pipeline import BatchUploader, Transform, load_flow_npy_into
+    from rcf_amd import synth
+    H, W, B = 120, 214, 3
+    tf = Transform(training=True, strong_aug=True, has_pl=True)
+    up = BatchUploader(B, 2, H, W, has_flow=True, has_pl=True, device="cuda:0")
+    for it in range(5):
+        samples = [synth.loader_sample(100 * it + b, H, W) for b in range(B)]
+        rng = np.random.RandomState(it)
+        params = np.stack([tf.sample_params(H, W, rng) for _ in range(B)])
+        up.wait_host()
+        st = up.stage()
+        for b, smp in enumerate(samples):
+            st["imgs"][b] = smp["frames"]
+            st["pl_masks"][b] = smp["pl"]
+            for key, name in (("fw", "gt_fw_flows"), ("bw", "gt_bw_flows")):
+                path = str(tmp_path / f"{key}_{it}_{b}.npy")
+                np.save(path, smp[key])
+                load_flow_npy_into(path, st[name][b])
+        got = tf(up.upload(), params=params)
+        ref = tf({"imgs": torch.from_numpy(np.stack([s["frames"] for s in samples])).cuda(),
+                  "gt_fw_flows": torch.from_numpy(np.stack([s["fw"] for s in samples])).cuda(),
+                  "gt_bw_flows": torch.from_numpy(np.stack([s["bw"] for s in samples])).cuda(),
+                  "pl_masks": torch.from_numpy(np.stack([s["pl"] for s in samples])).cuda()}, params=params)
+        assert "_release" not in got
+        for k in ("imgs", "gt_fw_flows", "gt_bw_flows", "pl_masks"):
+            for a, b_ in zip(got[k], ref[k]):
+                assert torch.equal(a, b_), (it, k)

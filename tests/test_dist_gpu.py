@@ -164,7 +164,19 @@ def _nccl_world1_worker(port, q):
     torch.cuda.synchronize()
     named = dict(m.named_parameters())
     g = named["backbone2.layer3.2.conv2.weight"].grad.cpu().contiguous().numpy().ravel()[:512].copy()
-    q.put((l, len(tr._pending), sorted(tr._done), g))
+    # one more step with every SyncBN collective counted and bracketed by events on the stream it is issued on
+    import time
+    m.dist.count, m.dist.bytes, m.dist.profile, m.dist.events = 0, 0, True, []
+    t0 = time.perf_counter()
+    tr.step(_batch(nb, slice(0, B), "cuda:0"))
+    torch.cuda.synchronize()
+    t_prof = time.perf_counter() - t0
+    ms = m.dist.profile_ms()
+    m.dist.profile = False
+    n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2d" and mod.training and mod.sync)
+    stats = dict(count=m.dist.count, bytes=m.dist.bytes, n_bn=n_bn, mean_us=1e3 * sum(ms) / max(len(ms), 1),
+                 max_us=1e3 * max(ms), total_ms=sum(ms), step_ms=1e3 * t_prof)
+    q.put((l, len(tr._pending), sorted(tr._done), g, stats))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -174,9 +186,14 @@ def test_rccl_world1_dry_run_of_chunked_allreduce(report):
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_world1_worker, args=(30900 + os.getpid() % 1000, q))
     p.start()
-    l, npend, done, g = q.get(timeout=600)
+    l, npend, done, g, st = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
+    # SyncBN: ONE all-reduce per batch norm and direction (forward [sum | sum of squares], backward [sum g | sum g xhat])
+    report(f"SyncBN collectives in one step (RCCL, world 1, 64x96 frames): {st['count']} all-reduces for {st['n_bn']} batch norms, "
+           f"{st['bytes']} bytes in total; device time per collective mean {st['mean_us']:.1f} us, max {st['max_us']:.1f} us, "
+           f"sum {st['total_ms']:.2f} ms of a {st['step_ms']:.1f} ms step")
+    assert st["count"] == 2 * st["n_bn"] and st["n_bn"] >= 50
     rcf_amd, m, nb = _setup()
     tr = rcf_amd.Trainer(m, device="cuda:0")
     want = [float(tr.step(_batch(nb, slice(0, B), "cuda:0"))["loss"]) for _ in range(2)]

@@ -201,6 +201,70 @@ def test_train_step_vs_oracle_all_grads(report):
     assert not bad and e_buf < TOL, bad
 
 
+def test_train_step_all_grads_at_fixed_relu_pattern(monkeypatch, report):
+    """EVERY parameter gradient against float64 with the ReLU lottery taken out.  A ReLU unit whose pre-activation lies
+    within fp32 noise of zero falls either way in two equally valid fp32 evaluations, and one such unit moves a channel's
+    weight gradient by percent -- which is why the test above needs a 1e-2 floor that would also hide a real precision
+    loss.  Here the float64 truth (and the CPU fp32 yardstick) are evaluated AT THE ACTIVATION PATTERN OF THE HIP RUN:
+    the HIP forward records `output > 0` of every batch norm + ReLU (layers.RELU_TRACE), and the oracle's F.relu is
+    replaced by a multiplication with those masks.  With the pattern fixed the network is smooth in its parameters, so
+    what remains is arithmetic error: limit 6x the CPU fp32 run's own error at the same pattern, floor 1e-4."""
+    import rcf_torch as orc
+    from rcf_amd import layers
+    H, W, B = 64, 96, 2
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    tr = rcf_amd.Trainer(hip, device=DEV)
+    tr.fp.zero_grad()
+    hip.train()
+    trace = []
+    monkeypatch.setattr(layers, "RELU_TRACE", trace)
+    lh = hip(_batch(B, H, W, DEV))
+    monkeypatch.setattr(layers, "RELU_TRACE", None)
+    lh["loss"].backward()
+    masks = [m.permute(0, 3, 1, 2).contiguous().cpu() for m in trace]              # NHWC -> NCHW, forward order
+
+    def forced_run(double):
+        m = _build(H, W, False, "cpu", orc.RCFModel)
+        b = _batch(B, H, W, "cpu")
+        if double:
+            m = m.double()
+            b = {k: ([t.double() for t in v] if k in ("imgs", "gt_fw_flows", "gt_bw_flows") else v) for k, v in b.items()}
+        queue = list(masks)
+
+        def forced_relu(x, inplace=False):
+            mk = queue.pop(0)
+            assert tuple(mk.shape) == tuple(x.shape), (tuple(mk.shape), tuple(x.shape))
+            return x * mk.to(x.dtype)
+        monkeypatch.setattr(orc.F, "relu", forced_relu)
+        try:
+            m.train()
+            losses = m(b)
+            losses["loss"].backward()
+        finally:
+            monkeypatch.undo()
+        assert not queue, f"{len(queue)} recorded ReLU maps were not consumed: the two forward orders differ"
+        return {k: float(v) for k, v in losses.items()}, dict(m.named_parameters())
+    l64, g64 = forced_run(True)
+    l32, g32 = forced_run(False)
+    e_loss = rel(float(lh["loss"]), l64["loss"])
+    worst_ratio, worst_name, worst_abs, worst_ref, bad = 0.0, "", 0.0, 0.0, []
+    for n, p in hip.named_parameters():
+        truth = g64[n].grad
+        scale = float(truth.norm())
+        if scale < 1e-12:
+            continue
+        e_hip = float((p.grad.cpu().double() - truth).norm()) / scale
+        e_ref = float((g32[n].grad.double() - truth).norm()) / scale
+        if e_hip > max(6.0 * e_ref, 1e-4):
+            bad.append((n, e_hip, e_ref))
+        if e_hip / max(e_ref, 1e-7) > worst_ratio:
+            worst_ratio, worst_name, worst_abs, worst_ref = e_hip / max(e_ref, 1e-7), n, e_hip, e_ref
+    report(f"all-grads at the HIP run's ReLU pattern ({len(masks)} ReLU layers, {sum(int(m.numel()) for m in masks)} units) vs "
+           f"float64: loss {e_loss:.2e}; worst HIP / CPU-fp32 error ratio {worst_ratio:.2f} at {worst_name} (HIP {worst_abs:.2e}, "
+           f"CPU fp32 {worst_ref:.2e}); parameters over max(6x ref, 1e-4): {len(bad)} {bad[:4]}")
+    assert e_loss < 1e-5 and not bad, bad
+
+
 def test_eval_forward_matches_oracle(report):
     import rcf_torch as orc
     H, W, B = 64, 96, 2
@@ -416,19 +480,69 @@ def test_bn_buffers_after_two_steps_vs_oracle(report):
     assert n >= 50 and worst_m < 2e-3 and worst_v < 2e-3
 
 
-def test_fullsize_b8_losses_vs_oracle(report):
-    """BASELINE configs[1] at its real batch: 8 pairs of 480x854 (16 frames through the backbone, SyncBN statistics over all
-    of them) -- every loss term of one training-mode forward against the oracle on the host (the reference-generated fixture
-    of this geometry holds one pair; the oracle is pinned to the reference on the small cases and on that pair)"""
+def test_fullsize_b8_losses_and_gradients_vs_oracle(report):
+    """BASELINE configs[1] at its real batch: 8 pairs of 480x854 (16 frames through the backbone, batch-norm statistics over
+    all of them) -- every loss term of one training-mode forward AND the gradient norm of every top-level module of the
+    backward against the oracle on the host in fp32 (the reference-generated fixture of this geometry holds one pair; the
+    oracle is pinned to the reference on the small cases and on that pair); the bf16 step (BASELINE configs[2] on one rank)
+    on the same batch against the same oracle numbers, at the reference's own autocast-vs-fp32 deviation of this geometry
+    (tests/golden/bf16.json, 480x854: gradient norms up to 8 %, losses 2e-4 .. 1.3e-3; limits 3x, floors 0.5 % / 10 %).
+    The oracle's backward at this size needs ~45 GB of host memory: hosts with less run the forward comparison only."""
+    import json
     import rcf_torch as orc
     H, W, B = 480, 854, 8
-    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    avail_gb = 0.0
+    try:
+        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+    except Exception:                                           # noqa: BLE001
+        pass
+    with_grad = avail_gb >= 90
+
+    def gnorms(model):
+        gn = {}
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+        return {k: v ** 0.5 for k, v in gn.items()}
     ora = _build(H, W, False, "cpu", orc.RCFModel)
-    hip.train()
     ora.train()
-    with torch.no_grad():
-        lh = hip(_batch(B, H, W, DEV))
+    if with_grad:
         lo = ora(_batch(B, H, W, "cpu"))
-    e = {k: rel(float(lh[k]), float(lo[k])) for k in lo}
-    report(f"480x854 b8 (16 frames): " + " ".join(f"{k} hip {float(lh[k]):.6f} oracle {float(lo[k]):.6f} ({e[k]:.1e})" for k in lo))
-    assert all(np.isfinite(float(v)) for v in lh.values()) and max(e.values()) < TOL
+        lo["loss"].backward()
+        go = gnorms(ora)
+    else:
+        with torch.no_grad():
+            lo = ora(_batch(B, H, W, "cpu"))
+        go = None
+    lo = {k: float(v) for k, v in lo.items()}
+    del ora
+    out = {}
+    for prec in ("fp32", "bf16"):
+        hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+        hip.precision = prec
+        hip.train()
+        lh = hip(_batch(B, H, W, DEV))
+        if with_grad:
+            lh["loss"].backward()
+        out[prec] = ({k: float(v) for k, v in lh.items()}, gnorms(hip) if with_grad else None)
+        del hip
+        torch.cuda.empty_cache()
+    e32 = {k: rel(out["fp32"][0][k], lo[k]) for k in lo}
+    e16 = {k: rel(out["bf16"][0][k], lo[k]) for k in lo}
+    msg = (f"480x854 b8 (16 frames): fp32 " + " ".join(f"{k} hip {out['fp32'][0][k]:.6f} oracle {lo[k]:.6f} ({e32[k]:.1e})" for k in lo) +
+           " | bf16 " + " ".join(f"{k} {e16[k]:.1e}" for k in lo))
+    assert all(np.isfinite(v) for v in out["fp32"][0].values()) and max(e32.values()) < TOL
+    ref16 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
+    assert all(e16[k] < max(3 * ref16["loss"][k], 5e-3) for k in e16), e16
+    if with_grad:
+        g32 = {k: rel(out["fp32"][1][k], v) for k, v in go.items()}
+        g16 = {k: rel(out["bf16"][1][k], v) for k, v in go.items()}
+        msg += (" | gradient norms vs oracle: fp32 " + " ".join(f"{k} {v:.1e}" for k, v in g32.items()) +
+                " bf16 " + " ".join(f"{k} {v:.1e}" for k, v in g16.items()))
+        report(msg)
+        # fp32: two valid fp32 evaluations of this network differ by up to 2.7e-3 in the backbone's gradient norm at this
+        # geometry (tests/golden/oracle_vs_reference.json: the reference against itself); limit 4x that
+        assert max(g32.values()) < 1.1e-2, g32
+        assert all(g16[k] < max(3 * ref16["gradnorm"][k], 0.10) for k in g16), g16
+    else:
+        report(msg + f" | host has {avail_gb:.0f} GB available: the oracle's backward at this size was skipped")
