@@ -41,7 +41,8 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *vid;              // [F][E]   bucket index after insert, then dense vertex id
     int *slot_vid;         // [F][E]   scan scratch: vertex id of representative slots
     int *vrep;             // [F][E]   vertex -> representative slot
-    int *nb;               // [F][E][2*(pd+1)] neighbour vertex ids (-1 = none), [axis][plus/minus]
+    int *nb;               // [F][pd+1][E][2] neighbour vertex ids (-1 = none): axis-major, so that a blur pass reads 8 contiguous
+                           // bytes per vertex (vertex-major [E][2(pd+1)] made every pass fetch all 48 bytes of a vertex's lists)
     int *cnt;              // [F][E]   entries per vertex, then fill cursor
     int *off;              // [F][E]   CSR offsets (exclusive scan of cnt)
     int2 *csr;             // [F][E]   (pixel, weight bits) grouped by vertex
@@ -344,9 +345,13 @@ __global__ void __launch_bounds__(256) lattice_entry_vid_kernel(Lattice Lt) {
 // the '-' neighbour of u (each link has exactly one writer).
 __global__ void __launch_bounds__(256) neighbours_init_kernel(Lattice Lt) {
     const int f = blockIdx.y;
-    const long total = (long)Lt.L[f] * 2 * (Lt.pd + 1);
+    const long per_axis = 2L * Lt.L[f], total = per_axis * (Lt.pd + 1);
     int *nb = Lt.nb + (long)f * Lt.E * 2 * (Lt.pd + 1);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) nb[i] = -1;
+    if (per_axis == 0) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long axis = i / per_axis;
+        nb[axis * 2 * Lt.E + (i - axis * per_axis)] = -1;        // [axis][vertex][+/-], axis stride 2E
+    }
 }
 __global__ void __launch_bounds__(256) lattice_neighbours_kernel(Lattice Lt) {
     const int f = blockIdx.y;
@@ -372,8 +377,8 @@ __global__ void __launch_bounds__(256) lattice_neighbours_kernel(Lattice Lt) {
             if (s == -1) break;
             if (key_eq(keys[s], want)) {
                 const int u = sv[s];
-                nb[v * (2 * nax) + 2 * axis] = u;            // v's '+' neighbour
-                nb[(long)u * (2 * nax) + 2 * axis + 1] = (int)v;   // u's '-' neighbour
+                nb[((long)axis * Lt.E + v) * 2] = u;              // v's '+' neighbour ([axis][vertex][+/-]: a blur pass reads 8 contiguous bytes per vertex)
+                nb[((long)axis * Lt.E + u) * 2 + 1] = (int)v;     // u's '-' neighbour
                 break;
             }
             if (++h == nbk) h = 0;
@@ -762,8 +767,8 @@ __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
             if (cur == PK_EMPTY) break;
             if (cur == want) {
                 const int u = sv[h];
-                nb[v * (2 * nax) + 2 * axis] = u;
-                nb[(long)u * (2 * nax) + 2 * axis + 1] = (int)v;
+                nb[((long)axis * Lt.E + v) * 2] = u;
+                nb[((long)axis * Lt.E + u) * 2 + 1] = (int)v;
                 break;
             }
             if (++h == nbk) h = 0;
@@ -905,7 +910,7 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T
     const long Lf = Lt.L[f];
     const long fb = (long)f * Lt.E;
     for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x) {
-        const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb + v) * nax2 + 2 * axis);
+        const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb * (nax2 / 2) + (long)axis * Lt.E + v) * 2);
         const T me = in[fb + v];
         T vp, vm;
         zero_of(vp);

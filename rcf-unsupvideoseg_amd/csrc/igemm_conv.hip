@@ -784,6 +784,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                         else if (p.act == 2) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
                     }
                     float *dq = drow + nr * 32 + 8 * g;
+                    if (p.dbg == 4) {
+                        // timing experiment (results are garbage): the same bytes as lane-linear 1 KB runs -- is the epilogue
+                        // bound by its store pattern (32-byte pieces of 32 different pixel rows per instruction)?
+                        const long tl = (long)tile_m % (p.mtiles - 1) * p.ntiles + tile_n;       // stays inside the output tensor
+                        dq = p.Y + ((tl * (MR * WM) + (wm * MR + mr)) * (NR * WN * 4) + (wn * NR + nr) * 4 + g) * 256 + lane * 4;
+                    }
                     if (whole) {
                         f32x4 *dst = reinterpret_cast<f32x4 *>(dq);
                         if (p.beta) v += *dst;
@@ -2002,7 +2008,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
 /* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
  * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
 extern "C" int rcf_conv_set_variant(int v) {
-    g_x3_dbg = v >= 0 ? ((v >> 15) & 1) | ((v >> 17) & 2) : 0;     // 0x8000: loads off; 0x40000: activation loads from a 64 KB window
+    g_x3_dbg = v >= 0 ? ((v >> 15) & 1) | ((v >> 17) & 2) | ((v >> 18) & 4) : 0;     // 0x8000: loads off; 0x40000: activation loads from a 64 KB window; 0x100000: lane-linear epilogue stores (timing only)
     g_wgrad_tr_off = v >= 0 ? (v >> 19) & 1 : 0;
     g_h2_off = v >= 0 ? (v >> 17) & 1 : 0;     // 0x20000: bf16 triples even when the operand ranges are given
     g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
