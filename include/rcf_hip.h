@@ -76,6 +76,9 @@ int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int R, int S, 
 /* A/B switch of the persistent kernel: mode -1 built-in rule (taken when K >= min_k), 0 never, 1 whenever eligible
  * (non-strided, no bias / activation, Cout-side % 256 == 0, K % 16 == 0, >= 32768 rows); min_k <= 0 keeps the current one */
 int rcf_conv_set_h2p(int mode, int min_k);
+/* A/B switch of the stream kernel of the 1x1 convs (conv_h2s_kernel, csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1
+ * whenever eligible (1x1, stride 1, whole tensor, Cout-side % 256 == 0, K % 64 == 0, K >= 192) */
+int rcf_conv_set_h2s(int mode);
 
 /* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
 int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);

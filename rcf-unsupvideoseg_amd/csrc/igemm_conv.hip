@@ -979,6 +979,7 @@ __global__ void __launch_bounds__(256) weight_pairs2_kernel(const float *__restr
 }
 
 #include "igemm_h2p.inc"
+#include "igemm_h2s.inc"
 
 // ------------------------------------------------------------------------------------------- wgrad
 struct WgradParams {
@@ -1882,10 +1883,55 @@ int launch_h2p(IgemmParams &p, hipStream_t st) {
     return 0;
 }
 
+// conv_h2s_kernel (igemm_h2s.inc): the 1x1 convs as one stream of K-steps per workgroup, epilogues under the next tile's
+// MFMAs.  g_h2s: -1 built-in rule, 0 never, 1 whenever eligible.  MEASURED SLOWER than the 128 x 256 kernel (0.70-0.90x on
+// the step's 1x1 layers, bit-identical results; tools/bench_h2p.py, profiles/r03_bench_h2p_ab.txt): with ONE wave per SIMD
+// every instruction of the epilogue chunks (scale, accumulate, store, statistics: ~35 per 6 MFMAs on top of the loader's
+// ~20) is issued by the wave that also issues the MFMAs -- a SIMD issues to its matrix, vector, LDS and memory pipes in the
+// same cycle only from DIFFERENT waves, so two independent workgroups per CU hide an epilogue better than one stream
+// does.  The built-in rule therefore never takes it; the tests force it (mode 1) to keep it correct.
+int g_h2s = -1;
+int h2s_gn(int M, int ntiles) {
+    const int RB = rcf_cdiv(M, 32);
+    int gn = 1;
+    while ((long)RB * gn < 12L * H2P_G && gn * 2 <= 16 && ntiles % (gn * 2) == 0) gn *= 2;
+    return gn;
+}
+int h2s_stat_rows(int M, int gn) {                        // 4-block sub-tiles of the longest row range
+    const int GM = H2P_G / gn;
+    const int RB = rcf_cdiv(M, 32), base = RB / GM, extra = RB - base * GM;
+    const int n = rcf_cdiv(extra ? base + 1 : base, 4);
+    return n < 1 ? 1 : n;
+}
+bool h2s_eligible(const IgemmParams &p, int batches) {
+    if (g_h2s == 0 || g_h2_off || !p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return false;
+    if (p.S != 1 || p.K != p.Cs || p.up != 1 || p.off != 0 || p.div > 1 || p.bias || p.act != 0) return false;
+    if (p.rh != p.Ho || p.rw != p.Wo || p.rband > 0 || p.Ho != p.Hs || p.Wo != p.Ws) return false;
+    if (p.Ncol % 256 || p.K % 64 || p.K < 192 || p.a_pitch % 4 || p.y_pitch % 4) return false;
+    if ((long)p.M * p.a_pitch * 4 >= (1L << 31) || (long)p.M * p.y_pitch * 4 >= (1L << 31)) return false;
+    const int gn = h2s_gn(p.M, p.Ncol / 256);
+    if (p.stats && (long)(H2P_G / gn) * h2s_stat_rows(p.M, gn) > rcf_cdiv(p.M, 64)) return false;
+    return g_h2s == 1;                                      // never by the built-in rule: see above
+}
+int launch_h2s(IgemmParams &p, hipStream_t st) {
+    const long bytes = (long)(p.K / 16) * p.Ncol * 64;
+    if (bytes >= (1L << 31)) return RCF_EINVAL;
+    p.b_bytes = (int)bytes;
+    p.ntiles = p.Ncol / 256;
+    p.h2p_gn = h2s_gn(p.M, p.ntiles);
+    p.mtiles8 = h2s_stat_rows(p.M, p.h2p_gn);
+    p.mtiles = (H2P_G / p.h2p_gn) * p.mtiles8;
+    if (p.step < 0) hipLaunchKernelGGL(conv_h2s_kernel<true>, dim3(H2P_G), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_h2s_kernel<false>, dim3(H2P_G), dim3(256), 0, st, p);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    if (h2s_eligible(p, batches)) return launch_h2s(p, st);
     if (h2p_eligible(p, batches)) return launch_h2p(p, st);
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
     const long per_tile_imgs = 256 / (long)p.rr + 2;
@@ -2187,6 +2233,12 @@ extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int
 extern "C" int rcf_conv_set_h2p(int mode, int min_k) {
     g_h2p = mode;
     if (min_k > 0) g_h2p_min_k = min_k;
+    return 0;
+}
+
+/* A/B switch of conv_h2s_kernel (the 1x1 convs as a stream of K-steps): -1 built-in rule, 0 never, 1 whenever eligible */
+extern "C" int rcf_conv_set_h2s(int mode) {
+    g_h2s = mode;
     return 0;
 }
 

@@ -250,6 +250,16 @@ def conv_set_h2p(mode=-1, min_k=0):
     _lib.load().rcf_conv_set_h2p(int(mode), int(min_k))
 
 
+def conv_set_h2s(mode=-1):
+    """A/B switch of the stream kernel of the 1x1 convs (csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1 whenever eligible"""
+    _lib.load().rcf_conv_set_h2s(int(mode))
+
+
+if "RCF_H2S" in os.environ:
+    try:
+        conv_set_h2s(int(os.environ["RCF_H2S"]))
+    except Exception:                  # noqa: BLE001
+        pass
 if "RCF_H2P" in os.environ:            # experiment knob: RCF_H2P=0 keeps every conv on the 128 x 256 kernel
     try:
         conv_set_h2p(int(os.environ["RCF_H2P"]), int(os.environ.get("RCF_H2P_MIN_K", "0")))

@@ -191,6 +191,11 @@ def test_conv_kernel_variants(variant, report):
     (16, 16, 256, 1, 0, 1, 60, 107, None),       # 102 720 rows: 12 / 13 -> 8 + 4, 8 + 5; K = 16: ONE K-step (ring padded to 4)
     (3, 48, 256, 3, 6, 6, 60, 107, (0, 0, 60, 107, 7)),      # border frame (the commuted decode-head conv's band)
     (3, 48, 256, 3, 6, 6, 60, 107, (5, 9, 40, 70)),          # rectangle
+    # 1x1 convs: the stream kernel (csrc/igemm_h2s.inc) -- epilogue of a tile under the MFMAs of the next one
+    (16, 256, 1024, 1, 0, 1, 60, 107, None),     # 12 / 13 row blocks per range: 3 + 1 sub-tiles (one of them 1 block), 4 column tiles, 16 K-steps
+    (5, 192, 256, 1, 0, 1, 60, 107, None),       # K = 192: 12 K-steps (no plain steps); ranges of 3 / 4 blocks: a single tile per workgroup
+    (2, 512, 512, 1, 0, 1, 33, 41, None),        # 2 706 rows = 85 blocks on 256 workgroups: most of them have NO tile; 32 K-steps
+    (9, 320, 768, 1, 0, 1, 60, 107, None),       # 3 column tiles (workgroups cannot share ranges: gn = 1), K = 320: 20 K-steps
 ])
 def test_conv_h2p_matches_x3(case, report):
     """the persistent LDS-DMA kernel (csrc/igemm_h2p.inc: one workgroup per CU, 4-stage ring, weights by DMA, balanced row
@@ -209,6 +214,7 @@ def test_conv_h2p_matches_x3(case, report):
     try:
         for mode in (0, 1):
             ops.conv_set_h2p(mode)
+            ops.conv_set_h2s(mode)
             y = torch.full((N, H, W, Cout), 3.0, device=DEV)
             ops.conv2d_fwd(xg, wg, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp, region=reg)
             dx = torch.full((N, H, W, Cin), 5.0, device=DEV)
@@ -228,6 +234,7 @@ def test_conv_h2p_matches_x3(case, report):
             res[mode] = (y, dxw, acc, st)
     finally:
         ops.conv_set_h2p(-1)
+        ops.conv_set_h2s(-1)
     a, b = res[0], res[1]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     if reg is None:

@@ -1,4 +1,5 @@
-"""A/B of the persistent LDS-DMA conv kernel (csrc/igemm_h2p.inc) against the 128x256 kernel on the step's layer shapes:
+"""A/B of the persistent LDS-DMA conv kernels (csrc/igemm_h2p.inc: deep 3x3 layers; csrc/igemm_h2s.inc: the 1x1 layers as a
+stream of K-steps) against the 128x256 kernel on the step's layer shapes:
 same process, interleaved, outputs compared bit for bit.  usage: python tools/bench_h2p.py [frames]"""
 import os
 import sys
@@ -20,6 +21,8 @@ SHAPES = [
     ("layer3.conv1 1x1 1024->256", 1024, 256, 1, 0, 1, 60, 107),
     ("layer3.conv3 1x1 256->1024", 256, 1024, 1, 0, 1, 60, 107),
     ("layer4.ds 1x1 1024->2048", 1024, 2048, 1, 0, 1, 60, 107),
+    ("layer2.conv3 1x1 128->512 (x3 only)", 128, 512, 1, 0, 1, 60, 107),
+    ("layer1.conv1 1x1 256->64 @120x214 (x3 only)", 256, 64, 1, 0, 1, 120, 214),
 ]
 
 
@@ -51,14 +54,18 @@ def main():
         res = {}
         for mode in (0, 1, 0, 1):
             ops.conv_set_h2p(mode)
+            ops.conv_set_h2s(mode)
             tf = timeit(lambda: ops.conv2d_fwd(x, w, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp))
             yk = y.clone()
             ys, sums = ops.conv2d_fwd_stats(x, w, 1, pad, dil, amax=(ax, aw), w_pairs=wp)
             td = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, 1, pad, dil, out=dx, amax=(ag, aw), w_pairs_t=wpt))
-            res.setdefault(mode, []).append((tf, td, yk, dx.clone(), ys, sums.clone()))
+            dxa = x.clone()
+            ops.conv2d_dgrad(dy, w, x.shape, 1, pad, dil, out=dxa, beta=1, amax=(ag, aw), w_pairs_t=wpt)
+            res.setdefault(mode, []).append((tf, td, yk, dx.clone(), ys, sums.clone(), dxa))
         ops.conv_set_h2p(-1)
+        ops.conv_set_h2s(-1)
         a, b = res[0][-1], res[1][-1]
-        same = (torch.equal(a[2], b[2]), torch.equal(a[3], b[3]), torch.equal(a[4], b[4]),
+        same = (torch.equal(a[2], b[2]), torch.equal(a[3], b[3]) and torch.equal(a[6], b[6]), torch.equal(a[4], b[4]),
                 float((a[5] - b[5]).abs().max() / a[5].abs().max()))
         t0f, t0d = min(r[0] for r in res[0]), min(r[1] for r in res[0])
         t1f, t1d = min(r[0] for r in res[1]), min(r[1] for r in res[1])
