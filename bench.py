@@ -309,6 +309,8 @@ def _self_launch(n):
 
 # bracket families (rcf_amd/ops.py) -> the kernel instance behind each
 FAMILIES_F32 = {
+    "conv_h2p_fwd": "conv_h2p_kernel<false> (forward of the deep 3x3 layers: persistent, one wave per SIMD, 4-stage LDS ring, weights by LDS-DMA, fp16 pairs; incl. the kernels that sum its fused BN statistics)",
+    "conv_h2p_dgrad": "conv_h2p_kernel<true> (data gradient of the deep 3x3 layers, same kernel)",
     "conv_x3_128x256": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (forward, fp16 pairs, 128x256 tile; incl. the two kernels that sum its fused BN statistics)",
     "conv_fwd_narrow": "igemm_conv_x3_kernel<2,{1,2},2,2,...> / fp32-MFMA stem (forward, <= 128 output channels)",
     "conv_dgrad_wide": "igemm_conv_x3_kernel<2,4,2,2,false,true,2,true,true> (data gradient, fp16 pairs, 128x256 tile; incl. the weight transpose+split pre-pass)",

@@ -79,6 +79,9 @@ int rcf_conv_set_h2p(int mode, int min_k);
 /* A/B switch of the stream kernel of the 1x1 convs (conv_h2s_kernel, csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1
  * whenever eligible (1x1, stride 1, whole tensor, Cout-side % 256 == 0, K % 64 == 0, K >= 192) */
 int rcf_conv_set_h2s(int mode);
+/* profiling labels: which kernel the last forward / data-gradient launch took (1: 128 x 256 family, 2: conv_h2p_kernel,
+ * 3: conv_h2s_kernel).  A plain global: meaningful right after a launch from the same thread only. */
+int rcf_conv_last_kernel(void);
 
 /* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
 int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);

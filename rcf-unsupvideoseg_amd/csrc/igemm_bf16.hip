@@ -11,6 +11,7 @@
 // chunk position c ^ ((r >> 2) & 3), which makes both the loader's ds_write_b128 and the MFMA operand fetch
 // (ds_read_b128: lane = row, lane >> 5 = which half of a 16-k substep) bank-conflict free without padding.
 #include <cstdlib>
+#include <type_traits>
 #include "rcf_common.h"
 
 namespace {
@@ -388,6 +389,54 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
 #pragma unroll
         for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
         const int cb = n0 + brow0 + nr * 32;              // first channel of this column tile
+        // The common case -- a whole column tile, no bias, no activation -- as straight-line code (csrc/igemm_conv.hip,
+        // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
+        const bool lean = p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
+        if (lean) {
+            auto quads = [&](auto BETA_) {
+                constexpr bool BETA = decltype(BETA_)::value;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    // rows past M multiplied zero activations: their accumulators are exactly zero
+                    f32x4 q[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = cb + 8 * g + 4 * kh;
+                        f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                        if (BETA) {
+                            if (rowok[mr]) {
+                                if constexpr (OBF) v += ld4(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + c);
+                                else v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c);
+                            }
+                        }
+                        q[g] = v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            cs[4 * g + e] += v[e];
+                            cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                        }
+                    }
+                    if constexpr (OBF) {
+                        bf16_t *yrow = reinterpret_cast<bf16_t *>(p.Y) + lin[mr] * p.y_pitch;
+#pragma unroll
+                        for (int g = 0; g < 4; g += 2) {
+                            u32x2 a = pack4(q[g]), b = pack4(q[g + 1]);
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                            if (rowok[mr]) *reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                        }
+                    } else {
+                        float *yrow = reinterpret_cast<float *>(p.Y) + lin[mr] * p.y_pitch;
+                        if (rowok[mr]) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(yrow + cb + 8 * g + 4 * kh) = q[g];
+                        }
+                    }
+                }
+            };
+            if (p.beta) quads(std::true_type{});
+            else quads(std::false_type{});
+        } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             // lanes of rows past M keep zeros and take part in the half-wave exchange (no divergence around it)
@@ -438,6 +487,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                     if (rowok[mr] && c < p.Ncol) *reinterpret_cast<f32x4 *>(yrow + c) = q[g];
                 }
             }
+        }
         }
         if (want_stats) {                                 // block-uniform
             // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly (igemm_conv.hip)

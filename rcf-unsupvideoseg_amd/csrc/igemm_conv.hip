@@ -761,11 +761,41 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         }
         double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
         if (want_stats) __syncthreads();                      // every wave is done with the operand stages
+        // The common case -- a whole column tile, no bias, no activation (every conv -> batch norm pair and every data
+        // gradient of the step) -- as straight-line code: the general loop below tests columns, bias, activation and beta
+        // per quad and per element, which the compiler turns into ~170 instructions in four basic blocks per 16-byte
+        // store; with 32 quads per thread that was three times the instructions of a 16-step K-loop (the 1x1 layers).
+        const bool lean = NP == 2 && p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             float cs[16], cq[16];                             // this lane's pixels: sums / sums of squares per channel register
 #pragma unroll
             for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+            if (lean) {
+                auto quads = [&](auto BETA_) {
+                    constexpr bool BETA = decltype(BETA_)::value;
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) {
+                        if (!rowok[mr]) continue;
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh + nr * 32);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                            v = (v * inv_a) * inv_b;
+                            if (BETA) v += dst[2 * g];
+                            dst[2 * g] = v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                                cs[4 * g + e] += v[e];
+                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                            }
+                        }
+                    }
+                };
+                if (p.beta) quads(std::true_type{});
+                else quads(std::false_type{});
+            } else {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
                 if (!rowok[mr]) continue;
@@ -811,6 +841,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                         cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
                     }
                 }
+            }
             }
             if (want_stats) {                                 // block-uniform
                 // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly -- at every
@@ -1865,10 +1896,16 @@ bool h2p_eligible(const IgemmParams &p, int batches) {
     // built-in rule: the deep 3x3 layers with few column tiles.  Many column tiles on a short K (the data gradient of a
     // 3x3 256 -> 2048 conv: 8 tiles, K = 2304) re-read the activation tile and pay the tile prologue / epilogue once per
     // column tile: measured equal to or 2 % behind the 128 x 256 kernel there
-    return g_h2p == 1 || (p.K >= g_h2p_min_k && p.M >= 32768 && (long)p.K * 256 >= 1152L * p.Ncol);
+    // ... and many rows (3x3 256 -> 256 at 120x214: 3 210 tiles of the 128 x 256 kernel = 6.3 rounds, little tail left to win,
+    // while a workgroup here walks 7 sub-tiles with nothing to overlap their prologues / epilogues: measured 0.92-0.95x)
+    return g_h2p == 1 || (p.K >= g_h2p_min_k && p.M >= 32768 && (long)p.K * 256 >= 1152L * p.Ncol &&
+                          (long)rcf_cdiv(p.M, 128) * (p.Ncol / 256) <= 2048);
 }
 
+int g_last_conv_kernel = 0;   // 1: igemm_conv_x3_kernel (or the fp32-MFMA kernels), 2: conv_h2p_kernel, 3: conv_h2s_kernel -- for profiling labels
+
 int launch_h2p(IgemmParams &p, hipStream_t st) {
+    g_last_conv_kernel = 2;
     const long bytes = (long)(p.K / 16) * p.Ncol * 64;
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (bytes >= (1L << 31) || per_tile_imgs * p.a_img_stride * 4 >= (1L << 31)) return RCF_EINVAL;
@@ -1914,6 +1951,7 @@ bool h2s_eligible(const IgemmParams &p, int batches) {
     return g_h2s == 1;                                      // never by the built-in rule: see above
 }
 int launch_h2s(IgemmParams &p, hipStream_t st) {
+    g_last_conv_kernel = 3;
     const long bytes = (long)(p.K / 16) * p.Ncol * 64;
     if (bytes >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)bytes;
@@ -1933,6 +1971,7 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
     if (h2s_eligible(p, batches)) return launch_h2s(p, st);
     if (h2p_eligible(p, batches)) return launch_h2p(p, st);
+    g_last_conv_kernel = 1;
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
@@ -2235,6 +2274,10 @@ extern "C" int rcf_conv_set_h2p(int mode, int min_k) {
     if (min_k > 0) g_h2p_min_k = min_k;
     return 0;
 }
+
+/* which kernel the last forward / data-gradient launch of this thread of control took (profiling labels only; not
+ * synchronised): 1 the 128 x 256 family, 2 conv_h2p_kernel, 3 conv_h2s_kernel */
+extern "C" int rcf_conv_last_kernel(void) { return g_last_conv_kernel; }
 
 /* A/B switch of conv_h2s_kernel (the 1x1 convs as a stream of K-steps): -1 built-in rule, 0 never, 1 whenever eligible */
 extern "C" int rcf_conv_set_h2s(int mode) {

@@ -72,6 +72,7 @@ class Act:
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
 OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
+OVERLAP_WGRAD_WITH_H2P = __import__("os").environ.get("RCF_OVERLAP_WGRAD_H2P", "1") != "0"   # A/B knob (tools/ab_overlap.py)
 # ... in the bf16 step the gain is smaller (same process, interleaved: 50.96 vs 51.98 ms/step, against 129.7 vs 140.6 in fp32;
 # before the bf16 weight gradient's prefetch worked, csrc/igemm_bf16.hip wgrad_tr_step, there was none: 57.8 vs 58.1)
 OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "1") != "0"
@@ -369,7 +370,12 @@ class Conv2d(nn.Module):
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
                 if self.weight.requires_grad:
                     if self.cin_pad == self.cin and self.cout_pad == self.cout:
-                        if OVERLAP_WGRAD and x.needs_grad:
+                        # the persistent data-gradient kernel (one workgroup per CU, 128 KB of LDS) leaves no room for a
+                        # second kernel's workgroups on its CUs: beside it the weight gradient only takes turns
+                        solo = (not OVERLAP_WGRAD_WITH_H2P and self.k == 3 and self.stride == 1 and self.cin % 256 == 0
+                                and 9 * self.cout >= 2304 and 9 * self.cout * 256 >= 1152 * self.cin
+                                and x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 32768)
+                        if OVERLAP_WGRAD and x.needs_grad and not solo:
                             side = _side_stream(dy.device)
                             side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready
                             with torch.cuda.stream(side):

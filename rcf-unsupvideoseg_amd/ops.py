@@ -91,6 +91,15 @@ class _Profile:
         e0.record()
         return e1
 
+    def relabel_last(self, which, new):
+        """the launch just bracketed under `which` turned out to run another kernel (the C side picks it): file it under `new`
+        -- or drop it when `new` is not being recorded"""
+        if self.which is None or which not in self.which or not self.records[which]:
+            return
+        rec = self.records[which].pop()
+        if new in self.which:
+            self.records[new].append(rec)
+
     def stop_detail(self):
         """{(family, tag): {launches, flops, ms}}: the brackets of stop(), kept apart by the launch's shape tag
         (tools/layer_table.py)"""
@@ -250,6 +259,12 @@ def conv_set_h2p(mode=-1, min_k=0):
     _lib.load().rcf_conv_set_h2p(int(mode), int(min_k))
 
 
+def _relabel_conv(family, h2p_family):
+    """profiling only: a forward / data-gradient launch that took the persistent kernel is filed under its own family"""
+    if _lib.load().rcf_conv_last_kernel() == 2:
+        PROFILE.relabel_last(family, h2p_family)
+
+
 def conv_set_h2s(mode=-1):
     """A/B switch of the stream kernel of the 1x1 convs (csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1 whenever eligible"""
     _lib.load().rcf_conv_set_h2s(int(mode))
@@ -310,6 +325,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
          slope, beta, _stream())
     if end is not None:
         end.record()
+        _relabel_conv("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
     return out
 
 
@@ -348,6 +364,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
         call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
     if end is not None:
         end.record()
+        _relabel_conv("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
     return out, sums
 
 
@@ -372,6 +389,7 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
          need, _stream())
     if end is not None:
         end.record()
+        _relabel_conv("conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other", "conv_h2p_dgrad")
     return out
 
 

@@ -32,7 +32,7 @@ def main():
     tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=prec)
     for _ in range(4):
         tr.step(batch)
-    fams = ["conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
+    fams = ["conv_h2p_fwd", "conv_h2p_dgrad", "conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
             "conv_bf16_fwd", "conv_bf16_fwd_narrow", "conv_bf16_dgrad_wide", "conv_bf16_dgrad_other", "conv_bf16_wgrad4",
             "conv_bf16_wgrad_other"]
     peak = 2500.0 if prec == "bf16" else 2500.0 / 3

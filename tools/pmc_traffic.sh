@@ -29,6 +29,7 @@ out = {}
 for tot, k, n, f, w in rows:
     for fam, pat in (("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true>"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
                      ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true>"),
+                     ("conv_h2p_fwd", "conv_h2p_kernel<false>"), ("conv_h2p_dgrad", "conv_h2p_kernel<true>"),
                      ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true>"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
                      ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
         if pat in k:
