@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
         // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
         const bool lean = p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
         if (lean) {
-            auto quads = [&](auto BETA_) {
-                constexpr bool BETA = decltype(BETA_)::value;
+            auto quads = [&](auto BETA_, auto STATS_) {
+                constexpr bool BETA = decltype(BETA_)::value, STATS = decltype(STATS_)::value;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     // rows past M multiplied zero activations: their accumulators are exactly zero
@@ -410,10 +410,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                             }
                         }
                         q[g] = v;
+                        if (STATS) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            cs[4 * g + e] += v[e];
-                            cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                            for (int e = 0; e < 4; ++e) {
+                                cs[4 * g + e] += v[e];
+                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                            }
                         }
                     }
                     if constexpr (OBF) {
@@ -434,8 +436,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                     }
                 }
             };
-            if (p.beta) quads(std::true_type{});
-            else quads(std::false_type{});
+            if (p.beta) { if (want_stats) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
+            else { if (want_stats) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
         } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -757,6 +759,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const int l31 = lane & 31, kh = lane >> 5;
+    if (i0 + 32 * MR * 2 <= p.Cout && j0 + 32 * NR * 2 <= p.Ktot && !(p.beta && gridDim.z == 1)) {
+        // the tile lies inside the weight tensor and is a split-K partial (or overwrites): store, nothing to test
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float *drow = out + (long)(i0 + arow0 + mr * 32 + 4 * kh + (e & 3) + 8 * (e >> 2)) * p.Ktot + j0 + brow0 + l31;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) drow[nr * 32] = acc[mr][nr][e];
+            }
+        return;
+    }
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
@@ -990,6 +1004,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const int l31 = lane & 31, kh = lane >> 5;
+    if (i0 + 32 * MR * 2 <= p.Cout && j0 + 32 * NR * 2 <= p.Ktot && !(p.beta && gridDim.z == 1)) {
+        // the tile lies inside the weight tensor and is a split-K partial (or overwrites): store, nothing to test
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float *drow = out + (long)(i0 + arow0 + mr * 32 + 4 * kh + (e & 3) + 8 * (e >> 2)) * p.Ktot + j0 + brow0 + l31;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) drow[nr * 32] = acc[mr][nr][e];
+            }
+        return;
+    }
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         const int rbase = i0 + arow0 + mr * 32 + 4 * kh;

@@ -576,10 +576,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
 
     int abase[A_PASS];        // float offset of tap (0,0) of the row from the descriptor base (STRIDED: of the image)
     int ay[A_PASS], ax[A_PASS];
+    // 1x1, stride 1, whole tensor (the bottlenecks' conv1 / conv3 and their data gradients: short K-loops, where every
+    // instruction of the tile's set-up counts): GEMM row m IS source pixel m -- no (image, y, x) decomposition, no divisions
+    const bool pointwise = !STRIDED && p.S == 1 && p.K == p.Cs && p.up == 1 && p.off == 0 && p.rband <= 0 && p.rh == p.Ho &&
+                           p.rw == p.Wo && p.Ho == p.Hs && p.Wo == p.Ws && p.a_img_stride == (long)HoWo * p.a_pitch;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + arow + ROWS * i;
-        if (m < p.M) {
+        if (pointwise) {
+            const bool ok = m < p.M;
+            abase[i] = ok ? (m - n_first * HoWo) * p.a_pitch : 0;
+            ay[i] = ok ? 0 : -(1 << 28);
+            ax[i] = ok ? 0 : -(1 << 28);
+        } else if (m < p.M) {
             const int n = m / HoWo;
             int y, x;
             region_yx(m - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
@@ -772,8 +781,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
 #pragma unroll
             for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
             if (lean) {
-                auto quads = [&](auto BETA_) {
-                    constexpr bool BETA = decltype(BETA_)::value;
+                // BETA: accumulate into the output; EXTRA: the by-products are wanted (batch-norm statistics of a forward
+                // conv, the output's range of a ViT GEMM) -- a data gradient wants neither: scale, (add,) store
+                auto quads = [&](auto BETA_, auto EXTRA_) {
+                    constexpr bool BETA = decltype(BETA_)::value, EXTRA = decltype(EXTRA_)::value;
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr) {
                         if (!rowok[mr]) continue;
@@ -784,17 +795,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                             v = (v * inv_a) * inv_b;
                             if (BETA) v += dst[2 * g];
                             dst[2 * g] = v;
+                            if (EXTRA) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                tmax = max(tmax, __float_as_uint(fabsf(v[e])));
-                                cs[4 * g + e] += v[e];
-                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                                for (int e = 0; e < 4; ++e) {
+                                    tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                                    cs[4 * g + e] += v[e];
+                                    cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                                }
                             }
                         }
                     }
                 };
-                if (p.beta) quads(std::true_type{});
-                else quads(std::false_type{});
+                const bool extra = want_stats || p.amax_out != nullptr;
+                if (p.beta) { if (extra) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
+                else { if (extra) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
             } else {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
@@ -1748,6 +1762,19 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     float *out = p.OUT + (long)blockIdx.z * p.split_stride;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     const int l31 = lane & 31, kh = lane >> 5;
+    if (i0 + BM <= p.Cout && j0 + BN <= Ktot && !(p.beta && gridDim.z == 1)) {
+        // the tile lies inside the weight tensor and is a split-K partial (or overwrites): scale and store, nothing to test
+        // (the general loop below is ~2 300 instructions in ~250 basic blocks; a workgroup's K-loop is ~10 000)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float *drow = out + (long)(i0 + arow0 + mr * 32 + 4 * kh + (e & 3) + 8 * (e >> 2)) * Ktot + j0 + brow0 + l31;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) drow[nr * 32] = (acc[mr][nr][e] * inv_a) * inv_b;
+            }
+        return;
+    }
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         const int rbase = i0 + arow0 + mr * 32 + 4 * kh;
