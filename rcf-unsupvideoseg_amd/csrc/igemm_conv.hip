@@ -1895,6 +1895,7 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
 
 // conv_h2p_kernel (igemm_h2p.inc): which launches take it.  g_h2p: -1 built-in rule, 0 never, 1 whenever eligible
 int g_h2p = -1;
+int g_h2s = -1;            // conv_h2s_kernel (igemm_h2s.inc): see the comment above h2s_eligible
 int g_h2p_min_k = 2304;    // the 3x3 layers.  Below (1x1 convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part
                            // of a tile's time and the kernel's single workgroup per CU has nothing to overlap it with: measured
                            // 0.90-1.0x of the 128x256 kernel there, 1.04-1.17x on the 3x3 layers (tools/bench_h2p.py)
@@ -1912,6 +1913,13 @@ int h2p_stat_rows(int M, int gn) {                        // partial statistics 
     int n = h2p_subtiles(extra ? base + 1 : base);
     if (extra && base > 0 && h2p_subtiles(base) > n) n = h2p_subtiles(base);
     return n < 1 ? 1 : n;
+}
+
+// can a conv of this shape ever take one of the kernels that read the pairs2 layout?  (rcf_conv_weight_pairs2_f32 writes that
+// half of its buffer only then: the split runs once per weight update = once per training step and layer)
+bool pairs2_useful(int rows, int K, int Cs) {
+    if (g_h2p == 1 || g_h2s == 1) return true;             // forced on (tests, A/B runs): every eligible shape
+    return g_h2p != 0 && rows % 256 == 0 && K % 16 == 0 && Cs % 16 == 0 && K >= g_h2p_min_k && (long)K * 256 >= 1152L * rows;
 }
 
 bool h2p_eligible(const IgemmParams &p, int batches) {
@@ -1953,8 +1961,8 @@ int launch_h2p(IgemmParams &p, hipStream_t st) {
 // every instruction of the epilogue chunks (scale, accumulate, store, statistics: ~35 per 6 MFMAs on top of the loader's
 // ~20) is issued by the wave that also issues the MFMAs -- a SIMD issues to its matrix, vector, LDS and memory pipes in the
 // same cycle only from DIFFERENT waves, so two independent workgroups per CU hide an epilogue better than one stream
-// does.  The built-in rule therefore never takes it; the tests force it (mode 1) to keep it correct.
-int g_h2s = -1;
+// does.  The built-in rule therefore never takes it; the tests force it (mode 1) to keep it correct.  (g_h2s is declared
+// beside g_h2p above.)
 int h2s_gn(int M, int ntiles) {
     const int RB = rcf_cdiv(M, 32);
     int gn = 1;
@@ -2217,7 +2225,11 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K; p.act = act; p.slope = slope; p.beta = beta;
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
-    if (s->w_pairs2) { p.b_pairs = s->w_pairs2; p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S); }
+    if (s->w_pairs2) {
+        p.b_pairs = s->w_pairs2;
+        if (pairs2_useful(s->Cout, s->R * s->S * s->Cin, s->Cin))
+            p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S);
+    }
     if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
     if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
     return launch_igemm<0>(p, rcf_stream(stream));
@@ -2275,21 +2287,22 @@ extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int
     const size_t one = rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, transpose) / 2;
     char *second = (char *)planes + one;
     const int rows = transpose ? Cin : Cout, K = R * S * (transpose ? Cout : Cin);
-    if (K % 16) {                                          // pairs2 holds whole K-steps only: the tail step's unused half stays zero
-        if (hipMemsetAsync(second, 0, one, rcf_stream(stream)) != hipSuccess) return RCF_EINVAL;
-    }
-    (void)rows;
+    // the second half is written only for shapes that can take a kernel reading it (the same test the launches apply; with
+    // rcf_conv_set_h2p / _h2s forcing those kernels on, build the buffers AFTER the switch)
+    const bool second_half = pairs2_useful(rows, K, transpose ? Cout : Cin) && K % 16 == 0;
     if (transpose) {
         if (int e = rcf_conv_weight_pairs_t_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
         const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
-        hipLaunchKernelGGL(weight_pairs2_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)second,
-                           Cout, Cin, R * S);
+        if (second_half)
+            hipLaunchKernelGGL(weight_pairs2_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)second,
+                               Cout, Cin, R * S);
     } else {
         if (int e = rcf_conv_weight_pairs_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
         const long n = (long)Cout * R * S * Cin;
         const long blocks = (n + 1023) / 1024;
-        hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
-                           rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S);
+        if (second_half)
+            hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                               rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S);
     }
     RCF_LAUNCH_CHECK();
     return 0;
@@ -2334,7 +2347,11 @@ extern "C" int rcf_conv2d_fwd_bnstats_f32(const float *x, const float *w, float 
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ldb = p.K;
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
-    if (s->w_pairs2) { p.b_pairs = s->w_pairs2; p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S); }
+    if (s->w_pairs2) {
+        p.b_pairs = s->w_pairs2;
+        if (pairs2_useful(s->Cout, s->R * s->S * s->Cin, s->Cin))
+            p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S);
+    }
     p.stats = (double *)workspace;
     if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
     return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cout, sums,
@@ -2383,7 +2400,7 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
         const dim3 tgrid(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S);
         if (p.amax_a && p.amax_b && !g_h2_off && wpt) {
             p.b_pairs = wpt;                               // prepared once per weight update by the caller
-            if (s->w_pairs2_t) p.b_pairs2 = (const char *)wpt + need;
+            if (s->w_pairs2_t && pairs2_useful(s->Cin, s->R * s->S * s->Cout, s->Cout)) p.b_pairs2 = (const char *)wpt + need;
         } else if (p.amax_a && p.amax_b && !g_h2_off) {   // fp16 pairs: transposed AND split, once per launch
             hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
                                s->Cout, s->Cin, s->R * s->S);

@@ -209,12 +209,14 @@ def test_conv_h2p_matches_x3(case, report):
     dy = torch.randn(N, Cout, H, W, generator=g)
     xg, wg, gg = to_nhwc(x), cl_weight(w), to_nhwc(dy)
     ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
-    wp, wpt = ops.weight_pairs(wg, aw), ops.weight_pairs_t(wg, aw)
     res = {}
     try:
         for mode in (0, 1):
             ops.conv_set_h2p(mode)
             ops.conv_set_h2s(mode)
+            # the split weights are built under the mode they are used with (the plane-separated half is only written for
+            # shapes that can take a kernel reading it)
+            wp, wpt = ops.weight_pairs(wg, aw), ops.weight_pairs_t(wg, aw)
             y = torch.full((N, H, W, Cout), 3.0, device=DEV)
             ops.conv2d_fwd(xg, wg, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp, region=reg)
             dx = torch.full((N, H, W, Cin), 5.0, device=DEV)

@@ -45,7 +45,9 @@ def main():
         x = torch.randn(N, H, W, Cin, device=dev)
         w = (torch.randn(Cout, Cin, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
         ax, aw = ops.absmax(x), ops.absmax(ops.weight_rsck(w))
-        wp, wpt = ops.weight_pairs(w, aw), ops.weight_pairs_t(w, aw)
+        ops.conv_set_h2p(1)
+        ops.conv_set_h2s(1)
+        wp, wpt = ops.weight_pairs(w, aw), ops.weight_pairs_t(w, aw)      # both layouts (built with the kernels forced on)
         y = torch.empty(N, H, W, Cout, device=dev)
         dy = torch.randn(N, H, W, Cout, device=dev)
         ag = ops.absmax(dy)

@@ -44,6 +44,7 @@ def main():
             if "fp16-exact" in name:
                 w = w.half().float().contiguous(memory_format=torch.channels_last)
             ax, aw = ops.absmax(x), ops.absmax(ops.weight_rsck(w))
+            ops.conv_set_h2p(1)
             wp = ops.weight_pairs(w, aw)
             out = []
             for mode in (0, 1):
