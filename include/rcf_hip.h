@@ -83,6 +83,17 @@ int rcf_conv_set_h2s(int mode);
  * 3: conv_h2s_kernel).  A plain global: meaningful right after a launch from the same thread only. */
 int rcf_conv_last_kernel(void);
 
+/* Batched weight preparation: the derived operands of EVERY conv weight of a model in three (fp16 pairs: ranges, forward
+ * buffers, transposed buffers) or two (bf16: forward, transposed) launches instead of one per weight and layout -- they are
+ * rebuilt after every optimizer step.  tab_*: device arrays of n entries {const float *w; void *out; unsigned *amax; int Cout,
+ * Cin, RS, first_block, nblocks, flags; int pad[2]} (56 bytes; csrc/rcf_common.h rcf_wprep_entry) -- block b of a launch
+ * serves the entry with first_block <= b < first_block + nblocks; flags bit 0 = also write the plane-separated half
+ * (rcf_conv_pairs2_useful).  Outputs are byte-identical to rcf_absmax_f32 / rcf_conv_weight_pairs2_f32 / rcf_conv_weight_bf16. */
+int rcf_conv_pairs2_useful(int Cout, int Cin, int R, int S, int transpose);
+int rcf_conv_weights_prepare_f32(const void *tab_absmax, int blocks_absmax, const void *tab_pairs, int blocks_pairs,
+                                 const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, void *stream);
+int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, void *stream);
+
 /* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
 int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);
 

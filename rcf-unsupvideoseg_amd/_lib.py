@@ -85,6 +85,9 @@ PROTOS = {
     "rcf_conv_set_h2p": (c_int, [c_int, c_int]),
     "rcf_conv_set_h2s": (c_int, [c_int]),
     "rcf_conv_last_kernel": (c_int, []),
+    "rcf_conv_pairs2_useful": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "rcf_conv_weights_prepare_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
+    "rcf_conv_weights_prepare_bf16": (c_int, [P, c_int, P, c_int, c_int, P]),
     "rcf_conv2d_fwd_bnstats_f32": (c_int, [P, P, P, _CS, P, _BF, P, c_size_t, P]),
     "rcf_conv2d_fwd_bnstats_bf16": (c_int, [P, P, P, c_int, _CS, P, _BF, P, c_size_t, P]),
     "rcf_sum_partials_f64": (c_int, [P, c_int, c_int, P, P, P]),

@@ -1195,6 +1195,47 @@ extern "C" size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, in
     return (size_t)((K + 31) / 32) * rows * 64;
 }
 
+namespace {
+// batched weight_bf16_kernel over a table of weights (rcf_common.h: rcf_wprep_entry; out = the layout of rcf_conv_weight_bf16)
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *__restrict__ tab, int n_entries) {
+    const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n_entries, blockIdx.x)];
+    const int rows = TRANSPOSE ? t.Cin : t.Cout;
+    const int K = TRANSPOSE ? t.RS * t.Cout : t.RS * t.Cin;
+    const int KT = (K + 31) >> 5;
+    const long n = (long)KT * rows * 32;
+    const long step = (long)t.nblocks * 256;
+    bf16_t *out = reinterpret_cast<bf16_t *>(t.out);
+    for (long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x; i < n; i += step) {
+        const int kl = (int)(i & 31);
+        const long q = i >> 5;
+        const int j = (int)(q % rows);
+        const int k = (int)(q / rows) * 32 + kl;
+        float v = 0.f;
+        if (k < K) {
+            if (!TRANSPOSE) {
+                v = t.w[(long)j * K + k];
+            } else {
+                const int rs = k / t.Cout, co = k - rs * t.Cout;
+                v = t.w[((long)co * t.RS + rs) * t.Cin + j];
+            }
+        }
+        out[i] = (bf16_t)v;
+    }
+}
+}  // namespace
+
+/* Batched rcf_conv_weight_bf16 for every weight of a model: two launches (forward operands, transposed operands).
+ * tab_*: device arrays of n rcf_wprep_entry with first_block / nblocks filled per launch. */
+extern "C" int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, void *stream) {
+    if (!tab_fwd || !tab_t || n <= 0 || blocks_fwd <= 0 || blocks_t <= 0) return RCF_EINVAL;
+    hipStream_t st = rcf_stream(stream);
+    hipLaunchKernelGGL(wprep_bf16_kernel<false>, dim3((unsigned)blocks_fwd), dim3(256), 0, st, (const rcf_wprep_entry *)tab_fwd, n);
+    hipLaunchKernelGGL(wprep_bf16_kernel<true>, dim3((unsigned)blocks_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_t, n);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, void *stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(out)) return RCF_EINVAL;
     const long n = (long)rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, transpose) / 2;

@@ -1023,6 +1023,84 @@ __global__ void __launch_bounds__(256) weight_pairs2_kernel(const float *__restr
     }
 }
 
+// ---- batched forms of absmax / weight_pairs / weight_pairs2 over a table of weights (rcf_common.h: rcf_wprep_entry)
+__global__ void __launch_bounds__(256) wprep_absmax_kernel(const rcf_wprep_entry *__restrict__ tab, int n) {
+    __shared__ unsigned sh[4];
+    const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n, blockIdx.x)];
+    const long total4 = (long)t.Cout * t.RS * t.Cin / 4, step = (long)t.nblocks * 256;
+    unsigned mx = 0u;
+    for (long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x; i < total4; i += step) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(t.w)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = max(mx, __float_as_uint(fabsf(v[e])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(t.amax, max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+
+// out = [pairs | pairs2 (flags bit 0)] of rcf_conv_weight_pairs2_f32(transpose = 0): the same values as weight_pairs_kernel<false>
+// and weight_pairs2_kernel<false>
+__global__ void __launch_bounds__(256) wprep_pairs_kernel(const rcf_wprep_entry *__restrict__ tab, int n) {
+    const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n, blockIdx.x)];
+    const float sc = pow2f(h2_exponent(*t.amax));
+    const int K = t.RS * t.Cin;
+    const long total = (long)t.Cout * K, step = (long)t.nblocks * 256;
+    _Float16 *planes = reinterpret_cast<_Float16 *>(t.out);
+    _Float16 *planes2 = planes + (long)((K + 15) / 16) * t.Cout * 32;        // pairs: cdiv(K, 16) * Cout * 64 bytes
+    const bool second = t.flags & 1;
+    for (long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x; i < total; i += step) {
+        const float v = t.w[i] * sc;
+        const _Float16 h = (_Float16)v, m = (_Float16)(v - (float)h);
+        const int j = (int)(i / K), k = (int)(i - (long)j * K);
+        const long q = pairs_index(j, k, t.Cout);
+        planes[q] = h;
+        planes[q + 4] = m;
+        if (second) {
+            planes2[pairs2_index(j, k, t.Cout, 0)] = h;
+            planes2[pairs2_index(j, k, t.Cout, 1)] = m;
+        }
+    }
+}
+
+// the transposed buffers (rcf_conv_weight_pairs2_f32(transpose = 1)); a block is one 32 x 32 (co, c) tile of one tap
+__global__ void __launch_bounds__(256) wprep_pairs_t_kernel(const rcf_wprep_entry *__restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n, blockIdx.x)];
+    const float sc = pow2f(h2_exponent(*t.amax));
+    const int nbx = (t.Cin + 31) >> 5, nby = (t.Cout + 31) >> 5;
+    int lb = blockIdx.x - t.first_block;
+    const int rs = lb / (nbx * nby);
+    lb -= rs * nbx * nby;
+    const int by = lb / nbx, bx = lb - by * nbx;
+    const int c0 = bx * 32, o0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = o0 + r, c = c0 + tx;
+        tile[r][tx] = (co < t.Cout && c < t.Cin) ? t.w[((long)co * t.RS + rs) * t.Cin + c] : 0.f;
+    }
+    __syncthreads();
+    _Float16 *planes = reinterpret_cast<_Float16 *>(t.out);
+    _Float16 *planes2 = planes + (long)((t.RS * t.Cout + 15) / 16) * 16 * t.Cin * 2;       // pairs_t: cdiv(RS Cout, 16) * 16 * Cin * 4 bytes
+    const bool second = t.flags & 1;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, co = o0 + tx;
+        if (c < t.Cin && co < t.Cout) {
+            const float v = tile[tx][r] * sc;
+            const _Float16 h = (_Float16)v, m = (_Float16)(v - (float)h);
+            const long q = pairs_index(c, rs * t.Cout + co, t.Cin);
+            planes[q] = h;
+            planes[q + 4] = m;
+            if (second) {
+                planes2[pairs2_index(c, rs * t.Cout + co, t.Cin, 0)] = h;
+                planes2[pairs2_index(c, rs * t.Cout + co, t.Cin, 1)] = m;
+            }
+        }
+    }
+}
+
 #include "igemm_h2p.inc"
 #include "igemm_h2s.inc"
 
@@ -2304,6 +2382,30 @@ extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int
             hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
                                rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S);
     }
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+/* would rcf_conv_weight_pairs2_f32 write the plane-separated half for this shape (and a launch read it)?  For callers
+ * that fill rcf_wprep_entry.flags */
+extern "C" int rcf_conv_pairs2_useful(int Cout, int Cin, int R, int S, int transpose) {
+    const int rows = transpose ? Cin : Cout, K = R * S * (transpose ? Cout : Cin), Cs = transpose ? Cout : Cin;
+    return pairs2_useful(rows, K, Cs) && K % 16 == 0 ? 1 : 0;
+}
+
+/* Batched weight preparation of the fp16-pair kernels: ranges (amax), then both rcf_conv_weight_pairs2_f32 buffers of every
+ * weight, in THREE launches for the whole model.  tab_*: device arrays of n rcf_wprep_entry (csrc/rcf_common.h) with
+ * first_block / nblocks filled per launch (blocks_* = their totals); amax_base: the n consecutive range slots the entries
+ * point to (zeroed here).  Entry i of every table describes the same weight.  Identical bytes to the per-weight calls. */
+extern "C" int rcf_conv_weights_prepare_f32(const void *tab_absmax, int blocks_absmax, const void *tab_pairs, int blocks_pairs,
+                                            const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, void *stream) {
+    if (!tab_absmax || !tab_pairs || !tab_pairs_t || n <= 0 || !amax_base || blocks_absmax <= 0 || blocks_pairs <= 0 || blocks_pairs_t <= 0)
+        return RCF_EINVAL;
+    hipStream_t st = rcf_stream(stream);
+    if (hipMemsetAsync(amax_base, 0, (size_t)n * sizeof(unsigned), st) != hipSuccess) return RCF_EINVAL;
+    hipLaunchKernelGGL(wprep_absmax_kernel, dim3((unsigned)blocks_absmax), dim3(256), 0, st, (const rcf_wprep_entry *)tab_absmax, n);
+    hipLaunchKernelGGL(wprep_pairs_kernel, dim3((unsigned)blocks_pairs), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs, n);
+    hipLaunchKernelGGL(wprep_pairs_t_kernel, dim3((unsigned)blocks_pairs_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs_t, n);
     RCF_LAUNCH_CHECK();
     return 0;
 }

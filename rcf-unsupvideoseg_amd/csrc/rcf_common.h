@@ -101,3 +101,28 @@ template <typename T, int V> __device__ __forceinline__ void stv(T *p, const fve
         else if ((xdt) == RCF_F32 && (ydt) == RCF_BF16) { CALL(float, bf16_t); }   \
         else return RCF_EINVAL;                                                    \
     } while (0)
+
+// ---- batched weight preparation (rcf_conv_weights_prepare_*): one launch per derived layout for ALL conv weights of a model
+// instead of one per layer -- the derived operands (ranges, fp16 pair planes, bf16 copies) are rebuilt after every optimizer
+// step, and ~60 layers x 4 five-microsecond launches were 1-2 % of a training step.  A device table holds one entry per
+// weight; block b of the launch serves entry e with first_block[e] <= b < first_block[e] + nblocks[e].
+struct rcf_wprep_entry {
+    const float *w;            // [Cout][R][S][Cin] fp32 master weight
+    void *out;                 // the layout this table is for (see rcf_conv_weights_prepare_* in include/rcf_hip.h)
+    unsigned *amax;            // the weight's range: raw bits of max |w| (written by the range launch, read by the pair launches)
+    int Cout, Cin, RS;
+    int first_block, nblocks;
+    int flags;                 // bit 0: also write the plane-separated (pairs2) half of `out`
+    int pad_[2];
+};
+static_assert(sizeof(rcf_wprep_entry) == 56 || sizeof(rcf_wprep_entry) == 64, "mirrored by ctypes in _lib.py");
+
+__device__ __forceinline__ int rcf_wprep_find(const rcf_wprep_entry *__restrict__ tab, int n, int block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                      // last entry with first_block <= block
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= block) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}

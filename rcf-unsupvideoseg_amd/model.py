@@ -181,11 +181,12 @@ class RCFModel(nn.Module):
     # switches them to training mode with everything else, so under main.py the stage-2.1 teacher runs with batch
     # statistics.  The override below only invalidates the cached weight operands (fp16 planes, bf16 copies, ranges):
     # they are keyed by (data_ptr, _version, epoch) and an in-place write through `.data` bumps none of those, so every
-    # mode switch and every load_state_dict starts from fresh operands.  Anything else that writes parameters through
+    # mode SWITCH (not the train() call a trainer repeats every step) and every load_state_dict starts from fresh operands.  Anything else that writes parameters through
     # `.data` / raw pointers after a forward must call `rcf_amd.ops.weights_changed()` itself.
 
     def train(self, mode=True):
-        ops.weights_changed()
+        if bool(mode) != self.training:                     # a transition (trainers call train() at the top of every step)
+            ops.weights_changed()
         return super().train(mode)
 
     def _dist(self):

@@ -750,8 +750,12 @@ def ema_update(dest, src, m):
     call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
 
 
-def fill(t, v):
-    weights_changed()
+def fill(t, v, weights=False):
+    """t[:] = v.  weights=True when `t` may be (part of) a parameter: the cached weight operands are dropped.  The callers in
+    this package fill gradient buffers only -- a bump there would throw away, at the top of every step, the operands the
+    trainer prepared after the previous optimizer step (trainer.WeightPrep)."""
+    if weights:
+        weights_changed()
     call("rcf_fill_f32", _p(t), t.numel(), float(v), _stream())
 
 

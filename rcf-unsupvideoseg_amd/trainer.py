@@ -10,6 +10,7 @@ small chunk overlap with the rest of backward -- instead of DDP's 25 MB buckets.
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -79,6 +80,103 @@ class FlatParams:
         self.bind_grads()
 
 
+BULK_WEIGHT_PREP = __import__("os").environ.get("RCF_BULK_WEIGHT_PREP", "1") != "0"    # A/B knob
+
+
+class WeightPrep:
+    """The conv layers' derived weight operands -- ranges and fp16 pair planes (fp32 step) or bf16 copies (bf16 step), in
+    the forward and the transposed (data-gradient) reading orders -- for ALL trainable conv weights in three / two launches
+    right after the optimizer step (`rcf_conv_weights_prepare_{f32,bf16}`), written into persistent buffers and handed to
+    the layers through their operand caches (`layers.Conv2d._derived`).  Without it every layer re-derives its operands on
+    first use after each weight update: ~60 layers x 4 five-microsecond launches, 1-2 % of a training step.  Byte-identical
+    to the per-layer path (tests/test_pipeline_gpu.py)."""
+
+    ENTRY = np.dtype([("w", "<u8"), ("out", "<u8"), ("amax", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("RS", "<i4"),
+                      ("first_block", "<i4"), ("nblocks", "<i4"), ("flags", "<i4"), ("pad", "<i4", (2,))])
+
+    def __init__(self, model, precision, device):
+        from . import layers, _lib
+        lib = _lib.load()
+        self.bf16 = precision == "bf16"
+        self.device = device
+        self.convs = []
+        for m in model.modules():
+            if not isinstance(m, layers.Conv2d) or not m.weight.requires_grad or not m.weight.is_cuda:
+                continue
+            if m.cin_pad != m.cin or m.cout_pad != m.cout:
+                continue                                    # padded copies are rebuilt per call, never cached
+            if self.bf16 and (m.cin % 8 or m.cout % 8 or getattr(m, "out_fp32", False)):
+                continue                                    # fp32-output heads / the stem keep their own paths
+            self.convs.append(m)
+        n = len(self.convs)
+        self.n = n
+        if n == 0:
+            return
+        assert self.ENTRY.itemsize == 56
+        u8 = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.amax = torch.zeros(n, dtype=torch.int32, device=device)
+        self.out_f, self.out_t = [], []
+        kinds = ("fwd", "t") if self.bf16 else ("absmax", "fwd", "t")
+        tabs = {k: np.zeros(n, dtype=self.ENTRY) for k in kinds}
+        first = {k: 0 for k in kinds}
+        for i, m in enumerate(self.convs):
+            Cout, Cin, R, S = m.weight.shape
+            w = ops.weight_rsck(m.weight)                   # raises unless the weight is channels_last ([Cout][R][S][Cin])
+            elems = Cout * Cin * R * S
+            if self.bf16:
+                of = u8(lib.rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, 0))
+                ot = u8(lib.rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, 1))
+                blocks = {"fwd": min((of.numel() // 2 + 1023) // 1024, 256), "t": min((ot.numel() // 2 + 1023) // 1024, 256)}
+                flags = {"fwd": 0, "t": 0}
+            else:
+                of = u8(lib.rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 0))
+                ot = u8(lib.rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 1))
+                blocks = {"absmax": max(1, min((elems // 4 + 1023) // 1024, 64)), "fwd": max(1, min((elems + 1023) // 1024, 256)),
+                          "t": ((Cin + 31) // 32) * ((Cout + 31) // 32) * R * S}
+                flags = {"absmax": 0, "fwd": lib.rcf_conv_pairs2_useful(Cout, Cin, R, S, 0), "t": lib.rcf_conv_pairs2_useful(Cout, Cin, R, S, 1)}
+            self.out_f.append(of)
+            self.out_t.append(ot)
+            for k in kinds:
+                e = tabs[k][i]
+                e["w"], e["amax"] = w.data_ptr(), self.amax.data_ptr() + 4 * i
+                e["out"] = of.data_ptr() if k == "fwd" else (ot.data_ptr() if k == "t" else 0)
+                e["Cout"], e["Cin"], e["RS"] = Cout, Cin, R * S
+                e["first_block"], e["nblocks"], e["flags"] = first[k], blocks[k], flags[k]
+                first[k] += blocks[k]
+        self.blocks = first
+        self.tabs = {k: torch.from_numpy(tabs[k].view(np.uint8).reshape(-1).copy()).to(device) for k in kinds}
+        self.ptrs = [ops.weight_rsck(m.weight).data_ptr() for m in self.convs]
+
+    def run(self):
+        """rebuild every derived operand from the current weights and install them in the layers' caches"""
+        from . import layers
+        if self.n == 0 or not layers.CACHE_WEIGHT_OPERANDS:
+            return
+        if [ops.weight_rsck(m.weight).data_ptr() for m in self.convs] != self.ptrs:
+            return                                          # the parameters moved (e.g. .to()): the per-layer path takes over
+        st, p = ops._stream(), ops._p
+        if self.bf16:
+            _lib_call("rcf_conv_weights_prepare_bf16", p(self.tabs["fwd"]), self.blocks["fwd"], p(self.tabs["t"]), self.blocks["t"],
+                      self.n, st)
+        else:
+            _lib_call("rcf_conv_weights_prepare_f32", p(self.tabs["absmax"]), self.blocks["absmax"], p(self.tabs["fwd"]),
+                      self.blocks["fwd"], p(self.tabs["t"]), self.blocks["t"], self.n, p(self.amax), st)
+        for i, m in enumerate(self.convs):
+            key = ops.weight_key(m.weight)
+            chk = ops.weight_checksum(m.weight) if ops.DEBUG_WEIGHT_CACHE else None
+            cache = m.__dict__.setdefault("_wcache", {})
+            if self.bf16:
+                cache["bf16"], cache["bf16_t"] = (key, self.out_f[i], chk), (key, self.out_t[i], chk)
+            else:
+                cache["amax"] = (key, self.amax[i:i + 1], chk)
+                cache["pairs"], cache["pairs_t"] = (key, self.out_f[i], chk), (key, self.out_t[i], chk)
+
+
+def _lib_call(name, *args):
+    from . import _lib
+    return _lib.call(name, *args)
+
+
 class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, epochs=200, power=0.9, min_lr=1e-6, device="cuda:0",
                  betas=(0.9, 0.999), eps=1e-8, force_group=False, precision=None):
@@ -105,6 +203,7 @@ class Trainer:
         own_group = __import__("os").environ.get("RCF_GRAD_GROUP", "1") != "0"
         self.grad_group = dist.new_group() if (self.chunked and own_group) else None
         self._pending, self._done = [], set()
+        self.prep = None                                    # WeightPrep, built after the first optimizer step
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
             self.model.grad_ready_hook = self._grads_ready
 
@@ -140,6 +239,10 @@ class Trainer:
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
                       self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)
+        if self.prep is None and BULK_WEIGHT_PREP:
+            self.prep = WeightPrep(self.model, self.model.precision or "fp32", self.device)
+        if self.prep is not None:
+            self.prep.run()                                 # the next forward finds every derived weight operand ready
         if check_nan and math.isnan(float(losses["loss"])):
             raise Exception("loss is NaN")                      # main.py:176-177
         return losses

@@ -185,10 +185,14 @@ def test_weight_operand_cache_invalidation(monkeypatch):
     assert ops.WEIGHT_EPOCH[0] > e0 and torch.equal(src.weight, dst.weight)
     kw = config.stage1_model_kwargs((24, 40), dropout=0.0, norm="BN")
     m = rcf_amd.RCFModel(types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None), **kw)
-    for fn in (lambda: m.train(), lambda: m.eval(), lambda: m.load_state_dict(m.state_dict())):
+    m.eval()
+    for fn in (lambda: m.train(), lambda: m.eval(), lambda: m.load_state_dict(m.state_dict())):      # transitions / loads
         e0 = ops.WEIGHT_EPOCH[0]
         fn()
         assert ops.WEIGHT_EPOCH[0] > e0
+    e0 = ops.WEIGHT_EPOCH[0]
+    m.eval()                                            # no transition: a trainer calling train() every step keeps its caches
+    assert ops.WEIGHT_EPOCH[0] == e0
     # debug mode: a stale hit raises instead of being used
     monkeypatch.setattr(ops, "DEBUG_WEIGHT_CACHE", True)
     conv2 = layers.Conv2d(4, 8, 3)

@@ -82,3 +82,55 @@ def test_training_steps_are_bit_reproducible(precision, report):
     for (la, ga, pa), (lb, gb, pb) in zip(a, b):
         assert la == lb and torch.equal(ga, gb) and torch.equal(pa, pb)
     report(f"reproducibility [{precision}]: 3 steps twice, losses {[round(x[0], 5) for x in a]}, gradients and parameters bit-identical")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_bulk_weight_preparation_equals_the_per_layer_path(prec):
+    """trainer.WeightPrep rebuilds the derived operands of every conv weight (ranges + fp16 pair planes in both reading orders,
+    or the two bf16 copies) in three / two launches after the optimizer step: the layers must find, in their caches, the very
+    bytes the per-layer calls produce from the same weights -- and a step with the bulk path must equal one without it"""
+    import copy
+    import types
+    import numpy as np
+    import rcf_amd
+    from rcf_amd import config, layers, ops, synth, trainer
+    H, W, B = 64, 96, 1
+    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None)
+    nb = synth.make_batch(B, H, W, config_id=1)
+    batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+    losses = {}
+    for bulk in (True, False):
+        trainer.BULK_WEIGHT_PREP = bulk
+        m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+        tr = rcf_amd.Trainer(m, device="cuda:0", precision=prec)
+        losses[bulk] = [float(tr.step(batch)["loss"]) for _ in range(3)]
+        if bulk:
+            assert tr.prep is not None and tr.prep.n >= 50
+            checked = 0
+            for conv in tr.prep.convs:
+                w = conv.weight
+                key = ops.weight_key(w)
+                c = conv._wcache
+                if prec == "fp32":
+                    assert c["amax"][0] == key and c["pairs"][0] == key and c["pairs_t"][0] == key
+                    aw = ops.absmax(ops.weight_rsck(w))
+                    assert int(aw) == int(c["amax"][1])
+                    Cout, Cin, R, S = w.shape
+                    for kind, fresh, tr_ in (("pairs", ops.weight_pairs(w, aw), 0), ("pairs_t", ops.weight_pairs_t(w, aw), 1)):
+                        if (R * S * (Cout if tr_ else Cin)) % 16:
+                            continue                        # K not a whole number of K-steps: the buffers hold unwritten padding
+                        got = c[kind][1]
+                        half = got.numel() // 2
+                        assert torch.equal(got[:half], fresh[:half]), (kind, tuple(w.shape))
+                        if ops._lib.load().rcf_conv_pairs2_useful(Cout, Cin, R, S, tr_):
+                            assert torch.equal(got[half:], fresh[half:]), (kind, "plane-separated half", tuple(w.shape))
+                else:
+                    assert c["bf16"][0] == key and c["bf16_t"][0] == key
+                    assert torch.equal(c["bf16"][1], ops.weight_bf16(w)) and torch.equal(c["bf16_t"][1], ops.weight_bf16(w, True))
+                checked += 1
+            assert checked == tr.prep.n
+    trainer.BULK_WEIGHT_PREP = True
+    assert losses[True] == losses[False], losses
