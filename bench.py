@@ -215,9 +215,11 @@ def main():
         out["roofline"].update({"executed_fp16_mfma_tflops": round(3 * out["roofline"]["achieved"], 1),
                                 "fp16_mfma_peak": BF16_MFMA_PEAK_TF, "fp32_mfma_peak": FP32_MFMA_PEAK_TF,
                                 "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload), not measured in this run"})
-        out["roofline"]["note"] = ("the weight gradients run on a second HIP stream beside the data gradients of the main stream (+8 % "
+        out["roofline"]["note"] = ("the weight gradients run on a second HIP stream beside the data gradients of the main stream (+1-2 % "
                                    "frames/s): a kernel's live duration includes what sharing the chip costs it; "
-                                   "roofline_by_kernel_one_stream holds the same brackets with everything on one stream")
+                                   "roofline_by_kernel_one_stream holds the same brackets with everything on one stream; the deep "
+                                   "convs are power-limited (tools/power_probe.py: the same launch 0.58 of peak on zero operands, 0.44 "
+                                   "on real data: DESIGN.md 4.1a)")
         if fam32 in by32s and by32s[fam32]["ms"] > 0:
             out["roofline"]["achieved_one_stream"] = round(by32s[fam32]["flops"] / (by32s[fam32]["ms"] * 1e-3) / 1e12, 2)
             out["roofline"]["frac_one_stream"] = round(out["roofline"]["achieved_one_stream"] / H2_MFMA_PEAK_TF, 4)
