@@ -9,8 +9,8 @@ the reference architecture.  frames/s = 2 * pairs_per_gpu * n_gpus * steps / tim
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the wide forward implicit-GEMM
-conv): algorithmic FLOPs of its launches / their HIP-event durations measured live in the timed
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128x256 weight-gradient
+implicit GEMM): algorithmic FLOPs of its launches / their HIP-event durations measured live in the timed
 region; `cpu_baseline` times the oracle (CPU restatement of the reference) on a bounded sample.
 """
 import argparse
@@ -164,10 +164,10 @@ def main():
         return out
 
     # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel with the largest share of
-    # the step's kernel time -- since the weight gradient's split-K plan changed (round 2) that is the 128x256 data-gradient
-    # tile on the main stream (28.2 ms per step; forward 28.0, weight gradient 27.3 with one stream); while it runs, the
-    # weight gradients of the layer above share the chip from the second stream
-    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_dgrad_wide")
+    # the step's kernel time -- since round 3 (lean epilogues, the deep 3x3 forward / data-gradient convs on the persistent
+    # kernel) that is the 128x256 weight-gradient tile again (igemm_wgrad_h2t_kernel<4,false,true>: 22.7 ms of a step's
+    # kernel time, profiles/r03_step_kernel_stats_one_stream.txt; data gradient 21.2, persistent forward 13.8)
+    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_wgrad_h2t4")
     dt, loss_val, prof, by32, by32s = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
     value = frames / dt
@@ -215,11 +215,12 @@ def main():
         out["roofline"].update({"executed_fp16_mfma_tflops": round(3 * out["roofline"]["achieved"], 1),
                                 "fp16_mfma_peak": BF16_MFMA_PEAK_TF, "fp32_mfma_peak": FP32_MFMA_PEAK_TF,
                                 "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload), not measured in this run"})
-        out["roofline"]["note"] = ("the weight gradients run on a second HIP stream beside the data gradients of the main stream (+1-2 % "
-                                   "frames/s): a kernel's live duration includes what sharing the chip costs it; "
-                                   "roofline_by_kernel_one_stream holds the same brackets with everything on one stream; the deep "
-                                   "convs are power-limited (tools/power_probe.py: the same launch 0.58 of peak on zero operands, 0.44 "
-                                   "on real data: DESIGN.md 4.1a)")
+        from rcf_amd import layers as _layers
+        out["config"]["second_stream_for_weight_gradients"] = bool(_layers.OVERLAP_WGRAD)
+        out["roofline"]["note"] = ("one HIP stream (round 3: the second stream for the weight gradients is off by default -- worth 1 % "
+                                   "since the persistent kernel and the lean epilogues, RCF_OVERLAP_WGRAD=1 re-enables it): a bracket "
+                                   "measures its kernel alone; the deep convs are power-limited (tools/power_probe.py: the same "
+                                   "launch 0.58 of peak on zero operands, 0.44 on real data: DESIGN.md 4.1a)")
         if fam32 in by32s and by32s[fam32]["ms"] > 0:
             out["roofline"]["achieved_one_stream"] = round(by32s[fam32]["flops"] / (by32s[fam32]["ms"] * 1e-3) / 1e12, 2)
             out["roofline"]["frac_one_stream"] = round(out["roofline"]["achieved_one_stream"] / H2_MFMA_PEAK_TF, 4)
@@ -227,9 +228,7 @@ def main():
         out["roofline_by_kernel_one_stream"] = by_kernel(by32s, FAMILIES_F32, H2_MFMA_PEAK_TF)
         if bf is not None:
             bf["roofline"] = roofline_of(prof16, fam16, FAMILIES_BF16.get(fam16, fam16), BF16_MFMA_PEAK_TF)
-            bf["roofline"]["note"] = ("weight gradients on a second HIP stream beside the main stream's data gradients and batch-norm "
-                                      "passes (-2 % step time): live durations include the sharing; roofline_by_kernel_one_stream "
-                                      "holds the same brackets with everything on one stream")
+            bf["roofline"]["note"] = "one HIP stream, as the fp32 leg"
             if fam16 in by16s and by16s[fam16]["ms"] > 0:
                 bf["roofline"]["achieved_one_stream"] = round(by16s[fam16]["flops"] / (by16s[fam16]["ms"] * 1e-3) / 1e12, 2)
                 bf["roofline"]["frac_one_stream"] = round(bf["roofline"]["achieved_one_stream"] / BF16_MFMA_PEAK_TF, 4)

@@ -71,7 +71,14 @@ class Act:
 # Weight gradients on a second HIP stream: wgrad and dgrad of a conv both read dy and are independent, so the one's
 # last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
 # (tape marks = all-reduce chunks, end of backward).
-OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
+# Round 3: OFF by default.  It was worth 8 % while every conv kernel left a fifth of the chip idle in its last round and
+# three quarters of a short tile's time in its epilogue; with the balanced persistent kernel on the deep layers and the
+# lean epilogues it is worth 1.0-1.5 ms of 115 (profiles/r03_ab_overlap.txt: 116.7 vs 117.7, 117.8 vs 119.4 ms), the two
+# gradients of a layer share the power budget anyway, and with one stream every kernel's duration is its own (the live
+# roofline brackets of bench.py measure the kernel, not its neighbour).  RCF_OVERLAP_WGRAD=1 turns it back on.
+OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "0") != "0"
+# stage 2.1: the EMA teacher's forward + CRF on a second stream beside the student's forward (152 vs 172 ms per step)
+OVERLAP_TEACHER = __import__("os").environ.get("RCF_OVERLAP_TEACHER", "1") != "0"
 OVERLAP_WGRAD_WITH_H2P = __import__("os").environ.get("RCF_OVERLAP_WGRAD_H2P", "1") != "0"   # A/B knob (tools/ab_overlap.py)
 # ... in the bf16 step the gain is smaller (same process, interleaved: 50.96 vs 51.98 ms/step, against 129.7 vs 140.6 in fp32;
 # before the bf16 weight gradient's prefetch worked, csrc/igemm_bf16.hip wgrad_tr_step, there was none: 57.8 vs 58.1)

@@ -243,7 +243,7 @@ class RCFModel(nn.Module):
         tape = Tape(on_mark=self.grad_ready_hook)
         img = self._images_nhwc(imgs)
         crf_side = None
-        if self.w_crf > 0 and self.crf_use_ema and layers.OVERLAP_WGRAD:
+        if self.w_crf > 0 and self.crf_use_ema and layers.OVERLAP_TEACHER:
             # the EMA teacher's forward + CRF need only the images: run them on the second stream beside the student's
             # forward (its HBM-bound BN passes and the teacher's MFMA-bound convs fill each other's gaps)
             crf_side = layers._side_stream(img.t.device)

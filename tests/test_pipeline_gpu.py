@@ -134,3 +134,34 @@ def test_bulk_weight_preparation_equals_the_per_layer_path(prec):
             assert checked == tr.prep.n
     trainer.BULK_WEIGHT_PREP = True
     assert losses[True] == losses[False], losses
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_second_stream_for_weight_gradients_changes_nothing(prec):
+    """the optional second HIP stream for the weight gradients (RCF_OVERLAP_WGRAD=1; off by default since round 3) only
+    reorders independent launches: losses of three steps and the parameters after them are identical with and without it"""
+    import copy
+    import types
+    import numpy as np
+    from rcf_amd import layers
+    H, W, B = 64, 96, 1
+    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None)
+    nb = synth.make_batch(B, H, W, config_id=1)
+    batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+    saved = layers.OVERLAP_WGRAD
+    res = {}
+    try:
+        for overlap in (False, True):
+            layers.OVERLAP_WGRAD = overlap
+            m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+            tr = rcf_amd.Trainer(m, device="cuda:0", precision=prec)
+            losses = [float(tr.step(batch)["loss"]) for _ in range(3)]
+            torch.cuda.synchronize()
+            res[overlap] = (losses, tr.fp.flat.clone())
+    finally:
+        layers.OVERLAP_WGRAD = saved
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1])

@@ -60,7 +60,7 @@ def main():
             ms = r["ms"] / r["launches"]
             tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
             print(f"{fam:22s} {tag:58s} x{n:2d}  {ms:7.3f} ms  {r['ms'] / nsteps:7.3f} ms/step  {tf:7.1f} TF/s  {tf / peak:5.3f}")
-    layers.OVERLAP_WGRAD = True
+    layers.OVERLAP_WGRAD = False
 
 
 if __name__ == "__main__":
