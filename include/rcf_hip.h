@@ -79,6 +79,14 @@ int rcf_conv_set_h2p(int mode, int min_k);
 /* A/B switch of the stream kernel of the 1x1 convs (conv_h2s_kernel, csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1
  * whenever eligible (1x1, stride 1, whole tensor, Cout-side % 256 == 0, K % 64 == 0, K >= 192) */
 int rcf_conv_set_h2s(int mode);
+/* A/B switch of the weight-gradient kernels' workgroup -> (output tile, pixel range) mapping: 1 (default) the workgroups that
+ * run together on one XCD read the same pixel range, 0 plain grid order.  Results are bit-identical either way. */
+int rcf_conv_set_wgrad_xcd(int mode);
+/* A/B switch of the K order of the forward / data-gradient convs: 1 (default) channel chunks of 64 outer, taps inner on the
+ * 3x3 layers with more than 64 channels per tap, 0 tap outer (the weight's memory order).  The derived weight operands
+ * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after
+ * a change.  Sums are re-associated, not changed otherwise. */
+int rcf_conv_set_korder(int mode);
 /* profiling labels: which kernel the last forward / data-gradient launch took (1: 128 x 256 family, 2: conv_h2p_kernel,
  * 3: conv_h2s_kernel).  A plain global: meaningful right after a launch from the same thread only. */
 int rcf_conv_last_kernel(void);

@@ -14,6 +14,9 @@
 #include <type_traits>
 #include "rcf_common.h"
 
+extern int rcf_g_wgrad_xcd;   // igemm_conv.hip: rcf_conv_set_wgrad_xcd
+extern int rcf_g_korder;      // igemm_conv.hip: rcf_conv_set_korder (rcf_common.h rcf_kchunk)
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -44,7 +47,9 @@ struct ConvParams {
     int beta;
     int mtiles, ntiles;
     int mtiles8;                  // ceil(mtiles / 8): XCD x (block id % 8) walks the contiguous row tiles [x mtiles8, (x + 1) mtiles8)
-    unsigned cs_magic, s_magic;
+    unsigned s_magic;
+    int kch, rsch;                // K order (rcf_common.h rcf_kchunk): channel chunk width (Cs = natural order), taps * kch
+    unsigned kch_magic, rsch_magic;
     int b_bytes;
     int ry0, rx0, rh, rw, rband, rr;      // region of the GEMM-row tensor (see igemm_conv.hip)
     double *stats;                        // forward only: per row tile, fp64 column sums | sums of squares
@@ -214,8 +219,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
             char *Bs = As + PA;
             const int k = kt * BKT + kq * 8;
             const bool kv = k < p.K;
-            const int rs = SCHED != 0 ? fast_div_nb(k, p.cs_magic) : fast_div(k, p.cs_magic);
-            const int c = k - rs * p.Cs;
+            // position k of the K loop = (channel chunk q, tap rs, channel inside the chunk); natural order: one chunk of Cs
+            const int q = SCHED != 0 ? fast_div_nb(k, p.rsch_magic) : fast_div(k, p.rsch_magic);
+            const int rem = k - q * p.rsch;
+            const int rs = SCHED != 0 ? fast_div_nb(rem, p.kch_magic) : fast_div(rem, p.kch_magic);
+            const int c = q * p.kch + (rem - rs * p.kch);
             const int r = SCHED != 0 ? fast_div_nb(rs, p.s_magic) : fast_div(rs, p.s_magic);
             const int s = rs - r * p.S;
             const int dy = r * p.step, dx = s * p.step;
@@ -297,8 +305,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     auto load_a = [&](int kt, u32x4 (&dst)[A_PASS]) {
         const int k = kt * BKT + kq * 8;
         const bool kv = k < p.K;
-        const int rs = fast_div(k, p.cs_magic);
-        const int c = k - rs * p.Cs;
+        const int q = fast_div(k, p.rsch_magic);
+        const int rem = k - q * p.rsch;
+        const int rs = fast_div(rem, p.kch_magic);
+        const int c = q * p.kch + (rem - rs * p.kch);
         const int r = fast_div(rs, p.s_magic);
         const int s = rs - r * p.S;
         const int dy = r * p.step, dx = s * p.step;
@@ -544,9 +554,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
 // TRANSPOSE (data gradient): rows = c (Cin), k = rs * Cout + co of w[co][rs][c].
 template <bool TRANSPOSE>
 __global__ void __launch_bounds__(256) weight_bf16_kernel(const float *__restrict__ w, bf16_t *__restrict__ out, int Cout,
-                                                          int Cin, int RS) {
+                                                          int Cin, int RS, int korder) {
     const int rows = TRANSPOSE ? Cin : Cout;
     const int K = TRANSPOSE ? RS * Cout : RS * Cin;
+    const int Cs = TRANSPOSE ? Cout : Cin, kch = rcf_kchunk(korder, RS, Cs, RCF_KCHUNK_BF16);      // K order of the kernel that reads `out`
     const int KT = (K + 31) >> 5;
     const long n = (long)KT * rows * 32;
     const long step = (long)gridDim.x * blockDim.x;
@@ -554,9 +565,10 @@ __global__ void __launch_bounds__(256) weight_bf16_kernel(const float *__restric
         const int kl = (int)(i & 31);
         const long t = i >> 5;
         const int j = (int)(t % rows);
-        const int k = (int)(t / rows) * 32 + kl;
+        const int kp = (int)(t / rows) * 32 + kl;
         float v = 0.f;
-        if (k < K) {
+        if (kp < K) {
+            const int k = rcf_kperm(kp, RS, Cs, kch);
             if (!TRANSPOSE) {
                 v = w[(long)j * K + k];
             } else {
@@ -583,6 +595,8 @@ struct WgradParams {
     int ry0, rx0, rh, rw, rband, rr;
     int Ktot;          // R*S*Cin: the GEMM columns are (tap, input channel) pairs
     int sched;         // LDS-DMA kernel: 1 = pieces interleaved with the MFMAs (default), 0 = ahead of them (A/B reference)
+    int xcd_map;       // rcf_wgrad_item mode (1 = an XCD's workgroups share their pixels)
+    int cblocks;       // rcf_wgrad_tile_ij (> 0: column tiles per tap, tiles numbered channel-block-major)
 };
 
 // byte offset `off` if ok == 1, an out-of-range offset (the load returns zeros) if ok == 0 -- arithmetic, so that a
@@ -614,9 +628,12 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = PLA + PLB;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    int tile, split;
+    rcf_wgrad_item(p.xcd_map, tile, split);
+    int tile_i, tile_j;
+    rcf_wgrad_tile_ij(tile, p.itiles, p.jtiles, p.cblocks, tile_i, tile_j);
     const int i0 = tile_i * BM, j0 = tile_j * BN;
-    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kbeg = (long)split * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
     const int klen = (int)(kend - kbeg);
 
@@ -757,7 +774,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
     }
     mma((KT - 1) & 1);
 
-    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    float *out = p.OUT + (long)split * p.split_stride;
     const int l31 = lane & 31, kh = lane >> 5;
     if (i0 + 32 * MR * 2 <= p.Cout && j0 + 32 * NR * 2 <= p.Ktot && !(p.beta && gridDim.z == 1)) {
         // the tile lies inside the weight tensor and is a split-K partial (or overwrites): store, nothing to test
@@ -836,9 +853,12 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
     constexpr int PLA = GA * GSZ, PLB = GB * GSZ, STAGE = PLA + PLB;
     __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
 
-    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    int tile, split;
+    rcf_wgrad_item(p.xcd_map, tile, split);
+    int tile_i, tile_j;
+    rcf_wgrad_tile_ij(tile, p.itiles, p.jtiles, p.cblocks, tile_i, tile_j);
     const int i0 = tile_i * BM, j0 = tile_j * BN;
-    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kbeg = (long)split * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
     const int klen = (int)(kend - kbeg);
 
@@ -1002,7 +1022,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
         st = st == 2 ? 0 : st + 1;
     }
 
-    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    float *out = p.OUT + (long)split * p.split_stride;
     const int l31 = lane & 31, kh = lane >> 5;
     if (i0 + 32 * MR * 2 <= p.Cout && j0 + 32 * NR * 2 <= p.Ktot && !(p.beta && gridDim.z == 1)) {
         // the tile lies inside the weight tensor and is a split-K partial (or overwrites): store, nothing to test
@@ -1104,9 +1124,15 @@ void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
 
 template <bool OBF>
 int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
-    p.cs_magic = magic_of(p.Cs);
     p.s_magic = magic_of(p.S);
-    if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
+    {
+        const int taps = p.K / p.Cs, kch = rcf_kchunk(rcf_g_korder, taps, p.Cs, RCF_KCHUNK_BF16);
+        p.kch = kch ? kch : p.Cs;
+        p.rsch = taps * p.kch;
+        p.kch_magic = magic_of(p.kch);
+        p.rsch_magic = magic_of(p.rsch);
+    }
+    if ((long)(p.K + BKT) * p.rsch >= (1L << 32)) return RCF_EINVAL;
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 2 >= (1L << 31)) return RCF_EINVAL;
@@ -1198,10 +1224,11 @@ extern "C" size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, in
 namespace {
 // batched weight_bf16_kernel over a table of weights (rcf_common.h: rcf_wprep_entry; out = the layout of rcf_conv_weight_bf16)
 template <bool TRANSPOSE>
-__global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *__restrict__ tab, int n_entries) {
+__global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *__restrict__ tab, int n_entries, int korder) {
     const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n_entries, blockIdx.x)];
     const int rows = TRANSPOSE ? t.Cin : t.Cout;
     const int K = TRANSPOSE ? t.RS * t.Cout : t.RS * t.Cin;
+    const int Cs = TRANSPOSE ? t.Cout : t.Cin, kch = rcf_kchunk(korder, t.RS, Cs, RCF_KCHUNK_BF16);
     const int KT = (K + 31) >> 5;
     const long n = (long)KT * rows * 32;
     const long step = (long)t.nblocks * 256;
@@ -1210,9 +1237,10 @@ __global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *
         const int kl = (int)(i & 31);
         const long q = i >> 5;
         const int j = (int)(q % rows);
-        const int k = (int)(q / rows) * 32 + kl;
+        const int kp = (int)(q / rows) * 32 + kl;
         float v = 0.f;
-        if (k < K) {
+        if (kp < K) {
+            const int k = rcf_kperm(kp, t.RS, Cs, kch);
             if (!TRANSPOSE) {
                 v = t.w[(long)j * K + k];
             } else {
@@ -1230,8 +1258,8 @@ __global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *
 extern "C" int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, void *stream) {
     if (!tab_fwd || !tab_t || n <= 0 || blocks_fwd <= 0 || blocks_t <= 0) return RCF_EINVAL;
     hipStream_t st = rcf_stream(stream);
-    hipLaunchKernelGGL(wprep_bf16_kernel<false>, dim3((unsigned)blocks_fwd), dim3(256), 0, st, (const rcf_wprep_entry *)tab_fwd, n);
-    hipLaunchKernelGGL(wprep_bf16_kernel<true>, dim3((unsigned)blocks_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_t, n);
+    hipLaunchKernelGGL(wprep_bf16_kernel<false>, dim3((unsigned)blocks_fwd), dim3(256), 0, st, (const rcf_wprep_entry *)tab_fwd, n, rcf_g_korder);
+    hipLaunchKernelGGL(wprep_bf16_kernel<true>, dim3((unsigned)blocks_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_t, n, rcf_g_korder);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1241,8 +1269,8 @@ extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, in
     const long n = (long)rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, transpose) / 2;
     const long blocks = (n + 1023) / 1024;
     const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
-    if (transpose) hipLaunchKernelGGL(weight_bf16_kernel<true>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S);
-    else hipLaunchKernelGGL(weight_bf16_kernel<false>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S);
+    if (transpose) hipLaunchKernelGGL(weight_bf16_kernel<true>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, rcf_g_korder);
+    else hipLaunchKernelGGL(weight_bf16_kernel<false>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, rcf_g_korder);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1357,6 +1385,7 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     p.Ktot = s->R * s->S * s->Cin;
     p.sched = g_bf16_tile == 4 ? 0 : 1;
+    p.xcd_map = rcf_g_wgrad_xcd;
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), 1u, (unsigned)pl.splitk);
 #define RCF_WG(MRv, NRv)                                                                              \
     do {                                                                                              \
@@ -1364,6 +1393,7 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
         else hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, false>), grid, dim3(256), 0, st, p);        \
     } while (0)
     const bool onetap = s->Cin % (64 * pl.nr) == 0;
+    p.cblocks = onetap && s->R * s->S > 1 && rcf_g_wgrad_xcd ? s->Cin / (64 * pl.nr) : 0;
 #define RCF_WGD(NRv)                                                                                              \
     do {                                                                                                          \
         if (region && onetap) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);   \

@@ -24,6 +24,9 @@
 
 #include <cstdlib>
 
+int rcf_g_wgrad_xcd = 1;      // rcf_conv_set_wgrad_xcd; read by igemm_bf16.hip too
+int rcf_g_korder = 1;         // rcf_conv_set_korder: K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk)
+
 namespace {
 
 constexpr int BK = 16;   // K-step of the weight-gradient kernel
@@ -49,6 +52,10 @@ struct IgemmParams {
     int mtiles, ntiles;
     int mtiles8;                  // ceil(mtiles / 8): XCD x (block id % 8) walks the contiguous row tiles [x mtiles8, (x + 1) mtiles8)
     unsigned cs_magic, s_magic;   // floor(2^32/d)+1 for d = Cs, S (exact k/d for k*d < 2^32; 0 when d == 1)
+    // split-bf16 / fp16-pair kernels: K order (rcf_common.h rcf_kchunk) -- channel chunk width (Cs = the natural order: one
+    // chunk), taps * kch, and their magics
+    int kch, rsch;
+    unsigned kch_magic, rsch_magic;
     int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
     int dbg;                      // timing experiments only (tools/bench_conv.py): 1 = no global loads after the first K-step
     // split-bf16 kernels: the GEMM rows are the pixels of the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of every image
@@ -618,8 +625,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     auto load_a = [&](int kt, f32x4 (&dst)[A_PASS]) {
         const int k = kt * BKT + kq * 4;
         const bool kv = k < p.K;
-        const int rs = fast_div(k, p.cs_magic);
-        const int c = k - rs * p.Cs;
+        // position k of the K loop = (channel chunk q, tap rs, channel inside the chunk); natural order: ONE chunk of Cs
+        const int q = fast_div(k, p.rsch_magic);
+        const int rem = k - q * p.rsch;
+        const int rs = fast_div(rem, p.kch_magic);
+        const int c = q * p.kch + (rem - rs * p.kch);
         const int r = fast_div(rs, p.s_magic);
         const int s = rs - r * p.S;
         const int dy = r * p.step, dx = s * p.step;
@@ -645,8 +655,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     };
     auto load_b = [&](int kt) {
         const int k = kt * BKT + kq * 4;
-        // pre-split weights: K-step major, 64 bytes per row and step (pairs_index)
-        const unsigned k4 = pre ? (unsigned)kt * (unsigned)p.Ncol * 64u + (unsigned)kq * 16u : (unsigned)k * 4u;
+        // pre-split weights: K-step major in the loop's own K order, 64 bytes per row and step (pairs_index); raw fp32 weights:
+        // the loop position's natural index tap * Cs + c
+        unsigned k4;
+        if constexpr (pre) {
+            k4 = (unsigned)kt * (unsigned)p.Ncol * 64u + (unsigned)kq * 16u;
+        } else {
+            const int q = fast_div(k, p.rsch_magic);
+            const int rem = k - q * p.rsch;
+            const int rs = fast_div(rem, p.kch_magic);
+            k4 = (unsigned)(rs * p.Cs + q * p.kch + (rem - rs * p.kch)) * 4u;
+        }
         const unsigned koob = ((unsigned)((int)(k < p.K) - 1) & X3_OOB) | dbg_oob;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i)
@@ -944,9 +963,10 @@ __device__ __forceinline__ long pairs_index(int j, int k, int rows) {
 
 template <bool TRANSPOSE>
 __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restrict__ w, const unsigned *__restrict__ amax,
-                                                           _Float16 *__restrict__ planes, int Cout, int Cin, int RS) {
+                                                           _Float16 *__restrict__ planes, int Cout, int Cin, int RS, int korder) {
     const float sc = pow2f(h2_exponent(*amax));
     const long n = (long)Cout * RS * Cin;
+    const int Cs = TRANSPOSE ? Cout : Cin, kch = rcf_kchunk(korder, RS, Cs, RCF_KCHUNK_F32);      // K order of the kernel that reads `planes`
     if (!TRANSPOSE) {
         const long step = (long)gridDim.x * blockDim.x;
         const int K = RS * Cin;
@@ -954,7 +974,7 @@ __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restri
             const float v = w[i] * sc;
             const _Float16 h = (_Float16)v;
             const int j = (int)(i / K);
-            const long q = pairs_index(j, (int)(i - (long)j * K), Cout);
+            const long q = pairs_index(j, rcf_kpos((int)(i - (long)j * K), RS, Cs, kch), Cout);
             planes[q] = h;
             planes[q + 4] = (_Float16)(v - (float)h);
         }
@@ -973,7 +993,7 @@ __global__ void __launch_bounds__(256) weight_pairs_kernel(const float *__restri
         if (c < Cin && co < Cout) {
             const float v = tile[tx][r] * sc;
             const _Float16 h = (_Float16)v;
-            const long q = pairs_index(c, rs * Cout + co, Cin);
+            const long q = pairs_index(c, rcf_kpos(rs * Cout + co, RS, Cs, kch), Cin);
             planes[q] = h;
             planes[q + 4] = (_Float16)(v - (float)h);
         }
@@ -989,16 +1009,17 @@ __device__ __forceinline__ long pairs2_index(int j, int k, int rows, int plane) 
 
 template <bool TRANSPOSE>
 __global__ void __launch_bounds__(256) weight_pairs2_kernel(const float *__restrict__ w, const unsigned *__restrict__ amax,
-                                                            _Float16 *__restrict__ planes, int Cout, int Cin, int RS) {
+                                                            _Float16 *__restrict__ planes, int Cout, int Cin, int RS, int korder) {
     const float sc = pow2f(h2_exponent(*amax));
     const long n = (long)Cout * RS * Cin;
+    const int Cs = TRANSPOSE ? Cout : Cin, kch = rcf_kchunk(korder, RS, Cs, RCF_KCHUNK_F32);
     if (!TRANSPOSE) {
         const long step = (long)gridDim.x * blockDim.x;
         const int K = RS * Cin;
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
             const float v = w[i] * sc;
             const _Float16 h = (_Float16)v;
-            const int j = (int)(i / K), k = (int)(i - (long)j * K);
+            const int j = (int)(i / K), k = rcf_kpos((int)(i - (long)j * K), RS, Cs, kch);
             planes[pairs2_index(j, k, Cout, 0)] = h;
             planes[pairs2_index(j, k, Cout, 1)] = (_Float16)(v - (float)h);
         }
@@ -1017,8 +1038,9 @@ __global__ void __launch_bounds__(256) weight_pairs2_kernel(const float *__restr
         if (c < Cin && co < Cout) {
             const float v = tile[tx][r] * sc;
             const _Float16 h = (_Float16)v;
-            planes[pairs2_index(c, rs * Cout + co, Cin, 0)] = h;
-            planes[pairs2_index(c, rs * Cout + co, Cin, 1)] = (_Float16)(v - (float)h);
+            const int k = rcf_kpos(rs * Cout + co, RS, Cs, kch);
+            planes[pairs2_index(c, k, Cin, 0)] = h;
+            planes[pairs2_index(c, k, Cin, 1)] = (_Float16)(v - (float)h);
         }
     }
 }
@@ -1043,10 +1065,10 @@ __global__ void __launch_bounds__(256) wprep_absmax_kernel(const rcf_wprep_entry
 
 // out = [pairs | pairs2 (flags bit 0)] of rcf_conv_weight_pairs2_f32(transpose = 0): the same values as weight_pairs_kernel<false>
 // and weight_pairs2_kernel<false>
-__global__ void __launch_bounds__(256) wprep_pairs_kernel(const rcf_wprep_entry *__restrict__ tab, int n) {
+__global__ void __launch_bounds__(256) wprep_pairs_kernel(const rcf_wprep_entry *__restrict__ tab, int n, int korder) {
     const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n, blockIdx.x)];
     const float sc = pow2f(h2_exponent(*t.amax));
-    const int K = t.RS * t.Cin;
+    const int K = t.RS * t.Cin, kch = rcf_kchunk(korder, t.RS, t.Cin, RCF_KCHUNK_F32);
     const long total = (long)t.Cout * K, step = (long)t.nblocks * 256;
     _Float16 *planes = reinterpret_cast<_Float16 *>(t.out);
     _Float16 *planes2 = planes + (long)((K + 15) / 16) * t.Cout * 32;        // pairs: cdiv(K, 16) * Cout * 64 bytes
@@ -1054,7 +1076,7 @@ __global__ void __launch_bounds__(256) wprep_pairs_kernel(const rcf_wprep_entry 
     for (long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x; i < total; i += step) {
         const float v = t.w[i] * sc;
         const _Float16 h = (_Float16)v, m = (_Float16)(v - (float)h);
-        const int j = (int)(i / K), k = (int)(i - (long)j * K);
+        const int j = (int)(i / K), k = rcf_kpos((int)(i - (long)j * K), t.RS, t.Cin, kch);
         const long q = pairs_index(j, k, t.Cout);
         planes[q] = h;
         planes[q + 4] = m;
@@ -1066,10 +1088,11 @@ __global__ void __launch_bounds__(256) wprep_pairs_kernel(const rcf_wprep_entry 
 }
 
 // the transposed buffers (rcf_conv_weight_pairs2_f32(transpose = 1)); a block is one 32 x 32 (co, c) tile of one tap
-__global__ void __launch_bounds__(256) wprep_pairs_t_kernel(const rcf_wprep_entry *__restrict__ tab, int n) {
+__global__ void __launch_bounds__(256) wprep_pairs_t_kernel(const rcf_wprep_entry *__restrict__ tab, int n, int korder) {
     __shared__ float tile[32][33];
     const rcf_wprep_entry t = tab[rcf_wprep_find(tab, n, blockIdx.x)];
     const float sc = pow2f(h2_exponent(*t.amax));
+    const int kch = rcf_kchunk(korder, t.RS, t.Cout, RCF_KCHUNK_F32);
     const int nbx = (t.Cin + 31) >> 5, nby = (t.Cout + 31) >> 5;
     int lb = blockIdx.x - t.first_block;
     const int rs = lb / (nbx * nby);
@@ -1090,12 +1113,13 @@ __global__ void __launch_bounds__(256) wprep_pairs_t_kernel(const rcf_wprep_entr
         if (c < t.Cin && co < t.Cout) {
             const float v = tile[tx][r] * sc;
             const _Float16 h = (_Float16)v, m = (_Float16)(v - (float)h);
-            const long q = pairs_index(c, rs * t.Cout + co, t.Cin);
+            const int k = rcf_kpos(rs * t.Cout + co, t.RS, t.Cout, kch);
+            const long q = pairs_index(c, k, t.Cin);
             planes[q] = h;
             planes[q + 4] = m;
             if (second) {
-                planes2[pairs2_index(c, rs * t.Cout + co, t.Cin, 0)] = h;
-                planes2[pairs2_index(c, rs * t.Cout + co, t.Cin, 1)] = m;
+                planes2[pairs2_index(c, k, t.Cin, 0)] = h;
+                planes2[pairs2_index(c, k, t.Cin, 1)] = m;
             }
         }
     }
@@ -1119,6 +1143,8 @@ struct WgradParams {
     int ry0, rx0, rh, rw;   // split-bf16 kernel: contributing output pixels = this rectangle of every image (M = N*rr)
     int rband, rr;          // frame thickness (0 = whole rectangle), pixels per image
     const unsigned *amax_a, *amax_b;   // fp16-pair kernels: max |dy|, max |x| (raw fp32 bits, device scalars)
+    int xcd_map;       // igemm_wgrad_h2t_kernel: rcf_wgrad_item mode (1 = an XCD's workgroups share their pixels)
+    int cblocks;       // igemm_wgrad_h2t_kernel: rcf_wgrad_tile_ij (> 0: column tiles per tap, tiles numbered channel-block-major)
 };
 
 // dw[co][rs][c] = sum_m dy[m][co] * x[src(m, rs)][c].  rows i = co, cols j = c, K = pixels.
@@ -1640,10 +1666,13 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-    const int tile_i = blockIdx.x / p.jtiles, tile_j = blockIdx.x - tile_i * p.jtiles;
+    int tile, split;
+    rcf_wgrad_item(p.xcd_map, tile, split);
+    int tile_i, tile_j;
+    rcf_wgrad_tile_ij(tile, p.itiles, p.jtiles, p.cblocks, tile_i, tile_j);
     const int i0 = tile_i * BM, j0 = tile_j * BN;
     const int Ktot = p.R * p.S * p.Cin;
-    const long kbeg = (long)blockIdx.z * p.chunk;
+    const long kbeg = (long)split * p.chunk;
     const long kend = min(p.M, kbeg + p.chunk);
     const int klen = (int)(kend - kbeg);
 
@@ -1837,7 +1866,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) 
     if (incr) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
-    float *out = p.OUT + (long)blockIdx.z * p.split_stride;
+    float *out = p.OUT + (long)split * p.split_stride;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     const int l31 = lane & 31, kh = lane >> 5;
     if (i0 + BM <= p.Cout && j0 + BN <= Ktot && !(p.beta && gridDim.z == 1)) {
@@ -2080,6 +2109,14 @@ int launch_h2s(IgemmParams &p, hipStream_t st) {
 
 int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     p.cs_magic = magic_of(p.Cs);
+    {
+        const int taps = p.K / p.Cs, kch = rcf_kchunk(rcf_g_korder, taps, p.Cs, RCF_KCHUNK_F32);
+        p.kch = kch ? kch : p.Cs;
+        p.rsch = taps * p.kch;
+        p.kch_magic = magic_of(p.kch);
+        p.rsch_magic = magic_of(p.rsch);
+        if ((long)(p.K + 16) * p.rsch >= (1L << 32)) return RCF_EINVAL;
+    }
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
     if (h2s_eligible(p, batches)) return launch_h2s(p, st);
@@ -2334,7 +2371,7 @@ extern "C" int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int 
     const long n = (long)Cout * R * S * Cin;
     const long blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(weight_pairs_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
-                       rcf_stream(stream), w, amax_w, (_Float16 *)planes, Cout, Cin, R * S);
+                       rcf_stream(stream), w, amax_w, (_Float16 *)planes, Cout, Cin, R * S, rcf_g_korder);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -2344,7 +2381,7 @@ extern "C" int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, in
     if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
     const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
     hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)planes,
-                       Cout, Cin, R * S);
+                       Cout, Cin, R * S, rcf_g_korder);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -2373,14 +2410,14 @@ extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int
         const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
         if (second_half)
             hipLaunchKernelGGL(weight_pairs2_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)second,
-                               Cout, Cin, R * S);
+                               Cout, Cin, R * S, rcf_g_korder);
     } else {
         if (int e = rcf_conv_weight_pairs_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
         const long n = (long)Cout * R * S * Cin;
         const long blocks = (n + 1023) / 1024;
         if (second_half)
             hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
-                               rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S);
+                               rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S, rcf_g_korder);
     }
     RCF_LAUNCH_CHECK();
     return 0;
@@ -2404,8 +2441,8 @@ extern "C" int rcf_conv_weights_prepare_f32(const void *tab_absmax, int blocks_a
     hipStream_t st = rcf_stream(stream);
     if (hipMemsetAsync(amax_base, 0, (size_t)n * sizeof(unsigned), st) != hipSuccess) return RCF_EINVAL;
     hipLaunchKernelGGL(wprep_absmax_kernel, dim3((unsigned)blocks_absmax), dim3(256), 0, st, (const rcf_wprep_entry *)tab_absmax, n);
-    hipLaunchKernelGGL(wprep_pairs_kernel, dim3((unsigned)blocks_pairs), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs, n);
-    hipLaunchKernelGGL(wprep_pairs_t_kernel, dim3((unsigned)blocks_pairs_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs_t, n);
+    hipLaunchKernelGGL(wprep_pairs_kernel, dim3((unsigned)blocks_pairs), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs, n, rcf_g_korder);
+    hipLaunchKernelGGL(wprep_pairs_t_kernel, dim3((unsigned)blocks_pairs_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs_t, n, rcf_g_korder);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -2424,6 +2461,21 @@ extern "C" int rcf_conv_last_kernel(void) { return g_last_conv_kernel; }
 /* A/B switch of conv_h2s_kernel (the 1x1 convs as a stream of K-steps): -1 built-in rule, 0 never, 1 whenever eligible */
 extern "C" int rcf_conv_set_h2s(int mode) {
     g_h2s = mode;
+    return 0;
+}
+
+/* A/B switch of the weight-gradient kernels' workgroup -> (tile, split) mapping (csrc/rcf_common.h rcf_wgrad_item): 1 (the
+ * default) an XCD's workgroups share their pixel range, 0 the plain grid order.  Same sums in the same order either way. */
+/* A/B switch of the K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk): 1 (default) channel chunks of 64
+ * outer, taps inner on the 3x3 layers; 0 the weight's memory order (tap outer).  The derived weight operands are laid out in
+ * the order the kernels walk: rebuild them after a change (rcf_amd.ops.weights_changed()). */
+extern "C" int rcf_conv_set_korder(int mode) {
+    rcf_g_korder = mode ? 1 : 0;
+    return 0;
+}
+
+extern "C" int rcf_conv_set_wgrad_xcd(int mode) {
+    rcf_g_wgrad_xcd = mode ? 1 : 0;
     return 0;
 }
 
@@ -2505,7 +2557,7 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
             if (s->w_pairs2_t && pairs2_useful(s->Cin, s->R * s->S * s->Cout, s->Cout)) p.b_pairs2 = (const char *)wpt + need;
         } else if (p.amax_a && p.amax_b && !g_h2_off) {   // fp16 pairs: transposed AND split, once per launch
             hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
-                               s->Cout, s->Cin, s->R * s->S);
+                               s->Cout, s->Cin, s->R * s->S, rcf_g_korder);
             p.b_pairs = workspace;
         } else {
             hipLaunchKernelGGL(weight_transpose_kernel, tgrid, dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin,
@@ -2563,6 +2615,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     p.amax_a = s->amax_dy; p.amax_b = s->amax_x;
+    p.xcd_map = rcf_g_wgrad_xcd;
     const bool smallc = s->Cin == 4;
     if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)((smallc || pl.cols) ? 1 : s->R * s->S), (unsigned)pl.splitk);
@@ -2585,6 +2638,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
         if (h2) {            // fp16 pairs
             if (pl.cols) {
                 const bool onetap = s->Cin % (64 * pl.nr) == 0;
+                p.cblocks = onetap && s->R * s->S > 1 && rcf_g_wgrad_xcd ? s->Cin / (64 * pl.nr) : 0;
                 if (pl.nr == 4) {
                     if (region && onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, true>), grid, dim3(256), 0, st, p);
                     else if (region) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, false>), grid, dim3(256), 0, st, p);

@@ -117,6 +117,75 @@ struct rcf_wprep_entry {
 };
 static_assert(sizeof(rcf_wprep_entry) == 56 || sizeof(rcf_wprep_entry) == 64, "mirrored by ctypes in _lib.py");
 
+// K order of the implicit-GEMM forward / data-gradient convs.  Natural: k = tap * Cs + c (the weight's memory order) -- a
+// workgroup streams ALL channels of its pixels for tap 0, then for tap 1, ...: by the time the next tap asks for the same
+// pixels (shifted by the dilation) they have left the XCD's 4 MB L2, and a 3x3 conv over 2048 / 4096 channels pulls its input
+// through the fabric 8 - 9 times (profiles/r03_pmc_traffic_by_layer_before.txt).  Chunked: K runs over (channel chunk of
+// 32 / 64, tap, channel inside the chunk) -- the nine taps of one chunk follow each other, the row tiles running together on an
+// XCD are neighbours (mtiles8), so a tap's pixels are still in L2 from the previous tap or from the neighbouring tile.
+// rcf_kchunk: chunk width of a (taps, channels-per-tap) pair, 0 = natural order; the weight preparation kernels and the conv
+// kernels evaluate the same rule.  rcf_kperm: position in the K loop -> natural index tap * Cs + c.
+// Chunk width: 128 bytes of a pixel (one cache line) in fp32, 128 bytes = two K-steps in bf16 -- the narrower the chunk, the
+// more workgroups of an XCD can drift apart by a chunk before their pixels fall out of L2 (fp32 at 64 channels: a 3x3
+// 4096 -> 256 conv still fetched 7 x its input, profiles/r03_pmc_traffic_by_layer.txt).
+constexpr int RCF_KCHUNK_F32 = 32, RCF_KCHUNK_BF16 = 64;
+__host__ __device__ inline int rcf_kchunk(int mode, int RS, int Cs, int width) {
+    return (mode && RS > 1 && Cs > width && Cs % width == 0) ? width : 0;
+}
+// rcf_kpos: natural index -> position in the K loop (the inverse of rcf_kperm)
+__host__ __device__ inline int rcf_kpos(int k, int RS, int Cs, int kch) {
+    if (!kch) return k;
+    const int tap = k / Cs, c = k - tap * Cs;
+    const int q = c / kch;
+    return q * (RS * kch) + tap * kch + (c - q * kch);
+}
+__host__ __device__ inline int rcf_kperm(int kp, int RS, int Cs, int kch) {
+    if (!kch) return kp;
+    const int per = RS * kch;
+    const int q = kp / per, rem = kp - q * per;
+    const int tap = rem / kch;
+    return tap * Cs + q * kch + (rem - tap * kch);
+}
+
+// Weight-gradient grids are (tiles, 1, splits): a split is a range of pixels of dy and x, every tile of a split reads that
+// range.  Workgroups go round-robin over the 8 XCDs in dispatch order (L = x + tiles * z -> XCD L % 8), so with the plain
+// mapping every XCD's L2 fetches every split's pixels.  mode 1: XCD x takes a CONTIGUOUS run of the (split, tile) sequence
+// -- the workgroups running together on one XCD walk the same pixels, which then cross the fabric once per XCD that needs
+// them instead of once per XCD (counters: profiles/r03_pmc_wgrad_xcd.txt).  A bijection of [0, tiles * splits) for any count.
+__device__ __forceinline__ void rcf_wgrad_item(int mode, int &tile, int &split) {
+    const unsigned tiles = gridDim.x, total = tiles * gridDim.z;
+    const unsigned L = blockIdx.x + tiles * blockIdx.z;
+    if (mode == 0 || total < 16) {
+        tile = (int)blockIdx.x;
+        split = (int)blockIdx.z;
+        return;
+    }
+    const unsigned q = total >> 3, r = total & 7u, x = L & 7u;
+    const unsigned seq = x * q + (x < r ? x : r) + (L >> 3);
+    const unsigned sp = seq / tiles;
+    split = (int)sp;
+    tile = (int)(seq - sp * tiles);
+}
+
+// Order of the output tiles inside a split.  With the (tap, channel) pairs as GEMM columns, column tile tj = tap * cblocks + cb
+// reads channel block cb of x shifted by the tap's offset: the nine tiles of ONE channel block read the same pixels of x.
+// cblocks > 0 (every column tile lies in one tap, several taps): tiles are numbered (channel block, tap, row tile), so the
+// workgroups running together on an XCD cover few channel blocks under all their taps -- a pixel of x crosses the fabric once
+// per XCD instead of once per tap (a 3x3 4096 -> 256 weight gradient: 10.5 x its algorithmic bytes before,
+// profiles/r03_pmc_traffic_by_layer_before.txt).  cblocks == 0: row-tile-major, as the grid was laid out originally.
+__device__ __forceinline__ void rcf_wgrad_tile_ij(int tile, int itiles, int jtiles, int cblocks, int &ti, int &tj) {
+    if (cblocks > 0) {
+        const int taps = jtiles / cblocks, per_cb = taps * itiles;
+        const int cb = tile / per_cb, rem = tile - cb * per_cb;
+        const int tap = rem / itiles;
+        ti = rem - tap * itiles;
+        tj = tap * cblocks + cb;
+    } else {
+        ti = tile / jtiles;
+        tj = tile - ti * jtiles;
+    }
+}
+
 __device__ __forceinline__ int rcf_wprep_find(const rcf_wprep_entry *__restrict__ tab, int n, int block) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {                                      // last entry with first_block <= block

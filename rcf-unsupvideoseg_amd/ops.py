@@ -270,6 +270,28 @@ def conv_set_h2s(mode=-1):
     _lib.load().rcf_conv_set_h2s(int(mode))
 
 
+def conv_set_wgrad_xcd(mode=1):
+    """A/B switch of the weight-gradient kernels' XCD-aware (tile, pixel range) mapping (csrc/rcf_common.h rcf_wgrad_item)"""
+    _lib.load().rcf_conv_set_wgrad_xcd(int(mode))
+
+
+def conv_set_korder(mode=1):
+    """A/B switch of the K order of the forward / data-gradient convs (csrc/rcf_common.h rcf_kchunk); the cached weight operands
+    are laid out in that order, so they are dropped"""
+    _lib.load().rcf_conv_set_korder(int(mode))
+    weights_changed()
+
+
+if "RCF_KORDER" in os.environ:
+    try:
+        conv_set_korder(int(os.environ["RCF_KORDER"]))
+    except Exception:                  # noqa: BLE001
+        pass
+if "RCF_WGRAD_XCD" in os.environ:
+    try:
+        conv_set_wgrad_xcd(int(os.environ["RCF_WGRAD_XCD"]))
+    except Exception:                  # noqa: BLE001
+        pass
 if "RCF_H2S" in os.environ:
     try:
         conv_set_h2s(int(os.environ["RCF_H2S"]))

@@ -357,6 +357,59 @@ def test_conv_wgrad_fp16_pairs_columns(case, report):
     assert e0 < max(4 * r, 5e-7) and e1 < max(4 * r, 5e-7)
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, pad, dil, H, W, region
+    (4, 256, 256, 3, 2, 2, 60, 107, None),                 # 18 tiles x many splits: total % 8 != 0
+    (2, 512, 136, 1, 0, 1, 33, 41, None),                  # 2 x 2 tiles, ragged rows
+    (16, 64, 256, 1, 0, 1, 60, 107, None),                 # ONE column tile of 128: 2 tiles, splits >> tiles
+    (3, 256, 136, 3, 3, 3, 19, 23, (0, 0, 19, 23, 5)),     # frame region
+    (1, 64, 64, 3, 1, 1, 9, 11, None),                     # fewer than 16 workgroups: plain order
+])
+def test_conv_wgrad_xcd_mapping_is_a_permutation(case, report):
+    """rcf_wgrad_item (csrc/rcf_common.h) only re-orders which workgroup computes which (output tile, pixel range): the
+    weight gradient must be BIT-identical with the mapping on and off, fp16 pairs and bf16, overwrite and accumulate"""
+    N, Cin, Cout, k, pad, dil, H, W, reg = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:8])))
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV)
+    wg = cl_weight(torch.randn(Cout, Cin, k, k, generator=g))
+    ax, ag = ops.absmax(x), ops.absmax(dy)
+    xb, dyb = x.bfloat16(), dy.bfloat16()
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.conv_set_wgrad_xcd(mode)
+            d32 = torch.full_like(wg, 3.0)
+            ops.conv2d_wgrad(x, dy, wg, d32, 1, pad, dil, beta=0, region=reg, amax=(ax, ag))
+            a32 = d32.clone()
+            ops.conv2d_wgrad(x, dy, wg, a32, 1, pad, dil, beta=1, region=reg, amax=(ax, ag))
+            d16 = torch.full_like(wg, 3.0)
+            ops.conv2d_wgrad_bf16(xb, dyb, wg, d16, 1, pad, dil, beta=0, region=reg)
+            res[mode] = (d32, a32, d16)
+    finally:
+        ops.conv_set_wgrad_xcd(1)
+    same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
+    ref = torch.nn.grad.conv2d_weight(from_nhwc(x).double(), tuple(wg.shape),
+                                      (from_nhwc(dy) * _region_mask(dy, reg).cpu()).double(), 1, pad, dil)
+    e = relerr(res[1][0], ref)
+    report(f"conv wgrad XCD mapping {case}: identical fp16-pairs / accumulate / bf16 {same}; vs float64 {e:.2e}")
+    assert all(same) and e < 2e-5
+
+
+def _region_mask(dy_nhwc, reg):
+    """[N,C,H,W] 0/1 mask of the contributing output pixels"""
+    N, H, W, C = dy_nhwc.shape
+    m = torch.ones(N, C, H, W, device=dy_nhwc.device)
+    if reg is not None:
+        y0, x0, rh, rw = reg[:4]
+        t = reg[4] if len(reg) > 4 else 0
+        m = torch.zeros(N, C, H, W, device=dy_nhwc.device)
+        m[:, :, y0:y0 + rh, x0:x0 + rw] = 1
+        if t:
+            m[:, :, y0 + t:y0 + rh - t, x0 + t:x0 + rw - t] = 0
+    return m
+
+
 @pytest.mark.parametrize("N,Cin,Cout,k,stride,pad,dil,H,W", [
     (2, 64, 64, 1, 1, 0, 1, 31, 45),           # 64-wide tiles, ragged last row tile
     (2, 4, 64, 7, 2, 3, 1, 60, 107),           # stem
