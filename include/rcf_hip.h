@@ -87,6 +87,11 @@ int rcf_conv_set_wgrad_xcd(int mode);
  * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after
  * a change.  Sums are re-associated, not changed otherwise. */
 int rcf_conv_set_korder(int mode);
+/* Row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back; 1 (default) on tensors of 192 MB
+ * and more eight bands (the conv kernels' XCD bands), forward apply and backward reduction downwards, backward apply upwards:
+ * a kernel starts in what its producer touched last, which the 256 MB Infinity Cache still holds; 2 the same on every tensor of
+ * 8192 rows and more (tests).  Element-wise outputs are bit-identical in every mode. */
+int rcf_bn_set_sweep(int mode);
 /* profiling labels: which kernel the last forward / data-gradient launch took (1: 128 x 256 family, 2: conv_h2p_kernel,
  * 3: conv_h2s_kernel).  A plain global: meaningful right after a launch from the same thread only. */
 int rcf_conv_last_kernel(void);

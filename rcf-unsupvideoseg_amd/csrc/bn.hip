@@ -14,6 +14,42 @@ namespace {
 
 constexpr int RED_THREADS = 256;
 
+// Order in which a streaming kernel walks the rows of a [rows][C] tensor.  The 256 MB Infinity Cache sits on the memory side
+// and keeps what the previous kernel wrote or read last (tools/mall_probe.py: a 105 MB tensor read right after it was written
+// streams at 6.2 TB/s, 3.4 after unrelated traffic); a tensor larger than the cache that is produced front to back and then
+// consumed front to back gets nothing out of it -- its head has been evicted by its tail.  So consumers walk BACKWARDS
+// through what the producer just wrote.  The conv kernels produce eight bands at once (XCD x walks the row tiles
+// [x mtiles8, (x + 1) mtiles8) upwards), hence:
+//   mode 0: position l = row l.
+//   mode 1 / 2: groups of `group` rows, dealt round-robin to eight bands of `band` rows (= mtiles8 * 128, the convs' bands);
+//               inside its band a group's place rises (1) or falls (2) with time.
+struct Sweep {
+    int mode, group;
+    long band;          // rows per band, a multiple of group
+    __device__ __forceinline__ long positions(long rows) const { return mode ? 8 * band : rows; }
+    __device__ __forceinline__ long row(long l) const {
+        if (!mode) return l;
+        const long g = l / group, w = l - g * group;
+        const long b = g & 7, pos = g >> 3, per = band / group;
+        return b * band + (mode == 2 ? per - 1 - pos : pos) * group + w;
+    }
+};
+int g_sweep = 1;      // rcf_bn_set_sweep: 0 plain, 1 the banded orders (forward apply falling, backward reduce falling, backward apply
+                      // rising) on tensors of 192 MB and more, 2 on every tensor of 8192 rows and more (tests)
+// Tensors the cache holds whole are served from it in any order, and the banded walk costs them 3 - 5 % (measured per launch,
+// profiles/r03_bn_sweep.txt: launches under 80 us lose, those over 100 us gain 3 - 15 %): plain order below 192 MB.
+Sweep make_sweep(int mode, long rows, int group, long row_bytes) {
+    Sweep s{0, 1, 0};
+    if (!g_sweep || mode == 0 || group <= 0 || 128 % group || rows < 8 * 1024 ||
+        (g_sweep == 1 && rows * row_bytes < (192L << 20)))
+        return s;
+    const long mtiles = (rows + 127) / 128, mtiles8 = (mtiles + 7) / 8;
+    s.mode = mode;
+    s.group = group;
+    s.band = mtiles8 * 128;
+    return s;
+}
+
 struct ColGeom {
     int cvB;      // channel vectors (V channels each) handled per block (<= 64)
     int RG;       // row groups per block = 256 / cvB
@@ -40,7 +76,8 @@ ColGeom col_geom(long rows, int C, int V = 4) {
 // Generic two-value column reduction.  F(row, c, out a[V], out b[V]) produces the two addends of V consecutive channels.
 template <class F, int V>
 __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows, int C, int cvB, int RG,
-                                                                 long rows_per_chunk, double *__restrict__ partial) {
+                                                                 long rows_per_chunk, double *__restrict__ partial,
+                                                                 Sweep sw = Sweep{0, 1, 0}) {
     __shared__ double red[RED_THREADS * 2 * V];
     const int tid = threadIdx.x;
     const int cv = tid % cvB, rg = tid / cvB;
@@ -52,6 +89,21 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
     for (int e = 0; e < V; ++e) { sa[e] = 0; sb[e] = 0; }
     if (rg < RG && c0 < C) {
         f.init(c0);                      // per-channel constants into registers, once per thread
+        if (sw.mode) {
+            // all blocks advance through the sweep together (block b: groups b, b + chunks, ..), not each through its own chunk
+            const long lend = sw.positions(rows), lstep = (long)gridDim.x * RG;
+            for (long l = (long)blockIdx.x * RG + rg; l < lend; l += lstep) {
+                const long r = sw.row(l);
+                if (r >= rows) continue;
+                float a[V], b[V];
+                f(r, c0, a, b);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    sa[e] += (double)a[e];
+                    sb[e] += (double)b[e];
+                }
+            }
+        } else {
         for (long r = r0 + rg; r < r1; r += RG) {
             float a[V], b[V];
             f(r, c0, a, b);
@@ -60,6 +112,7 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
                 sa[e] += (double)a[e];
                 sb[e] += (double)b[e];
             }
+        }
         }
     }
 #pragma unroll
@@ -337,7 +390,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int relu, const float *__restrict__ scale, long rows_per_image,
                                                        unsigned char *__restrict__ mask,
-                                                       unsigned *__restrict__ amax) {
+                                                       unsigned *__restrict__ amax, Sweep sw) {
     const int CV = C / V;
     const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
     const int cv = blockIdx.y * cvt + cx;
@@ -379,22 +432,30 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
 #pragma unroll
             for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
         };
-        long r = (long)blockIdx.x * rpb + ry;
-        for (; r + rstep < rows; r += 2 * rstep) {      // two rows in flight
-            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0), x1 = ldv<XT, V>(x + (r + rstep) * x_pitch + c0);
-            fvec<V> r0{}, r1{};
+        // l: position in the sweep (ascending in time), sw.row(l): the row it stands for (>= rows: a padding position)
+        long l = (long)blockIdx.x * rpb + ry;
+        const long lend = sw.positions(rows);
+        for (; l + rstep < lend; l += 2 * rstep) {      // two rows in flight
+            const long ra = sw.row(l), rb = sw.row(l + rstep);
+            const bool va = ra < rows, vb = rb < rows;
+            fvec<V> x0{}, x1{}, r0{}, r1{};
+            if (va) x0 = ldv<XT, V>(x + ra * x_pitch + c0);
+            if (vb) x1 = ldv<XT, V>(x + rb * x_pitch + c0);
             if (res) {
-                r0 = ldv<YT, V>(res + r * r_pitch + c0);
-                r1 = ldv<YT, V>(res + (r + rstep) * r_pitch + c0);
+                if (va) r0 = ldv<YT, V>(res + ra * r_pitch + c0);
+                if (vb) r1 = ldv<YT, V>(res + rb * r_pitch + c0);
             }
-            finish(r, x0, r0);
-            finish(r + rstep, x1, r1);
+            if (va) finish(ra, x0, r0);
+            if (vb) finish(rb, x1, r1);
         }
-        if (r < rows) {
-            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0);
-            fvec<V> r0{};
-            if (res) r0 = ldv<YT, V>(res + r * r_pitch + c0);
-            finish(r, x0, r0);
+        if (l < lend) {
+            const long ra = sw.row(l);
+            if (ra < rows) {
+                const fvec<V> x0 = ldv<XT, V>(x + ra * x_pitch + c0);
+                fvec<V> r0{};
+                if (res) r0 = ldv<YT, V>(res + ra * r_pitch + c0);
+                finish(ra, x0, r0);
+            }
         }
     }
     if (amax) block_amax(mx, amax);
@@ -408,7 +469,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
     float *__restrict__ dgamma, float *__restrict__ dbeta, const unsigned char *__restrict__ mask,
-    unsigned *__restrict__ amax) {
+    unsigned *__restrict__ amax, Sweep sw) {
     const int CV = C / V;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         // parameter gradients come from THIS rank's sums: the data-parallel gradient all-reduce adds the ranks
@@ -471,14 +532,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
                 stv<YT, V>(dr, g);
             }
         };
-        long r = (long)blockIdx.x * rpb + ry;
-        for (; r + rstep < rows; r += 2 * rstep) {      // two rows in flight
-            const fvec<V> g0 = ldv<YT, V>(dy + r * dy_pitch + c0), g1 = ldv<YT, V>(dy + (r + rstep) * dy_pitch + c0);
-            const fvec<V> x0 = ldv<XT, V>(x + r * x_pitch + c0), x1 = ldv<XT, V>(x + (r + rstep) * x_pitch + c0);
-            finish(r, g0, x0);
-            finish(r + rstep, g1, x1);
+        long l = (long)blockIdx.x * rpb + ry;           // position in the sweep (see Sweep)
+        const long lend = sw.positions(rows);
+        for (; l + rstep < lend; l += 2 * rstep) {      // two rows in flight
+            const long ra = sw.row(l), rb = sw.row(l + rstep);
+            const bool va = ra < rows, vb = rb < rows;
+            fvec<V> g0{}, g1{}, x0{}, x1{};
+            if (va) g0 = ldv<YT, V>(dy + ra * dy_pitch + c0);
+            if (vb) g1 = ldv<YT, V>(dy + rb * dy_pitch + c0);
+            if (va) x0 = ldv<XT, V>(x + ra * x_pitch + c0);
+            if (vb) x1 = ldv<XT, V>(x + rb * x_pitch + c0);
+            if (va) finish(ra, g0, x0);
+            if (vb) finish(rb, g1, x1);
         }
-        if (r < rows) finish(r, ldv<YT, V>(dy + r * dy_pitch + c0), ldv<XT, V>(x + r * x_pitch + c0));
+        if (l < lend) {
+            const long ra = sw.row(l);
+            if (ra < rows) finish(ra, ldv<YT, V>(dy + ra * dy_pitch + c0), ldv<XT, V>(x + ra * x_pitch + c0));
+        }
     }
     if (amax) block_amax(mx, amax);
 }
@@ -546,6 +616,16 @@ int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, 
     }
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32)), dim3(512), 0, st, partial, chunks, C, sums, fa);
     RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+/* Row order of the streaming batch-norm kernels (struct Sweep above): 0 front to back; 1 (default; 2 = regardless of the tensor's
+ * size, for tests) eight bands on tensors of 192 MB and more, the forward apply and
+ * the backward reduction walking them downwards, the backward apply upwards -- each starts where its producer stopped, i.e.
+ * in what the 256 MB Infinity Cache still holds.  Element-wise results are identical; the backward reduction groups its fp64
+ * partial sums differently (same precision). */
+extern "C" int rcf_bn_set_sweep(int mode) {
+    g_sweep = mode < 0 || mode > 2 ? 1 : mode;
     return 0;
 }
 
@@ -645,14 +725,14 @@ extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 8>), g.grid, dim3(256), 0,
                            rcf_stream(stream), (const bf16_t *)x, x_pitch, (const bf16_t *)residual, r_pitch, (bf16_t *)y,
                            y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, chan_scale,
-                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out);
+                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out, make_sweep(2, rows, g.rpb, (long)C * 2));
     } else {
         const EwGeom g = ew_geom(rows, C / 4);
 #define RCF_CALL(XT, YT)                                                                                                 \
     hipLaunchKernelGGL((bn_apply_kernel<XT, YT, 4>), g.grid, dim3(256), 0, rcf_stream(stream),                          \
                        (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, g.cvt, g.rpb,   \
                        mean, invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,  \
-                       amax_out)
+                       amax_out, make_sweep(2, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
@@ -684,13 +764,13 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
         BwdOp<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)y, mean, invstd, chan_scale,
                                     dy_pitch, x_pitch, y_pitch, relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};
         hipLaunchKernelGGL((colreduce2_kernel<BwdOp<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0,
-                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace);
+                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 2));
     } else {
 #define RCF_CALL(XT, YT)                                                                                                    \
     BwdOp<XT, YT, 4> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
                         relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};                               \
     hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,  \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace)
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
@@ -727,7 +807,7 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
                            rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (const bf16_t *)x, x_pitch, (const bf16_t *)y,
                            y_pitch, (bf16_t *)dx, dx_pitch, (bf16_t *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd,
                            gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
-                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out);
+                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 2));
     } else {
         const EwGeom g = ew_geom(rows, C / 4);
 #define RCF_CALL(XT, YT)                                                                                                     \
@@ -735,7 +815,7 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
                        (const YT *)dy, dy_pitch, (const XT *)x, x_pitch, (const YT *)y, y_pitch, (XT *)dx, dx_pitch,         \
                        (YT *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, chan_scale,       \
                        rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma,     \
-                       dbeta, relu_mask, amax_out)
+                       dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }

@@ -282,6 +282,16 @@ def conv_set_korder(mode=1):
     weights_changed()
 
 
+def bn_set_sweep(mode=1):
+    """row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back, 1 Infinity-Cache aware"""
+    _lib.load().rcf_bn_set_sweep(int(mode))
+
+
+if "RCF_BN_SWEEP" in os.environ:
+    try:
+        bn_set_sweep(int(os.environ["RCF_BN_SWEEP"]))
+    except Exception:                  # noqa: BLE001
+        pass
 if "RCF_KORDER" in os.environ:
     try:
         conv_set_korder(int(os.environ["RCF_KORDER"]))

@@ -527,6 +527,52 @@ def test_batchnorm_train(C, relu, res, drop, report):
     assert max(e_y, e_rm, e_rv, e_dx, e_dg, e_db, e_dr) < 2e-5
 
 
+@pytest.mark.parametrize("C,rows_shape,res,bf16", [(64, (3, 60, 107), False, False), (256, (2, 60, 107), True, False),
+                                                  (1024, (1, 83, 107), True, False), (48, (2, 60, 107), False, False),
+                                                  (512, (2, 60, 107), True, True)])
+def test_batchnorm_cache_aware_row_order(C, rows_shape, res, bf16, report):
+    """csrc/bn.hip struct Sweep: the banded row orders of the streaming batch-norm kernels visit every row exactly once -- the
+    element-wise outputs (y, ReLU mask, range, dx, dres) are BIT-identical to the front-to-back walk, the backward sums
+    agree to fp64 rounding; row counts that do not fill the eight bands, a channel count whose row group does not
+    divide the band (C = 48: falls back to the plain order), fp32 and bf16 storage"""
+    N, H, W = rows_shape
+    g = torch.Generator().manual_seed(C + N)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.7).to(DEV).to(dt)
+    r = torch.randn(N, H, W, C, generator=g).to(DEV).to(dt) if res else None
+    dy = torch.randn(N, H, W, C, generator=g).to(DEV).to(dt)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    count = N * H * W
+    out = {}
+    try:
+        for mode in (0, 2):                      # 2: the banded order whatever the tensor's size (1 = from 192 MB up)
+            ops.bn_set_sweep(mode)
+            rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            mean, invstd = ops.bn_finalize(ops.bn_stats(x), count, 1e-5, 0.1, rmean, rvar)
+            rmask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=DEV)
+            am = ops.new_amax(DEV) if not bf16 else None
+            y = ops.bn_apply(x, mean, invstd, gamma, beta, True, residual=r, relu_mask=rmask, amax_out=am)
+            s2 = ops.bn_bwd_reduce(dy, x, None, mean, invstd, True, relu_mask=rmask)
+            dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dres = torch.full_like(x, 0.25) if res else None
+            gam = ops.new_amax(DEV) if not bf16 else None
+            dx = ops.bn_bwd_apply(dy, x, None, mean, invstd, gamma, True, s2, count, dgam, dbet, dres=dres, res_beta=1 if res else 0,
+                                  relu_mask=rmask, amax_out=gam)
+            out[mode] = (y, rmask, am, s2, dx, dres, gam, dgam, dbet)
+    finally:
+        ops.bn_set_sweep(1)
+    a, b = out[0], out[2]
+    same = [torch.equal(a[i], b[i]) for i in (0, 1, 4)] + [a[2] is None or torch.equal(a[2], b[2]), not res or torch.equal(a[5], b[5])]
+    e_s = float((a[3] - b[3]).abs().max() / a[3].abs().max())
+    # dx: given the SAME sums it is bit-identical; with re-grouped fp64 sums it may move by an ulp
+    report(f"bn row order C={C} rows={count} res={res} bf16={bf16}: y / mask / dx / range / dres identical {same}; sums rel diff {e_s:.1e}")
+    assert same[0] and same[1] and same[3] and e_s < 1e-12
+    tol = 2e-2 if bf16 else 1e-6
+    assert float((a[4].float() - b[4].float()).abs().max() / a[4].float().abs().max()) < tol
+    if res:
+        assert torch.equal(a[5], b[5])
+
+
 def test_maxpool(report):
     g = torch.Generator().manual_seed(3)
     for (N, C, H, W) in [(2, 64, 15, 22), (1, 8, 240, 427), (2, 4, 8, 8)]:

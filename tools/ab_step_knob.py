@@ -1,5 +1,5 @@
 """Same-process, interleaved A/B of the training step (fp32 and bf16) over one library knob.
-usage: python tools/ab_step_knob.py <knob> [rounds=3] [steps=6]     knob: wgrad_xcd | korder"""
+usage: python tools/ab_step_knob.py <knob> [rounds=3] [steps=6]     knob: wgrad_xcd | korder | bn_sweep"""
 import os, sys, time, types
 import numpy as np
 import torch
@@ -8,7 +8,8 @@ import rcf_amd
 from rcf_amd import config, synth, ops
 
 KNOBS = {"wgrad_xcd": (ops.conv_set_wgrad_xcd, {"grid order": 0, "XCD-aware": 1}, 1),
-         "korder": (ops.conv_set_korder, {"tap outer": 0, "chunk outer": 1}, 1)}
+         "korder": (ops.conv_set_korder, {"tap outer": 0, "chunk outer": 1}, 1),
+         "bn_sweep": (ops.bn_set_sweep, {"front to back": 0, "cache aware >= 192 MB": 1, "cache aware, all": 2}, 1)}
 knob = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
@@ -39,6 +40,6 @@ for prec in ("fp32", "bf16"):
             res[name].append((time.perf_counter() - t0) / steps * 1e3)
     setter(default)
     for name, v in res.items():
-        print(f"{prec} step, {knob} = {name:12s}: " + " ".join(f"{x:7.2f}" for x in v) + f"   median {np.median(v):7.2f} ms/step", flush=True)
+        print(f"{prec} step, {knob} = {name:22s}: " + " ".join(f"{x:7.2f}" for x in v) + f"   median {np.median(v):7.2f} ms/step", flush=True)
     del tr, model
     torch.cuda.empty_cache()
