@@ -82,6 +82,10 @@ int rcf_conv_set_h2s(int mode);
 /* A/B switch of the weight-gradient kernels' workgroup -> (output tile, pixel range) mapping: 1 (default) the workgroups that
  * run together on one XCD read the same pixel range, 0 plain grid order.  Results are bit-identical either way. */
 int rcf_conv_set_wgrad_xcd(int mode);
+/* A/B switch of the forward / data-gradient grids' XCD mapping: 1 (default) convs whose weight operand exceeds the XCDs' L2
+ * many times over (the data gradient of the 2048- / 4096-channel decode-head convs) give every XCD its own COLUMN tiles of
+ * all row tiles instead of its own band of row tiles; 0 always row bands.  Bit-identical results. */
+int rcf_conv_set_colmap(int mode);
 /* A/B switch of the K order of the forward / data-gradient convs: 1 (default) channel chunks of 64 outer, taps inner on the
  * 3x3 layers with more than 64 channels per tap, 0 tap outer (the weight's memory order).  The derived weight operands
  * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after

@@ -16,6 +16,7 @@
 
 extern int rcf_g_wgrad_xcd;   // igemm_conv.hip: rcf_conv_set_wgrad_xcd
 extern int rcf_g_korder;      // igemm_conv.hip: rcf_conv_set_korder (rcf_common.h rcf_kchunk)
+extern int rcf_g_colmap;      // igemm_conv.hip: rcf_conv_set_colmap (rcf_common.h rcf_conv_tile)
 
 namespace {
 
@@ -48,6 +49,7 @@ struct ConvParams {
     int mtiles, ntiles;
     int mtiles8;                  // ceil(mtiles / 8): XCD x (block id % 8) walks the contiguous row tiles [x mtiles8, (x + 1) mtiles8)
     unsigned s_magic;
+    int colmap;                   // rcf_common.h rcf_conv_tile: 1 = an XCD owns column tiles, not a band of row tiles
     int kch, rsch;                // K order (rcf_common.h rcf_kchunk): channel chunk width (Cs = natural order), taps * kch
     unsigned kch_magic, rsch_magic;
     int b_bytes;
@@ -131,13 +133,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     constexpr int NSTAGE = DMA ? NST : 2;
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
-    const int bid = blockIdx.x;
-    const int grp = bid / (8 * p.ntiles);
-    const int rem = bid - grp * 8 * p.ntiles;
-    const int tile_n = rem >> 3;
     // XCD aware (as igemm_conv_x3_kernel): ids b, b + 8, .. walk the column tiles of one row tile, each XCD its own contiguous
-    // range of row tiles
-    const int tile_m = (rem & 7) * p.mtiles8 + grp;
+    // range of row tiles; p.colmap: each XCD its own column tiles of every row tile (rcf_common.h rcf_conv_tile)
+    int tile_m, tile_n;
+    rcf_conv_tile((int)blockIdx.x, p.mtiles8, p.ntiles, p.colmap, tile_m, tile_n);
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -1116,6 +1115,7 @@ void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     p.mtiles = rcf_cdiv(p.M, BM);
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
+    p.colmap = p.Ncol % BN == 0 && rcf_colmap_pays(rcf_g_colmap, (long)p.M * p.Cs * 2, (long)p.K * p.Ncol * 2, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
     if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);

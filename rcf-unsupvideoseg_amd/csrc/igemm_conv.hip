@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 int rcf_g_wgrad_xcd = 1;      // rcf_conv_set_wgrad_xcd; read by igemm_bf16.hip too
+int rcf_g_colmap = 1;         // rcf_conv_set_colmap: rcf_common.h rcf_conv_tile / rcf_colmap_pays
 int rcf_g_korder = 1;         // rcf_conv_set_korder: K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk)
 
 namespace {
@@ -56,6 +57,7 @@ struct IgemmParams {
     // chunk), taps * kch, and their magics
     int kch, rsch;
     unsigned kch_magic, rsch_magic;
+    int colmap;                   // rcf_common.h rcf_conv_tile: 1 = an XCD owns column tiles, not a band of row tiles
     int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
     int dbg;                      // timing experiments only (tools/bench_conv.py): 1 = no global loads after the first K-step
     // split-bf16 kernels: the GEMM rows are the pixels of the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of every image
@@ -547,14 +549,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-    const int bid = blockIdx.x;
-    const int grp = bid / (8 * p.ntiles);
-    const int rem = bid - grp * 8 * p.ntiles;
-    const int tile_n = rem >> 3;
     // XCD aware: block id % 8 is the XCD; its blocks b, b + 8, .. walk the column tiles of one row tile, then the next row tile
     // of the XCD's own contiguous range (the rows a dilated tap reaches belong to neighbouring row tiles: same L2;
-    // HBM traffic -2 ... -5 % in fp32, -14 ... -18 % in bf16 against row tiles interleaved over the XCDs, same time)
-    const int tile_m = (rem & 7) * p.mtiles8 + grp;
+    // HBM traffic -2 ... -5 % in fp32, -14 ... -18 % in bf16 against row tiles interleaved over the XCDs, same time) -- or,
+    // p.colmap, the XCD's own column tiles of every row tile (rcf_common.h rcf_conv_tile)
+    int tile_m, tile_n;
+    rcf_conv_tile((int)blockIdx.x, p.mtiles8, p.ntiles, p.colmap, tile_m, tile_n);
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (p.batch1 > 0) {                                       // one product of a batch per grid row
@@ -1982,6 +1982,8 @@ void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches)
     p.mtiles = rcf_cdiv(p.M, BM);
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
+    p.colmap = batches == 1 && p.Ncol % BN == 0 &&
+               rcf_colmap_pays(rcf_g_colmap, (long)p.M * p.Cs * 4, (long)p.K * p.Ncol * 4, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
     if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
@@ -2471,6 +2473,13 @@ extern "C" int rcf_conv_set_h2s(int mode) {
  * the order the kernels walk: rebuild them after a change (rcf_amd.ops.weights_changed()). */
 extern "C" int rcf_conv_set_korder(int mode) {
     rcf_g_korder = mode ? 1 : 0;
+    return 0;
+}
+
+/* A/B switch of the forward / data-gradient grids' XCD mapping for convs whose weights exceed L2 many times over
+ * (rcf_common.h rcf_conv_tile): 1 (default) the byte model decides, 0 always row bands.  Tiles are independent: bit-identical. */
+extern "C" int rcf_conv_set_colmap(int mode) {
+    rcf_g_colmap = mode ? 1 : 0;
     return 0;
 }
 

@@ -150,6 +150,32 @@ __host__ __device__ inline int rcf_kperm(int kp, int RS, int Cs, int kch) {
     return tap * Cs + q * kch + (rem - tap * kch);
 }
 
+// Forward / data-gradient grids: which XCD computes which (row tile, column tile).  Default (colmap 0): XCD x walks the row
+// tiles of ITS band [x mtiles8, (x + 1) mtiles8), all column tiles of a row tile one after the other -- the activation tile
+// stays in that XCD's L2 across the column tiles, the WEIGHTS stream through every XCD once per row tile.  That is right
+// while the weights fit L2 next to the activations (4 MB), and wrong for the data gradient of a conv with thousands of input
+// channels: 16 column tiles of 2304 x 256 weights = 19 - 38 MB per row tile, 400 - 800 row tiles -> 5 - 9 x the launch's
+// bytes through the fabric (profiles/r03_pmc_traffic_by_layer.txt).  colmap 1: XCD x owns the column tiles
+// [x ntiles/8, (x + 1) ntiles/8) of EVERY row tile -- its share of the weights stays in its L2, the (small) activation
+// operand is fetched by all eight XCDs.  rcf_colmap_pays: the byte model that picks it.
+__device__ __forceinline__ void rcf_conv_tile(int bid, int mtiles8, int ntiles, int colmap, int &tile_m, int &tile_n) {
+    if (colmap) {
+        const int x = bid & 7, k = bid >> 3, nt8 = ntiles >> 3;
+        tile_m = k / nt8;
+        tile_n = x * nt8 + (k - tile_m * nt8);
+    } else {
+        const int grp = bid / (8 * ntiles), rem = bid - grp * 8 * ntiles;
+        tile_n = rem >> 3;
+        tile_m = (rem & 7) * mtiles8 + grp;
+    }
+}
+// a_bytes / b_bytes: the activation operand (rows x channels per tap) and the whole weight operand as the kernel reads them
+static inline int rcf_colmap_pays(int mode, long a_bytes, long b_bytes, int mtiles, int ntiles) {
+    if (!mode || ntiles < 8 || ntiles % 8) return 0;
+    if (b_bytes < (8L << 20)) return 0;                 // the weights (nearly) fit L2: row bands already re-use them
+    return 8 * a_bytes < b_bytes * (mtiles / 4);        // a quarter of the row-band form's weight re-reads still hit L2
+}
+
 // Weight-gradient grids are (tiles, 1, splits): a split is a range of pixels of dy and x, every tile of a split reads that
 // range.  Workgroups go round-robin over the 8 XCDs in dispatch order (L = x + tiles * z -> XCD L % 8), so with the plain
 // mapping every XCD's L2 fetches every split's pixels.  mode 1: XCD x takes a CONTIGUOUS run of the (split, tile) sequence

@@ -282,6 +282,18 @@ def conv_set_korder(mode=1):
     weights_changed()
 
 
+def conv_set_colmap(mode=1):
+    """A/B switch of the forward / data-gradient grids' XCD mapping (csrc/rcf_common.h rcf_conv_tile)"""
+    _lib.load().rcf_conv_set_colmap(int(mode))
+
+
+if "RCF_COLMAP" in os.environ:
+    try:
+        conv_set_colmap(int(os.environ["RCF_COLMAP"]))
+    except Exception:                  # noqa: BLE001
+        pass
+
+
 def bn_set_sweep(mode=1):
     """row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back, 1 Infinity-Cache aware"""
     _lib.load().rcf_bn_set_sweep(int(mode))

@@ -357,6 +357,38 @@ def test_conv_wgrad_fp16_pairs_columns(case, report):
     assert e0 < max(4 * r, 5e-7) and e1 < max(4 * r, 5e-7)
 
 
+def test_conv_column_tile_xcd_mapping_is_a_permutation(report):
+    """csrc/rcf_common.h rcf_conv_tile: convs whose weight operand exceeds L2 many times over (the data gradient of a 3x3 conv
+    with 2048 input channels: 19 MB of fp16 pairs, 16 column tiles) give every XCD its own column tiles of all row tiles
+    instead of a band of row tiles -- only which workgroup computes which tile changes: bit-identical, fp32 pairs and bf16,
+    data gradient (the byte model takes the new mapping) and forward of the mirrored shape (2048 output channels)"""
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, H, W = 1, 2048, 256, 47, 107            # 5 029 rows: a ragged last row tile
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV)
+    w = cl_weight(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02)
+    wT = cl_weight(torch.randn(Cin, Cout, 3, 3, generator=g) * 0.02)       # a 256 -> 2048 conv: wide FORWARD
+    ag, aw, ax, awT = ops.absmax(dy), ops.absmax(ops.weight_rsck(w)), ops.absmax(x), ops.absmax(ops.weight_rsck(wT))
+    dyb = dy.bfloat16()
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.conv_set_colmap(mode)
+            dx = ops.conv2d_dgrad(dy, w, x.shape, 1, 3, 3, amax=(ag, aw), w_pairs_t=ops.weight_pairs_t(w, aw))
+            acc = dx.clone()
+            ops.conv2d_dgrad(dy, w, x.shape, 1, 3, 3, out=acc, beta=1, amax=(ag, aw), w_pairs_t=ops.weight_pairs_t(w, aw))
+            y = ops.conv2d_fwd(dy, wT, None, 1, 3, 3, amax=(ag, awT), w_pairs=ops.weight_pairs(wT, awT))
+            dxb = ops.conv2d_dgrad_bf16(dyb, w, x.shape, 1, 3, 3, w_t_bf16=ops.weight_bf16(w, transpose=True))
+            res[mode] = (dx, acc, y, dxb)
+    finally:
+        ops.conv_set_colmap(1)
+    same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
+    ref = F.conv_transpose2d(from_nhwc(dy).double(), w.cpu().double(), None, 1, 3, 0, 1, 3)
+    e = relerr(from_nhwc(res[1][0]), ref)
+    report(f"conv column-tile XCD mapping: identical dgrad / accumulate / forward / bf16 dgrad {same}; dgrad vs float64 {e:.2e}")
+    assert all(same) and e < 2e-5
+
+
 @pytest.mark.parametrize("case", [
     # N, Cin, Cout, k, pad, dil, H, W, region
     (4, 256, 256, 3, 2, 2, 60, 107, None),                 # 18 tiles x many splits: total % 8 != 0

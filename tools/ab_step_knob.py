@@ -1,5 +1,5 @@
 """Same-process, interleaved A/B of the training step (fp32 and bf16) over one library knob.
-usage: python tools/ab_step_knob.py <knob> [rounds=3] [steps=6]     knob: wgrad_xcd | korder | bn_sweep"""
+usage: python tools/ab_step_knob.py <knob> [rounds=3] [steps=6]     knob: wgrad_xcd | korder | colmap | bn_sweep"""
 import os, sys, time, types
 import numpy as np
 import torch
@@ -9,6 +9,7 @@ from rcf_amd import config, synth, ops
 
 KNOBS = {"wgrad_xcd": (ops.conv_set_wgrad_xcd, {"grid order": 0, "XCD-aware": 1}, 1),
          "korder": (ops.conv_set_korder, {"tap outer": 0, "chunk outer": 1}, 1),
+         "colmap": (ops.conv_set_colmap, {"row bands": 0, "byte model": 1}, 1),
          "bn_sweep": (ops.bn_set_sweep, {"front to back": 0, "cache aware >= 192 MB": 1, "cache aware, all": 2}, 1)}
 knob = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3

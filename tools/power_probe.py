@@ -52,6 +52,19 @@ def main():
                 t = timeit(lambda: ops.conv2d_fwd(x, w, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp))
                 out.append(f"{'persistent' if mode else '128x256   '} {t * 1e3:6.3f} ms {flops / t / 1e12:6.1f} TF/s")
             ops.conv_set_h2p(-1)
+            # the weight gradient of the same layer (the step's largest kernel family) and its bf16 twin
+            dy = gen(N, H, W, Cout)
+            ag = ops.absmax(dy)
+            dw = torch.zeros_like(w)
+            t = timeit(lambda: ops.conv2d_wgrad(x, dy, w, dw, 1, pad, dil, beta=0, amax=(ax, ag)))
+            out.append(f"weight gradient {t * 1e3:6.3f} ms {flops / t / 1e12:6.1f} TF/s")
+            xb, dyb = x.bfloat16(), dy.bfloat16()
+            t = timeit(lambda: ops.conv2d_wgrad_bf16(xb, dyb, w, dw, 1, pad, dil, beta=0))
+            out.append(f"bf16 weight gradient {t * 1e3:6.3f} ms {flops / t / 1e12:6.1f} TF/s")
+            wb = ops.weight_bf16(w)
+            yb = torch.empty(N, H, W, Cout, device=dev, dtype=torch.bfloat16)
+            t = timeit(lambda: ops.conv2d_fwd_bf16(xb, w, wb, None, 1, pad, dil, out=yb))
+            out.append(f"bf16 forward {t * 1e3:6.3f} ms {flops / t / 1e12:6.1f} TF/s")
             print(f"{name:36s} | " + " | ".join(out), flush=True)
 
 
