@@ -315,6 +315,9 @@ int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, fl
  * either output may be NULL.  Splits a gradient into its interior / border-band parts (see rcf_conv_region). */
 int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0, int x0,
                        int h, int w, void *stream);
+/* A/B switch of the exact-2x forms of the bilinear resize kernels (a thread makes the 2 x 2 outputs of one source pixel from
+ * 9 loads instead of 16; bit-identical): 1 default, 0 always the general kernels */
+int rcf_resize_set_2x(int mode);
 /* Mixed-precision forms (dt = RCF_F32 / RCF_BF16 storage of every tensor argument; `frame` 0 = the whole tensor) */
 int rcf_maxpool3x3s2_fwd_mp(const void *x, void *y, int dt, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo,
                             void *stream);

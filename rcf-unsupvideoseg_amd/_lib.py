@@ -88,6 +88,7 @@ PROTOS = {
     "rcf_conv_set_korder": (c_int, [c_int]),
     "rcf_conv_set_colmap": (c_int, [c_int]),
     "rcf_bn_set_sweep": (c_int, [c_int]),
+    "rcf_resize_set_2x": (c_int, [c_int]),
     "rcf_conv_last_kernel": (c_int, []),
     "rcf_conv_pairs2_useful": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "rcf_conv_weights_prepare_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),

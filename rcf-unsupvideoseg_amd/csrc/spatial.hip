@@ -6,6 +6,7 @@
 #include "rcf_common.h"
 
 namespace {
+int g_resize2x = 1;      // rcf_resize_set_2x: exact-2x bilinear up-sampling on resize2x_fwd_kernel (bit-identical; A/B switch)
 
 inline int ew_blocks(long total) {
     long b = (total + 255) / 256;
@@ -290,6 +291,70 @@ __global__ void __launch_bounds__(256) resize_rows_fwd_kernel(const T *__restric
     stv<T, V>(y + (((long)n * Ho + yo) * Wo + xo) * y_pitch + cv * V, o);
 }
 
+// Exact 2x up-sampling without align_corners (the decode heads' 60x107 -> 120x214: every bilinear resize of the step): a
+// thread produces the 2 x 2 outputs of ONE source pixel from the 3 x 3 source pixels around it -- 9 loads for 4 outputs where
+// resize_rows_fwd_kernel issues 16 (its 230 us per 420 MB of output were L2 read bandwidth: 7.3 TB/s of 16-byte gathers).
+// Same taps, same weights (src_index itself), same expression tree: hy (hx a + lx b) + ly (hx c + lx d) -- the horizontal blends
+// of the two source rows first, as there -- so the outputs are bit-identical.
+template <typename T, int V>
+__global__ void __launch_bounds__(256) resize2x_fwd_kernel(const T *__restrict__ x, int x_pitch, T *__restrict__ y,
+                                                           int y_pitch, int Hi, int Wi, int C) {
+    const int CV = C / V;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int j = idx / CV, cv = idx - j * CV;
+    if (j >= Wi) return;
+    const int n = blockIdx.y / Hi, i = blockIdx.y - n * Hi;                 // block-uniform
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int rr[3] = {max(i - 1, 0), i, min(i + 1, Hi - 1)}, cc[3] = {max(j - 1, 0), j, min(j + 1, Wi - 1)};
+    const T *base = x + (long)n * Hi * Wi * x_pitch + cv * V;
+    fvec<V> v[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[r][c] = ldv<T, V>(base + ((long)rr[r] * Wi + cc[c]) * x_pitch);
+    // output column 2j + b takes source columns (x0, x1) = slots (kx, kx + 1) of cc: slot 0 unless the left border clamps
+    fvec<V> h[3][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int x0, x1;
+        float lx;
+        src_index(2 * j + b, 0.5f, 0, Wi, x0, x1, lx);
+        const float hx = 1.f - lx;
+        const bool first = b == 0 && j > 0;                                   // (j-1, j); otherwise (j, j+1) -- at j == 0, b == 0: (0, 1)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = first ? v[r][0].q[q][e] : v[r][1].q[q][e];
+                    const float bb = first ? v[r][1].q[q][e] : v[r][2].q[q][e];
+                    h[r][b].q[q][e] = hx * a + lx * bb;
+                }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        int y0, y1;
+        float ly;
+        src_index(2 * i + a, 0.5f, 0, Hi, y0, y1, ly);
+        const float hy = 1.f - ly;
+        const bool first = a == 0 && i > 0;                                   // rows (i-1, i); otherwise (i, i+1) -- at i == 0, a == 0: (0, 1)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            fvec<V> o;
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = first ? h[0][b].q[q][e] : h[1][b].q[q][e];
+                    const float u = first ? h[1][b].q[q][e] : h[2][b].q[q][e];
+                    o.q[q][e] = hy * t + ly * u;
+                }
+            stv<T, V>(y + (((long)n * Ho + 2 * i + a) * Wo + 2 * j + b) * y_pitch + cv * V, o);
+        }
+    }
+}
+
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restrict__ dy, int dy_pitch, T *__restrict__ dx,
                                                               int dx_pitch, int beta, int Hi, int Wi, int Ho, int Wo, int C,
@@ -513,12 +578,33 @@ extern "C" int rcf_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, 
     return rcf_maxpool3x3s2_bwd_mp(dy, argmax, dx, RCF_F32, N, H, W, C, Ho, Wo, stream);
 }
 
+/* A/B switch of the exact-2x forms of the bilinear resize (bit-identical results): 1 default, 0 always the general kernels */
+extern "C" int rcf_resize_set_2x(int mode) {
+    g_resize2x = mode ? 1 : 0;
+    return 0;
+}
+
 /* frame == 0: the whole tensor */
 extern "C" int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void *y, int y_pitch, int dt, int N, int Hi,
                                                int Wi, int Ho, int Wo, int C, int align_corners, int frame, void *stream) {
     if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
     if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
     const long px = frame > 0 ? (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame)) : (long)N * Ho * Wo;
+    if (g_resize2x && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 && (long)N * Hi <= 65535 &&
+        (long)Wi * (C / 4) < (1L << 30)) {
+        if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {
+            hipLaunchKernelGGL((resize2x_fwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wi * (C / 8), 256), N * Hi), dim3(256), 0,
+                               rcf_stream(stream), (const bf16_t *)x, x_pitch, (bf16_t *)y, y_pitch, Hi, Wi, C);
+        } else {
+#define RCF_CALL(T)                                                                                                       \
+    hipLaunchKernelGGL((resize2x_fwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wi * (C / 4), 256), N * Hi), dim3(256), 0,         \
+                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, C)
+            RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+        }
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     if ((long)N * Ho <= 65535 && (long)Wo * (C / 4) < (1L << 30)) {
         const float sh = host_scale(Hi, Ho, align_corners), sw = host_scale(Wi, Wo, align_corners);
         if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {

@@ -294,6 +294,11 @@ if "RCF_COLMAP" in os.environ:
         pass
 
 
+def resize_set_2x(mode=1):
+    """A/B switch of the exact-2x bilinear resize kernels (csrc/spatial.hip resize2x_*): bit-identical to the general ones"""
+    _lib.load().rcf_resize_set_2x(int(mode))
+
+
 def bn_set_sweep(mode=1):
     """row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back, 1 Infinity-Cache aware"""
     _lib.load().rcf_bn_set_sweep(int(mode))

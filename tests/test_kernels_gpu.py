@@ -641,6 +641,30 @@ def test_resize_nhwc(Hi, Wi, Ho, Wo, align, report):
     assert max(e_y, e_dx, e_p) < 2e-5
 
 
+@pytest.mark.parametrize("N,Hi,Wi,C,bf16", [(2, 60, 107, 64, False), (1, 2, 2, 8, False), (3, 7, 33, 24, False), (2, 15, 27, 64, True)])
+def test_resize_exact_2x_kernels_are_bit_identical(N, Hi, Wi, C, bf16, report):
+    """csrc/spatial.hip resize2x_*: the exact-2x forms of the bilinear resize (a thread makes the 2 x 2 outputs of one source
+    pixel from 9 loads instead of 16) against the general kernels they replace: same taps, weights and expression tree, so
+    the outputs must be BIT-identical, borders included (2 x 2 sources: every output clamps somewhere), fp32 and bf16"""
+    g = torch.Generator().manual_seed(N * Hi + Wi)
+    x = torch.randn(N, Hi, Wi, C, generator=g).to(DEV)
+    dy = torch.randn(N, 2 * Hi, 2 * Wi, C, generator=g).to(DEV)
+    if bf16:
+        x, dy = x.bfloat16(), dy.bfloat16()
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.resize_set_2x(mode)
+            res[mode] = (ops.resize_nhwc_fwd(x, (2 * Hi, 2 * Wi), False), ops.resize_nhwc_bwd(dy, (Hi, Wi), False))
+    finally:
+        ops.resize_set_2x(1)
+    same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    e = float((res[1][0].double() - ref).abs().max() / ref.abs().max())
+    report(f"resize exact 2x {(N, Hi, Wi, C)} bf16={bf16}: forward / backward identical to the general kernels {same}; forward vs float64 {e:.1e}")
+    assert all(same) and e < (1e-2 if bf16 else 1e-6)
+
+
 def test_layout_copy_colsum(report):
     g = torch.Generator().manual_seed(8)
     x = torch.randn(2, 3, 10, 13, generator=g)
