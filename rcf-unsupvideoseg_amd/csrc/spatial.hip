@@ -355,6 +355,74 @@ __global__ void __launch_bounds__(256) resize2x_fwd_kernel(const T *__restrict__
     }
 }
 
+// Backward of the exact 2x up-sampling: a thread gathers for a 2 x 2 block of input pixels from the 6 x 6 output pixels that
+// can reach it, one output row at a time -- 36 loads for 4 inputs where resize_rows_bwd_kernel issues 16 per input.  Every
+// input accumulates the same terms g * (wy * wx) (tap_weight itself, zero weights skipped) in the same order (output rows
+// upwards, columns upwards): bit-identical.
+template <typename T, int V>
+__global__ void __launch_bounds__(256) resize2x_bwd_kernel(const T *__restrict__ dy, int dy_pitch, T *__restrict__ dx,
+                                                           int dx_pitch, int beta, int Hi, int Wi, int C) {
+    const int CV = C / V, Wh = (Wi + 1) >> 1, Hh = (Hi + 1) >> 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int j2 = idx / CV, cv = idx - j2 * CV;
+    if (j2 >= Wh) return;
+    const int n = blockIdx.y / Hh, i2 = blockIdx.y - n * Hh;                // block-uniform
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int i0 = 2 * i2, j0 = 2 * j2;
+    fvec<V> acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) acc[a][b].q[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xo0 = 2 * j0 - 1;                                             // first candidate column; candidates xo0 .. xo0 + 5
+    float wx[2][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int xo = xo0 + k;
+        const bool ok = xo >= 0 && xo < Wo;
+        wx[0][k] = ok ? tap_weight(xo, j0, 0.5f, 0, Wi) : 0.f;
+        wx[1][k] = ok && j0 + 1 < Wi ? tap_weight(xo, j0 + 1, 0.5f, 0, Wi) : 0.f;
+    }
+    for (int yo = max(2 * i0 - 1, 0); yo <= min(2 * i0 + 4, Ho - 1); ++yo) {
+        const float wy0 = tap_weight(yo, i0, 0.5f, 0, Hi);
+        const float wy1 = i0 + 1 < Hi ? tap_weight(yo, i0 + 1, 0.5f, 0, Hi) : 0.f;
+        if (wy0 == 0.f && wy1 == 0.f) continue;
+        const T *row = dy + (((long)n * Ho + yo) * Wo + xo0) * dy_pitch + cv * V;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (wx[0][k] == 0.f && wx[1][k] == 0.f) continue;               // also: column out of range
+            const fvec<V> g = ldv<T, V>(row + (long)k * dy_pitch);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float wy = a ? wy1 : wy0;
+                if (wy == 0.f) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (wx[b][k] == 0.f) continue;
+                    const float w = wy * wx[b][k];
+#pragma unroll
+                    for (int h = 0; h < V / 4; ++h) acc[a][b].q[h] += g.q[h] * w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (i0 + a >= Hi || j0 + b >= Wi) continue;
+            T *dst = dx + (((long)n * Hi + i0 + a) * Wi + j0 + b) * dx_pitch + cv * V;
+            if (beta) {
+                const fvec<V> old = ldv<T, V>(dst);
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) acc[a][b].q[h] = old.q[h] + acc[a][b].q[h];
+            }
+            stv<T, V>(dst, acc[a][b]);
+        }
+}
+
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize_rows_bwd_kernel(const T *__restrict__ dy, int dy_pitch, T *__restrict__ dx,
                                                               int dx_pitch, int beta, int Hi, int Wi, int Ho, int Wo, int C,
@@ -657,6 +725,22 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, voi
         if (2 * tc >= Hi || 2 * tc >= Wi) tc = 0;
     }
     const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
+    if (g_resize2x && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 &&
+        (long)N * ((Hi + 1) / 2) <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
+        const int Hh = (Hi + 1) / 2, Wh = (Wi + 1) / 2;
+        if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {
+            hipLaunchKernelGGL((resize2x_bwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wh * (C / 8), 256), N * Hh), dim3(256), 0,
+                               rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (bf16_t *)dx, dx_pitch, beta, Hi, Wi, C);
+        } else {
+#define RCF_CALL(T)                                                                                                       \
+    hipLaunchKernelGGL((resize2x_bwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wh * (C / 4), 256), N * Hh), dim3(256), 0,         \
+                       rcf_stream(stream), (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, Hi, Wi, C)
+            RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+        }
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     if ((long)N * Hi <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
         const float sh = host_scale(Hi, Ho, align_corners), sw = host_scale(Wi, Wo, align_corners);
         if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {

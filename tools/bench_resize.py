@@ -1,44 +1,40 @@
-#!/usr/bin/env python3
-"""bilinear NHWC resize at the step's large tensor ([16,60,107,256] <-> [16,120,214,256]): time and bytes moved"""
-import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+"""A/B of the exact-2x bilinear resize kernels (csrc/spatial.hip resize2x_*) against the general ones on the decode heads'
+tensors.  usage: python tools/bench_resize.py"""
+import os
+import sys
+
 import torch
-import rcf_amd
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rcf_amd  # noqa
 from rcf_amd import ops
 
 
-def timeit(fn, n=20):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
+    for _ in range(iters):
         fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
 
 
-for dt in (torch.bfloat16, torch.float32):
-    x = torch.randn(16, 60, 107, 256, device="cuda:0").to(dt)
-    g = torch.randn(16, 120, 214, 256, device="cuda:0").to(dt)
-    b = x.element_size()
-    tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False))
-    tb = timeit(lambda: ops.resize_nhwc_bwd(g, (60, 107), False))
-    nb = (x.numel() + g.numel()) * b
-    y = ops.resize_nhwc_fwd(x, (120, 214), False).float()
-    ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), size=(120, 214), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
-    xg = x.float().requires_grad_(True)
-    torch.nn.functional.interpolate(xg.permute(0, 3, 1, 2), size=(120, 214), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).backward(g.float())
-    gb = ops.resize_nhwc_bwd(g, (60, 107), False).float()
-    print(f"{dt}: fwd {tf*1e6:7.1f} us {nb/tf/1e12:.2f} TB/s | bwd {tb*1e6:7.1f} us {nb/tb/1e12:.2f} TB/s | "
-          f"fwd err {float((y-ref).abs().max()):.2e} bwd err {float((gb-xg.grad).abs().max()):.2e}")
-
-# frame-restricted forms (the commuted up-sampling of the decode head's dilated conv): only the border frame is written / read
-for dt in (torch.bfloat16, torch.float32):
-    x = torch.randn(16, 60, 107, 256, device="cuda:0").to(dt)
-    g = torch.randn(16, 120, 214, 256, device="cuda:0").to(dt)
-    out = torch.zeros(16, 120, 214, 256, device="cuda:0").to(dt)
-    gx = torch.zeros(16, 60, 107, 256, device="cuda:0").to(dt)
-    for fr in (6, 12):
-        tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False, out=out, frame=fr))
-        tb = timeit(lambda: ops.resize_nhwc_bwd(g, (60, 107), False, out=gx, beta=1, frame=fr))
-        print(f"{dt} frame {fr}: fwd {tf*1e6:7.1f} us | bwd (beta=1) {tb*1e6:7.1f} us")
+for dt in (torch.float32, torch.bfloat16):
+    for C in (256, 512):
+        x = torch.randn(16, 60, 107, C, device="cuda:0").to(dt)
+        dy = torch.randn(16, 120, 214, C, device="cuda:0").to(dt)
+        out = {}
+        for mode in (0, 1, 0, 1):
+            ops.resize_set_2x(mode)
+            tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False))
+            tb = timeit(lambda: ops.resize_nhwc_bwd(dy, (60, 107), False))
+            out.setdefault(mode, []).append((tf, tb))
+        ops.resize_set_2x(1)
+        f0, b0 = min(t[0] for t in out[0]), min(t[1] for t in out[0])
+        f1, b1 = min(t[0] for t in out[1]), min(t[1] for t in out[1])
+        mb = dy.numel() * dy.element_size() / 1e6
+        print(f"{str(dt):15s} C={C}: forward general {f0*1e6:6.1f} us, exact-2x {f1*1e6:6.1f} us ({f0/f1:4.2f}x; {mb/f1/1e6:4.2f} TB/s of output) | "
+              f"backward general {b0*1e6:6.1f} us, exact-2x {b1*1e6:6.1f} us ({b0/b1:4.2f}x)", flush=True)
