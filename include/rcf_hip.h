@@ -82,10 +82,18 @@ int rcf_conv_set_h2s(int mode);
 /* A/B switch of the weight-gradient kernels' workgroup -> (output tile, pixel range) mapping: 1 (default) the workgroups that
  * run together on one XCD read the same pixel range, 0 plain grid order.  Results are bit-identical either way. */
 int rcf_conv_set_wgrad_xcd(int mode);
+/* A/B switch of the weight gradients' tile, a bit mask: bit 0 (default on) the fp16-pair kernel takes 256 x 256 tiles on one
+ * workgroup per CU where Cout and Cin are multiples of 256 (1.02 - 1.08 x the 128 x 256 tile on two workgroups: a third fewer
+ * loads, splits, LDS writes and fragment reads per MFMA on a power-bound kernel), bit 1 (default off: 0.86 - 1.04 x) the bf16
+ * kernel does.  Same K order: bit-identical when the split counts agree. */
+int rcf_conv_set_wgrad_big(int mode);
 /* A/B switch of the forward / data-gradient grids' XCD mapping: 1 (default) convs whose weight operand exceeds the XCDs' L2
  * many times over (the data gradient of the 2048- / 4096-channel decode-head convs) give every XCD its own COLUMN tiles of
  * all row tiles instead of its own band of row tiles; 0 always row bands.  Bit-identical results. */
 int rcf_conv_set_colmap(int mode);
+/* experiment switch (default off): forward / data-gradient launches with K >= min_k, whole 256-column tiles and >= 32768 rows on
+ * 256 x 256 tiles of the 128 x 256 kernel family (one workgroup per CU) */
+int rcf_conv_set_x3_big(int mode, int min_k);
 /* A/B switch of the K order of the forward / data-gradient convs: 1 (default) channel chunks of 64 outer, taps inner on the
  * 3x3 layers with more than 64 channels per tap, 0 tap outer (the weight's memory order).  The derived weight operands
  * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after

@@ -17,6 +17,7 @@
 extern int rcf_g_wgrad_xcd;   // igemm_conv.hip: rcf_conv_set_wgrad_xcd
 extern int rcf_g_korder;      // igemm_conv.hip: rcf_conv_set_korder (rcf_common.h rcf_kchunk)
 extern int rcf_g_colmap;      // igemm_conv.hip: rcf_conv_set_colmap (rcf_common.h rcf_conv_tile)
+extern int rcf_g_wgrad_big_bf16;   // igemm_conv.hip: rcf_conv_set_wgrad_big bit 1
 
 namespace {
 
@@ -844,9 +845,10 @@ __device__ __forceinline__ void wgrad_tr_step(const char *__restrict__ As, const
 // ((p >> 1) & 1) << 2 (source address and fragment address alike): the 4 rows x 4 chunks a 32-lane half reads through
 // ds_read_b64_tr_b16 cover all 16 chunk positions of the 256-byte bank space (SQ_LDS_BANK_CONFLICT = 0).
 // ONETAP: Cin is a multiple of the tile width, so a tile's columns belong to one filter tap.
-template <int NR, bool REGION, bool ONETAP>
-__global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
-    constexpr int MR = 2, BM = 128, BN = 64 * NR, BK = 32;
+// MR = 4 (rcf_conv_set_wgrad_big): 256 x 256 tile, one workgroup per CU (96 KB of LDS, 256 accumulator registers per wave).
+template <int NR, bool REGION, bool ONETAP, int MR = 2>
+__global__ void __launch_bounds__(256, MR == 2 ? 2 : 1) wgrad_bf16_dma_kernel(WgradParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR, BK = 32;
     constexpr int GA = BM / 64, GB = BN / 64;                  // channel groups = DMA instructions per wave and K-step
     constexpr int GSZ = BK * 128;                              // bytes of one group: 32 pixels x 128 B
     constexpr int PLA = GA * GSZ, PLB = GB * GSZ, STAGE = PLA + PLB;
@@ -999,6 +1001,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
             mma(st);
             loads(kt + 2, st2);
             advance_rows();
+            if constexpr (MR == 4) {
+                // 256 x 256: the fragments of ONE k half at a time (64 registers for both would spill beside 256 accumulators)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MR * NR - NLD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MR + NR), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);
+            } else {
             __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MR + NR), 0);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
@@ -1006,6 +1020,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(WgradParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR - NLD, 0);
+            }
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD) : "memory");
             __builtin_amdgcn_s_barrier();
             st = st == 2 ? 0 : st + 1;
@@ -1172,6 +1187,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     // 64 output channels take the 128-row LDS-DMA kernel too when the columns allow it: these layers are bound by memory,
     // not by the half-empty tile rows (layer1 3x3 64->64: 0.104 -> 0.093 ms, 1x1 256->64: 0.089 -> 0.068)
     pl.mr = (s->Cout > 64 || (s->Cout == 64 && pl.nr >= 2)) ? 2 : 1;
+    if (rcf_g_wgrad_big_bf16 && pl.nr == 4 && s->Cout % 256 == 0 && s->Cin % 256 == 0 && (g_bf16_tile < 0 || g_bf16_tile >= 4)) pl.mr = 4;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ktot, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);
@@ -1185,7 +1201,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     const double px_us = 0.025 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
     const double wbytes = (double)s->Cout * ktot * 4.0;
     const long maxsk = M / 512 > 1 ? M / 512 : 1;
-    const long slots = 512, hi = maxsk < 256 ? maxsk : 256;
+    const long slots = pl.mr == 4 ? 256 : 512, hi = maxsk < 256 ? maxsk : 256;
     double best = 1e30;
     long sk = 1;
     for (long c = 1; c <= hi; ++c) {
@@ -1402,7 +1418,10 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
         else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, false, false>), grid, dim3(256), 0, st, p);                  \
     } while (0)
     const bool dma = g_bf16_tile < 0 || g_bf16_tile >= 4;      // tiles 0-3 select the register-staged references
-    if (pl.mr == 2 && pl.nr == 4 && dma) RCF_WGD(4);
+    if (pl.mr == 4) {
+        if (region) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<4, true, true, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<4, false, true, 4>), grid, dim3(256), 0, st, p);
+    } else if (pl.mr == 2 && pl.nr == 4 && dma) RCF_WGD(4);
     else if (pl.mr == 2 && pl.nr == 2 && dma) RCF_WGD(2);
     else if (pl.mr == 2 && pl.nr == 4) RCF_WG(2, 4);
     else if (pl.mr == 2 && pl.nr == 2) RCF_WG(2, 2);

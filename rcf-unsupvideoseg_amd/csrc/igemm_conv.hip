@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 int rcf_g_wgrad_xcd = 1;      // rcf_conv_set_wgrad_xcd; read by igemm_bf16.hip too
+int rcf_g_wgrad_big_bf16 = 0; // rcf_conv_set_wgrad_big bit 1: the bf16 weight gradient's 256 x 256 tile (measured 0.86 - 1.04 x: off)
 int rcf_g_colmap = 1;         // rcf_conv_set_colmap: rcf_common.h rcf_conv_tile / rcf_colmap_pays
 int rcf_g_korder = 1;         // rcf_conv_set_korder: K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk)
 
@@ -543,7 +544,7 @@ __device__ __forceinline__ unsigned x3_oob_unless(unsigned off, int ok) { return
 // TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue; every instance is launched with TR = true
 // (the batch-norm statistics, column sums, are a butterfly over the pixels = lanes of a half-wavefront there)
 template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD>
-__global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && MR * NR < 16 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
     constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
@@ -1658,9 +1659,11 @@ __device__ __forceinline__ u32x2 lds_tr16(const char *p) {
 // instead of once per tap.  Cin % 64 == 0: each of a thread's 64-channel groups lies in ONE tap, which is block-uniform
 // (scalar registers).  ONETAP: Cin % BN == 0, the whole tile belongs to one tap.
 // REGION: only the pixels of p's rectangle / frame contribute (M = N * rr); the pixel walk divides.
-template <int NR, bool REGION, bool ONETAP>
-__global__ void __launch_bounds__(256, 2) igemm_wgrad_h2t_kernel(WgradParams p) {
-    constexpr int MR = 2, BM = 128, BN = 64 * NR;
+// MR = 4 (rcf_conv_set_wgrad_big): a 256 x 256 tile, ONE workgroup per CU -- 128 x 128 accumulators per wave (256 registers),
+// 74 KB of LDS: a third fewer loads, splits, LDS writes and fragment reads per MFMA than the 128 x 256 tile.
+template <int NR, bool REGION, bool ONETAP, int MR = 2>
+__global__ void __launch_bounds__(256, MR == 2 ? 2 : 1) igemm_wgrad_h2t_kernel(WgradParams p) {
+    constexpr int BM = 64 * MR, BN = 64 * NR;
     constexpr int NAP = BM / 64, NBP = BN / 64;                  // 64-channel groups per thread: dy, x
     constexpr int PIA = BM * 2 + 64, PIB = BN * 2 + 64;          // row (pixel) pitch of the dy / x planes, bytes (= 64 mod 256)
     constexpr int PLA = BK * PIA, PLB = BK * PIB, STAGE = 2 * (PLA + PLB);
@@ -2003,6 +2006,7 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
 }
 
 // conv_h2p_kernel (igemm_h2p.inc): which launches take it.  g_h2p: -1 built-in rule, 0 never, 1 whenever eligible
+int g_x3_big = 0, g_x3_big_min_k = 1024;     // rcf_conv_set_x3_big (experiment)
 int g_h2p = -1;
 int g_h2s = -1;            // conv_h2s_kernel (igemm_h2s.inc): see the comment above h2s_eligible
 int g_h2p_min_k = 2304;    // the 3x3 layers.  Below (1x1 convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part
@@ -2137,6 +2141,14 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     const bool strided = p.div > 1;
     int tile = g_x3_tile;
     if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
+    // experiment (rcf_conv_set_x3_big): 256 x 256 tiles, 128 x 128 accumulators per wave, one workgroup per CU, on long-K
+    // layers with whole column tiles
+    if (g_x3_big && !strided && batches == 1 && p.Ncol % 256 == 0 && p.K >= g_x3_big_min_k && p.M >= 32768 && p.amax_a && p.amax_b &&
+        p.b_pairs && !g_h2_off) {
+        launch_x3_cfg<4, 4, 2, 2>(p, strided, st, batches);
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.Ncol <= 64 && (long)rcf_cdiv(p.M, 128) * batches < 512) launch_x3_cfg<1, 1, 2, 2>(p, strided, st, batches);   // few rows: 64x64 tiles fill more CUs
     else if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st, batches);
     else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st, batches);
@@ -2168,6 +2180,7 @@ struct WgradPlan {
     long chunk;
     bool cols;      // igemm_wgrad_h2t_kernel: the taps are GEMM columns (grid.y = 1)
 };
+int g_wgrad_big = 1;          // rcf_conv_set_wgrad_big bit 0: the 256 x 256 weight-gradient tile where whole tiles of one tap fit (+3 - 8 %)
 int g_wgrad_plan_us = 1;      // 1: split-K by the microsecond cost model (same-box A/B: -0.5 ms per fp32 step); RCF_WGRAD_PLAN_US=0: round-1 model
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullptr) {
     static const int env_plan = getenv("RCF_WGRAD_PLAN_US") ? atoi(getenv("RCF_WGRAD_PLAN_US")) : -1;
@@ -2190,6 +2203,8 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     if (pl.cols) {
         pl.mr = 2;
         pl.nr = ktot >= 256 ? 4 : 2;
+        // 256 x 256 tile, one workgroup per CU: whole 256-row and 256-column tiles of one tap only
+        if (g_wgrad_big && pl.nr == 4 && s->Cout % 256 == 0 && s->Cin % 256 == 0) pl.mr = 4;
     }
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = pl.cols ? rcf_cdiv(ktot, 64 * pl.nr) : rcf_cdiv(ncols, 64 * pl.nr);
@@ -2201,10 +2216,10 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     if (sk > maxsk) sk = maxsk;
     if (sk > 256) sk = 256;
     if (sk < 1) sk = 1;
-    if (use_x3(4) && !smallc && pl.mr == 2 && pl.nr >= 2) {
+    if (use_x3(4) && !smallc && pl.mr >= 2 && pl.nr >= 2) {
         // the split-bf16 kernel runs 3 workgroups per CU (768 slots): pick the split whose last round is fullest
         // (time ~ rounds / split; the fixed-order reduction costs ~ split)
-        const long slots = pl.nr == 4 ? 512 : 768, hi = maxsk < 256 ? maxsk : 256;   // (the 128 x 256 kernel: 2 per CU = 512)
+        const long slots = pl.mr == 4 ? 256 : (pl.nr == 4 ? 512 : 768), hi = maxsk < 256 ? maxsk : 256;   // (the 128 x 256 kernel: 2 per CU = 512; 256 x 256: 1)
         double best = 1e30;
         if (g_wgrad_plan_us) {
             // the cost model of the bf16 weight gradient (csrc/igemm_bf16.hip), in microseconds: rounds x pixels per
@@ -2478,8 +2493,25 @@ extern "C" int rcf_conv_set_korder(int mode) {
 
 /* A/B switch of the forward / data-gradient grids' XCD mapping for convs whose weights exceed L2 many times over
  * (rcf_common.h rcf_conv_tile): 1 (default) the byte model decides, 0 always row bands.  Tiles are independent: bit-identical. */
+/* experiment: forward / data-gradient launches with K >= min_k, whole 256-column tiles and >= 32768 rows on 256 x 256 tiles
+ * (igemm_conv_x3_kernel<4, 4, 2, 2>: one workgroup per CU) instead of 128 x 256; 0 (default) off */
+extern "C" int rcf_conv_set_x3_big(int mode, int min_k) {
+    g_x3_big = mode ? 1 : 0;
+    if (min_k > 0) g_x3_big_min_k = min_k;
+    return 0;
+}
+
 extern "C" int rcf_conv_set_colmap(int mode) {
     rcf_g_colmap = mode ? 1 : 0;
+    return 0;
+}
+
+/* A/B switch, bit 0: the fp16-pair weight gradient takes 256 x 256 tiles (one workgroup per CU) where Cout and Cin are multiples
+ * of 256, bit 1: the bf16 weight gradient does; 0: 128 x 256 tiles, two workgroups per CU.  Same sums per element (the K order does not change): bit-identical
+ * when the split counts agree, fp32-rounding differences otherwise. */
+extern "C" int rcf_conv_set_wgrad_big(int mode) {
+    g_wgrad_big = mode & 1;
+    rcf_g_wgrad_big_bf16 = (mode >> 1) & 1;
     return 0;
 }
 
@@ -2648,7 +2680,10 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
             if (pl.cols) {
                 const bool onetap = s->Cin % (64 * pl.nr) == 0;
                 p.cblocks = onetap && s->R * s->S > 1 && rcf_g_wgrad_xcd ? s->Cin / (64 * pl.nr) : 0;
-                if (pl.nr == 4) {
+                if (pl.mr == 4) {
+                    if (region) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, true, 4>), grid, dim3(256), 0, st, p);
+                    else hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, false, true, 4>), grid, dim3(256), 0, st, p);
+                } else if (pl.nr == 4) {
                     if (region && onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, true>), grid, dim3(256), 0, st, p);
                     else if (region) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, false>), grid, dim3(256), 0, st, p);
                     else if (onetap) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, false, true>), grid, dim3(256), 0, st, p);
