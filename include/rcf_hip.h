@@ -91,9 +91,6 @@ int rcf_conv_set_wgrad_big(int mode);
  * many times over (the data gradient of the 2048- / 4096-channel decode-head convs) give every XCD its own COLUMN tiles of
  * all row tiles instead of its own band of row tiles; 0 always row bands.  Bit-identical results. */
 int rcf_conv_set_colmap(int mode);
-/* experiment switch (default off): forward / data-gradient launches with K >= min_k, whole 256-column tiles and >= 32768 rows on
- * 256 x 256 tiles of the 128 x 256 kernel family (one workgroup per CU) */
-int rcf_conv_set_x3_big(int mode, int min_k);
 /* A/B switch of the K order of the forward / data-gradient convs: 1 (default) channel chunks of 64 outer, taps inner on the
  * 3x3 layers with more than 64 channels per tap, 0 tap outer (the weight's memory order).  The derived weight operands
  * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after

@@ -88,7 +88,6 @@ PROTOS = {
     "rcf_conv_set_wgrad_big": (c_int, [c_int]),
     "rcf_conv_set_korder": (c_int, [c_int]),
     "rcf_conv_set_colmap": (c_int, [c_int]),
-    "rcf_conv_set_x3_big": (c_int, [c_int, c_int]),
     "rcf_bn_set_sweep": (c_int, [c_int]),
     "rcf_resize_set_2x": (c_int, [c_int]),
     "rcf_conv_last_kernel": (c_int, []),

@@ -544,7 +544,7 @@ __device__ __forceinline__ unsigned x3_oob_unless(unsigned off, int ok) { return
 // TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue; every instance is launched with TR = true
 // (the batch-norm statistics, column sums, are a butterfly over the pixels = lanes of a half-wavefront there)
 template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD>
-__global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && MR * NR < 16 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
     constexpr int PA = BM * 32, PB = BN * 32, STAGE = NP * (PA + PB);
@@ -2006,7 +2006,6 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
 }
 
 // conv_h2p_kernel (igemm_h2p.inc): which launches take it.  g_h2p: -1 built-in rule, 0 never, 1 whenever eligible
-int g_x3_big = 0, g_x3_big_min_k = 1024;     // rcf_conv_set_x3_big (experiment)
 int g_h2p = -1;
 int g_h2s = -1;            // conv_h2s_kernel (igemm_h2s.inc): see the comment above h2s_eligible
 int g_h2p_min_k = 2304;    // the 3x3 layers.  Below (1x1 convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part
@@ -2141,14 +2140,6 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     const bool strided = p.div > 1;
     int tile = g_x3_tile;
     if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
-    // experiment (rcf_conv_set_x3_big): 256 x 256 tiles, 128 x 128 accumulators per wave, one workgroup per CU, on long-K
-    // layers with whole column tiles
-    if (g_x3_big && !strided && batches == 1 && p.Ncol % 256 == 0 && p.K >= g_x3_big_min_k && p.M >= 32768 && p.amax_a && p.amax_b &&
-        p.b_pairs && !g_h2_off) {
-        launch_x3_cfg<4, 4, 2, 2>(p, strided, st, batches);
-        RCF_LAUNCH_CHECK();
-        return 0;
-    }
     if (p.Ncol <= 64 && (long)rcf_cdiv(p.M, 128) * batches < 512) launch_x3_cfg<1, 1, 2, 2>(p, strided, st, batches);   // few rows: 64x64 tiles fill more CUs
     else if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st, batches);
     else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st, batches);
@@ -2493,14 +2484,6 @@ extern "C" int rcf_conv_set_korder(int mode) {
 
 /* A/B switch of the forward / data-gradient grids' XCD mapping for convs whose weights exceed L2 many times over
  * (rcf_common.h rcf_conv_tile): 1 (default) the byte model decides, 0 always row bands.  Tiles are independent: bit-identical. */
-/* experiment: forward / data-gradient launches with K >= min_k, whole 256-column tiles and >= 32768 rows on 256 x 256 tiles
- * (igemm_conv_x3_kernel<4, 4, 2, 2>: one workgroup per CU) instead of 128 x 256; 0 (default) off */
-extern "C" int rcf_conv_set_x3_big(int mode, int min_k) {
-    g_x3_big = mode ? 1 : 0;
-    if (min_k > 0) g_x3_big_min_k = min_k;
-    return 0;
-}
-
 extern "C" int rcf_conv_set_colmap(int mode) {
     rcf_g_colmap = mode ? 1 : 0;
     return 0;

@@ -294,18 +294,6 @@ if "RCF_WGRAD_BIG" in os.environ:
         pass
 
 
-def conv_set_x3_big(mode=1, min_k=0):
-    """experiment switch: 256 x 256 tiles for the long-K forward / data-gradient launches of the 128 x 256 kernel family"""
-    _lib.load().rcf_conv_set_x3_big(int(mode), int(min_k))
-
-
-if "RCF_X3_BIG" in os.environ:
-    try:
-        conv_set_x3_big(int(os.environ["RCF_X3_BIG"]), int(os.environ.get("RCF_X3_BIG_MIN_K", "0")))
-    except Exception:                  # noqa: BLE001
-        pass
-
-
 def conv_set_colmap(mode=1):
     """A/B switch of the forward / data-gradient grids' XCD mapping (csrc/rcf_common.h rcf_conv_tile)"""
     _lib.load().rcf_conv_set_colmap(int(mode))

@@ -10,7 +10,6 @@ from rcf_amd import config, synth, ops
 KNOBS = {"wgrad_xcd": (ops.conv_set_wgrad_xcd, {"grid order": 0, "XCD-aware": 1}, 1),
          "korder": (ops.conv_set_korder, {"tap outer": 0, "chunk outer": 1}, 1),
          "wgrad_big": (ops.conv_set_wgrad_big, {"128x256 x 2 per CU": 0, "256x256 x 1 per CU (fp16 pairs)": 1, "256x256 (both)": 3}, 1),
-         "x3_big": (ops.conv_set_x3_big, {"128x256": 0, "256x256 from K=1024": 1}, 0),
          "colmap": (ops.conv_set_colmap, {"row bands": 0, "byte model": 1}, 1),
          "bn_sweep": (ops.bn_set_sweep, {"front to back": 0, "cache aware >= 192 MB": 1, "cache aware, all": 2}, 1)}
 knob = sys.argv[1]
