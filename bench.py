@@ -165,8 +165,8 @@ def main():
 
     # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel with the largest share of
     # the step's kernel time -- since round 3 (lean epilogues, the deep 3x3 forward / data-gradient convs on the persistent
-    # kernel) that is the 128x256 weight-gradient tile again (igemm_wgrad_h2t_kernel<4,false,true>: 22.7 ms of a step's
-    # kernel time, profiles/r03_step_kernel_stats_one_stream.txt; data gradient 21.2, persistent forward 13.8)
+    # kernel) that is the weight-gradient family again (igemm_wgrad_h2t_kernel<4,*,*,MR>, 256x256 / 128x256 tiles: 25.4 ms of
+    # a step's kernel time, profiles/r03_layers_final_fp32.txt; 128x256 data gradient 20.5, persistent forward 12.4)
     fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_wgrad_h2t4")
     dt, loss_val, prof, by32, by32s = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
@@ -316,7 +316,7 @@ FAMILIES_F32 = {
     "conv_fwd_narrow": "igemm_conv_x3_kernel<2,{1,2},2,2,...> / fp32-MFMA stem (forward, <= 128 output channels)",
     "conv_dgrad_wide": "igemm_conv_x3_kernel<2,4,2,2,false,true,2,true,true> (data gradient, fp16 pairs, 128x256 tile; incl. the weight transpose+split pre-pass)",
     "conv_dgrad_other": "igemm_conv_x3_kernel<...,true,...> (data gradient: strided / narrow tiles)",
-    "conv_wgrad_h2t4": "igemm_wgrad_h2t_kernel<4,*,*> (weight gradient, fp16 pairs, 128x256 tile over (tap, channel) columns, transposing LDS reads, whole tensors and regions; incl. the split-K reduction)",
+    "conv_wgrad_h2t4": "igemm_wgrad_h2t_kernel<4,*,*,MR> (weight gradient, fp16 pairs, 256x256 (MR = 4: Cout and Cin multiples of 256) or 128x256 tile over (tap, channel) columns, transposing LDS reads, whole tensors and regions; incl. the split-K reduction)",
     "conv_wgrad_other": "igemm_wgrad_h2t_kernel<2,*,*> / igemm_wgrad_x3_kernel / igemm_wgrad_kernel (weight gradient: fewer than 256 columns, odd channel counts, stem)",
 }
 FAMILIES_BF16 = {

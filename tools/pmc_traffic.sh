@@ -26,15 +26,18 @@ with open("$R/gpurun_out/pmc_hbm_traffic.txt", "w") as o:
     for tot, k, n, f, w in rows[:40]:
         o.write(f"{k[:120]} | {n} | {f:.1f} | {w:.1f} | {(2*f+w)*1024/1e6:.1f}\n")
 out = {}
-for tot, k, n, f, w in rows:
-    for fam, pat in (("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true>"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
-                     ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true>"),
-                     ("conv_h2p_fwd", "conv_h2p_kernel<false>"), ("conv_h2p_dgrad", "conv_h2p_kernel<true>"),
-                     ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true>"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
-                     ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
-        if pat in k:
-            out[fam] = {"kernel": k, "launches": n, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-            print(fam, n, round((2 * f + w) * 1024 / 1e6, 1), "MB/launch")
+# a family = every kernel whose name starts like the pattern (template variants of one kernel: 128 x 256 and 256 x 256 tiles)
+for fam, pat in (("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
+                 ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true>"),
+                 ("conv_h2p_fwd", "conv_h2p_kernel<false>"), ("conv_h2p_dgrad", "conv_h2p_kernel<true>"),
+                 ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
+                 ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
+    sel = [(k, n, f, w) for tot, k, n, f, w in rows if pat in k]
+    if sel:
+        nn = sum(n for _, n, _, _ in sel)
+        bytes_ = sum((2 * f + w) * 1024 * n for _, n, f, w in sel)
+        out[fam] = {"kernel": " + ".join(k for k, _, _, _ in sel), "launches": nn, "hbm_bytes_per_launch": bytes_ / nn}
+        print(fam, nn, round(bytes_ / nn / 1e6, 1), "MB/launch")
 # bench.py reads the entry of the family it brackets in the timed region (fp32 leg: the 128x256 weight-gradient tile)
 if "conv_wgrad_h2t4" in out:
     d = dict(out["conv_wgrad_h2t4"], family="conv_wgrad_h2t4", by_family=out,
