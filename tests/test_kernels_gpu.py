@@ -357,6 +357,41 @@ def test_conv_wgrad_fp16_pairs_columns(case, report):
     assert e0 < max(4 * r, 5e-7) and e1 < max(4 * r, 5e-7)
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, pad, dil, H, W, region
+    (4, 256, 256, 3, 2, 2, 60, 107, None),                 # 3x3: 9 column tiles of one tap each
+    (3, 512, 256, 1, 0, 1, 60, 107, None),                 # 1x1, two column tiles
+    (2, 256, 512, 3, 3, 3, 33, 41, (0, 0, 33, 41, 6)),     # frame region, two row tiles
+])
+def test_conv_wgrad_256x256_tile_matches_128x256(case, report):
+    """igemm_wgrad_h2t_kernel<.., MR = 4> (256 x 256 tile, one workgroup per CU: rcf_conv_set_wgrad_big bit 0, the default where
+    Cout and Cin are multiples of 256) against the 128 x 256 tile: every element is the same sum over the same pixel chunks in
+    the same order when the split counts agree, and fp32-level agreement otherwise; both against float64"""
+    N, Cin, Cout, k, pad, dil, H, W, reg = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:8])))
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV)
+    wg = cl_weight(torch.randn(Cout, Cin, k, k, generator=g))
+    ax, ag = ops.absmax(x), ops.absmax(dy)
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.conv_set_wgrad_big(mode)
+            dw = torch.full_like(wg, 3.0)
+            ops.conv2d_wgrad(x, dy, wg, dw, 1, pad, dil, beta=0, region=reg, amax=(ax, ag))
+            acc = dw.clone()
+            ops.conv2d_wgrad(x, dy, wg, acc, 1, pad, dil, beta=1, region=reg, amax=(ax, ag))
+            res[mode] = (dw, acc)
+    finally:
+        ops.conv_set_wgrad_big(1)
+    d = [float((a - b).abs().max() / a.abs().max()) for a, b in zip(res[0], res[1])]
+    ref = torch.nn.grad.conv2d_weight(from_nhwc(x).double(), tuple(wg.shape), (from_nhwc(dy) * _region_mask(dy, reg).cpu()).double(),
+                                      1, pad, dil)
+    e = relerr(res[1][0], ref)
+    report(f"conv wgrad 256x256 tile {case}: max difference to the 128x256 tile {d[0]:.1e} (accumulated {d[1]:.1e}); vs float64 {e:.2e}")
+    assert max(d) < 2e-6 and e < 2e-5
+
+
 def test_conv_column_tile_xcd_mapping_is_a_permutation(report):
     """csrc/rcf_common.h rcf_conv_tile: convs whose weight operand exceeds L2 many times over (the data gradient of a 3x3 conv
     with 2048 input channels: 19 MB of fp16 pairs, 16 column tiles) give every XCD its own column tiles of all row tiles
