@@ -652,12 +652,13 @@ def commuted_concat_conv(a, b, conv, tape):
     ya = Act(y)
 
     def bwd():
+        rdy = ya.take_grad_range() if h2 else None                         # from the batch norm's backward when it left one
         dy = ya.take_grad()
         dy_int, dy_band = ops.split_rect(dy, interior)
         g4 = ops.resize_nhwc_bwd(dy_int, (hb, wb), False)                  # adjoint of the interior's up-sampling
-        rdy = rg4 = None
+        rg4 = None
         if h2:
-            rdy, rg4 = ops.absmax(dy), ops.absmax(g4)                      # dy_band is a part of dy
+            rg4 = ops.absmax(g4)                                           # dy_band is a part of dy
         if W.requires_grad:
             gW = _param_grad(W).permute(0, 2, 3, 1)                       # [Co,3,3,C] as stored
             dwa = torch.empty_like(wa)
@@ -701,6 +702,7 @@ def pair_concat(x, tape, B, I, order=None):
             for i in range(I):
                 ops.copy2d(x.t[b * I + order[i]], C, out[b][..., i * C:], I * C, HW, C)
     ya = Act(out)
+    ya.amax = x.amax                 # the same values in another order: the range the producer left is this tensor's range
 
     def bwd():
         g = ya.take_grad()
