@@ -80,6 +80,11 @@ OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "0") != "0"
 # stage 2.1: the EMA teacher's forward + CRF on a second stream beside the student's forward (152 vs 172 ms per step)
 OVERLAP_TEACHER = __import__("os").environ.get("RCF_OVERLAP_TEACHER", "1") != "0"
 OVERLAP_WGRAD_WITH_H2P = __import__("os").environ.get("RCF_OVERLAP_WGRAD_H2P", "1") != "0"   # A/B knob (tools/ab_overlap.py)
+# With OVERLAP_WGRAD: start a layer's weight gradient AFTER its data gradient, so that it runs beside the next layer's batch-norm
+# backward (HBM-bound) instead of beside its own data gradient (MFMA-bound like itself).  Measured with the 128 x 256
+# weight-gradient tile (RCF_WGRAD_BIG=0; the 256 x 256 tile holds a CU's registers for a whole launch): 115.2 (one stream) ->
+# 112.8 ms, against 113.4 for the round-2 order (profiles/r03_ab_late_wgrad.txt).  Off like OVERLAP_WGRAD, for the same reason.
+LATE_WGRAD = __import__("os").environ.get("RCF_LATE_WGRAD", "0") != "0"
 # ... in the bf16 step the gain is smaller (same process, interleaved: 50.96 vs 51.98 ms/step, against 129.7 vs 140.6 in fp32;
 # before the bf16 weight gradient's prefetch worked, csrc/igemm_bf16.hip wgrad_tr_step, there was none: 57.8 vs 58.1)
 OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "1") != "0"
@@ -375,6 +380,16 @@ class Conv2d(nn.Module):
                 dy = ya.take_grad()
                 if self.act:
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
+                done_dgrad = [False]
+
+                def late_dgrad():
+                    gx, beta = x.grad_slot()
+                    wpt = None
+                    if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
+                        wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
+                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                     amax=(ady, aw), w_pairs_t=wpt)
+                    done_dgrad[0] = True
                 if self.weight.requires_grad:
                     if self.cin_pad == self.cin and self.cout_pad == self.cout:
                         # the persistent data-gradient kernel (one workgroup per CU, 128 KB of LDS) leaves no room for a
@@ -384,7 +399,12 @@ class Conv2d(nn.Module):
                                 and x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 32768)
                         if OVERLAP_WGRAD and x.needs_grad and not solo:
                             side = _side_stream(dy.device)
-                            side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready
+                            if LATE_WGRAD:
+                                # the data gradient first, alone; the weight gradient starts when it is done and so runs beside
+                                # the NEXT layer's batch-norm backward (HBM-bound) instead of beside this layer's data
+                                # gradient (MFMA-bound like itself)
+                                late_dgrad()
+                            side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready (LATE_WGRAD: the data gradient is done)
                             with torch.cuda.stream(side):
                                 ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
                                                  self.dilation, beta=1, amax=(ax, ady))
@@ -411,13 +431,8 @@ class Conv2d(nn.Module):
                         db = torch.zeros(self.cout_pad, dtype=torch.float32, device=dy.device)
                         ops.colsum(dy, db, beta=0)
                         _param_grad(self.bias).add_(db[:self.cout])
-                if x.needs_grad:
-                    gx, beta = x.grad_slot()
-                    wpt = None
-                    if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
-                        wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
-                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                     amax=(ady, aw), w_pairs_t=wpt)
+                if x.needs_grad and not done_dgrad[0]:
+                    late_dgrad()
             tape.push(bwd)
         return ya
 

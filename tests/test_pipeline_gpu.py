@@ -149,11 +149,13 @@ def test_second_stream_for_weight_gradients_changes_nothing(prec):
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None)
     nb = synth.make_batch(B, H, W, config_id=1)
     batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
-    saved = layers.OVERLAP_WGRAD
+    saved = layers.OVERLAP_WGRAD, layers.LATE_WGRAD
     res = {}
     try:
-        for overlap in (False, True):
-            layers.OVERLAP_WGRAD = overlap
+        # False / True: one stream / the weight gradient beside its layer's data gradient; "late": started after the data
+        # gradient, i.e. beside the next layer's batch-norm backward (RCF_LATE_WGRAD=1; fp32 path)
+        for overlap in (False, True, "late"):
+            layers.OVERLAP_WGRAD, layers.LATE_WGRAD = bool(overlap), overlap == "late"
             m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
             shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
             m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
@@ -162,6 +164,6 @@ def test_second_stream_for_weight_gradients_changes_nothing(prec):
             torch.cuda.synchronize()
             res[overlap] = (losses, tr.fp.flat.clone())
     finally:
-        layers.OVERLAP_WGRAD = saved
-    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
-    assert torch.equal(res[False][1], res[True][1])
+        layers.OVERLAP_WGRAD, layers.LATE_WGRAD = saved
+    assert res[False][0] == res[True][0] == res["late"][0], (res[False][0], res[True][0], res["late"][0])
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][1], res["late"][1])
