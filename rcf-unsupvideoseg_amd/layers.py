@@ -322,11 +322,21 @@ class Conv2d(nn.Module):
                     ops.cast(dy, torch.bfloat16, out=d16[..., :dy.shape[3]])
                     dy = d16
                     wk = self._packed_weight(8)
+                done_dgrad = [False]
+
+                def dgrad():
+                    gx, beta = x.grad_slot()
+                    wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
+                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                          w_t_bf16=wt)
+                    done_dgrad[0] = True
                 if self.weight.requires_grad:
                     padded = wk is not self.weight
                     dw = torch.empty_like(wk) if padded else _param_grad(self.weight)
                     if OVERLAP_WGRAD and OVERLAP_WGRAD_BF16 and x.needs_grad and not padded:
                         side = _side_stream(dy.device)
+                        if LATE_WGRAD:
+                            dgrad()                   # see LATE_WGRAD: the weight gradient beside the next batch-norm backward
                         side.wait_stream(torch.cuda.current_stream(dy.device))
                         with torch.cuda.stream(side):
                             ops.conv2d_wgrad_bf16(x.t, dy, wk, dw, self.stride, self.padding, self.dilation, beta=1)
@@ -339,11 +349,8 @@ class Conv2d(nn.Module):
                         g = _param_grad(self.weight)
                         n = g.numel()
                         ops.copy2d(dw.permute(0, 2, 3, 1), n, g.permute(0, 2, 3, 1), n, 1, n, beta=1)
-                if x.needs_grad:
-                    gx, beta = x.grad_slot()
-                    wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
-                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                          w_t_bf16=wt)
+                if x.needs_grad and not done_dgrad[0]:
+                    dgrad()
             tape.push(bwd)
         return ya
 
