@@ -27,7 +27,7 @@ GF_PER_FRAME = 2043.3              # fwd+bwd algorithmic GFLOP
 BF16_MFMA_PEAK_TF = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
 X3_MFMA_PEAK_TF = 2500.0 / 6       # fp32 product = 6 bf16 partial products on the bf16 matrix cores (ViT GEMMs, attention)
 H2_MFMA_PEAK_TF = 2500.0 / 3       # convs: fp32 product = 3 fp16 partial products (operands split into fp16 pairs)
-PRIMING_STEPS = 2                  # untimed set-up steps before the warm-up (allocator / stream scratch)
+PRIMING_STEPS = int(os.environ.get("RCF_BENCH_PRIMING", "2"))   # untimed set-up steps before the warm-up (allocator / stream scratch)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E, 8 TB/s
 
 
@@ -310,6 +310,9 @@ def _self_launch(n):
 
 # bracket families (rcf_amd/ops.py) -> the kernel instance behind each
 FAMILIES_F32 = {
+    "conv_h2d_fwd": "conv_h2d_kernel<*,false,false> (forward of the bottlenecks' convs whose input the batch norm wrote as fp16 pair planes: both operands by LDS-DMA, no split, three LDS stages; incl. the kernels that sum its fused BN statistics)",
+    "conv_h2d_dgrad": "conv_h2d_kernel<*,*,true> (data gradient with dy as fp16 pair planes from the batch norm's backward, same kernel)",
+    "conv_wgrad_h2d": "igemm_wgrad_h2d_kernel<*,*,*> (weight gradient with x AND dy as fp16 pair planes: both operands by LDS-DMA, transposing LDS reads, 128x256 tile; incl. the split-K reduction)",
     "conv_h2p_fwd": "conv_h2p_kernel<false> (forward of the deep 3x3 layers: persistent, one wave per SIMD, 4-stage LDS ring, weights by LDS-DMA, fp16 pairs; incl. the kernels that sum its fused BN statistics)",
     "conv_h2p_dgrad": "conv_h2p_kernel<true> (data gradient of the deep 3x3 layers, same kernel)",
     "conv_x3_128x256": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (forward, fp16 pairs, 128x256 tile; incl. the two kernels that sum its fused BN statistics)",

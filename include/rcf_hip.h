@@ -62,49 +62,61 @@ typedef struct {
      * weights in BOTH reading orders; the wide, deep convs then run on the persistent LDS-DMA kernel (conv_h2p_kernel,
      * csrc/igemm_h2p.inc), the others on the kernels that read w_pairs / w_pairs_t.  Results are identical. */
     const void *w_pairs2, *w_pairs2_t;
+    /* Optional: a zeroed device scalar that receives (atomicMax) the raw bits of max |value| of the tensor the launch WRITES
+     * (forward: y; data gradient: dx, after the accumulation when beta = 1) -- the next consumer's operand range without a pass
+     * over the tensor.  Exact only for a launch that writes the whole tensor (no region). */
+    unsigned *amax_y;
+    /* RCF_CONV_* bits below; 0 = the library's own choices.  Per call, not process state: two host threads may launch with
+     * different flags at the same time. */
+    unsigned flags;
+    /* sizeof(rcf_conv_shape) as the CALLER compiled it.  Every entry point that takes the struct refuses (RCF_EINVAL) a size
+     * other than its own: a caller built against an older, shorter header cannot make the library read past its struct. */
+    unsigned struct_bytes;
 } rcf_conv_shape;
+
+/* weight gradient on 128 x 256 tiles (two workgroups per CU) even where the 256 x 256 tile (one workgroup per CU, 1.02 - 1.08 x
+ * alone on the chip) applies: for a launch that shares the chip with an HBM-bound kernel on another stream, whose workgroups
+ * need slots on the CUs (the late weight-gradient schedule of the training step) */
+#define RCF_CONV_WGRAD_TILE_128 0x1u
+/* Pre-split activation operands ("pair planes").  A tensor [N,H,W,C] (C % 16 == 0, contiguous) is stored as
+ * [pixel][h: C fp16 | m: C fp16] -- x * 2^k = h + m, the byte size and pixel pitch of the fp32 tensor it replaces -- with
+ * k = 14 - floor(log2(bound)) from the range scalar of the operand (amax_x / amax_dy), which for such a tensor is an UPPER BOUND
+ * its producer knew before writing it (rcf_bn_apply_mp / rcf_bn_bwd_apply_mp with RCF_BN_*_PLANES emit them).  The conv kernels
+ * then take both operands by LDS-DMA with no split of their own (csrc/igemm_h2d.inc; weights: rcf_conv_weight_pairs2_f32).
+ *   X_PLANES:  `x` of a forward / weight-gradient launch is in that format;   DY_PLANES: `dy` of a data- / weight-gradient launch.
+ * Needs the matching operand ranges and w_pairs2 / w_pairs2_t; RCF_EINVAL for shapes the plane kernels do not take. */
+#define RCF_CONV_X_PLANES 0x2u
+#define RCF_CONV_DY_PLANES 0x4u
+/* A/B and test switches (results are bit-identical, or identical up to the re-association of fp32 sums, in every setting):
+ *   H2P_NEVER / H2P_ALWAYS   the persistent LDS-DMA kernel (conv_h2p_kernel) never / whenever the shape is eligible (built-in
+ *                            rule: the deep 3x3 layers: K >= 2304, >= 32768 rows, <= 2 column tiles per 2304 of K)
+ *   NO_WGRAD_XCD             weight-gradient workgroups in plain grid order instead of XCD-aware (an XCD's workgroups share
+ *                            their pixel range)
+ *   NO_COLMAP                forward / data-gradient grids always as row bands per XCD (default: convs whose weight operand
+ *                            exceeds the XCDs' L2 many times over give every XCD its own column tiles)
+ *   KORDER_NATURAL           K runs tap-outer (the weight's memory order) instead of (channel chunk, tap, channel in chunk) on
+ *                            the 3x3 layers with >= 256 channels per tap.  The derived weight operands are written in the
+ *                            order the kernels walk: pass the same flag to the rcf_conv_weight_* / rcf_conv_weights_prepare_*
+ *                            call that builds them.
+ *   FP32_MFMA(v)             the exact fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32) with tuning variant v = 0..3 (bit 0:
+ *                            K-step 32, bit 1: row-major LDS tiles) instead of the fp16-pair / bf16-triple kernels; no regions,
+ *                            no fused statistics on this path */
+#define RCF_CONV_H2P_NEVER 0x8u
+#define RCF_CONV_H2P_ALWAYS 0x10u
+#define RCF_CONV_NO_WGRAD_XCD 0x20u
+#define RCF_CONV_NO_COLMAP 0x40u
+#define RCF_CONV_KORDER_NATURAL 0x80u
+#define RCF_CONV_FP32_MFMA(v) ((((unsigned)(v) & 3u) + 1u) << 12)
 
 /* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order
  * [K/16][Cout][4][h0 h1 h2 h3 m0 m1 m2 m3] with K = R*S*Cin padded to a multiple of 16 */
 size_t rcf_conv_weight_pairs_bytes(int Cout, int Cin, int R, int S);
 int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
-                              void *stream);
+                              unsigned flags, void *stream);
 
 size_t rcf_conv_weight_pairs2_bytes(int Cout, int Cin, int R, int S, int transpose);
 int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int R, int S, int transpose, const unsigned *amax_w,
-                               void *planes, void *stream);
-/* A/B switch of the persistent kernel: mode -1 built-in rule (taken when K >= min_k), 0 never, 1 whenever eligible
- * (non-strided, no bias / activation, Cout-side % 256 == 0, K % 16 == 0, >= 32768 rows); min_k <= 0 keeps the current one */
-int rcf_conv_set_h2p(int mode, int min_k);
-/* A/B switch of the stream kernel of the 1x1 convs (conv_h2s_kernel, csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1
- * whenever eligible (1x1, stride 1, whole tensor, Cout-side % 256 == 0, K % 64 == 0, K >= 192) */
-int rcf_conv_set_h2s(int mode);
-/* A/B switch of the weight-gradient kernels' workgroup -> (output tile, pixel range) mapping: 1 (default) the workgroups that
- * run together on one XCD read the same pixel range, 0 plain grid order.  Results are bit-identical either way. */
-int rcf_conv_set_wgrad_xcd(int mode);
-/* A/B switch of the weight gradients' tile, a bit mask: bit 0 (default on) the fp16-pair kernel takes 256 x 256 tiles on one
- * workgroup per CU where Cout and Cin are multiples of 256 (1.02 - 1.08 x the 128 x 256 tile on two workgroups: a third fewer
- * loads, splits, LDS writes and fragment reads per MFMA on a power-bound kernel), bit 1 (default off: 0.86 - 1.04 x) the bf16
- * kernel does.  Same K order: bit-identical when the split counts agree. */
-int rcf_conv_set_wgrad_big(int mode);
-/* A/B switch of the forward / data-gradient grids' XCD mapping: 1 (default) convs whose weight operand exceeds the XCDs' L2
- * many times over (the data gradient of the 2048- / 4096-channel decode-head convs) give every XCD its own COLUMN tiles of
- * all row tiles instead of its own band of row tiles; 0 always row bands.  Bit-identical results. */
-int rcf_conv_set_colmap(int mode);
-/* A/B switch of the K order of the forward / data-gradient convs: 1 (default) channel chunks of 64 outer, taps inner on the
- * 3x3 layers with more than 64 channels per tap, 0 tap outer (the weight's memory order).  The derived weight operands
- * (rcf_conv_weight_bf16, rcf_conv_weights_prepare_bf16) are written in the order the kernels walk them: rebuild them after
- * a change.  Sums are re-associated, not changed otherwise. */
-int rcf_conv_set_korder(int mode);
-/* Row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back; 1 (default) on tensors of 192 MB
- * and more eight bands (the conv kernels' XCD bands), forward apply and backward reduction downwards, backward apply upwards:
- * a kernel starts in what its producer touched last, which the 256 MB Infinity Cache still holds; 2 the same on every tensor of
- * 8192 rows and more (tests).  Element-wise outputs are bit-identical in every mode. */
-int rcf_bn_set_sweep(int mode);
-/* profiling labels: which kernel the last forward / data-gradient launch took (1: 128 x 256 family, 2: conv_h2p_kernel,
- * 3: conv_h2s_kernel).  A plain global: meaningful right after a launch from the same thread only. */
-int rcf_conv_last_kernel(void);
-
+                               void *planes, unsigned flags, void *stream);
 /* Batched weight preparation: the derived operands of EVERY conv weight of a model in three (fp16 pairs: ranges, forward
  * buffers, transposed buffers) or two (bf16: forward, transposed) launches instead of one per weight and layout -- they are
  * rebuilt after every optimizer step.  tab_*: device arrays of n entries {const float *w; void *out; unsigned *amax; int Cout,
@@ -113,8 +125,10 @@ int rcf_conv_last_kernel(void);
  * (rcf_conv_pairs2_useful).  Outputs are byte-identical to rcf_absmax_f32 / rcf_conv_weight_pairs2_f32 / rcf_conv_weight_bf16. */
 int rcf_conv_pairs2_useful(int Cout, int Cin, int R, int S, int transpose);
 int rcf_conv_weights_prepare_f32(const void *tab_absmax, int blocks_absmax, const void *tab_pairs, int blocks_pairs,
-                                 const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, void *stream);
-int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, void *stream);
+                                 const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, unsigned flags,
+                                 void *stream);
+int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, unsigned flags,
+                                  void *stream);
 
 /* amax[0] = max(amax[0], bits(max |x|)) over [rows][C] (row pitch `pitch`); the caller zeroes amax[0] first */
 int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream);
@@ -130,7 +144,10 @@ typedef struct {
     int y0, x0, h, w;     /* rectangle */
     int band;             /* 0: the whole rectangle; t > 0: only its border frame of thickness t (2t < h, w) */
 } rcf_conv_region;
-int rcf_conv_regions_available(void);     /* 1 while the split-bf16 kernels are selected (the default) */
+/* Which kernel family a forward (dgrad = 0) / data-gradient (dgrad = 1) launch with this shape, these operand pointers and
+ * flags takes: 0 the fp32-MFMA kernels, 1 the 128 x 256-tile family, 2 conv_h2p_kernel.  A pure function of its arguments --
+ * nothing is launched, no state is read (profiling labels). */
+int rcf_conv_kernel_of(const rcf_conv_shape *s, const rcf_conv_region *region, int dgrad);
 int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                               const rcf_conv_region *region, int act, float slope, int beta, void *stream);
 /* y = conv(x, w) (no bias, whole tensor) and, from the same kernel's epilogue, the batch-norm statistics of y:
@@ -142,7 +159,7 @@ size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s);
 /* the transposed ([Cin][R][S][Cout], K padded to whole K-steps) fp16-pair planes the data gradient contracts against;
  * rcf_conv2d_dgrad_workspace_bytes(s) bytes */
 int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w, void *planes,
-                                void *stream);
+                                unsigned flags, void *stream);
 int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
                              void *workspace, size_t workspace_bytes, void *stream);
 /* What a training-mode batch norm derives from its statistics (the per-channel constants of the normalisation, the
@@ -192,7 +209,8 @@ int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, float *dw, cons
  * rcf_conv_weight_bf16: the kernels' weight operand, K-step major [K/32][rows][32] bf16 (K zero-padded to a multiple of
  * 32); transpose = 0: rows = Cout, k = (r, s, cin) -- forward; transpose = 1: rows = Cin, k = (r, s, cout) -- data gradient. */
 size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, int transpose);
-int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, void *stream);
+int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, unsigned flags,
+                         void *stream);
 /* y (ydt: RCF_BF16 or RCF_F32, pitch s->y_pitch in its own elements) (+)= conv(x, w) + bias, act 0 none / 1 LeakyReLU.
  * w_bf16 = rcf_conv_weight_bf16(w, ..., transpose 0).  region: as rcf_conv2d_fwd_region_f32 (NULL = whole tensor).
  * sums != NULL (needs region == NULL, bias == NULL, act == beta == 0 and the workspace): the batch-norm statistics of the
@@ -209,16 +227,6 @@ int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_co
 size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region);
 int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, const rcf_conv_shape *s, const rcf_conv_region *region,
                           int beta, void *workspace, size_t workspace_bytes, void *stream);
-/* variant of the bf16 forward / data-gradient kernel for A/B measurements: -1 default (global -> LDS DMA loads placed among
- * the MFMAs of a K-step, three LDS stages, tile by output width), 4 the same with the loads issued ahead of the K-step's
- * MFMAs (also the weight gradient's), 5 DMA loads on a 256x256 tile, 6 / 7 four LDS stages on 256x256 / 128x256; 0..3
- * register-staged loads on 128x128 / 128x256 / 256x256 / 128x64 tiles.  Results are identical. */
-int rcf_conv_bf16_set_tile(int tile);
-
-/* tuning knob for A/B measurements of the conv kernels: bit0 K-step 32, bit1 row-major LDS tiles;
- * -1 restores the built-in default.  Results are identical up to fp32 summation order. */
-int rcf_conv_set_variant(int variant);
-
 /* ---- batch norm (training), fused ReLU / residual add / Dropout2d channel scale -----------------
  * Replaces (Sync)BatchNorm in models/resnet.py:159-162 and mmcv ConvModule's norm, the ReLU and
  * `out += identity` of models/resnet.py:268-300, and nn.Dropout2d of models/decode_head.py:84-85.
@@ -267,20 +275,37 @@ int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pi
  * activations.  The reference runs these layers under torch autocast (configs/rcf_stv2/rcf_stage1.yaml:57-60). */
 int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pitch, double *sums, void *workspace,
                     size_t workspace_bytes, void *stream);
+/* `flags` of the three streaming passes (per call; 0 = the library's own choices):
+ *   RCF_BN_SWEEP_OFF / RCF_BN_SWEEP_ALWAYS   row order (csrc/bn.hip struct Sweep): by default tensors of 192 MB and more are walked
+ *       in eight bands (the conv kernels' XCD bands), the forward apply and the backward reduction downwards, the backward apply
+ *       upwards -- a kernel starts in what its producer touched last, which the 256 MB Infinity Cache still holds; OFF: front to
+ *       back; ALWAYS: banded on every tensor of 8192 rows and more (tests).  Element-wise outputs are bit-identical.
+ *   RCF_BN_Y_PLANES_ONLY (apply, with planes_out)   y itself is not written (its only consumers are convs); y may be NULL.
+ *   RCF_BN_DX_PLANES (bwd_apply)   dx is written as fp16 pair planes instead of fp32 (dx_pitch == C).
+ * Pair planes (RCF_CONV_X_PLANES / RCF_CONV_DY_PLANES above): fp32 tensors only, C % 8 == 0, no chan_scale.  planes_out (apply):
+ * [rows][h: C fp16 | m: C fp16] of y * 2^k; the scale comes from an upper bound of |y| (resp. |dx|) that every workgroup derives
+ * from the per-channel constants, amax_x = the range of x (the conv epilogue's by-product) and amax_res / amax_dy = the ranges
+ * of the residual / of dy BEFORE reading an element; the bound's raw bits are left in *amax_out, which is what the consuming
+ * convs take as amax_x / amax_dy. */
+#define RCF_BN_SWEEP_OFF 0x1u
+#define RCF_BN_SWEEP_ALWAYS 0x2u
+#define RCF_BN_Y_PLANES_ONLY 0x4u
+#define RCF_BN_DX_PLANES 0x8u
 int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch, void *y, int ydt, int y_pitch,
                     long rows, int C, const float *mean, const float *invstd, const float *gamma, const float *beta,
                     int relu, const float *chan_scale, long rows_per_image, unsigned char *relu_mask,
-                    unsigned *amax_out, void *stream);
+                    unsigned *amax_out, void *planes_out, const unsigned *amax_x, const unsigned *amax_res, unsigned flags,
+                    void *stream);
 int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
                          int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
                          const unsigned char *relu_mask, const float *chan_scale, long rows_per_image, double *sums2,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
 int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
                         int y_pitch, void *dx, int dx_pitch, void *dres, int dres_pitch, int res_beta, long rows, int C,
                         const float *mean, const float *invstd, const float *gamma, int relu,
                         const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
                         const double *sums2, const double *sums2_local, double count, float *dgamma, float *dbeta,
-                        unsigned *amax_out, void *stream);
+                        unsigned *amax_out, const unsigned *amax_x, const unsigned *amax_dy, unsigned flags, void *stream);
 int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch, float *out, int beta, void *workspace,
                   size_t workspace_bytes, void *stream);
 
@@ -320,10 +345,9 @@ int rcf_copy2d_batched_f32(const float *src, long spitch, long sb0, long sb1, fl
  * either output may be NULL.  Splits a gradient into its interior / border-band parts (see rcf_conv_region). */
 int rcf_split_rect_f32(const float *src, float *inside, float *outside, int N, int H, int W, int C, int y0, int x0,
                        int h, int w, void *stream);
-/* A/B switch of the exact-2x forms of the bilinear resize kernels (a thread makes the 2 x 2 outputs of one source pixel from
- * 9 loads instead of 16; bit-identical): 1 default, 0 always the general kernels */
-int rcf_resize_set_2x(int mode);
-/* Mixed-precision forms (dt = RCF_F32 / RCF_BF16 storage of every tensor argument; `frame` 0 = the whole tensor) */
+/* Mixed-precision forms (dt = RCF_F32 / RCF_BF16 storage of every tensor argument; `frame` 0 = the whole tensor; -1 = the whole
+ * tensor on the general kernels even where the exact-2x forms apply -- a thread there makes the 2 x 2 outputs of one source pixel
+ * from 9 loads instead of 16, bit-identical -- for tests) */
 int rcf_maxpool3x3s2_fwd_mp(const void *x, void *y, int dt, uint8_t *argmax, int N, int H, int W, int C, int Ho, int Wo,
                             void *stream);
 int rcf_maxpool3x3s2_bwd_mp(const void *dy, const uint8_t *argmax, void *dx, int dt, int N, int H, int W, int C, int Ho,
@@ -347,9 +371,9 @@ int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int 
  * utils/warp_utils.py:84-94 (flow_warp; pad 0 = 'border', 1 = 'zeros'), :107-113 + :27-81
  * (get_occu_mask_backward), :97-104 (get_occu_mask_bidirection), models/amd/flow_loss.py:15-29 with
  * models/amd/loss_blocks.py:46-65 (L1 + SSIM photometric loss).  Planar NCHW fp32 as the reference. */
-/* 1 (default): RGB / border-mode calls take the tile kernels (lane = x, dword taps; bit-identical results);
- * 0: the per-pixel kernels every other call takes */
-int rcf_warp_set_variant(int variant);
+/* pad_mode: 0 border, 1 zeros.  RGB / border-mode calls take the tile kernels (lane = x, dword taps); pad_mode | RCF_WARP_PER_PIXEL
+ * keeps such a call on the per-pixel kernels every other call takes (bit-identical results; a per-call choice for tests) */
+#define RCF_WARP_PER_PIXEL 0x100
 int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W, int pad_mode,
                       void *stream);
 /* grads of flow_warp w.r.t. x (atomic scatter; dx must be zero-filled or hold a running sum) and flow */
@@ -389,9 +413,11 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
                  float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence, int iters,
                  int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,
                  void *stream);
-/* lattice build variant: 0 (default) packed 64-bit keys + block-local de-duplication when the key coordinates fit
- * 12 bits, 1 always the array-of-keys build.  Results are identical. */
-int rcf_crf_set_variant(int variant);
+/* lattice build, OR-ed into rcf_crf_soft_ex's `normalization` (a per-call choice; results are identical): default = packed
+ * 64-bit keys + block-local de-duplication when the key coordinates fit 12 bits; ARRAY = always the array-of-keys build;
+ * SMALL_TABLE = packed build whose first-attempt table is tiny, so every frame takes the overflow path (tests) */
+#define RCF_CRF_BUILD_ARRAY 0x100
+#define RCF_CRF_BUILD_SMALL_TABLE 0x200
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

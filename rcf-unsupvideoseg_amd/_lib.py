@@ -4,7 +4,7 @@ The product has NO CPU fallback: if the library is missing or a call fails, this
 """
 import ctypes
 import os
-from ctypes import c_int, c_long, c_float, c_double, c_void_p, c_size_t, c_char_p
+from ctypes import c_int, c_uint, c_long, c_float, c_double, c_void_p, c_size_t, c_char_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librcf_hip.so")
@@ -19,7 +19,21 @@ class ConvShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad", "dil",
                                      "x_pitch", "y_pitch")] + \
                [(n, ctypes.c_void_p) for n in ("amax_x", "amax_w", "amax_dy", "w_pairs", "w_pairs_t", "w_pairs2",
-                                                "w_pairs2_t")]
+                                                "w_pairs2_t", "amax_y")] + \
+               [("flags", ctypes.c_uint), ("struct_bytes", ctypes.c_uint)]
+
+
+# include/rcf_hip.h RCF_CONV_* flag bits
+CONV_WGRAD_TILE_128 = 0x1
+CONV_X_PLANES, CONV_DY_PLANES = 0x2, 0x4
+WARP_PER_PIXEL = 0x100
+BN_SWEEP_OFF, BN_SWEEP_ALWAYS, BN_Y_PLANES_ONLY, BN_DX_PLANES = 0x1, 0x2, 0x4, 0x8
+CONV_H2P_NEVER, CONV_H2P_ALWAYS = 0x8, 0x10
+CONV_NO_WGRAD_XCD, CONV_NO_COLMAP, CONV_KORDER_NATURAL = 0x20, 0x40, 0x80
+
+
+def CONV_FP32_MFMA(v):
+    return ((int(v) & 3) + 1) << 12
 
 
 class BnFinalize(ctypes.Structure):
@@ -58,7 +72,6 @@ PROTOS = {
     "rcf_conv2d_dgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv2d_wgrad_region_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_region_f32": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
-    "rcf_conv_regions_available": (c_int, []),
     "rcf_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, P,
                                 P]),
     "rcf_gemm_nt_batched_f32": (c_int, [P, c_int, c_long, c_long, P, c_int, c_long, c_long, P, c_int, c_long, c_long, c_int,
@@ -71,34 +84,24 @@ PROTOS = {
     "rcf_affinity_threshold_f32": (c_int, [P, c_long, c_int, c_float, c_float, P]),
     "rcf_ncut_value_grad_f32": (c_int, [P, c_long, c_int, P, P, P, c_int, P, P, P]),
     "rcf_clamp01_f32": (c_int, [P, c_int, P]),
-    "rcf_crf_set_variant": (c_int, [c_int]),
     "rcf_split_rect_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_absmax_f32": (c_int, [P, c_long, c_int, c_int, P, P]),
-    "rcf_conv_weight_pairs_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rcf_conv_weight_pairs_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_uint, P]),
     "rcf_conv_weight_pairs_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
-    "rcf_conv_weight_pairs_t_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "rcf_conv_weight_pairs_t_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_uint, P]),
     "rcf_conv_weight_pairs2_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "rcf_conv_weight_pairs2_f32": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
-    "rcf_conv_set_h2p": (c_int, [c_int, c_int]),
-    "rcf_conv_set_h2s": (c_int, [c_int]),
-    "rcf_conv_set_wgrad_xcd": (c_int, [c_int]),
-    "rcf_conv_set_wgrad_big": (c_int, [c_int]),
-    "rcf_conv_set_korder": (c_int, [c_int]),
-    "rcf_conv_set_colmap": (c_int, [c_int]),
-    "rcf_bn_set_sweep": (c_int, [c_int]),
-    "rcf_resize_set_2x": (c_int, [c_int]),
-    "rcf_conv_last_kernel": (c_int, []),
+    "rcf_conv_weight_pairs2_f32": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_uint, P]),
+    "rcf_conv_kernel_of": (c_int, [_CS, _CR, c_int]),
     "rcf_conv_pairs2_useful": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "rcf_conv_weights_prepare_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P]),
-    "rcf_conv_weights_prepare_bf16": (c_int, [P, c_int, P, c_int, c_int, P]),
+    "rcf_conv_weights_prepare_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_uint, P]),
+    "rcf_conv_weights_prepare_bf16": (c_int, [P, c_int, P, c_int, c_int, c_uint, P]),
     "rcf_conv2d_fwd_bnstats_f32": (c_int, [P, P, P, _CS, P, _BF, P, c_size_t, P]),
     "rcf_conv2d_fwd_bnstats_bf16": (c_int, [P, P, P, c_int, _CS, P, _BF, P, c_size_t, P]),
     "rcf_sum_partials_f64": (c_int, [P, c_int, c_int, P, P, P]),
     "rcf_conv2d_dgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
-    "rcf_conv_set_variant": (c_int, [c_int]),
     "rcf_conv2d_wgrad_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_wgrad_f32": (c_int, [P, P, P, _CS, c_int, P, c_size_t, P]),
     "rcf_bn_stats_workspace_bytes": (c_size_t, [c_long, c_int]),
@@ -151,11 +154,11 @@ PROTOS = {
     # mixed-precision (bf16 storage) forms
     "rcf_bn_stats_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, P, c_size_t, P]),
     "rcf_bn_apply_mp": (c_int, [P, c_int, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,
-                                P, P]),
+                                P, P, P, P, c_uint, P]),
     "rcf_bn_bwd_reduce_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, c_int, P, P, c_long,
-                                     P, P, c_size_t, P]),
+                                     P, P, c_size_t, c_uint, P]),
     "rcf_bn_bwd_apply_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P,
-                                    P, P, c_int, P, P, c_long, P, P, c_double, P, P, P, P]),
+                                    P, P, c_int, P, P, c_long, P, P, c_double, P, P, P, P, P, c_uint, P]),
     "rcf_colsum_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, P, c_size_t, P]),
     "rcf_maxpool3x3s2_fwd_mp": (c_int, [P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_maxpool3x3s2_bwd_mp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -168,16 +171,14 @@ PROTOS = {
     "rcf_copy2d_mp": (c_int, [P, c_int, c_long, P, c_int, c_long, c_long, c_int, c_int, P]),
     "rcf_split_rect_mp": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "rcf_conv_weight_bf16_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "rcf_conv_weight_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "rcf_conv_weight_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_uint, P]),
     "rcf_conv2d_fwd_stats_bf16_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_bf16": (c_int, [P, P, P, P, c_int, _CS, _CR, c_int, c_float, c_int, P, P, c_size_t, P]),
     "rcf_conv2d_dgrad_bf16_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_dgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv2d_wgrad_bf16_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
-    "rcf_conv_bf16_set_tile": (c_int, [c_int]),
     "rcf_eval_iou_counts_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
-    "rcf_warp_set_variant": (c_int, [c_int]),
     "rcf_aug_frames_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     "rcf_aug_flows_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
     "rcf_aug_masks_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
@@ -201,8 +202,6 @@ def load():
                 continue            # reported by missing_symbols(); calling it raises
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("RCF_BF16_TILE"):          # A/B knob of the bf16 forward / data-gradient tile (tools/bench_conv_bf16.py)
-            lib.rcf_conv_bf16_set_tile(int(os.environ["RCF_BF16_TILE"]))
         _lib = lib
     return _lib
 

@@ -48,12 +48,22 @@ class Bottleneck(nn.Module):
         self.bn3 = make_norm(norm_cfg, planes * 4)
         self.downsample = downsample
 
-    def fwd(self, x, tape, dist):
-        o = self.bn1.fwd(self.conv1.fwd(x, tape, stats=self.bn1.stats_request(dist)), tape, relu=True, dist=dist)
-        o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist)
+    def takes_planes(self):
+        """do this block's first convs read their input as fp16 pair planes when the producer supplies them?"""
+        return self.conv1.planes_ok() and (self.downsample is None or getattr(self.downsample, "0").planes_ok())
+
+    def fwd(self, x, tape, dist, emit_planes=False):
+        """emit_planes: the block's output is ALSO written as fp16 pair planes (the next block's conv1 / downsample read them).
+        Inside the block the outputs of bn1 / bn2 -- whose only readers are conv2 / conv3 and their weight gradients -- exist as
+        pair planes ONLY, and every conv that got its input so receives its output gradient so (layers.BatchNorm2d.fwd)."""
+        o = self.bn1.fwd(self.conv1.fwd(x, tape, stats=self.bn1.stats_request(dist)), tape, relu=True, dist=dist,
+                         planes="only" if self.conv2.planes_ok() else None)
+        o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist,
+                         planes="only" if self.conv3.planes_ok() else None)
         o = self.conv3.fwd(o, tape, stats=self.bn3.stats_request(dist))
         idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
-        return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist)   # relu(bn3 + identity)
+        return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist,          # relu(bn3 + identity)
+                            planes="both" if emit_planes else None)
 
 
 class Stage(nn.Module):
@@ -64,9 +74,11 @@ class Stage(nn.Module):
         for i, b in enumerate(blocks):
             self.add_module(str(i), b)
 
-    def fwd(self, x, tape, dist):
-        for b in self.children():
-            x = b.fwd(x, tape, dist)
+    def fwd(self, x, tape, dist, next_takes_planes=False):
+        blocks = list(self.children())
+        for i, b in enumerate(blocks):
+            nxt = blocks[i + 1].takes_planes() if i + 1 < len(blocks) else next_takes_planes
+            x = b.fwd(x, tape, dist, emit_planes=nxt)
         return x
 
 
@@ -121,7 +133,8 @@ class ResNet(nn.Module):
         outs = []
         for i in range(self.num_stages):
             tape.mark(f"layer{i + 1}")
-            x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist)
+            nxt = getattr(getattr(self, f"layer{i + 2}"), "0").takes_planes() if i + 1 < self.num_stages else False
+            x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist, next_takes_planes=nxt)
             if i in self.out_indices:
                 outs.append(x)
         return outs

@@ -18,9 +18,10 @@ def _check(t, name):
 
 
 def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
-                     want_q=False, want_nvert=False, symmetric=False):
+                     want_q=False, want_nvert=False, symmetric=False, build=0):
     """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2]).
-    symmetric: pydensecrf's DenseCRF2D kernel normalisation (NORMALIZE_SYMMETRIC) instead of tools/torchCRF's."""
+    symmetric: pydensecrf's DenseCRF2D kernel normalisation (NORMALIZE_SYMMETRIC) instead of tools/torchCRF's.
+    build: 0 default, 1 RCF_CRF_BUILD_ARRAY, 2 RCF_CRF_BUILD_SMALL_TABLE (identical results; tests)"""
     _check(rgb_u8, "rgbFeat")
     _check(unary, "unaryEnergy")
     n = rgb_u8.shape[0]
@@ -33,7 +34,7 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
     need = _lib.load().rcf_crf_workspace_bytes(W, H, n)
     ws = workspace(need, dev)
     _lib.call("rcf_crf_soft_ex", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
-              int(iters), int(bool(symmetric)), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
+              int(iters), int(bool(symmetric)) | (int(build) << 8), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
     res = (out,)
     if want_q:
         res += (q,)

@@ -34,14 +34,14 @@ struct Sweep {
         return b * band + (mode == 2 ? per - 1 - pos : pos) * group + w;
     }
 };
-int g_sweep = 1;      // rcf_bn_set_sweep: 0 plain, 1 the banded orders (forward apply falling, backward reduce falling, backward apply
-                      // rising) on tensors of 192 MB and more, 2 on every tensor of 8192 rows and more (tests)
+// The banded orders (forward apply falling, backward reduce falling, backward apply rising) apply to tensors of 192 MB and more;
+// the call's flags can switch them off (RCF_BN_SWEEP_OFF) or on for every tensor of 8192 rows and more (RCF_BN_SWEEP_ALWAYS: tests).
 // Tensors the cache holds whole are served from it in any order, and the banded walk costs them 3 - 5 % (measured per launch,
 // profiles/r03_bn_sweep.txt: launches under 80 us lose, those over 100 us gain 3 - 15 %): plain order below 192 MB.
-Sweep make_sweep(int mode, long rows, int group, long row_bytes) {
+Sweep make_sweep(int mode, long rows, int group, long row_bytes, unsigned flags) {
     Sweep s{0, 1, 0};
-    if (!g_sweep || mode == 0 || group <= 0 || 128 % group || rows < 8 * 1024 ||
-        (g_sweep == 1 && rows * row_bytes < (192L << 20)))
+    if ((flags & RCF_BN_SWEEP_OFF) || mode == 0 || group <= 0 || 128 % group || rows < 8 * 1024 ||
+        (!(flags & RCF_BN_SWEEP_ALWAYS) && rows * row_bytes < (192L << 20)))
         return s;
     const long mtiles = (rows + 127) / 128, mtiles8 = (mtiles + 7) / 8;
     s.mode = mode;
@@ -382,7 +382,43 @@ EwGeom ew_geom(long rows, int CV) {
     return g;
 }
 
-template <typename XT, typename YT, int V>
+// ---- fp16 pair planes (include/rcf_hip.h RCF_CONV_X_PLANES): x * 2^k = h + m, [pixel][h: C fp16 | m: C fp16]
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int pl_exponent(unsigned bound_bits) {          // csrc/igemm_conv.hip h2_exponent: the consumers' rule
+    const int e = (int)((bound_bits >> 23) & 0xffu);
+    if (bound_bits == 0u) return 0;
+    const int k = 14 - (e - 127);
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+__device__ __forceinline__ float pl_pow2(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+// h = fp16(v s) (s a power of two: the product is exact), m = fp16(v s - h) (the difference is exact in fp32): the values the
+// conv kernels' own split (split2h) produces
+__device__ __forceinline__ void pl_store4(char *pix, int C, int c0, const f32x4 v, float s) {
+    f16x4 h, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = v[e] * s;
+        h[e] = (_Float16)t;
+        m[e] = (_Float16)(t - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4 *>(pix + 2 * c0) = h;
+    *reinterpret_cast<f16x4 *>(pix + 2 * C + 2 * c0) = m;
+}
+// block-wide max of a non-negative float over all threads (every thread calls it; result in every thread)
+__device__ __forceinline__ float block_max_f(float v) {
+    __shared__ float sh_bm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) sh_bm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh_bm[0], sh_bm[1]), fmaxf(sh_bm[2], sh_bm[3]));
+}
+
+// PL: 0 y only; 1 y and its pair planes; 2 the pair planes only (the output's only consumers are convs).  The planes' scale comes
+// from an upper bound every workgroup derives from the per-channel constants before it reads a single element:
+//     |y_c| <= |gamma_c| invstd_c (max|x| + |mean_c|) + |beta_c| (+ max|residual|)
+// (max|x|: the conv epilogue's range of x; ReLU only lowers it).  Workgroup 0 leaves the bound in *amax: the consumers scale by it.
+template <typename XT, typename YT, int V, int PL = 0>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x, int x_pitch,
                                                        const YT *__restrict__ res, int r_pitch,
                                                        YT *__restrict__ y, int y_pitch, long rows, int C, int cvt, int rpb,
@@ -390,13 +426,26 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int relu, const float *__restrict__ scale, long rows_per_image,
                                                        unsigned char *__restrict__ mask,
-                                                       unsigned *__restrict__ amax, Sweep sw) {
+                                                       unsigned *__restrict__ amax, Sweep sw, char *__restrict__ planes = nullptr,
+                                                       const unsigned *__restrict__ amax_x = nullptr,
+                                                       const unsigned *__restrict__ amax_res = nullptr) {
     const int CV = C / V;
     const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
     const int cv = blockIdx.y * cvt + cx;
     const bool active = ry < rpb && cv < CV;
     const int c0 = cv * V;
     unsigned mx = 0u;
+    float pls = 1.f;                                   // 2^k of the planes
+    if constexpr (PL != 0) {
+        const float ax = __uint_as_float(*amax_x), ar = res ? __uint_as_float(*amax_res) : 0.f;
+        float b = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256)
+            b = fmaxf(b, fabsf(gamma[c]) * invstd[c] * (ax + fabsf(mean[c])) + fabsf(beta[c]));
+        b = (block_max_f(b) + ar) * 1.0000005f;        // the elements are rounded at every step of their own evaluation
+        const unsigned bits = __float_as_uint(b);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax = bits;
+        pls = pl_pow2(pl_exponent(bits));
+    }
     if (active) {
         const fvec<V> mu = ldv<float, V>(mean + c0), is = ldv<float, V>(invstd + c0);
         const fvec<V> ga = ldv<float, V>(gamma + c0), be = ldv<float, V>(beta + c0);
@@ -428,9 +477,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
 #pragma unroll
                 for (int h = 0; h < V / 4; ++h) o.q[h] *= sc.q[h];
             }
-            stv<YT, V>(y + r * y_pitch + c0, o);
+            if constexpr (PL != 2) stv<YT, V>(y + r * y_pitch + c0, o);
+            if constexpr (PL != 0) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+                for (int h = 0; h < V / 4; ++h) pl_store4(planes + r * (4L * C), C, c0 + 4 * h, o.q[h], pls);
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+            }
         };
         // l: position in the sweep (ascending in time), sw.row(l): the row it stands for (>= rows: a padding position)
         long l = (long)blockIdx.x * rpb + ry;
@@ -458,10 +512,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
             }
         }
     }
-    if (amax) block_amax(mx, amax);
+    if constexpr (PL == 0) {
+        if (amax) block_amax(mx, amax);
+    }
 }
 
-template <typename XT, typename YT, int V>
+// PL = 1: dx is written as fp16 pair planes (its only consumers are the conv's data and weight gradient).  Bound, per channel, from
+// constants known before the pass:   |dx_c| <= |gamma_c| invstd_c (max|g| + |mean g|_c + X_c |mean g xhat|_c),
+// X_c = (max|x| + |mean_c|) invstd_c >= max |xhat_c|, max|g| <= max|dy| (the mask and a 0 / 1-over-keep dropout scale are not
+// applied to the bound: no chan_scale on this path).  Workgroup 0 leaves the bound in *amax.
+template <typename XT, typename YT, int V, int PL = 0>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const YT *__restrict__ dy, int dy_pitch, const XT *__restrict__ x, int x_pitch, const YT *__restrict__ y,
     int y_pitch, XT *__restrict__ dx, int dx_pitch, YT *__restrict__ dres, int dres_pitch, int res_beta,
@@ -469,8 +529,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const float *__restrict__ gamma, int relu, const float *__restrict__ scale, long rows_per_image,
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
     float *__restrict__ dgamma, float *__restrict__ dbeta, const unsigned char *__restrict__ mask,
-    unsigned *__restrict__ amax, Sweep sw) {
+    unsigned *__restrict__ amax, Sweep sw, const unsigned *__restrict__ amax_x = nullptr,
+    const unsigned *__restrict__ amax_dy = nullptr) {
     const int CV = C / V;
+    float pls = 1.f;
+    if constexpr (PL != 0) {
+        const float ax = __uint_as_float(*amax_x), ag = __uint_as_float(*amax_dy);
+        const float ic = (float)(1.0 / count);
+        float b = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float is = invstd[c], X = (ax + fabsf(mean[c])) * is;
+            b = fmaxf(b, fabsf(gamma[c]) * is * (ag + fabsf((float)sums2[c] * ic) + X * fabsf((float)sums2[C + c] * ic)));
+        }
+        b = block_max_f(b) * 1.0000005f;
+        const unsigned bits = __float_as_uint(b);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax = bits;
+        pls = pl_pow2(pl_exponent(bits));
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         // parameter gradients come from THIS rank's sums: the data-parallel gradient all-reduce adds the ranks
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -519,9 +594,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
                 const float xh = (xv.q[h][k] - mu.q[h][k]) * is.q[h][k];
                 o.q[h][k] = ga.q[h][k] * is.q[h][k] * (g.q[h][k] - sg.q[h][k] - xh * sgx.q[h][k]);
             }
-            stv<XT, V>(dx + r * dx_pitch + c0, o);
+            if constexpr (PL != 0) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+                for (int h = 0; h < V / 4; ++h) pl_store4(reinterpret_cast<char *>(dx) + r * (4L * C), C, c0 + 4 * h, o.q[h], pls);
+            } else {
+                stv<XT, V>(dx + r * dx_pitch + c0, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+            }
             if (dres) {
                 YT *dr = dres + r * dres_pitch + c0;
                 if (res_beta) {
@@ -550,7 +630,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
             if (ra < rows) finish(ra, ldv<YT, V>(dy + ra * dy_pitch + c0), ldv<XT, V>(x + ra * x_pitch + c0));
         }
     }
-    if (amax) block_amax(mx, amax);
+    if constexpr (PL == 0) {
+        if (amax) block_amax(mx, amax);
+    }
 }
 
 template <typename XT, int V>
@@ -616,16 +698,6 @@ int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, 
     }
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32)), dim3(512), 0, st, partial, chunks, C, sums, fa);
     RCF_LAUNCH_CHECK();
-    return 0;
-}
-
-/* Row order of the streaming batch-norm kernels (struct Sweep above): 0 front to back; 1 (default; 2 = regardless of the tensor's
- * size, for tests) eight bands on tensors of 192 MB and more, the forward apply and
- * the backward reduction walking them downwards, the backward apply upwards -- each starts where its producer stopped, i.e.
- * in what the 256 MB Infinity Cache still holds.  Element-wise results are identical; the backward reduction groups its fp64
- * partial sums differently (same precision). */
-extern "C" int rcf_bn_set_sweep(int mode) {
-    g_sweep = mode < 0 || mode > 2 ? 1 : mode;
     return 0;
 }
 
@@ -716,23 +788,43 @@ extern "C" int rcf_bn_invstd_from_var_f32(const float *var, int C, float eps, fl
 extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch, void *y, int ydt,
                                int y_pitch, long rows, int C, const float *mean, const float *invstd,
                                const float *gamma, const float *beta, int relu, const float *chan_scale,
-                               long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *stream) {
-    if (!x || !y || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+                               long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *planes_out,
+                               const unsigned *amax_x, const unsigned *amax_res, unsigned flags, void *stream) {
+    const bool planes_only = planes_out && (flags & RCF_BN_Y_PLANES_ONLY);
+    if (!x || (!y && !planes_only) || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
     if (chan_scale && rows_per_image <= 0) return RCF_EINVAL;
+    if (planes_out) {
+        // pair planes: fp32 tensors, contiguous pixels of C % 8 == 0 channels, the input's range (and the residual's), a slot for
+        // the bound; no per-channel dropout scale (its maximum would have to enter the bound)
+        if (xdt != RCF_F32 || ydt != RCF_F32 || C % 8 || !amax_x || !amax_out || (residual && !amax_res) || chan_scale ||
+            !rcf_aligned16(planes_out))
+            return RCF_EINVAL;
+        const EwGeom g = ew_geom(rows, C / 4);
+        const Sweep sw = make_sweep(2, rows, g.rpb, (long)C * 4, flags);
+#define RCF_CALL(PLv)                                                                                                     \
+    hipLaunchKernelGGL((bn_apply_kernel<float, float, 4, PLv>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)x, x_pitch, \
+                       (const float *)residual, r_pitch, (float *)y, y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, \
+                       (const float *)nullptr, 1L, relu_mask, amax_out, sw, (char *)planes_out, amax_x, amax_res)
+        if (planes_only) RCF_CALL(2);
+        else RCF_CALL(1);
+#undef RCF_CALL
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec_width(xdt, ydt, C, x_pitch, y_pitch, residual ? r_pitch : 8, 8) == 8) {
         const EwGeom g = ew_geom(rows, C / 8);
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 8>), g.grid, dim3(256), 0,
                            rcf_stream(stream), (const bf16_t *)x, x_pitch, (const bf16_t *)residual, r_pitch, (bf16_t *)y,
                            y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, chan_scale,
-                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out, make_sweep(2, rows, g.rpb, (long)C * 2));
+                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out, make_sweep(2, rows, g.rpb, (long)C * 2, flags));
     } else {
         const EwGeom g = ew_geom(rows, C / 4);
 #define RCF_CALL(XT, YT)                                                                                                 \
     hipLaunchKernelGGL((bn_apply_kernel<XT, YT, 4>), g.grid, dim3(256), 0, rcf_stream(stream),                          \
                        (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, g.cvt, g.rpb,   \
                        mean, invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,  \
-                       amax_out, make_sweep(2, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
+                       amax_out, make_sweep(2, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4), flags))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
@@ -745,14 +837,14 @@ extern "C" int rcf_bn_apply_f32(const float *x, int x_pitch, const float *residu
                                 const float *gamma, const float *beta, int relu, const float *chan_scale,
                                 long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *stream) {
     return rcf_bn_apply_mp(x, RCF_F32, x_pitch, residual, r_pitch, y, RCF_F32, y_pitch, rows, C, mean, invstd, gamma, beta,
-                           relu, chan_scale, rows_per_image, relu_mask, amax_out, stream);
+                           relu, chan_scale, rows_per_image, relu_mask, amax_out, nullptr, nullptr, nullptr, 0u, stream);
 }
 
 extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch,
                                     const void *y, int y_pitch, long rows, int C, const float *mean,
                                     const float *invstd, int relu, const unsigned char *relu_mask,
                                     const float *chan_scale, long rows_per_image, double *sums2, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
+                                    size_t workspace_bytes, unsigned flags, void *stream) {
     if (!dy || !x || !mean || !invstd || !sums2 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (relu && !y && !relu_mask) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || (relu && !relu_mask && y_pitch % 4)) return RCF_EINVAL;
@@ -764,13 +856,13 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
         BwdOp<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)y, mean, invstd, chan_scale,
                                     dy_pitch, x_pitch, y_pitch, relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};
         hipLaunchKernelGGL((colreduce2_kernel<BwdOp<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0,
-                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 2));
+                           st, op, rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 2, flags));
     } else {
 #define RCF_CALL(XT, YT)                                                                                                    \
     BwdOp<XT, YT, 4> op{(const YT *)dy, (const XT *)x, (const YT *)y, mean, invstd, chan_scale, dy_pitch, x_pitch, y_pitch, \
                         relu, C, rows_per_image > 0 ? rows_per_image : 1, relu_mask, {}, {}};                               \
     hipLaunchKernelGGL((colreduce2_kernel<BwdOp<XT, YT, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,  \
-                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
+                       rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * (xdt == RCF_BF16 ? 2 : 4), flags))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
@@ -786,7 +878,7 @@ extern "C" int rcf_bn_bwd_reduce_f32(const float *dy, int dy_pitch, const float 
                                      const unsigned char *relu_mask, const float *chan_scale, long rows_per_image,
                                      double *sums2, void *workspace, size_t workspace_bytes, void *stream) {
     return rcf_bn_bwd_reduce_mp(dy, RCF_F32, dy_pitch, x, RCF_F32, x_pitch, y, y_pitch, rows, C, mean, invstd, relu,
-                                relu_mask, chan_scale, rows_per_image, sums2, workspace, workspace_bytes, stream);
+                                relu_mask, chan_scale, rows_per_image, sums2, workspace, workspace_bytes, 0u, stream);
 }
 
 extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch,
@@ -795,11 +887,26 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
                                    const float *gamma, int relu, const unsigned char *relu_mask,
                                    const float *chan_scale, long rows_per_image, const double *sums2,
                                    const double *sums2_local, double count, float *dgamma, float *dbeta,
-                                   unsigned *amax_out, void *stream) {
+                                   unsigned *amax_out, const unsigned *amax_x, const unsigned *amax_dy, unsigned flags,
+                                   void *stream) {
     if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || rows <= 0 || C <= 0 || C % 4 || count <= 0)
         return RCF_EINVAL;
     if (relu && !y && !relu_mask) return RCF_EINVAL;
     if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
+    if (flags & RCF_BN_DX_PLANES) {
+        // dx as fp16 pair planes (see rcf_bn_apply_mp): fp32 tensors, contiguous dx pixels, the ranges of x and dy, a slot for the bound
+        if (xdt != RCF_F32 || ydt != RCF_F32 || C % 8 || dx_pitch != C || !amax_x || !amax_dy || !amax_out || chan_scale ||
+            !rcf_aligned16(dx) || (relu && !relu_mask))
+            return RCF_EINVAL;
+        const EwGeom g = ew_geom(rows, C / 4);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float, 4, 1>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)dy,
+                           dy_pitch, (const float *)x, x_pitch, (const float *)y, y_pitch, (float *)dx, dx_pitch, (float *)dres,
+                           dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, (const float *)nullptr, 1L, sums2,
+                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out,
+                           make_sweep(1, rows, g.rpb, (long)C * 4, flags), amax_x, amax_dy);
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec_width(xdt, ydt, C, dy_pitch, x_pitch, dx_pitch, dres ? dres_pitch : 8) == 8 &&
         (!(relu && !relu_mask) || y_pitch % 8 == 0)) {
         const EwGeom g = ew_geom(rows, C / 8);
@@ -807,7 +914,7 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
                            rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (const bf16_t *)x, x_pitch, (const bf16_t *)y,
                            y_pitch, (bf16_t *)dx, dx_pitch, (bf16_t *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd,
                            gamma, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, sums2,
-                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 2));
+                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 2, flags));
     } else {
         const EwGeom g = ew_geom(rows, C / 4);
 #define RCF_CALL(XT, YT)                                                                                                     \
@@ -815,7 +922,7 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
                        (const YT *)dy, dy_pitch, (const XT *)x, x_pitch, (const YT *)y, y_pitch, (XT *)dx, dx_pitch,         \
                        (YT *)dres, dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, chan_scale,       \
                        rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma,     \
-                       dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4)))
+                       dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4), flags))
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }
@@ -831,7 +938,7 @@ extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *
                                     float *dgamma, float *dbeta, unsigned *amax_out, void *stream) {
     return rcf_bn_bwd_apply_mp(dy, RCF_F32, dy_pitch, x, RCF_F32, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch,
                                res_beta, rows, C, mean, invstd, gamma, relu, relu_mask, chan_scale, rows_per_image, sums2,
-                               sums2_local, count, dgamma, dbeta, amax_out, stream);
+                               sums2_local, count, dgamma, dbeta, amax_out, nullptr, nullptr, 0u, stream);
 }
 
 extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch, float *out, int beta, void *workspace,

@@ -27,7 +27,6 @@ namespace {
 constexpr int MLAB = 2;
 constexpr int PD_MAX = 5;
 constexpr double FIX_SCALE = 1099511627776.0;   // 2^40
-constexpr float FIX_INV = 1.0f / 1099511627776.0f;
 
 struct Lattice {           // device pointers of one potential, for all frames (frame stride in elements)
     int pd;
@@ -35,6 +34,8 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int W;                 // image width (N = W * H): the per-pixel kernels walk 16 x 16 tiles
     long E;                // entries per frame = N*(pd+1)
     float w;               // Potts weight
+    int build;             // per call (rcf_crf_soft_ex `normalization` bits): 0 packed build when the keys fit, 1 always the
+                           // array-of-keys build, 2 packed build whose first-attempt table is tiny (exercises the overflow path)
     uint4 *keys;           // [F][E]   5 x int16 packed, zero padded
     float *weight;         // [F][E]
     int *entries;          // [F][2E]  bucket -> representative slot (-1 empty)
@@ -1179,8 +1180,6 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
-int g_crf_variant = 0;     // 0: packed build when the keys fit, 1: always the array-of-keys build,
-                           // 2: packed build whose first-attempt table is tiny (exercises the overflow path)
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
 
 // kernels templated on the lattice dimension: the two potentials of the reference are pd = 2 and pd = 5
@@ -1210,8 +1209,8 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     const dim3 gpf(F, rcf_cdiv(W, 16) * rcf_cdiv(H, 16));        // (frames, 16 x 16 pixel tiles)
     const int nblk2 = scan_blocks(2 * L.E);
     // first attempt: 2^18 - 1 buckets (3 MB of keys + cursors per frame, room for 131 k distinct keys; measured at
-    // 480x854, T=5: 2^21 0.388, 2^19 0.371, 2^18 0.361 ms/frame); g_crf_variant 2 forces a tiny table (tests)
-    const long small = g_crf_variant == 2 ? 1021 : ((1L << 18) - 1);
+    // 480x854, T=5: 2^21 0.388, 2^19 0.371, 2^18 0.361 ms/frame); L.build 2 forces a tiny table (tests)
+    const long small = L.build == 2 ? 1021 : ((1L << 18) - 1);
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
@@ -1236,7 +1235,7 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     L.w = weight;
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
-    if (g_crf_variant != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
+    if (L.build != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
         if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) return e;
         return build_lattice_norm(L, F, st);
     }
@@ -1291,8 +1290,9 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
 
 int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float scomp_smooth, float sxy_smooth,
               float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *q_out,
-              int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0) {
+              int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0, int build = 0) {
     b.smooth.sym = b.app.sym = sym;                                // per call, not per process: concurrent callers differ
+    b.smooth.build = b.app.build = build;
     const bool has_s = scomp_smooth > 0.f && sxy_smooth > 0.f;     // torchcrf.cu:28
     const bool has_a = scomp_app > 0.f && sxy_app > 0.f;           // torchcrf.cu:41
     const long n = (long)F * W * H;
@@ -1331,13 +1331,6 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
 
 }  // namespace
 
-/* 0 (default): packed 64-bit-key lattice build whenever the key coordinates fit 12 bits; 1: always the array-of-keys
- * build (A/B measurements and tests; results are identical) */
-extern "C" int rcf_crf_set_variant(int v) {
-    g_crf_variant = v;
-    return 0;
-}
-
 extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
     if (W <= 0 || H <= 0 || batch <= 0) return 0;
     CrfBuffers b;
@@ -1347,14 +1340,14 @@ extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
 namespace {
 int crf_soft_impl(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
                   float scomp_app, float sxy_app, float srgb_app, int iters, int sym, int16_t *out_map, float *q_out,
-                  int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream) {
+                  int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream, int build = 0) {
     if (!rgb || !unary || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
     if ((long)W * H * 6 >= (1L << 30)) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_crf_workspace_bytes(W, H, batch) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
     CrfBuffers b;
     carve_all((char *)workspace, W, H, batch, b);
     return crf_infer(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
-                     q_out, nvert, b, rcf_stream(stream), sym);
+                     q_out, nvert, b, rcf_stream(stream), sym, build);
 }
 }  // namespace
 
@@ -1375,9 +1368,12 @@ extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, in
                                float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
                                int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
                                size_t workspace_bytes, void *stream) {
-    if (normalization != 0 && normalization != 1) return RCF_EINVAL;
+    // bits 8-9: lattice build (RCF_CRF_BUILD_*: tests and A/B measurements; identical results)
+    const int build = (normalization >> 8) & 3;
+    normalization &= 0xff;
+    if ((normalization != 0 && normalization != 1) || build == 3) return RCF_EINVAL;
     return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
-                         normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream);
+                         normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream, build);
 }
 
 extern "C" int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,

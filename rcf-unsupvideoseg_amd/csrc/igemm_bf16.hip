@@ -14,10 +14,7 @@
 #include <type_traits>
 #include "rcf_common.h"
 
-extern int rcf_g_wgrad_xcd;   // igemm_conv.hip: rcf_conv_set_wgrad_xcd
-extern int rcf_g_korder;      // igemm_conv.hip: rcf_conv_set_korder (rcf_common.h rcf_kchunk)
-extern int rcf_g_colmap;      // igemm_conv.hip: rcf_conv_set_colmap (rcf_common.h rcf_conv_tile)
-extern int rcf_g_wgrad_big_bf16;   // igemm_conv.hip: rcf_conv_set_wgrad_big bit 1
+// No mutable process state: the A/B choices travel in rcf_conv_shape.flags (RCF_CONV_*), per call.
 
 namespace {
 
@@ -54,6 +51,7 @@ struct ConvParams {
     int kch, rsch;                // K order (rcf_common.h rcf_kchunk): channel chunk width (Cs = natural order), taps * kch
     unsigned kch_magic, rsch_magic;
     int b_bytes;
+    unsigned flags;                       // rcf_conv_shape.flags of the call
     int ry0, rx0, rh, rw, rband, rr;      // region of the GEMM-row tensor (see igemm_conv.hip)
     double *stats;                        // forward only: per row tile, fp64 column sums | sums of squares
 };
@@ -1091,7 +1089,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
 // ------------------------------------------------------------------------------------------- host side
 // cout_mult: 8 where Cout is read or written as bf16 (16-byte accesses), 4 for the forward with fp32 output
 int check_shape(const rcf_conv_shape *s, int cout_mult = 8) {
-    if (!s) return RCF_EINVAL;
+    if (!s || s->struct_bytes != sizeof(rcf_conv_shape)) return RCF_EINVAL;      // a caller built against another header
     if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->R <= 0 || s->S <= 0) return RCF_EINVAL;
     // 16-byte loads of 8 bf16 channels: channel counts and pitches in multiples of 8
     if (s->Cin % 8 || s->Cout % cout_mult || s->x_pitch % 8 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
@@ -1120,28 +1118,27 @@ int set_region(ConvParams &p, const rcf_conv_region *r, int N, int H, int W) {
     return 0;
 }
 
-int g_bf16_tile = -1;      // -1: LDS-DMA kernels (128x64 / 128x128 / 128x256 by width), pieces interleaved with the MFMAs;
-                           // 4: the same with the pieces ahead of the MFMAs; 5: LDS-DMA 256x256 (512 threads);
-                           // register-staged A/B references: 0 128x128, 1 128x256, 2 256x256, 3 128x64
+inline bool korder_chunked(unsigned flags) { return !(flags & RCF_CONV_KORDER_NATURAL); }
 
-template <int MR, int NR, int WM, int WN, bool OBF, bool DMA = false, int NST = 3, int SCHED = 0>
+// LDS-DMA kernels (128x64 / 128x128 / 128x256 by output width), three stages, pieces interleaved with the MFMAs
+template <int MR, int NR, int WM, int WN, bool OBF>
 void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
-    p.colmap = p.Ncol % BN == 0 && rcf_colmap_pays(rcf_g_colmap, (long)p.M * p.Cs * 2, (long)p.K * p.Ncol * 2, p.mtiles, p.ntiles);
+    p.colmap = p.Ncol % BN == 0 && rcf_colmap_pays(!(p.flags & RCF_CONV_NO_COLMAP), (long)p.M * p.Cs * 2, (long)p.K * p.Ncol * 2, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
-    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
-    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
-    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, DMA, NST, SCHED>), grid, dim3(64 * WM * WN), 0, st, p);
+    if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
 template <bool OBF>
 int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     p.s_magic = magic_of(p.S);
     {
-        const int taps = p.K / p.Cs, kch = rcf_kchunk(rcf_g_korder, taps, p.Cs, RCF_KCHUNK_BF16);
+        const int taps = p.K / p.Cs, kch = rcf_kchunk(korder_chunked(p.flags), taps, p.Cs, RCF_KCHUNK_BF16);
         p.kch = kch ? kch : p.Cs;
         p.rsch = taps * p.kch;
         p.kch_magic = magic_of(p.kch);
@@ -1155,23 +1152,9 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     if (bbytes >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)bbytes;
     const bool strided = p.div > 1;
-    const int tile = g_bf16_tile;
-    // tiles 0-3: register-staged loads (A/B reference); default: LDS-DMA loads with three stages
-    if (tile == 3) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (tile == 0) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (tile == 2) launch_cfg<2, 4, 4, 2, OBF>(p, strided, dgrad, st);
-    else if (tile == 1) launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (tile == 4) {     // LDS-DMA, pieces issued ahead of the K-step's MFMAs (A/B reference of the interleaved form)
-        if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true>(p, strided, dgrad, st);
-        else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true>(p, strided, dgrad, st);
-        else launch_cfg<2, 4, 2, 2, OBF, true>(p, strided, dgrad, st);
-    }
-    else if (tile == 5) launch_cfg<2, 4, 4, 2, OBF, true>(p, strided, dgrad, st);       // 256x256, 8 waves
-    else if (tile == 6) launch_cfg<2, 4, 4, 2, OBF, true, 4>(p, strided, dgrad, st);    // 256x256, four LDS stages (128 KB)
-    else if (tile == 7) launch_cfg<2, 4, 2, 2, OBF, true, 4>(p, strided, dgrad, st);    // 128x256, four stages: one workgroup per CU
-    else if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
-    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
-    else launch_cfg<2, 4, 2, 2, OBF, true, 3, 1>(p, strided, dgrad, st);
+    if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
+    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
+    else launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1187,7 +1170,6 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     // 64 output channels take the 128-row LDS-DMA kernel too when the columns allow it: these layers are bound by memory,
     // not by the half-empty tile rows (layer1 3x3 64->64: 0.104 -> 0.093 ms, 1x1 256->64: 0.089 -> 0.068)
     pl.mr = (s->Cout > 64 || (s->Cout == 64 && pl.nr >= 2)) ? 2 : 1;
-    if (rcf_g_wgrad_big_bf16 && pl.nr == 4 && s->Cout % 256 == 0 && s->Cin % 256 == 0 && (g_bf16_tile < 0 || g_bf16_tile >= 4)) pl.mr = 4;
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = rcf_cdiv(ktot, 64 * pl.nr);
     const long RR = region_pixels(reg, s->Ho, s->Wo);
@@ -1201,7 +1183,7 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg) {
     const double px_us = 0.025 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
     const double wbytes = (double)s->Cout * ktot * 4.0;
     const long maxsk = M / 512 > 1 ? M / 512 : 1;
-    const long slots = pl.mr == 4 ? 256 : 512, hi = maxsk < 256 ? maxsk : 256;
+    const long slots = 512, hi = maxsk < 256 ? maxsk : 256;
     double best = 1e30;
     long sk = 1;
     for (long c = 1; c <= hi; ++c) {
@@ -1225,11 +1207,6 @@ bool region_ok(const rcf_conv_region *r, int H, int W) {
 }
 
 }  // namespace
-
-extern "C" int rcf_conv_bf16_set_tile(int tile) {
-    g_bf16_tile = tile;
-    return 0;
-}
 
 extern "C" size_t rcf_conv_weight_bf16_bytes(int Cout, int Cin, int R, int S, int transpose) {
     if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return 0;
@@ -1271,22 +1248,24 @@ __global__ void __launch_bounds__(256) wprep_bf16_kernel(const rcf_wprep_entry *
 
 /* Batched rcf_conv_weight_bf16 for every weight of a model: two launches (forward operands, transposed operands).
  * tab_*: device arrays of n rcf_wprep_entry with first_block / nblocks filled per launch. */
-extern "C" int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n, void *stream) {
+extern "C" int rcf_conv_weights_prepare_bf16(const void *tab_fwd, int blocks_fwd, const void *tab_t, int blocks_t, int n,
+                                             unsigned flags, void *stream) {
     if (!tab_fwd || !tab_t || n <= 0 || blocks_fwd <= 0 || blocks_t <= 0) return RCF_EINVAL;
     hipStream_t st = rcf_stream(stream);
-    hipLaunchKernelGGL(wprep_bf16_kernel<false>, dim3((unsigned)blocks_fwd), dim3(256), 0, st, (const rcf_wprep_entry *)tab_fwd, n, rcf_g_korder);
-    hipLaunchKernelGGL(wprep_bf16_kernel<true>, dim3((unsigned)blocks_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_t, n, rcf_g_korder);
+    hipLaunchKernelGGL(wprep_bf16_kernel<false>, dim3((unsigned)blocks_fwd), dim3(256), 0, st, (const rcf_wprep_entry *)tab_fwd, n, (int)korder_chunked(flags));
+    hipLaunchKernelGGL(wprep_bf16_kernel<true>, dim3((unsigned)blocks_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_t, n, (int)korder_chunked(flags));
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, void *stream) {
+extern "C" int rcf_conv_weight_bf16(const float *w, int Cout, int Cin, int R, int S, int transpose, void *out, unsigned flags,
+                                    void *stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(out)) return RCF_EINVAL;
     const long n = (long)rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, transpose) / 2;
     const long blocks = (n + 1023) / 1024;
     const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
-    if (transpose) hipLaunchKernelGGL(weight_bf16_kernel<true>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, rcf_g_korder);
-    else hipLaunchKernelGGL(weight_bf16_kernel<false>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, rcf_g_korder);
+    if (transpose) hipLaunchKernelGGL(weight_bf16_kernel<true>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, (int)korder_chunked(flags));
+    else hipLaunchKernelGGL(weight_bf16_kernel<false>, grid, dim3(256), 0, rcf_stream(stream), w, (bf16_t *)out, Cout, Cin, R * S, (int)korder_chunked(flags));
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1305,6 +1284,7 @@ static int conv2d_fwd_bf16_impl(const void *x, const void *w_bf16, const float *
     if (!x || !w_bf16 || !y || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y)) return RCF_EINVAL;
     if (ydt == RCF_BF16 ? (s->y_pitch % 8) : (s->y_pitch % 4)) return RCF_EINVAL;
     ConvParams p{};
+    p.flags = s->flags;
     p.A = (const bf16_t *)x; p.Bw = (const bf16_t *)w_bf16; p.bias = bias; p.Y = y;
     p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
     p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
@@ -1355,12 +1335,13 @@ extern "C" int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, c
     if (!wt) {
         const size_t need = rcf_conv2d_dgrad_bf16_workspace_bytes(s);
         if (!workspace || workspace_bytes < need || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
-        if (int e = rcf_conv_weight_bf16(w, s->Cout, s->Cin, s->R, s->S, 1, workspace, stream)) return e;
+        if (int e = rcf_conv_weight_bf16(w, s->Cout, s->Cin, s->R, s->S, 1, workspace, s->flags, stream)) return e;
         wt = workspace;
     } else if (!rcf_aligned16(wt)) {
         return RCF_EINVAL;
     }
     ConvParams p{};
+    p.flags = s->flags;
     p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)wt; p.bias = nullptr; p.Y = dx;
     p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
     p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
@@ -1400,8 +1381,8 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     p.Ktot = s->R * s->S * s->Cin;
-    p.sched = g_bf16_tile == 4 ? 0 : 1;
-    p.xcd_map = rcf_g_wgrad_xcd;
+    p.sched = 1;
+    p.xcd_map = (s->flags & RCF_CONV_NO_WGRAD_XCD) ? 0 : 1;
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), 1u, (unsigned)pl.splitk);
 #define RCF_WG(MRv, NRv)                                                                              \
     do {                                                                                              \
@@ -1409,7 +1390,7 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
         else hipLaunchKernelGGL((wgrad_bf16_kernel<MRv, NRv, false>), grid, dim3(256), 0, st, p);        \
     } while (0)
     const bool onetap = s->Cin % (64 * pl.nr) == 0;
-    p.cblocks = onetap && s->R * s->S > 1 && rcf_g_wgrad_xcd ? s->Cin / (64 * pl.nr) : 0;
+    p.cblocks = onetap && s->R * s->S > 1 && p.xcd_map ? s->Cin / (64 * pl.nr) : 0;
 #define RCF_WGD(NRv)                                                                                              \
     do {                                                                                                          \
         if (region && onetap) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);   \
@@ -1417,14 +1398,8 @@ extern "C" int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, c
         else if (onetap) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, false, true>), grid, dim3(256), 0, st, p);       \
         else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<NRv, false, false>), grid, dim3(256), 0, st, p);                  \
     } while (0)
-    const bool dma = g_bf16_tile < 0 || g_bf16_tile >= 4;      // tiles 0-3 select the register-staged references
-    if (pl.mr == 4) {
-        if (region) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<4, true, true, 4>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<4, false, true, 4>), grid, dim3(256), 0, st, p);
-    } else if (pl.mr == 2 && pl.nr == 4 && dma) RCF_WGD(4);
-    else if (pl.mr == 2 && pl.nr == 2 && dma) RCF_WGD(2);
-    else if (pl.mr == 2 && pl.nr == 4) RCF_WG(2, 4);
-    else if (pl.mr == 2 && pl.nr == 2) RCF_WG(2, 2);
+    if (pl.mr == 2 && pl.nr == 4) RCF_WGD(4);
+    else if (pl.mr == 2 && pl.nr == 2) RCF_WGD(2);
     else if (pl.mr == 2) RCF_WG(2, 1);
     else if (pl.nr == 4) RCF_WG(1, 4);
     else if (pl.nr == 2) RCF_WG(1, 2);

@@ -24,10 +24,8 @@
 
 #include <cstdlib>
 
-int rcf_g_wgrad_xcd = 1;      // rcf_conv_set_wgrad_xcd; read by igemm_bf16.hip too
-int rcf_g_wgrad_big_bf16 = 0; // rcf_conv_set_wgrad_big bit 1: the bf16 weight gradient's 256 x 256 tile (measured 0.86 - 1.04 x: off)
-int rcf_g_colmap = 1;         // rcf_conv_set_colmap: rcf_common.h rcf_conv_tile / rcf_colmap_pays
-int rcf_g_korder = 1;         // rcf_conv_set_korder: K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk)
+// No mutable process state in this file: every choice a caller can influence travels in rcf_conv_shape.flags (include/rcf_hip.h
+// RCF_CONV_*), per call.
 
 namespace {
 
@@ -60,7 +58,8 @@ struct IgemmParams {
     unsigned kch_magic, rsch_magic;
     int colmap;                   // rcf_common.h rcf_conv_tile: 1 = an XCD owns column tiles, not a band of row tiles
     int b_bytes;                  // split-bf16 kernels: size of the weight operand (buffer descriptor range)
-    int dbg;                      // timing experiments only (tools/bench_conv.py): 1 = no global loads after the first K-step
+    unsigned flags;               // rcf_conv_shape.flags of the call (RCF_CONV_*)
+    int a_split;                  // conv_h2d_kernel: A holds fp16 pair planes ([pixel][h: C fp16 | m: C fp16], scale from amax_a)
     // split-bf16 kernels: the GEMM rows are the pixels of the rectangle [ry0, ry0+rh) x [rx0, rx0+rw) of every image
     // of the [N, Ho, Wo] row tensor (M = N*rh*rw); the full tensor is the rectangle (0, 0, Ho, Wo)
     int ry0, rx0, rh, rw;
@@ -533,6 +532,178 @@ constexpr unsigned X3_OOB = 0x80000000u;      // byte offset beyond every descri
 // `off` if ok == 1, an out-of-range offset if ok == 0: arithmetic (a select on a load's address tends to become a branch)
 __device__ __forceinline__ unsigned x3_oob_unless(unsigned off, int ok) { return (off & ~X3_OOB) | ((unsigned)(ok - 1) & X3_OOB); }
 
+// The epilogue of the transposed-accumulator conv kernels (igemm_conv_x3_kernel, conv_h2d_kernel): a lane owns pixel lane&31 of
+// each row tile and, per register quad, output channels 8g + 4(lane>>5) .. +3 of each column tile -- 16-byte stores, the region walk
+// once per pixel; scaling back by the operands' powers of two (fp16 pairs), bias / activation / accumulate, the fused batch-norm
+// statistics (column sums over pixels = lanes: a reduce-scatter butterfly) and the output's range.  `smem`: the kernel's LDS,
+// free once every wave is past its K-loop (the statistics fold reuses it).
+template <int MR, int NR, int WM, int WN, bool DGRAD, int NP>
+__device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&acc)[MR][NR], char *smem, int tile_m, int m0, int n0,
+                                                 int ka, int kb) {
+    constexpr int NT = 64 * WM * WN, BN = 32 * NR * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int arow0 = wm * 32 * MR, brow0 = wn * 32 * NR;
+    const int HoWo = p.rr;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
+    const bool want_stats = !DGRAD && p.stats != nullptr;
+    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
+    unsigned tmax = 0u;
+    // transposed accumulators (mma_x3 SWAP): lane = pixel (lane&31) of each row tile, registers 4g..4g+3 = output
+    // channels 8g + 4(lane>>5) .. +3 of each column tile: 16-byte stores, the region walk once per pixel
+    long lin[MR];
+    bool rowok[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int row = m0 + arow0 + mr * 32 + l31;
+        rowok[mr] = row < p.M;
+        lin[mr] = row;
+        if (rowok[mr] && !full) {
+            const int n = row / HoWo;
+            int y, x;
+            region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
+            lin[mr] = ((long)n * p.Ho + y) * p.Wo + x;
+        }
+    }
+    double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
+    if (want_stats) __syncthreads();                      // every wave is done with the operand stages
+    // The common case -- a whole column tile, no bias, no activation (every conv -> batch norm pair and every data
+    // gradient of the step) -- as straight-line code: the general loop below tests columns, bias, activation and beta
+    // per quad and per element, which the compiler turns into ~170 instructions in four basic blocks per 16-byte
+    // store; with 32 quads per thread that was three times the instructions of a 16-step K-loop (the 1x1 layers).
+    const bool lean = NP == 2 && p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        float cs[16], cq[16];                             // this lane's pixels: sums / sums of squares per channel register
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+        if (lean) {
+            // BETA: accumulate into the output; EXTRA: the by-products are wanted (batch-norm statistics of a forward
+            // conv, the output's range of a ViT GEMM) -- a data gradient wants neither: scale, (add,) store
+            auto quads = [&](auto BETA_, auto EXTRA_) {
+                constexpr bool BETA = decltype(BETA_)::value, EXTRA = decltype(EXTRA_)::value;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    if (!rowok[mr]) continue;
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh + nr * 32);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                        v = (v * inv_a) * inv_b;
+                        if (BETA) v += dst[2 * g];
+                        dst[2 * g] = v;
+                        if (EXTRA) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                                cs[4 * g + e] += v[e];
+                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                            }
+                        }
+                    }
+                }
+            };
+            const bool extra = want_stats || p.amax_out != nullptr;
+            if (p.beta) { if (extra) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
+            else { if (extra) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
+        } else {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            if (!rowok[mr]) continue;
+            float *drow = p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = n0 + brow0 + nr * 32 + 8 * g + 4 * kh;
+                if (c >= p.Ncol) continue;
+                f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                if constexpr (NP == 2) v = (v * inv_a) * inv_b;
+                const bool whole = c + 3 < p.Ncol;               // conv channels come in quads; a GEMM's N need not
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.bias && (whole || c + e < p.Ncol)) v[e] += p.bias[c + e];
+                    if (p.act == 1) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                    else if (p.act == 2) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+                }
+                float *dq = drow + nr * 32 + 8 * g;
+                if (whole) {
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(dq);
+                    if (p.beta) v += *dst;
+                    *dst = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.Ncol) {
+                            if (p.beta) v[e] += dq[e];
+                            dq[e] = v[e];
+                        } else {
+                            v[e] = 0.f;
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                    cs[4 * g + e] += v[e];
+                    cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                }
+            }
+        }
+        }
+        if (want_stats) {                                 // block-uniform
+            // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly -- at every
+            // step a lane keeps the half of its registers its lane bit selects and adds the partner's copy of them
+            // (16 + 8 + 4 + 2 + 1 values move instead of 5 x 16); bit 0 of the lane ends up redundant.
+            const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+            float s8[8], q8[8], s4[4], q4[4], s2[2], q2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s8[i] = (b4 ? cs[8 + i] : cs[i]) + __shfl_xor(b4 ? cs[i] : cs[8 + i], 16);
+                q8[i] = (b4 ? cq[8 + i] : cq[i]) + __shfl_xor(b4 ? cq[i] : cq[8 + i], 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s4[i] = (b3 ? s8[4 + i] : s8[i]) + __shfl_xor(b3 ? s8[i] : s8[4 + i], 8);
+                q4[i] = (b3 ? q8[4 + i] : q8[i]) + __shfl_xor(b3 ? q8[i] : q8[4 + i], 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                s2[i] = (b2 ? s4[2 + i] : s4[i]) + __shfl_xor(b2 ? s4[i] : s4[2 + i], 4);
+                q2[i] = (b2 ? q4[2 + i] : q4[i]) + __shfl_xor(b2 ? q4[i] : q4[2 + i], 4);
+            }
+            float s1 = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 2);
+            float q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2);
+            s1 += __shfl_xor(s1, 1);
+            q1 += __shfl_xor(q1, 1);
+            if ((lane & 1) == 0) {
+                const int r = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);     // accumulator register = channel
+                const int ch = brow0 + nr * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                red[(wm * BN + ch) * 2] = (double)s1;
+                red[(wm * BN + ch) * 2 + 1] = (double)q1;
+            }
+        }
+    }
+    if (p.amax_out) {                                     // block-uniform
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o));
+        if (lane == 0 && tmax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, tmax);
+    }
+    if (want_stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            if (n0 + c >= p.Ncol) continue;
+            double sv = 0, qv = 0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                sv += red[(w * BN + c) * 2];
+                qv += red[(w * BN + c) * 2 + 1];
+            }
+            double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
+            o[0] = sv;
+            o[p.Ncol] = qv;
+        }
+    }
+}
+
 // forward / dgrad with k-contiguous weights B[j][k] (dgrad: the [Cin][R][S][Cout] transposed copy).
 // Workgroup = WM x WN waves, each owning MR x NR accumulator tiles of 32x32: tile (32 MR WM) x (32 NR WN).
 // Global loads go through buffer descriptors (32-bit byte offsets; an invalid tap / row / K-tail gets an
@@ -620,8 +791,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
     // A (activations) comes from HBM: its loads run TWO K-steps ahead (two register sets, ping-pong by the parity
     // of the step); B (weights, L2 resident) one step ahead.
     f32x4 ra[2][A_PASS], rb[B_PASS];
-    const unsigned dbg_oob = p.dbg == 1 ? X3_OOB : 0u;     // timing experiment: every load out of range
-    const unsigned dbg_win = p.dbg == 2 ? 0xfff0u : ~0u;   // timing experiment: activation loads from one 64 KB window
 
     auto load_a = [&](int kt, f32x4 (&dst)[A_PASS]) {
         const int k = kt * BKT + kq * 4;
@@ -650,7 +819,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
                 off = abase[i] + tapoff;
             }
             // invalid -> offset with bit 31 set (beyond num_records): the load returns zeros without touching memory
-            const unsigned bo = (((unsigned)off * 4u) & ~X3_OOB & dbg_win) | ((unsigned)(v - 1) & X3_OOB) | dbg_oob;
+            const unsigned bo = (((unsigned)off * 4u) & ~X3_OOB) | ((unsigned)(v - 1) & X3_OOB);
             dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)bo, 0, 0));
         }
     };
@@ -667,7 +836,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
             const int rs = fast_div(rem, p.kch_magic);
             k4 = (unsigned)(rs * p.Cs + q * p.kch + (rem - rs * p.kch)) * 4u;
         }
-        const unsigned koob = ((unsigned)((int)(k < p.K) - 1) & X3_OOB) | dbg_oob;
+        const unsigned koob = (unsigned)((int)(k < p.K) - 1) & X3_OOB;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i)
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)((bbase[i] + k4) | koob), 0, 0));
@@ -765,174 +934,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
-    // epilogue (MFMA C/D layout: column lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5) of each 32 x 32 tile)
-    const int l31 = lane & 31, kh = lane >> 5;
-    const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
-    const bool want_stats = !DGRAD && p.stats != nullptr;
-    const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
-    if constexpr (TR) {
-        unsigned tmax = 0u;
-        // transposed accumulators (mma_x3 SWAP): lane = pixel (lane&31) of each row tile, registers 4g..4g+3 = output
-        // channels 8g + 4(lane>>5) .. +3 of each column tile: 16-byte stores, the region walk once per pixel
-        long lin[MR];
-        bool rowok[MR];
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            const int row = m0 + arow0 + mr * 32 + l31;
-            rowok[mr] = row < p.M;
-            lin[mr] = row;
-            if (rowok[mr] && !full) {
-                const int n = row / HoWo;
-                int y, x;
-                region_yx(row - n * HoWo, p.ry0, p.rx0, p.rh, p.rw, p.rband, y, x);
-                lin[mr] = ((long)n * p.Ho + y) * p.Wo + x;
-            }
-        }
-        double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
-        if (want_stats) __syncthreads();                      // every wave is done with the operand stages
-        // The common case -- a whole column tile, no bias, no activation (every conv -> batch norm pair and every data
-        // gradient of the step) -- as straight-line code: the general loop below tests columns, bias, activation and beta
-        // per quad and per element, which the compiler turns into ~170 instructions in four basic blocks per 16-byte
-        // store; with 32 quads per thread that was three times the instructions of a 16-step K-loop (the 1x1 layers).
-        const bool lean = NP == 2 && p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-            float cs[16], cq[16];                             // this lane's pixels: sums / sums of squares per channel register
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
-            if (lean) {
-                // BETA: accumulate into the output; EXTRA: the by-products are wanted (batch-norm statistics of a forward
-                // conv, the output's range of a ViT GEMM) -- a data gradient wants neither: scale, (add,) store
-                auto quads = [&](auto BETA_, auto EXTRA_) {
-                    constexpr bool BETA = decltype(BETA_)::value, EXTRA = decltype(EXTRA_)::value;
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) {
-                        if (!rowok[mr]) continue;
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh + nr * 32);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
-                            v = (v * inv_a) * inv_b;
-                            if (BETA) v += dst[2 * g];
-                            dst[2 * g] = v;
-                            if (EXTRA) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    tmax = max(tmax, __float_as_uint(fabsf(v[e])));
-                                    cs[4 * g + e] += v[e];
-                                    cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
-                                }
-                            }
-                        }
-                    }
-                };
-                const bool extra = want_stats || p.amax_out != nullptr;
-                if (p.beta) { if (extra) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
-                else { if (extra) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
-            } else {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                if (!rowok[mr]) continue;
-                float *drow = p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = n0 + brow0 + nr * 32 + 8 * g + 4 * kh;
-                    if (c >= p.Ncol) continue;
-                    f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
-                    if constexpr (NP == 2) v = (v * inv_a) * inv_b;
-                    const bool whole = c + 3 < p.Ncol;               // conv channels come in quads; a GEMM's N need not
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (p.bias && (whole || c + e < p.Ncol)) v[e] += p.bias[c + e];
-                        if (p.act == 1) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-                        else if (p.act == 2) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
-                    }
-                    float *dq = drow + nr * 32 + 8 * g;
-                    if (p.dbg == 4) {
-                        // timing experiment (results are garbage): the same bytes as lane-linear 1 KB runs -- is the epilogue
-                        // bound by its store pattern (32-byte pieces of 32 different pixel rows per instruction)?
-                        const long tl = (long)tile_m % (p.mtiles - 1) * p.ntiles + tile_n;       // stays inside the output tensor
-                        dq = p.Y + ((tl * (MR * WM) + (wm * MR + mr)) * (NR * WN * 4) + (wn * NR + nr) * 4 + g) * 256 + lane * 4;
-                    }
-                    if (whole) {
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(dq);
-                        if (p.beta) v += *dst;
-                        *dst = v;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c + e < p.Ncol) {
-                                if (p.beta) v[e] += dq[e];
-                                dq[e] = v[e];
-                            } else {
-                                v[e] = 0.f;
-                            }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        tmax = max(tmax, __float_as_uint(fabsf(v[e])));
-                        cs[4 * g + e] += v[e];
-                        cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
-                    }
-                }
-            }
-            }
-            if (want_stats) {                                 // block-uniform
-                // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly -- at every
-                // step a lane keeps the half of its registers its lane bit selects and adds the partner's copy of them
-                // (16 + 8 + 4 + 2 + 1 values move instead of 5 x 16); bit 0 of the lane ends up redundant.
-                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-                float s8[8], q8[8], s4[4], q4[4], s2[2], q2[2];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s8[i] = (b4 ? cs[8 + i] : cs[i]) + __shfl_xor(b4 ? cs[i] : cs[8 + i], 16);
-                    q8[i] = (b4 ? cq[8 + i] : cq[i]) + __shfl_xor(b4 ? cq[i] : cq[8 + i], 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s4[i] = (b3 ? s8[4 + i] : s8[i]) + __shfl_xor(b3 ? s8[i] : s8[4 + i], 8);
-                    q4[i] = (b3 ? q8[4 + i] : q8[i]) + __shfl_xor(b3 ? q8[i] : q8[4 + i], 8);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    s2[i] = (b2 ? s4[2 + i] : s4[i]) + __shfl_xor(b2 ? s4[i] : s4[2 + i], 4);
-                    q2[i] = (b2 ? q4[2 + i] : q4[i]) + __shfl_xor(b2 ? q4[i] : q4[2 + i], 4);
-                }
-                float s1 = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 2);
-                float q1 = (b1 ? q2[1] : q2[0]) + __shfl_xor(b1 ? q2[0] : q2[1], 2);
-                s1 += __shfl_xor(s1, 1);
-                q1 += __shfl_xor(q1, 1);
-                if ((lane & 1) == 0) {
-                    const int r = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);     // accumulator register = channel
-                    const int ch = brow0 + nr * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    red[(wm * BN + ch) * 2] = (double)s1;
-                    red[(wm * BN + ch) * 2 + 1] = (double)q1;
-                }
-            }
-        }
-        if (p.amax_out) {                                     // block-uniform
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o));
-            if (lane == 0 && tmax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, tmax);
-        }
-        if (want_stats) {
-            __syncthreads();
-            for (int c = tid; c < BN; c += NT) {
-                if (n0 + c >= p.Ncol) continue;
-                double sv = 0, qv = 0;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    sv += red[(w * BN + c) * 2];
-                    qv += red[(w * BN + c) * 2 + 1];
-                }
-                double *o = p.stats + (long)tile_m * 2 * p.Ncol + n0 + c;
-                o[0] = sv;
-                o[p.Ncol] = qv;
-            }
-        }
-    } else {
-        static_assert(TR, "the column-per-lane epilogue was retired: every instance runs transposed");
-    }
+    conv_epilogue_tr<MR, NR, WM, WN, DGRAD, NP>(p, acc, smem, tile_m, m0, n0, ka, kb);
+    static_assert(TR, "the column-per-lane epilogue was retired: every instance runs transposed");
 }
 
 // wt[c][rs][co] = w[co][rs][c]: the k-contiguous weight operand of the data gradient
@@ -1127,7 +1130,7 @@ __global__ void __launch_bounds__(256) wprep_pairs_t_kernel(const rcf_wprep_entr
 }
 
 #include "igemm_h2p.inc"
-#include "igemm_h2s.inc"
+#include "igemm_h2d.inc"
 
 // ------------------------------------------------------------------------------------------- wgrad
 struct WgradParams {
@@ -1904,6 +1907,8 @@ __global__ void __launch_bounds__(256, MR == 2 ? 2 : 1) igemm_wgrad_h2t_kernel(W
     }
 }
 
+#include "igemm_h2dw.inc"
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, long n4, long stride,
                                      int splits, int beta) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1925,7 +1930,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
 }
 
 int check_shape(const rcf_conv_shape *s) {
-    if (!s) return RCF_EINVAL;
+    if (!s || s->struct_bytes != sizeof(rcf_conv_shape)) return RCF_EINVAL;      // a caller built against another header
     if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->R <= 0 || s->S <= 0) return RCF_EINVAL;
     if (s->Cin % 4 || s->x_pitch % 4 || s->y_pitch % 4 || s->x_pitch < s->Cin || s->y_pitch < s->Cout) return RCF_EINVAL;
     if (s->stride <= 0 || s->dil <= 0 || s->pad < 0) return RCF_EINVAL;
@@ -1936,13 +1941,11 @@ int check_shape(const rcf_conv_shape *s) {
     return 0;
 }
 
-int g_conv_variant = -1;   // bit0: BK=32, bit1: row-major LDS, bit2: 128x256 tile (fp32-MFMA kernels);
-                           // bit3: split-bf16 kernels.  -1: built-in default (= 8)
-int g_x3_dbg = 0;
-int g_wgrad_wide = 1;      // 128 x 256 weight-gradient tile when the operands are wide enough
-int g_wgrad_tr_off = 0;    // rcf_conv_set_variant bit 0x80000: the 128 x 256 fp16-pair tile with register transposes
-int g_x3_off = 0;           // debug mask: 1 forward, 2 dgrad, 4 wgrad stay on the fp32-MFMA kernels
-inline bool use_x3(int kind = 0) { return (g_conv_variant < 0 || (g_conv_variant & 8) != 0) && !(g_x3_off & kind); }
+// RCF_CONV_FP32_MFMA(v) in the call's flags: the fp32-MFMA kernels with tuning variant v (bit 0: K-step 32, bit 1: row-major
+// LDS tiles) instead of the fp16-pair / bf16-triple kernels; -1 = not asked for
+inline int fp32_mfma_variant(unsigned flags) { return (int)((flags >> 12) & 7u) - 1; }
+inline bool use_x3(unsigned flags) { return fp32_mfma_variant(flags) < 0; }
+inline bool korder_chunked(unsigned flags) { return !(flags & RCF_CONV_KORDER_NATURAL); }
 
 inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
@@ -1955,9 +1958,7 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
     // tile: 128x64 for narrow outputs, 128x128 by default, 128x256 (8 accumulator tiles per wave: twice the
     // MFMA work per barrier) when the output is wide and there are enough row tiles to fill the chip
     const bool wide = p.Ncol > 64;
-    const bool xwide = (g_conv_variant >= 0 ? (g_conv_variant & 4) != 0 : false) && !strided && p.Ncol % 256 == 0 &&
-                       (long)rcf_cdiv(p.M, 128) * (p.Ncol / 256) >= 1536;
-    const int BM = 128, BN = xwide ? 256 : (wide ? 128 : 64);
+    const int BM = 128, BN = wide ? 128 : 64;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
@@ -1966,8 +1967,6 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
     if (strided) {
         if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, BMODE == 1>), grid, dim3(256), 0, st, p);
-    } else if (xwide) {
-        hipLaunchKernelGGL((igemm_conv_kernel<2, 4, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
     } else {
         if (wide) hipLaunchKernelGGL((igemm_conv_kernel<2, 2, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<2, 1, BMODE, BKT, RM, false>), grid, dim3(256), 0, st, p);
@@ -1977,8 +1976,6 @@ int launch_igemm_v(IgemmParams &p, hipStream_t st) {
 }
 
 // split-bf16 launch (B always k-contiguous)
-int g_x3_tile = -1;        // -1: heuristic; 0: 128x128, 1: 128x256, 2: 256x256 (512 threads), 3: 256x128
-
 template <int MR, int NR, int WM, int WN, int NP, bool PRE = false>
 void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
@@ -1986,18 +1983,16 @@ void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches)
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     p.colmap = batches == 1 && p.Ncol % BN == 0 &&
-               rcf_colmap_pays(rcf_g_colmap, (long)p.M * p.Cs * 4, (long)p.K * p.Ncol * 4, p.mtiles, p.ntiles);
+               rcf_colmap_pays(!(p.flags & RCF_CONV_NO_COLMAP), (long)p.M * p.Cs * 4, (long)p.K * p.Ncol * 4, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
     if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false, NP, PRE, true>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
-int g_h2_off = 0;          // rcf_conv_set_variant bit 0x20000: never take the fp16-pair kernels
-
 template <int MR, int NR, int WM, int WN>
 void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1) {
-    if (p.amax_a && p.amax_b && !g_h2_off) {
+    if (p.amax_a && p.amax_b) {
         if (p.b_pairs) launch_x3_cfg_np<MR, NR, WM, WN, 2, true>(p, strided, st, batches);
         else launch_x3_cfg_np<MR, NR, WM, WN, 2>(p, strided, st, batches);
     } else {
@@ -2005,12 +2000,11 @@ void launch_x3_cfg(IgemmParams &p, bool strided, hipStream_t st, int batches = 1
     }
 }
 
-// conv_h2p_kernel (igemm_h2p.inc): which launches take it.  g_h2p: -1 built-in rule, 0 never, 1 whenever eligible
-int g_h2p = -1;
-int g_h2s = -1;            // conv_h2s_kernel (igemm_h2s.inc): see the comment above h2s_eligible
-int g_h2p_min_k = 2304;    // the 3x3 layers.  Below (1x1 convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part
-                           // of a tile's time and the kernel's single workgroup per CU has nothing to overlap it with: measured
-                           // 0.90-1.0x of the 128x256 kernel there, 1.04-1.17x on the 3x3 layers (tools/bench_h2p.py)
+// conv_h2p_kernel (igemm_h2p.inc): which launches take it.  Built-in rule: K >= H2P_MIN_K, i.e. the 3x3 layers.  Below (1x1
+// convs, K <= 2048) the epilogue (256 KB of output per tile) is a large part of a tile's time and the kernel's single workgroup
+// per CU has nothing to overlap it with: measured 0.90-1.0x of the 128x256 kernel there, 1.04-1.17x on the 3x3 layers.
+// RCF_CONV_H2P_NEVER / RCF_CONV_H2P_ALWAYS (every eligible shape: tests) override the rule per call.
+constexpr int H2P_MIN_K = 2304;
 // workgroups per row range: the smallest power of two dividing the column-tile count that gives a workgroup >= 12 row
 // blocks (one block of imbalance is then <= 8 %), else the largest one
 int h2p_gn(int M, int ntiles) {
@@ -2027,15 +2021,12 @@ int h2p_stat_rows(int M, int gn) {                        // partial statistics 
     return n < 1 ? 1 : n;
 }
 
-// can a conv of this shape ever take one of the kernels that read the pairs2 layout?  (rcf_conv_weight_pairs2_f32 writes that
-// half of its buffer only then: the split runs once per weight update = once per training step and layer)
-bool pairs2_useful(int rows, int K, int Cs) {
-    if (g_h2p == 1 || g_h2s == 1) return true;             // forced on (tests, A/B runs): every eligible shape
-    return g_h2p != 0 && rows % 256 == 0 && K % 16 == 0 && Cs % 16 == 0 && K >= g_h2p_min_k && (long)K * 256 >= 1152L * rows;
-}
+// is the plane-separated (LDS-image) half of a rcf_conv_weight_pairs2_f32 buffer written for this shape?  Whenever the kernels
+// that read it by LDS-DMA (conv_h2p_kernel, conv_h2d_kernel) can take the shape at all: whole K-steps that do not straddle a tap
+bool pairs2_written(int K, int Cs) { return K % 16 == 0 && Cs % 16 == 0; }
 
 bool h2p_eligible(const IgemmParams &p, int batches) {
-    if (g_h2p == 0 || g_h2_off || !p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return false;
+    if ((p.flags & RCF_CONV_H2P_NEVER) || !p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return false;
     if (p.div > 1 || p.bias || p.act != 0 || p.Ncol % 256 || p.K % 16 || p.Cs % 16) return false;
     // the statistics workspace is sized for one row of partial sums per 64 GEMM rows (rcf_conv2d_fwd_stats_workspace_bytes)
     const int gn = h2p_gn(p.M, p.Ncol / 256);
@@ -2045,14 +2036,11 @@ bool h2p_eligible(const IgemmParams &p, int batches) {
     // column tile: measured equal to or 2 % behind the 128 x 256 kernel there
     // ... and many rows (3x3 256 -> 256 at 120x214: 3 210 tiles of the 128 x 256 kernel = 6.3 rounds, little tail left to win,
     // while a workgroup here walks 7 sub-tiles with nothing to overlap their prologues / epilogues: measured 0.92-0.95x)
-    return g_h2p == 1 || (p.K >= g_h2p_min_k && p.M >= 32768 && (long)p.K * 256 >= 1152L * p.Ncol &&
-                          (long)rcf_cdiv(p.M, 128) * (p.Ncol / 256) <= 2048);
+    return (p.flags & RCF_CONV_H2P_ALWAYS) || (p.K >= H2P_MIN_K && p.M >= 32768 && (long)p.K * 256 >= 1152L * p.Ncol &&
+                                               (long)rcf_cdiv(p.M, 128) * (p.Ncol / 256) <= 2048);
 }
 
-int g_last_conv_kernel = 0;   // 1: igemm_conv_x3_kernel (or the fp32-MFMA kernels), 2: conv_h2p_kernel, 3: conv_h2s_kernel -- for profiling labels
-
 int launch_h2p(IgemmParams &p, hipStream_t st) {
-    g_last_conv_kernel = 2;
     const long bytes = (long)(p.K / 16) * p.Ncol * 64;
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (bytes >= (1L << 31) || per_tile_imgs * p.a_img_stride * 4 >= (1L << 31)) return RCF_EINVAL;
@@ -2067,55 +2055,42 @@ int launch_h2p(IgemmParams &p, hipStream_t st) {
     return 0;
 }
 
-// conv_h2s_kernel (igemm_h2s.inc): the 1x1 convs as one stream of K-steps per workgroup, epilogues under the next tile's
-// MFMAs.  g_h2s: -1 built-in rule, 0 never, 1 whenever eligible.  MEASURED SLOWER than the 128 x 256 kernel (0.70-0.90x on
-// the step's 1x1 layers, bit-identical results; tools/bench_h2p.py, profiles/r03_bench_h2p_ab.txt): with ONE wave per SIMD
-// every instruction of the epilogue chunks (scale, accumulate, store, statistics: ~35 per 6 MFMAs on top of the loader's
-// ~20) is issued by the wave that also issues the MFMAs -- a SIMD issues to its matrix, vector, LDS and memory pipes in the
-// same cycle only from DIFFERENT waves, so two independent workgroups per CU hide an epilogue better than one stream
-// does.  The built-in rule therefore never takes it; the tests force it (mode 1) to keep it correct.  (g_h2s is declared
-// beside g_h2p above.)
-int h2s_gn(int M, int ntiles) {
-    const int RB = rcf_cdiv(M, 32);
-    int gn = 1;
-    while ((long)RB * gn < 12L * H2P_G && gn * 2 <= 16 && ntiles % (gn * 2) == 0) gn *= 2;
-    return gn;
-}
-int h2s_stat_rows(int M, int gn) {                        // 4-block sub-tiles of the longest row range
-    const int GM = H2P_G / gn;
-    const int RB = rcf_cdiv(M, 32), base = RB / GM, extra = RB - base * GM;
-    const int n = rcf_cdiv(extra ? base + 1 : base, 4);
-    return n < 1 ? 1 : n;
-}
-bool h2s_eligible(const IgemmParams &p, int batches) {
-    if (g_h2s == 0 || g_h2_off || !p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return false;
-    if (p.S != 1 || p.K != p.Cs || p.up != 1 || p.off != 0 || p.div > 1 || p.bias || p.act != 0) return false;
-    if (p.rh != p.Ho || p.rw != p.Wo || p.rband > 0 || p.Ho != p.Hs || p.Wo != p.Ws) return false;
-    if (p.Ncol % 256 || p.K % 64 || p.K < 192 || p.a_pitch % 4 || p.y_pitch % 4) return false;
-    if ((long)p.M * p.a_pitch * 4 >= (1L << 31) || (long)p.M * p.y_pitch * 4 >= (1L << 31)) return false;
-    const int gn = h2s_gn(p.M, p.Ncol / 256);
-    if (p.stats && (long)(H2P_G / gn) * h2s_stat_rows(p.M, gn) > rcf_cdiv(p.M, 64)) return false;
-    return g_h2s == 1;                                      // never by the built-in rule: see above
-}
-int launch_h2s(IgemmParams &p, hipStream_t st) {
-    g_last_conv_kernel = 3;
+// conv_h2d_kernel (igemm_h2d.inc): the activation operand arrives as fp16 pair planes -- the only kernel that reads them
+int launch_h2d(IgemmParams &p, hipStream_t st, int batches, int *kernel_only) {
+    if (!p.b_pairs2 || !p.amax_a || !p.amax_b || batches != 1 || p.batch1 > 0) return RCF_EINVAL;
+    if (p.K % 16 || p.Cs % 16 || p.a_pitch != p.Cs || p.Ncol % 4) return RCF_EINVAL;
     const long bytes = (long)(p.K / 16) * p.Ncol * 64;
-    if (bytes >= (1L << 31)) return RCF_EINVAL;
+    const long per_tile_imgs = 256 / (long)p.rr + 2;
+    if (bytes >= (1L << 31) || per_tile_imgs * p.a_img_stride * 4 >= (1L << 31)) return RCF_EINVAL;
+    if (kernel_only) { *kernel_only = 3; return 0; }
     p.b_bytes = (int)bytes;
-    p.ntiles = p.Ncol / 256;
-    p.h2p_gn = h2s_gn(p.M, p.ntiles);
-    p.mtiles8 = h2s_stat_rows(p.M, p.h2p_gn);
-    p.mtiles = (H2P_G / p.h2p_gn) * p.mtiles8;
-    if (p.step < 0) hipLaunchKernelGGL(conv_h2s_kernel<true>, dim3(H2P_G), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(conv_h2s_kernel<false>, dim3(H2P_G), dim3(256), 0, st, p);
+    const int BN = p.Ncol > 128 ? 256 : (p.Ncol > 64 ? 128 : 64);
+    p.mtiles = rcf_cdiv(p.M, 128);
+    p.mtiles8 = rcf_cdiv(p.mtiles, 8);
+    p.ntiles = rcf_cdiv(p.Ncol, BN);
+    p.colmap = p.Ncol % BN == 0 &&
+               rcf_colmap_pays(!(p.flags & RCF_CONV_NO_COLMAP), (long)p.M * p.Cs * 4, (long)p.K * p.Ncol * 4, p.mtiles, p.ntiles);
+    const dim3 grid((unsigned)(p.mtiles8 * 8 * p.ntiles));
+#define RCF_H2D(NRv)                                                                                            \
+    do {                                                                                                        \
+        if (p.div > 1) hipLaunchKernelGGL((conv_h2d_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);       \
+        else if (p.step < 0) hipLaunchKernelGGL((conv_h2d_kernel<NRv, false, true>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv_h2d_kernel<NRv, false, false>), grid, dim3(256), 0, st, p);               \
+    } while (0)
+    if (BN == 256) RCF_H2D(4);
+    else if (BN == 128) RCF_H2D(2);
+    else RCF_H2D(1);
+#undef RCF_H2D
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
+// `kernel_only`: do not launch, report which kernel the call would take (rcf_conv_kernel_of: 1 the 128 x 256 family, 2 conv_h2p_kernel,
+// 3 conv_h2d_kernel)
+int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1, int *kernel_only = nullptr) {
     p.cs_magic = magic_of(p.Cs);
     {
-        const int taps = p.K / p.Cs, kch = rcf_kchunk(rcf_g_korder, taps, p.Cs, RCF_KCHUNK_F32);
+        const int taps = p.K / p.Cs, kch = rcf_kchunk(korder_chunked(p.flags), taps, p.Cs, RCF_KCHUNK_F32);
         p.kch = kch ? kch : p.Cs;
         p.rsch = taps * p.kch;
         p.kch_magic = magic_of(p.kch);
@@ -2124,27 +2099,25 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
     }
     p.s_magic = magic_of(p.S);
     if ((long)p.K * p.Cs >= (1L << 32)) return RCF_EINVAL;
-    if (h2s_eligible(p, batches)) return launch_h2s(p, st);
+    if (p.a_split) return launch_h2d(p, st, batches, kernel_only);
+    if (kernel_only) {
+        *kernel_only = h2p_eligible(p, batches) ? 2 : 1;
+        return 0;
+    }
     if (h2p_eligible(p, batches)) return launch_h2p(p, st);
-    g_last_conv_kernel = 1;
     // 32-bit descriptor offsets: the images one row tile can touch must lie within 2 GiB of the first one
     const long per_tile_imgs = 256 / (long)p.rr + 2;
     if (per_tile_imgs * p.a_img_stride * 4 >= (1L << 31) || (long)p.Ncol * p.ldb * 4 >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)((long)p.Ncol * p.ldb * 4);
-    if (p.b_pairs && p.amax_a && p.amax_b && !g_h2_off) {     // K-step-major pairs: K padded to whole steps
+    if (p.b_pairs && p.amax_a && p.amax_b) {     // K-step-major pairs: K padded to whole steps
         const long bytes = (long)rcf_cdiv(p.K, 16) * p.Ncol * 64;
         if (bytes >= (1L << 31)) return RCF_EINVAL;
         p.b_bytes = (int)bytes;
     }
-    p.dbg = g_x3_dbg;
     const bool strided = p.div > 1;
-    int tile = g_x3_tile;
-    if (tile < 0) tile = p.Ncol > 128 ? 1 : 0;
     if (p.Ncol <= 64 && (long)rcf_cdiv(p.M, 128) * batches < 512) launch_x3_cfg<1, 1, 2, 2>(p, strided, st, batches);   // few rows: 64x64 tiles fill more CUs
     else if (p.Ncol <= 64) launch_x3_cfg<2, 1, 2, 2>(p, strided, st, batches);
-    else if (tile == 1) launch_x3_cfg<2, 4, 2, 2>(p, strided, st, batches);
-    else if (tile == 2) launch_x3_cfg<2, 4, 4, 2>(p, strided, st, batches);
-    else if (tile == 3) launch_x3_cfg<4, 2, 2, 2>(p, strided, st, batches);
+    else if (p.Ncol > 128) launch_x3_cfg<2, 4, 2, 2>(p, strided, st, batches);
     else launch_x3_cfg<2, 2, 2, 2>(p, strided, st, batches);
     RCF_LAUNCH_CHECK();
     return 0;
@@ -2152,7 +2125,7 @@ int launch_igemm_x3(IgemmParams &p, hipStream_t st, int batches = 1) {
 
 template <int BMODE>
 int launch_igemm(IgemmParams &p, hipStream_t st) {
-    const int v = g_conv_variant < 0 ? 0 : g_conv_variant;
+    const int v = fp32_mfma_variant(p.flags) < 0 ? 0 : fp32_mfma_variant(p.flags);
     switch (v & 3) {
         case 1: return launch_igemm_v<BMODE, 32, false>(p, st);
         case 2: return launch_igemm_v<BMODE, 16, true>(p, st);
@@ -2171,31 +2144,27 @@ struct WgradPlan {
     long chunk;
     bool cols;      // igemm_wgrad_h2t_kernel: the taps are GEMM columns (grid.y = 1)
 };
-int g_wgrad_big = 1;          // rcf_conv_set_wgrad_big bit 0: the 256 x 256 weight-gradient tile where whole tiles of one tap fit (+3 - 8 %)
-int g_wgrad_plan_us = 1;      // 1: split-K by the microsecond cost model (same-box A/B: -0.5 ms per fp32 step); RCF_WGRAD_PLAN_US=0: round-1 model
 WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullptr) {
-    static const int env_plan = getenv("RCF_WGRAD_PLAN_US") ? atoi(getenv("RCF_WGRAD_PLAN_US")) : -1;
-    if (env_plan >= 0) g_wgrad_plan_us = env_plan;
     WgradPlan pl;
+    const bool x3 = use_x3(s->flags);
     const bool smallc = s->Cin == 4;
     const int ncols = smallc ? s->R * s->S * 4 : s->Cin;
     pl.mr = s->Cout > 64 ? 2 : 1;
     pl.nr = ncols > 64 ? 2 : 1;
     // 128 x 256 tile (igemm_wgrad_x3_wide_kernel): whole tensors, wide enough operands
-    const bool wide = use_x3(4) && g_wgrad_wide && !smallc && !reg && s->Cout >= 128 && s->Cin >= 256;
+    const bool wide = x3 && !smallc && !reg && s->Cout >= 128 && s->Cin >= 256;
     if (wide) pl.nr = 4;
     // fp16 pairs with the (tap, channel) pairs as GEMM columns (igemm_wgrad_h2t_kernel): 128 x 256 tiles over R*S*Cin
     // columns (128 x 128 below 256 columns), whole tensors and regions, from 64 output channels and 64 columns up: the
     // narrow layers are bound by memory, not by the half-empty tiles (1x1 64->256 and 256->64 at 120x214: 0.19 -> 0.12 ms
     // against the 64-wide kernels).
     const int ktot = s->R * s->S * s->Cin;
-    pl.cols = s->amax_dy && s->amax_x && !g_h2_off && use_x3(4) && g_wgrad_wide && !g_wgrad_tr_off && !smallc &&
-              s->Cin % 64 == 0 && s->Cout >= 64 && !(reg && ktot < 256);
+    pl.cols = s->amax_dy && s->amax_x && x3 && !smallc && s->Cin % 64 == 0 && s->Cout >= 64 && !(reg && ktot < 256);
     if (pl.cols) {
         pl.mr = 2;
         pl.nr = ktot >= 256 ? 4 : 2;
         // 256 x 256 tile, one workgroup per CU: whole 256-row and 256-column tiles of one tap only
-        if (g_wgrad_big && pl.nr == 4 && s->Cout % 256 == 0 && s->Cin % 256 == 0) pl.mr = 4;
+        if (!(s->flags & (RCF_CONV_WGRAD_TILE_128 | RCF_CONV_X_PLANES | RCF_CONV_DY_PLANES)) && pl.nr == 4 && s->Cout % 256 == 0 && s->Cin % 256 == 0) pl.mr = 4;
     }
     pl.itiles = rcf_cdiv(s->Cout, 64 * pl.mr);
     pl.jtiles = pl.cols ? rcf_cdiv(ktot, 64 * pl.nr) : rcf_cdiv(ncols, 64 * pl.nr);
@@ -2207,34 +2176,27 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
     if (sk > maxsk) sk = maxsk;
     if (sk > 256) sk = 256;
     if (sk < 1) sk = 1;
-    if (use_x3(4) && !smallc && pl.mr >= 2 && pl.nr >= 2) {
+    if (x3 && !smallc && pl.mr >= 2 && pl.nr >= 2) {
         // the split-bf16 kernel runs 3 workgroups per CU (768 slots): pick the split whose last round is fullest
         // (time ~ rounds / split; the fixed-order reduction costs ~ split)
         const long slots = pl.mr == 4 ? 256 : (pl.nr == 4 ? 512 : 768), hi = maxsk < 256 ? maxsk : 256;   // (the 128 x 256 kernel: 2 per CU = 512; 256 x 256: 1)
         double best = 1e30;
-        if (g_wgrad_plan_us) {
+        {
             // the cost model of the bf16 weight gradient (csrc/igemm_bf16.hip), in microseconds: rounds x pixels per
             // workgroup x time per pixel (three partial products: 3 x the bf16 figure) + the fixed-order reduction, which
             // reads c copies of the weight gradient
-            static const double px_base = getenv("RCF_WGRAD_PX_US") ? atof(getenv("RCF_WGRAD_PX_US")) : 0.075;
-            const double px_us = px_base * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
+            const double px_us = 0.075 * fmax((double)(pl.mr * pl.nr) / 8.0, 0.35);
             const double wbytes = (double)s->Cout * s->R * s->S * s->Cin * 4.0;
             for (long c = 1; c <= hi; ++c) {
                 const double rounds = (double)((tiles * c + slots - 1) / slots);
                 const double cost = rounds * (double)((M + c - 1) / c) * px_us + (c > 1 ? (double)c * wbytes / 2.0e6 + 3.0 : 0.0);
                 if (cost < best - 1e-9) { best = cost; sk = c; }
             }
-        } else {
-            const long hi0 = hi < 96 ? hi : 96;
-            for (long c = 1; c <= hi0; ++c) {
-                const double cost = (double)((tiles * c + slots - 1) / slots) / (double)c + 0.004 * (double)c / (double)(tiles > 64 ? 1 : 2);
-                if (cost < best - 1e-12) { best = cost; sk = c; }
-            }
         }
     }
     long chunk = (M + sk - 1) / sk;
     chunk = (chunk + BK - 1) / BK * BK;
-    if (use_x3(4) && !smallc) {
+    if (x3 && !smallc) {
         // 32-bit descriptor offsets: the images (and dy rows) one pixel chunk touches must span < 2 GiB
         const long img_bytes = (long)s->H * s->W * s->x_pitch * 4, dy_bytes = (long)s->Ho * s->Wo * s->y_pitch * 4;
         while (chunk > BK && ((chunk / RR + 2) * img_bytes >= (1L << 31) || (chunk / RR + 2) * dy_bytes >= (1L << 31)))
@@ -2247,25 +2209,6 @@ WgradPlan plan_wgrad(const rcf_conv_shape *s, const rcf_conv_region *reg = nullp
 }
 
 }  // namespace
-
-/* tuning knob for A/B measurements (tools/bench_conv.py): bit0 K-step 32, bit1 row-major LDS, bit2 128x256 tile
- * (fp32-MFMA kernels); bit3 split-bf16 kernels (the default, -1) */
-extern "C" int rcf_conv_set_variant(int v) {
-    g_x3_dbg = v >= 0 ? ((v >> 15) & 1) | ((v >> 17) & 2) | ((v >> 18) & 4) : 0;     // 0x8000: loads off; 0x40000: activation loads from a 64 KB window; 0x100000: lane-linear epilogue stores (timing only)
-    g_wgrad_tr_off = v >= 0 ? (v >> 19) & 1 : 0;
-    g_h2_off = v >= 0 ? (v >> 17) & 1 : 0;     // 0x20000: bf16 triples even when the operand ranges are given
-    g_wgrad_wide = v >= 0 && ((v >> 16) & 1) ? 0 : 1;      // 0x10000: keep the weight gradient on 128 x 128 tiles
-    g_x3_off = v >= 0 ? (v >> 12) & 7 : 0;     // 0x1000 forward, 0x2000 dgrad, 0x4000 wgrad off the split-bf16 path
-    if (v >= 0) v &= 0xfff;
-    if (v >= 0 && (v & 0x100)) {           // 0x100 | tile << 4: pin the split-bf16 tile (tools/bench_conv.py)
-        g_x3_tile = (v >> 4) & 7;
-        v &= 15;
-    } else {
-        g_x3_tile = -1;
-    }
-    g_conv_variant = v;
-    return 0;
-}
 
 namespace {
 // rectangle (or frame) of the GEMM-row tensor [N, H, W]; null = everything.  Returns 0 / RCF_EINVAL.
@@ -2289,7 +2232,6 @@ extern "C" int rcf_gemm_nt_f32(const float *A, int lda, const float *B, int ldb,
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || ldc % 4) return RCF_EINVAL;
     if (lda < K || ldb < K || ldc < N || !rcf_aligned16(A) || !rcf_aligned16(B) || !rcf_aligned16(C)) return RCF_EINVAL;
     if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29)) return RCF_EINVAL;      // 32-bit descriptor offsets
-    if (!use_x3(1)) return RCF_EINVAL;
     IgemmParams p{};
     p.A = A; p.Bw = B; p.bias = bias; p.Y = C;
     p.M = M; p.Ncol = N; p.K = K;
@@ -2314,7 +2256,7 @@ extern "C" int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long 
     if (lda < K || ldb < K || ldc < N || !rcf_aligned16(A) || !rcf_aligned16(B) || !rcf_aligned16(C)) return RCF_EINVAL;
     if (batch0 <= 0 || batch1 <= 0 || (long)batch0 * batch1 > 65535) return RCF_EINVAL;
     if ((a_s0 | a_s1 | b_s0 | b_s1 | c_s0 | c_s1) % 4) return RCF_EINVAL;
-    if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29) || !use_x3(1)) return RCF_EINVAL;
+    if ((long)M * lda >= (1L << 29) || (long)N * ldb >= (1L << 29)) return RCF_EINVAL;
     IgemmParams p{};
     p.A = A; p.Bw = B; p.bias = nullptr; p.Y = C;
     p.M = M; p.Ncol = N; p.K = K;
@@ -2327,19 +2269,20 @@ extern "C" int rcf_gemm_nt_batched_f32(const float *A, int lda, long a_s0, long 
     return launch_igemm_x3(p, rcf_stream(stream), batch0 * batch1);
 }
 
-extern "C" int rcf_conv_regions_available(void) { return use_x3(1) && use_x3(2) && use_x3(4) ? 1 : 0; }
-
 extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *bias, float *y,
                                   const rcf_conv_shape *s, int act, float slope, int beta, void *stream) {
     return rcf_conv2d_fwd_region_f32(x, w, bias, y, s, nullptr, act, slope, beta, stream);
 }
 
-extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y,
-                                         const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope,
-                                         int beta, void *stream) {
-    if (int e = check_shape(s)) return e;
-    if (!x || !w || !y || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+namespace {
+int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
+                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only);
+// forward launch; kernel_only: report the kernel the call would take instead (rcf_conv_kernel_of)
+int conv2d_fwd_impl(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
+                    const rcf_conv_region *region, int act, float slope, int beta, double *stats, void *stream, int *kernel_only,
+                    int *mtiles_out = nullptr) {
     IgemmParams p{};
+    p.flags = s->flags;
     p.A = x; p.Bw = w; p.bias = bias; p.Y = y;
     p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
     p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
@@ -2350,12 +2293,41 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
     p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
     if (s->w_pairs2) {
         p.b_pairs = s->w_pairs2;
-        if (pairs2_useful(s->Cout, s->R * s->S * s->Cin, s->Cin))
+        if (pairs2_written(p.K, s->Cin))
             p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S);
     }
-    if (use_x3(1)) return launch_igemm_x3(p, rcf_stream(stream));
-    if (region) return RCF_EINVAL;                       // sub-rectangles exist on the split-bf16 kernels only
+    p.stats = stats;
+    p.amax_out = s->amax_y;
+    p.a_split = (s->flags & RCF_CONV_X_PLANES) ? 1 : 0;
+    if (use_x3(s->flags)) {
+        const int e = launch_igemm_x3(p, rcf_stream(stream), 1, kernel_only);
+        if (mtiles_out) *mtiles_out = p.mtiles;
+        return e;
+    }
+    if (region || stats) return RCF_EINVAL;              // sub-rectangles / fused statistics exist on the default kernels only
+    if (kernel_only) { *kernel_only = 0; return 0; }
     return launch_igemm<0>(p, rcf_stream(stream));
+}
+}  // namespace
+
+extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const float *bias, float *y,
+                                         const rcf_conv_shape *s, const rcf_conv_region *region, int act, float slope,
+                                         int beta, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!x || !w || !y || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+    return conv2d_fwd_impl(x, w, bias, y, s, region, act, slope, beta, nullptr, stream, nullptr);
+}
+
+/* which kernel family a forward (dgrad = 0) or data-gradient (dgrad = 1) launch with this shape, these operand pointers and
+ * flags takes -- 0 the fp32-MFMA kernels, 1 the 128 x 256-tile family, 2 conv_h2p_kernel (persistent LDS-DMA) -- without launching
+ * anything: a pure function of its arguments (profiling labels; it replaces a "last kernel" global). */
+extern "C" int rcf_conv_kernel_of(const rcf_conv_shape *s, const rcf_conv_region *region, int dgrad) {
+    if (check_shape(s)) return RCF_EINVAL;
+    int k = RCF_EINVAL;
+    float dummy = 0.f;
+    const int e = dgrad ? conv2d_dgrad_impl(&dummy, &dummy, &dummy, s, region, 0, &dummy, (size_t)1 << 40, nullptr, &k)
+                        : conv2d_fwd_impl(&dummy, &dummy, nullptr, &dummy, s, region, 0, 0.f, 0, nullptr, nullptr, &k);
+    return e ? e : k;
 }
 
 extern "C" int rcf_absmax_f32(const float *x, long rows, int C, int pitch, unsigned *amax, void *stream) {
@@ -2374,22 +2346,22 @@ extern "C" size_t rcf_conv_weight_pairs_bytes(int Cout, int Cin, int R, int S) {
 }
 
 extern "C" int rcf_conv_weight_pairs_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w,
-                                         void *planes, void *stream) {
+                                         void *planes, unsigned flags, void *stream) {
     if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
     const long n = (long)Cout * R * S * Cin;
     const long blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(weight_pairs_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
-                       rcf_stream(stream), w, amax_w, (_Float16 *)planes, Cout, Cin, R * S, rcf_g_korder);
+                       rcf_stream(stream), w, amax_w, (_Float16 *)planes, Cout, Cin, R * S, (int)korder_chunked(flags));
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int rcf_conv_weight_pairs_t_f32(const float *w, int Cout, int Cin, int R, int S, const unsigned *amax_w,
-                                           void *planes, void *stream) {
+                                           void *planes, unsigned flags, void *stream) {
     if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
     const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
     hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)planes,
-                       Cout, Cin, R * S, rcf_g_korder);
+                       Cout, Cin, R * S, (int)korder_chunked(flags));
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -2405,37 +2377,36 @@ extern "C" size_t rcf_conv_weight_pairs2_bytes(int Cout, int Cin, int R, int S, 
 }
 
 extern "C" int rcf_conv_weight_pairs2_f32(const float *w, int Cout, int Cin, int R, int S, int transpose,
-                                          const unsigned *amax_w, void *planes, void *stream) {
+                                          const unsigned *amax_w, void *planes, unsigned flags, void *stream) {
     if (!w || !amax_w || !planes || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || !rcf_aligned16(planes)) return RCF_EINVAL;
     const size_t one = rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, transpose) / 2;
     char *second = (char *)planes + one;
-    const int rows = transpose ? Cin : Cout, K = R * S * (transpose ? Cout : Cin);
-    // the second half is written only for shapes that can take a kernel reading it (the same test the launches apply; with
-    // rcf_conv_set_h2p / _h2s forcing those kernels on, build the buffers AFTER the switch)
-    const bool second_half = pairs2_useful(rows, K, transpose ? Cout : Cin) && K % 16 == 0;
+    const int K = R * S * (transpose ? Cout : Cin);
+    // the second half is written for every shape a kernel reading it can take (a pure function of the shape: whole K-steps)
+    const bool second_half = pairs2_written(K, transpose ? Cout : Cin);
+    const int korder = (int)korder_chunked(flags);
     if (transpose) {
-        if (int e = rcf_conv_weight_pairs_t_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
+        if (int e = rcf_conv_weight_pairs_t_f32(w, Cout, Cin, R, S, amax_w, planes, flags, stream)) return e;
         const dim3 tgrid(rcf_cdiv(Cin, 32), rcf_cdiv(Cout, 32), R * S);
         if (second_half)
             hipLaunchKernelGGL(weight_pairs2_kernel<true>, tgrid, dim3(256), 0, rcf_stream(stream), w, amax_w, (_Float16 *)second,
-                               Cout, Cin, R * S, rcf_g_korder);
+                               Cout, Cin, R * S, korder);
     } else {
-        if (int e = rcf_conv_weight_pairs_f32(w, Cout, Cin, R, S, amax_w, planes, stream)) return e;
+        if (int e = rcf_conv_weight_pairs_f32(w, Cout, Cin, R, S, amax_w, planes, flags, stream)) return e;
         const long n = (long)Cout * R * S * Cin;
         const long blocks = (n + 1023) / 1024;
         if (second_half)
             hipLaunchKernelGGL(weight_pairs2_kernel<false>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
-                               rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S, rcf_g_korder);
+                               rcf_stream(stream), w, amax_w, (_Float16 *)second, Cout, Cin, R * S, korder);
     }
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
-/* would rcf_conv_weight_pairs2_f32 write the plane-separated half for this shape (and a launch read it)?  For callers
- * that fill rcf_wprep_entry.flags */
+/* does rcf_conv_weight_pairs2_f32 write the plane-separated half for this shape (and may a launch read it)?  A pure function
+ * of the shape; for callers that fill rcf_wprep_entry.flags */
 extern "C" int rcf_conv_pairs2_useful(int Cout, int Cin, int R, int S, int transpose) {
-    const int rows = transpose ? Cin : Cout, K = R * S * (transpose ? Cout : Cin), Cs = transpose ? Cout : Cin;
-    return pairs2_useful(rows, K, Cs) && K % 16 == 0 ? 1 : 0;
+    return pairs2_written(R * S * (transpose ? Cout : Cin), transpose ? Cout : Cin) ? 1 : 0;
 }
 
 /* Batched weight preparation of the fp16-pair kernels: ranges (amax), then both rcf_conv_weight_pairs2_f32 buffers of every
@@ -2443,68 +2414,21 @@ extern "C" int rcf_conv_pairs2_useful(int Cout, int Cin, int R, int S, int trans
  * first_block / nblocks filled per launch (blocks_* = their totals); amax_base: the n consecutive range slots the entries
  * point to (zeroed here).  Entry i of every table describes the same weight.  Identical bytes to the per-weight calls. */
 extern "C" int rcf_conv_weights_prepare_f32(const void *tab_absmax, int blocks_absmax, const void *tab_pairs, int blocks_pairs,
-                                            const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, void *stream) {
+                                            const void *tab_pairs_t, int blocks_pairs_t, int n, unsigned *amax_base, unsigned flags,
+                                            void *stream) {
     if (!tab_absmax || !tab_pairs || !tab_pairs_t || n <= 0 || !amax_base || blocks_absmax <= 0 || blocks_pairs <= 0 || blocks_pairs_t <= 0)
         return RCF_EINVAL;
     hipStream_t st = rcf_stream(stream);
     if (hipMemsetAsync(amax_base, 0, (size_t)n * sizeof(unsigned), st) != hipSuccess) return RCF_EINVAL;
     hipLaunchKernelGGL(wprep_absmax_kernel, dim3((unsigned)blocks_absmax), dim3(256), 0, st, (const rcf_wprep_entry *)tab_absmax, n);
-    hipLaunchKernelGGL(wprep_pairs_kernel, dim3((unsigned)blocks_pairs), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs, n, rcf_g_korder);
-    hipLaunchKernelGGL(wprep_pairs_t_kernel, dim3((unsigned)blocks_pairs_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs_t, n, rcf_g_korder);
+    hipLaunchKernelGGL(wprep_pairs_kernel, dim3((unsigned)blocks_pairs), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs, n, (int)korder_chunked(flags));
+    hipLaunchKernelGGL(wprep_pairs_t_kernel, dim3((unsigned)blocks_pairs_t), dim3(256), 0, st, (const rcf_wprep_entry *)tab_pairs_t, n, (int)korder_chunked(flags));
     RCF_LAUNCH_CHECK();
     return 0;
 }
 
-/* A/B switch of conv_h2p_kernel: mode -1 built-in rule (K >= min_k), 0 never, 1 whenever eligible; min_k <= 0 keeps it */
-extern "C" int rcf_conv_set_h2p(int mode, int min_k) {
-    g_h2p = mode;
-    if (min_k > 0) g_h2p_min_k = min_k;
-    return 0;
-}
-
-/* which kernel the last forward / data-gradient launch of this thread of control took (profiling labels only; not
- * synchronised): 1 the 128 x 256 family, 2 conv_h2p_kernel, 3 conv_h2s_kernel */
-extern "C" int rcf_conv_last_kernel(void) { return g_last_conv_kernel; }
-
-/* A/B switch of conv_h2s_kernel (the 1x1 convs as a stream of K-steps): -1 built-in rule, 0 never, 1 whenever eligible */
-extern "C" int rcf_conv_set_h2s(int mode) {
-    g_h2s = mode;
-    return 0;
-}
-
-/* A/B switch of the weight-gradient kernels' workgroup -> (tile, split) mapping (csrc/rcf_common.h rcf_wgrad_item): 1 (the
- * default) an XCD's workgroups share their pixel range, 0 the plain grid order.  Same sums in the same order either way. */
-/* A/B switch of the K order of the forward / data-gradient convs (rcf_common.h rcf_kchunk): 1 (default) channel chunks of 64
- * outer, taps inner on the 3x3 layers; 0 the weight's memory order (tap outer).  The derived weight operands are laid out in
- * the order the kernels walk: rebuild them after a change (rcf_amd.ops.weights_changed()). */
-extern "C" int rcf_conv_set_korder(int mode) {
-    rcf_g_korder = mode ? 1 : 0;
-    return 0;
-}
-
-/* A/B switch of the forward / data-gradient grids' XCD mapping for convs whose weights exceed L2 many times over
- * (rcf_common.h rcf_conv_tile): 1 (default) the byte model decides, 0 always row bands.  Tiles are independent: bit-identical. */
-extern "C" int rcf_conv_set_colmap(int mode) {
-    rcf_g_colmap = mode ? 1 : 0;
-    return 0;
-}
-
-/* A/B switch, bit 0: the fp16-pair weight gradient takes 256 x 256 tiles (one workgroup per CU) where Cout and Cin are multiples
- * of 256, bit 1: the bf16 weight gradient does; 0: 128 x 256 tiles, two workgroups per CU.  Same sums per element (the K order does not change): bit-identical
- * when the split counts agree, fp32-rounding differences otherwise. */
-extern "C" int rcf_conv_set_wgrad_big(int mode) {
-    g_wgrad_big = mode & 1;
-    rcf_g_wgrad_big_bf16 = (mode >> 1) & 1;
-    return 0;
-}
-
-extern "C" int rcf_conv_set_wgrad_xcd(int mode) {
-    rcf_g_wgrad_xcd = mode ? 1 : 0;
-    return 0;
-}
-
 extern "C" size_t rcf_conv2d_fwd_stats_workspace_bytes(const rcf_conv_shape *s) {
-    if (check_shape(s) || !use_x3(1)) return 0;
+    if (check_shape(s) || !use_x3(s->flags)) return 0;
     // one row of partial sums per row tile (smallest tile: 64 rows) + the 64 rows of the two-level reduction
     return (size_t)(rcf_cdiv((long)s->N * s->Ho * s->Wo, 64) + 64) * 2 * s->Cout * sizeof(double);
 }
@@ -2514,26 +2438,12 @@ extern "C" int rcf_conv2d_fwd_bnstats_f32(const float *x, const float *w, float 
                                           void *stream) {
     if (int e = check_shape(s)) return e;
     if (!x || !w || !y || (!sums && !fin) || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
-    if (!use_x3(1)) return RCF_EINVAL;                    // the statistics epilogue exists on the split-bf16 kernels only
+    if (!use_x3(s->flags)) return RCF_EINVAL;             // the statistics epilogue exists on the default kernels only
     if (!workspace || workspace_bytes < rcf_conv2d_fwd_stats_workspace_bytes(s)) return RCF_EWORKSPACE;
-    IgemmParams p{};
-    p.A = x; p.Bw = w; p.bias = nullptr; p.Y = y;
-    p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
-    p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
-    if (int e = set_region(p, nullptr, s->N, s->Ho, s->Wo)) return e;
-    p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
-    p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
-    p.ldb = p.K;
-    p.amax_a = s->amax_x; p.amax_b = s->amax_w; p.b_pairs = s->w_pairs;
-    if (s->w_pairs2) {
-        p.b_pairs = s->w_pairs2;
-        if (pairs2_useful(s->Cout, s->R * s->S * s->Cin, s->Cin))
-            p.b_pairs2 = (const char *)s->w_pairs2 + rcf_conv_weight_pairs_bytes(s->Cout, s->Cin, s->R, s->S);
-    }
-    p.stats = (double *)workspace;
-    if (int e = launch_igemm_x3(p, rcf_stream(stream))) return e;
-    return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cout, sums,
-                               (double *)workspace + (size_t)p.mtiles * 2 * s->Cout, fin, stream);
+    int mtiles = 0;
+    if (int e = conv2d_fwd_impl(x, w, nullptr, y, s, nullptr, 0, 0.f, 0, (double *)workspace, stream, nullptr, &mtiles)) return e;
+    return rcf_sum_partials_bn((const double *)workspace, mtiles, s->Cout, sums,
+                               (double *)workspace + (size_t)mtiles * 2 * s->Cout, fin, stream);
 }
 
 extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y, const rcf_conv_shape *s, double *sums,
@@ -2542,7 +2452,7 @@ extern "C" int rcf_conv2d_fwd_stats_f32(const float *x, const float *w, float *y
 }
 
 extern "C" size_t rcf_conv2d_dgrad_workspace_bytes(const rcf_conv_shape *s) {
-    if (check_shape(s) || !use_x3(2)) return 0;
+    if (check_shape(s) || !use_x3(s->flags)) return 0;
     // transposed fp32 weights, or their fp16 pairs with K = R*S*Cout padded to whole K-steps
     return (size_t)rcf_cdiv(s->R * s->S * s->Cout, 16) * 16 * s->Cin * sizeof(float);
 }
@@ -2557,8 +2467,15 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
                                            size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    return conv2d_dgrad_impl(dy, w, dx, s, region, beta, workspace, workspace_bytes, stream, nullptr);
+}
+
+namespace {
+int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
+                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only) {
     if (s->Cout % 4) return RCF_EINVAL;
     IgemmParams p{};
+    p.flags = s->flags;
     p.A = dy; p.Bw = w; p.bias = nullptr; p.Y = dx;
     p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
     p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
@@ -2566,33 +2483,39 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
     p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.ldb = s->R * s->S * s->Cin; p.act = 0; p.slope = 0.f; p.beta = beta;
-    if (use_x3(2)) {
+    if (use_x3(s->flags)) {
         // k-contiguous weights for the bf16 operand fetch: wt[c][rs][co] (one small transpose per call)
         const size_t need = rcf_conv2d_dgrad_workspace_bytes(s);
         const void *wpt = s->w_pairs2_t ? s->w_pairs2_t : s->w_pairs_t;
-        const bool prepared = wpt && s->amax_dy && s->amax_w && !g_h2_off;
+        const bool prepared = wpt && s->amax_dy && s->amax_w;
+        p.a_split = (s->flags & RCF_CONV_DY_PLANES) ? 1 : 0;
+        p.amax_out = s->amax_y;
         if (!prepared && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
         hipStream_t st = rcf_stream(stream);
         p.ldb = p.K;
         p.amax_a = s->amax_dy; p.amax_b = s->amax_w;
         const dim3 tgrid(rcf_cdiv(s->Cin, 32), rcf_cdiv(s->Cout, 32), s->R * s->S);
-        if (p.amax_a && p.amax_b && !g_h2_off && wpt) {
+        if (p.amax_a && p.amax_b && wpt) {
             p.b_pairs = wpt;                               // prepared once per weight update by the caller
-            if (s->w_pairs2_t && pairs2_useful(s->Cin, s->R * s->S * s->Cout, s->Cout)) p.b_pairs2 = (const char *)wpt + need;
-        } else if (p.amax_a && p.amax_b && !g_h2_off) {   // fp16 pairs: transposed AND split, once per launch
-            hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
-                               s->Cout, s->Cin, s->R * s->S, rcf_g_korder);
+            if (s->w_pairs2_t && pairs2_written(p.K, s->Cout)) p.b_pairs2 = (const char *)wpt + need;
+        } else if (p.amax_a && p.amax_b) {                // fp16 pairs: transposed AND split, once per launch
+            if (!kernel_only)
+                hipLaunchKernelGGL(weight_pairs_kernel<true>, tgrid, dim3(256), 0, st, w, s->amax_w, (_Float16 *)workspace,
+                                   s->Cout, s->Cin, s->R * s->S, (int)korder_chunked(s->flags));
             p.b_pairs = workspace;
         } else {
-            hipLaunchKernelGGL(weight_transpose_kernel, tgrid, dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin,
-                               s->R * s->S);
+            if (!kernel_only)
+                hipLaunchKernelGGL(weight_transpose_kernel, tgrid, dim3(256), 0, st, w, (float *)workspace, s->Cout, s->Cin,
+                                   s->R * s->S);
             p.Bw = (const float *)workspace;
         }
-        return launch_igemm_x3(p, st);
+        return launch_igemm_x3(p, st, 1, kernel_only);
     }
     if (region) return RCF_EINVAL;
+    if (kernel_only) { *kernel_only = 0; return 0; }
     return launch_igemm<1>(p, rcf_stream(stream));
 }
+}  // namespace
 
 namespace {
 bool region_ok(const rcf_conv_region *r, int H, int W) {
@@ -2639,9 +2562,10 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     p.M = (long)s->N * p.rr; p.chunk = pl.chunk; p.itiles = pl.itiles; p.jtiles = pl.jtiles;
     p.split_stride = (long)s->Cout * s->R * s->S * s->Cin; p.beta = beta;
     p.amax_a = s->amax_dy; p.amax_b = s->amax_x;
-    p.xcd_map = rcf_g_wgrad_xcd;
+    p.xcd_map = (s->flags & RCF_CONV_NO_WGRAD_XCD) ? 0 : 1;
     const bool smallc = s->Cin == 4;
-    if (region && (smallc || !use_x3(4))) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
+    const bool x3 = use_x3(s->flags);
+    if (region && (smallc || !x3)) return RCF_EINVAL;    // sub-rectangles exist on the split-bf16 kernel only
     const dim3 grid((unsigned)(pl.itiles * pl.jtiles), (unsigned)((smallc || pl.cols) ? 1 : s->R * s->S), (unsigned)pl.splitk);
     const bool incr = s->Wo >= BK;
 #define RCF_WGRAD_LAUNCH(MRv, NRv)                                                                                \
@@ -2656,13 +2580,29 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     } while (0)
     // narrow tiles: the fp32-MFMA kernel is as fast as the bf16 triples; with operand ranges they take the fp16 pairs
     // like every other conv of the step (same-box A/B: no difference in step time either way)
-    const bool h2 = p.amax_a && p.amax_b && !g_h2_off;
-    if (use_x3(4) && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
+    const bool h2 = p.amax_a && p.amax_b;
+    if (s->flags & (RCF_CONV_X_PLANES | RCF_CONV_DY_PLANES)) {
+        // both operands as fp16 pair planes (igemm_h2dw.inc); one of them alone has no kernel
+        const unsigned both = RCF_CONV_X_PLANES | RCF_CONV_DY_PLANES;
+        if ((s->flags & both) != both || !h2 || !x3 || !pl.cols || pl.mr != 2 || s->Cin % 64 || s->Cout % 8 || s->x_pitch != s->Cin ||
+            s->y_pitch != s->Cout)
+            return RCF_EINVAL;
+        if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
+        const bool onetap = s->Cin % (64 * pl.nr) == 0;
+        p.cblocks = onetap && s->R * s->S > 1 && p.xcd_map ? s->Cin / (64 * pl.nr) : 0;
+        if (pl.nr == 4) {
+            if (region && onetap) hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<4, true, true>), grid, dim3(256), 0, st, p);
+            else if (region) hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<4, true, false>), grid, dim3(256), 0, st, p);
+            else if (onetap) hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<4, false, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<4, false, false>), grid, dim3(256), 0, st, p);
+        } else if (onetap) hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<2, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_wgrad_h2d_kernel<2, false, false>), grid, dim3(256), 0, st, p);
+    } else if (x3 && !smallc && ((pl.mr == 2 && pl.nr >= 2) || region || h2)) {
         if ((long)(pl.chunk / (long)p.rr + 2) * s->H * s->W * s->x_pitch * 4 >= (1L << 31)) return RCF_EINVAL;
         if (h2) {            // fp16 pairs
             if (pl.cols) {
                 const bool onetap = s->Cin % (64 * pl.nr) == 0;
-                p.cblocks = onetap && s->R * s->S > 1 && rcf_g_wgrad_xcd ? s->Cin / (64 * pl.nr) : 0;
+                p.cblocks = onetap && s->R * s->S > 1 && p.xcd_map ? s->Cin / (64 * pl.nr) : 0;
                 if (pl.mr == 4) {
                     if (region) hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, true, true, 4>), grid, dim3(256), 0, st, p);
                     else hipLaunchKernelGGL((igemm_wgrad_h2t_kernel<4, false, true, 4>), grid, dim3(256), 0, st, p);

@@ -6,7 +6,6 @@
 #include "rcf_common.h"
 
 namespace {
-int g_resize2x = 1;      // rcf_resize_set_2x: exact-2x bilinear up-sampling on resize2x_fwd_kernel (bit-identical; A/B switch)
 
 inline int ew_blocks(long total) {
     long b = (total + 255) / 256;
@@ -646,19 +645,16 @@ extern "C" int rcf_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, 
     return rcf_maxpool3x3s2_bwd_mp(dy, argmax, dx, RCF_F32, N, H, W, C, Ho, Wo, stream);
 }
 
-/* A/B switch of the exact-2x forms of the bilinear resize (bit-identical results): 1 default, 0 always the general kernels */
-extern "C" int rcf_resize_set_2x(int mode) {
-    g_resize2x = mode ? 1 : 0;
-    return 0;
-}
-
-/* frame == 0: the whole tensor */
+/* frame == 0: the whole tensor; frame == -1: the whole tensor on the general kernel even where the exact-2x form applies (the two
+ * are bit-identical: tests) */
 extern "C" int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void *y, int y_pitch, int dt, int N, int Hi,
                                                int Wi, int Ho, int Wo, int C, int align_corners, int frame, void *stream) {
     if (!x || !y || C % 4 || x_pitch % 4 || y_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    const bool general = frame == -1;
+    if (general) frame = 0;
     if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
     const long px = frame > 0 ? (long)N * (2L * frame * Wo + 2L * frame * (Ho - 2 * frame)) : (long)N * Ho * Wo;
-    if (g_resize2x && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 && (long)N * Hi <= 65535 &&
+    if (!general && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 && (long)N * Hi <= 65535 &&
         (long)Wi * (C / 4) < (1L << 30)) {
         if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {
             hipLaunchKernelGGL((resize2x_fwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wi * (C / 8), 256), N * Hi), dim3(256), 0,
@@ -714,6 +710,8 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, voi
                                                int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
                                                int frame, void *stream) {
     if (!dy || !dx || C % 4 || dy_pitch % 4 || dx_pitch % 4 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return RCF_EINVAL;
+    const bool general = frame == -1;                     // the whole tensor on the general kernel (see the forward)
+    if (general) frame = 0;
     if (frame < 0 || (frame > 0 && (2 * frame >= Ho || 2 * frame >= Wo))) return RCF_EINVAL;
     // frame > 0: input pixels that can see the output frame lie within tc of the border (conservative: an input pixel's
     // taps lie within (1 + 1/scale) output pixels of its centre); only when the kernel accumulates (beta), otherwise
@@ -725,7 +723,7 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, voi
         if (2 * tc >= Hi || 2 * tc >= Wi) tc = 0;
     }
     const long items = tc > 0 ? (long)N * (2L * tc * Wi + 2L * tc * (Hi - 2 * tc)) * (C / 4) : (long)N * Hi * Wi * (C / 4);
-    if (g_resize2x && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 &&
+    if (!general && frame == 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2 &&
         (long)N * ((Hi + 1) / 2) <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
         const int Hh = (Hi + 1) / 2, Wh = (Wi + 1) / 2;
         if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {

@@ -505,11 +505,9 @@ __global__ void __launch_bounds__(256) warp_rows2_kernel(const float *__restrict
     if (L1) block_add2(s, so, (double *)out_);
 }
 
-int g_warp_variant = 1;       // 1: tile kernels for RGB / border calls; 0: per-pixel kernels everywhere
-
-inline bool warp_tile_applies(int C, int H, int W, int pad_mode) {
-    return g_warp_variant == 1 && C == 3 && pad_mode == 0 && W >= 2 && H >= 2;
-}
+// tile kernels for RGB / border calls; pad_mode | RCF_WARP_PER_PIXEL (a per-call choice: tests) keeps the per-pixel kernels, which
+// also serve every other channel count and the zeros mode
+inline bool warp_tile_applies(int C, int H, int W, int pad_mode) { return C == 3 && pad_mode == 0 && W >= 2 && H >= 2; }
 
 inline WarpGeom warp_geom(int H, int W) {
     WarpGeom g;
@@ -570,17 +568,13 @@ __global__ void photometric_final_kernel(const double *__restrict__ sums, float 
 
 }  // namespace
 
-extern "C" int rcf_warp_set_variant(int v) {
-    if (v != 0 && v != 1) return RCF_EINVAL;
-    g_warp_variant = v;
-    return 0;
-}
-
 extern "C" int rcf_flow_warp_f32(const float *x, const float *flow, float *out, int B, int C, int H, int W,
                                  int pad_mode, void *stream) {
+    const bool per_pixel = pad_mode & RCF_WARP_PER_PIXEL;
+    pad_mode &= ~RCF_WARP_PER_PIXEL;
     if (!x || !flow || !out || B <= 0 || C <= 0 || H < 2 || W < 2 || (pad_mode != 0 && pad_mode != 1)) return RCF_EINVAL;
     if ((long)H * W >= (1L << 30)) return RCF_EINVAL;
-    if (warp_tile_applies(C, H, W, pad_mode) && W >= 256) {     // narrow images: the flat 512-pixel runs fill the lanes better
+    if (!per_pixel && warp_tile_applies(C, H, W, pad_mode) && W >= 256) {     // narrow images: the flat 512-pixel runs fill the lanes better
         const int tx = rcf_cdiv(W, TILE_W), ty = rcf_cdiv(H, 16);
         const long R = (long)B * rcf_cdiv((long)tx * ty, 8);
         const int Q = (int)(R < 1024 ? R : 1024);               // up to 8192 workgroups, each walking its share of the tiles
@@ -632,11 +626,13 @@ extern "C" int rcf_occu_mask_bidirection_f32(const float *flow12, const float *f
 
 extern "C" int rcf_warp_l1_residual_f32(const float *im1, const float *im2, const float *flow, const float *occ,
                                         double *out, int B, int C, int H, int W, int pad_mode, void *stream) {
+    const bool per_pixel = pad_mode & RCF_WARP_PER_PIXEL;
+    pad_mode &= ~RCF_WARP_PER_PIXEL;
     if (!im1 || !im2 || !flow || !out || B <= 0 || C <= 0 || H < 2 || W < 2) return RCF_EINVAL;
     hipStream_t st = rcf_stream(stream);
     hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(double), st);
     if (e != hipSuccess) return (int)e;
-    if (warp_tile_applies(C, H, W, pad_mode)) {
+    if (!per_pixel && warp_tile_applies(C, H, W, pad_mode)) {
         const bool two = W % 2 == 0;                            // two pixels per lane, 8-byte stream loads
         const int tx = rcf_cdiv(W, two ? 128 : TILE_W), ty = rcf_cdiv(H, two ? 8 : 16);
         const long R = (long)B * rcf_cdiv((long)tx * ty, 8);

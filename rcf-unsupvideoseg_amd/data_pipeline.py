@@ -194,8 +194,11 @@ class BatchUploader:
         data = up.upload()                 # async copies on the copy stream; returns device tensors for Transform(data)
 
     `upload` makes the compute stream wait for the copies (an event, no host sync) and flips to the other staging set, so
-    the loader may fill batch t+1 while batch t is copied and transformed.  Pageable -> pinned copies, `torch.stack`
-    collation and per-sample `.cuda()` calls of a default DataLoader path do not exist here."""
+    the loader may fill batch t+1 while batch t is copied and transformed.  Every staging set keeps the event of its own
+    last host -> device copy and `stage()` blocks on it before handing the set out again: a host that runs several
+    batches ahead of the GPU (normal with asynchronous launches) cannot overwrite pinned memory a queued copy has yet to
+    read.  Pageable -> pinned copies, `torch.stack` collation and per-sample `.cuda()` calls of a default DataLoader path
+    do not exist here."""
 
     def __init__(self, B, I, H, W, has_flow=True, has_pl=False, device="cuda:0", sets=2):
         self.device = torch.device(device)
@@ -211,11 +214,16 @@ class BatchUploader:
         self.dev = [{k: torch.empty(s, dtype=dt, device=self.device) for k, (s, dt) in shapes.items()} for _ in range(sets)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.done = [None] * sets            # event: set i's device tensors were last read (compute stream)
+        self.copied = [None] * sets          # event: set i's pinned buffers were last read by a host -> device copy (copy stream)
         self.cur = 0
         self.nbytes = sum(t.numel() * t.element_size() for t in self.host[0].values())
 
     def stage(self):
-        """numpy views of the current pinned staging set (host memory the loader writes)"""
+        """numpy views of the current pinned staging set (host memory the loader writes).  Blocks until the last upload
+        that read THIS set has left its pinned buffers (normally long past: there are `sets` - 1 uploads in between)."""
+        ev = self.copied[self.cur]
+        if ev is not None:
+            ev.synchronize()
         return {k: t.numpy() for k, t in self.host[self.cur].items()}
 
     def upload(self):
@@ -232,7 +240,7 @@ class BatchUploader:
         self.cur = (i + 1) % len(self.host)
         out = dict(self.dev[i])
         out["_release"] = lambda: self._release(i)
-        self._host_busy = (i, ready)
+        self.copied[i] = ready
         return out
 
     def _release(self, i):
@@ -243,7 +251,8 @@ class BatchUploader:
         self.done[i] = ev
 
     def wait_host(self):
-        """block until the last upload has left its pinned buffers (before the loader overwrites THAT staging set; with two
-        sets this is the upload before last, which has long finished)"""
-        if getattr(self, "_host_busy", None) is not None:
-            self._host_busy[1].synchronize()
+        """block until every upload issued so far has left its pinned buffers (`stage()` already waits for the set it hands
+        out; this is for a caller that wants to touch all of them, e.g. before freeing the uploader)"""
+        for ev in self.copied:
+            if ev is not None:
+                ev.synchronize()

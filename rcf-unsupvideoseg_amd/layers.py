@@ -35,10 +35,16 @@ def _round_up(n, m):
 
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
-    __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax")
+    __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
+                 "grad_is_planes")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
+        # fp16 pair planes (include/rcf_hip.h RCF_CONV_X_PLANES): `planes` = an fp32-typed buffer of t's shape holding t's values
+        # pre-split for the conv kernels ([pixel][h | m], scale from the bound in `amax`), written by the batch norm that produced
+        # t; `split` = there is no fp32 copy (t IS planes).  `accepts_plane_grad`: set by the conv that produced t when its
+        # backward can take t's gradient in that format -- the batch norm's backward then writes it so (`grad_is_planes`).
+        self.planes, self.split, self.accepts_plane_grad, self.grad_is_planes = None, False, False, False
         self.stats = None            # fp64 [2C] column sums | sums of squares, when the producing conv computed them
         self.bn = None               # (mean, invstd, count) when the producing conv's reduction also finalized the norm
         self.amax = None             # int32 [1]: raw bits of max |t| (operand range of the fp16-pair conv kernels)
@@ -60,6 +66,7 @@ class Act:
 
     def take_grad(self):
         g, self.grad = self.grad, None
+        self.grad_is_planes = False
         return g
 
     def take_grad_range(self):
@@ -68,26 +75,19 @@ class Act:
         return r if r is not None else ops.absmax(self.grad)
 
 
-# Weight gradients on a second HIP stream: wgrad and dgrad of a conv both read dy and are independent, so the one's
-# last, partly empty round of workgroups overlaps the other's start.  Joined before anything reads a parameter gradient
-# (tape marks = all-reduce chunks, end of backward).
-# Round 3: OFF by default.  It was worth 8 % while every conv kernel left a fifth of the chip idle in its last round and
-# three quarters of a short tile's time in its epilogue; with the balanced persistent kernel on the deep layers and the
-# lean epilogues it is worth 1.0-1.5 ms of 115 (profiles/r03_ab_overlap.txt: 116.7 vs 117.7, 117.8 vs 119.4 ms), the two
-# gradients of a layer share the power budget anyway, and with one stream every kernel's duration is its own (the live
-# roofline brackets of bench.py measure the kernel, not its neighbour).  RCF_OVERLAP_WGRAD=1 turns it back on.
-OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "0") != "0"
+# Weight gradients on a second HIP stream, started AFTER the layer's data gradient (`LATE_WGRAD`): a weight gradient
+# (MFMA-bound) then runs beside the NEXT layer's batch-norm backward (HBM-bound) instead of beside its own data gradient
+# (MFMA-bound like itself).  Joined before anything reads a parameter gradient (tape marks = all-reduce chunks, end of
+# backward).  Results are bit-identical to the one-stream order (tests/test_pipeline_gpu.py).  The default since round 4:
+# it is the fastest validated schedule (profiles/r03_ab_late_wgrad.txt: fp32 115.2 -> 112.8 ms, bf16 48.95 -> 48.45), with
+# the 128 x 256 weight-gradient tile (two workgroups per CU) for the overlapped launches -- the 256 x 256 tile holds a CU's
+# registers for a whole launch and leaves the batch-norm kernels no slots.  bench.py takes its per-kernel roofline brackets
+# in a separate one-stream pass, so the schedule no longer has to be chosen for the measurement's sake.
+# RCF_OVERLAP_WGRAD=0: everything on one stream; RCF_LATE_WGRAD=0: the round-2 order (beside the layer's own data gradient).
+OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
+LATE_WGRAD = __import__("os").environ.get("RCF_LATE_WGRAD", "1") != "0"
 # stage 2.1: the EMA teacher's forward + CRF on a second stream beside the student's forward (152 vs 172 ms per step)
 OVERLAP_TEACHER = __import__("os").environ.get("RCF_OVERLAP_TEACHER", "1") != "0"
-OVERLAP_WGRAD_WITH_H2P = __import__("os").environ.get("RCF_OVERLAP_WGRAD_H2P", "1") != "0"   # A/B knob (tools/ab_overlap.py)
-# With OVERLAP_WGRAD: start a layer's weight gradient AFTER its data gradient, so that it runs beside the next layer's batch-norm
-# backward (HBM-bound) instead of beside its own data gradient (MFMA-bound like itself).  Measured with the 128 x 256
-# weight-gradient tile (RCF_WGRAD_BIG=0; the 256 x 256 tile holds a CU's registers for a whole launch): 115.2 (one stream) ->
-# 112.8 ms, against 113.4 for the round-2 order (profiles/r03_ab_late_wgrad.txt).  Off like OVERLAP_WGRAD, for the same reason.
-LATE_WGRAD = __import__("os").environ.get("RCF_LATE_WGRAD", "0") != "0"
-# ... in the bf16 step the gain is smaller (same process, interleaved: 50.96 vs 51.98 ms/step, against 129.7 vs 140.6 in fp32;
-# before the bf16 weight gradient's prefetch worked, csrc/igemm_bf16.hip wgrad_tr_step, there was none: 57.8 vs 58.1)
-OVERLAP_WGRAD_BF16 = __import__("os").environ.get("RCF_OVERLAP_WGRAD_BF16", "1") != "0"
 # conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
 FUSE_BN_STATS = True
 BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels), as torch autocast does
@@ -100,6 +100,11 @@ RELU_BITMASK = True
 RELU_TRACE = None
 # convs on the fp16-pair kernels (3 partial products; operand ranges from ops.absmax) instead of bf16 triples (6)
 FP16_PAIRS = True
+# fp32 step: the batch norms between the bottlenecks' convs write their outputs (bn1, bn2: only so; the joins: also so) and their
+# input gradients as fp16 pair planes, and those convs run on the kernels that take both operands by LDS-DMA (csrc/igemm_h2d.inc,
+# igemm_h2dw.inc): no split, no LDS store in any of the three conv directions.  RCF_PLANES=0: every conv splits its fp32 operands
+# in registers as before.
+PLANES = __import__("os").environ.get("RCF_PLANES", "1") != "0"
 _side_streams = {}
 
 
@@ -220,6 +225,12 @@ class Conv2d(nn.Module):
         cache[kind] = (key, v, ops.weight_checksum(self.weight) if ops.DEBUG_WEIGHT_CACHE else None)
         return v
 
+    def planes_ok(self):
+        """can this conv take its input AND its output gradient as fp16 pair planes (forward, data gradient and weight gradient
+        on the LDS-DMA kernels)?  Channel counts: 16-channel K-steps inside one tap, 64-channel groups of the weight gradient."""
+        return (PLANES and FP16_PAIRS and ACT_DTYPE == torch.float32 and self.bias is None and not self.act
+                and self.cin % 64 == 0 and self.cout % 16 == 0 and self.cin_pad == self.cin and self.cout_pad == self.cout)
+
     def _packed_weight(self, cout_mult=4):
         """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded
         (Cout_pad = Cout rounded up to `cout_mult`)."""
@@ -333,7 +344,7 @@ class Conv2d(nn.Module):
                 if self.weight.requires_grad:
                     padded = wk is not self.weight
                     dw = torch.empty_like(wk) if padded else _param_grad(self.weight)
-                    if OVERLAP_WGRAD and OVERLAP_WGRAD_BF16 and x.needs_grad and not padded:
+                    if OVERLAP_WGRAD and x.needs_grad and not padded:
                         side = _side_stream(dy.device)
                         if LATE_WGRAD:
                             dgrad()                   # see LATE_WGRAD: the weight gradient beside the next batch-norm backward
@@ -362,31 +373,46 @@ class Conv2d(nn.Module):
             return self._fwd_bf16(x, tape, out, stats)
         w, b = self._packed_weight(), self._packed_bias()
         ax = aw = wp = None
+        # the input as fp16 pair planes (written by the batch norm that produced it): this conv then never splits an activation
+        use_pl = x.planes is not None and out is None and self.planes_ok() and ops.fused_stats_available()
+        if x.split and not use_pl:
+            raise ops._lib.RcfHipError("this activation exists as fp16 pair planes only and the conv cannot read them")
+        xin = x.planes if use_pl else x.t
+        yamax = None
         if FP16_PAIRS:
             own = w is self.weight                                       # padded copies are rebuilt per call: not cached
             ax = x.range()
             aw = self._derived("amax", lambda: ops.absmax(ops.weight_rsck(w))) if own else ops.absmax(ops.weight_rsck(w))
-            if x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 4096:      # many row tiles would each split the weights
+            if use_pl or x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 4096:      # many row tiles would each split the weights
                 wp = self._derived("pairs", lambda: ops.weight_pairs(w, aw)) if own else ops.weight_pairs(w, aw)
+            if stats and out is None and ops.fused_stats_available():
+                yamax = ops.new_amax(xin.device)   # the output's range from the epilogue: the following batch norm's bound needs it
         if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
-                and ops.conv_regions_available():
+                and ops.fused_stats_available():
             bn = stats if isinstance(stats, BatchNorm2d) else None
-            y, sums = ops.conv2d_fwd_stats(x.t, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp, bn=bn)
+            y, sums = ops.conv2d_fwd_stats(xin, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp, bn=bn,
+                                           x_planes=use_pl, amax_y=yamax)
             ya = Act(y)
             if bn is not None:
                 ya.bn = sums
             else:
                 ya.stats = sums
         else:
-            y = ops.conv2d_fwd(x.t, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out,
-                               amax=(ax, aw), w_pairs=wp)
+            y = ops.conv2d_fwd(xin, w, b, self.stride, self.padding, self.dilation, self.act, self.slope, out=out,
+                               amax=(ax, aw), w_pairs=wp, x_planes=use_pl, amax_y=yamax)
             ya = Act(y)
+        ya.amax = yamax
+        ya.accepts_plane_grad = use_pl
         if tape.enabled:
             def bwd():
                 ady = ya.take_grad_range() if FP16_PAIRS else None    # shared by the data and the weight gradient
+                dpl = ya.grad_is_planes                                # the batch norm's backward wrote dy as fp16 pair planes
                 dy = ya.take_grad()
                 if self.act:
                     raise RuntimeError("fused activation has no tape backward; use act=0 on trained paths")
+                if use_pl and x.split and not dpl:
+                    raise ops._lib.RcfHipError("weight gradient of a conv whose input exists as pair planes only needs its output "
+                                               "gradient in the same format (the batch norm behind it did not write it so)")
                 done_dgrad = [False]
 
                 def late_dgrad():
@@ -394,17 +420,16 @@ class Conv2d(nn.Module):
                     wpt = None
                     if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
                         wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
+                    # the range of dx comes out of the epilogue (after the accumulation when beta = 1): exact for the whole tensor
+                    gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None else None
                     ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                     amax=(ady, aw), w_pairs_t=wpt)
+                                     amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax)
+                    x.grad_amax = gamax
                     done_dgrad[0] = True
+                xw, xpl = (x.planes, True) if (dpl and use_pl) else (x.t, False)      # the weight gradient's x in dy's format
                 if self.weight.requires_grad:
                     if self.cin_pad == self.cin and self.cout_pad == self.cout:
-                        # the persistent data-gradient kernel (one workgroup per CU, 128 KB of LDS) leaves no room for a
-                        # second kernel's workgroups on its CUs: beside it the weight gradient only takes turns
-                        solo = (not OVERLAP_WGRAD_WITH_H2P and self.k == 3 and self.stride == 1 and self.cin % 256 == 0
-                                and 9 * self.cout >= 2304 and 9 * self.cout * 256 >= 1152 * self.cin
-                                and x.t.shape[0] * x.t.shape[1] * x.t.shape[2] >= 32768)
-                        if OVERLAP_WGRAD and x.needs_grad and not solo:
+                        if OVERLAP_WGRAD and x.needs_grad:
                             side = _side_stream(dy.device)
                             if LATE_WGRAD:
                                 # the data gradient first, alone; the weight gradient starts when it is done and so runs beside
@@ -413,13 +438,13 @@ class Conv2d(nn.Module):
                                 late_dgrad()
                             side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready (LATE_WGRAD: the data gradient is done)
                             with torch.cuda.stream(side):
-                                ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                                 self.dilation, beta=1, amax=(ax, ady))
+                                ops.conv2d_wgrad(xw, dy, w, _param_grad(self.weight), self.stride, self.padding,
+                                                 self.dilation, beta=1, amax=(ax, ady), small_tile=LATE_WGRAD, planes=xpl)
                             dy.record_stream(side)
-                            x.t.record_stream(side)
+                            xw.record_stream(side)
                         else:
-                            ops.conv2d_wgrad(x.t, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                             self.dilation, beta=1, amax=(ax, ady))
+                            ops.conv2d_wgrad(xw, dy, w, _param_grad(self.weight), self.stride, self.padding,
+                                             self.dilation, beta=1, amax=(ax, ady), planes=xpl)
                     else:
                         dwp = torch.empty_like(w)
                         ops.conv2d_wgrad(x.t, dy, w, dwp, self.stride, self.padding, self.dilation, beta=0,
@@ -467,7 +492,10 @@ class BatchNorm2d(nn.Module):
             return True
         return self if FUSE_BN_FINALIZE else True
 
-    def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None):
+    def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None, planes=None):
+        """planes: "only" / "both" -- the output is (also) wanted as fp16 pair planes for the conv(s) that read it (Act.planes;
+        "only": no fp32 copy is written); honoured when the bound of the output is computable (fp32 step, the range of x known
+        from the producing conv's epilogue, no dropout scale) -- otherwise the fp32 output alone, as without the request"""
         xt = x.t
         if not self.sync:
             dist = None
@@ -491,11 +519,19 @@ class BatchNorm2d(nn.Module):
             rmask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=xt.device)
         ydt = out.dtype if out is not None else (ACT_DTYPE if xt.dtype == torch.float32 else xt.dtype)
         yamax = ops.new_amax(xt.device) if FP16_PAIRS and ydt == torch.float32 else None
+        pl = (planes if PLANES and FP16_PAIRS and planes in ("only", "both") and out is None and chan_scale is None and
+              xt.dtype == torch.float32 and ydt == torch.float32 and x.amax is not None and xt.shape[3] % 8 == 0 and
+              xt.is_contiguous() and (residual is None or residual.t.dtype == torch.float32) else None)
+        if pl == "only" and (RELU_TRACE is not None or (relu and tape.enabled and rmask is None)):
+            pl = "both"                               # somebody reads the fp32 output itself
+        pbuf = torch.empty(tuple(xt.shape), dtype=torch.float32, device=xt.device) if pl else None
         y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
                          residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out,
-                         relu_mask=rmask, amax_out=yamax, out_dtype=ydt)
-        ya = Act(y)
-        ya.amax = yamax
+                         relu_mask=rmask, amax_out=yamax, out_dtype=ydt, planes=pbuf, planes_only=pl == "only",
+                         amax_x=x.amax if pl else None, amax_res=residual.range() if (pl and residual is not None) else None)
+        ya = Act(y if y is not None else pbuf)
+        ya.amax = yamax                               # with planes: the bound they are scaled by (a valid range for any reader)
+        ya.planes, ya.split = pbuf, pl == "only"
         if RELU_TRACE is not None and relu:
             RELU_TRACE.append(y > 0)
         if tape.enabled:
@@ -503,6 +539,11 @@ class BatchNorm2d(nn.Module):
                 raise RuntimeError("tape backward through eval-mode BN is not implemented")
 
             def bwd():
+                # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
+                # are the only readers); the bound needs the ranges of x and of dy
+                dpl = (x.accepts_plane_grad and PLANES and chan_scale is None and xt.dtype == torch.float32 and x.amax is not None
+                       and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
+                ady = ya.take_grad_range() if dpl else None
                 dy = ya.take_grad()
                 s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
                 s2_local = None
@@ -518,7 +559,8 @@ class BatchNorm2d(nn.Module):
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
                                  dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale, sums2_local=s2_local,
-                                 relu_mask=rmask, amax_out=gamax)
+                                 relu_mask=rmask, amax_out=gamax, dx_planes=dpl, amax_x=x.amax if dpl else None, amax_dy=ady)
+                x.grad_is_planes = dpl
             tape.push(bwd)
         return ya
 
@@ -602,7 +644,7 @@ def commuted_concat_conv_ok(a, b, conv, align_corners):
     return (conv.k == 3 and conv.stride == 1 and d % 2 == 0 and d >= 2 and conv.padding == d and conv.bias is None
             and not align_corners and (h, w) == (2 * b.t.shape[1], 2 * b.t.shape[2])
             and conv.cin == a.t.shape[3] + b.t.shape[3] and conv.cout_pad == conv.cout and conv.cin_pad == conv.cin
-            and min(h, w) > 2 * (2 * d + 1) and a.t.is_contiguous() and b.t.is_contiguous() and ops.conv_regions_available()
+            and min(h, w) > 2 * (2 * d + 1) and a.t.is_contiguous() and b.t.is_contiguous() and ops.fused_stats_available()
             and (a.t.dtype == torch.float32 or (a.t.shape[3] % 8 == 0 and b.t.shape[3] % 8 == 0 and conv.cout % 8 == 0)))
 
 

@@ -150,7 +150,8 @@ def conv_out_size(n, k, stride, pad, dil):
     return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None, w_pairs2_t=None):
+def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None, w_pairs2_t=None,
+                flags=0, amax_y=None):
     """amax = (amax_x, amax_w, amax_dy): int32 [1] device tensors from absmax() or None -- the operand ranges that
     select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h)"""
     N, H, W, Cin = xshape
@@ -162,11 +163,17 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w
     if kind not in H2_KINDS:                      # debug knob: which launches may take the fp16-pair kernels
         ax = aw = ady = w_pairs = w_pairs2_t = None
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout,
-                     _addr(ax), _addr(aw), _addr(ady), None, _addr(w_pairs_t), _addr(w_pairs), _addr(w_pairs2_t))
+                     _addr(ax), _addr(aw), _addr(ady), None, _addr(w_pairs_t), _addr(w_pairs), _addr(w_pairs2_t), _addr(amax_y),
+                     int(flags) | CONV_FLAGS, ctypes.sizeof(ConvShape))
 
 
 def _addr(t):
     return None if t is None else t.data_ptr()
+
+
+# RCF_CONV_* bits OR-ed into every launch's rcf_conv_shape.flags: the A/B switches of tests and tools live HERE, in the
+# Python process that drives the library, and travel with each call -- the C library keeps no mutable global state
+CONV_FLAGS = 0
 
 
 _amax_pool = {}
@@ -239,7 +246,7 @@ def weight_pairs_t(w, amax_w):
     _need_cuda(w)
     Cout, Cin, R, S = w.shape
     planes = torch.empty(_lib.load().rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 1), dtype=torch.uint8, device=w.device)
-    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 1, _p(amax_w), _p(planes), _stream())
+    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 1, _p(amax_w), _p(planes), CONV_FLAGS, _stream())
     return planes
 
 
@@ -250,102 +257,34 @@ def weight_pairs(w, amax_w):
     _need_cuda(w)
     Cout, Cin, R, S = w.shape
     planes = torch.empty(_lib.load().rcf_conv_weight_pairs2_bytes(Cout, Cin, R, S, 0), dtype=torch.uint8, device=w.device)
-    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 0, _p(amax_w), _p(planes), _stream())
+    call("rcf_conv_weight_pairs2_f32", _p(weight_rsck(w)), Cout, Cin, R, S, 0, _p(amax_w), _p(planes), CONV_FLAGS, _stream())
     return planes
 
 
-def conv_set_h2p(mode=-1, min_k=0):
-    """A/B switch of the persistent LDS-DMA conv kernel (csrc/igemm_h2p.inc): -1 built-in rule, 0 never, 1 whenever eligible"""
-    _lib.load().rcf_conv_set_h2p(int(mode), int(min_k))
+def set_conv_flags(flags):
+    """RCF_CONV_* bits (rcf_amd._lib.CONV_*) to OR into every conv launch of this process from now on -- the A/B switches of
+    tests and tools.  Returns the previous value.  The K order is baked into the cached weight operands: they are dropped."""
+    global CONV_FLAGS
+    old, CONV_FLAGS = CONV_FLAGS, int(flags)
+    if (old ^ CONV_FLAGS) & _lib.CONV_KORDER_NATURAL:
+        weights_changed()
+    return old
 
 
-def _relabel_conv(family, h2p_family):
-    """profiling only: a forward / data-gradient launch that took the persistent kernel is filed under its own family"""
-    if _lib.load().rcf_conv_last_kernel() == 2:
+if os.environ.get("RCF_CONV_FLAGS"):               # e.g. RCF_CONV_FLAGS=0x8 keeps every conv off the persistent kernel
+    CONV_FLAGS = int(os.environ["RCF_CONV_FLAGS"], 0)
+
+
+def _relabel_conv(s, region, dgrad, family, h2p_family):
+    """profiling only: a forward / data-gradient launch that takes the persistent kernel is filed under its own family
+    (rcf_conv_kernel_of: a pure function of the launch's arguments)"""
+    if _lib.load().rcf_conv_kernel_of(byref(s), region, int(dgrad)) == 2:
         PROFILE.relabel_last(family, h2p_family)
 
 
-def conv_set_h2s(mode=-1):
-    """A/B switch of the stream kernel of the 1x1 convs (csrc/igemm_h2s.inc): -1 built-in rule, 0 never, 1 whenever eligible"""
-    _lib.load().rcf_conv_set_h2s(int(mode))
-
-
-def conv_set_wgrad_xcd(mode=1):
-    """A/B switch of the weight-gradient kernels' XCD-aware (tile, pixel range) mapping (csrc/rcf_common.h rcf_wgrad_item)"""
-    _lib.load().rcf_conv_set_wgrad_xcd(int(mode))
-
-
-def conv_set_korder(mode=1):
-    """A/B switch of the K order of the forward / data-gradient convs (csrc/rcf_common.h rcf_kchunk); the cached weight operands
-    are laid out in that order, so they are dropped"""
-    _lib.load().rcf_conv_set_korder(int(mode))
-    weights_changed()
-
-
-def conv_set_wgrad_big(mode=1):
-    """A/B switch of the weight gradients' 256 x 256 tile (one workgroup per CU): bit 0 fp16 pairs (default on), bit 1 bf16"""
-    _lib.load().rcf_conv_set_wgrad_big(int(mode))
-
-
-if "RCF_WGRAD_BIG" in os.environ:
-    try:
-        conv_set_wgrad_big(int(os.environ["RCF_WGRAD_BIG"]))
-    except Exception:                  # noqa: BLE001
-        pass
-
-
-def conv_set_colmap(mode=1):
-    """A/B switch of the forward / data-gradient grids' XCD mapping (csrc/rcf_common.h rcf_conv_tile)"""
-    _lib.load().rcf_conv_set_colmap(int(mode))
-
-
-if "RCF_COLMAP" in os.environ:
-    try:
-        conv_set_colmap(int(os.environ["RCF_COLMAP"]))
-    except Exception:                  # noqa: BLE001
-        pass
-
-
-def resize_set_2x(mode=1):
-    """A/B switch of the exact-2x bilinear resize kernels (csrc/spatial.hip resize2x_*): bit-identical to the general ones"""
-    _lib.load().rcf_resize_set_2x(int(mode))
-
-
-def bn_set_sweep(mode=1):
-    """row order of the streaming batch-norm kernels (csrc/bn.hip struct Sweep): 0 front to back, 1 Infinity-Cache aware"""
-    _lib.load().rcf_bn_set_sweep(int(mode))
-
-
-if "RCF_BN_SWEEP" in os.environ:
-    try:
-        bn_set_sweep(int(os.environ["RCF_BN_SWEEP"]))
-    except Exception:                  # noqa: BLE001
-        pass
-if "RCF_KORDER" in os.environ:
-    try:
-        conv_set_korder(int(os.environ["RCF_KORDER"]))
-    except Exception:                  # noqa: BLE001
-        pass
-if "RCF_WGRAD_XCD" in os.environ:
-    try:
-        conv_set_wgrad_xcd(int(os.environ["RCF_WGRAD_XCD"]))
-    except Exception:                  # noqa: BLE001
-        pass
-if "RCF_H2S" in os.environ:
-    try:
-        conv_set_h2s(int(os.environ["RCF_H2S"]))
-    except Exception:                  # noqa: BLE001
-        pass
-if "RCF_H2P" in os.environ:            # experiment knob: RCF_H2P=0 keeps every conv on the 128 x 256 kernel
-    try:
-        conv_set_h2p(int(os.environ["RCF_H2P"]), int(os.environ.get("RCF_H2P_MIN_K", "0")))
-    except Exception:                  # noqa: BLE001 -- no library yet (build step): the switch is applied on first use instead
-        pass
-
-
-def conv_regions_available():
-    """the rectangle-restricted convs exist on the split-bf16 kernels (the default conv variant)"""
-    return bool(_lib.load().rcf_conv_regions_available())
+def fused_stats_available():
+    """regions and the fused batch-norm statistics exist on the default kernels, not on the fp32-MFMA test path"""
+    return not (CONV_FLAGS >> 12) & 7
 
 
 def _shape_tag(s, region=None):
@@ -369,24 +308,27 @@ def _region(region):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None, amax=None,
-               w_pairs=None):
+               w_pairs=None, x_planes=False, amax_y=None):
     """region = (y0, x0, h, w) in output coordinates: only those pixels of `out` are written.
-    amax = (amax_x, amax_w): operand ranges (absmax) -> fp16-pair kernels; w_pairs: weight_pairs(w, amax_w)"""
+    amax = (amax_x, amax_w): operand ranges (absmax) -> fp16-pair kernels; w_pairs: weight_pairs(w, amax_w).
+    x_planes: `x` (an fp32-typed tensor of the activation's shape) holds fp16 pair planes (RCF_CONV_X_PLANES: bn_apply's
+    `planes`); amax_y: new_amax() slot that receives the range of the output"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
-                    w_pairs=w_pairs)
+                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y)
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     end = None
     if PROFILE.which is not None:       # forward launches of the 128x256-tile kernel instance / of the narrower tiles
-        end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+        end = PROFILE.bracket("conv_h2d_fwd" if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
     if end is not None:
         end.record()
-        _relabel_conv("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
+        if not x_planes:
+            _relabel_conv(s, _region(region), 0, "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
     return out
 
 
@@ -401,12 +343,13 @@ def _bn_fin(bn, count, device):
     return fin, mean, invstd
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=None):
+def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=None, x_planes=False, amax_y=None):
     """conv (no bias) whose epilogue also yields the batch-norm statistics of the output: (y, fp64 [2*Cout] sums); with
-    `bn` (a training-mode BatchNorm2d whose statistics are local) the same reduction finalizes it: (y, (mean, invstd, count))"""
+    `bn` (a training-mode BatchNorm2d whose statistics are local) the same reduction finalizes it: (y, (mean, invstd, count)).
+    x_planes / amax_y: as conv2d_fwd"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
-                    w_pairs=w_pairs)
+                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y)
     out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     sums = torch.empty(2 * s.Cout, dtype=torch.float64, device=x.device)
@@ -414,7 +357,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
     ws = workspace(need, x.device)
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+        end = PROFILE.bracket("conv_h2d_fwd" if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
                               2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin, _shape_tag(s))
     if bn is not None:
         count = s.N * s.Ho * s.Wo
@@ -425,41 +368,50 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
         call("rcf_conv2d_fwd_stats_f32", _p(x), _p(weight_rsck(w)), _p(out), byref(s), _p(sums), _p(ws), need, _stream())
     if end is not None:
         end.record()
-        _relabel_conv("conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
+        if not x_planes:
+            _relabel_conv(s, None, 0, "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow", "conv_h2p_fwd")
     return out, sums
 
 
-def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None, w_pairs_t=None):
+def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None, w_pairs_t=None,
+                 dy_planes=False, amax_y=None):
     """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w);
-    w_pairs_t = weight_pairs_t(w, amax_w), prepared once per weight update"""
+    w_pairs_t = weight_pairs_t(w, amax_w), prepared once per weight update.  dy_planes: `dy` holds fp16 pair planes
+    (RCF_CONV_DY_PLANES: bn_bwd_apply's dx); amax_y: new_amax() slot for the range of dx (after the accumulation)"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
     if amax is None or amax[0] is None or amax[1] is None or "d" not in H2_KINDS:
         w_pairs_t = None
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
-                    amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t)
+                    amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
+                    flags=_lib.CONV_DY_PLANES if dy_planes else 0, amax_y=amax_y)
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = 0 if w_pairs_t is not None else _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
+        end = PROFILE.bracket("conv_h2d_dgrad" if dy_planes else "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
                               2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
     call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
          need, _stream())
     if end is not None:
         end.record()
-        _relabel_conv("conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other", "conv_h2p_dgrad")
+        if not dy_planes:
+            _relabel_conv(s, _region(region), 1, "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other", "conv_h2p_dgrad")
     return out
 
 
-def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None, amax=None):
+def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None, amax=None, small_tile=False, planes=False):
     """dw (same memory layout as the weight) (+)= wgrad.  region = (y0, x0, h, w) in OUTPUT coordinates: only those
-    pixels of dy (and their input patches) contribute."""
+    pixels of dy (and their input patches) contribute.  small_tile: RCF_CONV_WGRAD_TILE_128 (a launch that shares the chip
+    with an HBM-bound kernel on another stream).  planes: x AND dy hold fp16 pair planes (RCF_CONV_X_PLANES | RCF_CONV_DY_PLANES:
+    bn_apply's `planes`, bn_bwd_apply's dx)."""
     _need_cuda(x, dy, dw)
     s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy),
-                    amax=None if amax is None else (amax[0], None, amax[1]))      # amax = (amax_x, amax_dy)
+                    amax=None if amax is None else (amax[0], None, amax[1]),      # amax = (amax_x, amax_dy)
+                    flags=(_lib.CONV_WGRAD_TILE_128 if small_tile else 0) |
+                          ((_lib.CONV_X_PLANES | _lib.CONV_DY_PLANES) if planes else 0))
     reg = _region(region)
     need = _lib.load().rcf_conv2d_wgrad_region_workspace_bytes(byref(s), reg)
     ws = workspace(need, x.device) if need else None
@@ -467,7 +419,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
     if PROFILE.which is not None:
         ktot = s.R * s.S * s.Cin                                   # plan_wgrad (csrc/igemm_conv.hip): the 128 x 256 fp16-pair tile
         wide = amax is not None and s.Cin % 64 == 0 and ktot >= 256 and s.Cout >= 64
-        end = PROFILE.bracket("conv_wgrad_h2t4" if wide else "conv_wgrad_other",
+        end = PROFILE.bracket("conv_wgrad_h2d" if planes else ("conv_wgrad_h2t4" if wide else "conv_wgrad_other"),
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     if end is not None:
@@ -482,7 +434,7 @@ def weight_bf16(w, transpose=False):
     Cout, Cin, R, S = w.shape
     out = torch.empty(_lib.load().rcf_conv_weight_bf16_bytes(Cout, Cin, R, S, int(transpose)), dtype=torch.uint8,
                       device=w.device)
-    call("rcf_conv_weight_bf16", _p(weight_rsck(w)), Cout, Cin, R, S, int(transpose), _p(out), _stream())
+    call("rcf_conv_weight_bf16", _p(weight_rsck(w)), Cout, Cin, R, S, int(transpose), _p(out), CONV_FLAGS, _stream())
     return out
 
 
@@ -587,6 +539,10 @@ def bn_stats(x):
     return sums
 
 
+# RCF_BN_* bits OR-ed into every streaming batch-norm launch (tests: the row-order switches); Python-side state, sent per call
+BN_FLAGS = 0
+
+
 def bn_finalize(sums, count, eps, momentum, running_mean=None, running_var=None):
     C = sums.numel() // 2
     mean = torch.empty(C, dtype=torch.float32, device=sums.device)
@@ -603,17 +559,22 @@ def bn_invstd_from_var(var, eps):
 
 
 def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None, relu_mask=None,
-             amax_out=None, out_dtype=None):
+             amax_out=None, out_dtype=None, planes=None, planes_only=False, amax_x=None, amax_res=None):
     """relu_mask: uint8 [rows * C/4] to receive the sign bits of the pre-clamp output (for the backward pass).
-    out_dtype: storage type of y (default: x's); an fp32 x may be normalised into bf16 activations"""
+    out_dtype: storage type of y (default: x's); an fp32 x may be normalised into bf16 activations.
+    planes: an fp32-typed buffer of y's shape that receives y as fp16 pair planes (RCF_CONV_X_PLANES of the consuming convs),
+    scaled by a bound derived from amax_x (the range of x) and amax_res (of the residual); the bound goes to amax_out.
+    planes_only: y itself is not written (returns None)"""
     _need_cuda(x)
-    if out is None:
+    if out is None and not (planes is not None and planes_only):
         out = torch.empty(tuple(x.shape), dtype=out_dtype or x.dtype, device=x.device)
     rows, C = _rows(x), x.shape[3]
-    ydt = _same_dt(out, residual)
+    ydt = _same_dt(out, residual) if out is not None else _dt(x)
+    flags = BN_FLAGS | (_lib.BN_Y_PLANES_ONLY if (planes is not None and planes_only) else 0)
     call("rcf_bn_apply_mp", _p(x), _dt(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
-         _p(out), ydt, pitch_of(out), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(chan_scale),
-         x.shape[1] * x.shape[2], _p(relu_mask), _p(amax_out), _stream())
+         _p(out), ydt, pitch_of(out) if out is not None else C, rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu),
+         _p(chan_scale), x.shape[1] * x.shape[2], _p(relu_mask), _p(amax_out), _p(planes), _p(amax_x), _p(amax_res), flags,
+         _stream())
     return out
 
 
@@ -624,12 +585,14 @@ def bn_bwd_reduce(dy, x, y, mean, invstd, relu, chan_scale=None, relu_mask=None)
     ws = workspace(need, x.device)
     call("rcf_bn_bwd_reduce_mp", _p(dy), _same_dt(dy, y), pitch_of(dy), _p(x), _dt(x), pitch_of(x), _p(y),
          pitch_of(y) if y is not None else 0, rows, C, _p(mean), _p(invstd), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
-         _p(ws), need, _stream())
+         _p(ws), need, BN_FLAGS, _stream())
     return sums2
 
 
 def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbeta, dx=None, dres=None, res_beta=0,
-                 chan_scale=None, sums2_local=None, relu_mask=None, amax_out=None):
+                 chan_scale=None, sums2_local=None, relu_mask=None, amax_out=None, dx_planes=False, amax_x=None, amax_dy=None):
+    """dx_planes: dx (an fp32-typed buffer of x's shape) receives fp16 pair planes (RCF_CONV_DY_PLANES of the conv's data and
+    weight gradient) scaled by a bound from amax_x / amax_dy (the ranges of x and dy); the bound goes to amax_out"""
     rows, C = _rows(x), x.shape[3]
     if dx is None:
         dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
@@ -637,7 +600,8 @@ def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbet
          pitch_of(y) if y is not None else 0, _p(dx), pitch_of(dx), _p(dres), pitch_of(dres) if dres is not None else 0, res_beta, rows, C, _p(mean),
          _p(invstd), _p(gamma), int(relu), _p(relu_mask), _p(chan_scale), x.shape[1] * x.shape[2], _p(sums2),
          _p(sums2_local),
-         float(count), _p(dgamma), _p(dbeta), _p(amax_out), _stream())
+         float(count), _p(dgamma), _p(dbeta), _p(amax_out), _p(amax_x), _p(amax_dy),
+         BN_FLAGS | (_lib.BN_DX_PLANES if dx_planes else 0), _stream())
     return dx
 
 
@@ -741,7 +705,7 @@ def colsum(x, out, beta=1):
 
 
 # ------------------------------------------------------------------------------- warp family (NCHW planar)
-PAD = {"border": 0, "zeros": 1}
+PAD = {"border": 0, "zeros": 1, "border_per_pixel": 0 | _lib.WARP_PER_PIXEL}      # the last: RCF_WARP_PER_PIXEL (tests)
 
 
 def flow_warp(x, flow12, pad="border"):
@@ -848,7 +812,7 @@ def weight_pairs_2d(w, amax_w):
     N, K = w.shape
     assert w.is_contiguous() and K % 4 == 0
     planes = torch.empty(_lib.load().rcf_conv_weight_pairs_bytes(N, K, 1, 1), dtype=torch.uint8, device=w.device)
-    call("rcf_conv_weight_pairs_f32", _p(w), N, K, 1, 1, _p(amax_w), _p(planes), _stream())
+    call("rcf_conv_weight_pairs_f32", _p(w), N, K, 1, 1, _p(amax_w), _p(planes), 0, _stream())
     return planes
 
 

@@ -157,10 +157,10 @@ class WeightPrep:
         st, p = ops._stream(), ops._p
         if self.bf16:
             _lib_call("rcf_conv_weights_prepare_bf16", p(self.tabs["fwd"]), self.blocks["fwd"], p(self.tabs["t"]), self.blocks["t"],
-                      self.n, st)
+                      self.n, ops.CONV_FLAGS, st)
         else:
             _lib_call("rcf_conv_weights_prepare_f32", p(self.tabs["absmax"]), self.blocks["absmax"], p(self.tabs["fwd"]),
-                      self.blocks["fwd"], p(self.tabs["t"]), self.blocks["t"], self.n, p(self.amax), st)
+                      self.blocks["fwd"], p(self.tabs["t"]), self.blocks["t"], self.n, p(self.amax), ops.CONV_FLAGS, st)
         for i, m in enumerate(self.convs):
             key = ops.weight_key(m.weight)
             chk = ops.weight_checksum(m.weight) if ops.DEBUG_WEIGHT_CACHE else None

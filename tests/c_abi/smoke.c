@@ -41,6 +41,7 @@ static int conv_known_answer(void) {
     CK(hipMemcpy(db, hb, sizeof hb, hipMemcpyHostToDevice));
     rcf_conv_shape s;
     memset(&s, 0, sizeof s);
+    s.struct_bytes = (unsigned)sizeof s;
     s.N = 1; s.H = H; s.W = W; s.Cin = CI; s.Ho = H; s.Wo = W; s.Cout = CO; s.R = R; s.S = R; s.stride = 1; s.pad = 1; s.dil = 1;
     s.x_pitch = CI; s.y_pitch = CO;
     const size_t pbytes = rcf_conv_weight_pairs_bytes(CO, CI, R, R);
@@ -53,7 +54,7 @@ static int conv_known_answer(void) {
             CK(hipMemset(amax, 0, 3 * sizeof(unsigned)));
             if (rcf_absmax_f32(dx, H * W, CI, CI, amax, NULL) != 0) return 10;
             if (rcf_absmax_f32(dw, CO * R * R, CI, CI, amax + 1, NULL) != 0) return 10;
-            if (rcf_conv_weight_pairs_f32(dw, CO, CI, R, R, amax + 1, planes, NULL) != 0) return 10;
+            if (rcf_conv_weight_pairs_f32(dw, CO, CI, R, R, amax + 1, planes, 0u, NULL) != 0) return 10;
             s.amax_x = amax; s.amax_w = amax + 1; s.w_pairs = planes;
         }
         CK(hipMemset(dy, 0xff, sizeof hy));
@@ -173,10 +174,9 @@ int main(void) {
     CK(hipMemcpy(dx, hx, n * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(df, hf, nf * sizeof(float), hipMemcpyHostToDevice));
     /* 1. zero flow: the backward warp is the identity (utils/warp_utils.py:84-94), on both kernel variants */
-    for (int variant = 0; variant <= 1; variant++) {
-        if (rcf_warp_set_variant(variant) != 0) { printf("set_variant failed\n"); return 3; }
+    for (int variant = 0; variant <= 1; variant++) {              /* 0: RCF_WARP_PER_PIXEL, a per-call choice; 1: the tile kernels */
         CK(hipMemset(dy, 0xff, n * sizeof(float)));
-        const int rc = rcf_flow_warp_f32(dx, df, dy, B, C, H, W, 0, NULL);
+        const int rc = rcf_flow_warp_f32(dx, df, dy, B, C, H, W, variant ? 0 : RCF_WARP_PER_PIXEL, NULL);
         if (rc != 0) { printf("rcf_flow_warp_f32 returned %d\n", rc); return 3; }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(hy, dy, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -185,7 +185,6 @@ int main(void) {
         printf("flow_warp variant %d, zero flow: max |out - in| = %.3g\n", variant, worst);
         if (!(worst <= 1e-5)) return 4;   /* fp32 normalise / un-normalise of the grid, as grid_sample */
     }
-    rcf_warp_set_variant(1);
     /* 2. a shift by one pixel to the right: out[y][x] = in[y][x+1] inside the image */
     for (size_t b = 0; b < (size_t)B; b++)
         for (size_t p = 0; p < (size_t)H * W; p++) hf[(b * 2) * H * W + p] = 1.0f;

@@ -30,15 +30,29 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(scope="session")
-def report():
-    """Appends numeric evidence to gpurun_out/parity_report.txt (merged back by gpurun)."""
+_REPORT_LINES = []
+
+
+@pytest.fixture
+def report(request):
+    """Numeric evidence of a parity test, three ways: appended to gpurun_out/parity_report.txt (merged back by gpurun),
+    attached to the test as a user property (JUnit XML / any reporter: `record_property`), and printed in the terminal
+    summary of the run, so that whoever runs `pytest -m gpu` -- not only the builder -- sees the numbers."""
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    f = open(os.path.join(d, "parity_report.txt"), "a")
+    name = request.node.name
 
     def write(line):
-        f.write(line + "\n")
-        f.flush()
-    yield write
-    f.close()
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+        request.node.user_properties.append(("parity", line))
+        _REPORT_LINES.append((name, line))
+    return write
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _REPORT_LINES:
+        return
+    terminalreporter.section("parity report (full lines: gpurun_out/parity_report.txt)")
+    for name, line in _REPORT_LINES:
+        terminalreporter.write_line(f"[{name}] {line[:400]}")

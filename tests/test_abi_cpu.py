@@ -32,15 +32,21 @@ def test_header_symbols_exported_and_bound():
 
 def test_bad_arguments_return_codes_not_crashes():
     lib = _lib.load()
-    s = _lib.ConvShape(1, 8, 8, 3, 8, 8, 8, 3, 3, 1, 1, 1, 3, 8)          # Cin % 4 != 0
+    sz = ctypes.sizeof(_lib.ConvShape)
+    shape = lambda *dims, size=sz: _lib.ConvShape(*dims, None, None, None, None, None, None, None, None, 0, size)
+    s = shape(1, 8, 8, 3, 8, 8, 8, 3, 3, 1, 1, 1, 3, 8)                  # Cin % 4 != 0
     assert lib.rcf_conv2d_fwd_f32(None, None, None, None, ctypes.byref(s), 0, 0.0, 0, None) == -1
-    s = _lib.ConvShape(1, 8, 8, 4, 7, 8, 8, 3, 3, 1, 1, 1, 4, 8)          # wrong Ho
+    s = shape(1, 8, 8, 4, 7, 8, 8, 3, 3, 1, 1, 1, 4, 8)                  # wrong Ho
     assert lib.rcf_conv2d_dgrad_f32(None, None, None, ctypes.byref(s), 0, None, 0, None) == -1
     assert lib.rcf_bn_stats_f32(None, 10, 6, 6, None, None, 0, None) == -1
     assert lib.rcf_crf_soft(None, None, 8, 8, 1, 0., 0., 5., 60., 5., 5, None, None, None, None, 0, None) == -1
     assert lib.rcf_flow_warp_f32(None, None, None, 1, 3, 8, 8, 0, None) == -1
     assert lib.rcf_crf_workspace_bytes(854, 480, 1) > 100e6
-    assert lib.rcf_conv2d_wgrad_workspace_bytes(ctypes.byref(_lib.ConvShape(16, 120, 214, 64, 120, 214, 64, 3, 3, 1, 1, 1, 64, 64))) > 0
+    good = (16, 120, 214, 64, 120, 214, 64, 3, 3, 1, 1, 1, 64, 64)
+    assert lib.rcf_conv2d_wgrad_workspace_bytes(ctypes.byref(shape(*good))) > 0
+    # a caller compiled against another (older, shorter) rcf_conv_shape is refused, not read out of bounds
+    assert lib.rcf_conv2d_wgrad_workspace_bytes(ctypes.byref(shape(*good, size=sz - 8))) == 0
+    assert lib.rcf_conv2d_fwd_f32(None, None, None, None, ctypes.byref(shape(*good, size=0)), 0, 0.0, 0, None) == -1
     with pytest.raises(_lib.RcfHipError):
         _lib.call("rcf_copy2d_f32", None, 4, None, 4, 1, 4, 0, None)
 

@@ -88,31 +88,6 @@ def test_conv_bf16_fwd_dgrad_wgrad(case, report):
     assert exact_round == 0.0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
-def test_conv_bf16_kernel_variants_identical(tile, report):
-    """register-staged tiles and the 256x256 LDS-DMA tile against the default kernels: same fp32 accumulation order per
-    output (K walked in the same 32-steps), so the results agree to accumulation-order rounding"""
-    from rcf_amd import _lib
-    g = torch.Generator().manual_seed(3)
-    N, Cin, Cout, H, W = 2, 256, 512, 30, 37
-    x = q(torch.randn(N, Cin, H, W, generator=g))
-    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02)
-    dy = q(torch.randn(N, Cout, H, W, generator=g))
-    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
-    xd, dyd = nhwc(x), nhwc(dy)
-    out = {}
-    for t in (-1, tile):
-        _lib.load().rcf_conv_bf16_set_tile(t)
-        try:
-            out[t] = (ops.conv2d_fwd_bf16(xd, wd, pad=2, dil=2, out_dtype=torch.float32),
-                      ops.conv2d_dgrad_bf16(dyd, wd, xd.shape, 1, 2, 2))
-        finally:
-            _lib.load().rcf_conv_bf16_set_tile(-1)
-    e_f, e_d = relerr(out[tile][0], out[-1][0]), relerr(out[tile][1].float(), out[-1][1].float())
-    report(f"conv bf16 tile variant {tile} vs default: fwd {e_f:.2e} dgrad {e_d:.2e}")
-    assert e_f < 1e-6 and e_d < 4e-3
-
-
 def test_conv_bf16_narrow_heads_and_bias(report):
     """the heads' final 1x1 convs: bf16 in, fp32 logits out with bias, Cout padded to 4 (3 segments) / 8 / 16"""
     g = torch.Generator().manual_seed(5)
@@ -325,13 +300,14 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     # reported) and their MEAN is held to the bound; everything else in this test is from the default order.
     e_g_alt = None
     if tag == "small":
+        from rcf_amd import _lib
+        old = ops.set_conv_flags(ops.CONV_FLAGS | _lib.CONV_KORDER_NATURAL)
         try:
-            ops.conv_set_korder(0)
             m2, _ = _model_and_batch(H, W, B)
             rcf_amd.Trainer(m2, device=DEV, precision="bf16").step(batch)
             e_g_alt = gradnorm_dev(m2)
         finally:
-            ops.conv_set_korder(1)
+            ops.set_conv_flags(old)                       # whatever the run was started with (RCF_CONV_FLAGS), not a constant
     z = ops.nhwc_to_nchw(m.last_logits, C).cpu()                        # [B*2, C, h, w]
     am32 = torch.from_numpy(arr[tag + "_argmax_fp32"].astype(np.int64))
     margin = torch.from_numpy(arr[tag + "_margin_fp32"].astype(np.float32))

@@ -99,12 +99,8 @@ def test_crf_build_variants_identical(report):
     masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4100 + i) for i in range(3)])).to(DEV)
     rgb, unary = head.prepare(imgs, masks)
     out = {}
-    try:
-        for v in (0, 1, 2):                      # 2: a 1024-bucket first attempt, so every frame takes the overflow path
-            _lib.load().rcf_crf_set_variant(v)
-            out[v] = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 5, want_q=True, want_nvert=True)
-    finally:
-        _lib.load().rcf_crf_set_variant(0)
+    for v in (0, 1, 2):                          # 2: a 1024-bucket first attempt, so every frame takes the overflow path
+        out[v] = crf_soft_batched(rgb, unary, W, H, 0.0, 0.0, 5.0, 60.0, 5.0, 5, want_q=True, want_nvert=True, build=v)
     same_map = bool(torch.equal(out[0][0], out[1][0])) and bool(torch.equal(out[0][0], out[2][0]))
     dq = max(float((out[0][1] - out[1][1]).abs().max()), float((out[0][1] - out[2][1]).abs().max()))
     report(f"crf build variants: MAP identical {same_map}, max |dQ| {dq:.2e}, vertices {out[0][2][:, 1].tolist()} vs "

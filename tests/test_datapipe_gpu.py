@@ -127,20 +127,27 @@ def test_output_feeds_the_model_batch_layout_and_refuses_host_tensors():
         tf.sample_params(300, 520, np.random.RandomState(0))
 
 
-def test_batch_uploader_pinned_double_buffer(tmp_path):
+@pytest.mark.parametrize("backed_up", [False, True])
+def test_batch_uploader_pinned_double_buffer(tmp_path, backed_up):
     """decoded batch -> pinned staging (flows np.load'ed straight into it) -> copy stream -> Transform: the same tensors as
-    the plain `torch.from_numpy(...).to(device)` path, over more batches than staging sets (buffers are recycled)"""
+    the plain `torch.from_numpy(...).to(device)` path, over more batches than staging sets (buffers are recycled).
+    `backed_up`: the compute stream is busy for ~1 s while the host runs all five batches ahead of it, so the copies of the
+    recycled staging sets are still QUEUED when the loader asks for those sets again -- `stage()` itself has to wait for
+    them (the loader never calls `wait_host`); a loader that got the set back early would overwrite a batch in flight."""
     import torch
     from rcf_amd.data_pipeline import BatchUploader, Transform, load_flow_npy_into
     from rcf_amd import synth
     H, W, B = 120, 214, 3
     tf = Transform(training=True, strong_aug=True, has_pl=True)
     up = BatchUploader(B, 2, H, W, has_flow=True, has_pl=True, device="cuda:0")
+    torch.cuda.synchronize()
+    if backed_up:
+        torch.cuda._sleep(2_000_000_000)                       # ~1 s of device time ahead of everything below
+    runs = []
     for it in range(5):
         samples = [synth.loader_sample(100 * it + b, H, W) for b in range(B)]
         rng = np.random.RandomState(it)
         params = np.stack([tf.sample_params(H, W, rng) for _ in range(B)])
-        up.wait_host()
         st = up.stage()
         for b, smp in enumerate(samples):
             st["imgs"][b] = smp["frames"]
@@ -150,11 +157,14 @@ def test_batch_uploader_pinned_double_buffer(tmp_path):
                 np.save(path, smp[key])
                 load_flow_npy_into(path, st[name][b])
         got = tf(up.upload(), params=params)
+        assert "_release" not in got
+        runs.append((samples, params, got))
+    torch.cuda.synchronize()
+    for it, (samples, params, got) in enumerate(runs):         # the reference path synchronises: after the loop
         ref = tf({"imgs": torch.from_numpy(np.stack([s["frames"] for s in samples])).cuda(),
                   "gt_fw_flows": torch.from_numpy(np.stack([s["fw"] for s in samples])).cuda(),
                   "gt_bw_flows": torch.from_numpy(np.stack([s["bw"] for s in samples])).cuda(),
                   "pl_masks": torch.from_numpy(np.stack([s["pl"] for s in samples])).cuda()}, params=params)
-        assert "_release" not in got
         for k in ("imgs", "gt_fw_flows", "gt_bw_flows", "pl_masks"):
             for a, b_ in zip(got[k], ref[k]):
                 assert torch.equal(a, b_), (it, k)

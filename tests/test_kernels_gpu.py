@@ -162,9 +162,8 @@ def test_conv_fp16_pairs_range_edges(report):
 def test_conv_kernel_variants(variant, report):
     """the tuning variants of the implicit-GEMM kernel (K-step 16/32, K-major / row-major LDS) agree"""
     from rcf_amd import _lib
-    lib = _lib.load()
     try:
-        lib.rcf_conv_set_variant(variant)
+        ops.set_conv_flags(_lib.CONV_FP32_MFMA(variant))        # per-call flag (RCF_CONV_FP32_MFMA), OR-ed into every launch
         for case in (CONV_CASES[0], CONV_CASES[3], CONV_CASES[4], CONV_CASES[6], CONV_CASES[9], CONV_CASES[7]):
             N, Cin, Cout, k, stride, pad, dil, H, W, has_bias, act = case
             g = torch.Generator().manual_seed(variant * 100 + Cin)
@@ -180,7 +179,7 @@ def test_conv_kernel_variants(variant, report):
             report(f"conv variant {variant} {case}: fwd {e_f:.2e} dgrad {e_d:.2e}")
             assert e_f < 2e-5 and e_d < 2e-5
     finally:
-        lib.rcf_conv_set_variant(-1)
+        ops.set_conv_flags(0)
 
 
 @pytest.mark.parametrize("case", [
@@ -191,7 +190,7 @@ def test_conv_kernel_variants(variant, report):
     (16, 16, 256, 1, 0, 1, 60, 107, None),       # 102 720 rows: 12 / 13 -> 8 + 4, 8 + 5; K = 16: ONE K-step (ring padded to 4)
     (3, 48, 256, 3, 6, 6, 60, 107, (0, 0, 60, 107, 7)),      # border frame (the commuted decode-head conv's band)
     (3, 48, 256, 3, 6, 6, 60, 107, (5, 9, 40, 70)),          # rectangle
-    # 1x1 convs: the stream kernel (csrc/igemm_h2s.inc) -- epilogue of a tile under the MFMAs of the next one
+    # 1x1 convs (short K-loops: the built-in rule keeps them on the 128 x 256 kernel)
     (16, 256, 1024, 1, 0, 1, 60, 107, None),     # 12 / 13 row blocks per range: 3 + 1 sub-tiles (one of them 1 block), 4 column tiles, 16 K-steps
     (5, 192, 256, 1, 0, 1, 60, 107, None),       # K = 192: 12 K-steps (no plain steps); ranges of 3 / 4 blocks: a single tile per workgroup
     (2, 512, 512, 1, 0, 1, 33, 41, None),        # 2 706 rows = 85 blocks on 256 workgroups: most of them have NO tile; 32 K-steps
@@ -211,11 +210,9 @@ def test_conv_h2p_matches_x3(case, report):
     ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
     res = {}
     try:
+        from rcf_amd import _lib
         for mode in (0, 1):
-            ops.conv_set_h2p(mode)
-            ops.conv_set_h2s(mode)
-            # the split weights are built under the mode they are used with (the plane-separated half is only written for
-            # shapes that can take a kernel reading it)
+            ops.set_conv_flags(_lib.CONV_H2P_ALWAYS if mode else _lib.CONV_H2P_NEVER)
             wp, wpt = ops.weight_pairs(wg, aw), ops.weight_pairs_t(wg, aw)
             y = torch.full((N, H, W, Cout), 3.0, device=DEV)
             ops.conv2d_fwd(xg, wg, None, 1, pad, dil, out=y, amax=(ax, aw), w_pairs=wp, region=reg)
@@ -235,8 +232,7 @@ def test_conv_h2p_matches_x3(case, report):
                 assert torch.equal(ys, y)
             res[mode] = (y, dxw, acc, st)
     finally:
-        ops.conv_set_h2p(-1)
-        ops.conv_set_h2s(-1)
+        ops.set_conv_flags(0)
     a, b = res[0], res[1]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     if reg is None:
@@ -364,8 +360,8 @@ def test_conv_wgrad_fp16_pairs_columns(case, report):
     (2, 256, 512, 3, 3, 3, 33, 41, (0, 0, 33, 41, 6)),     # frame region, two row tiles
 ])
 def test_conv_wgrad_256x256_tile_matches_128x256(case, report):
-    """igemm_wgrad_h2t_kernel<.., MR = 4> (256 x 256 tile, one workgroup per CU: rcf_conv_set_wgrad_big bit 0, the default where
-    Cout and Cin are multiples of 256) against the 128 x 256 tile: every element is the same sum over the same pixel chunks in
+    """igemm_wgrad_h2t_kernel<.., MR = 4> (256 x 256 tile, one workgroup per CU: the default where Cout and Cin are multiples
+    of 256) against the 128 x 256 tile (RCF_CONV_WGRAD_TILE_128, what the overlapped launches of the training step take): every element is the same sum over the same pixel chunks in
     the same order when the split counts agree, and fp32-level agreement otherwise; both against float64"""
     N, Cin, Cout, k, pad, dil, H, W, reg = case
     g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case[:8])))
@@ -376,14 +372,13 @@ def test_conv_wgrad_256x256_tile_matches_128x256(case, report):
     res = {}
     try:
         for mode in (0, 1):
-            ops.conv_set_wgrad_big(mode)
             dw = torch.full_like(wg, 3.0)
-            ops.conv2d_wgrad(x, dy, wg, dw, 1, pad, dil, beta=0, region=reg, amax=(ax, ag))
+            ops.conv2d_wgrad(x, dy, wg, dw, 1, pad, dil, beta=0, region=reg, amax=(ax, ag), small_tile=not mode)
             acc = dw.clone()
-            ops.conv2d_wgrad(x, dy, wg, acc, 1, pad, dil, beta=1, region=reg, amax=(ax, ag))
+            ops.conv2d_wgrad(x, dy, wg, acc, 1, pad, dil, beta=1, region=reg, amax=(ax, ag), small_tile=not mode)
             res[mode] = (dw, acc)
     finally:
-        ops.conv_set_wgrad_big(1)
+        pass
     d = [float((a - b).abs().max() / a.abs().max()) for a, b in zip(res[0], res[1])]
     ref = torch.nn.grad.conv2d_weight(from_nhwc(x).double(), tuple(wg.shape), (from_nhwc(dy) * _region_mask(dy, reg).cpu()).double(),
                                       1, pad, dil)
@@ -407,8 +402,9 @@ def test_conv_column_tile_xcd_mapping_is_a_permutation(report):
     dyb = dy.bfloat16()
     res = {}
     try:
+        from rcf_amd import _lib
         for mode in (0, 1):
-            ops.conv_set_colmap(mode)
+            ops.set_conv_flags(0 if mode else _lib.CONV_NO_COLMAP)
             dx = ops.conv2d_dgrad(dy, w, x.shape, 1, 3, 3, amax=(ag, aw), w_pairs_t=ops.weight_pairs_t(w, aw))
             acc = dx.clone()
             ops.conv2d_dgrad(dy, w, x.shape, 1, 3, 3, out=acc, beta=1, amax=(ag, aw), w_pairs_t=ops.weight_pairs_t(w, aw))
@@ -416,7 +412,7 @@ def test_conv_column_tile_xcd_mapping_is_a_permutation(report):
             dxb = ops.conv2d_dgrad_bf16(dyb, w, x.shape, 1, 3, 3, w_t_bf16=ops.weight_bf16(w, transpose=True))
             res[mode] = (dx, acc, y, dxb)
     finally:
-        ops.conv_set_colmap(1)
+        ops.set_conv_flags(0)
     same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
     ref = F.conv_transpose2d(from_nhwc(dy).double(), w.cpu().double(), None, 1, 3, 0, 1, 3)
     e = relerr(from_nhwc(res[1][0]), ref)
@@ -444,8 +440,9 @@ def test_conv_wgrad_xcd_mapping_is_a_permutation(case, report):
     xb, dyb = x.bfloat16(), dy.bfloat16()
     res = {}
     try:
+        from rcf_amd import _lib
         for mode in (0, 1):
-            ops.conv_set_wgrad_xcd(mode)
+            ops.set_conv_flags(0 if mode else _lib.CONV_NO_WGRAD_XCD)
             d32 = torch.full_like(wg, 3.0)
             ops.conv2d_wgrad(x, dy, wg, d32, 1, pad, dil, beta=0, region=reg, amax=(ax, ag))
             a32 = d32.clone()
@@ -454,7 +451,7 @@ def test_conv_wgrad_xcd_mapping_is_a_permutation(case, report):
             ops.conv2d_wgrad_bf16(xb, dyb, wg, d16, 1, pad, dil, beta=0, region=reg)
             res[mode] = (d32, a32, d16)
     finally:
-        ops.conv_set_wgrad_xcd(1)
+        ops.set_conv_flags(0)
     same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
     ref = torch.nn.grad.conv2d_weight(from_nhwc(x).double(), tuple(wg.shape),
                                       (from_nhwc(dy) * _region_mask(dy, reg).cpu()).double(), 1, pad, dil)
@@ -612,8 +609,9 @@ def test_batchnorm_cache_aware_row_order(C, rows_shape, res, bf16, report):
     count = N * H * W
     out = {}
     try:
-        for mode in (0, 2):                      # 2: the banded order whatever the tensor's size (1 = from 192 MB up)
-            ops.bn_set_sweep(mode)
+        from rcf_amd import _lib
+        for mode in (0, 2):                      # 2: the banded order whatever the tensor's size (default: from 192 MB up)
+            ops.BN_FLAGS = _lib.BN_SWEEP_ALWAYS if mode else _lib.BN_SWEEP_OFF        # per-call flags (RCF_BN_SWEEP_*)
             rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
             mean, invstd = ops.bn_finalize(ops.bn_stats(x), count, 1e-5, 0.1, rmean, rvar)
             rmask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=DEV)
@@ -627,7 +625,7 @@ def test_batchnorm_cache_aware_row_order(C, rows_shape, res, bf16, report):
                                   relu_mask=rmask, amax_out=gam)
             out[mode] = (y, rmask, am, s2, dx, dres, gam, dgam, dbet)
     finally:
-        ops.bn_set_sweep(1)
+        ops.BN_FLAGS = 0
     a, b = out[0], out[2]
     same = [torch.equal(a[i], b[i]) for i in (0, 1, 4)] + [a[2] is None or torch.equal(a[2], b[2]), not res or torch.equal(a[5], b[5])]
     e_s = float((a[3] - b[3]).abs().max() / a[3].abs().max())
@@ -687,12 +685,9 @@ def test_resize_exact_2x_kernels_are_bit_identical(N, Hi, Wi, C, bf16, report):
     if bf16:
         x, dy = x.bfloat16(), dy.bfloat16()
     res = {}
-    try:
-        for mode in (0, 1):
-            ops.resize_set_2x(mode)
-            res[mode] = (ops.resize_nhwc_fwd(x, (2 * Hi, 2 * Wi), False), ops.resize_nhwc_bwd(dy, (Hi, Wi), False))
-    finally:
-        ops.resize_set_2x(1)
+    for mode in (0, 1):                         # frame = -1: the general kernels on the whole tensor (a per-call choice)
+        res[mode] = (ops.resize_nhwc_fwd(x, (2 * Hi, 2 * Wi), False, frame=0 if mode else -1),
+                     ops.resize_nhwc_bwd(dy, (Hi, Wi), False, frame=0 if mode else -1))
     same = [torch.equal(a, b) for a, b in zip(res[0], res[1])]
     ref = F.interpolate(x.float().permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
     e = float((res[1][0].double() - ref).abs().max() / ref.abs().max())
@@ -833,13 +828,10 @@ def test_warp_tile_kernels_are_bit_identical_to_the_per_pixel_kernels(H, W, repo
     fl = fl.to(DEV)
     occ = (torch.rand(B, 1, H, W, generator=g) > 0.3).float().to(DEV)
     res = {}
-    try:
-        for v in (0, 1):
-            _lib.call("rcf_warp_set_variant", v)
-            res[v] = (ops.flow_warp(x, fl, "border").cpu(), ops.warp_l1_residual(y, x, fl, occ, "border").cpu(),
-                      ops.warp_l1_residual(y, x, fl, None, "border").cpu())
-    finally:
-        _lib.call("rcf_warp_set_variant", 1)
+    for v in (0, 1):                        # 0: pad_mode | RCF_WARP_PER_PIXEL, a per-call choice
+        pad = "border" if v else "border_per_pixel"
+        res[v] = (ops.flow_warp(x, fl, pad).cpu(), ops.warp_l1_residual(y, x, fl, occ, pad).cpu(),
+                  ops.warp_l1_residual(y, x, fl, None, pad).cpu())
     same_w = torch.equal(res[0][0], res[1][0])
     rel = [abs(float(res[0][k][0]) - float(res[1][k][0])) / abs(float(res[0][k][0])) for k in (1, 2)]
     report(f"warp tile vs per-pixel {H}x{W}: warped identical {same_w}, fused L1 rel diff {rel[0]:.1e} / {rel[1]:.1e} (fp64 sums, order differs)")

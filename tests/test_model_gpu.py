@@ -49,21 +49,6 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def _sampled_grad_errors_ulp(H, W, affine, B, fx, seed):
-    """one training step with every parameter moved by one unit in the last place (random signs, the recipe of
-    tests/golden/make_golden.py's reference runs): sampled-gradient errors against the float64 truth"""
-    model = _build(H, W, affine, DEV, rcf_amd.RCFModel)
-    g = torch.Generator().manual_seed(1000 + seed)
-    for k, v in model.state_dict().items():
-        if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")):
-            v.mul_(1 + (torch.randint(0, 2, v.shape, generator=g).float() * 2 - 1).to(v.device) * 2.0 ** -23)
-    tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=DEV)
-    tr.step(_batch(B, H, W, DEV))
-    named = dict(model.named_parameters())
-    return {str(n): rel(named[str(n)].grad.detach().cpu().contiguous().numpy().ravel()[:256], fx[f"truth_grad_{i}"])
-            for i, n in enumerate(fx["sampled"])}
-
-
 @pytest.mark.parametrize("tag,H,W,affine", [("rcf_small", 96, 160, False), ("rcf_small_affine", 64, 96, True)])
 def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
     fx = np.load(os.path.join(golden_dir, tag + ".npz"))
@@ -124,82 +109,10 @@ def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
     assert mism == 0
     assert max(e_loss.values()) < TOL
     assert all(e_gn[k] < lim_gn[k] for k in e_gn), (e_gn, lim_gn)
-    if not all(e_grad[k] < lim_grad[k] for k in e_grad):
-        # Per-element gradients of this net jump when one ReLU / max-pool / clamp decision that sits within an ulp of
-        # its kink falls the other way (measured: the error of a sampled slice is bimodal, ~1e-3 or ~1.3e-2, over
-        # evaluations whose parameters differ by one unit in the last place -- tools/h2_lottery.py).  Backward
-        # stability is the criterion: the result must be the float64 truth's, to the limit, for SOME input within one
-        # ulp of the given one, and within 10x the limit for all of them.
-        worst, first = dict(e_grad), dict(e_grad)
-        for seed in (1, 2, 3, 4):
-            e_s = _sampled_grad_errors_ulp(H, W, affine, B, fx, seed)
-            e_grad = {k: min(e_grad[k], e_s[k]) for k in e_grad}
-            worst = {k: max(worst[k], e_s[k]) for k in worst}
-        import warnings
-        marker = (f"ONE-ULP-CRITERION USED [{tag}]: the plain run missed the sampled-gradient limit on "
-                  f"{[k for k in worst if not first[k] < lim_grad[k]]}; best of 5 one-ulp-perturbed runs {e_grad}, worst {worst}")
-        report(marker)
-        warnings.warn(marker)
-        print(marker)
-        assert all(worst[k] < 10 * lim_grad[k] for k in worst), (worst, lim_grad)
     assert all(e_grad[k] < lim_grad[k] for k in e_grad), (e_grad, lim_grad)
     # the first Adam step is sign-like (g / (|g| + 1e-8)): fp32 noise on near-zero gradients flips +-lr updates,
     # so the post-step loss is only loosely comparable (the Adam kernel itself is pinned in test_kernels_gpu)
     assert e_after < 1e-2
-
-
-def test_train_step_vs_oracle_all_grads(report):
-    """EVERY parameter gradient of the HIP tape (through the `loss.backward()` bridge main.py uses) against
-    the oracle in float64; yardstick = the oracle's own fp32 error against that truth."""
-    import rcf_torch as orc
-    H, W, B = 64, 96, 2
-    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
-    o32 = _build(H, W, False, "cpu", orc.RCFModel)
-    o64 = _build(H, W, False, "cpu", orc.RCFModel).double()
-    tr = rcf_amd.Trainer(hip, device=DEV)
-    b32 = _batch(B, H, W, "cpu")
-    b64 = {k: ([t.double() for t in v] if k in ("imgs", "gt_fw_flows", "gt_bw_flows") else v) for k, v in b32.items()}
-    for m, b in ((o32, b32), (o64, b64)):
-        m.train()
-        m(b)["loss"].backward()
-    # other equally valid fp32 evaluations of the same model on this host: one thread, channels_last convolutions
-    alt = []
-    nthreads = torch.get_num_threads()
-    for nt, cl in ((1, False), (nthreads, True)):
-        torch.set_num_threads(nt)
-        m = _build(H, W, False, "cpu", orc.RCFModel)
-        m = m.to(memory_format=torch.channels_last) if cl else m
-        m.train()
-        m(b32)["loss"].backward()
-        alt.append(dict(m.named_parameters()))
-    torch.set_num_threads(nthreads)
-    tr.fp.zero_grad()
-    hip.train()
-    lh = hip(_batch(B, H, W, DEV))
-    lh["loss"].backward()
-    g32, g64 = dict(o32.named_parameters()), dict(o64.named_parameters())
-    # per-parameter relative L2 error.  A ReLU whose pre-activation is within fp32 noise of zero can switch
-    # between two valid fp32 evaluations; with 96..192 pixels per channel at this geometry ONE switched unit moves
-    # that channel's weight gradient by ~1/sqrt(pixels) and the tensor's L2 error to ~5e-3, whichever
-    # implementation it happens in -- hence the 1e-2 floor next to the 6x-the-reference's-own-error limit.
-    worst_ratio, worst_name, worst_abs, bad = 0.0, "", 0.0, []
-    for n, p in hip.named_parameters():
-        truth = g64[n].grad
-        scale = float(truth.norm())
-        if scale < 1e-12:
-            continue
-        e_hip = float((p.grad.cpu().double() - truth).norm()) / scale
-        e_ref = max(float((g[n].grad.double() - truth).norm()) / scale for g in [g32] + alt)
-        ratio = e_hip / max(e_ref, 1e-5)
-        if e_hip > max(6.0 * e_ref, 1e-2):
-            bad.append((n, e_hip, e_ref))
-        if ratio > worst_ratio:
-            worst_ratio, worst_name, worst_abs = ratio, n, e_hip
-    ob = dict(o32.named_buffers())
-    e_buf = max(rel(b.cpu().numpy(), ob[n].numpy()) for n, b in hip.named_buffers() if b.dtype == torch.float32)
-    report(f"all-grads vs float64 oracle (relative L2 per parameter): worst HIP/CPU-fp32 error ratio {worst_ratio:.2f} at "
-           f"{worst_name} (HIP err {worst_abs:.2e}); parameters over max(6x ref, 1e-2): {len(bad)}; BN buffers {e_buf:.2e}")
-    assert not bad and e_buf < TOL, bad
 
 
 def test_train_step_all_grads_at_fixed_relu_pattern(monkeypatch, report):
@@ -482,69 +395,102 @@ def test_bn_buffers_after_two_steps_vs_oracle(report):
     assert n >= 50 and worst_m < 2e-3 and worst_v < 2e-3
 
 
-def test_fullsize_b8_losses_and_gradients_vs_oracle(report):
+def _mem_available_gb():
+    try:
+        return [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+    except Exception:                                           # noqa: BLE001
+        return 0.0
+
+
+def _module_gradnorms(model):
+    gn = {}
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+    return {k: v ** 0.5 for k, v in gn.items()}
+
+
+def test_fullsize_b8_losses_and_argmax_vs_oracle(report):
     """BASELINE configs[1] at its real batch: 8 pairs of 480x854 (16 frames through the backbone, batch-norm statistics over
-    all of them) -- every loss term of one training-mode forward AND the gradient norm of every top-level module of the
-    backward against the oracle on the host in fp32 (the reference-generated fixture of this geometry holds one pair; the
-    oracle is pinned to the reference on the small cases and on that pair); the bf16 step (BASELINE configs[2] on one rank)
-    on the same batch against the same oracle numbers, at the reference's own autocast-vs-fp32 deviation of this geometry
-    (tests/golden/bf16.json, 480x854: gradient norms up to 8 %, losses 2e-4 .. 1.3e-3; limits 3x, floors 0.5 % / 10 %).
-    The oracle's backward at this size needs ~45 GB of host memory: hosts with less run the forward comparison only."""
+    all of them) -- every loss term of one training-mode forward, the logits and the segment arg-max of all 16 frames against
+    the oracle on the host in fp32 (the reference-generated fixture of this geometry holds one pair; the oracle is pinned to
+    the reference on the small cases and on that pair).  Arg-max: identical on every pixel whose top-2 margin exceeds
+    1e-4 x max |logit| (the criterion of the small cases).  The bf16 step (BASELINE configs[2] on one rank) on the same batch
+    against the same oracle losses, at the reference's own autocast-vs-fp32 deviation of this geometry (tests/golden/bf16.json)."""
     import json
     import rcf_torch as orc
     H, W, B = 480, 854, 8
-    avail_gb = 0.0
-    try:
-        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
-    except Exception:                                           # noqa: BLE001
-        pass
-    with_grad = avail_gb >= 90
-
-    def gnorms(model):
-        gn = {}
-        for n, p in model.named_parameters():
-            if p.grad is not None:
-                gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
-        return {k: v ** 0.5 for k, v in gn.items()}
     ora = _build(H, W, False, "cpu", orc.RCFModel)
     ora.train()
-    if with_grad:
+    grabbed = {}
+    hook = ora.decode_head2.register_forward_hook(lambda m, i, o: grabbed.__setitem__("logits", o.detach()))
+    with torch.no_grad():
         lo = ora(_batch(B, H, W, "cpu"))
-        lo["loss"].backward()
-        go = gnorms(ora)
-    else:
-        with torch.no_grad():
-            lo = ora(_batch(B, H, W, "cpu"))
-        go = None
+    hook.remove()
     lo = {k: float(v) for k, v in lo.items()}
+    lg_o = grabbed["logits"].float().numpy()                           # [16, 4, 120, 214]
+    del ora
+    out, lg_h = {}, None
+    for prec in ("fp32", "bf16"):
+        hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+        hip.precision = prec
+        hip.train()
+        with torch.no_grad():
+            lh = hip(_batch(B, H, W, DEV))
+        out[prec] = {k: float(v) for k, v in lh.items()}
+        if prec == "fp32":
+            lg_h = rcf_amd.ops.nhwc_to_nchw(hip.last_logits).cpu().numpy()
+        del hip
+        torch.cuda.empty_cache()
+    e32 = {k: rel(out["fp32"][k], lo[k]) for k in lo}
+    e16 = {k: rel(out["bf16"][k], lo[k]) for k in lo}
+    e_logits = rel(lg_h, lg_o)
+    top2 = np.sort(lg_o, axis=1)[:, -2:]
+    sure = (top2[:, 1] - top2[:, 0]) > TOL * float(np.abs(lg_o).max())
+    mism = int((lg_h.argmax(1) != lg_o.argmax(1))[sure].sum())
+    report(f"480x854 b8 (16 frames): fp32 " + " ".join(f"{k} hip {out['fp32'][k]:.6f} oracle {lo[k]:.6f} ({e32[k]:.1e})" for k in lo) +
+           f" | logits {e_logits:.2e}, arg-max mismatches on sure pixels {mism} of {int(sure.sum())} (unsure {int((~sure).sum())})"
+           " | bf16 " + " ".join(f"{k} {e16[k]:.1e}" for k in lo))
+    assert all(np.isfinite(v) for v in out["fp32"].values()) and max(e32.values()) < TOL
+    assert e_logits < TOL and mism == 0
+    ref16 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
+    assert all(e16[k] < max(3 * ref16["loss"][k], 5e-3) for k in e16), e16
+
+
+def test_fullsize_b8_gradients_vs_oracle(report):
+    """the backward of the same batch: the gradient norm of every top-level module against the oracle's fp32 backward on the
+    host.  Yardstick (tests/golden/oracle_b8_selfdev.json, tools/oracle_b8_selfdev.py): how far two equally valid fp32
+    evaluations of the ORACLE differ on this very batch (contiguous vs channels_last convolutions) -- limit 4 x that, floor
+    1e-4, per module (the small cases use 4 x the reference's own fp32 error the same way).  bf16: the reference's own
+    autocast-vs-fp32 deviation of this geometry (limits 3x, floor 10 %).
+    The oracle's backward at this size needs ~45 GB of host memory: SKIPPED, visibly, on hosts with less than 90 GB free."""
+    import json
+    import rcf_torch as orc
+    H, W, B = 480, 854, 8
+    avail_gb = _mem_available_gb()
+    if avail_gb < 90:
+        pytest.skip(f"host has {avail_gb:.0f} GB available: the oracle's fp32 backward at 8 x 480x854 needs ~45 GB (limit 90)")
+    here = os.path.dirname(os.path.abspath(__file__))
+    dev_self = json.load(open(os.path.join(here, "golden", "oracle_b8_selfdev.json")))["gradnorm_dev"]
+    ora = _build(H, W, False, "cpu", orc.RCFModel)
+    ora.train()
+    ora(_batch(B, H, W, "cpu"))["loss"].backward()
+    go = _module_gradnorms(ora)
     del ora
     out = {}
     for prec in ("fp32", "bf16"):
         hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
         hip.precision = prec
         hip.train()
-        lh = hip(_batch(B, H, W, DEV))
-        if with_grad:
-            lh["loss"].backward()
-        out[prec] = ({k: float(v) for k, v in lh.items()}, gnorms(hip) if with_grad else None)
+        hip(_batch(B, H, W, DEV))["loss"].backward()
+        out[prec] = _module_gradnorms(hip)
         del hip
         torch.cuda.empty_cache()
-    e32 = {k: rel(out["fp32"][0][k], lo[k]) for k in lo}
-    e16 = {k: rel(out["bf16"][0][k], lo[k]) for k in lo}
-    msg = (f"480x854 b8 (16 frames): fp32 " + " ".join(f"{k} hip {out['fp32'][0][k]:.6f} oracle {lo[k]:.6f} ({e32[k]:.1e})" for k in lo) +
-           " | bf16 " + " ".join(f"{k} {e16[k]:.1e}" for k in lo))
-    assert all(np.isfinite(v) for v in out["fp32"][0].values()) and max(e32.values()) < TOL
-    ref16 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
-    assert all(e16[k] < max(3 * ref16["loss"][k], 5e-3) for k in e16), e16
-    if with_grad:
-        g32 = {k: rel(out["fp32"][1][k], v) for k, v in go.items()}
-        g16 = {k: rel(out["bf16"][1][k], v) for k, v in go.items()}
-        msg += (" | gradient norms vs oracle: fp32 " + " ".join(f"{k} {v:.1e}" for k, v in g32.items()) +
-                " bf16 " + " ".join(f"{k} {v:.1e}" for k, v in g16.items()))
-        report(msg)
-        # fp32: two valid fp32 evaluations of this network differ by up to 2.7e-3 in the backbone's gradient norm at this
-        # geometry (tests/golden/oracle_vs_reference.json: the reference against itself); limit 4x that
-        assert max(g32.values()) < 1.1e-2, g32
-        assert all(g16[k] < max(3 * ref16["gradnorm"][k], 0.10) for k in g16), g16
-    else:
-        report(msg + f" | host has {avail_gb:.0f} GB available: the oracle's backward at this size was skipped")
+    g32 = {k: rel(out["fp32"][k], v) for k, v in go.items()}
+    g16 = {k: rel(out["bf16"][k], v) for k, v in go.items()}
+    lim32 = {k: max(TOL, 4 * float(dev_self[k])) for k in go}
+    report("480x854 b8 gradient norms vs oracle: fp32 " + " ".join(f"{k} {v:.1e} (limit {lim32[k]:.1e})" for k, v in g32.items()) +
+           " bf16 " + " ".join(f"{k} {v:.1e}" for k, v in g16.items()))
+    assert all(g32[k] < lim32[k] for k in g32), (g32, lim32)
+    ref16 = json.load(open(os.path.join(here, "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
+    assert all(g16[k] < max(3 * ref16["gradnorm"][k], 0.10) for k in g16), g16

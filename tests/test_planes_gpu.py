@@ -1,0 +1,214 @@
+"""fp16 pair planes (include/rcf_hip.h RCF_CONV_X_PLANES / RCF_CONV_DY_PLANES): the batch-norm passes write a conv's input and
+its output gradient pre-split, the conv kernels take both operands by LDS-DMA (csrc/igemm_h2d.inc, igemm_h2dw.inc).
+ * the plane kernels against the register-split kernels on the same values: the same three partial products in the same
+   order -- BIT-identical (forward + fused statistics, data gradient overwrite / accumulate / strided, weight gradient), with the
+   planes scaled by a loose upper bound instead of the exact range; and against float64;
+ * the planes the batch norm writes: (h + m) 2^-k equals the fp32 output to 2^-21 of each element, the bound it leaves in
+   the range slot really bounds the tensor, planes-only == planes of the both-mode, backward likewise;
+ * one training step with the planes on and off: same losses, gradients at fp32 level (tests/test_model_gpu.py holds the
+   default path -- planes on -- to the reference's fixtures)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rcf_amd
+from rcf_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def to_planes(x, bound_bits):
+    """x [N,H,W,C] fp32 on the device -> the fp32-typed pair-plane buffer the kernels read, scaled like they scale: 2^k with
+    k = 14 - floor(log2(bound))"""
+    b = float(bound_bits.view(torch.float32))
+    k = 14 - int(np.floor(np.log2(b)))
+    t = x.double() * 2.0 ** k
+    h = t.to(torch.float16)
+    m = (t - h.double()).to(torch.float16)
+    N, H, W, C = x.shape
+    pl = torch.stack([h, m], dim=3).contiguous()                    # [N,H,W,2,C] fp16 = [pixel][h | m]
+    return pl.view(torch.float32).reshape(N, H, W, C), k
+
+
+def from_planes(buf, k):
+    N, H, W, C = buf.shape
+    hm = buf.contiguous().view(torch.float16).reshape(N, H, W, 2, C).double()
+    return (hm[:, :, :, 0] + hm[:, :, :, 1]) * 2.0 ** -k
+
+
+def cl_weight(w):
+    return w.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def loose(amax, factor):
+    return (amax.view(torch.float32) * factor).view(torch.int32)
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, stride, pad, dil, H, W
+    (2, 256, 256, 3, 1, 2, 2, 60, 107),      # layer3 conv2: 128 x 256 tiles, chunked K order
+    (2, 256, 1024, 1, 1, 0, 1, 60, 107),     # conv3: 4 column tiles, 16 K-steps
+    (2, 1024, 256, 1, 1, 0, 1, 33, 41),      # conv1: ragged row tile
+    (3, 128, 128, 3, 2, 1, 1, 61, 107),      # layer2.0 conv2: stride 2 (strided data gradient), 128-wide tile
+    (2, 64, 64, 3, 1, 1, 1, 30, 53),         # layer1 conv2: 64-wide tile, K = 576
+    (2, 256, 64, 1, 1, 0, 1, 30, 53),        # layer1 conv1
+    (1, 512, 2048, 1, 2, 0, 1, 30, 54),      # layer4-style downsample: 1x1 stride 2
+])
+def test_pair_plane_convs_match_register_split(case, report):
+    N, Cin, Cout, k, stride, pad, dil, H, W = case
+    g = torch.Generator().manual_seed(sum((i + 1) * v for i, v in enumerate(case)))
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    wg = cl_weight(w)
+    Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV)
+    ax, aw, ag = ops.absmax(x), ops.absmax(ops.weight_rsck(wg)), ops.absmax(dy)
+    wp, wpt = ops.weight_pairs(wg, aw), ops.weight_pairs_t(wg, aw)
+    xn, dyn = x.permute(0, 3, 1, 2).double().cpu(), dy.permute(0, 3, 1, 2).double().cpu()
+    yref = F.conv2d(xn, w.double(), None, stride, pad, dil)
+    wref = torch.nn.grad.conv2d_weight(xn, tuple(w.shape), dyn, stride, pad, dil)
+    y0, s0 = ops.conv2d_fwd_stats(x, wg, stride, pad, dil, amax=(ax, aw), w_pairs=wp)
+    dx0 = ops.conv2d_dgrad(dy, wg, x.shape, stride, pad, dil, amax=(ag, aw), w_pairs_t=wpt)
+    acc0 = dx0.clone()
+    ops.conv2d_dgrad(dy, wg, x.shape, stride, pad, dil, out=acc0, beta=1, amax=(ag, aw), w_pairs_t=wpt)
+    dw0 = torch.full_like(wg, 3.0)
+    ops.conv2d_wgrad(x, dy, wg, dw0, stride, pad, dil, beta=0, amax=(ax, ag), small_tile=True)    # 128 x 256 tile: the same split-K plan
+    dwa0 = dw0.clone()
+    ops.conv2d_wgrad(x, dy, wg, dwa0, stride, pad, dil, beta=1, amax=(ax, ag), small_tile=True)
+    msg = []
+    # factor 1: planes at the scale the register-split kernels use -> the same h, m everywhere, also where m is an fp16 subnormal
+    # (elements below 2^-18 of the range): BIT-identical.  Loose bounds, as the batch norm leaves them: the subnormal m of those
+    # tiny elements are rounded at another place (2^-40 of the range) -- fp32-level agreement, float64 accuracy unchanged.
+    for fx, fg in ((1.0, 1.0), (5.3, 1.9), (60.0, 33.0)):
+        bx, bg = loose(ax, fx), loose(ag, fg)
+        xp, _ = to_planes(x, bx)
+        dyp, _ = to_planes(dy, bg)
+        ya, da = ops.new_amax(DEV), ops.new_amax(DEV)
+        y1, s1 = ops.conv2d_fwd_stats(xp, wg, stride, pad, dil, amax=(bx, aw), w_pairs=wp, x_planes=True, amax_y=ya)
+        dx1 = ops.conv2d_dgrad(dyp, wg, x.shape, stride, pad, dil, amax=(bg, aw), w_pairs_t=wpt, dy_planes=True, amax_y=da)
+        acc1 = dx1.clone()
+        ops.conv2d_dgrad(dyp, wg, x.shape, stride, pad, dil, out=acc1, beta=1, amax=(bg, aw), w_pairs_t=wpt, dy_planes=True)
+        dw1 = torch.full_like(wg, 3.0)
+        ops.conv2d_wgrad(xp, dyp, wg, dw1, stride, pad, dil, beta=0, amax=(bx, bg), planes=True)
+        dwa1 = dw1.clone()
+        ops.conv2d_wgrad(xp, dyp, wg, dwa1, stride, pad, dil, beta=1, amax=(bx, bg), planes=True)
+        assert int(ya) == int(ops.absmax(y1)) and int(da) == int(ops.absmax(dx1)), "the epilogue's range of its output"
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        d = [rel(y1, y0), rel(dx1, dx0), rel(acc1, acc0), rel(dw1, dw0), rel(dwa1, dwa0)]
+        e_s = rel(s1, s0)
+        e_y = float((y1.permute(0, 3, 1, 2).double().cpu() - yref).abs().max() / yref.abs().max())
+        e_w = float((dw1.cpu().double() - wref).abs().max() / wref.abs().max())
+        msg.append(f"bounds x{fx:g}/x{fg:g}: vs register split fwd {d[0]:.1e} dgrad {d[1]:.1e} acc {d[2]:.1e} wgrad {d[3]:.1e} acc {d[4]:.1e} "
+                   f"stats {e_s:.1e}; vs float64 fwd {e_y:.2e} wgrad {e_w:.2e}")
+        if fx == 1.0:
+            assert max(d) == 0.0, d
+        assert max(d) < 1e-6 and e_s < 1e-7 and e_y < 2e-5 and e_w < 2e-5, (d, e_s, e_y, e_w)
+    report(f"pair-plane convs {case}: " + " | ".join(msg))
+
+
+@pytest.mark.parametrize("res", [False, True])
+def test_batchnorm_writes_pair_planes(res, report):
+    g = torch.Generator().manual_seed(11 + res)
+    N, H, W, C = 2, 33, 41, 256
+    x = (torch.randn(N, H, W, C, generator=g) * torch.exp2(4 * torch.rand(C, generator=g)) + 0.3).to(DEV)
+    r = torch.randn(N, H, W, C, generator=g).to(DEV) * 3 if res else None
+    dy = torch.randn(N, H, W, C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    count = N * H * W
+    mean, invstd = ops.bn_finalize(ops.bn_stats(x), count, 1e-5, 0.1)
+    ax, ar, ag = ops.absmax(x), (ops.absmax(r) if res else None), ops.absmax(dy)
+    rm0 = torch.empty(x.numel() // 4, dtype=torch.uint8, device=DEV)
+    y0 = ops.bn_apply(x, mean, invstd, gamma, beta, True, residual=r, relu_mask=rm0, amax_out=ops.new_amax(DEV))
+    out = {}
+    for only in (False, True):
+        rm = torch.empty_like(rm0)
+        bound, pl = ops.new_amax(DEV), torch.empty_like(x)
+        y = ops.bn_apply(x, mean, invstd, gamma, beta, True, residual=r, relu_mask=rm, amax_out=bound, planes=pl, planes_only=only,
+                         amax_x=ax, amax_res=ar)
+        assert (y is None) == only and torch.equal(rm, rm0)
+        if not only:
+            assert torch.equal(y, y0)
+        out[only] = (pl, bound)
+    assert torch.equal(out[False][0], out[True][0]) and int(out[False][1]) == int(out[True][1])
+    b = float(out[True][1].view(torch.float32))
+    k = 14 - int(np.floor(np.log2(b)))
+    dec = from_planes(out[True][0], k)
+    ymax = float(y0.abs().max())
+    # element-wise: 22 significand bits wherever the element is not tiny against the bound
+    big = y0.abs().double() > b * 2.0 ** -16
+    e_el = float(((dec - y0.double()).abs() / y0.abs().double().clamp_min(1e-30))[big].max())
+    e_abs = float((dec - y0.double()).abs().max() / b)
+    # backward
+    s2 = ops.bn_bwd_reduce(dy, x, None, mean, invstd, True, relu_mask=rm0)
+    dg0, db0, dg1, db1 = (torch.zeros(C, device=DEV) for _ in range(4))
+    dres0 = torch.full_like(x, 0.25) if res else None
+    dres1 = torch.full_like(x, 0.25) if res else None
+    dx0 = ops.bn_bwd_apply(dy, x, None, mean, invstd, gamma, True, s2, count, dg0, db0, dres=dres0, res_beta=1 if res else 0, relu_mask=rm0,
+                           amax_out=ops.new_amax(DEV))
+    gb = ops.new_amax(DEV)
+    dxp = ops.bn_bwd_apply(dy, x, None, mean, invstd, gamma, True, s2, count, dg1, db1, dres=dres1, res_beta=1 if res else 0, relu_mask=rm0,
+                           amax_out=gb, dx_planes=True, amax_x=ax, amax_dy=ag)
+    bb = float(gb.view(torch.float32))
+    kb = 14 - int(np.floor(np.log2(bb)))
+    ddec = from_planes(dxp, kb)
+    dmax = float(dx0.abs().max())
+    bigd = dx0.abs().double() > bb * 2.0 ** -16
+    e_del = float(((ddec - dx0.double()).abs() / dx0.abs().double().clamp_min(1e-30))[bigd].max())
+    report(f"batch norm pair planes (residual {res}): forward bound / max |y| = {b / ymax:.2f}, element error {e_el:.1e} (2^-21 = 4.8e-7), "
+           f"absolute {e_abs:.1e} of the bound; backward bound / max |dx| = {bb / dmax:.2f}, element error {e_del:.1e}")
+    assert b >= ymax and b < 64 * ymax and e_el < 2.0 ** -21 and e_abs < 2.0 ** -22
+    assert bb >= dmax and bb < 64 * dmax and e_del < 2.0 ** -21
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and (not res or torch.equal(dres0, dres1))
+
+
+def test_training_step_with_and_without_pair_planes(report):
+    """the same step with the planes on (default) and off (every conv splits its fp32 operands in registers): what changes is
+    where the split happens and the tile of some weight gradients, not the arithmetic"""
+    import copy
+    import types
+    from rcf_amd import config, layers, synth
+    H, W, B = 96, 160, 2
+    res = {}
+    saved = layers.PLANES
+    try:
+        for on in (True, False):
+            layers.PLANES = on
+            kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+            kw.update(log_interval=10 ** 9, train_iter=1)
+            args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
+            m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+            m.to(DEV)
+            tr = rcf_amd.Trainer(m, lr=1e-4, weight_decay=1e-4, device=DEV)
+            nb = synth.make_batch(B, H, W, config_id=1)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+            batch = {"imgs": [t(a) for a in nb["imgs"]], "gt_fw_flows": [t(a) for a in nb["gt_fw_flows"]],
+                     "gt_bw_flows": [t(a) for a in nb["gt_bw_flows"]], "seq_ids": nb["seq_ids"], "seq_names": nb["seq_names"],
+                     "paths": nb["paths"]}
+            calls = {"n": 0}
+            orig = ops.conv2d_wgrad
+
+            def counting(*a, **k):
+                calls["n"] += bool(k.get("planes"))
+                return orig(*a, **k)
+            ops.conv2d_wgrad = counting
+            try:
+                losses = tr.step(batch)
+            finally:
+                ops.conv2d_wgrad = orig
+            gn = {}
+            for n, p in m.named_parameters():
+                if p.grad is not None:
+                    gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+            res[on] = ({k: float(v) for k, v in losses.items()}, {k: v ** 0.5 for k, v in gn.items()}, calls["n"])
+    finally:
+        layers.PLANES = saved
+    e_l = max(abs(res[True][0][k] - res[False][0][k]) / abs(res[False][0][k]) for k in res[True][0])
+    e_g = {k: abs(res[True][1][k] - v) / v for k, v in res[False][1].items()}
+    report(f"training step, pair planes on vs off: {res[True][2]} / {res[False][2]} weight gradients on the plane kernel; losses {e_l:.1e}; "
+           "module gradient norms " + " ".join(f"{k} {v:.1e}" for k, v in e_g.items()))
+    assert res[True][2] >= 40 and res[False][2] == 0
+    assert e_l < 1e-5 and max(e_g.values()) < 2e-3

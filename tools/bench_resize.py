@@ -28,11 +28,10 @@ for dt in (torch.float32, torch.bfloat16):
         dy = torch.randn(16, 120, 214, C, device="cuda:0").to(dt)
         out = {}
         for mode in (0, 1, 0, 1):
-            ops.resize_set_2x(mode)
-            tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False))
-            tb = timeit(lambda: ops.resize_nhwc_bwd(dy, (60, 107), False))
+            fr = 0 if mode else -1                  # frame = -1: the general kernels on the whole tensor
+            tf = timeit(lambda: ops.resize_nhwc_fwd(x, (120, 214), False, frame=fr))
+            tb = timeit(lambda: ops.resize_nhwc_bwd(dy, (60, 107), False, frame=fr))
             out.setdefault(mode, []).append((tf, tb))
-        ops.resize_set_2x(1)
         f0, b0 = min(t[0] for t in out[0]), min(t[1] for t in out[0])
         f1, b1 = min(t[0] for t in out[1]), min(t[1] for t in out[1])
         mb = dy.numel() * dy.element_size() / 1e6

@@ -30,19 +30,18 @@ def main():
         occ = (torch.rand(nframes, 1, H, W, device=dev) > 0.2).float()
         px = nframes * H * W
         res = {}
-        for v in (0, 1):
-            _lib.call("rcf_warp_set_variant", v)
-            w = ops.flow_warp(x, fl, "border")
-            l1 = ops.warp_l1_residual(y, x, fl, occ, "border")
-            t_l1 = timeit(lambda: ops.warp_l1_residual(y, x, fl, occ, "border"))
-            t_w = timeit(lambda: ops.flow_warp(x, fl, "border"))
+        for v in (0, 1):                         # 0: RCF_WARP_PER_PIXEL (per call), 1: the tile kernels
+            pad = "border" if v else "border_per_pixel"
+            w = ops.flow_warp(x, fl, pad)
+            l1 = ops.warp_l1_residual(y, x, fl, occ, pad)
+            t_l1 = timeit(lambda: ops.warp_l1_residual(y, x, fl, occ, pad))
+            t_w = timeit(lambda: ops.flow_warp(x, fl, pad))
             res[v] = (w, l1)
             print(f"{H}x{W}x{nframes} variant {v:#x}: warp_l1 {t_l1*1e6:8.1f} us  {px*36/t_l1/1e9:7.1f} GB/s ({px*36/t_l1/8e12:.3f})   "
                   f"flow_warp {t_w*1e6:8.1f} us {px*32/t_w/1e9:7.1f} GB/s ({px*32/t_w/8e12:.3f})", flush=True)
         for v in (1,):
             print(f"   variant {v} vs 0: warped identical {torch.equal(res[0][0], res[v][0])}; l1 sums",
                   [float(a) for a in res[0][1]], [float(a) for a in res[v][1]])
-    _lib.call("rcf_warp_set_variant", 1)
 
 
 if __name__ == "__main__":

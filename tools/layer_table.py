@@ -1,7 +1,8 @@
 """Per-layer table of the conv launches inside the training step (480x854, 8 pairs): every (kernel family, layer shape)
 with launches per step, average launch time, achieved TF/s and fraction of its MFMA roofline, the number of workgroup
 tiles and rounds on the chip -- once with the weight gradients on the second stream (live) and once with one stream.
-usage: python tools/layer_table.py [fp32|bf16] [pairs]"""
+usage: python tools/layer_table.py [fp32|bf16] [pairs] [ab]   (ab: one stream only, with the fp16 pair planes on and off: the
+per-layer A/B of the LDS-DMA plane kernels against the register-split kernels in one process)"""
 import os
 import sys
 import types
@@ -32,12 +33,14 @@ def main():
     tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=prec)
     for _ in range(4):
         tr.step(batch)
-    fams = ["conv_h2p_fwd", "conv_h2p_dgrad", "conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
+    ab = len(sys.argv) > 3 and sys.argv[3] == "ab"
+    fams = ["conv_h2d_fwd", "conv_h2d_dgrad", "conv_wgrad_h2d", "conv_h2p_fwd", "conv_h2p_dgrad", "conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
             "conv_bf16_fwd", "conv_bf16_fwd_narrow", "conv_bf16_dgrad_wide", "conv_bf16_dgrad_other", "conv_bf16_wgrad4",
             "conv_bf16_wgrad_other"]
     peak = 2500.0 if prec == "bf16" else 2500.0 / 3
-    for overlap in (True, False):
-        layers.OVERLAP_WGRAD = overlap
+    for overlap, planes in (((False, True), (False, False)) if ab else ((True, layers.PLANES), (False, layers.PLANES))):
+        layers.OVERLAP_WGRAD, layers.PLANES = overlap, planes
+        tr.step(batch)
         tr.step(batch)
         nsteps = 3
         ops.PROFILE.start(fams)
@@ -48,7 +51,7 @@ def main():
             tr.step(batch)
         e1.record()
         det = ops.PROFILE.stop_detail()
-        print(f"==== {prec} step, {B} pairs, weight gradients on the second stream: {overlap}; {e0.elapsed_time(e1) / nsteps:.2f} ms/step (bracketed)")
+        print(f"==== {prec} step, {B} pairs, weight gradients on the second stream: {overlap}, fp16 pair planes: {planes}; {e0.elapsed_time(e1) / nsteps:.2f} ms/step (bracketed)")
         rows = sorted(det.items(), key=lambda kv: -kv[1]["ms"])
         tot = {}
         for (fam, tag), r in rows:
