@@ -56,12 +56,23 @@ class Bottleneck(nn.Module):
         """emit_planes: the block's output is ALSO written as fp16 pair planes (the next block's conv1 / downsample read them).
         Inside the block the outputs of bn1 / bn2 -- whose only readers are conv2 / conv3 and their weight gradients -- exist as
         pair planes ONLY, and every conv that got its input so receives its output gradient so (layers.BatchNorm2d.fwd)."""
-        o = self.bn1.fwd(self.conv1.fwd(x, tape, stats=self.bn1.stats_request(dist)), tape, relu=True, dist=dist,
-                         planes="only" if self.conv2.planes_ok() else None)
+        o1 = self.conv1.fwd(x, tape, stats=self.bn1.stats_request(dist))
+        ods = None
+        if self.downsample is not None and dist is not None and dist.on and self.bn1.sync and getattr(self.downsample, "1").sync:
+            # data parallel: conv1 and the downsample conv read the same input, so their statistics exist together -- ONE
+            # all-reduce for both batch norms instead of two latency-bound ones (the single-rank order is left as it was)
+            ods = getattr(self.downsample, "0").fwd(x, tape, stats=getattr(self.downsample, "1").stats_request(dist))
+            if o1.stats is not None and ods.stats is not None:
+                dist.allreduce_sum_many([o1.stats, ods.stats])
+                o1.stats_global = ods.stats_global = True
+        o = self.bn1.fwd(o1, tape, relu=True, dist=dist, planes="only" if self.conv2.planes_ok() else None)
         o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist,
                          planes="only" if self.conv3.planes_ok() else None)
         o = self.conv3.fwd(o, tape, stats=self.bn3.stats_request(dist))
-        idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
+        if ods is not None:
+            idt = getattr(self.downsample, "1").fwd(ods, tape, relu=False, dist=dist)
+        else:
+            idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
         return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist,          # relu(bn3 + identity)
                             planes="both" if emit_planes else None)
 

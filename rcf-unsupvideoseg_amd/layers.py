@@ -36,7 +36,7 @@ def _round_up(n, m):
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
-                 "grad_is_planes")
+                 "grad_is_planes", "stats_global")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -45,6 +45,7 @@ class Act:
         # t; `split` = there is no fp32 copy (t IS planes).  `accepts_plane_grad`: set by the conv that produced t when its
         # backward can take t's gradient in that format -- the batch norm's backward then writes it so (`grad_is_planes`).
         self.planes, self.split, self.accepts_plane_grad, self.grad_is_planes = None, False, False, False
+        self.stats_global = False    # `stats` were already all-reduced over the data-parallel ranks (DistCtx.allreduce_sum_many)
         self.stats = None            # fp64 [2C] column sums | sums of squares, when the producing conv computed them
         self.bn = None               # (mean, invstd, count) when the producing conv's reduction also finalized the norm
         self.amax = None             # int32 [1]: raw bits of max |t| (operand range of the fp16-pair conv kernels)
@@ -177,6 +178,22 @@ class DistCtx:
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def allreduce_sum_many(self, ts):
+        """ONE collective for several statistics vectors whose producers do not depend on each other (a bottleneck's conv1 and
+        downsample conv read the same input): the latency of a SyncBN exchange is per collective, not per byte"""
+        ts = [t for t in ts if t is not None]
+        if not self.on or not ts:
+            return
+        if len(ts) == 1:
+            self.allreduce_sum(ts[0])
+            return
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        self.allreduce_sum(flat)
+        o = 0
+        for t in ts:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
 
     def profile_ms(self):
         """profile mode: per-collective device time between the events around it (ms), after a synchronize"""
@@ -506,7 +523,8 @@ class BatchNorm2d(nn.Module):
             sums = x.stats if x.stats is not None else ops.bn_stats(xt)
             count = local_rows
             if dist is not None and dist.on:                    # SyncBN: statistics over the global batch
-                dist.allreduce_sum(sums)
+                if not x.stats_global:
+                    dist.allreduce_sum(sums)
                 count = local_rows * dist.world
             mean, invstd = ops.bn_finalize(sums, count, self.eps, self.momentum, self.running_mean, self.running_var)
             self.num_batches_tracked += 1

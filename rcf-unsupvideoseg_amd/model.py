@@ -101,7 +101,7 @@ def momentum_update_param_and_buffer(src, dest, m):
             ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m)
         else:
             d[k].data.copy_(d[k].data * m + s[k].data * (1.0 - m))
-    ops.weights_changed()
+    ops.weights_changed(dest)            # only `dest` was written: the source's cached operands stay valid
 
 
 class RCFModel(nn.Module):
@@ -197,15 +197,19 @@ class RCFModel(nn.Module):
     def _teacher_dist(self):
         """the EMA teacher's SyncBN exchanges on their OWN communicator: its forward is enqueued (on the side stream)
         ahead of the student's, and on one communicator every statistics all-reduce of the student would queue behind
-        all of the teacher's -- the two forwards would serialise across ranks.  RCF_TEACHER_GROUP=0 keeps the default
-        group (a fallback should two more concurrent RCCL communicators misbehave on a given system)."""
+        all of the teacher's -- the two forwards would serialise across ranks.  The group is created EAGERLY by the trainer
+        (`Trainer.__init__`, next to its gradient group: `new_group` is a collective of its own, not something to hide inside
+        a forward) and only on request, RCF_TEACHER_GROUP=1: no multi-GPU run of this repo has exercised three concurrent RCCL
+        communicators yet, so the default shares the student's communicator (correct, slower in stage 2.1)."""
         d = self._dist()
-        if not d.on or os.environ.get("RCF_TEACHER_GROUP", "1") == "0":
-            return d
-        if getattr(self, "_tdist", None) is None:
+        t = getattr(self, "_tdist", None)
+        return t if (d.on and t is not None) else d
+
+    def make_teacher_group(self):
+        """collective: every rank calls it at the same point (Trainer.__init__)"""
+        if self._dist().on and self.w_crf > 0 and self.crf_use_ema and os.environ.get("RCF_TEACHER_GROUP", "0") == "1":
             import torch.distributed as tdist
             self._tdist = DistCtx(group=tdist.new_group())
-        return self._tdist
 
     def _select_precision(self):
         p = self.precision

@@ -226,8 +226,15 @@ WEIGHT_EPOCH = [0]
 DEBUG_WEIGHT_CACHE = os.environ.get("RCF_DEBUG_WEIGHT_CACHE", "0") == "1"
 
 
-def weights_changed():
-    WEIGHT_EPOCH[0] += 1
+def weights_changed(module=None):
+    """weights were written behind torch's back.  Without an argument every cached derived operand of the process is
+    dropped (the epoch moves); with a module only the caches of that module's conv layers (e.g. the EMA teacher after its
+    momentum update: the student's operands, prepared in bulk after the optimizer step, stay valid)."""
+    if module is None:
+        WEIGHT_EPOCH[0] += 1
+        return
+    for m in module.modules():
+        m.__dict__.pop("_wcache", None)
 
 
 def weight_key(w):

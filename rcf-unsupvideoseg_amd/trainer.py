@@ -202,6 +202,8 @@ class Trainer:
         # configuration no multi-GPU box has exercised yet)
         own_group = __import__("os").environ.get("RCF_GRAD_GROUP", "1") != "0"
         self.grad_group = dist.new_group() if (self.chunked and own_group) else None
+        if self.chunked and hasattr(self.model, "make_teacher_group"):
+            self.model.make_teacher_group()                 # stage 2.1, RCF_TEACHER_GROUP=1: created here, collectively
         self._pending, self._done = [], set()
         self.prep = None                                    # WeightPrep, built after the first optimizer step
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
@@ -240,7 +242,8 @@ class Trainer:
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
                       self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)
         if self.prep is None and BULK_WEIGHT_PREP:
-            self.prep = WeightPrep(self.model, self.model.precision or "fp32", self.device)
+            prec = self.model.precision or ("bf16" if torch.is_autocast_enabled() else "fp32")     # RCFModel._select_precision
+            self.prep = WeightPrep(self.model, prec, self.device)
         if self.prep is not None:
             self.prep.run()                                 # the next forward finds every derived weight operand ready
         if check_nan and math.isnan(float(losses["loss"])):

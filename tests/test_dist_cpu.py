@@ -33,6 +33,12 @@ def _worker(rank, world, port, q):
     xh = (mine - mean.view(1, 8, 1, 1)) / torch.sqrt(var.view(1, 8, 1, 1) + 1e-5)
     s2 = torch.cat([gy[rank * 2:(rank + 1) * 2].sum(dim=(0, 2, 3)), (gy[rank * 2:(rank + 1) * 2] * xh).sum(dim=(0, 2, 3))])
     ctx.allreduce_sum(s2)
+    # two independent statistics vectors in ONE collective (a bottleneck's conv1 / downsample pair)
+    a, b = torch.full((6,), float(rank + 1), dtype=torch.float64), torch.arange(4, dtype=torch.float64) * (rank + 1)
+    n0 = ctx.count
+    ctx.allreduce_sum_many([a, b])
+    assert ctx.count == n0 + 1 and torch.equal(a, torch.full((6,), 3.0, dtype=torch.float64))
+    assert torch.equal(b, torch.arange(4, dtype=torch.float64) * 3)
     # flat gradient all-reduce + 1/world scaling == gradient of the mean loss over the global batch
     grad = torch.full((1000,), float(rank + 1))
     dist.all_reduce(grad)

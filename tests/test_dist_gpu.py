@@ -17,12 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, B = 64, 96, 2
 
 
-def _setup():
+def _setup(mode="fp32"):
+    """mode: fp32 / bf16 (the stage-1 step in either precision) / stage21 (EMA teacher + CRF self-labels)"""
     sys.path.insert(0, ROOT)
     import rcf_amd
     from rcf_amd import config, synth
-    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
-    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=None)
+    if mode == "stage21":
+        kw = config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
+        args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=1)
+    else:
+        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
+        args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=None)
     m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
@@ -35,15 +40,24 @@ def _batch(nb, sl, dev):
     return {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rcf_amd, m, nb = _setup()
-    tr = rcf_amd.Trainer(m, device="cuda:0")
+    rcf_amd, m, nb = _setup(mode)
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode == "bf16" else None)
     assert tr.world == world
     per = B // world
     losses = tr.step(_batch(nb, slice(rank * per, (rank + 1) * per), "cuda:0"))
     torch.cuda.synchronize()
+    if mode != "fp32":
+        # SyncBN exchanges of this rank: one per batch norm and direction, less the conv1 / downsample pairs that share one
+        bns = [(n, mod) for n, mod in m.named_modules() if type(mod).__name__ == "BatchNorm2d" and mod.training and mod.sync]
+        n_bn = (sum(1 for n, _ in bns if "_ema" not in n), sum(1 for n, _ in bns if "_ema" in n))      # (student, EMA teacher)
+        q.put((rank, {k: float(v) for k, v in losses.items()}, m.dist.count, n_bn,
+               float(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # the gradient all-reduce went out in chunks as backward finished them (tape marks), in backward order
     assert tr.ranges is not None and len(tr._pending) == 6 and tr._done == {"heads", "layer4", "layer3", "layer2", "layer1", "stem"}
     assert sum(e - s for s, e in tr.ranges.values()) == tr.fp.total
@@ -81,6 +95,40 @@ def test_two_rank_step_equals_global_batch_step(report):
     e_rv = float(np.abs(res[0][3] - m.backbone2.bn1.running_var.cpu().numpy()).max())
     report(f"2-rank DP vs single process: loss {e_loss:.2e} worst sampled grad {worst:.2e} running_var {e_rv:.2e}")
     assert e_loss < 1e-5 and worst < 1e-4 and e_rv < 1e-6      # measured 5e-8 / 1.6e-6 / 0
+
+
+@pytest.mark.parametrize("mode", ["bf16", "stage21"])
+def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
+    """the N > 1 path of the other two step flavours on ONE device (gloo): the mixed-precision step (BASELINE configs[2]) and the
+    stage-2.1 step (EMA teacher with its own SyncBN exchanges + CRF) over two ranks against the single-process step on the global
+    batch; and the number of SyncBN collectives a rank issues: one per norm and direction, minus one for each bottleneck whose
+    conv1 and downsample statistics travel together"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 1000 + (7 if mode == "bf16" else 13)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rcf_amd, m, nb = _setup(mode)
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode == "bf16" else None)
+    losses = {k: float(v) for k, v in tr.step(_batch(nb, slice(0, B), "cuda:0")).items()}
+    gn = float(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5)
+    # rank losses are per-rank means over half the batch: their mean is the global loss
+    e = {k: abs(0.5 * (res[0][1][k] + res[1][1][k]) - v) / (abs(v) + 1e-30) for k, v in losses.items()}
+    e_gn = abs(res[0][4] / 2 - gn) / gn          # flat gradient after the all-reduce (sum over ranks) is scaled by 1/world in Adam
+    count, (n_st, n_te) = res[0][2], res[0][3]
+    # student: forward + backward; the teacher (stage 2.1, in training mode like the reference's) forward only; each network
+    # has four bottlenecks with a downsample branch
+    want = 2 * n_st - 4 + ((n_te - 4) if n_te else 0)
+    report(f"2-rank {mode} step vs single process: losses {e}; gradient norm {e_gn:.1e}; SyncBN collectives per rank {count} for {n_st} "
+           f"student + {n_te} teacher norms (one per norm and direction would be {2 * n_st + n_te})")
+    tol = 2e-2 if mode == "bf16" else 2e-4         # bf16: the two ranks round their halves of the batch independently
+    assert max(e.values()) < tol and e_gn < (5e-2 if mode == "bf16" else 2e-3)
+    assert res[0][2] == res[1][2] and count == want
 
 
 def _ddp_worker(rank, world, port, q):
@@ -193,7 +241,7 @@ def test_rccl_world1_dry_run_of_chunked_allreduce(report):
     report(f"SyncBN collectives in one step (RCCL, world 1, 64x96 frames): {st['count']} all-reduces for {st['n_bn']} batch norms, "
            f"{st['bytes']} bytes in total; device time per collective mean {st['mean_us']:.1f} us, max {st['max_us']:.1f} us, "
            f"sum {st['total_ms']:.2f} ms of a {st['step_ms']:.1f} ms step")
-    assert st["count"] == 2 * st["n_bn"] and st["n_bn"] >= 50
+    assert st["count"] == 2 * st["n_bn"] - 4 and st["n_bn"] >= 50       # the four conv1 / downsample pairs share one exchange each
     rcf_amd, m, nb = _setup()
     tr = rcf_amd.Trainer(m, device="cuda:0")
     want = [float(tr.step(_batch(nb, slice(0, B), "cuda:0"))["loss"]) for _ in range(2)]
