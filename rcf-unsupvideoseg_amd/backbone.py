@@ -121,6 +121,7 @@ class ResNet(nn.Module):
             blocks += [Bottleneck(inplanes, planes, 1, dil, None, norm_cfg) for _ in range(1, nblocks)]
             setattr(self, f"layer{i + 1}", Stage(blocks))
         self.feat_dim = inplanes
+        self.heads_take_planes = True       # RCFModel: the last stage's output also as fp16 pair planes (layers.PLANES gates it)
 
     def init_weights(self, pretrained=None):
         if pretrained is not None:
@@ -144,7 +145,8 @@ class ResNet(nn.Module):
         outs = []
         for i in range(self.num_stages):
             tape.mark(f"layer{i + 1}")
-            nxt = getattr(getattr(self, f"layer{i + 2}"), "0").takes_planes() if i + 1 < self.num_stages else False
+            # the last stage's output is read by the decode heads: decode_head3's first conv takes it as planes (through pair_concat)
+            nxt = getattr(getattr(self, f"layer{i + 2}"), "0").takes_planes() if i + 1 < self.num_stages else self.heads_take_planes
             x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist, next_takes_planes=nxt)
             if i in self.out_indices:
                 outs.append(x)
@@ -168,8 +170,10 @@ class ConvModule(nn.Module):
         self.conv = Conv2d(cin, cout, k, stride=stride, padding=padding, dilation=dilation)
         self.bn = make_norm(norm_cfg, cout)
 
-    def fwd(self, x, tape, dist, chan_scale=None):
-        return self.bn.fwd(self.conv.fwd(x, tape, stats=self.bn.stats_request(dist)), tape, relu=True, chan_scale=chan_scale, dist=dist)
+    def fwd(self, x, tape, dist, chan_scale=None, planes=None):
+        """planes: "only" when the next module is a conv that reads fp16 pair planes (layers.BatchNorm2d.fwd)"""
+        return self.bn.fwd(self.conv.fwd(x, tape, stats=self.bn.stats_request(dist)), tape, relu=True, chan_scale=chan_scale, dist=dist,
+                           planes=planes)
 
 
 class FCNHead(nn.Module):
@@ -232,10 +236,12 @@ class FCNHead(nn.Module):
                 scale = torch.bernoulli(torch.full((src.shape[0], self.channels), keep, device=src.device)) / keep
         for i, m in enumerate(mods):
             cs = scale if i == len(mods) - 1 else None
+            # a conv module whose successor is another conv module hands its output on as fp16 pair planes only
+            pl = "only" if (i + 1 < len(mods) and cs is None and mods[i + 1].conv.planes_ok()) else None
             if i == 0 and first is not None:
-                x = m.bn.fwd(first, tape, relu=True, chan_scale=cs, dist=dist)
+                x = m.bn.fwd(first, tape, relu=True, chan_scale=cs, dist=dist, planes=pl)
             else:
-                x = m.fwd(x, tape, dist, chan_scale=cs)
+                x = m.fwd(x, tape, dist, chan_scale=cs, planes=pl)
         return self.conv_seg.fwd(x, tape)
 
     def forward(self, inputs):

@@ -519,8 +519,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
 
 // PL = 1: dx is written as fp16 pair planes (its only consumers are the conv's data and weight gradient).  Bound, per channel, from
 // constants known before the pass:   |dx_c| <= |gamma_c| invstd_c (max|g| + |mean g|_c + X_c |mean g xhat|_c),
-// X_c = (max|x| + |mean_c|) invstd_c >= max |xhat_c|, max|g| <= max|dy| (the mask and a 0 / 1-over-keep dropout scale are not
-// applied to the bound: no chan_scale on this path).  Workgroup 0 leaves the bound in *amax.
+// X_c = (max|x| + |mean_c|) invstd_c >= max |xhat_c|, max|g| <= max|dy| max(chan_scale) (the ReLU mask only lowers it; the
+// Dropout2d scale, 0 or 1 / keep per (image, channel), enters with its largest entry: `nscale` values are scanned in the
+// prologue).  Workgroup 0 leaves the bound in *amax.
 template <typename XT, typename YT, int V, int PL = 0>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const YT *__restrict__ dy, int dy_pitch, const XT *__restrict__ x, int x_pitch, const YT *__restrict__ y,
@@ -530,11 +531,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count,
     float *__restrict__ dgamma, float *__restrict__ dbeta, const unsigned char *__restrict__ mask,
     unsigned *__restrict__ amax, Sweep sw, const unsigned *__restrict__ amax_x = nullptr,
-    const unsigned *__restrict__ amax_dy = nullptr) {
+    const unsigned *__restrict__ amax_dy = nullptr, long nscale = 0) {
     const int CV = C / V;
     float pls = 1.f;
     if constexpr (PL != 0) {
-        const float ax = __uint_as_float(*amax_x), ag = __uint_as_float(*amax_dy);
+        float smax = 1.f;
+        if (scale) {
+            float m = 0.f;
+            for (long i = threadIdx.x; i < nscale; i += 256) m = fmaxf(m, fabsf(scale[i]));
+            smax = block_max_f(m);
+            __syncthreads();                           // block_max_f's scratch is reused below
+        }
+        const float ax = __uint_as_float(*amax_x), ag = __uint_as_float(*amax_dy) * smax;
         const float ic = (float)(1.0 / count);
         float b = 0.f;
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -895,15 +903,16 @@ extern "C" int rcf_bn_bwd_apply_mp(const void *dy, int ydt, int dy_pitch, const 
     if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || (dres && dres_pitch % 4)) return RCF_EINVAL;
     if (flags & RCF_BN_DX_PLANES) {
         // dx as fp16 pair planes (see rcf_bn_apply_mp): fp32 tensors, contiguous dx pixels, the ranges of x and dy, a slot for the bound
-        if (xdt != RCF_F32 || ydt != RCF_F32 || C % 8 || dx_pitch != C || !amax_x || !amax_dy || !amax_out || chan_scale ||
-            !rcf_aligned16(dx) || (relu && !relu_mask))
+        if (xdt != RCF_F32 || ydt != RCF_F32 || C % 8 || dx_pitch != C || !amax_x || !amax_dy || !amax_out ||
+            !rcf_aligned16(dx) || (relu && !relu_mask) || (chan_scale && rows % (rows_per_image > 0 ? rows_per_image : 1)))
             return RCF_EINVAL;
         const EwGeom g = ew_geom(rows, C / 4);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float, 4, 1>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)dy,
                            dy_pitch, (const float *)x, x_pitch, (const float *)y, y_pitch, (float *)dx, dx_pitch, (float *)dres,
-                           dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, (const float *)nullptr, 1L, sums2,
-                           sums2_local ? sums2_local : sums2, count, dgamma, dbeta, relu_mask, amax_out,
-                           make_sweep(1, rows, g.rpb, (long)C * 4, flags), amax_x, amax_dy);
+                           dres_pitch, res_beta, rows, C, g.cvt, g.rpb, mean, invstd, gamma, relu, chan_scale,
+                           rows_per_image > 0 ? rows_per_image : 1, sums2, sums2_local ? sums2_local : sums2, count, dgamma, dbeta,
+                           relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 4, flags), amax_x, amax_dy,
+                           chan_scale ? (rows / (rows_per_image > 0 ? rows_per_image : 1)) * (long)C : 0L);
         RCF_LAUNCH_CHECK();
         return 0;
     }

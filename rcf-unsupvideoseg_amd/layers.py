@@ -559,7 +559,7 @@ class BatchNorm2d(nn.Module):
             def bwd():
                 # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
                 # are the only readers); the bound needs the ranges of x and of dy
-                dpl = (x.accepts_plane_grad and PLANES and chan_scale is None and xt.dtype == torch.float32 and x.amax is not None
+                dpl = (x.accepts_plane_grad and PLANES and xt.dtype == torch.float32 and x.amax is not None
                        and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
                 ady = ya.take_grad_range() if dpl else None
                 dy = ya.take_grad()
@@ -785,6 +785,15 @@ def pair_concat(x, tape, B, I, order=None):
                 ops.copy2d(x.t[b * I + order[i]], C, out[b][..., i * C:], I * C, HW, C)
     ya = Act(out)
     ya.amax = x.amax                 # the same values in another order: the range the producer left is this tensor's range
+    if x.planes is not None and batched and C % 2 == 0 and PLANES:
+        # the fp16 pair planes travel too ([pixel][h: C fp16 | m: C fp16] = C floats per pixel, h first): the pair's h halves side
+        # by side, then its m halves -- two launches of C / 2 floats per pixel each, same bound
+        pl = torch.empty((B, H, W, I * C), dtype=torch.float32, device=x.t.device)
+        src = x.planes[order[0]]
+        for half in (0, 1):
+            ops.copy2d_batched(src.reshape(-1)[half * (C // 2):], C, (I * HW * C, step * HW * C),
+                               pl.reshape(-1)[half * (I * C // 2):], I * C, (HW * I * C, C // 2), HW, C // 2, (B, I))
+        ya.planes = pl
 
     def bwd():
         g = ya.take_grad()

@@ -347,3 +347,56 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     assert float(mism.float().mean()) < 2 * ref["argmax_mismatch_frac"] + 0.01
     assert n_sure_bad == 0
     assert all(h < 1.5 * r + 0.02 for h, r in zip(rate_h, rate_r)), (rate_h, rate_r)
+
+
+def test_stv2_variant_under_autocast_precision(golden_dir, report):
+    """the reference trains STv2 (and FBMS) with Lightning `precision: 16` = fp16 autocast + GradScaler
+    (configs/rcf_stv2/rcf_stage1.yaml:57-60); here any autocast runs as bf16 storage.  The STv2
+    variant of the config registry -- single-map head + compactness loss -- entered the way Lightning enters it (the model called
+    inside torch.autocast with fp16 as the requested dtype, a loss scale of 2^14 handed to backward like GradScaler's), against its
+    fp32 fixture from the reference.  Yardstick: the REFERENCE's own 16-bit autocast steps of this variant on this batch
+    (tests/golden/variants_autocast.json, make_golden_variants_autocast.py: bf16 loss terms 0.2-1.0 % from its fp32 run, module
+    gradient norms 4-89 %; its fp16 run with this very loss scale overflows the backbone gradient -- the step GradScaler skips).
+    Every loss term within 3x the reference's largest bf16 loss-term deviation; module gradient norms (after unscaling, against
+    float64) within max(3x the reference's bf16 deviation of that module, 35 %) -- a 64x96 batch of 2 is noise-dominated in 16
+    bits (the full-size figures are in test_fullsize_b8_gradients_vs_oracle: 0.1-6 %); nothing non-finite."""
+    import copy
+    import json
+    import os
+    import types
+    from rcf_amd import config, synth
+    fx = json.load(open(os.path.join(golden_dir, "variants.json")))["stv2"]
+    fa = json.load(open(os.path.join(golden_dir, "variants_autocast.json")))["stv2"]
+    ref = fa["ref_autocast_vs_fp32"]["bf16"]
+    H, W, B = fx["H"], fx["W"], fx["B"]
+    assert (fa["H"], fa["W"], fa["B"]) == (H, W, B)
+    kw, oc = config.variant_model_kwargs("stv2", H, W)
+    args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=oc, eval_save=False, eval_export=False)
+    m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=fx["weight_seed"]).items()})
+    m.to(DEV).train()
+    nb = synth.make_batch(B, H, W, config_id=1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    batch = {"imgs": [t(a) for a in nb["imgs"]], "gt_fw_flows": [t(a) for a in nb["gt_fw_flows"]],
+             "gt_bw_flows": [t(a) for a in nb["gt_bw_flows"]], "seq_ids": nb["seq_ids"], "seq_names": nb["seq_names"], "paths": nb["paths"]}
+    scale = 2.0 ** 14
+    with torch.autocast("cuda", dtype=torch.float16):
+        losses = m(batch)
+    assert rcf_amd.layers.ACT_DTYPE == torch.bfloat16, "autocast (fp16 requested) must select the bf16 storage path"
+    (losses["loss"] * scale).backward()
+    e = {k: abs(float(losses[k]) - v) / abs(v) for k, v in fx["loss"].items()}
+    gn = {}
+    finite = True
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            finite &= bool(torch.isfinite(p.grad).all())
+            gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float((p.grad.double() / scale).pow(2).sum())
+    e_gn = {k: abs(gn[k] ** 0.5 - v) / v for k, v in fx["truth_gradnorm"].items()}
+    report("STv2 variant under autocast (fp16 requested -> bf16 storage, loss scale 2^14): losses vs the reference's fp32 " +
+           " ".join(f"{k} {v:.1e}" for k, v in e.items()) + " | gradient norms vs float64 " + " ".join(f"{k} {v:.1e}" for k, v in e_gn.items()) +
+           " | the reference's own bf16 autocast vs its fp32: losses " + " ".join(f"{k} {v:.1e}" for k, v in ref["loss"].items()) +
+           " gradient norms " + " ".join(f"{k} {v:.1e}" for k, v in ref["gradnorm"].items()))
+    lim_l = 3 * max(ref["loss"].values())
+    assert finite and all(v < lim_l for v in e.values()), (e, lim_l)
+    assert all(e_gn[k] < max(3 * ref["gradnorm"][k], 0.35) for k in e_gn), (e_gn, ref["gradnorm"])
