@@ -294,6 +294,13 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             out["data_transform"] = None
             out["data_transform_error"] = str(e)[:200]
+        # does the loader keep up?  host JPEG decode + .npy reads + upload + transform, against the bf16 step
+        if world == 1:
+            try:
+                out["loader"] = loader_bench(torch, rcf_amd, synth, dev, H, W, B, step_frames_per_s=out.get("bf16_frames_per_s"))
+            except Exception as e:                              # noqa: BLE001
+                out["loader"] = None
+                out["loader_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(_finite(out)), flush=True)
@@ -507,6 +514,76 @@ def datapipe_bench(torch, rcf_amd, synth, dev, H, W, B):
             "launches_per_batch": 3, "algorithmic_bytes_per_batch": round(out_b + src_b),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4)}}
+
+
+def loader_bench(torch, rcf_amd, synth, dev, H, W, B, workers=16, batches=10, step_frames_per_s=None):
+    """SURVEY.md section 8(f) rank 4's question: does the loader keep up with the step?  The path the reference's DataLoader
+    walks (dataset/data.py:62-70,122-128; 16 workers: configs/rcf/rcf_stage1.yaml:10) with this repo's device side: JPEG files
+    -> PIL decode (host, `workers` threads: the decoder and the file reads release the GIL) and `.npy` flows read straight
+    into the pinned staging set of `BatchUploader` -> copy stream -> `Transform` (three launches).  Files are written to a
+    temporary directory first and stay in the page cache (what a training run sees from its second epoch on); the GPU does
+    nothing else meanwhile.  frames/s = 2 B per batch over the wall time of `batches` batches after 2 untimed ones."""
+    import concurrent.futures as cf
+    import os
+    import shutil
+    import tempfile
+    import time
+    import numpy as np
+    from PIL import Image
+    from rcf_amd.data_pipeline import BatchUploader, Transform, load_flow_npy_into
+    tmp = tempfile.mkdtemp(prefix="rcf_loader_")
+    try:
+        nsamp = 2 * B
+        jpeg_bytes = 0
+        for i in range(nsamp):
+            smp = synth.loader_sample(7000 + i, H, W)
+            for f in range(2):
+                fp = os.path.join(tmp, f"{i}_{f}.jpg")
+                Image.fromarray(smp["frames"][f]).save(fp, quality=95)
+                jpeg_bytes += os.path.getsize(fp)
+            np.save(os.path.join(tmp, f"{i}_fw.npy"), smp["fw"])
+            np.save(os.path.join(tmp, f"{i}_bw.npy"), smp["bw"])
+        tf = Transform(training=True, strong_aug=True, has_flow=True)
+        up = BatchUploader(B, 2, H, W, has_flow=True, has_pl=False, device=dev)
+        rng = np.random.RandomState(3)
+
+        def fill(job):                                          # one FILE per task: 4 B tasks per batch keep 16 workers busy
+            st, b, i, what = job
+            if what in (0, 1):
+                with Image.open(os.path.join(tmp, f"{i}_{what}.jpg")) as im:
+                    st["imgs"][b, what] = np.asarray(im.convert("RGB"))
+            else:
+                load_flow_npy_into(os.path.join(tmp, f"{i}_{what}.npy"), st["gt_" + what + "_flows"][b])
+
+        def one(it, pool):
+            st = up.stage()
+            list(pool.map(fill, [(st, b, (it * B + b) % nsamp, what) for b in range(B) for what in (0, 1, "fw", "bw")]))
+            params = np.stack([tf.sample_params(H, W, rng) for _ in range(B)])
+            return tf(up.upload(), params=params)
+        out = {}
+        with cf.ThreadPoolExecutor(workers) as pool:
+            for it in range(2):
+                one(it, pool)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            host = 0.0
+            for it in range(batches):
+                h0 = time.perf_counter()
+                one(2 + it, pool)
+                host += time.perf_counter() - h0
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        fps = 2 * B * batches / dt
+        out = {"what": f"{H}x{W} JPEG pairs (q95, {jpeg_bytes / (2 * nsamp) / 1e3:.0f} KB per frame, page cache) + 2 .npy flows per sample: "
+                       f"PIL decode on {workers} host threads -> pinned staging -> copy stream -> Transform(training, strong_aug) on the GPU; "
+                       f"one batch of {B} samples in flight at a time",
+               "workers": workers, "host_cores": os.cpu_count(), "frames_per_s": round(fps, 1), "ms_per_batch": round(1e3 * dt / batches, 2),
+               "host_ms_per_batch": round(1e3 * host / batches, 2), "uploaded_bytes_per_batch": up.nbytes}
+        if step_frames_per_s:
+            out["vs_bf16_step_frames_per_s"] = round(fps / step_frames_per_s, 3)
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _cpu_info():

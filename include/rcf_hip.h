@@ -191,6 +191,24 @@ int rcf_conv2d_dgrad_f32(const float *dy, const float *w, float *dx, const rcf_c
 int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s,
                                 const rcf_conv_region *region, int beta, void *workspace, size_t workspace_bytes,
                                 void *stream);
+/* The data gradient of a conv whose INPUT is the output of a training-mode batch norm + ReLU (the bottlenecks' bn1 -> conv2,
+ * bn2 -> conv3, bn3 + identity -> the next block's conv1; models/resnet.py:268-302), and, from the same kernel's epilogue, the
+ * two sums that norm's backward needs: sums2[2*Cin] = [sum g | sum g * xhat] with g = dx masked by the norm's ReLU sign bits
+ * (dx after the accumulation when beta = 1: the call must be the LAST writer of dx) and xhat = (x - mean) * invstd of the norm's
+ * input x -- what rcf_bn_bwd_reduce_mp would read dx and x back for.  A lane's <= 64 values of a column are added in fp32,
+ * everything above in fp64, in a fixed order.  rcf_conv2d_dgrad_bnsums_ok(s): 1 when the launch this shape takes has that epilogue
+ * (fp16-pair kernels with prepared weights -- w_pairs_t / w_pairs2_t and both ranges --, Cin = 64, 128 or a multiple of 256);
+ * otherwise the entry point returns RCF_EINVAL before launching anything and the caller runs the two passes. */
+typedef struct rcf_bn_bwd_in {
+    const float *x;                 /* the norm's input [N*H*W][x_pitch] */
+    int x_pitch;
+    const unsigned char *relu_mask; /* [N*H*W][Cin/4] as rcf_bn_apply_mp writes it */
+    const float *mean, *invstd;     /* [Cin] */
+} rcf_bn_bwd_in;
+int rcf_conv2d_dgrad_bnsums_ok(const rcf_conv_shape *s);
+size_t rcf_conv2d_dgrad_bnsums_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_dgrad_bnsums_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
+                                const rcf_bn_bwd_in *bn, double *sums2, void *workspace, size_t workspace_bytes, void *stream);
 /* dw[Cout][R][S][Cin] (+)= sum_pixels dy * x.  Split over pixels into `workspace`, then reduced
  * deterministically (no float atomics). */
 size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);

@@ -23,6 +23,12 @@ class ConvShape(ctypes.Structure):
                [("flags", ctypes.c_uint), ("struct_bytes", ctypes.c_uint)]
 
 
+class BnBwdIn(ctypes.Structure):
+    """mirror of rcf_bn_bwd_in"""
+    _fields_ = [("x", ctypes.c_void_p), ("x_pitch", c_int), ("relu_mask", ctypes.c_void_p), ("mean", ctypes.c_void_p),
+                ("invstd", ctypes.c_void_p)]
+
+
 # include/rcf_hip.h RCF_CONV_* flag bits
 CONV_WGRAD_TILE_128 = 0x1
 CONV_X_PLANES, CONV_DY_PLANES = 0x2, 0x4
@@ -89,6 +95,9 @@ PROTOS = {
     "rcf_conv_weight_pairs_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_uint, P]),
     "rcf_conv_weight_pairs_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rcf_conv2d_dgrad_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_dgrad_bnsums_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_dgrad_bnsums_ok": (c_int, [_CS]),
+    "rcf_conv2d_dgrad_bnsums_f32": (c_int, [P, P, P, _CS, c_int, ctypes.POINTER(BnBwdIn), P, P, c_size_t, P]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
     "rcf_conv_weight_pairs_t_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_uint, P]),

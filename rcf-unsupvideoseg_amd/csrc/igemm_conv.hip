@@ -83,6 +83,13 @@ struct IgemmParams {
     const void *b_pairs2;
     int h2p_gn;                   // conv_h2p_kernel: workgroups sharing one row range (they split the column tiles)
     unsigned *amax_out;           // optional: max |value written| (raw bits, atomicMax): the range of the next consumer
+    // data gradient whose output is the gradient of a batch norm + ReLU's OUTPUT (rcf_conv2d_dgrad_bnsums_f32): that norm's
+    // input x ([rows][bn_x_pitch], the rows of Y), its ReLU sign bits ([rows][Ncol / 4], bit e = output 4 j + e was positive) and
+    // constants; `stats` then receives per row tile [sum g | sum g xhat], g = the masked value written, xhat = (x - mean) invstd
+    const float *bn_x;
+    const unsigned char *bn_mask;
+    const float *bn_mean, *bn_invstd;
+    int bn_x_pitch;
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -537,7 +544,7 @@ __device__ __forceinline__ unsigned x3_oob_unless(unsigned off, int ok) { return
 // once per pixel; scaling back by the operands' powers of two (fp16 pairs), bias / activation / accumulate, the fused batch-norm
 // statistics (column sums over pixels = lanes: a reduce-scatter butterfly) and the output's range.  `smem`: the kernel's LDS,
 // free once every wave is past its K-loop (the statistics fold reuses it).
-template <int MR, int NR, int WM, int WN, bool DGRAD, int NP>
+template <int MR, int NR, int WM, int WN, bool DGRAD, int NP, bool BST = false>
 __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&acc)[MR][NR], char *smem, int tile_m, int m0, int n0,
                                                  int ka, int kb) {
     constexpr int NT = 64 * WM * WN, BN = 32 * NR * WN;
@@ -548,6 +555,9 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;   // rows map linearly onto the output tensor
     const bool want_stats = !DGRAD && p.stats != nullptr;
+    // BST: the batch-norm backward's two sums (lean path only: the launch checks) -- its own instantiation: the sums' registers
+    // (32 accumulators beside the tile's 128) would cost every other data gradient occupancy or spills
+    constexpr bool want_bstats = DGRAD && BST;
     const float inv_a = pow2f(-ka), inv_b = pow2f(-kb);
     unsigned tmax = 0u;
     // transposed accumulators (mma_x3 SWAP): lane = pixel (lane&31) of each row tile, registers 4g..4g+3 = output
@@ -567,7 +577,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
         }
     }
     double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
-    if (want_stats) __syncthreads();                      // every wave is done with the operand stages
+    if (want_stats || want_bstats) __syncthreads();       // every wave is done with the operand stages
     // The common case -- a whole column tile, no bias, no activation (every conv -> batch norm pair and every data
     // gradient of the step) -- as straight-line code: the general loop below tests columns, bias, activation and beta
     // per quad and per element, which the compiler turns into ~170 instructions in four basic blocks per 16-byte
@@ -581,32 +591,67 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
         if (lean) {
             // BETA: accumulate into the output; EXTRA: the by-products are wanted (batch-norm statistics of a forward
             // conv, the output's range of a ViT GEMM) -- a data gradient wants neither: scale, (add,) store
+            // EXTRA 2 (data gradients): the value written is the gradient of a batch norm + ReLU's output -- mask it with the
+            // norm's sign bits and add g and g * xhat per channel (what rcf_bn_bwd_reduce_mp would read the tensor back for)
             auto quads = [&](auto BETA_, auto EXTRA_) {
-                constexpr bool BETA = decltype(BETA_)::value, EXTRA = decltype(EXTRA_)::value;
+                constexpr bool BETA = decltype(BETA_)::value;
+                constexpr int EXTRA = decltype(EXTRA_)::value;
+                const int cb = n0 + brow0 + 4 * kh + nr * 32;           // this lane's first channel of the column tile
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     if (!rowok[mr]) continue;
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + n0 + brow0 + 4 * kh + nr * 32);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + cb);
+                    const f32x4 *xs = nullptr;
+                    const unsigned char *ms = nullptr;
+                    if constexpr (EXTRA == 2) {
+                        xs = reinterpret_cast<const f32x4 *>(p.bn_x + lin[mr] * p.bn_x_pitch + cb);
+                        ms = p.bn_mask + lin[mr] * (p.Ncol >> 2) + (cb >> 2);
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
                         v = (v * inv_a) * inv_b;
                         if (BETA) v += dst[2 * g];
                         dst[2 * g] = v;
-                        if (EXTRA) {
+                        if constexpr (EXTRA == 1) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 tmax = max(tmax, __float_as_uint(fabsf(v[e])));
-                                cs[4 * g + e] += v[e];
-                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                                if constexpr (!DGRAD) {                  // a data gradient wants the range only
+                                    cs[4 * g + e] += v[e];
+                                    cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                                }
+                            }
+                        }
+                        if constexpr (EXTRA == 2) {
+                            // the channel constants are re-read per quad (L1 / scalar-cache hits): kept in registers over the
+                            // tile they would be 32 more live values
+                            const f32x4 mu = *reinterpret_cast<const f32x4 *>(p.bn_mean + cb + 8 * g);
+                            const f32x4 is = *reinterpret_cast<const f32x4 *>(p.bn_invstd + cb + 8 * g);
+                            const f32x4 xq = xs[2 * g];
+                            const unsigned mq = ms[2 * g];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                tmax = max(tmax, __float_as_uint(fabsf(v[e])));
+                                const float gg = (mq >> e) & 1u ? v[e] : 0.f;
+                                cs[4 * g + e] += gg;
+                                cq[4 * g + e] += gg * ((xq[e] - mu[e]) * is[e]);      // BwdOp's operation order (csrc/bn.hip)
                             }
                         }
                     }
                 }
             };
             const bool extra = want_stats || p.amax_out != nullptr;
-            if (p.beta) { if (extra) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
-            else { if (extra) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            if constexpr (want_bstats) {
+                if (p.beta) quads(std::true_type{}, I2{}); else quads(std::false_type{}, I2{});
+            } else {
+                (void)sizeof(I2);
+                if (p.beta) { if (extra) quads(std::true_type{}, I1{}); else quads(std::true_type{}, I0{}); }
+                else { if (extra) quads(std::false_type{}, I1{}); else quads(std::false_type{}, I0{}); }
+            }
         } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -649,7 +694,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
             }
         }
         }
-        if (want_stats) {                                 // block-uniform
+        if (want_stats || want_bstats) {                  // block-uniform
             // column sums over the 32 pixels (lanes) of this half-wavefront: a reduce-scatter butterfly -- at every
             // step a lane keeps the half of its registers its lane bit selects and adds the partner's copy of them
             // (16 + 8 + 4 + 2 + 1 values move instead of 5 x 16); bit 0 of the lane ends up redundant.
@@ -687,7 +732,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
         for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o));
         if (lane == 0 && tmax > __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.amax_out, tmax);
     }
-    if (want_stats) {
+    if (want_stats || want_bstats) {
         __syncthreads();
         for (int c = tid; c < BN; c += NT) {
             if (n0 + c >= p.Ncol) continue;
@@ -714,7 +759,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
 // PRE (NP == 2 only): the weight operand arrives split (p.b_pairs: two fp16 planes)
 // TR: transposed accumulator tiles (mma_x3 SWAP) and the 16-byte epilogue; every instance is launched with TR = true
 // (the batch-norm statistics, column sums, are a butterfly over the pixels = lanes of a half-wavefront there)
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD>
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD = false, int NP = 3, bool PRE = false, bool TR = DGRAD, bool BST = false>
 __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ? 2 : 1) igemm_conv_x3_kernel(IgemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, BKT = 16;
@@ -934,7 +979,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MR * NR >= 8 && WM * WN == 4) ?
         mma_x3<MR, NR, PA, PB, false, NP, TR>(As, As + NP * PA, arow0, brow0, lane, acc);
     }
 
-    conv_epilogue_tr<MR, NR, WM, WN, DGRAD, NP>(p, acc, smem, tile_m, m0, n0, ka, kb);
+    conv_epilogue_tr<MR, NR, WM, WN, DGRAD, NP, BST>(p, acc, smem, tile_m, m0, n0, ka, kb);
     static_assert(TR, "the column-per-lane epilogue was retired: every instance runs transposed");
 }
 
@@ -1985,6 +2030,13 @@ void launch_x3_cfg_np(IgemmParams &p, bool strided, hipStream_t st, int batches)
     p.colmap = batches == 1 && p.Ncol % BN == 0 &&
                rcf_colmap_pays(!(p.flags & RCF_CONV_NO_COLMAP), (long)p.M * p.Cs * 4, (long)p.K * p.Ncol * 4, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles), (unsigned)batches);
+    if constexpr (NP == 2 && PRE) {              // data gradient + the batch-norm backward sums (rcf_conv2d_dgrad_bnsums_f32)
+        if (p.stats && p.step < 0) {
+            if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE, true, true>), grid, dim3(64 * WM * WN), 0, st, p);
+            else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE, true, true>), grid, dim3(64 * WM * WN), 0, st, p);
+            return;
+        }
+    }
     if (strided) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, true, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (p.step < 0) hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, true, NP, PRE>), grid, dim3(64 * WM * WN), 0, st, p);
     else hipLaunchKernelGGL((igemm_conv_x3_kernel<MR, NR, WM, WN, false, false, NP, PRE, true>), grid, dim3(64 * WM * WN), 0, st, p);
@@ -2073,7 +2125,9 @@ int launch_h2d(IgemmParams &p, hipStream_t st, int batches, int *kernel_only) {
     const dim3 grid((unsigned)(p.mtiles8 * 8 * p.ntiles));
 #define RCF_H2D(NRv)                                                                                            \
     do {                                                                                                        \
-        if (p.div > 1) hipLaunchKernelGGL((conv_h2d_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);       \
+        if (p.stats && p.step < 0 && p.div > 1) hipLaunchKernelGGL((conv_h2d_kernel<NRv, true, true, true>), grid, dim3(256), 0, st, p); \
+        else if (p.stats && p.step < 0) hipLaunchKernelGGL((conv_h2d_kernel<NRv, false, true, true>), grid, dim3(256), 0, st, p);        \
+        else if (p.div > 1) hipLaunchKernelGGL((conv_h2d_kernel<NRv, true, true>), grid, dim3(256), 0, st, p);  \
         else if (p.step < 0) hipLaunchKernelGGL((conv_h2d_kernel<NRv, false, true>), grid, dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((conv_h2d_kernel<NRv, false, false>), grid, dim3(256), 0, st, p);               \
     } while (0)
@@ -2276,7 +2330,8 @@ extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *b
 
 namespace {
 int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
-                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only);
+                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only, const rcf_bn_bwd_in *bn = nullptr,
+                      double *stats = nullptr, int *mtiles_out = nullptr);
 // forward launch; kernel_only: report the kernel the call would take instead (rcf_conv_kernel_of)
 int conv2d_fwd_impl(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                     const rcf_conv_region *region, int act, float slope, int beta, double *stats, void *stream, int *kernel_only,
@@ -2470,12 +2525,54 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
     return conv2d_dgrad_impl(dy, w, dx, s, region, beta, workspace, workspace_bytes, stream, nullptr);
 }
 
+extern "C" size_t rcf_conv2d_dgrad_bnsums_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s) || !use_x3(s->flags)) return 0;
+    // one row of partial sums per row tile (smallest tile: 64 rows) + the 64 rows of the two-level reduction
+    return (size_t)(rcf_cdiv((long)s->N * s->H * s->W, 64) + 64) * 2 * s->Cin * sizeof(double);
+}
+
+extern "C" int rcf_conv2d_dgrad_bnsums_ok(const rcf_conv_shape *s) {
+    if (check_shape(s) || !use_x3(s->flags) || s->Cout % 4) return 0;
+    const int bnw = s->Cin > 128 ? 256 : (s->Cin > 64 ? 128 : 64);
+    const void *wpt = s->w_pairs2_t ? s->w_pairs2_t : s->w_pairs_t;
+    if (s->Cin % bnw || !wpt || !s->amax_dy || !s->amax_w) return 0;
+    if ((s->flags & RCF_CONV_DY_PLANES) && !(s->w_pairs2_t && pairs2_written(s->R * s->S * s->Cout, s->Cout))) return 0;
+    return 1;
+}
+
+extern "C" int rcf_conv2d_dgrad_bnsums_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
+                                           const rcf_bn_bwd_in *bn, double *sums2, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!dy || !w || !dx || !bn || !sums2 || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    if (!rcf_conv2d_dgrad_bnsums_ok(s)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < rcf_conv2d_dgrad_bnsums_workspace_bytes(s) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+    int mtiles = 0;
+    if (int e = conv2d_dgrad_impl(dy, w, dx, s, nullptr, beta, nullptr, 0, stream, nullptr, bn, (double *)workspace, &mtiles)) return e;
+    return rcf_sum_partials_f64((const double *)workspace, mtiles, 2 * s->Cin, sums2, (double *)workspace + (size_t)mtiles * 2 * s->Cin,
+                                stream);
+}
+
 namespace {
 int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
-                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only) {
+                      void *workspace, size_t workspace_bytes, void *stream, int *kernel_only, const rcf_bn_bwd_in *bn, double *stats,
+                      int *mtiles_out) {
     if (s->Cout % 4) return RCF_EINVAL;
     IgemmParams p{};
     p.flags = s->flags;
+    if (bn) {
+        // the batch-norm sums come out of the lean epilogue of the 128-row fp16-pair kernels: whole column tiles, the whole tensor,
+        // weights prepared by the caller (the workspace holds the partial sums), not the persistent kernel (its own epilogue)
+        const int bnw = s->Cin > 128 ? 256 : (s->Cin > 64 ? 128 : 64);
+        const void *wpt = s->w_pairs2_t ? s->w_pairs2_t : s->w_pairs_t;
+        if (!use_x3(s->flags) || region || s->Cin % bnw || !wpt || !s->amax_dy || !s->amax_w || !stats || !bn->x || !bn->relu_mask ||
+            !bn->mean || !bn->invstd || bn->x_pitch % 4 || bn->x_pitch < s->Cin || !rcf_aligned16(bn->x) || !rcf_aligned16(bn->mean) ||
+            !rcf_aligned16(bn->invstd))
+            return RCF_EINVAL;
+        p.flags |= RCF_CONV_H2P_NEVER;
+        p.stats = stats;
+        p.bn_x = bn->x; p.bn_x_pitch = bn->x_pitch; p.bn_mask = bn->relu_mask; p.bn_mean = bn->mean; p.bn_invstd = bn->invstd;
+    }
     p.A = dy; p.Bw = w; p.bias = nullptr; p.Y = dx;
     p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
     p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
@@ -2509,9 +2606,11 @@ int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv
                                    s->R * s->S);
             p.Bw = (const float *)workspace;
         }
-        return launch_igemm_x3(p, st, 1, kernel_only);
+        const int e = launch_igemm_x3(p, st, 1, kernel_only);
+        if (mtiles_out) *mtiles_out = p.mtiles;
+        return e;
     }
-    if (region) return RCF_EINVAL;
+    if (region || bn) return RCF_EINVAL;
     if (kernel_only) { *kernel_only = 0; return 0; }
     return launch_igemm<1>(p, rcf_stream(stream));
 }

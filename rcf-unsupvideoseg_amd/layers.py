@@ -36,7 +36,7 @@ def _round_up(n, m):
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
-                 "grad_is_planes", "stats_global")
+                 "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -50,6 +50,10 @@ class Act:
         self.bn = None               # (mean, invstd, count) when the producing conv's reduction also finalized the norm
         self.amax = None             # int32 [1]: raw bits of max |t| (operand range of the fp16-pair conv kernels)
         self.grad_amax = None        # the same for `grad`, when its only producer computed it
+        # the batch norm + ReLU that produced t leaves (its input, sign bits, mean, invstd) here; the conv that read t FIRST in
+        # the forward pass writes t's gradient LAST in the backward pass and can then deliver the norm's backward sums from its
+        # data gradient's epilogue (`grad_sums2`; any later writer of `grad` -- there should be none -- voids them in grad_slot)
+        self.bn_ctx = self.first_reader = self.grad_sums2 = None
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -63,6 +67,7 @@ class Act:
             self.grad = torch.empty(tuple(self.t.shape), dtype=self.t.dtype, device=self.t.device)
             return self.grad, 0
         self.grad_amax = None        # a second producer accumulates: the first one's range no longer bounds the sum
+        self.grad_sums2 = None       # ... nor are sums taken over an earlier state of the gradient the sums of the final one
         return self.grad, 1
 
     def take_grad(self):
@@ -94,6 +99,9 @@ FUSE_BN_STATS = True
 BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels), as torch autocast does
 CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once per weight update, not per launch
 FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
+# fp32 step: the two sums of a batch norm's backward (sum g, sum g xhat) from the epilogue of the data gradient that writes the
+# norm's output gradient last (ops.conv2d_dgrad(bn_bwd=...)) instead of a pass over dy and x.  RCF_FUSE_BN_BWD=0: the pass.
+FUSE_BN_BWD = __import__("os").environ.get("RCF_FUSE_BN_BWD", "1") != "0"
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
 # test hook (tests/test_model_gpu.py::test_train_step_all_grads_at_fixed_relu_pattern): a list that receives, in forward
@@ -395,6 +403,9 @@ class Conv2d(nn.Module):
         if x.split and not use_pl:
             raise ops._lib.RcfHipError("this activation exists as fp16 pair planes only and the conv cannot read them")
         xin = x.planes if use_pl else x.t
+        tok = object()
+        if x.first_reader is None:
+            x.first_reader = tok                   # first reader in forward order = last writer of x's gradient in the backward pass
         yamax = None
         if FP16_PAIRS:
             own = w is self.weight                                       # padded copies are rebuilt per call: not cached
@@ -439,9 +450,12 @@ class Conv2d(nn.Module):
                         wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
                     # the range of dx comes out of the epilogue (after the accumulation when beta = 1): exact for the whole tensor
                     gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None else None
-                    ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                     amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax)
+                    bnb = x.bn_ctx if (FUSE_BN_BWD and wpt is not None and x.first_reader is tok) else None
+                    r = ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                         amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax, bn_bwd=bnb)
                     x.grad_amax = gamax
+                    if bnb is not None:
+                        x.grad_sums2 = r[1]            # None when the launch had no such epilogue: the norm runs its reduction pass
                     done_dgrad[0] = True
                 xw, xpl = (x.planes, True) if (dpl and use_pl) else (x.t, False)      # the weight gradient's x in dy's format
                 if self.weight.requires_grad:
@@ -555,6 +569,8 @@ class BatchNorm2d(nn.Module):
         if tape.enabled:
             if not self.training:
                 raise RuntimeError("tape backward through eval-mode BN is not implemented")
+            if relu and rmask is not None and chan_scale is None and xt.dtype == torch.float32 and ydt == torch.float32 and xt.is_contiguous():
+                ya.bn_ctx = (xt, rmask, mean, invstd)
 
             def bwd():
                 # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
@@ -563,7 +579,9 @@ class BatchNorm2d(nn.Module):
                        and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
                 ady = ya.take_grad_range() if dpl else None
                 dy = ya.take_grad()
-                s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
+                s2, ya.grad_sums2 = ya.grad_sums2, None          # from the epilogue of the data gradient that wrote dy last
+                if s2 is None:
+                    s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
                 s2_local = None
                 if dist is not None and dist.on:
                     s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them

@@ -381,10 +381,13 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
 
 
 def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None, w_pairs_t=None,
-                 dy_planes=False, amax_y=None):
+                 dy_planes=False, amax_y=None, bn_bwd=None):
     """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w);
     w_pairs_t = weight_pairs_t(w, amax_w), prepared once per weight update.  dy_planes: `dy` holds fp16 pair planes
-    (RCF_CONV_DY_PLANES: bn_bwd_apply's dx); amax_y: new_amax() slot for the range of dx (after the accumulation)"""
+    (RCF_CONV_DY_PLANES: bn_bwd_apply's dx); amax_y: new_amax() slot for the range of dx (after the accumulation).
+    bn_bwd = (x_bn, relu_mask, mean, invstd) of the batch norm + ReLU whose OUTPUT is this conv's input, given when this call is the
+    last writer of dx: returns (dx, sums2) with the norm's backward sums from the kernel's epilogue (rcf_conv2d_dgrad_bnsums_f32),
+    or (dx, None) when the launch this shape takes has no such epilogue -- the caller then runs bn_bwd_reduce"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
@@ -394,19 +397,30 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
                     amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
                     flags=_lib.CONV_DY_PLANES if dy_planes else 0, amax_y=amax_y)
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
+    fuse = (bn_bwd is not None and region is None and out.is_contiguous() and bn_bwd[0].dtype == torch.float32 and
+            tuple(bn_bwd[0].shape) == tuple(out.shape) and _lib.load().rcf_conv2d_dgrad_bnsums_ok(byref(s)) == 1)
     need = 0 if w_pairs_t is not None else _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
+    if fuse:
+        need = _lib.load().rcf_conv2d_dgrad_bnsums_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_h2d_dgrad" if dy_planes else "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
                               2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
-    call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
-         need, _stream())
+    sums2 = None
+    if fuse:
+        xb, mask, mean, invstd = bn_bwd
+        sums2 = torch.empty(2 * s.Cin, dtype=torch.float64, device=dy.device)
+        bn = _lib.BnBwdIn(xb.data_ptr(), pitch_of(xb), mask.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+        call("rcf_conv2d_dgrad_bnsums_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, byref(bn), _p(sums2), _p(ws), need, _stream())
+    else:
+        call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
+             need, _stream())
     if end is not None:
         end.record()
-        if not dy_planes:
+        if not dy_planes and not fuse:
             _relabel_conv(s, _region(region), 1, "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other", "conv_h2p_dgrad")
-    return out
+    return (out, sums2) if bn_bwd is not None else out
 
 
 def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None, amax=None, small_tile=False, planes=False):

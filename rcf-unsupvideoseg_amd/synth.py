@@ -207,3 +207,38 @@ def fill_vit_state_dict(shapes, seed=21):
         else:
             out[k] = (0.05 * g.standard_normal(shp)).astype(np.float32)
     return out
+
+
+def grad_sketch(named_grads, k=8):
+    """A small linear fingerprint of a set of gradient tensors: per tensor, k sums of its elements under pseudo-random +-1
+    sign patterns (a hash of the element index: the same pattern on every device and in every process).  E[(s - t)^2] of two
+    sketches is the squared distance of the tensors they came from, so |sketch(g) - sketch(truth)| / |sketch(truth)| over a
+    module's tensors estimates the relative VECTOR error of the module's gradient from a few kilobytes of fixture instead of
+    100 MB of float64 gradients (tools/oracle_b8_selfdev.py, tests/test_model_gpu.py::test_fullsize_b8_gradients_vs_oracle).
+    named_grads: {name: torch tensor}; returns {name: [k floats]}."""
+    import torch
+    out = {}
+    for name, g in named_grads.items():
+        v = g.detach().reshape(-1).double()
+        idx = torch.arange(v.numel(), device=v.device, dtype=torch.int64)
+        row = []
+        for j in range(k):
+            h = idx * (2654435761 + 81006 * j) + 2654435769 * (j + 1)
+            h = (h ^ (h >> 15)) * 2246822519
+            h = h ^ (h >> 13)
+            sign = 1.0 - 2.0 * ((h >> 7) & 1).double()
+            row.append(float((sign * v).sum()))
+        out[name] = row
+    return out
+
+
+def sketch_error(sketch, truth, prefix=None):
+    """relative distance of two grad_sketch() results over the tensors whose name starts with `prefix` (None: all)"""
+    num = den = 0.0
+    for name, t in truth.items():
+        if prefix is not None and not name.startswith(prefix):
+            continue
+        s = sketch[name]
+        num += sum((a - b) ** 2 for a, b in zip(s, t))
+        den += sum(b ** 2 for b in t)
+    return (num / den) ** 0.5 if den > 0 else 0.0

@@ -458,20 +458,26 @@ def test_fullsize_b8_losses_and_argmax_vs_oracle(report):
 
 
 def test_fullsize_b8_gradients_vs_oracle(report):
-    """the backward of the same batch: the gradient norm of every top-level module against the oracle's FLOAT64 backward of
-    this very batch (tests/golden/oracle_b8_selfdev.json, made by tools/oracle_b8_selfdev.py on the GPU box's host: the
-    float64 step needs ~90 GB and minutes, so it is a committed fixture, not a live run).  Limit per module: 4 x the error
-    of the oracle's own fp32 evaluations against that truth (`gradnorm_fp32_err`: the worse of two thread counts), floor
-    1e-4 -- the rule the small cases use with their `ref32_err_*` fixtures.  The fixture's losses tie it to the batch.
+    """the backward of the same batch against the oracle's FLOAT64 backward of this very batch (tests/golden/oracle_b8_selfdev.json,
+    made by tools/oracle_b8_selfdev.py on the GPU box's host: the float64 step needs ~90 GB and minutes, so it is a committed
+    fixture, not a live run; the fixture's loss ties it to the batch).
+    The step is ill-conditioned at this size -- 57 train-mode batch norms, ReLU / max-pool / arg-max decisions: EVERY fp32
+    evaluation's gradient VECTOR is ~1.5e-2 (backbone) from the float64 one, the oracle's own included, and its norm then lands
+    anywhere within a fraction of that (the exact-fp32 HIP kernels in another summation order: 1.9e-3; the oracle on images
+    perturbed by one ulp: 2e-4 at 8 pairs, 1.4e-3 at one; tools/grad_error_b8.py, tools/grad_bias_probe.py, profiles/r04_grad_*).
+    So the check that means something is on the vectors: per module, the HIP step's relative vector error against float64
+    (from `synth.grad_sketch` fingerprints: 32 signed sums per parameter tensor) must be within 1.5 x the WORST of the oracle's
+    own fp32 evaluations (as is / images perturbed by one fp32 ulp, two seeds), floor 1e-4; the norms are reported beside the
+    oracle's norm spread and must at least stay inside the oracle's vector error (a norm error is one projection of it).
     bf16: the reference's own autocast-vs-fp32 deviation of this geometry (limits 3x, floor 10 %)."""
     import json
+    from rcf_amd import synth as _synth
     H, W, B = 480, 854, 8
     here = os.path.dirname(os.path.abspath(__file__))
     fx = json.load(open(os.path.join(here, "golden", "oracle_b8_selfdev.json")))
     assert (fx["B"], fx["H"], fx["W"]) == (B, H, W)
-    go, err_self = fx["gradnorm_f64"], fx["gradnorm_fp32_err"]
-    losses = {}
-    out = {}
+    go, spread, vec_ref, sk_truth = fx["gradnorm_f64"], fx["gradnorm_fp32_spread"], fx["vector_fp32_err"], fx["sketch_f64"]
+    losses, out, vec = {}, {}, {}
     for prec in ("fp32", "bf16"):
         hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
         hip.precision = prec
@@ -480,14 +486,19 @@ def test_fullsize_b8_gradients_vs_oracle(report):
         l["loss"].backward()
         losses[prec] = float(l["loss"])
         out[prec] = _module_gradnorms(hip)
+        if prec == "fp32":
+            sk = _synth.grad_sketch({n: p.grad for n, p in hip.named_parameters() if p.grad is not None}, k=fx["sketch_k"])
+            assert sorted(sk) == sorted(sk_truth), "parameter names differ from the oracle's"
+            vec = {k: _synth.sketch_error(sk, sk_truth, k + ".") for k in go}
         del hip
         torch.cuda.empty_cache()
     assert rel(losses["fp32"], fx["loss_f64"]["loss"]) < TOL, (losses, fx["loss_f64"])       # same batch, same weights
     g32 = {k: rel(out["fp32"][k], v) for k, v in go.items()}
     g16 = {k: rel(out["bf16"][k], v) for k, v in go.items()}
-    lim32 = {k: max(TOL, 4 * float(err_self[k])) for k in go}
-    report("480x854 b8 gradient norms vs the oracle's float64: fp32 " + " ".join(f"{k} {v:.1e} (limit {lim32[k]:.1e})" for k, v in g32.items()) +
-           " bf16 " + " ".join(f"{k} {v:.1e}" for k, v in g16.items()))
-    assert all(g32[k] < lim32[k] for k in g32), (g32, lim32)
+    report("480x854 b8 gradients vs the oracle's float64: fp32 vector error (oracle's own fp32, worst of 3) " +
+           " ".join(f"{k} {vec[k]:.1e} ({vec_ref[k]:.1e})" for k in go) + " | norm error (oracle's fp32 spread) " +
+           " ".join(f"{k} {g32[k]:.1e} ({spread[k]:.1e})" for k in go) + " | bf16 norms " + " ".join(f"{k} {v:.1e}" for k, v in g16.items()))
+    assert all(vec[k] < max(TOL, 1.5 * vec_ref[k]) for k in go), (vec, vec_ref)
+    assert all(g32[k] < max(TOL, 4 * spread[k], vec_ref[k]) for k in go), (g32, spread, vec_ref)
     ref16 = json.load(open(os.path.join(here, "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
     assert all(g16[k] < max(3 * ref16["gradnorm"][k], 0.10) for k in g16), g16

@@ -212,3 +212,118 @@ def test_training_step_with_and_without_pair_planes(report):
            "module gradient norms " + " ".join(f"{k} {v:.1e}" for k, v in e_g.items()))
     assert res[True][2] >= 40 and res[False][2] == 0
     assert e_l < 1e-5 and max(e_g.values()) < 2e-3
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, stride, pad, dil, H, W   (Cin = the batch norm's channels = the data gradient's output columns)
+    (2, 256, 256, 3, 1, 2, 2, 60, 107),      # bn1 -> conv2 of layer3: 256-wide tile
+    (2, 256, 1024, 1, 1, 0, 1, 33, 41),      # bn2 -> conv3: ragged row tile
+    (2, 1024, 256, 1, 1, 0, 1, 33, 41),      # join -> the next block's conv1: four column tiles, accumulating
+    (3, 128, 128, 3, 2, 1, 1, 61, 107),      # layer2.0 conv2: strided data gradient, 128-wide tile
+    (2, 64, 64, 3, 1, 1, 1, 30, 53),         # layer1: 64-wide tile
+    (1, 64, 256, 1, 1, 0, 1, 20, 30),        # few rows: the 64 x 64 tile of the register-split family
+])
+def test_data_gradient_delivers_batchnorm_backward_sums(case, report):
+    """rcf_conv2d_dgrad_bnsums_f32: the data gradient whose output is the gradient of a batch norm + ReLU's output also delivers
+    that norm's two backward sums (sum g, sum g xhat; g masked by the norm's sign bits) from its epilogue.  Against
+    rcf_bn_bwd_reduce_mp run on the tensor the same data gradient wrote: dx BIT-identical to the plain launch, sums to fp32
+    summation-order level (a lane's <= 64 values per column are added in fp32 here, in fp64 there) -- overwrite and accumulate,
+    register-split and pair-plane operand, whole model shapes of every tile width."""
+    N, Cin, Cout, k, stride, pad, dil, H, W = case
+    g = torch.Generator().manual_seed(7 + sum((i + 1) * v for i, v in enumerate(case)))
+    xbn = (torch.randn(N, H, W, Cin, generator=g) * torch.exp2(2 * torch.rand(Cin, generator=g)) + 0.4).to(DEV)   # the norm's input
+    gamma, beta_ = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (0.3 * torch.randn(Cin, generator=g)).to(DEV)
+    mean, invstd = ops.bn_finalize(ops.bn_stats(xbn), N * H * W, 1e-5, 0.1)
+    rmask = torch.empty(xbn.numel() // 4, dtype=torch.uint8, device=DEV)
+    y = ops.bn_apply(xbn, mean, invstd, gamma, beta_, True, relu_mask=rmask)            # the conv's input
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    wg = cl_weight(w)
+    Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV)
+    prev = torch.randn(N, H, W, Cin, generator=g).to(DEV)                                # an earlier writer of the same gradient
+    aw, ag = ops.absmax(ops.weight_rsck(wg)), ops.absmax(dy)
+    wpt = ops.weight_pairs_t(wg, aw)
+    dyp, _ = to_planes(dy, loose(ag, 1.7))
+    msg = []
+    for planes in (False, True):
+        src, bound = (dyp, loose(ag, 1.7)) if planes else (dy, ag)
+        for beta in (0, 1):
+            ref = prev.clone()
+            ops.conv2d_dgrad(src, wg, y.shape, stride, pad, dil, out=ref, beta=beta, amax=(bound, aw), w_pairs_t=wpt, dy_planes=planes)
+            s_ref = ops.bn_bwd_reduce(ref, xbn, y, mean, invstd, True, relu_mask=rmask)
+            out, rng = prev.clone(), ops.new_amax(DEV)
+            got, s2 = ops.conv2d_dgrad(src, wg, y.shape, stride, pad, dil, out=out, beta=beta, amax=(bound, aw), w_pairs_t=wpt,
+                                       dy_planes=planes, amax_y=rng, bn_bwd=(xbn, rmask, mean, invstd))
+            assert s2 is not None, "this shape must take the fused epilogue"
+            assert torch.equal(got, ref), "dx differs from the plain data gradient"
+            assert int(rng) == int(ops.absmax(ref))
+            scale = s_ref.abs().reshape(2, Cin).max(dim=1).values.repeat_interleave(Cin)
+            e = float(((s2 - s_ref).abs() / scale).max())
+            msg.append(f"{'planes' if planes else 'split'} beta {beta}: {e:.1e}")
+            assert e < 2e-6, e
+    report(f"data gradient + batch-norm backward sums {case}: max |sums - reduce pass| / max |sums| " + ", ".join(msg))
+
+
+def test_data_gradient_bnsums_refuses_what_it_cannot_do():
+    """a shape without the fused epilogue (Cin not a whole column tile) returns (dx, None): nothing half-done"""
+    g = torch.Generator().manual_seed(3)
+    N, H, W, Cin, Cout = 1, 12, 20, 96, 64
+    xbn = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    mean, invstd = ops.bn_finalize(ops.bn_stats(xbn), N * H * W, 1e-5, 0.1)
+    rmask = torch.empty(xbn.numel() // 4, dtype=torch.uint8, device=DEV)
+    y = ops.bn_apply(xbn, mean, invstd, torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV), True, relu_mask=rmask)
+    wg = cl_weight(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV)
+    aw, ag = ops.absmax(ops.weight_rsck(wg)), ops.absmax(dy)
+    wpt = ops.weight_pairs_t(wg, aw)
+    ref = ops.conv2d_dgrad(dy, wg, y.shape, amax=(ag, aw), w_pairs_t=wpt)
+    got, s2 = ops.conv2d_dgrad(dy, wg, y.shape, amax=(ag, aw), w_pairs_t=wpt, bn_bwd=(xbn, rmask, mean, invstd))
+    assert s2 is None and torch.equal(got, ref)
+
+
+def test_training_step_with_and_without_fused_bn_backward_sums(report):
+    """the same step with the batch-norm backward sums taken from the data gradients' epilogues (default) and by the reduction
+    pass (RCF_FUSE_BN_BWD=0): identical forward, gradients at summation-order level; how many norms still run the pass"""
+    import copy
+    import types
+    from rcf_amd import config, layers, synth
+    H, W, B = 96, 160, 2
+    res = {}
+    saved = layers.FUSE_BN_BWD
+    try:
+        for on in (True, False):
+            layers.FUSE_BN_BWD = on
+            kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+            kw.update(log_interval=10 ** 9, train_iter=1)
+            args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
+            m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+            m.to(DEV).train()
+            nb = synth.make_batch(B, H, W, config_id=1)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+            batch = {"imgs": [t(a) for a in nb["imgs"]], "gt_fw_flows": [t(a) for a in nb["gt_fw_flows"]],
+                     "gt_bw_flows": [t(a) for a in nb["gt_bw_flows"]], "seq_ids": nb["seq_ids"], "seq_names": nb["seq_names"],
+                     "paths": nb["paths"]}
+            calls = {"n": 0}
+            orig = ops.bn_bwd_reduce
+
+            def counting(*a, **k):
+                calls["n"] += 1
+                return orig(*a, **k)
+            ops.bn_bwd_reduce = counting
+            try:
+                losses = m(batch)
+                losses["loss"].backward()
+            finally:
+                ops.bn_bwd_reduce = orig
+            grads = {n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None}
+            res[on] = ({k: float(v) for k, v in losses.items()}, grads, calls["n"])
+    finally:
+        layers.FUSE_BN_BWD = saved
+    assert res[True][0] == res[False][0], "the forward pass does not depend on the switch"
+    worst = max((float((res[True][1][n] - g).norm() / g.norm()), n) for n, g in res[False][1].items() if float(g.norm()) > 0)
+    report(f"training step, batch-norm backward sums from the data gradients' epilogues: {res[False][2]} -> {res[True][2]} reduction passes; "
+           f"worst parameter-gradient difference {worst[0]:.1e} ({worst[1]})")
+    assert res[False][2] >= 55 and res[True][2] <= 12
+    assert worst[0] < 1e-4

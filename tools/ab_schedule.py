@@ -1,7 +1,8 @@
 """A/B of the training step's schedule and operand format in ONE process (boxes differ by more than the effects): the weight
 gradients on the main stream / on a second stream beside the layer's data gradient / started after it (layers.LATE_WGRAD), with
 the fp16 pair planes (layers.PLANES) on and off.  Interleaved rounds, median of 3 x 6 steps.
-usage: python tools/ab_schedule.py [fp32|bf16]"""
+usage: python tools/ab_schedule.py [fp32|bf16] [bnsums]   (bnsums: the default schedule and the one-stream order with the batch-norm
+backward sums from the data gradients' epilogues (layers.FUSE_BN_BWD) on and off)"""
 import os, sys, time, types
 import numpy as np
 import torch
@@ -23,13 +24,18 @@ batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows"
 configs = {}
 for planes in ((True, False) if prec == "fp32" else (False,)):
     for name, ov, late in (("one stream", False, False), ("two streams, beside dgrad", True, False), ("two streams, LATE", True, True)):
-        configs[f"{name}, planes {'on' if planes else 'off'}"] = (ov, late, planes)
+        configs[f"{name}, planes {'on' if planes else 'off'}"] = (ov, late, planes, layers.FUSE_BN_BWD)
+if len(sys.argv) > 2 and sys.argv[2] == "bnsums":
+    configs = {}
+    for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)):
+        for fuse in (True, False):
+            configs[f"{name}, bn sums {'from the dgrad epilogue' if fuse else 'by the reduction pass'}"] = (ov, late, prec == "fp32", fuse)
 for _ in range(4):
     tr.step(batch)
 res = {k: [] for k in configs}
 for r in range(3):
-    for name, (ov, late, planes) in configs.items():
-        layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES = ov, late, planes
+    for name, (ov, late, planes, fuse) in configs.items():
+        layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES, layers.FUSE_BN_BWD = ov, late, planes, fuse
         tr.step(batch)
         tr.step(batch)
         torch.cuda.synchronize()
@@ -39,4 +45,4 @@ for r in range(3):
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / 6 * 1e3)
 for name, v in res.items():
-    print(f"{name:44s}: " + " ".join(f"{x:7.2f}" for x in v) + f"   median {np.median(v):7.2f} ms/step", flush=True)
+    print(f"{name:60s}: " + " ".join(f"{x:7.2f}" for x in v) + f"   median {np.median(v):7.2f} ms/step", flush=True)
