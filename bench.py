@@ -331,9 +331,12 @@ def _self_launch(n):
 
 # bracket families (rcf_amd/ops.py) -> the kernel instance behind each
 FAMILIES_F32 = {
-    "conv_h2d_fwd": "conv_h2d_kernel<*,false,false> (forward of the bottlenecks' convs whose input the batch norm wrote as fp16 pair planes: both operands by LDS-DMA, no split, three LDS stages; incl. the kernels that sum its fused BN statistics)",
-    "conv_h2d_dgrad": "conv_h2d_kernel<*,*,true> (data gradient with dy as fp16 pair planes from the batch norm's backward, same kernel)",
-    "conv_wgrad_h2d": "igemm_wgrad_h2d_kernel<*,*,*> (weight gradient with x AND dy as fp16 pair planes: both operands by LDS-DMA, transposing LDS reads, 128x256 tile; incl. the split-K reduction)",
+    "conv_h2d_fwd": "conv_h2d_kernel<4,false,false> (256-wide column tile; forward of the bottlenecks' convs whose input the batch norm wrote as fp16 pair planes: both operands by LDS-DMA, no split, three LDS stages; incl. the kernels that sum its fused BN statistics)",
+    "conv_h2d_fwd_narrow": "conv_h2d_kernel<{1,2},false,false> (the same kernel's 64- / 128-wide column tiles: <= 128 output channels)",
+    "conv_h2d_dgrad": "conv_h2d_kernel<4,false,true> (data gradient with dy as fp16 pair planes from the batch norm's backward: the forward kernel on the transposed weights, 256-wide column tile, stride 1)",
+    "conv_h2d_dgrad_narrow": "conv_h2d_kernel<{1,2},*,true> / <4,true,true> (the same kernel's 64- / 128-wide column tiles and its strided form)",
+    "conv_wgrad_h2d_narrow": "igemm_wgrad_h2d_kernel<2,*,*> (the same weight-gradient kernel on fewer than 256 (tap, channel) columns: 128x128 tile)",
+    "conv_wgrad_h2d": "igemm_wgrad_h2d_kernel<4,*,*> (weight gradient with x AND dy as fp16 pair planes: both operands by LDS-DMA, transposing LDS reads, 128x256 tile; incl. the split-K reduction)",
     "conv_h2p_fwd": "conv_h2p_kernel<false> (forward of the deep 3x3 layers: persistent, one wave per SIMD, 4-stage LDS ring, weights by LDS-DMA, fp16 pairs; incl. the kernels that sum its fused BN statistics)",
     "conv_h2p_dgrad": "conv_h2p_kernel<true> (data gradient of the deep 3x3 layers, same kernel)",
     "conv_x3_128x256": "igemm_conv_x3_kernel<2,4,2,2,false,false,2,true,true> (forward, fp16 pairs, 128x256 tile; incl. the two kernels that sum its fused BN statistics)",

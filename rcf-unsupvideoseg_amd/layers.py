@@ -100,8 +100,13 @@ BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (
 CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once per weight update, not per launch
 FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
 # fp32 step: the two sums of a batch norm's backward (sum g, sum g xhat) from the epilogue of the data gradient that writes the
-# norm's output gradient last (ops.conv2d_dgrad(bn_bwd=...)) instead of a pass over dy and x.  RCF_FUSE_BN_BWD=0: the pass.
-FUSE_BN_BWD = __import__("os").environ.get("RCF_FUSE_BN_BWD", "1") != "0"
+# norm's output gradient last (ops.conv2d_dgrad(bn_bwd=...)) instead of a pass over dy and x: 57 -> 6 reduction passes per step,
+# gradients equal to 2e-6 (tests/test_planes_gpu.py).  OFF by default because it does not pay: measured in one process
+# (tools/ab_schedule.py fp32 bnsums, profiles/r04_ab_bn_bwd_sums.txt) 108.27 vs 108.36 ms on one stream, 107.03 vs 106.50 ms with
+# the default two-stream schedule -- the pass reads a gradient the data gradient has just left in the Infinity Cache and, in the
+# default schedule, runs beside the previous layer's weight gradient anyway; the epilogue's reads of x are exposed at the end
+# of every tile of a power-limited kernel.  RCF_FUSE_BN_BWD=1 turns it on.
+FUSE_BN_BWD = __import__("os").environ.get("RCF_FUSE_BN_BWD", "0") == "1"
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
 # test hook (tests/test_model_gpu.py::test_train_step_all_grads_at_fixed_relu_pattern): a list that receives, in forward

@@ -328,7 +328,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     s.y_pitch = pitch_of(out)
     end = None
     if PROFILE.which is not None:       # forward launches of the 128x256-tile kernel instance / of the narrower tiles
-        end = PROFILE.bracket("conv_h2d_fwd" if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+        end = PROFILE.bracket(("conv_h2d_fwd" if s.Cout > 128 else "conv_h2d_fwd_narrow") if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_fwd_region_f32", _p(x), _p(weight_rsck(w)), _p(bias), _p(out), byref(s), _region(region), act,
          slope, beta, _stream())
@@ -364,7 +364,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
     ws = workspace(need, x.device)
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_h2d_fwd" if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
+        end = PROFILE.bracket(("conv_h2d_fwd" if s.Cout > 128 else "conv_h2d_fwd_narrow") if x_planes else "conv_x3_128x256" if s.Cout > 128 else "conv_fwd_narrow",
                               2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin, _shape_tag(s))
     if bn is not None:
         count = s.N * s.Ho * s.Wo
@@ -405,7 +405,8 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     ws = workspace(need, dy.device) if need else None
     end = None
     if PROFILE.which is not None:
-        end = PROFILE.bracket("conv_h2d_dgrad" if dy_planes else "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
+        end = PROFILE.bracket(("conv_h2d_dgrad" if (s.Cin > 128 and stride == 1) else "conv_h2d_dgrad_narrow") if dy_planes else
+                              "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
                               2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
     sums2 = None
     if fuse:
@@ -440,7 +441,7 @@ def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None,
     if PROFILE.which is not None:
         ktot = s.R * s.S * s.Cin                                   # plan_wgrad (csrc/igemm_conv.hip): the 128 x 256 fp16-pair tile
         wide = amax is not None and s.Cin % 64 == 0 and ktot >= 256 and s.Cout >= 64
-        end = PROFILE.bracket("conv_wgrad_h2d" if planes else ("conv_wgrad_h2t4" if wide else "conv_wgrad_other"),
+        end = PROFILE.bracket(("conv_wgrad_h2d" if ktot >= 256 else "conv_wgrad_h2d_narrow") if planes else ("conv_wgrad_h2t4" if wide else "conv_wgrad_other"),
                               2.0 * s.N * _region_pixels(region, s.Ho, s.Wo) * s.Cout * s.R * s.S * s.Cin, _shape_tag(s, region))
     call("rcf_conv2d_wgrad_region_f32", _p(x), _p(dy), _p(weight_rsck(dw)), byref(s), reg, beta, _p(ws), need, _stream())
     if end is not None:

@@ -34,7 +34,7 @@ def main():
     for _ in range(4):
         tr.step(batch)
     ab = len(sys.argv) > 3 and sys.argv[3] == "ab"
-    fams = ["conv_h2d_fwd", "conv_h2d_dgrad", "conv_wgrad_h2d", "conv_h2p_fwd", "conv_h2p_dgrad", "conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
+    fams = ["conv_h2d_fwd", "conv_h2d_fwd_narrow", "conv_h2d_dgrad", "conv_h2d_dgrad_narrow", "conv_wgrad_h2d", "conv_wgrad_h2d_narrow", "conv_h2p_fwd", "conv_h2p_dgrad", "conv_x3_128x256", "conv_fwd_narrow", "conv_dgrad_wide", "conv_dgrad_other", "conv_wgrad_h2t4", "conv_wgrad_other",
             "conv_bf16_fwd", "conv_bf16_fwd_narrow", "conv_bf16_dgrad_wide", "conv_bf16_dgrad_other", "conv_bf16_wgrad4",
             "conv_bf16_wgrad_other"]
     peak = 2500.0 if prec == "bf16" else 2500.0 / 3
