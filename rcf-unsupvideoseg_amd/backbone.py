@@ -9,7 +9,7 @@ Only the options the RCF configs use are implemented; anything else raises.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import layers, ops
 from .layers import (Act, BatchNorm2d, Conv2d, commuted_concat_conv, commuted_concat_conv_ok, concat_channels,
                      maxpool3x3s2)
 
@@ -50,7 +50,8 @@ class Bottleneck(nn.Module):
 
     def takes_planes(self):
         """do this block's first convs read their input as fp16 pair planes when the producer supplies them?"""
-        return self.conv1.planes_ok() and (self.downsample is None or getattr(self.downsample, "0").planes_ok())
+        ok = self.conv1.planes_ok() and (self.downsample is None or getattr(self.downsample, "0").planes_ok())
+        return ok and (layers.JOIN_PLANES == "all" or self.downsample is not None)
 
     def fwd(self, x, tape, dist, emit_planes=False):
         """emit_planes: the block's output is ALSO written as fp16 pair planes (the next block's conv1 / downsample read them).

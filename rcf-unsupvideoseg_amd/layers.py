@@ -119,6 +119,12 @@ FP16_PAIRS = True
 # igemm_h2dw.inc): no split, no LDS store in any of the three conv directions.  RCF_PLANES=0: every conv splits its fp32 operands
 # in registers as before.
 PLANES = __import__("os").environ.get("RCF_PLANES", "1") != "0"
+# which bottleneck JOINS (relu(bn3 + identity): fp32 copy needed by the next residual add) are ALSO written as planes for the next
+# block's conv1 / downsample conv: "stage" = only in front of a stage's first block (its two convs read them; the wide downsample
+# conv gains 7-15 %), "all" = every join.  A join's planes cost 8 more bytes per element in an HBM-bound pass (0.05-0.17 ms per join)
+# while an identity block's 1x1 conv1 (short K, epilogue-bound) gains 0.02-0.13 ms from them: measured per layer in
+# profiles/r04_layers_planes_ab.txt, as a step in profiles/r04_ab_join_planes.txt.
+JOIN_PLANES = __import__("os").environ.get("RCF_JOIN_PLANES", "stage")
 _side_streams = {}
 
 
