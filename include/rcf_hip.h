@@ -209,6 +209,15 @@ int rcf_conv2d_dgrad_bnsums_ok(const rcf_conv_shape *s);
 size_t rcf_conv2d_dgrad_bnsums_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_dgrad_bnsums_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
                                 const rcf_bn_bwd_in *bn, double *sums2, void *workspace, size_t workspace_bytes, void *stream);
+/* The same launch with a masked addend: dx = conv_transpose(dy, w) + (add_mask ? add : 0), add [N*H*W][add_pitch], add_mask
+ * [N*H*W][Cin/4] (rcf_bn_apply_mp's sign bits) -- the conv1 of a bottleneck whose input also feeds the block's identity branch
+ * (models/resnet.py:268-302): the identity's gradient IS the join's output gradient under the join's ReLU mask, so the batch norm's
+ * backward need not write it (rcf_bn_bwd_apply_mp with dres = NULL: one tensor write less per identity block) and this launch need
+ * not read it back -- it reads the join's output gradient instead.  Bit-identical to dres + accumulate.  beta must be 0 with an
+ * addend; bn / sums2 / workspace as in rcf_conv2d_dgrad_bnsums_f32 or all NULL; same shapes (rcf_conv2d_dgrad_bnsums_ok). */
+int rcf_conv2d_dgrad_add_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta, const float *add,
+                             int add_pitch, const unsigned char *add_mask, const rcf_bn_bwd_in *bn, double *sums2,
+                             void *workspace, size_t workspace_bytes, void *stream);
 /* dw[Cout][R][S][Cin] (+)= sum_pixels dy * x.  Split over pixels into `workspace`, then reduced
  * deterministically (no float atomics). */
 size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s);
@@ -293,6 +302,11 @@ int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *x, int x_pi
  * activations.  The reference runs these layers under torch autocast (configs/rcf_stv2/rcf_stage1.yaml:57-60). */
 int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pitch, double *sums, void *workspace,
                     size_t workspace_bytes, void *stream);
+/* out (+)= relu_mask ? dy : 0 (bit e of byte [row][c/4] = channel 4 (c/4) + e was positive, as rcf_bn_apply_mp writes it): the
+ * gradient a join relu(bn3(x) + identity) passes to its identity branch (models/resnet.py:296-300), for callers that did not
+ * let rcf_bn_bwd_apply_mp write it (dres = NULL) and cannot take it as the addend of rcf_conv2d_dgrad_add_f32. */
+int rcf_relu_mask_copy_mp(const void *dy, int dt, int dy_pitch, const unsigned char *relu_mask, void *out, int out_pitch,
+                          long rows, int C, int beta, void *stream);
 /* `flags` of the three streaming passes (per call; 0 = the library's own choices):
  *   RCF_BN_SWEEP_OFF / RCF_BN_SWEEP_ALWAYS   row order (csrc/bn.hip struct Sweep): by default tensors of 192 MB and more are walked
  *       in eight bands (the conv kernels' XCD bands), the forward apply and the backward reduction downwards, the backward apply

@@ -98,6 +98,8 @@ PROTOS = {
     "rcf_conv2d_dgrad_bnsums_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_dgrad_bnsums_ok": (c_int, [_CS]),
     "rcf_conv2d_dgrad_bnsums_f32": (c_int, [P, P, P, _CS, c_int, ctypes.POINTER(BnBwdIn), P, P, c_size_t, P]),
+    "rcf_conv2d_dgrad_add_f32": (c_int, [P, P, P, _CS, c_int, P, c_int, P, ctypes.POINTER(BnBwdIn), P, P, c_size_t, P]),
+    "rcf_relu_mask_copy_mp": (c_int, [P, c_int, c_int, P, P, c_int, c_long, c_int, c_int, P]),
     "rcf_conv2d_fwd_stats_workspace_bytes": (c_size_t, [_CS]),
     "rcf_conv2d_fwd_stats_f32": (c_int, [P, P, P, _CS, P, P, c_size_t, P]),
     "rcf_conv_weight_pairs_t_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_uint, P]),

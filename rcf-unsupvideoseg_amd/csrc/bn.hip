@@ -365,6 +365,29 @@ __global__ void invstd_from_var_kernel(const float *__restrict__ var, int C, flo
 // registers: no reloads, no index divisions in the loop) and walks the rows with a grid stride, two rows in flight.
 // Thread layout: cvt = min(CV, 256) threads across the channels, 256 / cvt rows per block; layers wider than 256
 // vectors loop over channel chunks (grid.y).
+// out = mask ? dy : 0 -- the gradient a batch norm + ReLU join passes to its identity branch, materialised (the fallback of the
+// deferred form: csrc/igemm_conv.hip adds the masked tensor in the data gradient's epilogue instead, rcf_conv2d_dgrad_add_f32)
+template <typename T>
+__global__ void __launch_bounds__(256) relu_mask_copy_kernel(const T *__restrict__ dy, int dy_pitch, const unsigned char *__restrict__ mask,
+                                                             T *__restrict__ out, int out_pitch, long rows, int C, int beta) {
+    const int CV = C >> 2;
+    const long n = rows * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / CV;
+        const int c0 = (int)(i - r * CV) << 2;
+        fvec<4> g = ldv<T, 4>(dy + r * dy_pitch + c0);
+        const unsigned m = mask[r * CV + (c0 >> 2)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.q[0][e] = (m >> e) & 1u ? g.q[0][e] : 0.f;
+        if (beta) {
+            const fvec<4> o = ldv<T, 4>(out + r * out_pitch + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g.q[0][e] += o.q[0][e];
+        }
+        stv<T, 4>(out + r * out_pitch + c0, g);
+    }
+}
+
 struct EwGeom {
     int cvt, rpb;      // threads across channels, rows per block
     dim3 grid;
@@ -948,6 +971,21 @@ extern "C" int rcf_bn_bwd_apply_f32(const float *dy, int dy_pitch, const float *
     return rcf_bn_bwd_apply_mp(dy, RCF_F32, dy_pitch, x, RCF_F32, x_pitch, y, y_pitch, dx, dx_pitch, dres, dres_pitch,
                                res_beta, rows, C, mean, invstd, gamma, relu, relu_mask, chan_scale, rows_per_image, sums2,
                                sums2_local, count, dgamma, dbeta, amax_out, nullptr, nullptr, 0u, stream);
+}
+
+extern "C" int rcf_relu_mask_copy_mp(const void *dy, int dt, int dy_pitch, const unsigned char *relu_mask, void *out, int out_pitch,
+                                     long rows, int C, int beta, void *stream) {
+    if (!dy || !relu_mask || !out || rows <= 0 || C <= 0 || C % 4 || dy_pitch % 4 || out_pitch % 4 || dy_pitch < C || out_pitch < C)
+        return RCF_EINVAL;
+    const long n = rows * (C / 4);
+    const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+#define RCF_CALL(T)                                                                                                  \
+    hipLaunchKernelGGL((relu_mask_copy_kernel<T>), dim3(blocks), dim3(256), 0, rcf_stream(stream), (const T *)dy, dy_pitch, \
+                       relu_mask, (T *)out, out_pitch, rows, C, beta)
+    RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+    RCF_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch, float *out, int beta, void *workspace,

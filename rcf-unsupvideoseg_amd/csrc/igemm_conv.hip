@@ -90,6 +90,11 @@ struct IgemmParams {
     const unsigned char *bn_mask;
     const float *bn_mean, *bn_invstd;
     int bn_x_pitch;
+    // data gradient + masked addend (rcf_conv2d_dgrad_add_f32): Y = result + (mask ? add : 0); add [rows][add_pitch], mask
+    // [rows][Ncol / 4] -- the identity branch of a residual join, whose gradient is the join's output gradient under its ReLU mask
+    const float *add_src;
+    const unsigned char *add_mask;
+    int add_pitch;
 };
 
 // pixel `pix` (0 <= pix < rr) of a region -> image coordinates.  Rectangle: row-major.  Frame of thickness t: the top
@@ -594,13 +599,19 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
             // EXTRA 2 (data gradients): the value written is the gradient of a batch norm + ReLU's output -- mask it with the
             // norm's sign bits and add g and g * xhat per channel (what rcf_bn_bwd_reduce_mp would read the tensor back for)
             auto quads = [&](auto BETA_, auto EXTRA_) {
-                constexpr bool BETA = decltype(BETA_)::value;
+                constexpr int BETA = decltype(BETA_)::value;     // 0 overwrite, 1 accumulate into Y, 2 add the masked tensor p.add_src
                 constexpr int EXTRA = decltype(EXTRA_)::value;
                 const int cb = n0 + brow0 + 4 * kh + nr * 32;           // this lane's first channel of the column tile
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     if (!rowok[mr]) continue;
                     f32x4 *dst = reinterpret_cast<f32x4 *>(p.Y + lin[mr] * p.y_pitch + cb);
+                    const f32x4 *as = nullptr;
+                    const unsigned char *am = nullptr;
+                    if constexpr (BETA == 2) {
+                        as = reinterpret_cast<const f32x4 *>(p.add_src + lin[mr] * p.add_pitch + cb);
+                        am = p.add_mask + lin[mr] * (p.Ncol >> 2) + (cb >> 2);
+                    }
                     const f32x4 *xs = nullptr;
                     const unsigned char *ms = nullptr;
                     if constexpr (EXTRA == 2) {
@@ -611,7 +622,13 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
                         v = (v * inv_a) * inv_b;
-                        if (BETA) v += dst[2 * g];
+                        if constexpr (BETA == 1) v += dst[2 * g];
+                        if constexpr (BETA == 2) {
+                            const f32x4 a = as[2 * g];
+                            const unsigned m = am[2 * g];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (m >> e) & 1u ? a[e] : 0.f;   // = the value rcf_bn_bwd_apply_mp's dres would hold
+                        }
                         dst[2 * g] = v;
                         if constexpr (EXTRA == 1) {
 #pragma unroll
@@ -645,12 +662,16 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
+            const int bmode = (DGRAD && p.add_src) ? 2 : (p.beta ? 1 : 0);
             if constexpr (want_bstats) {
-                if (p.beta) quads(std::true_type{}, I2{}); else quads(std::false_type{}, I2{});
+                if (bmode == 2) quads(I2{}, I2{}); else if (bmode == 1) quads(I1{}, I2{}); else quads(I0{}, I2{});
+            } else if constexpr (DGRAD) {
+                if (bmode == 2) { if (extra) quads(I2{}, I1{}); else quads(I2{}, I0{}); }
+                else if (bmode == 1) { if (extra) quads(I1{}, I1{}); else quads(I1{}, I0{}); }
+                else { if (extra) quads(I0{}, I1{}); else quads(I0{}, I0{}); }
             } else {
-                (void)sizeof(I2);
-                if (p.beta) { if (extra) quads(std::true_type{}, I1{}); else quads(std::true_type{}, I0{}); }
-                else { if (extra) quads(std::false_type{}, I1{}); else quads(std::false_type{}, I0{}); }
+                if (p.beta) { if (extra) quads(I1{}, I1{}); else quads(I1{}, I0{}); }
+                else { if (extra) quads(I0{}, I1{}); else quads(I0{}, I0{}); }
             }
         } else {
 #pragma unroll
@@ -2331,7 +2352,8 @@ extern "C" int rcf_conv2d_fwd_f32(const float *x, const float *w, const float *b
 namespace {
 int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
                       void *workspace, size_t workspace_bytes, void *stream, int *kernel_only, const rcf_bn_bwd_in *bn = nullptr,
-                      double *stats = nullptr, int *mtiles_out = nullptr);
+                      double *stats = nullptr, int *mtiles_out = nullptr, const float *add = nullptr, int add_pitch = 0,
+                      const unsigned char *add_mask = nullptr);
 // forward launch; kernel_only: report the kernel the call would take instead (rcf_conv_kernel_of)
 int conv2d_fwd_impl(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s,
                     const rcf_conv_region *region, int act, float slope, int beta, double *stats, void *stream, int *kernel_only,
@@ -2543,12 +2565,22 @@ extern "C" int rcf_conv2d_dgrad_bnsums_ok(const rcf_conv_shape *s) {
 extern "C" int rcf_conv2d_dgrad_bnsums_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta,
                                            const rcf_bn_bwd_in *bn, double *sums2, void *workspace, size_t workspace_bytes,
                                            void *stream) {
+    return rcf_conv2d_dgrad_add_f32(dy, w, dx, s, beta, nullptr, 0, nullptr, bn, sums2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rcf_conv2d_dgrad_add_f32(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta, const float *add,
+                                        int add_pitch, const unsigned char *add_mask, const rcf_bn_bwd_in *bn, double *sums2,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
-    if (!dy || !w || !dx || !bn || !sums2 || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    if (!dy || !w || !dx || (!bn && !add) || (bn && !sums2) || (add && beta) || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx))
+        return RCF_EINVAL;
     if (!rcf_conv2d_dgrad_bnsums_ok(s)) return RCF_EINVAL;
-    if (!workspace || workspace_bytes < rcf_conv2d_dgrad_bnsums_workspace_bytes(s) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
+    if (bn && (!workspace || workspace_bytes < rcf_conv2d_dgrad_bnsums_workspace_bytes(s) || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;
     int mtiles = 0;
-    if (int e = conv2d_dgrad_impl(dy, w, dx, s, nullptr, beta, nullptr, 0, stream, nullptr, bn, (double *)workspace, &mtiles)) return e;
+    if (int e = conv2d_dgrad_impl(dy, w, dx, s, nullptr, beta, nullptr, 0, stream, nullptr, bn, bn ? (double *)workspace : nullptr, &mtiles,
+                                  add, add_pitch, add_mask))
+        return e;
+    if (!bn) return 0;
     return rcf_sum_partials_f64((const double *)workspace, mtiles, 2 * s->Cin, sums2, (double *)workspace + (size_t)mtiles * 2 * s->Cin,
                                 stream);
 }
@@ -2556,10 +2588,20 @@ extern "C" int rcf_conv2d_dgrad_bnsums_f32(const float *dy, const float *w, floa
 namespace {
 int conv2d_dgrad_impl(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, const rcf_conv_region *region, int beta,
                       void *workspace, size_t workspace_bytes, void *stream, int *kernel_only, const rcf_bn_bwd_in *bn, double *stats,
-                      int *mtiles_out) {
+                      int *mtiles_out, const float *add, int add_pitch, const unsigned char *add_mask) {
     if (s->Cout % 4) return RCF_EINVAL;
     IgemmParams p{};
     p.flags = s->flags;
+    if (add) {
+        // the masked addend lives in the lean epilogue of the fp16-pair kernels, like the batch-norm sums below: same conditions
+        const int bnw = s->Cin > 128 ? 256 : (s->Cin > 64 ? 128 : 64);
+        const void *wpt = s->w_pairs2_t ? s->w_pairs2_t : s->w_pairs_t;
+        if (!use_x3(s->flags) || region || beta || s->Cin % bnw || !wpt || !s->amax_dy || !s->amax_w || !add_mask || add_pitch % 4 ||
+            add_pitch < s->Cin || !rcf_aligned16(add))
+            return RCF_EINVAL;
+        p.flags |= RCF_CONV_H2P_NEVER;
+        p.add_src = add; p.add_pitch = add_pitch; p.add_mask = add_mask;
+    }
     if (bn) {
         // the batch-norm sums come out of the lean epilogue of the 128-row fp16-pair kernels: whole column tiles, the whole tensor,
         // weights prepared by the caller (the workspace holds the partial sums), not the persistent kernel (its own epilogue)

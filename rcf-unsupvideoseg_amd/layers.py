@@ -36,7 +36,7 @@ def _round_up(n, m):
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
-                 "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2")
+                 "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -54,6 +54,10 @@ class Act:
         # the forward pass writes t's gradient LAST in the backward pass and can then deliver the norm's backward sums from its
         # data gradient's epilogue (`grad_sums2`; any later writer of `grad` -- there should be none -- voids them in grad_slot)
         self.bn_ctx = self.first_reader = self.grad_sums2 = None
+        # deferred residual gradient (DEFER_RESIDUAL): a join relu(bn3 + identity) leaves (its output gradient, its sign bits) here
+        # instead of writing the identity's gradient; the conv that read t first (`addend_ok`: its data gradient can take a masked
+        # addend) adds it in its epilogue.  Anybody else who wants `grad` gets it materialised (relu_mask_copy).
+        self.pending_add, self.addend_ok = None, False
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -61,8 +65,20 @@ class Act:
             self.amax = ops.absmax(self.t)
         return self.amax
 
-    def grad_slot(self):
-        """(tensor, beta) for the next gradient producer."""
+    def _materialize_pending(self):
+        dy, mask = self.pending_add
+        self.pending_add = None
+        if self.grad is None:
+            self.grad = ops.relu_mask_copy(dy, mask)
+        else:
+            ops.relu_mask_copy(dy, mask, out=self.grad, beta=1)
+        self.grad_amax = self.grad_sums2 = None
+
+    def grad_slot(self, takes_addend=False):
+        """(tensor, beta) for the next gradient producer.  takes_addend: the producer adds `pending_add` itself (it must take it
+        with `take_pending` when this returns beta 0)."""
+        if self.pending_add is not None and not (takes_addend and self.grad is None):
+            self._materialize_pending()
         if self.grad is None:
             self.grad = torch.empty(tuple(self.t.shape), dtype=self.t.dtype, device=self.t.device)
             return self.grad, 0
@@ -70,13 +86,21 @@ class Act:
         self.grad_sums2 = None       # ... nor are sums taken over an earlier state of the gradient the sums of the final one
         return self.grad, 1
 
+    def take_pending(self):
+        p, self.pending_add = self.pending_add, None
+        return p
+
     def take_grad(self):
+        if self.pending_add is not None:
+            self._materialize_pending()
         g, self.grad = self.grad, None
         self.grad_is_planes = False
         return g
 
     def take_grad_range(self):
         """call before take_grad: max |grad| as a device scalar (from the producer when it left one)"""
+        if self.pending_add is not None:
+            self._materialize_pending()
         r, self.grad_amax = self.grad_amax, None
         return r if r is not None else ops.absmax(self.grad)
 
@@ -107,6 +131,10 @@ FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also fin
 # default schedule, runs beside the previous layer's weight gradient anyway; the epilogue's reads of x are exposed at the end
 # of every tile of a power-limited kernel.  RCF_FUSE_BN_BWD=1 turns it on.
 FUSE_BN_BWD = __import__("os").environ.get("RCF_FUSE_BN_BWD", "0") == "1"
+# fp32 step: a residual join does not WRITE the gradient of its identity branch (= its own output gradient under its ReLU mask);
+# the block's conv1 -- whose data gradient is the other, and last, writer of that tensor -- adds it in its epilogue from the join's
+# output gradient and sign bits (ops.conv2d_dgrad(addend=...)): one tensor write less per identity block, bit-identical.
+DEFER_RESIDUAL = __import__("os").environ.get("RCF_DEFER_RESIDUAL", "1") != "0"
 # training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
 RELU_BITMASK = True
 # test hook (tests/test_model_gpu.py::test_train_step_all_grads_at_fixed_relu_pattern): a list that receives, in forward
@@ -417,6 +445,9 @@ class Conv2d(nn.Module):
         tok = object()
         if x.first_reader is None:
             x.first_reader = tok                   # first reader in forward order = last writer of x's gradient in the backward pass
+            # ... and as such it can take the identity branch's deferred gradient as a masked addend (checked again at launch)
+            x.addend_ok = (DEFER_RESIDUAL and FP16_PAIRS and tape.enabled and out is None and w is self.weight and
+                           (self.cin in (64, 128) or self.cin % 256 == 0))
         yamax = None
         if FP16_PAIRS:
             own = w is self.weight                                       # padded copies are rebuilt per call: not cached
@@ -455,15 +486,19 @@ class Conv2d(nn.Module):
                 done_dgrad = [False]
 
                 def late_dgrad():
-                    gx, beta = x.grad_slot()
                     wpt = None
                     if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
                         wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
+                    can_add = (x.pending_add is not None and x.first_reader is tok and wpt is not None and
+                               ops.dgrad_takes_addend(w, x.t.shape, self.stride, self.padding, self.dilation, ops.pitch_of(dy),
+                                                      (ady, aw), wpt, dpl))
+                    gx, beta = x.grad_slot(takes_addend=can_add)
+                    add = x.take_pending() if (can_add and beta == 0) else None
                     # the range of dx comes out of the epilogue (after the accumulation when beta = 1): exact for the whole tensor
                     gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None else None
                     bnb = x.bn_ctx if (FUSE_BN_BWD and wpt is not None and x.first_reader is tok) else None
                     r = ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                         amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax, bn_bwd=bnb)
+                                         amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax, bn_bwd=bnb, addend=add)
                     x.grad_amax = gamax
                     if bnb is not None:
                         x.grad_sums2 = r[1]            # None when the launch had no such epilogue: the norm runs its reduction pass
@@ -599,7 +634,12 @@ class BatchNorm2d(nn.Module):
                     dist.allreduce_sum(s2)
                 dres, rbeta = (None, 0)
                 if residual is not None and residual.needs_grad:
-                    dres, rbeta = residual.grad_slot()
+                    if (DEFER_RESIDUAL and relu and rmask is not None and chan_scale is None and residual.addend_ok and residual.grad is None
+                            and residual.pending_add is None and dy.dtype == torch.float32 and residual.t.dtype == torch.float32
+                            and dy.is_contiguous()):
+                        residual.pending_add = (dy, rmask)       # the identity's gradient = dy under this join's mask: not written here
+                    else:
+                        dres, rbeta = residual.grad_slot()
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
                 gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS and xt.dtype == torch.float32 else None
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,

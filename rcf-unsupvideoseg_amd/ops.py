@@ -381,13 +381,14 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
 
 
 def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region=None, amax=None, w_pairs_t=None,
-                 dy_planes=False, amax_y=None, bn_bwd=None):
+                 dy_planes=False, amax_y=None, bn_bwd=None, addend=None):
     """region = (y0, x0, h, w) in INPUT coordinates: only those pixels of dx are written.  amax = (amax_dy, amax_w);
     w_pairs_t = weight_pairs_t(w, amax_w), prepared once per weight update.  dy_planes: `dy` holds fp16 pair planes
     (RCF_CONV_DY_PLANES: bn_bwd_apply's dx); amax_y: new_amax() slot for the range of dx (after the accumulation).
     bn_bwd = (x_bn, relu_mask, mean, invstd) of the batch norm + ReLU whose OUTPUT is this conv's input, given when this call is the
     last writer of dx: returns (dx, sums2) with the norm's backward sums from the kernel's epilogue (rcf_conv2d_dgrad_bnsums_f32),
-    or (dx, None) when the launch this shape takes has no such epilogue -- the caller then runs bn_bwd_reduce"""
+    or (dx, None) when the launch this shape takes has no such epilogue -- the caller then runs bn_bwd_reduce.
+    addend = (t, relu_mask): dx = data gradient + (relu_mask ? t : 0) (rcf_conv2d_dgrad_add_f32; needs dgrad_takes_addend(...), beta 0)"""
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
@@ -399,6 +400,10 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     fuse = (bn_bwd is not None and region is None and out.is_contiguous() and bn_bwd[0].dtype == torch.float32 and
             tuple(bn_bwd[0].shape) == tuple(out.shape) and _lib.load().rcf_conv2d_dgrad_bnsums_ok(byref(s)) == 1)
+    if addend is not None:
+        assert beta == 0 and region is None and tuple(addend[0].shape) == tuple(out.shape) and addend[0].dtype == torch.float32
+        if _lib.load().rcf_conv2d_dgrad_bnsums_ok(byref(s)) != 1:
+            raise _lib.RcfHipError("this data gradient cannot take a masked addend (ask ops.dgrad_takes_addend first)")
     need = 0 if w_pairs_t is not None else _lib.load().rcf_conv2d_dgrad_workspace_bytes(byref(s))
     if fuse:
         need = _lib.load().rcf_conv2d_dgrad_bnsums_workspace_bytes(byref(s))
@@ -409,19 +414,42 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
                               "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other",
                               2.0 * s.N * _region_pixels(region, s.H, s.W) * s.Cin * s.R * s.S * s.Cout, _shape_tag(s, region))
     sums2 = None
-    if fuse:
-        xb, mask, mean, invstd = bn_bwd
-        sums2 = torch.empty(2 * s.Cin, dtype=torch.float64, device=dy.device)
-        bn = _lib.BnBwdIn(xb.data_ptr(), pitch_of(xb), mask.data_ptr(), mean.data_ptr(), invstd.data_ptr())
-        call("rcf_conv2d_dgrad_bnsums_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, byref(bn), _p(sums2), _p(ws), need, _stream())
+    if fuse or addend is not None:
+        bn = None
+        if fuse:
+            xb, mask, mean, invstd = bn_bwd
+            sums2 = torch.empty(2 * s.Cin, dtype=torch.float64, device=dy.device)
+            bn = byref(_lib.BnBwdIn(xb.data_ptr(), pitch_of(xb), mask.data_ptr(), mean.data_ptr(), invstd.data_ptr()))
+        ad, am = addend if addend is not None else (None, None)
+        call("rcf_conv2d_dgrad_add_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), beta, _p(ad), pitch_of(ad) if ad is not None else 0,
+             _p(am), bn, _p(sums2), _p(ws) if fuse else None, need if fuse else 0, _stream())
     else:
         call("rcf_conv2d_dgrad_region_f32", _p(dy), _p(weight_rsck(w)), _p(out), byref(s), _region(region), beta, _p(ws),
              need, _stream())
     if end is not None:
         end.record()
-        if not dy_planes and not fuse:
+        if not dy_planes and not fuse and addend is None:
             _relabel_conv(s, _region(region), 1, "conv_dgrad_wide" if (s.Cin > 128 and stride == 1) else "conv_dgrad_other", "conv_h2p_dgrad")
     return (out, sums2) if bn_bwd is not None else out
+
+
+def dgrad_takes_addend(w, xshape, stride, pad, dil, dy_pitch, amax, w_pairs_t, dy_planes):
+    """can conv2d_dgrad(addend=...) run for this launch?  (rcf_conv2d_dgrad_bnsums_ok: fp16-pair kernels with prepared weights, Cin
+    a whole column tile)"""
+    if amax is None or amax[0] is None or amax[1] is None or w_pairs_t is None or "d" not in H2_KINDS:
+        return False
+    s = _conv_shape(xshape, xshape[3], w, stride, pad, dil, dy_pitch, amax=(None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
+                    flags=_lib.CONV_DY_PLANES if dy_planes else 0)
+    return _lib.load().rcf_conv2d_dgrad_bnsums_ok(byref(s)) == 1
+
+
+def relu_mask_copy(dy, relu_mask, out=None, beta=0):
+    """out (+)= relu_mask ? dy : 0 (rcf_relu_mask_copy_mp)"""
+    _need_cuda(dy)
+    if out is None:
+        out = torch.empty(tuple(dy.shape), dtype=dy.dtype, device=dy.device)
+    call("rcf_relu_mask_copy_mp", _p(dy), _dt(dy), pitch_of(dy), _p(relu_mask), _p(out), pitch_of(out), _rows(dy), dy.shape[3], int(beta), _stream())
+    return out
 
 
 def conv2d_wgrad(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None, amax=None, small_tile=False, planes=False):

@@ -327,3 +327,103 @@ def test_training_step_with_and_without_fused_bn_backward_sums(report):
            f"worst parameter-gradient difference {worst[0]:.1e} ({worst[1]})")
     assert res[False][2] >= 55 and res[True][2] <= 12
     assert worst[0] < 1e-4
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, k, H, W    (conv1 of an identity bottleneck: 1x1, Cin = the join's channels)
+    (2, 1024, 256, 1, 33, 41),
+    (2, 256, 64, 1, 30, 53),
+    (1, 128, 128, 3, 20, 31),
+    (2, 64, 64, 1, 16, 24),
+])
+def test_data_gradient_with_masked_addend(case, report):
+    """rcf_conv2d_dgrad_add_f32: dx = data gradient + (mask ? add : 0) in one launch -- BIT-identical to writing the masked tensor
+    (rcf_relu_mask_copy_mp, what rcf_bn_bwd_apply_mp's dres holds) and accumulating the data gradient onto it; register-split and
+    pair-plane operand; with the batch-norm backward sums riding along."""
+    N, Cin, Cout, k, H, W = case
+    g = torch.Generator().manual_seed(41 + sum((i + 1) * v for i, v in enumerate(case)))
+    pad = k // 2
+    xbn = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    mean, invstd = ops.bn_finalize(ops.bn_stats(xbn), N * H * W, 1e-5, 0.1)
+    rm_in = torch.empty(xbn.numel() // 4, dtype=torch.uint8, device=DEV)
+    ops.bn_apply(xbn, mean, invstd, torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV), True, relu_mask=rm_in)
+    wg = cl_weight(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(DEV)
+    add = torch.randn(N, H, W, Cin, generator=g).to(DEV)                                   # the join's output gradient
+    jmask = torch.randint(0, 16, (N * H * W * Cin // 4,), generator=g, dtype=torch.uint8).to(DEV)   # the join's sign bits
+    aw, ag = ops.absmax(ops.weight_rsck(wg)), ops.absmax(dy)
+    wpt = ops.weight_pairs_t(wg, aw)
+    dyp, _ = to_planes(dy, loose(ag, 2.3))
+    bits = torch.stack([(jmask >> e) & 1 for e in range(4)], dim=1).reshape(N, H, W, Cin).bool()
+    masked = ops.relu_mask_copy(add, jmask)
+    assert torch.equal(masked, torch.where(bits, add, torch.zeros_like(add)))
+    acc = masked.clone()
+    ops.relu_mask_copy(add, jmask, out=acc, beta=1)
+    assert torch.equal(acc, masked + masked)
+    for planes in (False, True):
+        src, bound = (dyp, loose(ag, 2.3)) if planes else (dy, ag)
+        assert ops.dgrad_takes_addend(wg, xbn.shape, 1, pad, 1, Cout, (bound, aw), wpt, planes)
+        ref = masked.clone()
+        ops.conv2d_dgrad(src, wg, xbn.shape, 1, pad, 1, out=ref, beta=1, amax=(bound, aw), w_pairs_t=wpt, dy_planes=planes)
+        rng = ops.new_amax(DEV)
+        got = ops.conv2d_dgrad(src, wg, xbn.shape, 1, pad, 1, amax=(bound, aw), w_pairs_t=wpt, dy_planes=planes, amax_y=rng, addend=(add, jmask))
+        assert torch.equal(got, ref) and int(rng) == int(ops.absmax(ref))
+        s_ref = ops.bn_bwd_reduce(ref, xbn, None, mean, invstd, True, relu_mask=rm_in)
+        got2, s2 = ops.conv2d_dgrad(src, wg, xbn.shape, 1, pad, 1, amax=(bound, aw), w_pairs_t=wpt, dy_planes=planes, addend=(add, jmask),
+                                    bn_bwd=(xbn, rm_in, mean, invstd))
+        assert torch.equal(got2, ref) and s2 is not None
+        scale = s_ref.abs().reshape(2, Cin).max(dim=1).values.repeat_interleave(Cin)
+        assert float(((s2 - s_ref).abs() / scale).max()) < 2e-6
+    report(f"data gradient + masked addend {case}: bit-identical to mask copy + accumulate (register split and pair planes), sums ride along")
+
+
+def test_training_step_with_and_without_deferred_residual_gradient(report):
+    """the same step with the identity branches' gradients added in conv1's data-gradient epilogue (default) and written by the
+    join's batch-norm backward (RCF_DEFER_RESIDUAL=0): every parameter gradient BIT-identical; how many joins defer"""
+    import copy
+    import types
+    from rcf_amd import config, layers, synth
+    H, W, B = 96, 160, 2
+    res = {}
+    saved = layers.DEFER_RESIDUAL
+    try:
+        for on in (True, False):
+            layers.DEFER_RESIDUAL = on
+            kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+            kw.update(log_interval=10 ** 9, train_iter=1)
+            args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
+            m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+            m.to(DEV).train()
+            nb = synth.make_batch(B, H, W, config_id=1)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+            batch = {"imgs": [t(a) for a in nb["imgs"]], "gt_fw_flows": [t(a) for a in nb["gt_fw_flows"]],
+                     "gt_bw_flows": [t(a) for a in nb["gt_bw_flows"]], "seq_ids": nb["seq_ids"], "seq_names": nb["seq_names"],
+                     "paths": nb["paths"]}
+            calls = {"add": 0, "copy": 0}
+            o_d, o_c = ops.conv2d_dgrad, ops.relu_mask_copy
+
+            def dgrad(*a, **k):
+                calls["add"] += k.get("addend") is not None
+                return o_d(*a, **k)
+
+            def mcopy(*a, **k):
+                calls["copy"] += 1
+                return o_c(*a, **k)
+            ops.conv2d_dgrad, ops.relu_mask_copy = dgrad, mcopy
+            try:
+                losses = m(batch)
+                losses["loss"].backward()
+            finally:
+                ops.conv2d_dgrad, ops.relu_mask_copy = o_d, o_c
+            res[on] = ({k: float(v) for k, v in losses.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                       dict(calls))
+    finally:
+        layers.DEFER_RESIDUAL = saved
+    assert res[True][0] == res[False][0]
+    diff = [n for n, g in res[False][1].items() if not torch.equal(g, res[True][1][n])]
+    report(f"training step, deferred residual gradients: {res[True][2]['add']} of 16 joins add in conv1's epilogue "
+           f"({res[True][2]['copy']} materialised), {len(diff)} parameter gradients differ")
+    assert res[True][2]["add"] == 12 and res[True][2]["copy"] == 0 and res[False][2]["add"] == 0
+    assert not diff, diff[:5]

@@ -1,7 +1,7 @@
 """A/B of the training step's schedule and operand format in ONE process (boxes differ by more than the effects): the weight
 gradients on the main stream / on a second stream beside the layer's data gradient / started after it (layers.LATE_WGRAD), with
 the fp16 pair planes (layers.PLANES) on and off.  Interleaved rounds, median of 3 x 6 steps.
-usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins]   (joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
+usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins|defer]   (defer: layers.DEFER_RESIDUAL on / off; joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
 backward sums from the data gradients' epilogues (layers.FUSE_BN_BWD) on and off)"""
 import os, sys, time, types
 import numpy as np
@@ -30,6 +30,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "bnsums":
     for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)):
         for fuse in (True, False):
             configs[f"{name}, bn sums {'from the dgrad epilogue' if fuse else 'by the reduction pass'}"] = (ov, late, prec == "fp32", fuse)
+if len(sys.argv) > 2 and sys.argv[2] == "defer":
+    # the identity branches' gradients added in conv1's data-gradient epilogue (layers.DEFER_RESIDUAL) or written by the join's
+    # batch-norm backward and accumulated onto
+    configs = {f"{name}, {'deferred residual gradients' if d else 'identity gradients written'}": (ov, late, prec == "fp32", layers.FUSE_BN_BWD, d)
+               for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)) for d in (True, False)}
 joins = len(sys.argv) > 2 and sys.argv[2] == "joins"
 if joins:
     # which tensors exist as planes beside their fp32 copy: the bottleneck joins (all / only in front of a stage's first block) and
@@ -45,6 +50,8 @@ for r in range(3):
         layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES, layers.FUSE_BN_BWD = ov, late, planes, fuse
         if joins:
             layers.JOIN_PLANES, model.backbone2.heads_take_planes = cfg[4], cfg[5]
+        elif len(cfg) == 5:
+            layers.DEFER_RESIDUAL = cfg[4]
         tr.step(batch)
         tr.step(batch)
         torch.cuda.synchronize()

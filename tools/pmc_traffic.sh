@@ -27,9 +27,9 @@ with open("$R/gpurun_out/pmc_hbm_traffic.txt", "w") as o:
         o.write(f"{k[:120]} | {n} | {f:.1f} | {w:.1f} | {(2*f+w)*1024/1e6:.1f}\n")
 out = {}
 # a family = every kernel whose name starts like the pattern (template variants of one kernel: 128 x 256 and 256 x 256 tiles)
-for fam, pat in (("conv_h2d_dgrad", "conv_h2d_kernel<4, false, true>"), ("conv_h2d_fwd", "conv_h2d_kernel<4, false, false>"),
-                 ("conv_wgrad_h2d", "igemm_wgrad_h2d_kernel<4, false"), ("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true>"),
-                 ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true>"),
+for fam, pat in (("conv_h2d_dgrad", "conv_h2d_kernel<4, false, true,"), ("conv_h2d_fwd", "conv_h2d_kernel<4, false, false,"),
+                 ("conv_wgrad_h2d", "igemm_wgrad_h2d_kernel<4, false"), ("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true,"),
+                 ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true,"),
                  ("conv_h2p_fwd", "conv_h2p_kernel<false>"), ("conv_h2p_dgrad", "conv_h2p_kernel<true>"),
                  ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
                  ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
