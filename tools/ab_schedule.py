@@ -44,7 +44,7 @@ if joins:
 for _ in range(4):
     tr.step(batch)
 res = {k: [] for k in configs}
-for r in range(3):
+for r in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for name, cfg in configs.items():
         ov, late, planes, fuse = cfg[:4]
         layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES, layers.FUSE_BN_BWD = ov, late, planes, fuse
