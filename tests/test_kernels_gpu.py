@@ -78,7 +78,7 @@ def test_conv_fwd_dgrad_wgrad(case, report):
 
 @pytest.mark.parametrize("xs,ws,gs,heavy", [(1.0, 1.0, 1.0, False), (1e-6, 30.0, 1e-9, False), (3e4, 1e-3, 1e5, False),
                                             (1.0, 1.0, 1e-7, True)])
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 9, 10)] + [(2, 256, 512, 3, 1, 1, 1, 24, 40, False, 0)])
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 6, 9, 10)] + [(2, 256, 512, 3, 1, 1, 1, 24, 40, False, 0)])
 def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
     """the fp16-pair kernels (operand ranges given: x*2^k = h + m in fp16, 3 partial products) against float64, over
     operand magnitudes from 1e-9 to 1e5 and a heavy-tailed gradient; the yardstick is torch's own fp32 conv error"""
