@@ -427,3 +427,35 @@ def test_training_step_with_and_without_deferred_residual_gradient(report):
            f"({res[True][2]['copy']} materialised), {len(diff)} parameter gradients differ")
     assert res[True][2]["add"] == 12 and res[True][2]["copy"] == 0 and res[False][2]["add"] == 0
     assert not diff, diff[:5]
+
+
+def test_deferred_residual_gradient_is_materialised_for_other_readers():
+    """Act.pending_add (a join's output gradient + sign bits left for conv1's data gradient) reaches every OTHER kind of reader as
+    the tensor the join would have written: take_grad, take_grad_range and a producer that does not take addends"""
+    from rcf_amd.layers import Act
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 2, 9, 13, 64
+    t = torch.randn(N, H, W, C, generator=g).to(DEV)
+    dy = torch.randn(N, H, W, C, generator=g).to(DEV)
+    mask = torch.randint(0, 16, (N * H * W * C // 4,), generator=g, dtype=torch.uint8).to(DEV)
+    bits = torch.stack([(mask >> e) & 1 for e in range(4)], dim=1).reshape(N, H, W, C).bool()
+    want = torch.where(bits, dy, torch.zeros_like(dy))
+    a = Act(t)
+    a.pending_add = (dy, mask)
+    assert torch.equal(a.take_grad(), want) and a.pending_add is None
+    a = Act(t)
+    a.pending_add = (dy, mask)
+    assert int(a.take_grad_range()) == int(ops.absmax(want)) and torch.equal(a.grad, want)
+    a = Act(t)
+    a.pending_add = (dy, mask)
+    buf, beta = a.grad_slot()                       # an ordinary producer: gets the materialised tensor to accumulate onto
+    assert beta == 1 and torch.equal(buf, want) and a.pending_add is None
+    a = Act(t)
+    a.pending_add = (dy, mask)
+    buf, beta = a.grad_slot(takes_addend=True)      # conv1's data gradient: first writer, takes the pair itself
+    assert beta == 0 and a.take_pending() == (dy, mask)
+    a = Act(t)
+    a.grad = want.clone()
+    a.pending_add = (dy, mask)
+    buf, beta = a.grad_slot(takes_addend=True)      # somebody wrote before: accumulate, the pending pair is folded in first
+    assert beta == 1 and torch.equal(buf, want + want) and a.pending_add is None
