@@ -453,7 +453,8 @@ def test_deferred_residual_gradient_is_materialised_for_other_readers():
     a = Act(t)
     a.pending_add = (dy, mask)
     buf, beta = a.grad_slot(takes_addend=True)      # conv1's data gradient: first writer, takes the pair itself
-    assert beta == 0 and a.take_pending() == (dy, mask)
+    pend = a.take_pending()
+    assert beta == 0 and pend[0] is dy and pend[1] is mask and a.pending_add is None
     a = Act(t)
     a.grad = want.clone()
     a.pending_add = (dy, mask)
