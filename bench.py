@@ -163,11 +163,12 @@ def main():
                          "frac": round(ach / peak, 4)}
         return out
 
-    # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel with the largest share of
-    # the step's kernel time -- since round 3 (lean epilogues, the deep 3x3 forward / data-gradient convs on the persistent
-    # kernel) that is the weight-gradient family again (igemm_wgrad_h2t_kernel<4,*,*,MR>, 256x256 / 128x256 tiles: 25.4 ms of
-    # a step's kernel time, profiles/r03_layers_final_fp32.txt; 128x256 data gradient 20.5, persistent forward 12.4)
-    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_h2d_dgrad")
+    # ---- headline: fp32 step (BASELINE configs[1]).  Bracketed in the timed region: the kernel instantiation with the largest
+    # share of the step's kernel time -- since round 4 (pair planes; join planes only in front of stage-first blocks) that is the
+    # 256-wide plane FORWARD kernel conv_h2d_kernel<4,false,false> (15.0-15.7 ms of a step, roofline_by_kernel_one_stream; the
+    # same kernel on the transposed weights = the data gradient 14.1-14.9, the plane weight gradient 13.4-14.1).  The forward pass
+    # has no second stream beside it, so its live bracket and its one-stream bracket measure the same thing.
+    fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_h2d_fwd")
     dt, loss_val, prof, by32, by32s = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
     value = frames / dt
@@ -191,7 +192,7 @@ def main():
     # ---- BASELINE configs[2]: the same step with bf16 activations / operands, fp32 master weights and gradients
     bf = None
     if not a.no_bf16:
-        fam16 = os.environ.get("RCF_BENCH_FAMILY_BF16", "conv_bf16_wgrad4")
+        fam16 = os.environ.get("RCF_BENCH_FAMILY_BF16", "conv_bf16_dgrad_wide")     # the largest share of the bf16 step (10.6 of 50.6 ms)
         dt16, loss16, prof16, by16, by16s = step_leg("bf16", fam16, a.steps, a.warmup)
         v16 = frames / dt16
         bf = {"workload": f"the same step in mixed precision (BASELINE configs[2]): bf16 activations and MFMA operands, fp32 "

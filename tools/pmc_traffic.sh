@@ -39,9 +39,8 @@ for fam, pat in (("conv_h2d_dgrad", "conv_h2d_kernel<4, false, true,"), ("conv_h
         bytes_ = sum((2 * f + w) * 1024 * n for _, n, f, w in sel)
         out[fam] = {"kernel": " + ".join(k for k, _, _, _ in sel), "launches": nn, "hbm_bytes_per_launch": bytes_ / nn}
         print(fam, nn, round(bytes_ / nn / 1e6, 1), "MB/launch")
-# bench.py reads the entry of the family its headline roofline brackets (fp32 leg: the plane data gradient; the 256-wide
-# instantiation stands for the family: its 128- / 64-wide launches are the bottlenecks' narrow layers)
-head = "conv_h2d_dgrad" if "conv_h2d_dgrad" in out else "conv_wgrad_h2t4"
+# bench.py reads the entry of the family its headline roofline brackets (fp32 leg: the 256-wide plane forward kernel)
+head = "conv_h2d_fwd" if "conv_h2d_fwd" in out else "conv_wgrad_h2t4"
 if head in out:
     d = dict(out[head], family=head, by_family=out,
              note="(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 1; "
