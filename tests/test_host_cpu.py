@@ -200,3 +200,27 @@ def test_weight_operand_cache_invalidation(monkeypatch):
     conv2.weight.data.mul_(3.0)
     with pytest.raises(ops._lib.RcfHipError):
         conv2._derived("amax", lambda: 1)
+
+
+def test_grad_sketch_estimates_vector_distance_and_matches_the_committed_fixture_format(golden_dir):
+    """synth.grad_sketch / sketch_error (the fingerprints behind test_fullsize_b8_gradients_vs_oracle): deterministic, linear,
+    an estimator of the relative vector distance good to ~10 % with a few hundred numbers, and the committed float64 fixture
+    carries one k-vector per parameter tensor of the model"""
+    import json
+    g = torch.Generator().manual_seed(0)
+    truth = {f"m.{i}.w": torch.randn(257, 33, generator=g, dtype=torch.float64) * (1 + i) for i in range(12)}
+    noisy = {k: v + 3e-3 * v.abs().mean() * torch.randn(v.shape, generator=g, dtype=torch.float64) for k, v in truth.items()}
+    st, sn = synth.grad_sketch(truth, k=32), synth.grad_sketch(noisy, k=32)
+    assert st == synth.grad_sketch({k: v.clone() for k, v in truth.items()}, k=32)                      # deterministic
+    both = synth.grad_sketch({k: truth[k] + noisy[k] for k in truth}, k=32)
+    assert all(abs(a + b - c) <= 1e-9 * (abs(a) + abs(b) + 1) for n in st for a, b, c in zip(st[n], sn[n], both[n]))   # linear
+    true_rel = (sum(float(((noisy[k] - truth[k]) ** 2).sum()) for k in truth) / sum(float((truth[k] ** 2).sum()) for k in truth)) ** 0.5
+    est = synth.sketch_error(sn, st, "m.")
+    assert abs(est / true_rel - 1) < 0.15, (est, true_rel)
+    assert synth.sketch_error(st, st) == 0.0 and synth.sketch_error(sn, st, "absent.") == 0.0
+    fx = json.load(open(os.path.join(golden_dir, "oracle_b8_selfdev.json")))
+    m = rcf_amd.RCFModel(types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False),
+                         **config.stage1_model_kwargs(config.mask_size_for(fx["H"], fx["W"]), dropout=0.0, affine=False, norm="BN"))
+    names = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert set(fx["sketch_f64"]) <= names and all(len(v) == fx["sketch_k"] for v in fx["sketch_f64"].values())
+    assert set(fx["vector_fp32_err"]) == set(fx["gradnorm_f64"]) == {n.split(".")[0] for n in fx["sketch_f64"]}
