@@ -655,6 +655,7 @@ class BatchNorm2d(nn.Module):
 def maxpool3x3s2(x, tape):
     y, am = ops.maxpool_fwd(x.t)
     ya = Act(y)
+    ya.amax = x.amax            # every output is one of the inputs: the input's range bounds the output (no pass over it)
 
     def bwd():
         dy = ya.take_grad()
