@@ -640,6 +640,10 @@ class BatchNorm2d(nn.Module):
                         residual.pending_add = (dy, rmask)       # the identity's gradient = dy under this join's mask: not written here
                     else:
                         dres, rbeta = residual.grad_slot()
+                        if rbeta == 0 and ady is not None and chan_scale is None:
+                            # first writer: what it writes is dy under the ReLU mask, so dy's range bounds it (saves the
+                            # downsample norms' backward a pass over their 4C-wide output gradient)
+                            residual.grad_amax = ady
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
                 gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS and xt.dtype == torch.float32 else None
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
