@@ -1,7 +1,7 @@
 """A/B of the training step's schedule and operand format in ONE process (boxes differ by more than the effects): the weight
 gradients on the main stream / on a second stream beside the layer's data gradient / started after it (layers.LATE_WGRAD), with
 the fp16 pair planes (layers.PLANES) on and off.  Interleaved rounds, median of 3 x 6 steps.
-usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins|defer]   (defer: layers.DEFER_RESIDUAL on / off; joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
+usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins|defer|prio]   (defer: layers.DEFER_RESIDUAL on / off; joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
 backward sums from the data gradients' epilogues (layers.FUSE_BN_BWD) on and off)"""
 import os, sys, time, types
 import numpy as np
@@ -35,6 +35,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "defer":
     # batch-norm backward and accumulated onto
     configs = {f"{name}, {'deferred residual gradients' if d else 'identity gradients written'}": (ov, late, prec == "fp32", layers.FUSE_BN_BWD, d)
                for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)) for d in (True, False)}
+prio = len(sys.argv) > 2 and sys.argv[2] == "prio"
+if prio:
+    # HIP priority of the second stream (the weight gradients): 0 = the default, 1 = low, -1 = high (layers._side_stream, RCF_SIDE_PRIORITY)
+    configs = {f"two streams, LATE, second stream priority {p}": (True, True, prec == "fp32", layers.FUSE_BN_BWD, p) for p in (0, 1, -1)}
 joins = len(sys.argv) > 2 and sys.argv[2] == "joins"
 if joins:
     # which tensors exist as planes beside their fp32 copy: the bottleneck joins (all / only in front of a stage's first block) and
@@ -48,7 +52,11 @@ for r in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for name, cfg in configs.items():
         ov, late, planes, fuse = cfg[:4]
         layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES, layers.FUSE_BN_BWD = ov, late, planes, fuse
-        if joins:
+        if prio:
+            torch.cuda.synchronize()
+            os.environ["RCF_SIDE_PRIORITY"] = str(cfg[4])
+            layers._side_streams.clear()
+        elif joins:
             layers.JOIN_PLANES, model.backbone2.heads_take_planes = cfg[4], cfg[5]
         elif len(cfg) == 5:
             layers.DEFER_RESIDUAL = cfg[4]
