@@ -92,6 +92,26 @@ static int conv_known_answer(void) {
     for (int i = 0; i < CO * R * R * CI; i++) badw += hdw[i] != rdw[i];
     printf("conv2d_dgrad: %d of %d differ; conv2d_wgrad: %d of %d differ\n", badx, H * W * CI, badw, CO * R * R * CI);
     if (badx || badw) return 13;
+    /* the identity gradient of a residual join, materialised: out = mask ? g : 0 (bit e of byte [row][c/4] = channel 4 (c/4) + e);
+     * here the "join" is the data gradient just computed and the mask takes every other channel */
+    {
+        unsigned char hm[H * W * CI / 4], *dm;
+        float *dout, hout[H * W * CI];
+        for (int i = 0; i < H * W * CI / 4; i++) hm[i] = 0x5;
+        CK(hipMalloc((void **)&dm, sizeof hm)); CK(hipMalloc((void **)&dout, sizeof hout));
+        CK(hipMemcpy(dm, hm, sizeof hm, hipMemcpyHostToDevice));
+        if (rcf_relu_mask_copy_mp(ddx, RCF_F32, CI, dm, dout, CI, H * W, CI, 0, NULL) != 0) return 15;
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hout, dout, sizeof hout, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < H * W * CI; i++) bad += hout[i] != ((i % 4) % 2 == 0 ? rdx[i] : 0.f);
+        printf("relu_mask_copy: %d of %d differ\n", bad, H * W * CI);
+        if (bad) return 15;
+        /* a 4-channel data gradient has no whole column tile: the fused forms say so and refuse BEFORE launching anything */
+        if (rcf_conv2d_dgrad_bnsums_ok(&s) != 0) return 16;
+        if (rcf_conv2d_dgrad_add_f32(dy, dw, ddx, &s, 0, dout, CI, dm, NULL, NULL, NULL, 0, NULL) != RCF_EINVAL) return 16;
+        hipFree(dm); hipFree(dout);
+    }
     /* error codes, not crashes */
     if (rcf_conv2d_fwd_f32(NULL, dw, db, dy, &s, 0, 0.f, 0, NULL) != RCF_EINVAL) return 14;
     s.Cin = 3;
