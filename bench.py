@@ -9,9 +9,12 @@ the reference architecture.  frames/s = 2 * pairs_per_gpu * n_gpus * steps / tim
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128x256 weight-gradient
-implicit GEMM): algorithmic FLOPs of its launches / their HIP-event durations measured live in the timed
-region; `cpu_baseline` times the oracle (CPU restatement of the reference) on a bounded sample.
+Rank 0's LAST stdout line is the contract line: one JSON object of at most CONTRACT_LINE_MAX bytes (asserted) with the
+contract keys only -- `roofline` for the kernel instantiation with the largest share of the step's kernel time (the 256-wide
+plane forward kernel conv_h2d_kernel<4,false,false>): algorithmic FLOPs of its launches / their HIP-event durations;
+`cpu_baseline` = the oracle (CPU restatement of the reference) timed on a bounded sample.  Everything else (per-kernel tables,
+the bf16 step's own roofline, CRF / warp / stage 2.1 / ViT / loader legs, prose) goes to `gpurun_out/bench_detail.json` and to
+an EARLIER stdout line that starts with "BENCH_DETAIL " (so that no parser mistakes it for the contract line).
 """
 import argparse
 import json
@@ -181,8 +184,8 @@ def main():
                       "fp16's range and split into 2 fp16 parts (22 significand bits), 3 partial products on fp16 MFMA, fp32 "
                       "accumulate (the m*m' term is dropped); error vs float64 at the level of torch's own fp32 conv, rms AND "
                       "max (tests/test_kernels_gpu.py::test_conv_fp16_pairs)",
-        "config": {"workload": f"RCF stage-1 ResNet50+FCN train step, {B} pairs/GPU of {H}x{W} RGB+flow, "
-                               f"mask {mask[0]}x{mask[1]}, fp32, SyncBN, Adam (BASELINE configs[1])",
+        "config": {"workload": f"RCF stage-1 ResNet50+FCN train step, {B} pairs/GPU {H}x{W} RGB+flow, fp32, SyncBN, Adam (configs[1])",
+                   "mask_size": list(mask),
                    "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}"},
         "loss": round(loss_val, 6),
         "step_tflops_per_gpu": round(value / world * GF_PER_FRAME / 1e3, 2),
@@ -304,10 +307,69 @@ def main():
                 out["loader_error"] = str(e)[:200]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W)
-        print(json.dumps(_finite(out)), flush=True)
+        emit(_finite(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+CONTRACT_LINE_MAX = 2048            # the driver keeps an 8 KB stdout tail; round 4's 20.7 KB line could not be parsed
+
+
+def _clip(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def contract_line(out):
+    """The driver's line: the contract keys of the full result `out`, short strings, no tables.  <= CONTRACT_LINE_MAX bytes."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if d is not None and k in d}
+    cfg = out.get("config", {})
+    line = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data"))
+    line["config"] = {"workload": _clip(cfg.get("workload", ""), 120), **pick(cfg, ("pairs_per_gpu", "global_pairs", "parallelism"))}
+    rl = out.get("roofline")
+    if rl:
+        line["roofline"] = {"kernel": _clip(str(rl.get("kernel", "")).split(" (")[0], 80),
+                            **pick(rl, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
+                                        "flops_per_launch"))}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {**pick(cb, ("value", "unit", "cores", "kind", "s_per_step", "timed_steps")),
+                                "sample": _clip(cb.get("sample", ""), 160)}
+    line.update(pick(out, ("bf16_frames_per_s", "bf16_ms_per_step")))
+    bf = out.get("bf16_step") or {}
+    if bf.get("roofline"):
+        line["bf16_kernel_frac"] = bf["roofline"].get("frac")
+    if "frac_of_bf16_mfma_roofline" in bf:
+        line["bf16_step_frac"] = bf["frac_of_bf16_mfma_roofline"]
+    for key, short in (("crf_ms_per_frame", "crf"), ("crf_ms_per_frame_noise", "crf_noise")):
+        c = out.get(key)
+        if isinstance(c, dict):
+            line[short + "_ms_per_frame"] = c.get("value")
+            line[short + "_frac"] = (c.get("roofline") or {}).get("frac")
+    if isinstance(out.get("warp_roofline"), dict):
+        line["warp_frac"] = out["warp_roofline"].get("frac")
+    if isinstance(out.get("stage2_step"), dict):
+        line["stage2_ms_per_step"] = out["stage2_step"].get("ms_per_step")
+    line["detail"] = "gpurun_out/bench_detail.json"
+    return line
+
+
+def emit(out):
+    """full result -> gpurun_out/bench_detail.json + an earlier, prefixed stdout line; the contract line LAST."""
+    full = json.dumps(out)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:                                        # a read-only tree must not cost the run its line
+        print(f"bench_detail.json not written: {e}", file=sys.stderr)
+    print("BENCH_DETAIL " + full, flush=True)
+    line = json.dumps(contract_line(out))
+    assert len(line) <= CONTRACT_LINE_MAX, f"contract line is {len(line)} bytes"
+    print(line, flush=True)
 
 
 def _free_port():
@@ -681,9 +743,8 @@ def cpu_baseline(H, W):
     return {"value": round(2.0 * pairs / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "cpu_model": model_name, "logical_cpus": logical, "physical_cores": physical,
             "s_per_step": round(dt, 2), "timed_steps": nsteps, "steps_s": [round(x, 2) for x in times],
-            "sample": f"{pairs} pairs ({2 * pairs} frames) {H}x{W} (BASELINE configs[0]), {nsteps} timed fwd+bwd+Adam step(s) of "
-                      f"oracle/rcf_torch.py, mean {dt:.1f} s, after one untimed warm-up step on the same batch size ({warm:.1f} s); "
-                      f"{cores} threads = all physical cores (BASELINE.md section 4)",
+            "sample": f"{pairs} pairs {H}x{W} (configs[0]), {nsteps} timed fwd+bwd+Adam steps of oracle/rcf_torch.py after 1 warm-up "
+                      f"({warm:.0f} s), {cores} threads = all physical cores",
             **crf, "crf_cores": 1, "crf_kind": "port (oracle/crf_ref.c, sequential C restatement of tools/torchCRF)",
             "data_transform_kind": "port (oracle/transforms_np.py: numpy restatement of dataset/transforms.py's per-sample pipeline, 1 core)"}
 

@@ -158,6 +158,41 @@ def test_bench_line_helpers():
     assert b.HBM_PEAK_GBS == 8000.0 and b.BF16_MFMA_PEAK_TF == 2500.0
 
 
+def test_bench_contract_line_is_short_and_complete(capsys, tmp_path, monkeypatch):
+    """The driver keeps an 8 KB tail of stdout and parses the LAST line: round 4's 20.7 KB line came back `parsed: null`.
+    The contract line built from a full round-4 result (the largest this repo has printed) must stay under 2 KB, carry every
+    contract key incl. `roofline` and `cpu_baseline`, and be the last thing `emit` prints."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rcf_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench_n1.json")))
+    assert len(json.dumps(full)) > 16000
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    b.emit(full)
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert lines[-2].startswith("BENCH_DETAIL ") and json.loads(lines[-2][len("BENCH_DETAIL "):]) == full
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json")) == full
+    assert len(lines[-1]) <= b.CONTRACT_LINE_MAX <= 2048
+    line = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "bf16_frames_per_s", "bf16_ms_per_step", "crf_ms_per_frame",
+              "crf_frac", "warp_frac"):
+        assert k in line, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and len(line["config"]["workload"]) <= 120 and len(line["roofline"]["kernel"]) <= 80
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    # a worst-case result (every string at its clip length) still fits
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 500
+    fat["roofline"]["kernel"] = "k" * 500
+    fat["cpu_baseline"]["sample"] = "s" * 500
+    assert len(json.dumps(b.contract_line(fat))) <= b.CONTRACT_LINE_MAX
+
+
 def test_weight_operand_cache_invalidation(monkeypatch):
     """operands derived from a conv weight are cached by (data_ptr, _version, epoch): an in-place write on the parameter
     bumps `_version`, a write through `.data` bumps nothing -- the library's own `.data` writers (copy_param_and_buffer,
