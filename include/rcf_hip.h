@@ -250,6 +250,63 @@ int rcf_conv2d_fwd_bf16(const void *x, const void *w_bf16, const float *bias, vo
 size_t rcf_conv2d_dgrad_bf16_workspace_bytes(const rcf_conv_shape *s);
 int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_conv_shape *s, const rcf_conv_region *region,
                           int beta, void *workspace, size_t workspace_bytes, void *stream);
+/* ---- 1x1 conv -> training-mode batch norm -> (+ residual) -> ReLU as ONE tile (csrc/foldbn.hip, csrc/igemm_bf16.hip) ----------
+ * Replaces, in the bf16 step, the bottleneck tail `out = conv3(out); out = norm3(out); out += identity; out = relu(out)`
+ * (models/resnet.py:281-296) and the 1x1 downsample conv -> norm (models/res_layer.py:53-63) WITHOUT the conv output or its
+ * gradient ever existing in memory.  A 1x1 conv is linear in its input, so the norm's statistics and both of its backward sums
+ * are functions of two small moments of the conv's INPUT x [rows][K]: the column sums A1 [K] (rcf_colsum_mp) and the Gram
+ * matrix S = x^T x [K][K] (rcf_conv2d_wgrad_bf16 with dy = x).  W [N][K] is the fp32 master weight; every routine rounds it to
+ * bf16 as the conv kernels do.
+ *   forward   rcf_fold_fwd_f32:       P = W S [N][K] (kept for the backward pass), sums = [sum z | sum z^2] (fp64 [2N]; SyncBN
+ *                                     all-reduces them like any other statistics) and / or the finalized norm
+ *             rcf_fold_finalize_f32:  mean, invstd, running statistics, num_batches_tracked as rcf_bn_finalize_f32, plus the
+ *                                     folded constants scale = gamma invstd, shift = beta - mean scale (after the all-reduce)
+ *             rcf_conv2d_fwd_affine_bf16:  y = [relu](conv(x, w) * scale[c] + shift[c] [+ residual]) (bf16; whole column tiles:
+ *                                     Cout % 64 == 0 and Cout in {64, 128} or Cout % 256 == 0; stride 1)
+ *   backward  g = dy under the ReLU mask + its column sums: rcf_relu_mask_colsum_bf16 (one pass, in place allowed), or
+ *             rcf_conv2d_dgrad_masked_bf16 when a data gradient is the LAST writer of dy: dx = mask_src > 0 ? dgrad (+ dx) : 0
+ *             with colsums [2 Cin] (sum | sum of squares) from its epilogue
+ *             G = g^T x [N][K]: rcf_conv2d_wgrad_bf16(x, g)
+ *             rcf_fold_bwd_sums_f32:     sums2 = [sum g | sum g zhat] (fp64 [2N]) from G, W, the column sums of g
+ *             rcf_fold_wg_bf16:          wg_t = the data gradient's weight operand (bf16, rcf_conv_weight_bf16 layout, transpose = 1) of
+ *                                     scale[c] W[c][k] -- forward constants only, so g Wg^T may run beside the G product
+ *             rcf_fold_bwd_prepare_f32:  dW += ..., dgamma += sums2_local[N + c], dbeta += sums2_local[c] (sums2_local NULL = sums2),
+ *                                     negT (bf16, transpose = 0 layout of the K -> K weight -T), c0 [K]
+ *             dx = rcf_conv2d_dgrad_bf16(g, w_pairs_t = wg_t) then rcf_conv2d_fwd_bf16(x, negT, bias = c0, beta = 1)
+ * N % 64 == 0 and K % 64 == 0. */
+typedef struct rcf_fold_finalize {
+    double count;                 /* rows the statistics cover */
+    float eps, momentum;
+    const float *gamma, *beta;    /* the norm's affine parameters [C] */
+    float *mean, *invstd;         /* out [C] */
+    float *scale, *shift;         /* out [C]: gamma invstd, beta - mean gamma invstd */
+    float *running_mean, *running_var;   /* may be NULL */
+    long long *num_batches_tracked;      /* may be NULL */
+} rcf_fold_finalize;
+size_t rcf_fold_fwd_scratch_bytes(int N, int K);
+/* A1: fp64 [K] (the first half of rcf_bn_stats_mp's sums of x).  fin != NULL: the statistics are local, the norm is finalized by
+ * the same launch (sums may be NULL); fin == NULL: sums only.  N % 64 == 0, K % 64 == 0. */
+int rcf_fold_fwd_f32(const float *S, const double *A1, const float *W, float *P, double *sums, const rcf_fold_finalize *fin,
+                     void *scratch, size_t scratch_bytes, int N, int K, void *stream);
+int rcf_fold_finalize_f32(const double *sums, int C, const rcf_fold_finalize *fin, void *stream);
+int rcf_conv2d_fwd_affine_bf16(const void *x, const void *w_bf16, const float *scale, const float *shift, const void *residual,
+                               int res_pitch, int relu, void *y, const rcf_conv_shape *s, void *stream);
+size_t rcf_relu_mask_colsum_bf16_workspace_bytes(long rows, int C);
+int rcf_relu_mask_colsum_bf16(const void *dy, int dy_pitch, const void *y, int y_pitch, void *g, int g_pitch, long rows, int C,
+                              double *colsums, void *workspace, size_t workspace_bytes, void *stream);
+size_t rcf_conv2d_dgrad_masked_bf16_workspace_bytes(const rcf_conv_shape *s);
+int rcf_conv2d_dgrad_masked_bf16(const void *dy, const void *w_t_bf16, void *dx, const rcf_conv_shape *s, int beta,
+                                 const void *mask_src, int mask_pitch, double *colsums, void *workspace, size_t workspace_bytes,
+                                 void *stream);
+int rcf_fold_bwd_sums_f32(const float *G, const float *W, const double *colsums, const float *mean, const float *invstd,
+                          double *sums2, int N, int K, void *stream);
+size_t rcf_fold_bwd_scratch_bytes(int N, int K);
+int rcf_fold_wg_bf16(const float *W, const float *scale, void *wg_t_bf16, int N, int K, void *stream);
+int rcf_fold_bwd_prepare_f32(const float *G, const float *P, const double *A1, const float *W, const double *sums2,
+                             const double *sums2_local, double count, const float *mean, const float *invstd, const float *gamma,
+                             float *dW, float *dgamma, float *dbeta, void *negT_bf16, float *c0, void *scratch,
+                             size_t scratch_bytes, int N, int K, void *stream);
+
 /* dw (fp32, [Cout][R][S][Cin]) (+)= sum over pixels of dy (bf16) * x (bf16); deterministic split-K through the workspace */
 size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region);
 int rcf_conv2d_wgrad_bf16(const void *x, const void *dy, float *dw, const rcf_conv_shape *s, const rcf_conv_region *region,

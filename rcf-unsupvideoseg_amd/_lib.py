@@ -49,6 +49,13 @@ class BnFinalize(ctypes.Structure):
                 ("running_var", ctypes.c_void_p), ("num_batches_tracked", ctypes.c_void_p)]
 
 
+class FoldFinalize(ctypes.Structure):
+    """struct rcf_fold_finalize of include/rcf_hip.h"""
+    _fields_ = [("count", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float)] + \
+               [(n, ctypes.c_void_p) for n in ("gamma", "beta", "mean", "invstd", "scale", "shift", "running_mean", "running_var",
+                                               "num_batches_tracked")]
+
+
 class ConvRegion(ctypes.Structure):
     """mirror of rcf_conv_region"""
     _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w", "band")]
@@ -189,6 +196,18 @@ PROTOS = {
     "rcf_conv2d_dgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_conv2d_wgrad_bf16_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
+    "rcf_fold_fwd_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "rcf_fold_fwd_f32": (c_int, [P, P, P, P, P, ctypes.POINTER(FoldFinalize), P, c_size_t, c_int, c_int, P]),
+    "rcf_fold_finalize_f32": (c_int, [P, c_int, ctypes.POINTER(FoldFinalize), P]),
+    "rcf_conv2d_fwd_affine_bf16": (c_int, [P, P, P, P, P, c_int, c_int, P, _CS, P]),
+    "rcf_relu_mask_colsum_bf16_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "rcf_relu_mask_colsum_bf16": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_size_t, P]),
+    "rcf_conv2d_dgrad_masked_bf16_workspace_bytes": (c_size_t, [_CS]),
+    "rcf_conv2d_dgrad_masked_bf16": (c_int, [P, P, P, _CS, c_int, P, c_int, P, P, c_size_t, P]),
+    "rcf_fold_bwd_sums_f32": (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
+    "rcf_fold_bwd_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "rcf_fold_wg_bf16": (c_int, [P, P, P, c_int, c_int, P]),
+    "rcf_fold_bwd_prepare_f32": (c_int, [P] * 6 + [c_double] + [P] * 9 + [c_size_t, c_int, c_int, P]),
     "rcf_eval_iou_counts_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     "rcf_aug_frames_u8": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     "rcf_aug_flows_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),

@@ -31,8 +31,10 @@ class Downsample(nn.Module):
         self.add_module("1", norm)
 
     def fwd(self, x, tape, dist):
-        return getattr(self, "1").fwd(getattr(self, "0").fwd(x, tape, stats=getattr(self, "1").stats_request(dist)), tape, relu=False,
-                                    dist=dist)
+        conv, norm = getattr(self, "0"), getattr(self, "1")
+        if layers.fold_ok(conv, norm, x):
+            return layers.conv_bn_fold(conv, norm, x, tape, relu=False, dist=dist)
+        return norm.fwd(conv.fwd(x, tape, stats=norm.stats_request(dist)), tape, relu=False, dist=dist)
 
 
 class Bottleneck(nn.Module):
@@ -48,9 +50,9 @@ class Bottleneck(nn.Module):
         self.bn3 = make_norm(norm_cfg, planes * 4)
         self.downsample = downsample
 
-    def takes_planes(self):
+    def takes_planes(self, act_dtype=torch.float32):
         """do this block's first convs read their input as fp16 pair planes when the producer supplies them?"""
-        ok = self.conv1.planes_ok() and (self.downsample is None or getattr(self.downsample, "0").planes_ok())
+        ok = self.conv1.planes_ok(act_dtype) and (self.downsample is None or getattr(self.downsample, "0").planes_ok(act_dtype))
         return ok and (layers.JOIN_PLANES == "all" or self.downsample is not None)
 
     def fwd(self, x, tape, dist, emit_planes=False):
@@ -66,14 +68,17 @@ class Bottleneck(nn.Module):
             if o1.stats is not None and ods.stats is not None:
                 dist.allreduce_sum_many([o1.stats, ods.stats])
                 o1.stats_global = ods.stats_global = True
-        o = self.bn1.fwd(o1, tape, relu=True, dist=dist, planes="only" if self.conv2.planes_ok() else None)
+        o = self.bn1.fwd(o1, tape, relu=True, dist=dist, planes="only" if self.conv2.planes_ok(tape.act_dtype) else None)
         o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist,
-                         planes="only" if self.conv3.planes_ok() else None)
-        o = self.conv3.fwd(o, tape, stats=self.bn3.stats_request(dist))
+                         planes="only" if self.conv3.planes_ok(tape.act_dtype) else None)
         if ods is not None:
             idt = getattr(self.downsample, "1").fwd(ods, tape, relu=False, dist=dist)
         else:
             idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
+        if layers.fold_ok(self.conv3, self.bn3, o, idt):
+            # bf16 step: conv3 -> bn3 -> + identity -> ReLU as one tile, conv3's output never written (layers.conv_bn_fold)
+            return layers.conv_bn_fold(self.conv3, self.bn3, o, tape, relu=True, residual=idt, dist=dist)
+        o = self.conv3.fwd(o, tape, stats=self.bn3.stats_request(dist))
         return self.bn3.fwd(o, tape, relu=True, residual=idt, dist=dist,          # relu(bn3 + identity)
                             planes="both" if emit_planes else None)
 
@@ -89,7 +94,7 @@ class Stage(nn.Module):
     def fwd(self, x, tape, dist, next_takes_planes=False):
         blocks = list(self.children())
         for i, b in enumerate(blocks):
-            nxt = blocks[i + 1].takes_planes() if i + 1 < len(blocks) else next_takes_planes
+            nxt = blocks[i + 1].takes_planes(tape.act_dtype) if i + 1 < len(blocks) else next_takes_planes
             x = b.fwd(x, tape, dist, emit_planes=nxt)
         return x
 
@@ -147,7 +152,7 @@ class ResNet(nn.Module):
         for i in range(self.num_stages):
             tape.mark(f"layer{i + 1}")
             # the last stage's output is read by the decode heads: decode_head3's first conv takes it as planes (through pair_concat)
-            nxt = getattr(getattr(self, f"layer{i + 2}"), "0").takes_planes() if i + 1 < self.num_stages else self.heads_take_planes
+            nxt = getattr(getattr(self, f"layer{i + 2}"), "0").takes_planes(tape.act_dtype) if i + 1 < self.num_stages else self.heads_take_planes
             x = getattr(self, f"layer{i + 1}").fwd(x, tape, dist, next_takes_planes=nxt)
             if i in self.out_indices:
                 outs.append(x)
@@ -238,7 +243,7 @@ class FCNHead(nn.Module):
         for i, m in enumerate(mods):
             cs = scale if i == len(mods) - 1 else None
             # a conv module whose successor is another conv module hands its output on as fp16 pair planes only
-            pl = "only" if (i + 1 < len(mods) and cs is None and mods[i + 1].conv.planes_ok()) else None
+            pl = "only" if (i + 1 < len(mods) and cs is None and mods[i + 1].conv.planes_ok(tape.act_dtype)) else None
             if i == 0 and first is not None:
                 x = m.bn.fwd(first, tape, relu=True, chan_scale=cs, dist=dist, planes=pl)
             else:

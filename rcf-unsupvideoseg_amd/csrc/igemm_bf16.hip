@@ -53,7 +53,15 @@ struct ConvParams {
     int b_bytes;
     unsigned flags;                       // rcf_conv_shape.flags of the call
     int ry0, rx0, rh, rw, rband, rr;      // region of the GEMM-row tensor (see igemm_conv.hip)
-    double *stats;                        // forward only: per row tile, fp64 column sums | sums of squares
+    double *stats;                        // per row tile, fp64 column sums | sums of squares (forward; EP 2 data gradients)
+    // fused epilogues of whole column tiles (template parameter EP of conv_bf16_kernel; bf16 output only):
+    //   EP 1 (forward):        y = [max(0,] acc * ep_scale[c] + ep_shift[c] [+ ep_side[row][c]] [)]   -- conv -> batch norm (folded
+    //                          into per-channel constants) -> residual add -> ReLU in the tile that computed the conv
+    //   EP 2 (data gradient):  dx = ep_side[row][c] > 0 ? acc (+ old dx) : 0, column sums of what is written -> stats
+    //                          (the ReLU of the join whose output this conv read, applied by the LAST writer of its gradient)
+    const float *ep_scale, *ep_shift;
+    const bf16_t *ep_side;
+    int ep_side_pitch, ep_relu;
 };
 
 __device__ __forceinline__ void region_yx(int pix, int ry0, int rx0, int rh, int rw, int t, int &y, int &x) {
@@ -124,8 +132,9 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
 // registers, no ds_write pass); three LDS stages, the loads of K-step t+2 are issued before the MFMAs of step t and
 // stay in flight across the one barrier per step (counted s_waitcnt vmcnt).  The LDS image of a wave instruction is
 // lane-linear (1 KB = 16 rows x 64 B), so the XOR swizzle of the 16-byte chunks is applied to the SOURCE address.
-template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false, int NST = 3, int SCHED = 0>
+template <int MR, int NR, int WM, int WN, bool STRIDED, bool DGRAD, bool OBF, bool DMA = false, int NST = 3, int SCHED = 0, int EP = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 : 1) conv_bf16_kernel(ConvParams p) {
+    static_assert(EP == 0 || OBF, "the fused epilogues write bf16");
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     constexpr int PA = BM * 64, PB = BN * 64, STAGE = PA + PB;
@@ -374,7 +383,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     // 8g + 4(lane>>5) .. +3 of each column tile.
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;
-    const bool want_stats = !DGRAD && p.stats != nullptr;
+    const bool want_stats = (!DGRAD || EP == 2) && p.stats != nullptr;
     long lin[MR];
     bool rowok[MR];
 #pragma unroll
@@ -399,7 +408,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
         const int cb = n0 + brow0 + nr * 32;              // first channel of this column tile
         // The common case -- a whole column tile, no bias, no activation -- as straight-line code (csrc/igemm_conv.hip,
         // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
-        const bool lean = p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
+        // (a bias rides along as one uniform test per quad: the folded data gradient's second half, dx += x (-T) + c0)
+        const bool lean = (p.bias == nullptr || (OBF && !want_stats)) && p.act == 0 && n0 + BN <= p.Ncol;
         if (lean) {
             auto quads = [&](auto BETA_, auto STATS_) {
                 constexpr bool BETA = decltype(BETA_)::value, STATS = decltype(STATS_)::value;
@@ -407,15 +417,45 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                 for (int mr = 0; mr < MR; ++mr) {
                     // rows past M multiplied zero activations: their accumulators are exactly zero
                     f32x4 q[4];
+                    f32x4 side[4];                        // EP: the residual (1) / the activation whose sign masks the gradient (2)
+                    if constexpr (EP != 0) {
+                        // read in the STORE layout (a lane pair = 32 contiguous bytes of a row, one 16-byte load per lane) and
+                        // brought into the accumulator layout by the inverse of the half-wave exchange below
+                        const bool rd = rowok[mr] && p.ep_side != nullptr;
+#pragma unroll
+                        for (int g = 0; g < 4; g += 2) {
+                            u32x4 d = {0u, 0u, 0u, 0u};
+                            if (rd) d = *reinterpret_cast<const u32x4 *>(p.ep_side + lin[mr] * p.ep_side_pitch + cb + 8 * (g + kh));
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                            side[g] = f32x4{__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u),
+                                            __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u)};
+                            side[g + 1] = f32x4{__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u),
+                                                __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u)};
+                        }
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c = cb + 8 * g + 4 * kh;
                         f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+                        if (p.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(p.bias + c);
+                        if constexpr (EP == 1) {
+                            v = v * *reinterpret_cast<const f32x4 *>(p.ep_scale + c) + *reinterpret_cast<const f32x4 *>(p.ep_shift + c);
+                            v += side[g];                 // zeros without a residual
+                            if (p.ep_relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            }
+                        }
                         if (BETA) {
                             if (rowok[mr]) {
                                 if constexpr (OBF) v += ld4(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + c);
                                 else v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c);
                             }
+                        }
+                        if constexpr (EP == 2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = side[g][e] > 0.f ? v[e] : 0.f;
                         }
                         q[g] = v;
                         if (STATS) {
@@ -1122,20 +1162,28 @@ inline bool korder_chunked(unsigned flags) { return !(flags & RCF_CONV_KORDER_NA
 
 // LDS-DMA kernels (128x64 / 128x128 / 128x256 by output width), three stages, pieces interleaved with the MFMAs
 template <int MR, int NR, int WM, int WN, bool OBF>
-void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st) {
+void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st, int ep) {
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN;
     p.mtiles = rcf_cdiv(p.M, BM);
     p.mtiles8 = rcf_cdiv(p.mtiles, 8);
     p.ntiles = rcf_cdiv(p.Ncol, BN);
     p.colmap = p.Ncol % BN == 0 && rcf_colmap_pays(!(p.flags & RCF_CONV_NO_COLMAP), (long)p.M * p.Cs * 2, (long)p.K * p.Ncol * 2, p.mtiles, p.ntiles);
     const dim3 grid((unsigned)(rcf_cdiv(p.mtiles, 8) * 8 * p.ntiles));
+    if constexpr (OBF) {
+        // fused epilogues (the caller checked: whole column tiles, stride 1, no bias / activation)
+        if (ep == 1) { hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, true, true, 3, 1, 1>), grid, dim3(64 * WM * WN), 0, st, p); return; }
+        if (ep == 2) { hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, true, true, 3, 1, 2>), grid, dim3(64 * WM * WN), 0, st, p); return; }
+    }
     if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
     else if (dgrad) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
     else hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
 }
 
+// column-tile width launch_conv picks for Ncol output columns
+inline int conv_bn_of(int Ncol) { return Ncol <= 64 ? 64 : (Ncol <= 128 ? 128 : 256); }
+
 template <bool OBF>
-int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
+int launch_conv(ConvParams &p, bool dgrad, hipStream_t st, int ep = 0) {
     p.s_magic = magic_of(p.S);
     {
         const int taps = p.K / p.Cs, kch = rcf_kchunk(korder_chunked(p.flags), taps, p.Cs, RCF_KCHUNK_BF16);
@@ -1152,9 +1200,10 @@ int launch_conv(ConvParams &p, bool dgrad, hipStream_t st) {
     if (bbytes >= (1L << 31)) return RCF_EINVAL;
     p.b_bytes = (int)bbytes;
     const bool strided = p.div > 1;
-    if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st);
-    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st);
-    else launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st);
+    if (ep && (strided || !OBF || p.Ncol % conv_bn_of(p.Ncol) || p.bias || p.act)) return RCF_EINVAL;
+    if (p.Ncol <= 64) launch_cfg<2, 1, 2, 2, OBF>(p, strided, dgrad, st, ep);
+    else if (p.Ncol <= 128) launch_cfg<2, 2, 2, 2, OBF>(p, strided, dgrad, st, ep);
+    else launch_cfg<2, 4, 2, 2, OBF>(p, strided, dgrad, st, ep);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1350,6 +1399,60 @@ extern "C" int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, c
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.act = 0; p.slope = 0.f; p.beta = beta;
     return launch_conv<true>(p, true, rcf_stream(stream));
+}
+
+/* Fused forms (include/rcf_hip.h): conv -> folded batch norm -> residual -> ReLU; data gradient -> ReLU mask -> column sums */
+extern "C" int rcf_conv2d_fwd_affine_bf16(const void *x, const void *w_bf16, const float *scale, const float *shift,
+                                          const void *residual, int res_pitch, int relu, void *y, const rcf_conv_shape *s,
+                                          void *stream) {
+    if (int e = check_shape(s, 8)) return e;
+    if (!x || !w_bf16 || !y || !scale || !shift || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y) ||
+        !rcf_aligned16(scale) || !rcf_aligned16(shift)) return RCF_EINVAL;
+    if (s->y_pitch % 8 || (residual && (!rcf_aligned16(residual) || res_pitch % 8 || res_pitch < s->Cout))) return RCF_EINVAL;
+    if (s->stride != 1) return RCF_EINVAL;
+    ConvParams p{};
+    p.flags = s->flags;
+    p.A = (const bf16_t *)x; p.Bw = (const bf16_t *)w_bf16; p.bias = nullptr; p.Y = y;
+    p.Ncol = s->Cout; p.K = s->R * s->S * s->Cin;
+    p.Ho = s->Ho; p.Wo = s->Wo; p.Hs = s->H; p.Ws = s->W; p.Cs = s->Cin; p.S = s->S;
+    if (int e = set_region(p, nullptr, s->N, s->Ho, s->Wo)) return e;
+    p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
+    p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
+    p.ep_scale = scale; p.ep_shift = shift; p.ep_side = (const bf16_t *)residual; p.ep_side_pitch = res_pitch; p.ep_relu = relu;
+    return launch_conv<true>(p, false, rcf_stream(stream), 1);
+}
+
+extern "C" size_t rcf_conv2d_dgrad_masked_bf16_workspace_bytes(const rcf_conv_shape *s) {
+    if (check_shape(s)) return 0;
+    return (size_t)(rcf_cdiv((long)s->N * s->H * s->W, 128) + 64) * 2 * s->Cin * sizeof(double);
+}
+
+extern "C" int rcf_conv2d_dgrad_masked_bf16(const void *dy, const void *w_t_bf16, void *dx, const rcf_conv_shape *s, int beta,
+                                            const void *mask_src, int mask_pitch, double *colsums, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+    if (int e = check_shape(s)) return e;
+    if (!dy || !w_t_bf16 || !dx || !mask_src || !rcf_aligned16(dy) || !rcf_aligned16(w_t_bf16) || !rcf_aligned16(dx) ||
+        !rcf_aligned16(mask_src)) return RCF_EINVAL;
+    if (s->y_pitch % 8 || mask_pitch % 8 || mask_pitch < s->Cin || s->stride != 1) return RCF_EINVAL;
+    ConvParams p{};
+    p.flags = s->flags;
+    p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)w_t_bf16; p.bias = nullptr; p.Y = dx;
+    p.Ncol = s->Cin; p.K = s->R * s->S * s->Cout;
+    p.Ho = s->H; p.Wo = s->W; p.Hs = s->Ho; p.Ws = s->Wo; p.Cs = s->Cout; p.S = s->S;
+    if (int e = set_region(p, nullptr, s->N, s->H, s->W)) return e;
+    p.up = 1; p.off = s->pad; p.step = -s->dil; p.div = s->stride;
+    p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
+    p.beta = beta;
+    p.ep_side = (const bf16_t *)mask_src; p.ep_side_pitch = mask_pitch;
+    if (colsums) {
+        if (!workspace || workspace_bytes < rcf_conv2d_dgrad_masked_bf16_workspace_bytes(s)) return RCF_EWORKSPACE;
+        p.stats = (double *)workspace;
+    }
+    if (int e = launch_conv<true>(p, true, rcf_stream(stream), 2)) return e;
+    if (!colsums) return 0;
+    // [sum | sum of squares] per input channel of what was written; the caller reads the first half
+    return rcf_sum_partials_bn((const double *)workspace, p.mtiles, s->Cin, colsums,
+                               (double *)workspace + (size_t)p.mtiles * 2 * s->Cin, nullptr, stream);
 }
 
 extern "C" size_t rcf_conv2d_wgrad_bf16_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region) {

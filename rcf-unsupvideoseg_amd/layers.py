@@ -16,17 +16,10 @@ from . import ops
 
 # Storage type of the activations (and their gradients) between layers: torch.float32, or torch.bfloat16 for the
 # mixed-precision step (BASELINE configs[2]: bf16 forward / fp32 gradients -- what the reference's AMP configs do under
-# torch autocast, configs/rcf_stv2/rcf_stage1.yaml:57-60).  In bf16 mode the stem conv (fp32 image, Cin = 3) and the loss
-# tail stay fp32: the first batch norm turns the stem's fp32 output into bf16 activations, every conv after it runs on
-# the bf16-operand kernels (csrc/igemm_bf16.hip) with fp32 accumulation, the heads' final 1x1 convs write fp32 logits,
-# parameter gradients are fp32.  Set by RCFModel at the start of each forward.
-ACT_DTYPE = torch.float32
-
-
-def set_act_dtype(dtype):
-    global ACT_DTYPE
-    assert dtype in (torch.float32, torch.bfloat16)
-    ACT_DTYPE = dtype
+# torch autocast, configs/rcf_stv2/rcf_stage1.yaml:57-60).  In bf16 mode the loss tail stays fp32: every conv runs on the
+# bf16-operand kernels (csrc/igemm_bf16.hip) with fp32 accumulation, the heads' final 1x1 convs write fp32 logits,
+# parameter gradients are fp32.  The type is a property of the FORWARD PASS -- `Tape.act_dtype`, set by RCFModel from its
+# `precision` / the ambient autocast state -- not of the process: two models of different precision coexist.
 
 
 def _round_up(n, m):
@@ -36,7 +29,8 @@ def _round_up(n, m):
 class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
-                 "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok")
+                 "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok",
+                 "relu_out", "grad_masked", "grad_colsum")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -58,6 +52,10 @@ class Act:
         # instead of writing the identity's gradient; the conv that read t first (`addend_ok`: its data gradient can take a masked
         # addend) adds it in its epilogue.  Anybody else who wants `grad` gets it materialised (relu_mask_copy).
         self.pending_add, self.addend_ok = None, False
+        # folded conv + batch norm + ReLU (conv_bn_fold): `relu_out` = t is the output of a ReLU whose backward wants grad under
+        # its own mask (t > 0) plus that gradient's column sums; the LAST writer of `grad` (the conv that read t first) may apply
+        # the mask in its epilogue and leave `grad_masked` / `grad_colsum` -- any writer after that would add unmasked terms
+        self.relu_out, self.grad_masked, self.grad_colsum = False, False, None
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -79,11 +77,15 @@ class Act:
         with `take_pending` when this returns beta 0)."""
         if self.pending_add is not None and not (takes_addend and self.grad is None):
             self._materialize_pending()
+        if self.grad_masked:
+            raise ops._lib.RcfHipError("a gradient producer after the one that applied the ReLU mask (Act.grad_masked): the "
+                                       "first reader of this activation in the forward pass is not the last writer of its gradient")
         if self.grad is None:
             self.grad = torch.empty(tuple(self.t.shape), dtype=self.t.dtype, device=self.t.device)
             return self.grad, 0
         self.grad_amax = None        # a second producer accumulates: the first one's range no longer bounds the sum
         self.grad_sums2 = None       # ... nor are sums taken over an earlier state of the gradient the sums of the final one
+        self.grad_colsum = None
         return self.grad, 1
 
     def take_pending(self):
@@ -95,6 +97,7 @@ class Act:
             self._materialize_pending()
         g, self.grad = self.grad, None
         self.grad_is_planes = False
+        self.grad_masked, self.grad_colsum = False, None
         return g
 
     def take_grad_range(self):
@@ -153,6 +156,12 @@ PLANES = __import__("os").environ.get("RCF_PLANES", "1") != "0"
 # while an identity block's 1x1 conv1 (short K, epilogue-bound) gains 0.02-0.13 ms from them: measured per layer in
 # profiles/r04_layers_planes_ab.txt, as a step in profiles/r04_ab_join_planes.txt.
 JOIN_PLANES = __import__("os").environ.get("RCF_JOIN_PLANES", "stage")
+# bf16 step: 1x1 conv -> training-mode batch norm (-> + residual -> ReLU) as one tile -- the bottlenecks' conv3 / bn3 / join and
+# the stride-1 downsample conv + norm -- with neither the conv output nor its gradient in memory (conv_bn_fold below;
+# csrc/foldbn.hip).  RCF_FOLD_BN=0: the three-pass form (conv, statistics, apply; reduce, apply, data / weight gradient).
+FOLD_BN = __import__("os").environ.get("RCF_FOLD_BN", "1") != "0"
+FOLD_MAX_K = 512            # the Gram matrix of the conv's input costs 2 rows K^2 FLOPs: conv3 (K <= 512), not layer4's downsample
+FOLD_MASKED_DGRAD = __import__("os").environ.get("RCF_FOLD_MASKED_DGRAD", "1") != "0"
 _side_streams = {}
 
 
@@ -172,8 +181,9 @@ def join_side_stream(device=None):
 
 
 class Tape:
-    def __init__(self, enabled=True, on_mark=None):
-        self.ops, self.enabled, self.on_mark = [], enabled, on_mark
+    def __init__(self, enabled=True, on_mark=None, act_dtype=torch.float32):
+        assert act_dtype in (torch.float32, torch.bfloat16)
+        self.ops, self.enabled, self.on_mark, self.act_dtype = [], enabled, on_mark, act_dtype
 
     def push(self, fn):
         if self.enabled:
@@ -289,11 +299,13 @@ class Conv2d(nn.Module):
         cache[kind] = (key, v, ops.weight_checksum(self.weight) if ops.DEBUG_WEIGHT_CACHE else None)
         return v
 
-    def planes_ok(self):
+    def planes_ok(self, act_dtype=torch.float32):
         """can this conv take its input AND its output gradient as fp16 pair planes (forward, data gradient and weight gradient
-        on the LDS-DMA kernels)?  Channel counts: 16-channel K-steps inside one tap, 64-channel groups of the weight gradient."""
-        return (PLANES and FP16_PAIRS and ACT_DTYPE == torch.float32 and self.bias is None and not self.act
-                and self.cin % 64 == 0 and self.cout % 16 == 0 and self.cin_pad == self.cin and self.cout_pad == self.cout)
+        on the LDS-DMA kernels)?  Channel counts: 16-channel K-steps inside one tap, 64-channel groups of the weight gradient.
+        act_dtype: the forward pass's activation type (Tape.act_dtype): planes exist in the fp32 step only."""
+        return (PLANES and FP16_PAIRS and act_dtype == torch.float32 and self.bias is None and not self.act
+                and self.cin % 64 == 0 and self.cout % 16 == 0 and self.cout >= 64      # (the plane weight gradient's tiles: >= 64 rows)
+                and self.cin_pad == self.cin and self.cout_pad == self.cout)
 
     def _packed_weight(self, cout_mult=4):
         """weight as the kernels want it: [Cout_pad][R][S][Cin_pad] (channels_last view), zero padded
@@ -378,6 +390,9 @@ class Conv2d(nn.Module):
             else:
                 ya = Act(ops.conv2d_fwd_bf16(x.t, w, self._derived("bf16", lambda: ops.weight_bf16(w)), b, self.stride,
                                              self.padding, self.dilation, out=out))
+        tok = object()
+        if x.first_reader is None:
+            x.first_reader = tok                   # first reader in forward order = last writer of x's gradient in the backward pass
         if tape.enabled:
             def bwd():
                 dy = ya.take_grad()
@@ -402,8 +417,17 @@ class Conv2d(nn.Module):
                 def dgrad():
                     gx, beta = x.grad_slot()
                     wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
-                    ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
-                                          w_t_bf16=wt)
+                    tile = 64 if self.cin <= 64 else (128 if self.cin <= 128 else 256)
+                    if (FOLD_MASKED_DGRAD and x.relu_out and x.first_reader is tok and wt is not None and self.stride == 1
+                            and self.cin % tile == 0 and gx.dtype == torch.bfloat16 and x.t.dtype == torch.bfloat16):
+                        # x is the output of a folded conv + norm + ReLU and this is the LAST writer of its gradient: the mask of
+                        # that ReLU and the column sums its backward needs come out of this epilogue (no pass over the gradient)
+                        _, cs = ops.conv2d_dgrad_masked_bf16(dy, wk, x.t.shape, wt, x.t, gx, beta=beta, stride=self.stride,
+                                                             pad=self.padding, dil=self.dilation)
+                        x.grad_masked, x.grad_colsum = True, cs
+                    else:
+                        ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
+                                              w_t_bf16=wt)
                     done_dgrad[0] = True
                 if self.weight.requires_grad:
                     padded = wk is not self.weight
@@ -438,7 +462,7 @@ class Conv2d(nn.Module):
         w, b = self._packed_weight(), self._packed_bias()
         ax = aw = wp = None
         # the input as fp16 pair planes (written by the batch norm that produced it): this conv then never splits an activation
-        use_pl = x.planes is not None and out is None and self.planes_ok() and ops.fused_stats_available()
+        use_pl = x.planes is not None and out is None and self.planes_ok(tape.act_dtype) and ops.fused_stats_available()
         if x.split and not use_pl:
             raise ops._lib.RcfHipError("this activation exists as fp16 pair planes only and the conv cannot read them")
         xin = x.planes if use_pl else x.t
@@ -495,7 +519,7 @@ class Conv2d(nn.Module):
                     gx, beta = x.grad_slot(takes_addend=can_add)
                     add = x.take_pending() if (can_add and beta == 0) else None
                     # the range of dx comes out of the epilogue (after the accumulation when beta = 1): exact for the whole tensor
-                    gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None else None
+                    gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None and ops.fused_stats_available() else None
                     bnb = x.bn_ctx if (FUSE_BN_BWD and wpt is not None and x.first_reader is tok) else None
                     r = ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
                                          amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax, bn_bwd=bnb, addend=add)
@@ -595,7 +619,7 @@ class BatchNorm2d(nn.Module):
         if relu and tape.enabled and RELU_BITMASK:
             # the backward kernels read this (one byte per 4 channels) instead of y
             rmask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=xt.device)
-        ydt = out.dtype if out is not None else (ACT_DTYPE if xt.dtype == torch.float32 else xt.dtype)
+        ydt = out.dtype if out is not None else (tape.act_dtype if xt.dtype == torch.float32 else xt.dtype)
         yamax = ops.new_amax(xt.device) if FP16_PAIRS and ydt == torch.float32 else None
         pl = (planes if PLANES and FP16_PAIRS and planes in ("only", "both") and out is None and chan_scale is None and
               xt.dtype == torch.float32 and ydt == torch.float32 and x.amax is not None and xt.shape[3] % 8 == 0 and
@@ -654,6 +678,83 @@ class BatchNorm2d(nn.Module):
                 x.grad_is_planes = dpl
             tape.push(bwd)
         return ya
+
+
+def fold_ok(conv, bn, x, residual=None):
+    """can conv (1x1, stride 1) -> bn (training mode) [-> + residual] [-> ReLU] run as conv_bn_fold?"""
+    t = x.t
+    return (FOLD_BN and t.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
+            and not conv.act and bn.training and conv.cin % 64 == 0 and conv.cin <= FOLD_MAX_K
+            and (conv.cout in (64, 128) or conv.cout % 256 == 0) and t.is_contiguous() and bn.num_features == conv.cout
+            and (residual is None or (residual.t.dtype == torch.bfloat16 and tuple(residual.t.shape[:3]) == tuple(t.shape[:3])
+                                      and residual.t.shape[3] == conv.cout)))
+
+
+def conv_bn_fold(conv, bn, x, tape, relu, residual=None, dist=None):
+    """y = [relu](bn(conv(x)) [+ residual]) for a 1x1 stride-1 conv and a training-mode batch norm, in ONE pass over x: the norm's
+    statistics come from the moments of x (column sums + Gram matrix), the conv kernel normalises, adds and clamps in its
+    epilogue; the backward pass needs neither the conv's output nor its gradient (csrc/foldbn.hip has the algebra).
+    models/resnet.py:281-296, models/res_layer.py:53-63."""
+    xt, w = x.t, conv.weight
+    rows, K, C = xt.shape[0] * xt.shape[1] * xt.shape[2], conv.cin, conv.cout
+    if not bn.sync:
+        dist = None
+    wb = conv._derived("bf16", lambda: ops.weight_bf16(w))
+    S = ops.gram_bf16(xt)
+    A1 = ops.bn_stats(xt)                                   # fp64 [2K]: the column sums (and sums of squares, unused) of x
+    count = rows
+    if dist is not None and dist.on:                        # SyncBN: the statistics of the global batch
+        P, sums = ops.fold_fwd(S, A1, w)
+        dist.allreduce_sum(sums)
+        count = rows * dist.world
+        mean, invstd, scale, shift = ops.fold_finalize(sums, count, bn)
+    else:
+        P, (mean, invstd, scale, shift) = ops.fold_fwd(S, A1, w, bn, count)
+    if x.first_reader is None:
+        x.first_reader = object()
+    y = ops.conv2d_fwd_affine_bf16(xt, w, wb, scale, shift, residual.t if residual is not None else None, relu)
+    ya = Act(y)
+    ya.relu_out = bool(relu)
+    if RELU_TRACE is not None and relu:
+        RELU_TRACE.append(y > 0)
+    if tape.enabled:
+        def bwd():
+            masked, cs = ya.grad_masked, ya.grad_colsum
+            dy = ya.take_grad()
+            if relu and not masked:
+                g, cs = ops.relu_mask_colsum(dy, y, out=dy)       # in place: dy has no other reader
+            else:
+                g = dy
+                if cs is None:
+                    cs = ops.bn_stats(g)                         # no ReLU: the plain column sums
+            if residual is not None and residual.needs_grad:
+                if residual.grad is None and residual.pending_add is None:
+                    residual.grad = g        # the identity's gradient IS g; whoever writes next accumulates, after the reads below
+                    residual.grad_colsum = cs    # ... and these are its column sums until then (a folded downsample norm wants them)
+                else:
+                    rg, _ = residual.grad_slot()
+                    ops.copy2d(g, ops.pitch_of(g), rg, ops.pitch_of(rg), rows, C, beta=1)
+            # dx = g (a W)^T - x T + c0; T and c0 need G = g^T x.  Both products stay on THIS stream: G is on the critical path, and
+            # waiting for the second stream here would also wait for every weight gradient queued on it (measured: +0.7 ms per step)
+            G = torch.empty((C, K, 1, 1), dtype=torch.float32, device=xt.device)
+            ops.conv2d_wgrad_bf16(xt, g, w, G, 1, 0, 1, beta=0)
+            gx = None
+            if x.needs_grad:
+                gx, beta = x.grad_slot()
+                wg_t = ops.fold_wg(w, scale)
+                ops.conv2d_dgrad_bf16(g, w, xt.shape, 1, 0, 1, out=gx, beta=beta, w_t_bf16=wg_t)      # g (a W)^T
+            sums2 = ops.fold_bwd_sums(G, w, cs, mean, invstd)
+            s2_local = None
+            if dist is not None and dist.on:
+                s2_local = sums2.clone()             # dgamma / dbeta stay per rank; the gradient all-reduce adds them
+                dist.allreduce_sum(sums2)
+            negT, c0 = ops.fold_bwd_prepare(
+                G, P, A1, w, sums2, s2_local, count, mean, invstd, bn.weight, _param_grad(w) if w.requires_grad else None,
+                _param_grad(bn.weight) if bn.weight.requires_grad else None, _param_grad(bn.bias) if bn.bias.requires_grad else None)
+            if gx is not None:
+                ops.conv2d_fwd_bf16(xt, S, negT, c0, 1, 0, 1, out=gx, beta=1)                      # - x T + c0
+        tape.push(bwd)
+    return ya
 
 
 def maxpool3x3s2(x, tape):

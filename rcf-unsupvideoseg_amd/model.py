@@ -95,10 +95,10 @@ def momentum_update_param_and_buffer(src, dest, m):
     s, d = src.state_dict(), dest.state_dict()
     for k in s:
         if d[k].dtype == torch.float32 and d[k].is_cuda and d[k].is_contiguous() and s[k].is_contiguous():
-            ops.ema_update(d[k], s[k], m)
+            ops.ema_update(d[k], s[k], m, invalidate=False)
         elif d[k].dtype == torch.float32 and d[k].is_cuda:
             # channels_last conv weights: same memory order on both sides
-            ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m)
+            ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m, invalidate=False)
         else:
             d[k].data.copy_(d[k].data * m + s[k].data * (1.0 - m))
     ops.weights_changed(dest)            # only `dest` was written: the source's cached operands stay valid
@@ -217,7 +217,7 @@ class RCFModel(nn.Module):
             p = "bf16" if torch.is_autocast_enabled() else "fp32"
         if p not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
-        layers.set_act_dtype(torch.bfloat16 if p == "bf16" else torch.float32)
+        self._act_dtype = torch.bfloat16 if p == "bf16" else torch.float32     # of THIS forward pass: every Tape it makes carries it
         return p
 
     def _images_nhwc(self, imgs):
@@ -225,7 +225,7 @@ class RCFModel(nn.Module):
         x = imgs.reshape(B * I, C3, H, W).contiguous().float()
         if not x.is_cuda:
             raise RuntimeError("RCFModel (HIP) needs the batch on the GPU: there is no CPU fallback")
-        if layers.ACT_DTYPE == torch.bfloat16 and layers.BF16_STEM:
+        if self._act_dtype == torch.bfloat16 and layers.BF16_STEM:
             # bf16 step: the stem conv takes bf16 operands like every other conv (torch autocast casts conv1's input too)
             return Act(ops.cast(ops.nchw_to_nhwc(x, 8), torch.bfloat16), needs_grad=False)
         return Act(ops.nchw_to_nhwc(x, 4), needs_grad=False)
@@ -244,7 +244,7 @@ class RCFModel(nn.Module):
         B, I = imgs.shape[:2]
         dist = self._dist()
         self._select_precision()
-        tape = Tape(on_mark=self.grad_ready_hook)
+        tape = Tape(on_mark=self.grad_ready_hook, act_dtype=self._act_dtype)
         img = self._images_nhwc(imgs)
         crf_side = None
         if self.w_crf > 0 and self.crf_use_ema and layers.OVERLAP_TEACHER:
@@ -260,7 +260,7 @@ class RCFModel(nn.Module):
         if any(q.requires_grad for q in self.backbone2.parameters()):
             feats = self.backbone2.fwd(img, tape, dist)
         else:                                            # freeze_backbone: nothing behind the features needs a gradient
-            feats = self.backbone2.fwd(img, Tape(enabled=False), dist)
+            feats = self.backbone2.fwd(img, Tape(enabled=False, act_dtype=self._act_dtype), dist)
             for f in feats:
                 f.needs_grad = False
         tape.mark("heads")                                                       # fires once all three heads are done
@@ -311,7 +311,7 @@ class RCFModel(nn.Module):
         """rcf_model.py:496-520: (EMA) masks -> object channel -> image size -> CRF -> mask size."""
         oc = self.args.object_channel
         if self.crf_use_ema:
-            t = Tape(enabled=False)
+            t = Tape(enabled=False, act_dtype=self._act_dtype)
             d = self._teacher_dist()     # in training mode (after model.train()) the teacher's SyncBN exchanges statistics too
             le = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img_act, t, d), t, d)
         else:
@@ -363,7 +363,7 @@ class RCFModel(nn.Module):
         visualisation grid (and with args.eval_export the object-channel / all-channel PNGs) are written."""
         B, I = imgs.shape[:2]
         self._select_precision()
-        t = Tape(enabled=False)
+        t = Tape(enabled=False, act_dtype=self._act_dtype)
         img = self._images_nhwc(imgs)
         if self.eval_on_ema:
             logits = self.decode_head2_ema.fwd(self.backbone2_ema.fwd(img, t), t)

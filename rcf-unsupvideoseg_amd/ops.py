@@ -565,6 +565,138 @@ def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=
     return dw
 
 
+# ------------------------------------------------------- folded 1x1 conv + batch norm (csrc/foldbn.hip; include/rcf_hip.h)
+def gram_bf16(x):
+    """S = x^T x: [K,K,1,1] fp32 (the weight-gradient kernel with dy = x) of an NHWC bf16 activation [.., K]"""
+    K = x.shape[3]
+    S = torch.empty((K, K, 1, 1), dtype=torch.float32, device=x.device)
+    conv2d_wgrad_bf16(x, x, S, S, 1, 0, 1, beta=0)
+    return S
+
+
+def _fold_fin(bn, count, device):
+    C = bn.num_features
+    mk = lambda: torch.empty(C, dtype=torch.float32, device=device)
+    mean, invstd, scale, shift = mk(), mk(), mk(), mk()
+    fin = _lib.FoldFinalize(float(count), bn.eps, bn.momentum, bn.weight.data_ptr(), bn.bias.data_ptr(), mean.data_ptr(),
+                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), bn.running_mean.data_ptr(),
+                            bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr())
+    return fin, (mean, invstd, scale, shift)
+
+
+def fold_fwd(S, A1, w, bn=None, count=None):
+    """P = W S [N,K] fp32 and the statistics of z = conv1x1(x, w) from the moments of x (A1: fp64 [K] column sums, S: Gram
+    matrix).  bn given (local statistics): returns (P, (mean, invstd, scale, shift)), the norm finalized in the same launch;
+    otherwise (P, sums fp64 [2N] = sum z | sum z^2) for fold_finalize after the all-reduce."""
+    N, K = w.shape[0], w.shape[1]
+    P = torch.empty((N, K, 1, 1), dtype=torch.float32, device=w.device)
+    need = _lib.load().rcf_fold_fwd_scratch_bytes(N, K)
+    ws = workspace(need, w.device)
+    if bn is not None:
+        fin, outs = _fold_fin(bn, count, w.device)
+        call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), None, byref(fin), _p(ws), need, N, K, _stream())
+        return P, outs
+    sums = torch.empty(2 * N, dtype=torch.float64, device=w.device)
+    call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), _p(sums), None, _p(ws), need, N, K, _stream())
+    return P, sums
+
+
+def fold_finalize(sums, count, bn):
+    """(mean, invstd, scale, shift) + the running statistics and num_batches_tracked of `bn` (a training-mode BatchNorm2d)"""
+    fin, outs = _fold_fin(bn, count, sums.device)
+    call("rcf_fold_finalize_f32", _p(sums), bn.num_features, byref(fin), _stream())
+    return outs
+
+
+def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True, stride=1, pad=0, dil=1):
+    """y = [relu](conv(x, w) * scale[c] + shift[c] [+ residual]) in the conv's own epilogue (bf16 in, bf16 out)"""
+    _need_cuda(x, w)
+    assert x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.bfloat16, device=x.device)
+    s.y_pitch = pitch_of(out)
+    if residual is not None:
+        assert tuple(residual.shape) == tuple(out.shape)
+    end = None
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_bf16_fwd" if s.Cout > 128 else "conv_bf16_fwd_narrow",
+                              2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin, _shape_tag(s) + " +bn")
+    call("rcf_conv2d_fwd_affine_bf16", _p(x), _p(w_bf16), _p(scale), _p(shift), _p(residual),
+         pitch_of(residual) if residual is not None else 0, int(relu), _p(out), byref(s), _stream())
+    if end is not None:
+        end.record()
+    return out
+
+
+def relu_mask_colsum(dy, y, out=None):
+    """(g = y > 0 ? dy : 0, fp64 [2C] whose first half holds the column sums of g); out may be dy (in place)"""
+    _need_cuda(dy, y)
+    assert dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and tuple(dy.shape) == tuple(y.shape)
+    if out is None:
+        out = torch.empty(tuple(dy.shape), dtype=dy.dtype, device=dy.device)
+    rows, C = _rows(dy), dy.shape[3]
+    cs = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+    need = _lib.load().rcf_relu_mask_colsum_bf16_workspace_bytes(rows, C)
+    ws = workspace(need, dy.device)
+    call("rcf_relu_mask_colsum_bf16", _p(dy), pitch_of(dy), _p(y), pitch_of(y), _p(out), pitch_of(out), rows, C, _p(cs), _p(ws),
+         need, _stream())
+    return out, cs
+
+
+def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, stride=1, pad=0, dil=1, colsums=True):
+    """dx = mask_src > 0 ? conv_transpose(dy, w) (+ dx) : 0 in the data gradient's epilogue, with the column sums of what it
+    writes (fp64 [2 Cin], first half): the LAST writer of a ReLU output's gradient applies that ReLU's mask"""
+    _need_cuda(dy, w, mask_src)
+    assert dy.dtype == torch.bfloat16 and mask_src.dtype == torch.bfloat16 and tuple(mask_src.shape) == tuple(xshape)
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    cs = ws = None
+    need = 0
+    if colsums:
+        cs = torch.empty(2 * s.Cin, dtype=torch.float64, device=dy.device)
+        need = _lib.load().rcf_conv2d_dgrad_masked_bf16_workspace_bytes(byref(s))
+        ws = workspace(need, dy.device)
+    end = None
+    if PROFILE.which is not None:
+        end = PROFILE.bracket("conv_bf16_dgrad_wide" if s.Cin > 128 else "conv_bf16_dgrad_other",
+                              2.0 * s.N * s.H * s.W * s.Cin * s.R * s.S * s.Cout, _shape_tag(s) + " +mask")
+    call("rcf_conv2d_dgrad_masked_bf16", _p(dy), _p(w_t_bf16), _p(out), byref(s), int(beta), _p(mask_src), pitch_of(mask_src),
+         _p(cs), _p(ws), need, _stream())
+    if end is not None:
+        end.record()
+    return out, cs
+
+
+def fold_bwd_sums(G, w, colsums, mean, invstd):
+    """fp64 [2N] = sum g | sum g zhat of the folded norm, from G = g^T x and the column sums of g"""
+    N, K = w.shape[0], w.shape[1]
+    sums2 = torch.empty(2 * N, dtype=torch.float64, device=w.device)
+    call("rcf_fold_bwd_sums_f32", _p(G), _p(weight_rsck(w)), _p(colsums), _p(mean), _p(invstd), _p(sums2), N, K, _stream())
+    return sums2
+
+
+def fold_wg(w, scale):
+    """(scale[c] W)^T as the bf16 operand of the folded data gradient g Wg^T (uint8 buffer, weight_bf16(.., True) layout)"""
+    N, K = w.shape[0], w.shape[1]
+    wg_t = torch.empty(_lib.load().rcf_conv_weight_bf16_bytes(N, K, 1, 1, 1), dtype=torch.uint8, device=w.device)
+    call("rcf_fold_wg_bf16", _p(weight_rsck(w)), _p(scale), _p(wg_t), N, K, _stream())
+    return wg_t
+
+
+def fold_bwd_prepare(G, P, A1, w, sums2, sums2_local, count, mean, invstd, gamma, dW, dgamma, dbeta):
+    """dW / dgamma / dbeta accumulate; returns (negT, c0): the K -> K weight operand and bias of the second half of the folded
+    data gradient, dx += x (-T) + c0"""
+    N, K = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    negT = torch.empty(lib.rcf_conv_weight_bf16_bytes(K, K, 1, 1, 0), dtype=torch.uint8, device=w.device)
+    c0 = torch.empty(K, dtype=torch.float32, device=w.device)
+    need = lib.rcf_fold_bwd_scratch_bytes(N, K)
+    ws = workspace(need, w.device)
+    call("rcf_fold_bwd_prepare_f32", _p(G), _p(P), _p(A1), _p(weight_rsck(w)), _p(sums2), _p(sums2_local), float(count), _p(mean),
+         _p(invstd), _p(gamma), _p(weight_rsck(dW)) if dW is not None else None, _p(dgamma), _p(dbeta), _p(negT), _p(c0),
+         _p(ws), need, N, K, _stream())
+    return negT, c0
+
+
 def cast(x, dtype, out=None):
     """NHWC activation (possibly a channel slice) -> the same values in `dtype` (fp32 <-> bf16)"""
     _need_cuda(x)
@@ -820,8 +952,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), ep
          eps, weight_decay, step, grad_scale, _stream())
 
 
-def ema_update(dest, src, m):
-    weights_changed()
+def ema_update(dest, src, m, invalidate=True):
+    """dest = dest m + src (1 - m).  invalidate=False: the caller drops the cached operands of the module it wrote itself
+    (momentum_update_param_and_buffer: only the teacher's) instead of every cached operand of the process"""
+    if invalidate:
+        weights_changed()
     call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
 
 

@@ -385,7 +385,7 @@ def test_stv2_variant_under_autocast_precision(golden_dir, report):
     scale = 2.0 ** 14
     with torch.autocast("cuda", dtype=torch.float16):
         losses = m(batch)
-    assert rcf_amd.layers.ACT_DTYPE == torch.bfloat16, "autocast (fp16 requested) must select the bf16 storage path"
+    assert m._act_dtype == torch.bfloat16, "autocast (fp16 requested) must select the bf16 storage path"
     (losses["loss"] * scale).backward()
     e = {k: abs(float(losses[k]) - v) / abs(v) for k, v in fx["loss"].items()}
     gn = {}

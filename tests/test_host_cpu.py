@@ -228,6 +228,14 @@ def test_weight_operand_cache_invalidation(monkeypatch):
     e0 = ops.WEIGHT_EPOCH[0]
     m.eval()                                            # no transition: a trainer calling train() every step keeps its caches
     assert ops.WEIGHT_EPOCH[0] == e0
+    # the EMA update writes the TEACHER only: the student's cached operands (prepared in bulk after the optimizer step) survive it
+    student, teacher = layers.Conv2d(4, 8, 3), layers.Conv2d(4, 8, 3)
+    student._derived("amax", lambda: 1.0)
+    teacher._derived("amax", lambda: 2.0)
+    key0, e0 = student.__dict__["_wcache"]["amax"][0], ops.WEIGHT_EPOCH[0]
+    rcf_amd.model.momentum_update_param_and_buffer(student, teacher, 0.9)
+    assert ops.WEIGHT_EPOCH[0] == e0 and student.__dict__["_wcache"]["amax"][0] == key0 == ops.weight_key(student.weight)
+    assert "_wcache" not in teacher.__dict__
     # debug mode: a stale hit raises instead of being used
     monkeypatch.setattr(ops, "DEBUG_WEIGHT_CACHE", True)
     conv2 = layers.Conv2d(4, 8, 3)

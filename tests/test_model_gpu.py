@@ -62,7 +62,7 @@ def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
         from rcf_amd.layers import Tape, pair_concat
         t = Tape(enabled=False)
         imgs = torch.stack(batch["imgs"], dim=1)
-        model._select_precision()                           # the storage type is process-wide state: a bf16 test may have run before
+        model._select_precision()                           # fp32 (model.precision is None, no autocast): _images_nhwc reads it
         img = model._images_nhwc(imgs)
         saved = copy.deepcopy(model.state_dict())           # BN running stats move in train mode
         feats = model.backbone2.fwd(img, t)
@@ -243,7 +243,7 @@ def test_fullsize_480x854_vs_reference_golden(golden_dir, report):
         from rcf_amd.layers import Tape
         t = Tape(enabled=False)
         saved = copy.deepcopy(model.state_dict())
-        model._select_precision()                           # process-wide storage type (a bf16 test may have run before)
+        model._select_precision()                           # fp32 (model.precision is None, no autocast): _images_nhwc reads it
         img = model._images_nhwc(torch.stack(batch["imgs"], dim=1))
         logits = model.decode_head2.fwd(model.backbone2.fwd(img, t), t)
         model.load_state_dict(saved)
