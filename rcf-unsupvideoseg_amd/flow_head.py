@@ -157,7 +157,7 @@ class FlowAggregationHeadWithResidual(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)    # lives across fwd -> bwd
         return self._ws, need
 
-    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I, want_flows=False):
+    def loss_and_grads(self, model, logits, res, gfw, gbw, extra, B, I, want_flows=False, act_dtype=torch.float32):
         """Returns (losses, seed): seed(scale) writes d(scale*loss)/d logits and /d res into the Acts and
         accumulates this head's parameter gradients.  want_flows: also keep the reconstructed flows (overall,
         aggregated, residual adjustment, affine; [2B,2,h,w] per direction image) and the softmax masks in
@@ -183,7 +183,15 @@ class FlowAggregationHeadWithResidual(nn.Module):
         l1, l2 = self.flow_feat_after_agg[0], self.flow_feat_after_agg[2]
         w1p = c1._packed_weight()
         a1 = ops.conv2d_fwd(flow4, w1p, c1.bias, 1, c1.padding, 1, act=1, slope=0.1)
-        feat = ops.conv2d_fwd(a1, c2.weight, c2.bias, 1, c2.padding, 1, act=1, slope=0.1)
+        # bf16 step (act_dtype: the forward pass's activation type): the 64 -> 64 feature conv on the bf16-operand kernels, as
+        # torch autocast runs it (models/flow_aggregation_head_with_residual.py:84-93 under configs/rcf_stv2's AMP); its
+        # output stays fp32 for the fp32 loss tail.  a1 (Cin = 2 conv, fp32-MFMA) is rounded to bf16 once for all three directions.
+        bf = act_dtype == torch.bfloat16 and c2.cin % 8 == 0 and c2.cout % 8 == 0
+        if bf:
+            a1b = ops.cast(a1, torch.bfloat16)
+            feat = ops.conv2d_fwd_bf16(a1b, c2.weight, None, c2.bias, 1, c2.padding, 1, act=1, slope=0.1, out_dtype=torch.float32)
+        else:
+            feat = ops.conv2d_fwd(a1, c2.weight, c2.bias, 1, c2.padding, 1, act=1, slope=0.1)
         if tuple(res.t.shape[1:3]) != (h, w):
             if not self.allow_residual_resize:
                 raise RuntimeError("residual size differs from mask_size and allow_residual_resize is off")
@@ -233,9 +241,14 @@ class FlowAggregationHeadWithResidual(nn.Module):
             logits.grad = dlogits
             res.grad = dR if R is res.t else ops.resize_nhwc_bwd(dR, res.t.shape[1:3], False)
             # second 3x3 conv (64 -> 64): dfeat already carries the LeakyReLU derivative
-            ops.conv2d_wgrad(a1, dfeat, c2.weight, _param_grad(c2.weight), 1, c2.padding, 1, beta=1)
             ops.colsum(dfeat, _param_grad(c2.bias), beta=1)
-            da1 = ops.conv2d_dgrad(dfeat, c2.weight, a1.shape, 1, c2.padding, 1)
+            if bf:
+                dfb = ops.cast(dfeat, torch.bfloat16)
+                ops.conv2d_wgrad_bf16(a1b, dfb, c2.weight, _param_grad(c2.weight), 1, c2.padding, 1, beta=1)
+                da1 = ops.cast(ops.conv2d_dgrad_bf16(dfb, c2.weight, a1.shape, 1, c2.padding, 1), torch.float32)
+            else:
+                ops.conv2d_wgrad(a1, dfeat, c2.weight, _param_grad(c2.weight), 1, c2.padding, 1, beta=1)
+                da1 = ops.conv2d_dgrad(dfeat, c2.weight, a1.shape, 1, c2.padding, 1)
             _lib.call("rcf_lrelu_bwd_f32", _p(da1), _p(a1), _p(da1), da1.numel(), 0.1, _stream())
             # first 3x3 conv (2 -> 64, input zero-padded to 4 channels): no data gradient (input = RAFT flow)
             dwp = torch.empty_like(w1p)

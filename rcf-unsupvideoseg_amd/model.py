@@ -292,7 +292,8 @@ class RCFModel(nn.Module):
             else:
                 extra["crf_masks"] = self._crf_targets(img, imgs, logits, B, I)
         losses, seed = self.decode_head.loss_and_grads(
-            self, logits, res, gfw.view(B, nf, 2, *self.mask_size), gbw.view(B, nf, 2, *self.mask_size), extra, B, I)
+            self, logits, res, gfw.view(B, nf, 2, *self.mask_size), gbw.view(B, nf, 2, *self.mask_size), extra, B, I,
+            act_dtype=self._act_dtype)
         self._seed_backward = seed
         self._tape = tape
         self.last_targets = extra        # the pl / crf targets at mask size that entered the loss (tests look at them)

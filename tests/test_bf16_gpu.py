@@ -265,6 +265,28 @@ def test_bf16_step_runs_and_tracks_fp32(variant, report):
     assert max(e_l.values()) < 5e-2 and max(e_g.values()) < 0.3
 
 
+def test_two_precisions_coexist_in_one_process(report):
+    """the activation type is a property of the forward pass (layers.Tape.act_dtype, from RCFModel.precision), not of the
+    process: an fp32 and a bf16 model take steps in alternation and each reproduces what it computes alone, bit for bit"""
+    H, W, B = 64, 96, 2
+    alone = {}
+    for prec in ("fp32", "bf16"):
+        m, batch = _model_and_batch(H, W, B)
+        tr = rcf_amd.Trainer(m, device=DEV, precision=prec)
+        alone[prec] = [float(tr.step(batch)["loss"]) for _ in range(2)]
+    ms = {}
+    for prec in ("fp32", "bf16"):
+        m, batch = _model_and_batch(H, W, B)
+        ms[prec] = (rcf_amd.Trainer(m, device=DEV, precision=prec), batch)
+    mixed = {"fp32": [], "bf16": []}
+    for _ in range(2):
+        for prec in ("bf16", "fp32"):
+            tr, batch = ms[prec]
+            mixed[prec].append(float(tr.step(batch)["loss"]))
+    report(f"fp32 and bf16 models interleaved: {mixed} alone: {alone}")
+    assert mixed == alone
+
+
 @pytest.mark.parametrize("tag", ["small", "480x854"])
 def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     """BASELINE configs[2] parity: the mixed-precision step against the REFERENCE run in fp32 and under
