@@ -131,8 +131,8 @@ def main():
         # ... and once more with the weight gradients on the SAME stream as everything else: with the second stream a
         # weight gradient and a data gradient share the chip and each one's bracket also counts what the other costs it
         from rcf_amd import layers
-        saved = layers.OVERLAP_WGRAD
-        layers.OVERLAP_WGRAD = False
+        saved = layers.SCHED.overlap_wgrad
+        layers.SCHED.overlap_wgrad = False
         try:
             trainer.step(batch)
             ops.PROFILE.start(list(fams))
@@ -140,7 +140,7 @@ def main():
                 trainer.step(batch)
             by_serial = ops.PROFILE.stop()
         finally:
-            layers.OVERLAP_WGRAD = saved
+            layers.SCHED.overlap_wgrad = saved
         barrier()
         del trainer, model
         torch.cuda.empty_cache()
@@ -216,10 +216,10 @@ def main():
         # The convs run as fp32 contractions on the fp16 matrix cores (each operand scaled and split into 2 fp16
         # parts, 3 partial products, fp32 accumulate): the bound is the dense fp16 MFMA peak / 3 passes.
         from rcf_amd import layers as _layers
-        two_streams = bool(_layers.OVERLAP_WGRAD)
+        two_streams = bool(_layers.SCHED.overlap_wgrad)
         out["config"]["second_stream_for_weight_gradients"] = two_streams
-        out["config"]["late_weight_gradients"] = bool(_layers.OVERLAP_WGRAD and _layers.LATE_WGRAD)
-        out["config"]["fp16_pair_planes"] = bool(_layers.PLANES)
+        out["config"]["late_weight_gradients"] = bool(_layers.SCHED.overlap_wgrad and _layers.SCHED.late_wgrad)
+        out["config"]["fp16_pair_planes"] = bool(_layers.SCHED.planes)
         # The timed region runs the step as shipped: weight gradients on a second stream, started after their layer's data
         # gradient.  A bracket there also times what the kernel loses to its neighbour on the chip, so the headline `roofline`
         # is the SAME family bracketed in the separate pass of two steps that runs the whole step on one stream (every launch of

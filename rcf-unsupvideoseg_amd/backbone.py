@@ -53,7 +53,7 @@ class Bottleneck(nn.Module):
     def takes_planes(self, act_dtype=torch.float32):
         """do this block's first convs read their input as fp16 pair planes when the producer supplies them?"""
         ok = self.conv1.planes_ok(act_dtype) and (self.downsample is None or getattr(self.downsample, "0").planes_ok(act_dtype))
-        return ok and (layers.JOIN_PLANES == "all" or self.downsample is not None)
+        return ok and (layers.SCHED.join_planes == "all" or self.downsample is not None)
 
     def fwd(self, x, tape, dist, emit_planes=False):
         """emit_planes: the block's output is ALSO written as fp16 pair planes (the next block's conv1 / downsample read them).
@@ -127,7 +127,7 @@ class ResNet(nn.Module):
             blocks += [Bottleneck(inplanes, planes, 1, dil, None, norm_cfg) for _ in range(1, nblocks)]
             setattr(self, f"layer{i + 1}", Stage(blocks))
         self.feat_dim = inplanes
-        self.heads_take_planes = True       # RCFModel: the last stage's output also as fp16 pair planes (layers.PLANES gates it)
+        self.heads_take_planes = True       # RCFModel: the last stage's output also as fp16 pair planes (layers.SCHED.planes gates it)
 
     def init_weights(self, pretrained=None):
         if pretrained is not None:

@@ -175,3 +175,80 @@ def variant_model_kwargs(name, H, W, norm="BN"):
         raise KeyError(name)
     kw.update(log_interval=10 ** 9, train_iter=1)
     return kw, oc
+
+
+# ------------------------------------------------------------------------------------------------------------------- schedule
+class Schedule:
+    """Every choice of HOW the training step runs (never of WHAT it computes: all settings give the same results up to the
+    re-association of fp32 sums, most of them bit-identical -- tests/test_pipeline_gpu.py, test_planes_gpu.py, test_fold_gpu.py).
+    One object, `rcf_amd.config.SCHED`, read at call time by layers / model / trainer; tools and tests set its attributes
+    explicitly (`config.SCHED.overlap_wgrad = False`, `tools/step_prof.py bf16 4 8 fold_bn=0`).  No environment variable feeds it:
+    the only environment overrides the package reads are RCF_CONV_FLAGS (per-launch kernel A/B bits, ops.py) and
+    RCF_DEBUG_WEIGHT_CACHE.
+
+    streams
+      overlap_wgrad      weight gradients on a second HIP stream (joined before anything reads a parameter gradient)
+      late_wgrad         ... started AFTER the layer's data gradient, so that a weight gradient (MFMA-bound) runs beside the NEXT
+                         layer's batch-norm backward (HBM-bound); the overlapped launches take the 128 x 256 tile
+      side_priority      HIP priority of the second stream (0 default, -1 high, 1 low)
+      overlap_teacher    stage 2.1: the EMA teacher's forward + CRF on the second stream beside the student's forward
+    batch norm
+      fuse_bn_stats      conv -> training-mode norm: per-channel sums from the conv epilogue instead of a pass over its output
+      fuse_bn_finalize   the reduction of those sums also finalizes the norm (one launch, not four)
+      fuse_bn_bwd        fp32 step: the norm's backward sums from the epilogue of the data gradient that writes its output
+                         gradient last (57 -> 6 reduction passes; built, measured, does not pay: off)
+      relu_bitmask       norm + ReLU keeps the sign bits of its output (1/16 of its bytes) for the backward pass
+      defer_residual     fp32 step: a join does not write its identity branch's gradient; conv1's data gradient adds it
+      fold_bn            bf16 step: 1x1 conv -> norm (-> + residual -> ReLU) as ONE tile, statistics from the Gram matrix of the
+                         conv's input, algebraic backward: neither the conv output nor its gradient exists (layers.conv_bn_fold)
+      fold_max_k         ... for convs with at most this many input channels (the Gram matrix costs 2 rows K^2 FLOPs)
+      fold_masked_dgrad  ... the join's ReLU mask + column sums from the epilogue of the LAST writer of its gradient
+    operands
+      fp16_pairs         fp32 step: convs as 3 fp16 partial products (operand ranges known) instead of 6 bf16 ones
+      h2_kinds           which conv directions may do so: "f" forward, "d" data gradient, "w" weight gradient (debug)
+      planes             fp32 step: the norms between the bottlenecks' convs write fp16 pair planes, those convs take both operands
+                         by LDS-DMA
+      join_planes        which joins are ALSO written as planes: "stage" (in front of a stage's first block) or "all"
+      bf16_stem          bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels)
+      cache_weight_operands  derived weight operands once per weight update, not per launch
+      bulk_weight_prep   ... for all weights of the model in two / three launches right after the optimizer step (trainer.WeightPrep)
+    data parallel
+      grad_group         the gradient chunks' all-reduces on their OWN communicator (beside the default one that carries SyncBN)
+      teacher_group      stage 2.1: the EMA teacher's SyncBN exchanges on their own communicator
+                         Both default to False: one RCCL communicator in flight is the only configuration anyone has run
+                         (no multi-GPU box has been reachable from the build container: DESIGN.md section 7)."""
+
+    __slots__ = ("overlap_wgrad", "late_wgrad", "side_priority", "overlap_teacher", "fuse_bn_stats", "fuse_bn_finalize",
+                 "fuse_bn_bwd", "relu_bitmask", "defer_residual", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
+                 "h2_kinds", "planes", "join_planes", "bf16_stem", "cache_weight_operands", "bulk_weight_prep", "grad_group",
+                 "teacher_group")
+
+    def __init__(self):
+        self.overlap_wgrad = self.late_wgrad = self.overlap_teacher = True
+        self.side_priority = 0
+        self.fuse_bn_stats = self.fuse_bn_finalize = self.relu_bitmask = self.defer_residual = True
+        self.fuse_bn_bwd = False
+        self.fold_bn, self.fold_max_k, self.fold_masked_dgrad = True, 512, True
+        self.fp16_pairs, self.h2_kinds, self.planes, self.join_planes = True, "fdw", True, "stage"
+        self.bf16_stem = self.cache_weight_operands = self.bulk_weight_prep = True
+        self.grad_group = self.teacher_group = False
+
+    def set(self, **kw):
+        """set several fields; returns the previous values (for a `finally: SCHED.set(**old)`)"""
+        old = {k: getattr(self, k) for k in kw}
+        for k, v in kw.items():
+            setattr(self, k, v)
+        return old
+
+    def parse(self, items):
+        """`name=value` strings (command-line tails of the tools): booleans as 0 / 1, integers, or bare strings"""
+        for it in items:
+            k, v = it.split("=", 1)
+            cur = getattr(self, k)
+            setattr(self, k, (v not in ("0", "false", "False")) if isinstance(cur, bool) else (int(v) if isinstance(cur, int) else v))
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self.__slots__}
+
+
+SCHED = Schedule()

@@ -30,7 +30,7 @@ class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
                  "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok",
-                 "relu_out", "grad_masked", "grad_colsum")
+                 "relu_out", "grad_masked", "grad_colsum", "bn_in")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -48,7 +48,7 @@ class Act:
         # the forward pass writes t's gradient LAST in the backward pass and can then deliver the norm's backward sums from its
         # data gradient's epilogue (`grad_sums2`; any later writer of `grad` -- there should be none -- voids them in grad_slot)
         self.bn_ctx = self.first_reader = self.grad_sums2 = None
-        # deferred residual gradient (DEFER_RESIDUAL): a join relu(bn3 + identity) leaves (its output gradient, its sign bits) here
+        # deferred residual gradient (SCHED.defer_residual): a join relu(bn3 + identity) leaves (its output gradient, its sign bits) here
         # instead of writing the identity's gradient; the conv that read t first (`addend_ok`: its data gradient can take a masked
         # addend) adds it in its epilogue.  Anybody else who wants `grad` gets it materialised (relu_mask_copy).
         self.pending_add, self.addend_ok = None, False
@@ -56,6 +56,10 @@ class Act:
         # its own mask (t > 0) plus that gradient's column sums; the LAST writer of `grad` (the conv that read t first) may apply
         # the mask in its epilogue and leave `grad_masked` / `grad_colsum` -- any writer after that would add unmasked terms
         self.relu_out, self.grad_masked, self.grad_colsum = False, False, None
+        # SyncBN: the plain norm (no ReLU) that produced t leaves (its input, mean, invstd) here; a join that takes t as its
+        # residual computes that norm's backward sums beside its own -- both depend only on the join's masked output gradient --
+        # and sends them in ONE exchange (`grad_sums2` then holds (global sums, local sums) and the norm skips pass and exchange)
+        self.bn_in = None
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -108,68 +112,21 @@ class Act:
         return r if r is not None else ops.absmax(self.grad)
 
 
-# Weight gradients on a second HIP stream, started AFTER the layer's data gradient (`LATE_WGRAD`): a weight gradient
-# (MFMA-bound) then runs beside the NEXT layer's batch-norm backward (HBM-bound) instead of beside its own data gradient
-# (MFMA-bound like itself).  Joined before anything reads a parameter gradient (tape marks = all-reduce chunks, end of
-# backward).  Results are bit-identical to the one-stream order (tests/test_pipeline_gpu.py).  The default since round 4:
-# it is the fastest validated schedule (profiles/r03_ab_late_wgrad.txt: fp32 115.2 -> 112.8 ms, bf16 48.95 -> 48.45), with
-# the 128 x 256 weight-gradient tile (two workgroups per CU) for the overlapped launches -- the 256 x 256 tile holds a CU's
-# registers for a whole launch and leaves the batch-norm kernels no slots.  bench.py takes its per-kernel roofline brackets
-# in a separate one-stream pass, so the schedule no longer has to be chosen for the measurement's sake.
-# RCF_OVERLAP_WGRAD=0: everything on one stream; RCF_LATE_WGRAD=0: the round-2 order (beside the layer's own data gradient).
-OVERLAP_WGRAD = __import__("os").environ.get("RCF_OVERLAP_WGRAD", "1") != "0"
-LATE_WGRAD = __import__("os").environ.get("RCF_LATE_WGRAD", "1") != "0"
-# stage 2.1: the EMA teacher's forward + CRF on a second stream beside the student's forward (152 vs 172 ms per step)
-OVERLAP_TEACHER = __import__("os").environ.get("RCF_OVERLAP_TEACHER", "1") != "0"
-# conv -> training-mode batch norm: per-channel sums from the conv epilogue instead of a pass over the conv output
-FUSE_BN_STATS = True
-BF16_STEM = True            # bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels), as torch autocast does
-CACHE_WEIGHT_OPERANDS = True   # weight ranges / fp16 planes / bf16 copies once per weight update, not per launch
-FUSE_BN_FINALIZE = True     # the reduction of conv-produced statistics also finalizes the batch norm (one launch, not four)
-# fp32 step: the two sums of a batch norm's backward (sum g, sum g xhat) from the epilogue of the data gradient that writes the
-# norm's output gradient last (ops.conv2d_dgrad(bn_bwd=...)) instead of a pass over dy and x: 57 -> 6 reduction passes per step,
-# gradients equal to 2e-6 (tests/test_planes_gpu.py).  OFF by default because it does not pay: measured in one process
-# (tools/ab_schedule.py fp32 bnsums, profiles/r04_ab_bn_bwd_sums.txt) 108.27 vs 108.36 ms on one stream, 107.03 vs 106.50 ms with
-# the default two-stream schedule -- the pass reads a gradient the data gradient has just left in the Infinity Cache and, in the
-# default schedule, runs beside the previous layer's weight gradient anyway; the epilogue's reads of x are exposed at the end
-# of every tile of a power-limited kernel.  RCF_FUSE_BN_BWD=1 turns it on.
-FUSE_BN_BWD = __import__("os").environ.get("RCF_FUSE_BN_BWD", "0") == "1"
-# fp32 step: a residual join does not WRITE the gradient of its identity branch (= its own output gradient under its ReLU mask);
-# the block's conv1 -- whose data gradient is the other, and last, writer of that tensor -- adds it in its epilogue from the join's
-# output gradient and sign bits (ops.conv2d_dgrad(addend=...)): one tensor write less per identity block, bit-identical.
-DEFER_RESIDUAL = __import__("os").environ.get("RCF_DEFER_RESIDUAL", "1") != "0"
-# training-mode batch norm + ReLU keeps the sign bits of its output (1/16 of the output's bytes) for the backward pass
-RELU_BITMASK = True
+# How the step is scheduled (second stream, fused batch-norm forms, pair planes, the folded conv + norm, ...): ONE documented
+# object, rcf_amd.config.SCHED (class config.Schedule), read at call time.  Tools and tests set its fields explicitly.
+from .config import SCHED  # noqa: E402
+
 # test hook (tests/test_model_gpu.py::test_train_step_all_grads_at_fixed_relu_pattern): a list that receives, in forward
 # order, the boolean map `output > 0` of every batch norm + ReLU -- the activation pattern of this evaluation
 RELU_TRACE = None
-# convs on the fp16-pair kernels (3 partial products; operand ranges from ops.absmax) instead of bf16 triples (6)
-FP16_PAIRS = True
-# fp32 step: the batch norms between the bottlenecks' convs write their outputs (bn1, bn2: only so; the joins: also so) and their
-# input gradients as fp16 pair planes, and those convs run on the kernels that take both operands by LDS-DMA (csrc/igemm_h2d.inc,
-# igemm_h2dw.inc): no split, no LDS store in any of the three conv directions.  RCF_PLANES=0: every conv splits its fp32 operands
-# in registers as before.
-PLANES = __import__("os").environ.get("RCF_PLANES", "1") != "0"
-# which bottleneck JOINS (relu(bn3 + identity): fp32 copy needed by the next residual add) are ALSO written as planes for the next
-# block's conv1 / downsample conv: "stage" = only in front of a stage's first block (its two convs read them; the wide downsample
-# conv gains 7-15 %), "all" = every join.  A join's planes cost 8 more bytes per element in an HBM-bound pass (0.05-0.17 ms per join)
-# while an identity block's 1x1 conv1 (short K, epilogue-bound) gains 0.02-0.13 ms from them: measured per layer in
-# profiles/r04_layers_planes_ab.txt, as a step in profiles/r04_ab_join_planes.txt.
-JOIN_PLANES = __import__("os").environ.get("RCF_JOIN_PLANES", "stage")
-# bf16 step: 1x1 conv -> training-mode batch norm (-> + residual -> ReLU) as one tile -- the bottlenecks' conv3 / bn3 / join and
-# the stride-1 downsample conv + norm -- with neither the conv output nor its gradient in memory (conv_bn_fold below;
-# csrc/foldbn.hip).  RCF_FOLD_BN=0: the three-pass form (conv, statistics, apply; reduce, apply, data / weight gradient).
-FOLD_BN = __import__("os").environ.get("RCF_FOLD_BN", "1") != "0"
-FOLD_MAX_K = 512            # the Gram matrix of the conv's input costs 2 rows K^2 FLOPs: conv3 (K <= 512), not layer4's downsample
-FOLD_MASKED_DGRAD = __import__("os").environ.get("RCF_FOLD_MASKED_DGRAD", "1") != "0"
 _side_streams = {}
 
 
 def _side_stream(device):
     s = _side_streams.get(device.index)
     if s is None:
-        # RCF_SIDE_PRIORITY: -1 = high priority for the second stream (experiment knob; default: the same priority)
-        prio = int(__import__("os").environ.get("RCF_SIDE_PRIORITY", "0"))
+        # SCHED.side_priority: -1 = high priority for the second stream (experiment knob; default: the same priority)
+        prio = int(SCHED.side_priority)
         s = _side_streams[device.index] = torch.cuda.Stream(device=device, priority=prio)
     return s
 
@@ -285,7 +242,7 @@ class Conv2d(nn.Module):
     def _derived(self, kind, make):
         """an operand derived from self.weight (its range, its fp16 planes, its bf16 copies), made once per weight update
         instead of once per launch: valid while the weight's storage, torch version and the library's weight epoch stand"""
-        if not CACHE_WEIGHT_OPERANDS:
+        if not SCHED.cache_weight_operands:
             return make()
         key = ops.weight_key(self.weight)
         cache = self.__dict__.setdefault("_wcache", {})
@@ -303,7 +260,7 @@ class Conv2d(nn.Module):
         """can this conv take its input AND its output gradient as fp16 pair planes (forward, data gradient and weight gradient
         on the LDS-DMA kernels)?  Channel counts: 16-channel K-steps inside one tap, 64-channel groups of the weight gradient.
         act_dtype: the forward pass's activation type (Tape.act_dtype): planes exist in the fp32 step only."""
-        return (PLANES and FP16_PAIRS and act_dtype == torch.float32 and self.bias is None and not self.act
+        return (SCHED.planes and SCHED.fp16_pairs and act_dtype == torch.float32 and self.bias is None and not self.act
                 and self.cin % 64 == 0 and self.cout % 16 == 0 and self.cout >= 64      # (the plane weight gradient's tiles: >= 64 rows)
                 and self.cin_pad == self.cin and self.cout_pad == self.cout)
 
@@ -340,7 +297,7 @@ class Conv2d(nn.Module):
             raise ops._lib.RcfHipError("bf16 conv with Cin % 8 != 0: bias-free stem on an 8-channel-padded input only")
         wpad = self._derived("w_cin8", lambda: ops.nchw_to_nhwc(self.weight.detach().contiguous(), c8).permute(0, 3, 1, 2))
         wb = self._derived("bf16_cin8", lambda: ops.weight_bf16(wpad))
-        want = bool(stats) and FUSE_BN_STATS
+        want = bool(stats) and SCHED.fuse_bn_stats
         bn = stats if isinstance(stats, BatchNorm2d) else None
         res = ops.conv2d_fwd_bf16(x.t, wpad, wb, None, self.stride, self.padding, self.dilation, stats=want, bn=bn if want else None)
         if want:
@@ -378,7 +335,7 @@ class Conv2d(nn.Module):
             ya = Act(y)
         else:
             w, b = self.weight, self.bias
-            if stats and FUSE_BN_STATS and b is None and out is None:
+            if stats and SCHED.fuse_bn_stats and b is None and out is None:
                 bn = stats if isinstance(stats, BatchNorm2d) else None
                 y, sums = ops.conv2d_fwd_bf16(x.t, w, self._derived("bf16", lambda: ops.weight_bf16(w)), None, self.stride,
                                               self.padding, self.dilation, stats=True, bn=bn)
@@ -418,7 +375,7 @@ class Conv2d(nn.Module):
                     gx, beta = x.grad_slot()
                     wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
                     tile = 64 if self.cin <= 64 else (128 if self.cin <= 128 else 256)
-                    if (FOLD_MASKED_DGRAD and x.relu_out and x.first_reader is tok and wt is not None and self.stride == 1
+                    if (SCHED.fold_masked_dgrad and x.relu_out and x.first_reader is tok and wt is not None and self.stride == 1
                             and self.cin % tile == 0 and gx.dtype == torch.bfloat16 and x.t.dtype == torch.bfloat16):
                         # x is the output of a folded conv + norm + ReLU and this is the LAST writer of its gradient: the mask of
                         # that ReLU and the column sums its backward needs come out of this epilogue (no pass over the gradient)
@@ -432,10 +389,10 @@ class Conv2d(nn.Module):
                 if self.weight.requires_grad:
                     padded = wk is not self.weight
                     dw = torch.empty_like(wk) if padded else _param_grad(self.weight)
-                    if OVERLAP_WGRAD and x.needs_grad and not padded:
+                    if SCHED.overlap_wgrad and x.needs_grad and not padded:
                         side = _side_stream(dy.device)
-                        if LATE_WGRAD:
-                            dgrad()                   # see LATE_WGRAD: the weight gradient beside the next batch-norm backward
+                        if SCHED.late_wgrad:
+                            dgrad()                   # see SCHED.late_wgrad: the weight gradient beside the next batch-norm backward
                         side.wait_stream(torch.cuda.current_stream(dy.device))
                         with torch.cuda.stream(side):
                             ops.conv2d_wgrad_bf16(x.t, dy, wk, dw, self.stride, self.padding, self.dilation, beta=1)
@@ -470,10 +427,10 @@ class Conv2d(nn.Module):
         if x.first_reader is None:
             x.first_reader = tok                   # first reader in forward order = last writer of x's gradient in the backward pass
             # ... and as such it can take the identity branch's deferred gradient as a masked addend (checked again at launch)
-            x.addend_ok = (DEFER_RESIDUAL and FP16_PAIRS and tape.enabled and out is None and w is self.weight and
+            x.addend_ok = (SCHED.defer_residual and SCHED.fp16_pairs and tape.enabled and out is None and w is self.weight and
                            (self.cin in (64, 128) or self.cin % 256 == 0))
         yamax = None
-        if FP16_PAIRS:
+        if SCHED.fp16_pairs:
             own = w is self.weight                                       # padded copies are rebuilt per call: not cached
             ax = x.range()
             aw = self._derived("amax", lambda: ops.absmax(ops.weight_rsck(w))) if own else ops.absmax(ops.weight_rsck(w))
@@ -481,7 +438,7 @@ class Conv2d(nn.Module):
                 wp = self._derived("pairs", lambda: ops.weight_pairs(w, aw)) if own else ops.weight_pairs(w, aw)
             if stats and out is None and ops.fused_stats_available():
                 yamax = ops.new_amax(xin.device)   # the output's range from the epilogue: the following batch norm's bound needs it
-        if stats and FUSE_BN_STATS and b is None and not self.act and out is None and self.cout_pad == self.cout \
+        if stats and SCHED.fuse_bn_stats and b is None and not self.act and out is None and self.cout_pad == self.cout \
                 and ops.fused_stats_available():
             bn = stats if isinstance(stats, BatchNorm2d) else None
             y, sums = ops.conv2d_fwd_stats(xin, w, self.stride, self.padding, self.dilation, amax=(ax, aw), w_pairs=wp, bn=bn,
@@ -499,7 +456,7 @@ class Conv2d(nn.Module):
         ya.accepts_plane_grad = use_pl
         if tape.enabled:
             def bwd():
-                ady = ya.take_grad_range() if FP16_PAIRS else None    # shared by the data and the weight gradient
+                ady = ya.take_grad_range() if SCHED.fp16_pairs else None    # shared by the data and the weight gradient
                 dpl = ya.grad_is_planes                                # the batch norm's backward wrote dy as fp16 pair planes
                 dy = ya.take_grad()
                 if self.act:
@@ -511,7 +468,7 @@ class Conv2d(nn.Module):
 
                 def late_dgrad():
                     wpt = None
-                    if FP16_PAIRS and w is self.weight and ady is not None and aw is not None:
+                    if SCHED.fp16_pairs and w is self.weight and ady is not None and aw is not None:
                         wpt = self._derived("pairs_t", lambda: ops.weight_pairs_t(w, aw))
                     can_add = (x.pending_add is not None and x.first_reader is tok and wpt is not None and
                                ops.dgrad_takes_addend(w, x.t.shape, self.stride, self.padding, self.dilation, ops.pitch_of(dy),
@@ -519,8 +476,8 @@ class Conv2d(nn.Module):
                     gx, beta = x.grad_slot(takes_addend=can_add)
                     add = x.take_pending() if (can_add and beta == 0) else None
                     # the range of dx comes out of the epilogue (after the accumulation when beta = 1): exact for the whole tensor
-                    gamax = ops.new_amax(dy.device) if FP16_PAIRS and wpt is not None and ops.fused_stats_available() else None
-                    bnb = x.bn_ctx if (FUSE_BN_BWD and wpt is not None and x.first_reader is tok) else None
+                    gamax = ops.new_amax(dy.device) if SCHED.fp16_pairs and wpt is not None and ops.fused_stats_available() else None
+                    bnb = x.bn_ctx if (SCHED.fuse_bn_bwd and wpt is not None and x.first_reader is tok) else None
                     r = ops.conv2d_dgrad(dy, w, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
                                          amax=(ady, aw), w_pairs_t=wpt, dy_planes=dpl, amax_y=gamax, bn_bwd=bnb, addend=add)
                     x.grad_amax = gamax
@@ -530,17 +487,17 @@ class Conv2d(nn.Module):
                 xw, xpl = (x.planes, True) if (dpl and use_pl) else (x.t, False)      # the weight gradient's x in dy's format
                 if self.weight.requires_grad:
                     if self.cin_pad == self.cin and self.cout_pad == self.cout:
-                        if OVERLAP_WGRAD and x.needs_grad:
+                        if SCHED.overlap_wgrad and x.needs_grad:
                             side = _side_stream(dy.device)
-                            if LATE_WGRAD:
+                            if SCHED.late_wgrad:
                                 # the data gradient first, alone; the weight gradient starts when it is done and so runs beside
                                 # the NEXT layer's batch-norm backward (HBM-bound) instead of beside this layer's data
                                 # gradient (MFMA-bound like itself)
                                 late_dgrad()
-                            side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready (LATE_WGRAD: the data gradient is done)
+                            side.wait_stream(torch.cuda.current_stream(dy.device))       # dy is ready (SCHED.late_wgrad: the data gradient is done)
                             with torch.cuda.stream(side):
                                 ops.conv2d_wgrad(xw, dy, w, _param_grad(self.weight), self.stride, self.padding,
-                                                 self.dilation, beta=1, amax=(ax, ady), small_tile=LATE_WGRAD, planes=xpl)
+                                                 self.dilation, beta=1, amax=(ax, ady), small_tile=SCHED.late_wgrad, planes=xpl)
                             dy.record_stream(side)
                             xw.record_stream(side)
                         else:
@@ -570,6 +527,19 @@ class Conv2d(nn.Module):
         return ya
 
 
+def _residual_norm_sums(residual, dy, y, relu, rmask, chan_scale):
+    """local backward sums [sum g | sum g xhat] of the plain norm that produced `residual` (Act.bn_in), g = the join's output
+    gradient dy under the join's own ReLU mask -- what that norm's backward would reduce from its output gradient; None when the
+    residual is not such a norm's output or somebody else also feeds its gradient"""
+    if (residual is None or not residual.needs_grad or residual.bn_in is None or residual.grad is not None or
+            residual.pending_add is not None or chan_scale is not None or not relu or (rmask is None and y is None)):
+        return None
+    xr, mean_r, invstd_r = residual.bn_in
+    if xr.dtype != dy.dtype or tuple(xr.shape) != tuple(dy.shape):
+        return None
+    return ops.bn_bwd_reduce(dy, xr, y, mean_r, invstd_r, True, relu_mask=rmask)
+
+
 class BatchNorm2d(nn.Module):
     """(Sync)BatchNorm2d, eps 1e-5, momentum 0.1, with fused ReLU / residual add / Dropout2d scale.
     Same parameter and buffer names as torch's (state-dict compatible)."""
@@ -591,7 +561,7 @@ class BatchNorm2d(nn.Module):
             return False
         if self.sync and dist is not None and dist.on:
             return True
-        return self if FUSE_BN_FINALIZE else True
+        return self if SCHED.fuse_bn_finalize else True
 
     def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None, planes=None):
         """planes: "only" / "both" -- the output is (also) wanted as fp16 pair planes for the conv(s) that read it (Act.planes;
@@ -616,12 +586,12 @@ class BatchNorm2d(nn.Module):
             count = 0
             mean, invstd = self.running_mean, ops.bn_invstd_from_var(self.running_var, self.eps)
         rmask = None
-        if relu and tape.enabled and RELU_BITMASK:
+        if relu and tape.enabled and SCHED.relu_bitmask:
             # the backward kernels read this (one byte per 4 channels) instead of y
             rmask = torch.empty(xt.numel() // 4, dtype=torch.uint8, device=xt.device)
         ydt = out.dtype if out is not None else (tape.act_dtype if xt.dtype == torch.float32 else xt.dtype)
-        yamax = ops.new_amax(xt.device) if FP16_PAIRS and ydt == torch.float32 else None
-        pl = (planes if PLANES and FP16_PAIRS and planes in ("only", "both") and out is None and chan_scale is None and
+        yamax = ops.new_amax(xt.device) if SCHED.fp16_pairs and ydt == torch.float32 else None
+        pl = (planes if SCHED.planes and SCHED.fp16_pairs and planes in ("only", "both") and out is None and chan_scale is None and
               xt.dtype == torch.float32 and ydt == torch.float32 and x.amax is not None and xt.shape[3] % 8 == 0 and
               xt.is_contiguous() and (residual is None or residual.t.dtype == torch.float32) else None)
         if pl == "only" and (RELU_TRACE is not None or (relu and tape.enabled and rmask is None)):
@@ -639,26 +609,39 @@ class BatchNorm2d(nn.Module):
         if tape.enabled:
             if not self.training:
                 raise RuntimeError("tape backward through eval-mode BN is not implemented")
+            if not relu and residual is None and chan_scale is None and dist is not None and dist.on:
+                ya.bn_in = (xt, mean, invstd)
             if relu and rmask is not None and chan_scale is None and xt.dtype == torch.float32 and ydt == torch.float32 and xt.is_contiguous():
                 ya.bn_ctx = (xt, rmask, mean, invstd)
 
             def bwd():
                 # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
                 # are the only readers); the bound needs the ranges of x and of dy
-                dpl = (x.accepts_plane_grad and PLANES and xt.dtype == torch.float32 and x.amax is not None
+                dpl = (x.accepts_plane_grad and SCHED.planes and xt.dtype == torch.float32 and x.amax is not None
                        and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
                 ady = ya.take_grad_range() if dpl else None
                 dy = ya.take_grad()
                 s2, ya.grad_sums2 = ya.grad_sums2, None          # from the epilogue of the data gradient that wrote dy last
-                if s2 is None:
-                    s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
                 s2_local = None
-                if dist is not None and dist.on:
-                    s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them
-                    dist.allreduce_sum(s2)
+                if isinstance(s2, tuple):                        # (global, local): exchanged already, together with the join's own
+                    s2, s2_local = s2
+                else:
+                    if s2 is None:
+                        s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
+                    if dist is not None and dist.on:
+                        s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them
+                        r_s2 = _residual_norm_sums(residual, dy, y, relu, rmask, chan_scale)
+                        if r_s2 is not None:
+                            # a stage's first block: the downsample norm's backward sums depend on this join's masked output
+                            # gradient only -- one exchange for both norms instead of two latency-bound ones
+                            r_local = r_s2.clone()
+                            dist.allreduce_sum_many([s2, r_s2])
+                            residual.grad_sums2 = (r_s2, r_local)
+                        else:
+                            dist.allreduce_sum(s2)
                 dres, rbeta = (None, 0)
                 if residual is not None and residual.needs_grad:
-                    if (DEFER_RESIDUAL and relu and rmask is not None and chan_scale is None and residual.addend_ok and residual.grad is None
+                    if (SCHED.defer_residual and relu and rmask is not None and chan_scale is None and residual.addend_ok and residual.grad is None
                             and residual.pending_add is None and dy.dtype == torch.float32 and residual.t.dtype == torch.float32
                             and dy.is_contiguous()):
                         residual.pending_add = (dy, rmask)       # the identity's gradient = dy under this join's mask: not written here
@@ -669,7 +652,7 @@ class BatchNorm2d(nn.Module):
                             # downsample norms' backward a pass over their 4C-wide output gradient)
                             residual.grad_amax = ady
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
-                gamax = x.grad_amax = ops.new_amax(dy.device) if FP16_PAIRS and xt.dtype == torch.float32 else None
+                gamax = x.grad_amax = ops.new_amax(dy.device) if SCHED.fp16_pairs and xt.dtype == torch.float32 else None
                 ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
@@ -683,8 +666,8 @@ class BatchNorm2d(nn.Module):
 def fold_ok(conv, bn, x, residual=None):
     """can conv (1x1, stride 1) -> bn (training mode) [-> + residual] [-> ReLU] run as conv_bn_fold?"""
     t = x.t
-    return (FOLD_BN and t.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
-            and not conv.act and bn.training and conv.cin % 64 == 0 and conv.cin <= FOLD_MAX_K
+    return (SCHED.fold_bn and t.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
+            and not conv.act and bn.training and conv.cin % 64 == 0 and conv.cin <= SCHED.fold_max_k
             and (conv.cout in (64, 128) or conv.cout % 256 == 0) and t.is_contiguous() and bn.num_features == conv.cout
             and (residual is None or (residual.t.dtype == torch.bfloat16 and tuple(residual.t.shape[:3]) == tuple(t.shape[:3])
                                       and residual.t.shape[3] == conv.cout)))
@@ -747,7 +730,18 @@ def conv_bn_fold(conv, bn, x, tape, relu, residual=None, dist=None):
             s2_local = None
             if dist is not None and dist.on:
                 s2_local = sums2.clone()             # dgamma / dbeta stay per rank; the gradient all-reduce adds them
-                dist.allreduce_sum(sums2)
+                r_s2 = None
+                if residual is not None and residual.needs_grad and residual.bn_in is not None and residual.grad is g:
+                    # a stage's first block: the (plain) downsample norm's backward sums from the same g, in the same exchange
+                    xr, mean_r, invstd_r = residual.bn_in
+                    if xr.dtype == g.dtype:
+                        r_s2 = ops.bn_bwd_reduce(g, xr, None, mean_r, invstd_r, False)
+                if r_s2 is not None:
+                    r_local = r_s2.clone()
+                    dist.allreduce_sum_many([sums2, r_s2])
+                    residual.grad_sums2 = (r_s2, r_local)
+                else:
+                    dist.allreduce_sum(sums2)
             negT, c0 = ops.fold_bwd_prepare(
                 G, P, A1, w, sums2, s2_local, count, mean, invstd, bn.weight, _param_grad(w) if w.requires_grad else None,
                 _param_grad(bn.weight) if bn.weight.requires_grad else None, _param_grad(bn.bias) if bn.bias.requires_grad else None)
@@ -873,7 +867,7 @@ def commuted_concat_conv(a, b, conv, tape):
     # operand ranges of the fp16-pair kernels: bilinear interpolation is a convex combination (|Uup| <= max |b|),
     # and one range serves both halves of the weight
     ra = rb = rw = pa = pb = None
-    h2 = FP16_PAIRS and not bf
+    h2 = SCHED.fp16_pairs and not bf
     if h2:
         ra, rb, rw = a.range(), b.range(), ops.absmax(ops.weight_rsck(W))
         pa, pb = ops.weight_pairs(wa, rw), ops.weight_pairs(wbt, rw)
@@ -960,7 +954,7 @@ def pair_concat(x, tape, B, I, order=None):
                 ops.copy2d(x.t[b * I + order[i]], C, out[b][..., i * C:], I * C, HW, C)
     ya = Act(out)
     ya.amax = x.amax                 # the same values in another order: the range the producer left is this tensor's range
-    if x.planes is not None and batched and C % 2 == 0 and PLANES:
+    if x.planes is not None and batched and C % 2 == 0 and SCHED.planes:
         # the fp16 pair planes travel too ([pixel][h: C fp16 | m: C fp16] = C floats per pixel, h first): the pair's h halves side
         # by side, then its m halves -- two launches of C / 2 floats per pixel each, same bound
         pl = torch.empty((B, H, W, I * C), dtype=torch.float32, device=x.t.device)

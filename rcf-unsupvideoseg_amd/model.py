@@ -199,7 +199,7 @@ class RCFModel(nn.Module):
         ahead of the student's, and on one communicator every statistics all-reduce of the student would queue behind
         all of the teacher's -- the two forwards would serialise across ranks.  The group is created EAGERLY by the trainer
         (`Trainer.__init__`, next to its gradient group: `new_group` is a collective of its own, not something to hide inside
-        a forward) and only on request, RCF_TEACHER_GROUP=1: no multi-GPU run of this repo has exercised three concurrent RCCL
+        a forward) and only on request, SCHED.teacher_group: no multi-GPU run of this repo has exercised three concurrent RCCL
         communicators yet, so the default shares the student's communicator (correct, slower in stage 2.1)."""
         d = self._dist()
         t = getattr(self, "_tdist", None)
@@ -207,7 +207,7 @@ class RCFModel(nn.Module):
 
     def make_teacher_group(self):
         """collective: every rank calls it at the same point (Trainer.__init__)"""
-        if self._dist().on and self.w_crf > 0 and self.crf_use_ema and os.environ.get("RCF_TEACHER_GROUP", "0") == "1":
+        if self._dist().on and self.w_crf > 0 and self.crf_use_ema and layers.SCHED.teacher_group:
             import torch.distributed as tdist
             self._tdist = DistCtx(group=tdist.new_group())
 
@@ -225,7 +225,7 @@ class RCFModel(nn.Module):
         x = imgs.reshape(B * I, C3, H, W).contiguous().float()
         if not x.is_cuda:
             raise RuntimeError("RCFModel (HIP) needs the batch on the GPU: there is no CPU fallback")
-        if self._act_dtype == torch.bfloat16 and layers.BF16_STEM:
+        if self._act_dtype == torch.bfloat16 and layers.SCHED.bf16_stem:
             # bf16 step: the stem conv takes bf16 operands like every other conv (torch autocast casts conv1's input too)
             return Act(ops.cast(ops.nchw_to_nhwc(x, 8), torch.bfloat16), needs_grad=False)
         return Act(ops.nchw_to_nhwc(x, 4), needs_grad=False)
@@ -247,11 +247,11 @@ class RCFModel(nn.Module):
         tape = Tape(on_mark=self.grad_ready_hook, act_dtype=self._act_dtype)
         img = self._images_nhwc(imgs)
         crf_side = None
-        if self.w_crf > 0 and self.crf_use_ema and layers.OVERLAP_TEACHER:
+        if self.w_crf > 0 and self.crf_use_ema and layers.SCHED.overlap_teacher:
             # the EMA teacher's forward + CRF need only the images: run them on the second stream beside the student's
             # forward (its HBM-bound BN passes and the teacher's MFMA-bound convs fill each other's gaps)
             crf_side = layers._side_stream(img.t.device)
-            if layers.FP16_PAIRS and img.t.dtype == torch.float32:
+            if layers.SCHED.fp16_pairs and img.t.dtype == torch.float32:
                 img.range()      # on THIS stream, before the fork: teacher and student stems share the cached range
             ops.reserve_amax(img.t.device, 512)     # the teacher's range slots: zero-filled before the fork as well
             crf_side.wait_stream(torch.cuda.current_stream(img.t.device))

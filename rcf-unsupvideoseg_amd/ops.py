@@ -160,7 +160,7 @@ def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w
     Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
     ax, aw, ady = amax if amax is not None else (None, None, None)
     kind = "w" if aw is None else ("d" if ax is None else "f")
-    if kind not in H2_KINDS:                      # debug knob: which launches may take the fp16-pair kernels
+    if kind not in SCHED.h2_kinds:                      # debug knob: which launches may take the fp16-pair kernels
         ax = aw = ady = w_pairs = w_pairs2_t = None
     return ConvShape(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x_pitch, y_pitch or Cout,
                      _addr(ax), _addr(aw), _addr(ady), None, _addr(w_pairs_t), _addr(w_pairs), _addr(w_pairs2_t), _addr(amax_y),
@@ -177,7 +177,7 @@ CONV_FLAGS = 0
 
 
 _amax_pool = {}
-H2_KINDS = __import__("os").environ.get("RCF_H2_KINDS", "fdw")      # f: forward, d: data gradient, w: weight gradient
+from .config import SCHED  # noqa: E402  (SCHED.h2_kinds: which conv directions may take the fp16-pair kernels)
 
 
 def new_amax(device):
@@ -392,7 +392,7 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
     _need_cuda(dy, w)
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.float32, device=dy.device)
-    if amax is None or amax[0] is None or amax[1] is None or "d" not in H2_KINDS:
+    if amax is None or amax[0] is None or amax[1] is None or "d" not in SCHED.h2_kinds:
         w_pairs_t = None
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
                     amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
@@ -436,7 +436,7 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
 def dgrad_takes_addend(w, xshape, stride, pad, dil, dy_pitch, amax, w_pairs_t, dy_planes):
     """can conv2d_dgrad(addend=...) run for this launch?  (rcf_conv2d_dgrad_bnsums_ok: fp16-pair kernels with prepared weights, Cin
     a whole column tile)"""
-    if amax is None or amax[0] is None or amax[1] is None or w_pairs_t is None or "d" not in H2_KINDS:
+    if amax is None or amax[0] is None or amax[1] is None or w_pairs_t is None or "d" not in SCHED.h2_kinds:
         return False
     s = _conv_shape(xshape, xshape[3], w, stride, pad, dil, dy_pitch, amax=(None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
                     flags=_lib.CONV_DY_PLANES if dy_planes else 0)

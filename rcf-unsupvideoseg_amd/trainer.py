@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import config, ops
 
 
 def poly_lr_factor(epoch, epochs, power, base_lr, min_lr):
@@ -78,9 +78,6 @@ class FlatParams:
     def zero_grad(self):
         ops.fill(self.grad, 0.0)
         self.bind_grads()
-
-
-BULK_WEIGHT_PREP = __import__("os").environ.get("RCF_BULK_WEIGHT_PREP", "1") != "0"    # A/B knob
 
 
 class WeightPrep:
@@ -150,7 +147,7 @@ class WeightPrep:
     def run(self):
         """rebuild every derived operand from the current weights and install them in the layers' caches"""
         from . import layers
-        if self.n == 0 or not layers.CACHE_WEIGHT_OPERANDS:
+        if self.n == 0 or not layers.SCHED.cache_weight_operands:
             return
         if [ops.weight_rsck(m.weight).data_ptr() for m in self.convs] != self.ptrs:
             return                                          # the parameters moved (e.g. .to()): the per-layer path takes over
@@ -198,12 +195,12 @@ class Trainer:
         # The gradient chunks travel on their OWN communicator: with one process group the asynchronous 10-60 MB chunk
         # all-reduces and the small synchronous SyncBN all-reduces of the layers still in backward would share one
         # RCCL stream in issue order, and every statistics exchange would queue behind the chunk before it.
-        # RCF_GRAD_GROUP=0: the chunks share the default group (fallback: two RCCL communicators in flight at once is the
-        # configuration no multi-GPU box has exercised yet)
-        own_group = __import__("os").environ.get("RCF_GRAD_GROUP", "1") != "0"
+        # SCHED.grad_group (default False): the chunks share the default group -- two RCCL communicators in flight at once is a
+        # configuration no multi-GPU box has exercised yet, so it is opt-in until a measured run exists
+        own_group = bool(config.SCHED.grad_group)
         self.grad_group = dist.new_group() if (self.chunked and own_group) else None
         if self.chunked and hasattr(self.model, "make_teacher_group"):
-            self.model.make_teacher_group()                 # stage 2.1, RCF_TEACHER_GROUP=1: created here, collectively
+            self.model.make_teacher_group()                 # stage 2.1, SCHED.teacher_group: created here, collectively
         self._pending, self._done = [], set()
         self.prep = None                                    # WeightPrep, built after the first optimizer step
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
@@ -241,7 +238,7 @@ class Trainer:
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
                       self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)
-        if self.prep is None and BULK_WEIGHT_PREP:
+        if self.prep is None and config.SCHED.bulk_weight_prep:
             prec = self.model.precision or ("bf16" if torch.is_autocast_enabled() else "fp32")     # RCFModel._select_precision
             self.prep = WeightPrep(self.model, prec, self.device)
         if self.prep is not None:

@@ -318,10 +318,8 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     e_g = gradnorm_dev(m)
     # The module gradient norms of this randomly initialised net are a NOISY statistic of the bf16 roundings: the two K orders
     # of the 3x3 convs (csrc/rcf_common.h rcf_kchunk) are the same arithmetic at the same accuracy against float64 and move
-    # the backbone's norm deviation between 0.045 and 0.12 at 96x160.  So the statistic is taken over both roundings (both are
-    # reported) and their MEAN is held to the bound; everything else in this test is from the default order.  (Round 4 measured
-    # the same lottery in fp32, where nothing is rounded to 8 bits: equally valid fp32 evaluations of this step move the backbone's
-    # norm by 1-2e-3 at 8 x 480x854 while every one of them is 1.5e-2 from float64 as a vector: profiles/r04_grad_spread_probe.txt.)
+    # the backbone's norm deviation by several percent at 96x160 -- the second order is run and REPORTED as that spread; the
+    # bound below is on the shipped order alone.
     e_g_alt = None
     if tag == "small":
         from rcf_amd import _lib
@@ -365,9 +363,9 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
             " ref autocast: " + " ".join(f"{v:.3f}" for v in rate_r))
     report(msg)
     assert all(e_l[k] < max(3 * ref["loss"][k], 5e-3) for k in e_l), e_l
-    e_gm = e_g if e_g_alt is None else {k: 0.5 * (e_g[k] + e_g_alt[k]) for k in e_g}
-    assert all(e_gm[k] < max(3 * ref["gradnorm"][k], 0.10) for k in e_gm), (e_g, e_g_alt)
-    assert all(e_g[k] < max(3 * ref["gradnorm"][k], 0.20) for k in e_g), e_g                  # a single rounding: twice the floor
+    # the SHIPPED K order is held to the bound (round 5: with conv3 -> bn3 folded, the norm sees fp32 accumulators and every
+    # module's norm sits at 2-6 % at 96x160); the other order is reported above as the spread of the statistic, not averaged in
+    assert all(e_g[k] < max(3 * ref["gradnorm"][k], 0.10) for k in e_g), (e_g, e_g_alt)
     assert float(mism.float().mean()) < 2 * ref["argmax_mismatch_frac"] + 0.01
     assert n_sure_bad == 0
     assert all(h < 1.5 * r + 0.02 for h, r in zip(rate_h, rate_r)), (rate_h, rate_r)

@@ -123,7 +123,8 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     count, (n_st, n_te) = res[0][2], res[0][3]
     # student: forward + backward; the teacher (stage 2.1, in training mode like the reference's) forward only; each network
     # has four bottlenecks with a downsample branch
-    want = 2 * n_st - 4 + ((n_te - 4) if n_te else 0)
+    # ... and each stage-first block's join and downsample norms share their BACKWARD exchange too (round 5): 2 n - 8 for the student
+    want = 2 * n_st - 8 + ((n_te - 4) if n_te else 0)
     report(f"2-rank {mode} step vs single process: losses {e}; gradient norm {e_gn:.1e}; SyncBN collectives per rank {count} for {n_st} "
            f"student + {n_te} teacher norms (one per norm and direction would be {2 * n_st + n_te})")
     tol = 2e-2 if mode == "bf16" else 2e-4         # bf16: the two ranks round their halves of the batch independently
@@ -241,7 +242,8 @@ def test_rccl_world1_dry_run_of_chunked_allreduce(report):
     report(f"SyncBN collectives in one step (RCCL, world 1, 64x96 frames): {st['count']} all-reduces for {st['n_bn']} batch norms, "
            f"{st['bytes']} bytes in total; device time per collective mean {st['mean_us']:.1f} us, max {st['max_us']:.1f} us, "
            f"sum {st['total_ms']:.2f} ms of a {st['step_ms']:.1f} ms step")
-    assert st["count"] == 2 * st["n_bn"] - 4 and st["n_bn"] >= 50       # the four conv1 / downsample pairs share one exchange each
+    # the four conv1 / downsample pairs share one forward exchange each, the four join / downsample pairs one backward exchange
+    assert st["count"] == 2 * st["n_bn"] - 8 and st["n_bn"] >= 50
     rcf_amd, m, nb = _setup()
     tr = rcf_amd.Trainer(m, device="cuda:0")
     want = [float(tr.step(_batch(nb, slice(0, B), "cuda:0"))["loss"]) for _ in range(2)]
@@ -285,4 +287,7 @@ def test_bench_self_launches_its_ranks(report):
     report(f"python bench.py --gpus 2 (self-launched, gloo, shared GPU): {d['value']} frames/s; "
            f"bf16 {d.get('bf16_frames_per_s')} frames/s")
     assert d["n_gpus"] == 2 and d["config"]["global_pairs"] == 2 and d["value"] > 0
-    assert d["bf16_frames_per_s"] > 0 and d["roofline"]["bf16_step_frames_per_s"] == d["bf16_frames_per_s"]
+    # the contract line: short enough for the driver's 8 KB stdout tail, the detail on the prefixed line before it
+    assert d["bf16_frames_per_s"] > 0 and len(lines[0]) <= 2048 and "frac" in d["roofline"]
+    detail = [l for l in r.stdout.splitlines() if l.startswith("BENCH_DETAIL ")]
+    assert len(detail) == 1 and json.loads(detail[0][len("BENCH_DETAIL "):])["bf16_step"]["frames_per_s"] == d["bf16_frames_per_s"]

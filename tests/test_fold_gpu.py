@@ -180,8 +180,8 @@ class RefBottleneck(torch.nn.Module):
 
 
 def _run_stage(stage, x, dy, fold):
-    saved = layers.FOLD_BN
-    layers.FOLD_BN = fold
+    saved = layers.SCHED.fold_bn
+    layers.SCHED.fold_bn = fold
     try:
         for p_ in stage.parameters():
             p_.grad = None
@@ -195,7 +195,7 @@ def _run_stage(stage, x, dy, fold):
         grads = {n: p_.grad.detach().float().cpu().clone() for n, p_ in stage.named_parameters()}
         return ya.t.float().cpu(), xa.grad.float().cpu(), grads
     finally:
-        layers.FOLD_BN = saved
+        layers.SCHED.fold_bn = saved
 
 
 @pytest.mark.parametrize("geom", [(2, 64, 64, 1, 1, 24, 31, 3), (2, 256, 128, 1, 2, 16, 21, 2), (1, 512, 256, 1, 2, 14, 17, 2)])

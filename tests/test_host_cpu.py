@@ -267,3 +267,33 @@ def test_grad_sketch_estimates_vector_distance_and_matches_the_committed_fixture
     names = {n for n, p in m.named_parameters() if p.requires_grad}
     assert set(fx["sketch_f64"]) <= names and all(len(v) == fx["sketch_k"] for v in fx["sketch_f64"].values())
     assert set(fx["vector_fp32_err"]) == set(fx["gradnorm_f64"]) == {n.split(".")[0] for n in fx["sketch_f64"]}
+
+
+def test_schedule_object_is_the_only_home_of_the_step_knobs(monkeypatch):
+    """rcf_amd.config.Schedule: documented fields, explicit setters, no environment feed; the package's modules read
+    config.SCHED at call time, and the only environment variables the package still reads are the two documented ones"""
+    import glob
+    import re
+    from rcf_amd import config, layers, ops
+    assert layers.SCHED is config.SCHED and ops.SCHED is config.SCHED
+    d = config.Schedule().as_dict()
+    assert d["overlap_wgrad"] and d["late_wgrad"] and d["planes"] and d["fold_bn"] and not d["fuse_bn_bwd"]
+    assert d["grad_group"] is False and d["teacher_group"] is False          # one communicator until a multi-GPU run exists
+    for k in d:
+        assert re.search(r"\b" + k + r"\b", config.Schedule.__doc__), f"Schedule.{k} is not documented"
+    sc = config.Schedule()
+    old = sc.set(fold_bn=False, join_planes="all")
+    assert old == {"fold_bn": True, "join_planes": "stage"} and sc.fold_bn is False and sc.join_planes == "all"
+    sc.parse(["fold_bn=1", "side_priority=-1", "h2_kinds=fd", "overlap_wgrad=0"])
+    assert sc.fold_bn is True and sc.side_priority == -1 and sc.h2_kinds == "fd" and sc.overlap_wgrad is False
+    with pytest.raises(AttributeError):
+        sc.set(no_such_knob=1)
+    monkeypatch.setenv("RCF_FOLD_BN", "0")
+    assert config.Schedule().fold_bn is True                                  # the environment does not feed it
+    pkg = os.path.dirname(os.path.abspath(rcf_amd.__file__))
+    envs = set()
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        if os.path.basename(f) == "build.py":
+            continue
+        envs |= set(re.findall(r"environ(?:\.get)?[\[(]\s*\"(RCF_[A-Z0-9_]+)\"", open(f).read()))
+    assert envs <= {"RCF_CONV_FLAGS", "RCF_DEBUG_WEIGHT_CACHE"}, envs

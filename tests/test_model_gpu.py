@@ -115,17 +115,23 @@ def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
     assert e_after < 1e-2
 
 
-def test_train_step_all_grads_at_fixed_relu_pattern(monkeypatch, report):
-    """EVERY parameter gradient against float64 with the ReLU lottery taken out.  A ReLU unit whose pre-activation lies
+@pytest.mark.parametrize("H,W,B", [(64, 96, 2), (480, 854, 1)])
+def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, monkeypatch, report):
+    """EVERY parameter gradient against float64 with the ReLU lottery taken out -- at the small geometry and at the FULL
+    480x854 frame size (one pair: the float64 oracle fits a host's memory), so that a full-size shape meets the tight
+    criterion too.  A ReLU unit whose pre-activation lies
     within fp32 noise of zero falls either way in two equally valid fp32 evaluations, and one such unit moves a channel's
-    weight gradient by percent -- which is why the test above needs a 1e-2 floor that would also hide a real precision
+    weight gradient by percent -- a natural-pattern comparison needs a floor (1e-2) that would also hide a real precision
     loss.  Here the float64 truth (and the CPU fp32 yardstick) are evaluated AT THE ACTIVATION PATTERN OF THE HIP RUN:
     the HIP forward records `output > 0` of every batch norm + ReLU (layers.RELU_TRACE), and the oracle's F.relu is
     replaced by a multiplication with those masks.  With the pattern fixed the network is smooth in its parameters, so
     what remains is arithmetic error: limit 6x the CPU fp32 run's own error at the same pattern, floor 1e-4."""
     import rcf_torch as orc
     from rcf_amd import layers
-    H, W, B = 64, 96, 2
+    if H * W > 100000:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+        if avail < 40:
+            pytest.skip(f"the float64 oracle at {H}x{W} needs ~25 GB of host memory ({avail:.0f} GB available)")
     hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
     tr = rcf_amd.Trainer(hip, device=DEV)
     tr.fp.zero_grad()
@@ -173,7 +179,7 @@ def test_train_step_all_grads_at_fixed_relu_pattern(monkeypatch, report):
             bad.append((n, e_hip, e_ref))
         if e_hip / max(e_ref, 1e-7) > worst_ratio:
             worst_ratio, worst_name, worst_abs, worst_ref = e_hip / max(e_ref, 1e-7), n, e_hip, e_ref
-    report(f"all-grads at the HIP run's ReLU pattern ({len(masks)} ReLU layers, {sum(int(m.numel()) for m in masks)} units) vs "
+    report(f"all-grads at the HIP run's ReLU pattern, {H}x{W} B={B} ({len(masks)} ReLU layers, {sum(int(m.numel()) for m in masks)} units) vs "
            f"float64: loss {e_loss:.2e}; worst HIP / CPU-fp32 error ratio {worst_ratio:.2f} at {worst_name} (HIP {worst_abs:.2e}, "
            f"CPU fp32 {worst_ref:.2e}); parameters over max(6x ref, 1e-4): {len(bad)} {bad[:4]}")
     assert e_loss < 1e-5 and not bad, bad

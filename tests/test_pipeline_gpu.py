@@ -101,7 +101,7 @@ def test_bulk_weight_preparation_equals_the_per_layer_path(prec):
     batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
     losses = {}
     for bulk in (True, False):
-        trainer.BULK_WEIGHT_PREP = bulk
+        rcf_amd.config.SCHED.bulk_weight_prep = bulk
         m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
         shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
@@ -132,13 +132,13 @@ def test_bulk_weight_preparation_equals_the_per_layer_path(prec):
                     assert torch.equal(c["bf16"][1], ops.weight_bf16(w)) and torch.equal(c["bf16_t"][1], ops.weight_bf16(w, True))
                 checked += 1
             assert checked == tr.prep.n
-    trainer.BULK_WEIGHT_PREP = True
+    rcf_amd.config.SCHED.bulk_weight_prep = True
     assert losses[True] == losses[False], losses
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_second_stream_for_weight_gradients_changes_nothing(prec):
-    """the optional second HIP stream for the weight gradients (RCF_OVERLAP_WGRAD=1; off by default since round 3) only
+    """the optional second HIP stream for the weight gradients (config.SCHED.overlap_wgrad) only
     reorders independent launches: losses of three steps and the parameters after them are identical with and without it"""
     import copy
     import types
@@ -149,13 +149,13 @@ def test_second_stream_for_weight_gradients_changes_nothing(prec):
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_t", object_channel=None)
     nb = synth.make_batch(B, H, W, config_id=1)
     batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
-    saved = layers.OVERLAP_WGRAD, layers.LATE_WGRAD
+    saved = layers.SCHED.overlap_wgrad, layers.SCHED.late_wgrad
     res = {}
     try:
         # False / True: one stream / the weight gradient beside its layer's data gradient; "late": started after the data
-        # gradient, i.e. beside the next layer's batch-norm backward (RCF_LATE_WGRAD=1; fp32 path)
+        # gradient, i.e. beside the next layer's batch-norm backward (SCHED.late_wgrad; fp32 path)
         for overlap in (False, True, "late"):
-            layers.OVERLAP_WGRAD, layers.LATE_WGRAD = bool(overlap), overlap == "late"
+            layers.SCHED.overlap_wgrad, layers.SCHED.late_wgrad = bool(overlap), overlap == "late"
             m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
             shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
             m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
@@ -164,6 +164,6 @@ def test_second_stream_for_weight_gradients_changes_nothing(prec):
             torch.cuda.synchronize()
             res[overlap] = (losses, tr.fp.flat.clone())
     finally:
-        layers.OVERLAP_WGRAD, layers.LATE_WGRAD = saved
+        layers.SCHED.overlap_wgrad, layers.SCHED.late_wgrad = saved
     assert res[False][0] == res[True][0] == res["late"][0], (res[False][0], res[True][0], res["late"][0])
     assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][1], res["late"][1])

@@ -171,10 +171,10 @@ def test_training_step_with_and_without_pair_planes(report):
     from rcf_amd import config, layers, synth
     H, W, B = 96, 160, 2
     res = {}
-    saved = layers.PLANES
+    saved = layers.SCHED.planes
     try:
         for on in (True, False):
-            layers.PLANES = on
+            layers.SCHED.planes = on
             kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
             kw.update(log_interval=10 ** 9, train_iter=1)
             args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
@@ -205,7 +205,7 @@ def test_training_step_with_and_without_pair_planes(report):
                     gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
             res[on] = ({k: float(v) for k, v in losses.items()}, {k: v ** 0.5 for k, v in gn.items()}, calls["n"])
     finally:
-        layers.PLANES = saved
+        layers.SCHED.planes = saved
     e_l = max(abs(res[True][0][k] - res[False][0][k]) / abs(res[False][0][k]) for k in res[True][0])
     e_g = {k: abs(res[True][1][k] - v) / v for k, v in res[False][1].items()}
     report(f"training step, pair planes on vs off: {res[True][2]} / {res[False][2]} weight gradients on the plane kernel; losses {e_l:.1e}; "
@@ -283,16 +283,16 @@ def test_data_gradient_bnsums_refuses_what_it_cannot_do():
 
 def test_training_step_with_and_without_fused_bn_backward_sums(report):
     """the same step with the batch-norm backward sums taken from the data gradients' epilogues (default) and by the reduction
-    pass (RCF_FUSE_BN_BWD=0): identical forward, gradients at summation-order level; how many norms still run the pass"""
+    pass (SCHED.fuse_bn_bwd off): identical forward, gradients at summation-order level; how many norms still run the pass"""
     import copy
     import types
     from rcf_amd import config, layers, synth
     H, W, B = 96, 160, 2
     res = {}
-    saved = layers.FUSE_BN_BWD
+    saved = layers.SCHED.fuse_bn_bwd
     try:
         for on in (True, False):
-            layers.FUSE_BN_BWD = on
+            layers.SCHED.fuse_bn_bwd = on
             kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
             kw.update(log_interval=10 ** 9, train_iter=1)
             args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
@@ -320,7 +320,7 @@ def test_training_step_with_and_without_fused_bn_backward_sums(report):
             grads = {n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None}
             res[on] = ({k: float(v) for k, v in losses.items()}, grads, calls["n"])
     finally:
-        layers.FUSE_BN_BWD = saved
+        layers.SCHED.fuse_bn_bwd = saved
     assert res[True][0] == res[False][0], "the forward pass does not depend on the switch"
     worst = max((float((res[True][1][n] - g).norm() / g.norm()), n) for n, g in res[False][1].items() if float(g.norm()) > 0)
     report(f"training step, batch-norm backward sums from the data gradients' epilogues: {res[False][2]} -> {res[True][2]} reduction passes; "
@@ -379,16 +379,16 @@ def test_data_gradient_with_masked_addend(case, report):
 
 def test_training_step_with_and_without_deferred_residual_gradient(report):
     """the same step with the identity branches' gradients added in conv1's data-gradient epilogue (default) and written by the
-    join's batch-norm backward (RCF_DEFER_RESIDUAL=0): every parameter gradient BIT-identical; how many joins defer"""
+    join's batch-norm backward (SCHED.defer_residual off): every parameter gradient BIT-identical; how many joins defer"""
     import copy
     import types
     from rcf_amd import config, layers, synth
     H, W, B = 96, 160, 2
     res = {}
-    saved = layers.DEFER_RESIDUAL
+    saved = layers.SCHED.defer_residual
     try:
         for on in (True, False):
-            layers.DEFER_RESIDUAL = on
+            layers.SCHED.defer_residual = on
             kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
             kw.update(log_interval=10 ** 9, train_iter=1)
             args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
@@ -420,7 +420,7 @@ def test_training_step_with_and_without_deferred_residual_gradient(report):
             res[on] = ({k: float(v) for k, v in losses.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
                        dict(calls))
     finally:
-        layers.DEFER_RESIDUAL = saved
+        layers.SCHED.defer_residual = saved
     assert res[True][0] == res[False][0]
     diff = [n for n, g in res[False][1].items() if not torch.equal(g, res[True][1][n])]
     report(f"training step, deferred residual gradients: {res[True][2]['add']} of 16 joins add in conv1's epilogue "

@@ -24,8 +24,15 @@ def _kwargs(H, W):
     return config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
 
 
-def test_stage21_step_vs_oracle(report):
-    H, W, B = 64, 96, 2
+@pytest.mark.parametrize("H,W,B", [(64, 96, 2), (480, 854, 1)])
+def test_stage21_step_vs_oracle(H, W, B, report):
+    """one stage-2.1 step (EMA teacher forward -> CRF self-labels -> loss_crf -> backward -> EMA update) against the oracle, at
+    the small geometry and at the FULL 480x854 frame size (one pair): the CRF runs at image size, so this is where the
+    HIP mean-field CRF and the oracle's C restatement have to agree on 2 x 409 920 pixels for the losses to agree"""
+    if H * W > 100000:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+        if avail < 24:
+            pytest.skip(f"the oracle's step at {H}x{W} needs ~12 GB of host memory ({avail:.0f} GB available)")
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_s2", object_channel=1)
     hip = rcf_amd.RCFModel(args, **copy.deepcopy(_kwargs(H, W)))
     okw = copy.deepcopy(_kwargs(H, W))
@@ -58,8 +65,10 @@ def test_stage21_step_vs_oracle(report):
     gn_h = sum(float(p.grad.double().pow(2).sum()) for n, p in hip.named_parameters() if p.grad is not None and n.startswith("decode_head2.")) ** 0.5
     gn_o = sum(float(p.grad.double().pow(2).sum()) for n, p in ora.named_parameters() if p.grad is not None and n.startswith("decode_head2.")) ** 0.5
     e["gradnorm_dh2"] = rel(gn_h, gn_o)
-    report(f"stage 2.1 step vs oracle: {e} ema {e_ema:.2e}")
-    assert max(e.values()) < 2e-4 and e_ema < 1e-4
+    agree = float(((hip.last_targets["crf_masks"].cpu().reshape(-1) - lo["_crf_masks"].detach().reshape(-1)).abs() < 1e-5).float().mean())
+    report(f"stage 2.1 step vs oracle {H}x{W} B={B}: {e} ema {e_ema:.2e}; CRF targets at mask size equal on {agree:.6f} of the pixels")
+    assert max(e.values()) < 2e-4 and e_ema < 1e-4                      # (measured at 480x854: losses 3e-7, gradient norm 8e-5)
+    assert agree > 0.9995
 
 
 @pytest.mark.parametrize("variant", list(config.STAGE2_VARIANTS))

@@ -1,8 +1,8 @@
 """A/B of the training step's schedule and operand format in ONE process (boxes differ by more than the effects): the weight
-gradients on the main stream / on a second stream beside the layer's data gradient / started after it (layers.LATE_WGRAD), with
-the fp16 pair planes (layers.PLANES) on and off.  Interleaved rounds, median of 3 x 6 steps.
-usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins|defer|prio]   (defer: layers.DEFER_RESIDUAL on / off; joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
-backward sums from the data gradients' epilogues (layers.FUSE_BN_BWD) on and off)"""
+gradients on the main stream / on a second stream beside the layer's data gradient / started after it (layers.SCHED.late_wgrad), with
+the fp16 pair planes (layers.SCHED.planes) on and off.  Interleaved rounds, median of 3 x 6 steps.
+usage: python tools/ab_schedule.py [fp32|bf16] [bnsums|joins|defer|prio]   (defer: layers.SCHED.defer_residual on / off; joins: which join outputs are also written as planes; bnsums: the default schedule and the one-stream order with the batch-norm
+backward sums from the data gradients' epilogues (layers.SCHED.fuse_bn_bwd) on and off)"""
 import os, sys, time, types
 import numpy as np
 import torch
@@ -24,26 +24,26 @@ batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows"
 configs = {}
 for planes in ((True, False) if prec == "fp32" else (False,)):
     for name, ov, late in (("one stream", False, False), ("two streams, beside dgrad", True, False), ("two streams, LATE", True, True)):
-        configs[f"{name}, planes {'on' if planes else 'off'}"] = (ov, late, planes, layers.FUSE_BN_BWD)
+        configs[f"{name}, planes {'on' if planes else 'off'}"] = (ov, late, planes, layers.SCHED.fuse_bn_bwd)
 if len(sys.argv) > 2 and sys.argv[2] == "bnsums":
     configs = {}
     for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)):
         for fuse in (True, False):
             configs[f"{name}, bn sums {'from the dgrad epilogue' if fuse else 'by the reduction pass'}"] = (ov, late, prec == "fp32", fuse)
 if len(sys.argv) > 2 and sys.argv[2] == "defer":
-    # the identity branches' gradients added in conv1's data-gradient epilogue (layers.DEFER_RESIDUAL) or written by the join's
+    # the identity branches' gradients added in conv1's data-gradient epilogue (layers.SCHED.defer_residual) or written by the join's
     # batch-norm backward and accumulated onto
-    configs = {f"{name}, {'deferred residual gradients' if d else 'identity gradients written'}": (ov, late, prec == "fp32", layers.FUSE_BN_BWD, d)
+    configs = {f"{name}, {'deferred residual gradients' if d else 'identity gradients written'}": (ov, late, prec == "fp32", layers.SCHED.fuse_bn_bwd, d)
                for name, ov, late in (("one stream", False, False), ("two streams, LATE", True, True)) for d in (True, False)}
 prio = len(sys.argv) > 2 and sys.argv[2] == "prio"
 if prio:
-    # HIP priority of the second stream (the weight gradients): 0 = the default, 1 = low, -1 = high (layers._side_stream, RCF_SIDE_PRIORITY)
-    configs = {f"two streams, LATE, second stream priority {p}": (True, True, prec == "fp32", layers.FUSE_BN_BWD, p) for p in (0, 1, -1)}
+    # HIP priority of the second stream (the weight gradients): 0 = the default, 1 = low, -1 = high (layers._side_stream, SCHED.side_priority)
+    configs = {f"two streams, LATE, second stream priority {p}": (True, True, prec == "fp32", layers.SCHED.fuse_bn_bwd, p) for p in (0, 1, -1)}
 joins = len(sys.argv) > 2 and sys.argv[2] == "joins"
 if joins:
     # which tensors exist as planes beside their fp32 copy: the bottleneck joins (all / only in front of a stage's first block) and
     # the last stage's output for the decode heads; default schedule
-    configs = {f"joins {j}, heads {'on' if h else 'off'}": (True, True, True, layers.FUSE_BN_BWD, j, h)
+    configs = {f"joins {j}, heads {'on' if h else 'off'}": (True, True, True, layers.SCHED.fuse_bn_bwd, j, h)
                for j in ("all", "stage") for h in (True, False)}
 for _ in range(4):
     tr.step(batch)
@@ -51,15 +51,15 @@ res = {k: [] for k in configs}
 for r in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for name, cfg in configs.items():
         ov, late, planes, fuse = cfg[:4]
-        layers.OVERLAP_WGRAD, layers.LATE_WGRAD, layers.PLANES, layers.FUSE_BN_BWD = ov, late, planes, fuse
+        layers.SCHED.overlap_wgrad, layers.SCHED.late_wgrad, layers.SCHED.planes, layers.SCHED.fuse_bn_bwd = ov, late, planes, fuse
         if prio:
             torch.cuda.synchronize()
-            os.environ["RCF_SIDE_PRIORITY"] = str(cfg[4])
+            layers.SCHED.side_priority = int(cfg[4])
             layers._side_streams.clear()
         elif joins:
-            layers.JOIN_PLANES, model.backbone2.heads_take_planes = cfg[4], cfg[5]
+            layers.SCHED.join_planes, model.backbone2.heads_take_planes = cfg[4], cfg[5]
         elif len(cfg) == 5:
-            layers.DEFER_RESIDUAL = cfg[4]
+            layers.SCHED.defer_residual = cfg[4]
         tr.step(batch)
         tr.step(batch)
         torch.cuda.synchronize()

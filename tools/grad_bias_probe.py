@@ -74,7 +74,7 @@ if os.environ.get("PROBE", "kinds") == "spread":
     for nz, sd in ((2.0 ** -24, 1), (2.0 ** -24, 2), (2.0 ** -22, 3), (2.0 ** -22, 4)):
         loss, g = run(nz, sd); record(f"fp32 img*(1+-2^{int(np.log2(nz))}) s{sd}", g, loss)
     ops.set_conv_flags(old); ops.weights_changed()
-    layers.PLANES = False
+    layers.SCHED.planes = False
     loss, g = run(); record("pairs", g, loss)
     loss, g = run(2.0 ** -24, 1); record("pairs img 2^-24 s1", g, loss)
     loss, g = run(2.0 ** -24, 2); record("pairs img 2^-24 s2", g, loss)
@@ -82,8 +82,8 @@ else:
     cases = [("pairs fdw, planes", "fdw", True), ("pairs fdw", "fdw", False), ("pairs f only", "f", False), ("pairs d only", "d", False),
              ("pairs w only", "w", False), ("bf16 triples everywhere", "", False), ("pairs fd", "fd", False)]
     for name, kinds, planes in cases:
-        ops.H2_KINDS = kinds
-        layers.PLANES = planes
+        rcf_amd.config.SCHED.h2_kinds = kinds
+        layers.SCHED.planes = planes
         ops.weights_changed()
         loss, g = run()
         record(name, g, loss)

@@ -1,5 +1,5 @@
 """Where does the HIP step's gradient differ from the float64 truth at BASELINE configs[1]'s real batch (8 pairs of 480x854)?
-Per parameter: |g - truth| / |truth| of (a) the HIP fp32 step as shipped, (b) with RCF_PLANES off, (c) on the exact fp32 matrix-core
+Per parameter: |g - truth| / |truth| of (a) the HIP fp32 step as shipped, (b) with SCHED.planes off, (c) on the exact fp32 matrix-core
 kernels, and (d) of the oracle's own fp32 evaluation -- and the same for the per-module norms the parity test uses.
 Needs a GPU, ~100 GB of host memory and ~5 minutes on the GPU box's host (usage: python tools/grad_error_b8.py [B] [out.txt])."""
 import copy, os, sys, time, types
@@ -70,9 +70,9 @@ def oracle_run(double):
 
 runs = {}
 runs["hip"] = hip_run()
-layers.PLANES = False
+layers.SCHED.planes = False
 runs["hip_noplanes"] = hip_run()
-layers.PLANES = True
+layers.SCHED.planes = True
 old = ops.set_conv_flags(_lib.CONV_FP32_MFMA(0))
 ops.weights_changed()
 runs["hip_fp32mfma"] = hip_run()

@@ -38,8 +38,8 @@ def main():
             "conv_bf16_fwd", "conv_bf16_fwd_narrow", "conv_bf16_dgrad_wide", "conv_bf16_dgrad_other", "conv_bf16_wgrad4",
             "conv_bf16_wgrad_other"]
     peak = 2500.0 if prec == "bf16" else 2500.0 / 3
-    for overlap, planes in (((False, True), (False, False)) if ab else ((True, layers.PLANES), (False, layers.PLANES))):
-        layers.OVERLAP_WGRAD, layers.PLANES = overlap, planes
+    for overlap, planes in (((False, True), (False, False)) if ab else ((True, layers.SCHED.planes), (False, layers.SCHED.planes))):
+        layers.SCHED.overlap_wgrad, layers.SCHED.planes = overlap, planes
         tr.step(batch)
         tr.step(batch)
         nsteps = 3
@@ -63,7 +63,7 @@ def main():
             ms = r["ms"] / r["launches"]
             tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
             print(f"{fam:22s} {tag:58s} x{n:2d}  {ms:7.3f} ms  {r['ms'] / nsteps:7.3f} ms/step  {tf:7.1f} TF/s  {tf / peak:5.3f}")
-    layers.OVERLAP_WGRAD = False
+    layers.SCHED.overlap_wgrad = False
 
 
 if __name__ == "__main__":

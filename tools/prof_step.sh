@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: tools/prof_step.sh <tag> <fp32|bf16> [steps]  -> gpurun_out/prof_<tag>/ (rocprofv3 --kernel-trace --stats, csv) of
+# usage: tools/prof_step.sh <tag> <fp32|bf16> [steps] [pairs] [schedule_field=value ...]  -> gpurun_out/prof_<tag>/ (rocprofv3 --kernel-trace --stats, csv) of
 # tools/step_prof.py; prints the top of the kernel statistics with per-step milliseconds
-tag=$1; prec=$2; steps=${3:-4}
+tag=$1; prec=$2; steps=${3:-4}; pairs=${4:-8}; shift 4 2>/dev/null || shift $#
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-setsid rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o p -- python3 $R/tools/step_prof.py $prec $steps > $R/gpurun_out/prof_$tag.log 2>&1 &
+setsid rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o p -- python3 $R/tools/step_prof.py $prec $steps $pairs "$@" > $R/gpurun_out/prof_$tag.log 2>&1 &
 pid=$!
 ( sleep ${PROF_LIMIT:-420}; kill -KILL -- -$pid 2>/dev/null ) &
 wd=$!

@@ -1,6 +1,6 @@
 """Runs `steps` training steps of one precision ("fp32" | "bf16") at the bench geometry -- the program to put behind
 `rocprofv3 --kernel-trace --stats --` when only one leg of bench.py is wanted.
-usage: python tools/step_prof.py bf16 [steps=4] [pairs=8]"""
+usage: python tools/step_prof.py bf16 [steps=4] [pairs=8] [schedule_field=value ...]   (rcf_amd.config.Schedule fields, e.g. fold_bn=0)"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from rcf_amd import config, synth
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+config.SCHED.parse(sys.argv[4:])
 H, W = 480, 854
 dev = torch.device("cuda:0")
 args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=None, eval_save=False, eval_export=False)
