@@ -507,6 +507,12 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
  * SMALL_TABLE = packed build whose first-attempt table is tiny, so every frame takes the overflow path (tests) */
 #define RCF_CRF_BUILD_ARRAY 0x100
 #define RCF_CRF_BUILD_SMALL_TABLE 0x200
+/* SORT = the appearance lattice by ONE device-wide radix sort of all frames' (packed key, entry) pairs + run heads + scan
+ * instead of the hash table (the sort / unique / scan form of SURVEY section 7 step 6): vertices numbered in key order, neighbour
+ * search as a merge.  Slower than the packed build on natural frames (a few 10^4 vertices per frame), faster on noise-like
+ * ones (10^6 vertices): what the caller picks when the previous call's vertex counts were high (rcf_amd.crf.CRFHead).
+ * Needs keys that fit 12 bits per coordinate and batch <= 16; otherwise the default build runs. */
+#define RCF_CRF_BUILD_SORT 0x300
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

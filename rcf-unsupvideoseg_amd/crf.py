@@ -21,7 +21,7 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
                      want_q=False, want_nvert=False, symmetric=False, build=0):
     """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2]).
     symmetric: pydensecrf's DenseCRF2D kernel normalisation (NORMALIZE_SYMMETRIC) instead of tools/torchCRF's.
-    build: 0 default, 1 RCF_CRF_BUILD_ARRAY, 2 RCF_CRF_BUILD_SMALL_TABLE (identical results; tests)"""
+    build: 0 default, 1 RCF_CRF_BUILD_ARRAY, 2 RCF_CRF_BUILD_SMALL_TABLE, 3 RCF_CRF_BUILD_SORT (identical results)"""
     _check(rgb_u8, "rgbFeat")
     _check(unary, "unaryEnergy")
     n = rgb_u8.shape[0]
@@ -76,6 +76,34 @@ class CRFHead(nn.Module):
         self.refine_iters, self.crf_scale = refine_iters, crf_scale
         self._mean, self._std = tuple(mean), tuple(std)
         self._consts = None
+        # lattice build of the next call: "auto" = from the vertex counts of the PREVIOUS call (noise-like content -- more than
+        # SORT_ABOVE vertices per frame in the appearance lattice -- takes the sort build, RCF_CRF_BUILD_SORT, until a call comes
+        # in below SORT_BELOW); True / False = always / never.  Measured (tools/time_crf.py, profiles/r05_crf_sort_build.txt): the
+        # sort build wins from ~1.4 x 10^5 vertices per frame up (noise-like frames of any size), loses below ~7 x 10^4 (natural
+        # frames: 0.30 vs 0.43 ms per 480x854 frame).  The counts travel to the host by an asynchronous copy that is
+        # only read once its event has completed: no host wait, and the masks do not depend on the choice.
+        self.sort_build = "auto"
+        self.last_build = 0
+        self._nv_host = self._nv_evt = None
+        self._sorting = False
+
+    SORT_ABOVE, SORT_BELOW = 120000, 90000
+
+    def _pick_build(self, npix):
+        if self.sort_build != "auto":
+            return 3 if self.sort_build else 0
+        if self._nv_evt is not None and self._nv_evt.query():
+            verts = float(self._nv_host[:, 1].float().mean())
+            self._sorting = verts > (self.SORT_BELOW if self._sorting else self.SORT_ABOVE)
+            self._nv_evt = None
+        return 3 if self._sorting else 0
+
+    def _note_counts(self, nv):
+        if self._nv_host is None or self._nv_host.shape[0] != nv.shape[0]:
+            self._nv_host = torch.empty(tuple(nv.shape), dtype=nv.dtype, pin_memory=True)
+        self._nv_host.copy_(nv, non_blocking=True)
+        self._nv_evt = torch.cuda.Event()
+        self._nv_evt.record()
 
     def _mean_std(self, device):
         if self._consts is None or self._consts[0].device != device:
@@ -108,6 +136,11 @@ class CRFHead(nn.Module):
         symmetric kernel normalisation) instead of `crf` (torchcrf_cpp), batched on the GPU all the same."""
         rgb, unary = self.prepare(imgs, masks, unstandardize)
         N, H, W, _ = rgb.shape
+        auto = self.sort_build == "auto"
+        self.last_build = self._pick_build(H * W)
         m = crf_soft_batched(rgb, unary, W, H, self.scomp_smooth, self.sxy_smooth, self.scomp, self.sxy, self.srgb,
-                             self.refine_iters, symmetric=symmetric)
+                             self.refine_iters, symmetric=symmetric, want_nvert=auto, build=self.last_build)
+        if auto:
+            m, nv = m
+            self._note_counts(nv)
         return m.float()

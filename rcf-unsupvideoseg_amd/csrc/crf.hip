@@ -64,6 +64,9 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int cap_small;
     int *stat;                   // [F][4]  distinct keys of the small attempt, probe-limit flag, sampled distinct keys, -
     int sym;                     // 1: DenseCRF2D's symmetric kernel normalisation (rcf_crf_soft_ex), set per call by crf_infer
+    // sort build (build 3): rocPRIM's temporary storage, sized for F * E pairs
+    char *sort_tmp;
+    size_t sort_tmp_bytes;
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
@@ -777,6 +780,129 @@ __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
     }
 }
 
+// ---------------------------------------------------------------------------------- sort build
+// RCF_CRF_BUILD_SORT (build 3): the lattice by SORTING instead of hashing.  Every (pixel, remainder) entry of every frame of
+// the call becomes a 64-bit key (frame << 60 | packed lattice key) with its entry index as the value; one device-wide radix sort
+// (rocPRIM) puts a frame's entries in key order, i.e. grouped by vertex: the sorted sequence IS the CSR list, run heads are the
+// vertices, an inclusive scan numbers them.  Vertices come out numbered in KEY order, which is what makes this build worth its
+// sort on noise-like frames (millions of vertices met by one entry each): a blur pass gathers each vertex's two neighbours along
+// an axis, key + constant -- in key order those are two more nearly sequential streams instead of random 8-byte reads -- and the
+// neighbour search itself is a merge of two sorted sequences instead of six hash probes per vertex.  On natural frames (a few
+// 10^4 vertices, everything in L2 either way) the tile-local de-duplication of the packed build is cheaper than sorting 2.5 M
+// entries per frame (tools/lab/sort_lab.hip; profiles/r05_crf_sort_build.txt), so the packed build stays the default there.
+// Same lattice, same sums in fixed point: results are bit-identical to the other builds (tests/test_crf_gpu.py).
+constexpr unsigned long long KEY60 = (1ull << 60) - 1;
+
+template <int PD>
+__global__ void __launch_bounds__(256) sort_keys_kernel(Lattice Lt, const uint8_t *__restrict__ rgb, int W, float posdev,
+                                                        float featdev, unsigned long long *__restrict__ K, unsigned *__restrict__ V) {
+    const int pd = PD ? PD : Lt.pd;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= Lt.N) return;
+    int rem0[PD_MAX + 1], rank[PD_MAX + 1];
+    float bary[PD_MAX + 2];
+    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+    const long base = (long)f * Lt.E + p;
+    for (int r = 0; r <= pd; r++) {
+        short key[PD_MAX];
+        lattice_key(pd, r, rem0, rank, key);
+        const long e = base + (long)r * Lt.N;
+        K[e] = ((unsigned long long)f << 60) | pack64(key, pd);
+        V[e] = (unsigned)(r * Lt.N + p);
+        Lt.weight[e] = bary[r];
+    }
+}
+
+// flag = 1 at the first entry of every vertex (and of every frame)
+__global__ void __launch_bounds__(256) sort_heads_kernel(Lattice Lt, const unsigned long long *__restrict__ K, int *__restrict__ flag,
+                                                         long n) {
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long)gridDim.x * blockDim.x)
+        flag[g] = (g % Lt.E == 0 || K[g] != K[g - 1]) ? 1 : 0;
+}
+
+// sorted position g (frame f, CSR position i) -> the entry's vertex id, its CSR record, the vertex's list offset and key
+__global__ void __launch_bounds__(256) sort_scatter_kernel(Lattice Lt, const unsigned long long *__restrict__ K,
+                                                           const unsigned *__restrict__ V, const int *__restrict__ flag,
+                                                           const int *__restrict__ runs, unsigned long long *__restrict__ ukey) {
+    const int f = blockIdx.x;
+    const long fb = (long)f * Lt.E;
+    const int base = runs[fb] - 1;                        // inclusive scan: the frame's first entry is a head
+    for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < Lt.E; i += (long)gridDim.y * blockDim.x) {
+        const long g = fb + i;
+        const int v = runs[g] - 1 - base;
+        const unsigned e = V[g];
+        Lt.vid[fb + e] = v;
+        Lt.csr[g] = make_int2((int)(e % (unsigned)Lt.N), __float_as_int(Lt.weight[fb + e]));
+        if (flag[g]) {
+            Lt.off[fb + v] = (int)i;
+            ukey[fb + v] = K[g] & KEY60;
+        }
+        if (i == Lt.E - 1) Lt.L[f] = v + 1;
+    }
+}
+__global__ void __launch_bounds__(256) sort_cnt_kernel(Lattice Lt) {
+    const int f = blockIdx.x;
+    const long fb = (long)f * Lt.E, Lf = Lt.L[f];
+    for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x)
+        Lt.cnt[fb + v] = (v + 1 < Lf ? Lt.off[fb + v + 1] : (int)Lt.E) - Lt.off[fb + v];
+}
+
+// neighbours along every axis: the neighbour's packed key is this vertex's key PLUS A CONSTANT (no 12-bit field can wrap:
+// keys_fit_12bit), so the wanted keys of consecutive vertices are sorted like the keys themselves and their positions t(v) in the
+// key array are non-decreasing: a MERGE.  Two levels: a coarse kernel finds t for every 256th vertex (independent binary searches,
+// all in flight at once), the fine kernel searches each vertex inside [t(chunk start), t(next chunk start)] -- a window of a few
+// hundred keys that its workgroup keeps in L1/L2 -- without any barrier.
+__device__ __forceinline__ unsigned long long axis_delta(int pd, int axis) {
+    unsigned long long ones = 0;
+    for (int k = 0; k < pd; k++) ones |= 1ull << (12 * k);
+    return ones - (axis < pd ? ((unsigned long long)(pd + 1) << (12 * axis)) : 0ull);
+}
+__device__ __forceinline__ long lower_bound64(const unsigned long long *__restrict__ a, long lo, long hi, unsigned long long want) {
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (a[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <int PD>
+__global__ void __launch_bounds__(256) sort_neighbours_coarse_kernel(Lattice Lt, const unsigned long long *__restrict__ ukey,
+                                                                     int *__restrict__ coarse, int cstride) {
+    const int pd = PD ? PD : Lt.pd, nax = pd + 1;
+    const int f = blockIdx.x;
+    const long fb = (long)f * Lt.E, Lf = Lt.L[f];
+    const unsigned long long *uk = ukey + fb;
+    const long nchunk = (Lf + 255) / 256;
+    for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < nchunk * nax; i += (long)gridDim.y * blockDim.x) {
+        const int axis = (int)(i / nchunk);
+        const long c = i - (long)axis * nchunk;
+        coarse[((long)f * nax + axis) * cstride + c] = (int)lower_bound64(uk, 0, Lf, uk[c * 256] + axis_delta(pd, axis));
+    }
+}
+template <int PD>
+__global__ void __launch_bounds__(256) sort_neighbours_kernel(Lattice Lt, const unsigned long long *__restrict__ ukey,
+                                                              const int *__restrict__ coarse, int cstride) {
+    const int pd = PD ? PD : Lt.pd, nax = pd + 1;
+    const int f = blockIdx.x;
+    const long fb = (long)f * Lt.E, Lf = Lt.L[f];
+    const unsigned long long *uk = ukey + fb;
+    int *nb = Lt.nb + fb * 2 * nax;
+    const long nchunk = (Lf + 255) / 256;
+    for (long c = blockIdx.y; c < nchunk * nax; c += gridDim.y) {
+        const int axis = (int)(c / nchunk);
+        const long ch = c - (long)axis * nchunk, v = ch * 256 + threadIdx.x;
+        if (v >= Lf) continue;
+        const int *cw = coarse + ((long)f * nax + axis) * cstride;
+        const long lo = cw[ch], hi = ch + 1 < nchunk ? min((long)cw[ch + 1] + 1, Lf) : Lf;
+        const unsigned long long want = uk[v] + axis_delta(pd, axis);
+        const long t = lower_bound64(uk, lo, hi, want);
+        if (t < Lf && uk[t] == want) {
+            nb[((long)axis * Lt.E + v) * 2] = (int)t;
+            nb[((long)axis * Lt.E + t) * 2 + 1] = (int)v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- iteration
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -1156,6 +1282,8 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
     L.stat = c.take<int>((size_t)F * 4);
     L.cap_small = 0;
+    L.sort_tmp_bytes = rcf_crf_sort_tmp_bytes(FE);
+    L.sort_tmp = c.take<char>(L.sort_tmp_bytes);
 }
 
 struct CrfBuffers {
@@ -1230,13 +1358,48 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     return 0;
 }
 
+// RCF_CRF_BUILD_SORT: see "sort build" above.  Storage: the two key arrays alias `keys` (16 B per entry), the two value
+// arrays `entries`, the run flags `slot_vid`, the scanned run numbers `rel`, the vertices' keys `slot_vid2` / `slot_off`.
+int build_lattice_sorted(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev, hipStream_t st) {
+    const size_t FE = (size_t)F * L.E;
+    unsigned long long *K0 = reinterpret_cast<unsigned long long *>(L.keys), *K1 = K0 + FE;
+    unsigned *V0 = reinterpret_cast<unsigned *>(L.entries), *V1 = V0 + FE;
+    int *flag = L.slot_vid, *runs = L.rel;
+    unsigned long long *ukey = reinterpret_cast<unsigned long long *>(L.slot_vid2);
+    static_assert(sizeof(uint4) == 2 * sizeof(unsigned long long), "two key arrays in `keys`");
+    PD_LAUNCH(L.pd, sort_keys_kernel, dim3(rcf_cdiv(L.N, 256), F), dim3(256), st, L, rgb, W, posdev, featdev, K0, V0);
+    RCF_LAUNCH_CHECK();
+    int fbits = 0;
+    while ((1 << fbits) < F) ++fbits;
+    if (int e = rcf_crf_sort_pairs_u64(L.sort_tmp, L.sort_tmp_bytes, K0, K1, V0, V1, FE, 60 + fbits, st)) return e;
+    hipLaunchKernelGGL(sort_heads_kernel, dim3(4096), dim3(256), 0, st, L, (const unsigned long long *)K1, flag, (long)FE);
+    RCF_LAUNCH_CHECK();
+    if (int e = rcf_crf_inclusive_scan_i32(L.sort_tmp, L.sort_tmp_bytes, flag, runs, FE, st)) return e;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(F, 2048), dim3(256), 0, st, L, (const unsigned long long *)K1, (const unsigned *)V1,
+                       (const int *)flag, (const int *)runs, ukey);
+    hipLaunchKernelGGL(sort_cnt_kernel, dim3(F, 1024), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
+    int *coarse = L.slot_off;                                   // [F][pd + 1][E / 256 + 1] of its 2 F E ints
+    const int cstride = (int)(L.E / 256 + 1);
+    PD_LAUNCH(L.pd, sort_neighbours_coarse_kernel, dim3(F, 256), dim3(256), st, L, (const unsigned long long *)ukey, coarse, cstride);
+    PD_LAUNCH(L.pd, sort_neighbours_kernel, dim3(F, 4096), dim3(256), st, L, (const unsigned long long *)ukey, (const int *)coarse, cstride);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev, float weight,
                   hipStream_t st) {
     L.w = weight;
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
     if (L.build != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
-        if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) return e;
+        // the sort build for the appearance lattice only (the position lattice has a few hundred vertices whatever the frame
+        // shows); 60 key bits + up to 4 frame bits
+        if (L.build == 3 && L.pd == 5 && F <= 16) {
+            if (int e = build_lattice_sorted(L, rgb, W, H, F, posdev, featdev, st)) return e;
+        } else if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) {
+            return e;
+        }
         return build_lattice_norm(L, F, st);
     }
     CK(hipMemsetAsync(L.entries, 0xff, (size_t)F * 2 * L.E * sizeof(int), st));
@@ -1371,7 +1534,7 @@ extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, in
     // bits 8-9: lattice build (RCF_CRF_BUILD_*: tests and A/B measurements; identical results)
     const int build = (normalization >> 8) & 3;
     normalization &= 0xff;
-    if ((normalization != 0 && normalization != 1) || build == 3) return RCF_EINVAL;
+    if (normalization != 0 && normalization != 1) return RCF_EINVAL;
     return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
                          normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream, build);
 }

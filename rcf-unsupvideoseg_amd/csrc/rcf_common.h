@@ -19,6 +19,12 @@ static inline hipStream_t rcf_stream(void *s) { return (hipStream_t)s; }
 int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, double *scratch,
                         const rcf_bn_finalize *fin, void *stream);
 
+// csrc/crf_sort.hip: rocPRIM radix sort / inclusive scan for the sort-based lattice build (csrc/crf.hip)
+size_t rcf_crf_sort_tmp_bytes(size_t n);
+int rcf_crf_sort_pairs_u64(void *tmp, size_t tmp_bytes, const unsigned long long *k_in, unsigned long long *k_out,
+                           const unsigned *v_in, unsigned *v_out, size_t n, int end_bit, hipStream_t st);
+int rcf_crf_inclusive_scan_i32(void *tmp, size_t tmp_bytes, const int *in, int *out, size_t n, hipStream_t st);
+
 static inline int rcf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool rcf_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 

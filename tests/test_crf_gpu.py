@@ -108,6 +108,51 @@ def test_crf_build_variants_identical(report):
     assert same_map and dq == 0.0 and torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out[2][2])
 
 
+@pytest.mark.parametrize("kind,H,W,n", [("smooth", 120, 214, 3), ("noise", 120, 214, 3), ("smooth", 480, 854, 2), ("noise", 480, 854, 2),
+                                        ("mixed", 96, 160, 9)])
+def test_crf_sort_build_identical(kind, H, W, n, report):
+    """RCF_CRF_BUILD_SORT (radix sort / run heads / scan instead of the hash table; vertices numbered in key order, neighbours by
+    merging) against the default build: identical MAP, Q to the last bit (the splat's fixed-point sums do not depend on the list
+    order, the blur reads the same neighbours), identical vertex counts -- on smooth frames, noise frames, a batch that mixes
+    them (9 frames: 4 frame bits), both potentials on"""
+    from rcf_amd import synth
+    from rcf_amd.crf import crf_soft_batched
+    head = rcf_amd.CRFHead(None, refine_iters=5)
+    mk = lambda i: (synth.noise_rgb if (kind == "noise" or (kind == "mixed" and i % 2)) else synth.smooth_rgb)(H, W, 4300 + i)
+    imgs = torch.from_numpy(np.stack([synth.normalize_rgb(mk(i)) for i in range(n)])).to(DEV)
+    masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4300 + i) for i in range(n)])).to(DEV)
+    rgb, unary = head.prepare(imgs, masks)
+    res = {}
+    for pots in ((0.0, 0.0, 5.0, 60.0, 5.0), (3.0, 3.0, 5.0, 60.0, 5.0)):
+        a = crf_soft_batched(rgb, unary, W, H, *pots, 5, want_q=True, want_nvert=True, build=0)
+        b = crf_soft_batched(rgb, unary, W, H, *pots, 5, want_q=True, want_nvert=True, build=3)
+        res[pots[0]] = (bool(torch.equal(a[0], b[0])), float((a[1] - b[1]).abs().max()), bool(torch.equal(a[2], b[2])), a[2][:, 1].tolist())
+    report(f"crf sort build vs packed build [{kind} {H}x{W} x{n}]: appearance only: MAP equal {res[0.0][0]}, max |dQ| {res[0.0][1]:.1e}, "
+           f"vertex counts equal {res[0.0][2]} {res[0.0][3]}; both potentials: {res[3.0][:3]}")
+    for r in res.values():
+        assert r[0] and r[1] == 0.0 and r[2]
+
+
+def test_crf_head_picks_the_sort_build_for_noise_like_content(report):
+    """CRFHead chooses the lattice build from the vertex counts of its PREVIOUS call (an asynchronous copy, no host wait): noise-like
+    frames switch it to the sort build, natural ones back; the masks do not depend on the choice"""
+    from rcf_amd import synth
+    H, W, n = 120, 214, 4
+    head = rcf_amd.CRFHead(None, refine_iters=5)
+    ref = rcf_amd.CRFHead(None, refine_iters=5)
+    ref.sort_build = False
+    seq = []
+    for step, make in enumerate([synth.noise_rgb, synth.noise_rgb, synth.noise_rgb, synth.smooth_rgb, synth.smooth_rgb, synth.smooth_rgb]):
+        imgs = torch.from_numpy(np.stack([synth.normalize_rgb(make(H, W, 4400 + 10 * step + i)) for i in range(n)])).to(DEV)
+        masks = torch.from_numpy(np.stack([synth.soft_blob_mask(H, W, 4400 + i) for i in range(n)])).to(DEV)
+        out = head(imgs, masks)
+        torch.cuda.synchronize()                  # the test waits so that the next call sees this call's counts
+        seq.append(head.last_build)
+        assert torch.equal(out, ref(imgs, masks))
+    report(f"CRFHead build per call (3 noise calls, then 3 smooth ones): {seq}")
+    assert seq[0] == 0 and seq[1] == 3 and seq[2] == 3 and seq[3] == 3 and seq[4] == 0 and seq[5] == 0
+
+
 def test_offline_callers(report):
     """the offline 480x854 CRF callers (rcf_amd.offline): the pydenseCRF-style `refine` against the C restatement run
     on the same unary, and the double-CRF merge of semantic_constraints.py (unstandardize=False takes NHWC [0,1])"""
