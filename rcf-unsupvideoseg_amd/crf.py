@@ -30,7 +30,7 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
     dev = rgb_u8.device
     out = torch.empty((n, H, W), dtype=torch.int16, device=dev)
     q = torch.empty((n, H * W, 2), dtype=torch.float32, device=dev) if want_q else None
-    nv = torch.zeros((n, 2), dtype=torch.int32, device=dev) if want_nvert else None
+    nv = torch.empty((n, 2), dtype=torch.int32, device=dev) if want_nvert else None
     need = _lib.load().rcf_crf_workspace_bytes(W, H, n)
     ws = workspace(need, dev)
     _lib.call("rcf_crf_soft_ex", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
@@ -84,7 +84,7 @@ class CRFHead(nn.Module):
         # only read once its event has completed: no host wait, and the masks do not depend on the choice.
         self.sort_build = "auto"
         self.last_build = 0
-        self._nv_host = self._nv_evt = None
+        self._nv_host = None
         self._sorting = False
 
     SORT_ABOVE, SORT_BELOW = 120000, 90000
@@ -92,18 +92,19 @@ class CRFHead(nn.Module):
     def _pick_build(self, npix):
         if self.sort_build != "auto":
             return 3 if self.sort_build else 0
-        if self._nv_evt is not None and self._nv_evt.query():
+        if self._nv_host is not None:
+            # whatever the last completed copy left there (zeros before the first one): a count that is one or two calls old
+            # serves a heuristic as well as a fresh one, and no event / query is needed (a recorded event per call cost
+            # 0.3 ms per frame here: its release flushes the caches the next call's kernels were about to hit)
             verts = float(self._nv_host[:, 1].float().mean())
-            self._sorting = verts > (self.SORT_BELOW if self._sorting else self.SORT_ABOVE)
-            self._nv_evt = None
+            if verts > 0:
+                self._sorting = verts > (self.SORT_BELOW if self._sorting else self.SORT_ABOVE)
         return 3 if self._sorting else 0
 
     def _note_counts(self, nv):
         if self._nv_host is None or self._nv_host.shape[0] != nv.shape[0]:
-            self._nv_host = torch.empty(tuple(nv.shape), dtype=nv.dtype, pin_memory=True)
+            self._nv_host = torch.zeros(tuple(nv.shape), dtype=nv.dtype).pin_memory()
         self._nv_host.copy_(nv, non_blocking=True)
-        self._nv_evt = torch.cuda.Event()
-        self._nv_evt.record()
 
     def _mean_std(self, device):
         if self._consts is None or self._consts[0].device != device:

@@ -1146,6 +1146,13 @@ __global__ void __launch_bounds__(256) unary_from_label_kernel(const short *__re
     unary[p * 2 + 1] = b;
 }
 
+__global__ void vertex_counts_kernel(const int *__restrict__ Ls, const int *__restrict__ La, int32_t *__restrict__ nvert, int F) {
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        nvert[2 * f] = Ls ? Ls[f] : 0;
+        nvert[2 * f + 1] = La ? La[f] : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------- CRFHead prologue
 __device__ __forceinline__ unsigned to_u8(float v) {
     v = v * 255.f;
@@ -1481,13 +1488,10 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
         if (has_a) if (int e = apply_lattice(b.app, F, b.cur, unary, b.next, b.cur, (short *)out_map, has_s ? 0 : 1, 1, wm, st)) return e;
     }
     if (q_out) CK(hipMemcpyAsync(q_out, b.cur, n * MLAB * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (nvert) {
-        for (int f = 0; f < F; f++) {
-            if (has_s) CK(hipMemcpyAsync(nvert + 2 * f, b.smooth.L + f, sizeof(int), hipMemcpyDeviceToDevice, st));
-            else CK(hipMemsetAsync(nvert + 2 * f, 0, sizeof(int), st));
-            if (has_a) CK(hipMemcpyAsync(nvert + 2 * f + 1, b.app.L + f, sizeof(int), hipMemcpyDeviceToDevice, st));
-            else CK(hipMemsetAsync(nvert + 2 * f + 1, 0, sizeof(int), st));
-        }
+    if (nvert) {                                        // [F][2]: vertices of the position / appearance lattice (one launch)
+        hipLaunchKernelGGL(vertex_counts_kernel, dim3(1), dim3(64), 0, st, has_s ? b.smooth.L : (const int *)nullptr,
+                           has_a ? b.app.L : (const int *)nullptr, nvert, F);
+        RCF_LAUNCH_CHECK();
     }
     return 0;
 }

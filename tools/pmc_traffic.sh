@@ -31,8 +31,10 @@ for fam, pat in (("conv_h2d_dgrad", "conv_h2d_kernel<4, false, true,"), ("conv_h
                  ("conv_wgrad_h2d", "igemm_wgrad_h2d_kernel<4, false"), ("conv_wgrad_h2t4", "igemm_wgrad_h2t_kernel<4, false, true"), ("conv_x3_128x256", "igemm_conv_x3_kernel<2, 4, 2, 2, false, false, 2, true, true,"),
                  ("conv_dgrad_wide", "igemm_conv_x3_kernel<2, 4, 2, 2, false, true, 2, true, true,"),
                  ("conv_h2p_fwd", "conv_h2p_kernel<false>"), ("conv_h2p_dgrad", "conv_h2p_kernel<true>"),
-                 ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1>"),
-                 ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1>")):
+                 ("conv_bf16_wgrad4", "wgrad_bf16_dma_kernel<4, false, true"), ("conv_bf16_fwd", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1, 0>"),
+                 ("conv_bf16_fwd_folded", "conv_bf16_kernel<2, 4, 2, 2, false, false, true, true, 3, 1, 1>"),
+                 ("conv_bf16_dgrad_wide", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1, 0>"),
+                 ("conv_bf16_dgrad_masked", "conv_bf16_kernel<2, 4, 2, 2, false, true, true, true, 3, 1, 2>")):
     sel = [(k, n, f, w) for tot, k, n, f, w in rows if pat in k]
     if sel:
         nn = sum(n for _, n, _, _ in sel)
