@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(512, 1) k_teams(P p) {
         for (int i = 0; i < H; ++i) __builtin_amdgcn_s_barrier();
     }
     int st = 0;
+    bool prev_stores = false;
     for (int t = t0 + team; t < t1; t += 2) {
         int tm, tn;
         tile_mn(t, tm, tn);
@@ -474,12 +475,14 @@ __global__ void __launch_bounds__(512, 1) k_teams(P p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MR * NR - NLD, 0);
             // the previous tile's stores (older than everything issued in this tile) may still be in flight in the first slots:
             // in-order completion, so the counts below only ever wait for what the next slot needs
-            if (kt < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * NLD + STORES) : "memory");
+            // (only when the previous tile did issue all of its stores: not the first tile, not after a partial edge tile)
+            if (kt < 2 && prev_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * NLD + STORES) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * NLD) : "memory");
             __builtin_amdgcn_s_barrier();
             st = st == NST - 1 ? 0 : st + 1;
         }
         const bool live = tm < p.mtiles;
+        prev_stores = live && (tm + 1) * BM <= p.M && !(p.flags & 1);
 #pragma unroll
         for (int ch = 0; ch < E; ++ch) {
             if (live) store_chunk<MR, NR>(p, acc, tm * BM, tn * BN, arow0, brow0, lane, ch >> 1, ch & 1);
