@@ -614,10 +614,14 @@ class BatchNorm2d(nn.Module):
             if relu and rmask is not None and chan_scale is None and xt.dtype == torch.float32 and ydt == torch.float32 and xt.is_contiguous():
                 ya.bn_ctx = (xt, rmask, mean, invstd)
 
+            planes_at_fwd = bool(SCHED.planes)
+
             def bwd():
                 # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
                 # are the only readers); the bound needs the ranges of x and of dy
-                dpl = (x.accepts_plane_grad and SCHED.planes and xt.dtype == torch.float32 and x.amax is not None
+                # (decided with the FORWARD pass's setting: a conv whose input exists as planes only cannot take an fp32 gradient,
+                # whatever the schedule object says by the time the backward pass runs)
+                dpl = (x.accepts_plane_grad and planes_at_fwd and xt.dtype == torch.float32 and x.amax is not None
                        and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
                 ady = ya.take_grad_range() if dpl else None
                 dy = ya.take_grad()
