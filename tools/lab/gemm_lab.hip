@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <cmath>
+#include <chrono>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -596,6 +597,28 @@ int main(int argc, char **argv) {
         }
         printf("%-28s  back-to-back %.4f ms (%.0f TF/s, %.2f TB/s)   flushed %.4f ms (%.0f TF/s, %.2f TB/s)   maxrelerr %.2e\n", v.name, t_bb, gf / t_bb, mb / t_bb / 1e3,
                t_fl, gf / t_fl, mb / t_fl / 1e3, maxerr);
+    }
+    {
+        // can the two phases overlap AT ALL on this chip?  the main loop alone (nostore) and the stores alone (nomma), launched
+        // together on two streams, against each of them alone and against their sum
+        hipStream_t sa, sb;
+        CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
+        P pa = p, pb = p;
+        pa.flags = 1; pb.flags = 4;
+        const dim3 grid(8 * p.mtiles8 * p.ntiles);
+        auto wall = [&](int which) {
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int r = 0; r < reps; ++r) {
+                if (which & 1) k_base<2, 4, 2, 2, 3><<<grid, 256, 0, sa>>>(pa);
+                if (which & 2) k_base<2, 4, 2, 2, 3><<<grid, 256, 0, sb>>>(pb);
+            }
+            CK(hipDeviceSynchronize());
+            return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / reps;
+        };
+        wall(3);
+        const double ta = wall(1), tb = wall(2), tab = wall(3);
+        printf("two streams: main loop alone %.4f ms, stores alone %.4f ms, both at once %.4f ms (sum %.4f, max %.4f)\n", ta, tb, tab, ta + tb, ta > tb ? ta : tb);
     }
     return 0;
 }
