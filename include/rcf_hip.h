@@ -289,15 +289,21 @@ size_t rcf_fold_fwd_scratch_bytes(int N, int K);
 int rcf_fold_fwd_f32(const float *S, const double *A1, const float *W, float *P, double *sums, const rcf_fold_finalize *fin,
                      void *scratch, size_t scratch_bytes, int N, int K, void *stream);
 int rcf_fold_finalize_f32(const double *sums, int C, const rcf_fold_finalize *fin, void *stream);
+/* relu_bits (optional, with relu): receives the sign bits of y, one 64-bit wavefront ballot per (tile, wave, 32 x 32 sub-tile,
+ * accumulator register) -- rcf_conv_relu_bits_bytes(rows, Cout) bytes, 1/16 of y; only a launch over the SAME [rows][Cout]
+ * tensor can read them back (rcf_conv2d_dgrad_masked_bf16's mask_bits). */
+size_t rcf_conv_relu_bits_bytes(long rows, int C);
 int rcf_conv2d_fwd_affine_bf16(const void *x, const void *w_bf16, const float *scale, const float *shift, const void *residual,
-                               int res_pitch, int relu, void *y, const rcf_conv_shape *s, void *stream);
+                               int res_pitch, int relu, void *y, void *relu_bits, const rcf_conv_shape *s, void *stream);
 size_t rcf_relu_mask_colsum_bf16_workspace_bytes(long rows, int C);
 int rcf_relu_mask_colsum_bf16(const void *dy, int dy_pitch, const void *y, int y_pitch, void *g, int g_pitch, long rows, int C,
                               double *colsums, void *workspace, size_t workspace_bytes, void *stream);
 size_t rcf_conv2d_dgrad_masked_bf16_workspace_bytes(const rcf_conv_shape *s);
+/* the mask: mask_src (the bf16 ReLU output itself, [rows][Cin] with mask_pitch) or mask_bits (its sign bits as
+ * rcf_conv2d_fwd_affine_bf16 wrote them: 1/16 of the bytes; mask_src may then be NULL) */
 int rcf_conv2d_dgrad_masked_bf16(const void *dy, const void *w_t_bf16, void *dx, const rcf_conv_shape *s, int beta,
-                                 const void *mask_src, int mask_pitch, double *colsums, void *workspace, size_t workspace_bytes,
-                                 void *stream);
+                                 const void *mask_src, int mask_pitch, const void *mask_bits, double *colsums, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 int rcf_fold_bwd_sums_f32(const float *G, const float *W, const double *colsums, const float *mean, const float *invstd,
                           double *sums2, int N, int K, void *stream);
 size_t rcf_fold_bwd_scratch_bytes(int N, int K);

@@ -199,11 +199,12 @@ PROTOS = {
     "rcf_fold_fwd_scratch_bytes": (c_size_t, [c_int, c_int]),
     "rcf_fold_fwd_f32": (c_int, [P, P, P, P, P, ctypes.POINTER(FoldFinalize), P, c_size_t, c_int, c_int, P]),
     "rcf_fold_finalize_f32": (c_int, [P, c_int, ctypes.POINTER(FoldFinalize), P]),
-    "rcf_conv2d_fwd_affine_bf16": (c_int, [P, P, P, P, P, c_int, c_int, P, _CS, P]),
+    "rcf_conv_relu_bits_bytes": (c_size_t, [c_long, c_int]),
+    "rcf_conv2d_fwd_affine_bf16": (c_int, [P, P, P, P, P, c_int, c_int, P, P, _CS, P]),
     "rcf_relu_mask_colsum_bf16_workspace_bytes": (c_size_t, [c_long, c_int]),
     "rcf_relu_mask_colsum_bf16": (c_int, [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, c_size_t, P]),
     "rcf_conv2d_dgrad_masked_bf16_workspace_bytes": (c_size_t, [_CS]),
-    "rcf_conv2d_dgrad_masked_bf16": (c_int, [P, P, P, _CS, c_int, P, c_int, P, P, c_size_t, P]),
+    "rcf_conv2d_dgrad_masked_bf16": (c_int, [P, P, P, _CS, c_int, P, c_int, P, P, P, c_size_t, P]),
     "rcf_fold_bwd_sums_f32": (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
     "rcf_fold_bwd_scratch_bytes": (c_size_t, [c_int, c_int]),
     "rcf_fold_wg_bf16": (c_int, [P, P, P, c_int, c_int, P]),

@@ -204,8 +204,9 @@ __global__ void __launch_bounds__(256) fold_wg_kernel(const float *__restrict__ 
 }
 
 // per (c, k): dW += a (G - m A1 - q invstd (P - mean A1));  Wd = a invstd q W (fp32, for T);  c0 partial sums over this
-// workgroup's 32 channels: c0p[chunk][k] = sum_c e_c W[c][k], e = a mean invstd q - a m;  per c: dgamma += sum g zhat, dbeta += sum g.
-// Thread = k (coalesced rows), a workgroup = 32 channels x 256 k.
+// workgroup's PREP_CH channels: c0p[chunk][k] = sum_c e_c W[c][k], e = a mean invstd q - a m;  per c: dgamma += sum g zhat, dbeta += sum g.
+// Thread = k (coalesced rows), a workgroup = PREP_CH channels x 256 k.
+constexpr int PREP_CH = 8;
 __global__ void __launch_bounds__(256) fold_bwd_prep_kernel(const float *__restrict__ G, const float *__restrict__ P,
                                                             const double *__restrict__ A1, const float *__restrict__ W,
                                                             const double *__restrict__ sums2, const double *__restrict__ sums2_local,
@@ -214,12 +215,13 @@ __global__ void __launch_bounds__(256) fold_bwd_prep_kernel(const float *__restr
                                                             float *__restrict__ dW, float *__restrict__ dgamma,
                                                             float *__restrict__ dbeta, float *__restrict__ Wd,
                                                             float *__restrict__ c0p, int N, int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x, cbase = blockIdx.y * 32;
+    const int k = blockIdx.x * 256 + threadIdx.x, cbase = blockIdx.y * PREP_CH;
     const bool live = k < K;
     const float a1 = live ? (float)A1[k] : 0.f;
     const double inv_count = 1.0 / count;
     float part = 0.f;
-    for (int cc = 0; cc < 32; ++cc) {
+#pragma unroll
+    for (int cc = 0; cc < PREP_CH; ++cc) {
         const int c = cbase + cc;                            // uniform: the per-channel constants are scalar loads
         if (c >= N) break;
         const float is = invstd[c], mu = mean[c], a = gamma[c] * is;
@@ -344,7 +346,7 @@ extern "C" int rcf_fold_bwd_sums_f32(const float *G, const float *W, const doubl
 
 extern "C" size_t rcf_fold_bwd_scratch_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || N % 64 || K % 64) return 0;
-    return ((size_t)N * K + (size_t)rcf_cdiv(N, 32) * K + (size_t)gemm_splits(K, K, N) * K * K) * sizeof(float);
+    return ((size_t)N * K + (size_t)rcf_cdiv(N, PREP_CH) * K + (size_t)gemm_splits(K, K, N) * K * K) * sizeof(float);
 }
 
 extern "C" int rcf_fold_wg_bf16(const float *W, const float *scale, void *wg_t_bf16, int N, int K, void *stream) {
@@ -364,7 +366,7 @@ extern "C" int rcf_fold_bwd_prepare_f32(const float *G, const float *P, const do
         return RCF_EINVAL;
     if (!scratch || scratch_bytes < rcf_fold_bwd_scratch_bytes(N, K)) return RCF_EWORKSPACE;
     hipStream_t st = rcf_stream(stream);
-    const int chunks = rcf_cdiv(N, 32);
+    const int chunks = rcf_cdiv(N, PREP_CH);
     float *Wd = (float *)scratch, *c0p = Wd + (size_t)N * K, *Tpart = c0p + (size_t)chunks * K;
     hipLaunchKernelGGL(fold_bwd_prep_kernel, dim3(rcf_cdiv(K, 256), chunks), dim3(256), 0, st, G, P, A1, W, sums2, sums2_local, count,
                        mean, invstd, gamma, dW, dgamma, dbeta, Wd, c0p, N, K);

@@ -59,10 +59,23 @@ struct ConvParams {
     //                          into per-channel constants) -> residual add -> ReLU in the tile that computed the conv
     //   EP 2 (data gradient):  dx = ep_side[row][c] > 0 ? acc (+ old dx) : 0, column sums of what is written -> stats
     //                          (the ReLU of the join whose output this conv read, applied by the LAST writer of its gradient)
+    //   EP 3                   the same with the mask from ep_bits (the forward tile's ballots) instead of the tensor
     const float *ep_scale, *ep_shift;
     const bf16_t *ep_side;
     int ep_side_pitch, ep_relu;
+    // the ReLU's sign bits as the TILE decomposition produces them: one 64-bit ballot (lane = pixel row of the wave's 32-row tile
+    // x channel half) per (wave, mr, nr, quad, element) -- 1 bit per output element, 1/16 of the bf16 tensor.  EP 1 with ReLU
+    // writes them (ep_bits != null); EP 2 reads them INSTEAD of ep_side when given: both launches see the same [rows][Ncol]
+    // tensor with the same tile shape, so a tile finds its own words back without any addressing by row or channel
+    unsigned long long *ep_bits;
 };
+
+// v_cndmask with a wavefront-wide 64-bit mask held in scalar registers: out = mask[lane] ? v : 0
+__device__ __forceinline__ float keep_if(float v, unsigned long long mask) {
+    float out;
+    asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(out) : "v"(v), "s"(mask));
+    return out;
+}
 
 __device__ __forceinline__ void region_yx(int pix, int ry0, int rx0, int rh, int rw, int t, int &y, int &x) {
     if (t <= 0) {
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     // 8g + 4(lane>>5) .. +3 of each column tile.
     const int l31 = lane & 31, kh = lane >> 5;
     const bool full = p.rh == p.Ho && p.rw == p.Wo && p.rband <= 0;
-    const bool want_stats = (!DGRAD || EP == 2) && p.stats != nullptr;
+    const bool want_stats = (!DGRAD || EP >= 2) && p.stats != nullptr;
     long lin[MR];
     bool rowok[MR];
 #pragma unroll
@@ -418,7 +431,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                     // rows past M multiplied zero activations: their accumulators are exactly zero
                     f32x4 q[4];
                     f32x4 side[4];                        // EP: the residual (1) / the activation whose sign masks the gradient (2)
-                    if constexpr (EP != 0) {
+                    // EP 2 with sign bits: this (mr, nr) tile's 16 ballots, one per lane 0..15, handed out by readlane below
+                    unsigned long long bitword = 0ull;
+                    const long bits_at = ((((long)tile_m * p.ntiles + tile_n) * (WM * WN) + wave) * (MR * NR) + (mr * NR + nr)) * 16;
+                    if constexpr (EP == 3) {
+                        if (lane < 16) bitword = p.ep_bits[bits_at + lane];
+                    }
+                    unsigned long long mybits = 0ull;          // EP 1 with ReLU: the ballots this lane will store
+                    if constexpr (EP == 1 || EP == 2) {
                         // read in the STORE layout (a lane pair = 32 contiguous bytes of a row, one 16-byte load per lane) and
                         // brought into the accumulator layout by the inverse of the half-wave exchange below
                         const bool rd = rowok[mr] && p.ep_side != nullptr;
@@ -445,12 +465,27 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                             if (p.ep_relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                                if (p.ep_bits != nullptr) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const unsigned long long b = __ballot(v[e] > 0.f);
+                                        if (lane == 4 * g + e) mybits = b;
+                                    }
+                                }
                             }
                         }
                         if (BETA) {
                             if (rowok[mr]) {
                                 if constexpr (OBF) v += ld4(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + c);
                                 else v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c);
+                            }
+                        }
+                        if constexpr (EP == 3) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo = __builtin_amdgcn_readlane((unsigned)bitword, 4 * g + e);
+                                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(bitword >> 32), 4 * g + e);
+                                v[e] = keep_if(v[e], ((unsigned long long)hi << 32) | lo);
                             }
                         }
                         if constexpr (EP == 2) {
@@ -462,9 +497,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 cs[4 * g + e] += v[e];
-                                cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);
+                                if constexpr (EP < 2) cq[4 * g + e] = fmaf(v[e], v[e], cq[4 * g + e]);     // (the masked gradient: sums only)
                             }
                         }
+                    }
+                    if constexpr (EP == 1) {
+                        if (p.ep_relu && p.ep_bits != nullptr && lane < 16) p.ep_bits[bits_at + lane] = mybits;
                     }
                     if constexpr (OBF) {
                         bf16_t *yrow = reinterpret_cast<bf16_t *>(p.Y) + lin[mr] * p.y_pitch;
@@ -1172,6 +1210,7 @@ void launch_cfg(ConvParams &p, bool strided, bool dgrad, hipStream_t st, int ep)
     if constexpr (OBF) {
         // fused epilogues (the caller checked: whole column tiles, stride 1, no bias / activation)
         if (ep == 1) { hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, false, true, true, 3, 1, 1>), grid, dim3(64 * WM * WN), 0, st, p); return; }
+        if (ep == 2 && p.ep_bits != nullptr) { hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, true, true, 3, 1, 3>), grid, dim3(64 * WM * WN), 0, st, p); return; }
         if (ep == 2) { hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, false, true, true, true, 3, 1, 2>), grid, dim3(64 * WM * WN), 0, st, p); return; }
     }
     if (strided) hipLaunchKernelGGL((conv_bf16_kernel<MR, NR, WM, WN, true, true, OBF, true, 3, 1>), grid, dim3(64 * WM * WN), 0, st, p);
@@ -1402,9 +1441,16 @@ extern "C" int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, c
 }
 
 /* Fused forms (include/rcf_hip.h): conv -> folded batch norm -> residual -> ReLU; data gradient -> ReLU mask -> column sums */
+// 64-bit words of the ReLU sign bits of an [rows][C] output in the tile order of the kernel that takes C output columns
+extern "C" size_t rcf_conv_relu_bits_bytes(long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int bn = conv_bn_of(C);
+    return (size_t)rcf_cdiv(rows, 128) * rcf_cdiv(C, bn) * 4 * (2 * (bn / 64)) * 16 * sizeof(unsigned long long);
+}
+
 extern "C" int rcf_conv2d_fwd_affine_bf16(const void *x, const void *w_bf16, const float *scale, const float *shift,
-                                          const void *residual, int res_pitch, int relu, void *y, const rcf_conv_shape *s,
-                                          void *stream) {
+                                          const void *residual, int res_pitch, int relu, void *y, void *relu_bits,
+                                          const rcf_conv_shape *s, void *stream) {
     if (int e = check_shape(s, 8)) return e;
     if (!x || !w_bf16 || !y || !scale || !shift || !rcf_aligned16(x) || !rcf_aligned16(w_bf16) || !rcf_aligned16(y) ||
         !rcf_aligned16(scale) || !rcf_aligned16(shift)) return RCF_EINVAL;
@@ -1419,6 +1465,7 @@ extern "C" int rcf_conv2d_fwd_affine_bf16(const void *x, const void *w_bf16, con
     p.up = s->stride; p.off = -s->pad; p.step = s->dil; p.div = 1;
     p.a_pitch = s->x_pitch; p.a_img_stride = (long)s->H * s->W * s->x_pitch; p.y_pitch = s->y_pitch;
     p.ep_scale = scale; p.ep_shift = shift; p.ep_side = (const bf16_t *)residual; p.ep_side_pitch = res_pitch; p.ep_relu = relu;
+    p.ep_bits = relu ? (unsigned long long *)relu_bits : nullptr;
     return launch_conv<true>(p, false, rcf_stream(stream), 1);
 }
 
@@ -1428,12 +1475,13 @@ extern "C" size_t rcf_conv2d_dgrad_masked_bf16_workspace_bytes(const rcf_conv_sh
 }
 
 extern "C" int rcf_conv2d_dgrad_masked_bf16(const void *dy, const void *w_t_bf16, void *dx, const rcf_conv_shape *s, int beta,
-                                            const void *mask_src, int mask_pitch, double *colsums, void *workspace,
-                                            size_t workspace_bytes, void *stream) {
+                                            const void *mask_src, int mask_pitch, const void *mask_bits, double *colsums,
+                                            void *workspace, size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
-    if (!dy || !w_t_bf16 || !dx || !mask_src || !rcf_aligned16(dy) || !rcf_aligned16(w_t_bf16) || !rcf_aligned16(dx) ||
-        !rcf_aligned16(mask_src)) return RCF_EINVAL;
-    if (s->y_pitch % 8 || mask_pitch % 8 || mask_pitch < s->Cin || s->stride != 1) return RCF_EINVAL;
+    if (!dy || !w_t_bf16 || !dx || (!mask_src && !mask_bits) || !rcf_aligned16(dy) || !rcf_aligned16(w_t_bf16) || !rcf_aligned16(dx))
+        return RCF_EINVAL;
+    if (mask_src && (!rcf_aligned16(mask_src) || mask_pitch % 8 || mask_pitch < s->Cin)) return RCF_EINVAL;
+    if (s->y_pitch % 8 || s->stride != 1) return RCF_EINVAL;
     ConvParams p{};
     p.flags = s->flags;
     p.A = (const bf16_t *)dy; p.Bw = (const bf16_t *)w_t_bf16; p.bias = nullptr; p.Y = dx;
@@ -1444,6 +1492,7 @@ extern "C" int rcf_conv2d_dgrad_masked_bf16(const void *dy, const void *w_t_bf16
     p.a_pitch = s->y_pitch; p.a_img_stride = (long)s->Ho * s->Wo * s->y_pitch; p.y_pitch = s->x_pitch;
     p.beta = beta;
     p.ep_side = (const bf16_t *)mask_src; p.ep_side_pitch = mask_pitch;
+    p.ep_bits = (unsigned long long *)mask_bits;
     if (colsums) {
         if (!workspace || workspace_bytes < rcf_conv2d_dgrad_masked_bf16_workspace_bytes(s)) return RCF_EWORKSPACE;
         p.stats = (double *)workspace;

@@ -30,7 +30,7 @@ class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
                  "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok",
-                 "relu_out", "grad_masked", "grad_colsum", "bn_in")
+                 "relu_out", "grad_masked", "grad_colsum", "bn_in", "relu_bits")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -56,6 +56,7 @@ class Act:
         # its own mask (t > 0) plus that gradient's column sums; the LAST writer of `grad` (the conv that read t first) may apply
         # the mask in its epilogue and leave `grad_masked` / `grad_colsum` -- any writer after that would add unmasked terms
         self.relu_out, self.grad_masked, self.grad_colsum = False, False, None
+        self.relu_bits = None        # ... the ReLU's sign bits in the producing tile's order (ops.conv2d_fwd_affine_bf16 want_bits)
         # SyncBN: the plain norm (no ReLU) that produced t leaves (its input, mean, invstd) here; a join that takes t as its
         # residual computes that norm's backward sums beside its own -- both depend only on the join's masked output gradient --
         # and sends them in ONE exchange (`grad_sums2` then holds (global sums, local sums) and the norm skips pass and exchange)
@@ -380,7 +381,7 @@ class Conv2d(nn.Module):
                         # x is the output of a folded conv + norm + ReLU and this is the LAST writer of its gradient: the mask of
                         # that ReLU and the column sums its backward needs come out of this epilogue (no pass over the gradient)
                         _, cs = ops.conv2d_dgrad_masked_bf16(dy, wk, x.t.shape, wt, x.t, gx, beta=beta, stride=self.stride,
-                                                             pad=self.padding, dil=self.dilation)
+                                                             pad=self.padding, dil=self.dilation, mask_bits=x.relu_bits)
                         x.grad_masked, x.grad_colsum = True, cs
                     else:
                         ops.conv2d_dgrad_bf16(dy, wk, x.t.shape, self.stride, self.padding, self.dilation, out=gx, beta=beta,
@@ -699,9 +700,14 @@ def conv_bn_fold(conv, bn, x, tape, relu, residual=None, dist=None):
         P, (mean, invstd, scale, shift) = ops.fold_fwd(S, A1, w, bn, count)
     if x.first_reader is None:
         x.first_reader = object()
-    y = ops.conv2d_fwd_affine_bf16(xt, w, wb, scale, shift, residual.t if residual is not None else None, relu)
+    want_bits = bool(relu) and tape.enabled and SCHED.fold_masked_dgrad
+    y = ops.conv2d_fwd_affine_bf16(xt, w, wb, scale, shift, residual.t if residual is not None else None, relu, want_bits=want_bits)
+    bits = None
+    if want_bits:
+        y, bits = y
     ya = Act(y)
     ya.relu_out = bool(relu)
+    ya.relu_bits = bits
     if RELU_TRACE is not None and relu:
         RELU_TRACE.append(y > 0)
     if tape.enabled:

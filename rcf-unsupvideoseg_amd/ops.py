@@ -608,8 +608,9 @@ def fold_finalize(sums, count, bn):
     return outs
 
 
-def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True, stride=1, pad=0, dil=1):
-    """y = [relu](conv(x, w) * scale[c] + shift[c] [+ residual]) in the conv's own epilogue (bf16 in, bf16 out)"""
+def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True, stride=1, pad=0, dil=1, want_bits=False):
+    """y = [relu](conv(x, w) * scale[c] + shift[c] [+ residual]) in the conv's own epilogue (bf16 in, bf16 out).
+    want_bits (with relu): also the ReLU's sign bits in tile order, (y, bits) -- for conv2d_dgrad_masked_bf16(mask_bits=)"""
     _need_cuda(x, w)
     assert x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
@@ -621,11 +622,14 @@ def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True,
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_fwd" if s.Cout > 128 else "conv_bf16_fwd_narrow",
                               2.0 * s.N * s.Ho * s.Wo * s.Cout * s.R * s.S * s.Cin, _shape_tag(s) + " +bn")
+    bits = None
+    if want_bits and relu:
+        bits = torch.empty(_lib.load().rcf_conv_relu_bits_bytes(s.N * s.Ho * s.Wo, s.Cout), dtype=torch.uint8, device=x.device)
     call("rcf_conv2d_fwd_affine_bf16", _p(x), _p(w_bf16), _p(scale), _p(shift), _p(residual),
-         pitch_of(residual) if residual is not None else 0, int(relu), _p(out), byref(s), _stream())
+         pitch_of(residual) if residual is not None else 0, int(relu), _p(out), _p(bits), byref(s), _stream())
     if end is not None:
         end.record()
-    return out
+    return (out, bits) if want_bits else out
 
 
 def relu_mask_colsum(dy, y, out=None):
@@ -643,11 +647,14 @@ def relu_mask_colsum(dy, y, out=None):
     return out, cs
 
 
-def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, stride=1, pad=0, dil=1, colsums=True):
+def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, stride=1, pad=0, dil=1, colsums=True, mask_bits=None):
     """dx = mask_src > 0 ? conv_transpose(dy, w) (+ dx) : 0 in the data gradient's epilogue, with the column sums of what it
     writes (fp64 [2 Cin], first half): the LAST writer of a ReLU output's gradient applies that ReLU's mask"""
-    _need_cuda(dy, w, mask_src)
-    assert dy.dtype == torch.bfloat16 and mask_src.dtype == torch.bfloat16 and tuple(mask_src.shape) == tuple(xshape)
+    _need_cuda(dy, w)
+    assert dy.dtype == torch.bfloat16 and (mask_bits is not None or (mask_src.dtype == torch.bfloat16 and tuple(mask_src.shape) == tuple(xshape)))
+    if mask_bits is not None:
+        mask_src = None                       # the sign bits the forward tile wrote (1/16 of the bytes) instead of the tensor
+        assert mask_bits.numel() == _lib.load().rcf_conv_relu_bits_bytes(xshape[0] * xshape[1] * xshape[2], xshape[3])
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
     cs = ws = None
     need = 0
@@ -659,8 +666,8 @@ def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, str
     if PROFILE.which is not None:
         end = PROFILE.bracket("conv_bf16_dgrad_wide" if s.Cin > 128 else "conv_bf16_dgrad_other",
                               2.0 * s.N * s.H * s.W * s.Cin * s.R * s.S * s.Cout, _shape_tag(s) + " +mask")
-    call("rcf_conv2d_dgrad_masked_bf16", _p(dy), _p(w_t_bf16), _p(out), byref(s), int(beta), _p(mask_src), pitch_of(mask_src),
-         _p(cs), _p(ws), need, _stream())
+    call("rcf_conv2d_dgrad_masked_bf16", _p(dy), _p(w_t_bf16), _p(out), byref(s), int(beta), _p(mask_src),
+         pitch_of(mask_src) if mask_src is not None else 0, _p(mask_bits), _p(cs), _p(ws), need, _stream())
     if end is not None:
         end.record()
     return out, cs

@@ -49,6 +49,20 @@ def test_conv_affine_epilogue(case, report):
     assert e < 5e-3
     if relu:
         assert float(y.float().min()) >= 0.0
+        # the sign bits the tile leaves (one ballot per accumulator register), used as the mask of a data gradient over the same
+        # [rows][C] tensor: bit-identical to masking by y itself
+        y2, bits = ops.conv2d_fwd_affine_bf16(nhwc(x), wd, ops.weight_bf16(wd), scale.to(DEV), shift.to(DEV), nhwc(res) if with_res else None,
+                                              relu, want_bits=True)
+        assert torch.equal(y2, y)
+        Cd = 64
+        dy = q(torch.randn(N, Cd, H, W, generator=g))
+        w2 = q(torch.randn(Cd, C, 1, 1, generator=g) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for mb in (None, bits):
+            o = torch.zeros((N, H, W, C), dtype=BF, device=DEV)
+            _, cs = ops.conv2d_dgrad_masked_bf16(nhwc(dy), w2, (N, H, W, C), ops.weight_bf16(w2, True), y, o, beta=0, mask_bits=mb)
+            outs.append((o, cs))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("case", [(2, 64, 256, 19, 23, 0), (1, 256, 1024, 17, 31, 1), (2, 512, 2048, 7, 9, 1), (1, 64, 64, 21, 17, 0),
