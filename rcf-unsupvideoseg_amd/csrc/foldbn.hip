@@ -244,20 +244,35 @@ __global__ void __launch_bounds__(256) fold_bwd_prep_kernel(const float *__restr
 }
 
 // -T = -(sum of the Z partial products of W^T Wd) as the bf16 FORWARD weight operand of the K -> K 1x1 conv dx += x (-T):
-// element (row k, kk = j) = -T[j][k] at ((j >> 5) K + k) 32 + (j & 31)
+// element (row k, kk = j) = -T[j][k] at ((j >> 5) K + k) 32 + (j & 31).  T is symmetric, so thread (a, b) reads T[a][b]
+// (coalesced over b) and writes it as row a, kk = b (32 consecutive b = 64 contiguous bytes).  The last K / 32 workgroups add
+// the channel chunks' partial sums of c0 instead: 32 columns x 8 interleaved slices each, combined in a fixed order.
 __global__ void __launch_bounds__(256) fold_T_finish_kernel(const float *__restrict__ Tpart, int Z, bf16_t *__restrict__ negT, int K,
-                                                            const float *__restrict__ c0p, int chunks, float *__restrict__ c0) {
+                                                            const float *__restrict__ c0p, int chunks, float *__restrict__ c0,
+                                                            int t_blocks) {
+    if ((int)blockIdx.x >= t_blocks) {
+        __shared__ float sh[256];
+        const int kl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int k = ((int)blockIdx.x - t_blocks) * 32 + kl;
+        float s = 0.f;
+        if (k < K)
+            for (int q = sl; q < chunks; q += 8) s += c0p[(long)q * K + k];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0 && k < K) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += sh[q * 32 + kl];
+            c0[k] = t;
+        }
+        return;
+    }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)K * K) return;
-    const int j = (int)(i / K), k = (int)(i - (long)j * K);
+    const int a = (int)(i / K), b = (int)(i - (long)a * K);
     float t = 0.f;
     for (int z = 0; z < Z; ++z) t += Tpart[(long)z * K * K + i];
-    negT[((long)(j >> 5) * K + k) * 32 + (j & 31)] = (bf16_t)(-t);
-    if (j == 0) {                                          // c0[k] = the sum of the channel chunks' partial sums, in chunk order
-        float s = 0.f;
-        for (int q = 0; q < chunks; ++q) s += c0p[(long)q * K + k];
-        c0[k] = s;
-    }
+    negT[((long)(b >> 5) * K + a) * 32 + (b & 31)] = (bf16_t)(-t);
 }
 
 }  // namespace
@@ -376,8 +391,9 @@ extern "C" int rcf_fold_bwd_prepare_f32(const float *G, const float *P, const do
     hipLaunchKernelGGL(small_gemm_kernel<true>, dim3(K / 64, K / 64, Z), dim3(256), 0, st, W, 1L, (long)K, (const float *)Wd, (long)K,
                        Tpart, K, K, N / Z);
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fold_T_finish_kernel, dim3(rcf_cdiv((long)K * K, 256)), dim3(256), 0, st, (const float *)Tpart, Z,
-                       (bf16_t *)negT_bf16, K, (const float *)c0p, chunks, c0);
+    const int t_blocks = (int)rcf_cdiv((long)K * K, 256);
+    hipLaunchKernelGGL(fold_T_finish_kernel, dim3(t_blocks + rcf_cdiv(K, 32)), dim3(256), 0, st, (const float *)Tpart, Z,
+                       (bf16_t *)negT_bf16, K, (const float *)c0p, chunks, c0, t_blocks);
     RCF_LAUNCH_CHECK();
     return 0;
 }

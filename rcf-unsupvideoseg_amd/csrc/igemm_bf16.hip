@@ -165,6 +165,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
 
+    // Per-column constants of the straight-line epilogue (EP 1: scale | shift; otherwise the bias): asked for HERE, one column
+    // per thread, and parked in LDS behind the K loop.  Read from global memory inside the epilogue they sit behind each
+    // fragment's stores (a load may not pass a store it might alias): MR * NR dependent L2 round trips per tile.
+    static_assert(BN <= NT, "one column constant per thread");
+    static_assert(WM * BN * 2 * sizeof(double) + 2 * BN * sizeof(float) <= sizeof(smem), "statistics + column constants fit the stages");
+    const bool use_cc = OBF && (EP == 1 || p.bias != nullptr) && n0 + BN <= p.Ncol;
+    float cc0 = 0.f, cc1 = 0.f;
+    if (use_cc && tid < BN) {
+        if constexpr (EP == 1) { cc0 = p.ep_scale[n0 + tid]; cc1 = p.ep_shift[n0 + tid]; }
+        else cc1 = p.bias[n0 + tid];
+    }
+
     constexpr int ROWS = NT / 4;                      // 4 threads x 16 B per 64-byte row
     constexpr int A_PASS = BM / ROWS, B_PASS = BN / ROWS;
     static_assert(A_PASS >= 1 && B_PASS >= 1, "tile smaller than one loader pass");
@@ -412,18 +424,76 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
         }
     }
     double *red = reinterpret_cast<double *>(smem);       // [WM][BN][2] (fused batch-norm statistics)
-    if (want_stats) __syncthreads();                      // every wave is done with the operand stages
+    float *colc = reinterpret_cast<float *>(smem + WM * BN * 2 * sizeof(double));       // [2][BN] behind `red`
+    if (want_stats || use_cc) __syncthreads();            // every wave is done with the operand stages
+    if (use_cc) {
+        if (tid < BN) { colc[tid] = cc0; colc[BN + tid] = cc1; }
+        __syncthreads();
+    }
+    // The common case -- a whole column tile, no bias, no activation -- as straight-line code (csrc/igemm_conv.hip,
+    // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
+    // (a bias rides along as one uniform test per quad: the folded data gradient's second half, dx += x (-T) + c0)
+    const bool lean = (p.bias == nullptr || (OBF && !want_stats)) && p.act == 0 && n0 + BN <= p.Ncol;
+    // What the lean epilogue READS -- the residual / mask tensor (EP 1, 2), the ballots (EP 3), the old output (beta, bf16) --
+    // is asked for ahead of the stores, two column tiles (2 MR fragments) at a time: a load of the output tensor may not pass
+    // an earlier store to it, so loads left beside their fragment's stores run as MR * NR dependent HBM round trips
+    // (a 256-deep 1x1 conv then spends 3 us multiplying and 15 us waiting; the whole tile's worth at once does not fit beside
+    // its 128 accumulators).  16 bytes per lane in the STORE layout (a lane pair = 32 contiguous bytes of a row), brought into
+    // the accumulator layout by the inverse half-wave exchange.
+    constexpr bool PRE_SIDE = EP == 1 || EP == 2, PRE_BITS = EP == 3;
+    constexpr int NRG = NR >= 4 ? 2 : 1;                  // column tiles asked for together
+    u32x4 side_r[NRG][MR][2], old_r[NRG][MR][2];
+    unsigned long long bits_r[NRG][MR];
+    auto bits_index = [&](int mr, int nr) {
+        return ((((long)tile_m * p.ntiles + tile_n) * (WM * WN) + wave) * (MR * NR) + (mr * NR + nr)) * 16;
+    };
+    auto prefetch_group = [&](int nr0) {
+#pragma unroll
+        for (int j = 0; j < NRG; ++j) {
+            const int nr = nr0 + j;
+            const int cb = n0 + brow0 + nr * 32;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                if constexpr (PRE_SIDE) {
+                    const bool rd = rowok[mr] && p.ep_side != nullptr;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        side_r[j][mr][h] = u32x4{0u, 0u, 0u, 0u};
+                        if (rd) side_r[j][mr][h] = *reinterpret_cast<const u32x4 *>(p.ep_side + lin[mr] * p.ep_side_pitch + cb + 8 * (2 * h + kh));
+                    }
+                }
+                if constexpr (PRE_BITS) {
+                    bits_r[j][mr] = 0ull;
+                    if (lane < 16) bits_r[j][mr] = p.ep_bits[bits_index(mr, nr) + lane];
+                }
+                if constexpr (OBF && EP != 1) {           // (the affine entry point has no beta)
+                    if (p.beta) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            old_r[j][mr][h] = u32x4{0u, 0u, 0u, 0u};
+                            if (rowok[mr]) old_r[j][mr][h] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + cb + 8 * (2 * h + kh));
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // 8 bf16 of channel groups (g, g + 1) in the store layout -> the two accumulator-layout quads of this lane
+    auto unpack_pair = [&](const u32x4 d, f32x4 &lo, f32x4 &hi) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+        lo = f32x4{__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u)};
+        hi = f32x4{__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u)};
+    };
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         float cs[16], cq[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
         const int cb = n0 + brow0 + nr * 32;              // first channel of this column tile
-        // The common case -- a whole column tile, no bias, no activation -- as straight-line code (csrc/igemm_conv.hip,
-        // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
-        // (a bias rides along as one uniform test per quad: the folded data gradient's second half, dx += x (-T) + c0)
-        const bool lean = (p.bias == nullptr || (OBF && !want_stats)) && p.act == 0 && n0 + BN <= p.Ncol;
         if (lean) {
+            if (nr % NRG == 0) prefetch_group(nr);
+            const int nj = nr % NRG;
             auto quads = [&](auto BETA_, auto STATS_) {
                 constexpr bool BETA = decltype(BETA_)::value, STATS = decltype(STATS_)::value;
 #pragma unroll
@@ -431,36 +501,27 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                     // rows past M multiplied zero activations: their accumulators are exactly zero
                     f32x4 q[4];
                     f32x4 side[4];                        // EP: the residual (1) / the activation whose sign masks the gradient (2)
-                    // EP 2 with sign bits: this (mr, nr) tile's 16 ballots, one per lane 0..15, handed out by readlane below
+                    f32x4 old[4];                         // beta, bf16 output: what the tile adds to
+                    // EP 3: this (mr, nr) tile's 16 ballots, one per lane 0..15, handed out by readlane below
                     unsigned long long bitword = 0ull;
-                    const long bits_at = ((((long)tile_m * p.ntiles + tile_n) * (WM * WN) + wave) * (MR * NR) + (mr * NR + nr)) * 16;
-                    if constexpr (EP == 3) {
-                        if (lane < 16) bitword = p.ep_bits[bits_at + lane];
-                    }
+                    const long bits_at = bits_index(mr, nr);
+                    if constexpr (EP == 3) bitword = bits_r[nj][mr];
                     unsigned long long mybits = 0ull;          // EP 1 with ReLU: the ballots this lane will store
                     if constexpr (EP == 1 || EP == 2) {
-                        // read in the STORE layout (a lane pair = 32 contiguous bytes of a row, one 16-byte load per lane) and
-                        // brought into the accumulator layout by the inverse of the half-wave exchange below
-                        const bool rd = rowok[mr] && p.ep_side != nullptr;
-#pragma unroll
-                        for (int g = 0; g < 4; g += 2) {
-                            u32x4 d = {0u, 0u, 0u, 0u};
-                            if (rd) d = *reinterpret_cast<const u32x4 *>(p.ep_side + lin[mr] * p.ep_side_pitch + cb + 8 * (g + kh));
-                            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-                            side[g] = f32x4{__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u),
-                                            __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u)};
-                            side[g + 1] = f32x4{__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u),
-                                                __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u)};
-                        }
+                        unpack_pair(side_r[nj][mr][0], side[0], side[1]);
+                        unpack_pair(side_r[nj][mr][1], side[2], side[3]);
+                    }
+                    if constexpr (OBF && BETA) {
+                        unpack_pair(old_r[nj][mr][0], old[0], old[1]);
+                        unpack_pair(old_r[nj][mr][1], old[2], old[3]);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c = cb + 8 * g + 4 * kh;
                         f32x4 v = {acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
-                        if (p.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(p.bias + c);
+                        if (EP != 1 && p.bias != nullptr) v += *reinterpret_cast<const f32x4 *>(colc + BN + (c - n0));
                         if constexpr (EP == 1) {
-                            v = v * *reinterpret_cast<const f32x4 *>(p.ep_scale + c) + *reinterpret_cast<const f32x4 *>(p.ep_shift + c);
+                            v = v * *reinterpret_cast<const f32x4 *>(colc + (c - n0)) + *reinterpret_cast<const f32x4 *>(colc + BN + (c - n0));
                             v += side[g];                 // zeros without a residual
                             if (p.ep_relu) {
 #pragma unroll
@@ -474,11 +535,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                                 }
                             }
                         }
-                        if (BETA) {
-                            if (rowok[mr]) {
-                                if constexpr (OBF) v += ld4(reinterpret_cast<const bf16_t *>(p.Y) + lin[mr] * p.y_pitch + c);
-                                else v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c);
-                            }
+                        if constexpr (BETA) {
+                            if constexpr (OBF) v += old[g];
+                            else { if (rowok[mr]) v += ld4(reinterpret_cast<const float *>(p.Y) + lin[mr] * p.y_pitch + c); }
                         }
                         if constexpr (EP == 3) {
 #pragma unroll
@@ -522,7 +581,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                     }
                 }
             };
-            if (p.beta) { if (want_stats) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
+            if (EP != 1 && p.beta) { if (want_stats) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{}); }
             else { if (want_stats) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{}); }
         } else {
 #pragma unroll
