@@ -391,6 +391,19 @@ int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *residual, i
                     int relu, const float *chan_scale, long rows_per_image, unsigned char *relu_mask,
                     unsigned *amax_out, void *planes_out, const unsigned *amax_x, const unsigned *amax_res, unsigned flags,
                     void *stream);
+/* rcf_bn_apply_mp whose residual is itself a conv output in front of a finalized train-mode batch norm WITHOUT ReLU (a stage's
+ * downsample branch: models/resnet.py:293-294 `identity = self.downsample(x)`, `out += identity`): res_norm's four [C] vectors
+ * normalise the residual on the fly -- (r - mean) * invstd * gamma + beta, the apply pass's own operations and order, rounded to
+ * the storage type as the stored tensor would have been -- so that norm's apply pass never runs.  amax_res is then the range of
+ * the RAW residual.  res_norm == NULL: rcf_bn_apply_mp. */
+typedef struct rcf_bn_res_norm {
+    const float *mean, *invstd, *gamma, *beta;
+} rcf_bn_res_norm;
+int rcf_bn_apply_res_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch, const rcf_bn_res_norm *res_norm,
+                        void *y, int ydt, int y_pitch, long rows, int C, const float *mean, const float *invstd,
+                        const float *gamma, const float *beta, int relu, const float *chan_scale, long rows_per_image,
+                        unsigned char *relu_mask, unsigned *amax_out, void *planes_out, const unsigned *amax_x,
+                        const unsigned *amax_res, unsigned flags, void *stream);
 int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
                          int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
                          const unsigned char *relu_mask, const float *chan_scale, long rows_per_image, double *sums2,

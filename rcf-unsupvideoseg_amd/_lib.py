@@ -56,6 +56,11 @@ class FoldFinalize(ctypes.Structure):
                                                "num_batches_tracked")]
 
 
+class BnResNorm(ctypes.Structure):
+    """struct rcf_bn_res_norm of include/rcf_hip.h"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("mean", "invstd", "gamma", "beta")]
+
+
 class ConvRegion(ctypes.Structure):
     """mirror of rcf_conv_region"""
     _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w", "band")]
@@ -173,6 +178,8 @@ PROTOS = {
     "rcf_bn_stats_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, P, c_size_t, P]),
     "rcf_bn_apply_mp": (c_int, [P, c_int, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,
                                 P, P, P, P, c_uint, P]),
+    "rcf_bn_apply_res_mp": (c_int, [P, c_int, c_int, P, c_int, P, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,
+                                    P, P, P, P, c_uint, P]),
     "rcf_bn_bwd_reduce_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, c_int, P, P, c_long,
                                      P, P, c_size_t, c_uint, P]),
     "rcf_bn_bwd_apply_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P,

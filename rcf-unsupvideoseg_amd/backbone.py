@@ -30,11 +30,11 @@ class Downsample(nn.Module):
         self.add_module("0", conv)
         self.add_module("1", norm)
 
-    def fwd(self, x, tape, dist):
+    def fwd(self, x, tape, dist, lazy=False):
         conv, norm = getattr(self, "0"), getattr(self, "1")
         if layers.fold_ok(conv, norm, x):
             return layers.conv_bn_fold(conv, norm, x, tape, relu=False, dist=dist)
-        return norm.fwd(conv.fwd(x, tape, stats=norm.stats_request(dist)), tape, relu=False, dist=dist)
+        return norm.fwd(conv.fwd(x, tape, stats=norm.stats_request(dist)), tape, relu=False, dist=dist, lazy=lazy)
 
 
 class Bottleneck(nn.Module):
@@ -71,10 +71,12 @@ class Bottleneck(nn.Module):
         o = self.bn1.fwd(o1, tape, relu=True, dist=dist, planes="only" if self.conv2.planes_ok(tape.act_dtype) else None)
         o = self.bn2.fwd(self.conv2.fwd(o, tape, stats=self.bn2.stats_request(dist)), tape, relu=True, dist=dist,
                          planes="only" if self.conv3.planes_ok(tape.act_dtype) else None)
+        # the downsample norm's apply pass is left to the join (BatchNorm2d.fwd lazy) unless conv3 folds (its tile reads a tensor)
+        lazy = not layers.fold_ok(self.conv3, self.bn3, o)
         if ods is not None:
-            idt = getattr(self.downsample, "1").fwd(ods, tape, relu=False, dist=dist)
+            idt = getattr(self.downsample, "1").fwd(ods, tape, relu=False, dist=dist, lazy=lazy)
         else:
-            idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist)
+            idt = x if self.downsample is None else self.downsample.fwd(x, tape, dist, lazy=lazy)
         if layers.fold_ok(self.conv3, self.bn3, o, idt):
             # bf16 step: conv3 -> bn3 -> + identity -> ReLU as one tile, conv3's output never written (layers.conv_bn_fold)
             return layers.conv_bn_fold(self.conv3, self.bn3, o, tape, relu=True, residual=idt, dist=dist)

@@ -441,6 +441,13 @@ __device__ __forceinline__ float block_max_f(float v) {
 // from an upper bound every workgroup derives from the per-channel constants before it reads a single element:
 //     |y_c| <= |gamma_c| invstd_c (max|x| + |mean_c|) + |beta_c| (+ max|residual|)
 // (max|x|: the conv epilogue's range of x; ReLU only lowers it).  Workgroup 0 leaves the bound in *amax: the consumers scale by it.
+// rn: the residual is itself a conv output in front of a (train-mode, already finalized) batch norm without ReLU -- a stage's
+// downsample branch, models/resnet.py:293-294 -- and is normalised on the fly: that norm's apply pass (a read and a write of
+// the 4C-wide tensor) does not exist.  Same operations in the same order as the pass would have used.
+struct ResNorm {
+    const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr;
+};
+
 template <typename XT, typename YT, int V, int PL = 0>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x, int x_pitch,
                                                        const YT *__restrict__ res, int r_pitch,
@@ -451,7 +458,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
                                                        unsigned char *__restrict__ mask,
                                                        unsigned *__restrict__ amax, Sweep sw, char *__restrict__ planes = nullptr,
                                                        const unsigned *__restrict__ amax_x = nullptr,
-                                                       const unsigned *__restrict__ amax_res = nullptr) {
+                                                       const unsigned *__restrict__ amax_res = nullptr, ResNorm rn = ResNorm{}) {
     const int CV = C / V;
     const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
     const int cv = blockIdx.y * cvt + cx;
@@ -460,10 +467,17 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
     unsigned mx = 0u;
     float pls = 1.f;                                   // 2^k of the planes
     if constexpr (PL != 0) {
-        const float ax = __uint_as_float(*amax_x), ar = res ? __uint_as_float(*amax_res) : 0.f;
+        const float ax = __uint_as_float(*amax_x);
+        float ar = res ? __uint_as_float(*amax_res) : 0.f;
         float b = 0.f;
         for (int c = threadIdx.x; c < C; c += 256)
             b = fmaxf(b, fabsf(gamma[c]) * invstd[c] * (ax + fabsf(mean[c])) + fabsf(beta[c]));
+        if (res && rn.mean) {                          // amax_res is the range of the residual BEFORE its norm
+            float br = 0.f;
+            for (int c = threadIdx.x; c < C; c += 256)
+                br = fmaxf(br, fabsf(rn.gamma[c]) * rn.invstd[c] * (ar + fabsf(rn.mean[c])) + fabsf(rn.beta[c]));
+            ar = block_max_f(br) * 1.0000005f;
+        }
         b = (block_max_f(b) + ar) * 1.0000005f;        // the elements are rounded at every step of their own evaluation
         const unsigned bits = __float_as_uint(b);
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax = bits;
@@ -473,13 +487,27 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const XT *__restrict__ x,
         const fvec<V> mu = ldv<float, V>(mean + c0), is = ldv<float, V>(invstd + c0);
         const fvec<V> ga = ldv<float, V>(gamma + c0), be = ldv<float, V>(beta + c0);
         const long rstep = (long)gridDim.x * rpb;
-        auto finish = [&](long r, const fvec<V> &xv, const fvec<V> &rv) {
-            fvec<V> o;
+        const bool rnorm = res && rn.mean;
+        fvec<V> rmu{}, ris{}, rga{}, rbe{};
+        if (rnorm) {
+            rmu = ldv<float, V>(rn.mean + c0); ris = ldv<float, V>(rn.invstd + c0);
+            rga = ldv<float, V>(rn.gamma + c0); rbe = ldv<float, V>(rn.beta + c0);
+        }
+        auto finish = [&](long r, const fvec<V> &xv, const fvec<V> &rv_in) {
+            fvec<V> o, rv = rv_in;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const int h = e >> 2, k = e & 3;
                 // (x - mean) * invstd * gamma + beta, evaluated in the reference's order
                 o.q[h][k] = (xv.q[h][k] - mu.q[h][k]) * is.q[h][k] * ga.q[h][k] + be.q[h][k];
+            }
+            if (rnorm) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int h = e >> 2, k = e & 3;
+                    rv.q[h][k] = (rv.q[h][k] - rmu.q[h][k]) * ris.q[h][k] * rga.q[h][k] + rbe.q[h][k];
+                    if constexpr (!std::is_same<YT, float>::value) rv.q[h][k] = (float)(YT)rv.q[h][k];   // as the stored tensor was
+                }
             }
             if (res) {
 #pragma unroll
@@ -821,6 +849,21 @@ extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *
                                const float *gamma, const float *beta, int relu, const float *chan_scale,
                                long rows_per_image, unsigned char *relu_mask, unsigned *amax_out, void *planes_out,
                                const unsigned *amax_x, const unsigned *amax_res, unsigned flags, void *stream) {
+    return rcf_bn_apply_res_mp(x, xdt, x_pitch, residual, r_pitch, nullptr, y, ydt, y_pitch, rows, C, mean, invstd, gamma, beta, relu,
+                               chan_scale, rows_per_image, relu_mask, amax_out, planes_out, amax_x, amax_res, flags, stream);
+}
+
+extern "C" int rcf_bn_apply_res_mp(const void *x, int xdt, int x_pitch, const void *residual, int r_pitch,
+                                   const rcf_bn_res_norm *res_norm, void *y, int ydt, int y_pitch, long rows, int C,
+                                   const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
+                                   const float *chan_scale, long rows_per_image, unsigned char *relu_mask,
+                                   unsigned *amax_out, void *planes_out, const unsigned *amax_x, const unsigned *amax_res,
+                                   unsigned flags, void *stream) {
+    ResNorm rn{};
+    if (res_norm) {
+        if (!residual || !res_norm->mean || !res_norm->invstd || !res_norm->gamma || !res_norm->beta) return RCF_EINVAL;
+        rn.mean = res_norm->mean; rn.invstd = res_norm->invstd; rn.gamma = res_norm->gamma; rn.beta = res_norm->beta;
+    }
     const bool planes_only = planes_out && (flags & RCF_BN_Y_PLANES_ONLY);
     if (!x || (!y && !planes_only) || !mean || !invstd || !gamma || !beta || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
     if (x_pitch % 4 || y_pitch % 4 || (residual && r_pitch % 4)) return RCF_EINVAL;
@@ -836,7 +879,7 @@ extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *
 #define RCF_CALL(PLv)                                                                                                     \
     hipLaunchKernelGGL((bn_apply_kernel<float, float, 4, PLv>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)x, x_pitch, \
                        (const float *)residual, r_pitch, (float *)y, y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, \
-                       (const float *)nullptr, 1L, relu_mask, amax_out, sw, (char *)planes_out, amax_x, amax_res)
+                       (const float *)nullptr, 1L, relu_mask, amax_out, sw, (char *)planes_out, amax_x, amax_res, rn)
         if (planes_only) RCF_CALL(2);
         else RCF_CALL(1);
 #undef RCF_CALL
@@ -848,14 +891,16 @@ extern "C" int rcf_bn_apply_mp(const void *x, int xdt, int x_pitch, const void *
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 8>), g.grid, dim3(256), 0,
                            rcf_stream(stream), (const bf16_t *)x, x_pitch, (const bf16_t *)residual, r_pitch, (bf16_t *)y,
                            y_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, beta, relu, chan_scale,
-                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out, make_sweep(2, rows, g.rpb, (long)C * 2, flags));
+                           rows_per_image > 0 ? rows_per_image : 1, relu_mask, amax_out, make_sweep(2, rows, g.rpb, (long)C * 2, flags),
+                           (char *)nullptr, (const unsigned *)nullptr, (const unsigned *)nullptr, rn);
     } else {
         const EwGeom g = ew_geom(rows, C / 4);
 #define RCF_CALL(XT, YT)                                                                                                 \
     hipLaunchKernelGGL((bn_apply_kernel<XT, YT, 4>), g.grid, dim3(256), 0, rcf_stream(stream),                          \
                        (const XT *)x, x_pitch, (const YT *)residual, r_pitch, (YT *)y, y_pitch, rows, C, g.cvt, g.rpb,   \
                        mean, invstd, gamma, beta, relu, chan_scale, rows_per_image > 0 ? rows_per_image : 1, relu_mask,  \
-                       amax_out, make_sweep(2, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4), flags))
+                       amax_out, make_sweep(2, rows, g.rpb, (long)C * (xdt == RCF_BF16 ? 2 : 4), flags),               \
+                       (char *)nullptr, (const unsigned *)nullptr, (const unsigned *)nullptr, rn)
         RCF_DISPATCH2(xdt, ydt, RCF_CALL);
 #undef RCF_CALL
     }

@@ -30,7 +30,7 @@ class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
                  "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok",
-                 "relu_out", "grad_masked", "grad_colsum", "bn_in", "relu_bits")
+                 "relu_out", "grad_masked", "grad_colsum", "bn_in", "relu_bits", "res_norm")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -61,6 +61,9 @@ class Act:
         # residual computes that norm's backward sums beside its own -- both depend only on the join's masked output gradient --
         # and sends them in ONE exchange (`grad_sums2` then holds (global sums, local sums) and the norm skips pass and exchange)
         self.bn_in = None
+        # a plain norm applied LAZILY (BatchNorm2d.fwd lazy=True): t is the norm's INPUT and (mean, invstd, gamma, beta) is what
+        # the join that takes t as its residual normalises it by (ops.bn_apply res_norm) -- the norm's own apply pass never runs
+        self.res_norm = None
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -564,11 +567,15 @@ class BatchNorm2d(nn.Module):
             return True
         return self if SCHED.fuse_bn_finalize else True
 
-    def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None, planes=None):
+    def fwd(self, x, tape, relu, residual=None, chan_scale=None, out=None, dist=None, planes=None, lazy=False):
         """planes: "only" / "both" -- the output is (also) wanted as fp16 pair planes for the conv(s) that read it (Act.planes;
         "only": no fp32 copy is written); honoured when the bound of the output is computable (fp32 step, the range of x known
-        from the producing conv's epilogue, no dropout scale) -- otherwise the fp32 output alone, as without the request"""
+        from the producing conv's epilogue, no dropout scale) -- otherwise the fp32 output alone, as without the request.
+        lazy (a plain norm whose only reader is a join taking it as the residual -- a stage's downsample branch): statistics,
+        finalize and backward as always, but NO apply pass: the Act returned holds the norm's INPUT and `res_norm`, and the join's
+        own pass normalises it on the way in (bit-identical: the same operations, rounded to the storage type in between)."""
         xt = x.t
+        lazy = lazy and SCHED.lazy_downsample_norm and not relu and residual is None and chan_scale is None and out is None and planes is None
         if not self.sync:
             dist = None
         if self.training and x.bn is not None:            # finalized by the producing conv's statistics reduction
@@ -598,13 +605,20 @@ class BatchNorm2d(nn.Module):
         if pl == "only" and (RELU_TRACE is not None or (relu and tape.enabled and rmask is None)):
             pl = "both"                               # somebody reads the fp32 output itself
         pbuf = torch.empty(tuple(xt.shape), dtype=torch.float32, device=xt.device) if pl else None
-        y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
-                         residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out,
-                         relu_mask=rmask, amax_out=yamax, out_dtype=ydt, planes=pbuf, planes_only=pl == "only",
-                         amax_x=x.amax if pl else None, amax_res=residual.range() if (pl and residual is not None) else None)
-        ya = Act(y if y is not None else pbuf)
-        ya.amax = yamax                               # with planes: the bound they are scaled by (a valid range for any reader)
-        ya.planes, ya.split = pbuf, pl == "only"
+        if lazy and ydt == xt.dtype:
+            y = None
+            ya = Act(xt)
+            ya.res_norm = (mean, invstd, self.weight.detach(), self.bias.detach())
+            ya.amax = x.amax                          # the range of the RAW tensor (what rcf_bn_apply_res_mp's bound starts from)
+        else:
+            y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
+                             residual=residual.t if residual is not None else None, chan_scale=chan_scale, out=out,
+                             relu_mask=rmask, amax_out=yamax, out_dtype=ydt, planes=pbuf, planes_only=pl == "only",
+                             amax_x=x.amax if pl else None, amax_res=residual.range() if (pl and residual is not None) else None,
+                             res_norm=residual.res_norm if residual is not None else None)
+            ya = Act(y if y is not None else pbuf)
+            ya.amax = yamax                           # with planes: the bound they are scaled by (a valid range for any reader)
+            ya.planes, ya.split = pbuf, pl == "only"
         if RELU_TRACE is not None and relu:
             RELU_TRACE.append(y > 0)
         if tape.enabled:

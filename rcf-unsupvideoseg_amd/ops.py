@@ -748,8 +748,10 @@ def bn_invstd_from_var(var, eps):
 
 
 def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None, out=None, relu_mask=None,
-             amax_out=None, out_dtype=None, planes=None, planes_only=False, amax_x=None, amax_res=None):
+             amax_out=None, out_dtype=None, planes=None, planes_only=False, amax_x=None, amax_res=None, res_norm=None):
     """relu_mask: uint8 [rows * C/4] to receive the sign bits of the pre-clamp output (for the backward pass).
+    res_norm: (mean, invstd, gamma, beta) of a plain batch norm the RAW residual is normalised by on the fly
+    (rcf_bn_apply_res_mp: a stage's downsample branch, whose own apply pass then never runs); amax_res = the raw residual's range.
     out_dtype: storage type of y (default: x's); an fp32 x may be normalised into bf16 activations.
     planes: an fp32-typed buffer of y's shape that receives y as fp16 pair planes (RCF_CONV_X_PLANES of the consuming convs),
     scaled by a bound derived from amax_x (the range of x) and amax_res (of the residual); the bound goes to amax_out.
@@ -760,7 +762,11 @@ def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, chan_scale=None,
     rows, C = _rows(x), x.shape[3]
     ydt = _same_dt(out, residual) if out is not None else _dt(x)
     flags = BN_FLAGS | (_lib.BN_Y_PLANES_ONLY if (planes is not None and planes_only) else 0)
-    call("rcf_bn_apply_mp", _p(x), _dt(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
+    rn = None
+    if res_norm is not None:
+        rn = _lib.BnResNorm(*[t.data_ptr() for t in res_norm])
+    call("rcf_bn_apply_res_mp", _p(x), _dt(x), pitch_of(x), _p(residual), pitch_of(residual) if residual is not None else 0,
+         byref(rn) if rn is not None else None,
          _p(out), ydt, pitch_of(out) if out is not None else C, rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu),
          _p(chan_scale), x.shape[1] * x.shape[2], _p(relu_mask), _p(amax_out), _p(planes), _p(amax_x), _p(amax_res), flags,
          _stream())

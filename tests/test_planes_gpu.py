@@ -163,6 +163,44 @@ def test_batchnorm_writes_pair_planes(res, report):
     assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and (not res or torch.equal(dres0, dres1))
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_join_normalises_its_residual_on_the_fly(dt, report):
+    """rcf_bn_apply_res_mp: relu(bn3(z3) + bn_ds(z_ds)) in ONE pass over z3 and the RAW z_ds (a stage's downsample branch,
+    models/resnet.py:293-294) is bit-identical to the two passes it replaces -- output, sign bits, and (fp32) the pair planes,
+    whose bound starts from the raw residual's range."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 2, 29, 37, 256
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    z3 = (torch.randn(N, H, W, C, generator=g) * torch.exp2(3 * torch.rand(C, generator=g)) + 0.2).to(DEV).to(tdt)
+    zd = (torch.randn(N, H, W, C, generator=g) * 2.5 - 0.7).to(DEV).to(tdt)
+    ga3, be3 = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    gad, bed = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    count = N * H * W
+    m3, i3 = ops.bn_finalize(ops.bn_stats(z3), count, 1e-5, 0.1)
+    md, idd = ops.bn_finalize(ops.bn_stats(zd), count, 1e-5, 0.1)
+    idt = ops.bn_apply(zd, md, idd, gad, bed, False)
+    rm0, rm1 = (torch.empty(z3.numel() // 4, dtype=torch.uint8, device=DEV) for _ in range(2))
+    y0 = ops.bn_apply(z3, m3, i3, ga3, be3, True, residual=idt, relu_mask=rm0)
+    y1 = ops.bn_apply(z3, m3, i3, ga3, be3, True, residual=zd, relu_mask=rm1, res_norm=(md, idd, gad, bed))
+    assert torch.equal(y0, y1) and torch.equal(rm0, rm1)
+    msg = f"join with its residual normalised on the fly ({dt}): output and sign bits identical to the two passes"
+    if dt == "fp32":
+        ax, ar_raw, ar = ops.absmax(z3), ops.absmax(zd), ops.absmax(idt)
+        b0, p0, b1, p1 = ops.new_amax(DEV), torch.empty_like(z3), ops.new_amax(DEV), torch.empty_like(z3)
+        ops.bn_apply(z3, m3, i3, ga3, be3, True, residual=idt, relu_mask=rm0, amax_out=b0, planes=p0, planes_only=True, amax_x=ax, amax_res=ar)
+        ops.bn_apply(z3, m3, i3, ga3, be3, True, residual=zd, relu_mask=rm1, amax_out=b1, planes=p1, planes_only=True, amax_x=ax,
+                     amax_res=ar_raw, res_norm=(md, idd, gad, bed))
+        f0, f1 = float(b0.view(torch.float32)), float(b1.view(torch.float32))
+        k = 14 - int(np.floor(np.log2(f1)))
+        dec = from_planes(p1, k)
+        ymax = float(y0.abs().max())
+        big = y0.abs().double() > f1 * 2.0 ** -16
+        e_el = float(((dec - y0.double()).abs() / y0.abs().double().clamp_min(1e-30))[big].max())
+        msg += f"; planes: bound {f1 / ymax:.2f} x max |y| (two passes: {f0 / ymax:.2f}), element error {e_el:.1e}"
+        assert f1 >= ymax and f1 < 64 * ymax and e_el < 2.0 ** -21
+    report(msg)
+
+
 def test_training_step_with_and_without_pair_planes(report):
     """the same step with the planes on (default) and off (every conv splits its fp32 operands in registers): what changes is
     where the split happens and the tile of some weight gradients, not the arithmetic"""
