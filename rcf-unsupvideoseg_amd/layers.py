@@ -636,20 +636,35 @@ class BatchNorm2d(nn.Module):
                 # are the only readers); the bound needs the ranges of x and of dy
                 # (decided with the FORWARD pass's setting: a conv whose input exists as planes only cannot take an fp32 gradient,
                 # whatever the schedule object says by the time the backward pass runs)
-                dpl = (x.accepts_plane_grad and planes_at_fwd and xt.dtype == torch.float32 and x.amax is not None
-                       and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
-                ady = ya.take_grad_range() if dpl else None
-                dy = ya.take_grad()
+                relu_b, rmask_b, y_b = relu, rmask, y
+                pend = None
+                if ya.res_norm is not None and ya.pending_add is not None and ya.grad is None:
+                    # lazy downsample norm: the join left (its output gradient, its sign bits) instead of writing this norm's
+                    # output gradient -- the two passes below read the one under the other, as they would for a norm + ReLU
+                    pend = ya.take_pending()
+                if pend is not None:
+                    dy, rmask_b = pend
+                    relu_b, y_b = True, None
+                    dpl = (x.accepts_plane_grad and planes_at_fwd and xt.dtype == torch.float32 and x.amax is not None
+                           and dy.dtype == torch.float32)
+                    ady, ya.grad_amax = ya.grad_amax, None       # the join's: the mask only lowers the range
+                    if dpl and ady is None:
+                        ady = ops.absmax(dy)
+                else:
+                    dpl = (x.accepts_plane_grad and planes_at_fwd and xt.dtype == torch.float32 and x.amax is not None
+                           and (not relu or rmask is not None) and ya.grad is not None and ya.grad.dtype == torch.float32)
+                    ady = ya.take_grad_range() if dpl else None
+                    dy = ya.take_grad()
                 s2, ya.grad_sums2 = ya.grad_sums2, None          # from the epilogue of the data gradient that wrote dy last
                 s2_local = None
                 if isinstance(s2, tuple):                        # (global, local): exchanged already, together with the join's own
                     s2, s2_local = s2
                 else:
                     if s2 is None:
-                        s2 = ops.bn_bwd_reduce(dy, xt, y, mean, invstd, relu, chan_scale=chan_scale, relu_mask=rmask)
+                        s2 = ops.bn_bwd_reduce(dy, xt, y_b, mean, invstd, relu_b, chan_scale=chan_scale, relu_mask=rmask_b)
                     if dist is not None and dist.on:
                         s2_local = s2.clone()            # dgamma/dbeta stay per-rank; the gradient all-reduce adds them
-                        r_s2 = _residual_norm_sums(residual, dy, y, relu, rmask, chan_scale)
+                        r_s2 = _residual_norm_sums(residual, dy, y_b, relu_b, rmask_b, chan_scale)
                         if r_s2 is not None:
                             # a stage's first block: the downsample norm's backward sums depend on this join's masked output
                             # gradient only -- one exchange for both norms instead of two latency-bound ones
@@ -660,7 +675,11 @@ class BatchNorm2d(nn.Module):
                             dist.allreduce_sum(s2)
                 dres, rbeta = (None, 0)
                 if residual is not None and residual.needs_grad:
-                    if (SCHED.defer_residual and relu and rmask is not None and chan_scale is None and residual.addend_ok and residual.grad is None
+                    if (residual.res_norm is not None and relu and rmask is not None and chan_scale is None and residual.grad is None
+                            and residual.pending_add is None and dy.dtype == residual.t.dtype and dy.is_contiguous()):
+                        residual.pending_add = (dy, rmask)       # the lazy downsample norm's backward reads dy under this mask itself
+                        residual.grad_amax = ady
+                    elif (SCHED.defer_residual and relu and rmask is not None and chan_scale is None and residual.addend_ok and residual.grad is None
                             and residual.pending_add is None and dy.dtype == torch.float32 and residual.t.dtype == torch.float32
                             and dy.is_contiguous()):
                         residual.pending_add = (dy, rmask)       # the identity's gradient = dy under this join's mask: not written here
@@ -672,11 +691,11 @@ class BatchNorm2d(nn.Module):
                             residual.grad_amax = ady
                 gx, _ = x.grad_slot()     # conv outputs feed exactly one BN: always first writer
                 gamax = x.grad_amax = ops.new_amax(dy.device) if SCHED.fp16_pairs and xt.dtype == torch.float32 else None
-                ops.bn_bwd_apply(dy, xt, y, mean, invstd, self.weight, relu, s2, count,
+                ops.bn_bwd_apply(dy, xt, y_b, mean, invstd, self.weight, relu_b, s2, count,
                                  _param_grad(self.weight) if self.weight.requires_grad else None,
                                  _param_grad(self.bias) if self.bias.requires_grad else None,
                                  dx=gx, dres=dres, res_beta=rbeta, chan_scale=chan_scale, sums2_local=s2_local,
-                                 relu_mask=rmask, amax_out=gamax, dx_planes=dpl, amax_x=x.amax if dpl else None, amax_dy=ady)
+                                 relu_mask=rmask_b, amax_out=gamax, dx_planes=dpl, amax_x=x.amax if dpl else None, amax_dy=ady)
                 x.grad_is_planes = dpl
             tape.push(bwd)
         return ya
