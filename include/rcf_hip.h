@@ -404,6 +404,34 @@ int rcf_bn_apply_res_mp(const void *x, int xdt, int x_pitch, const void *residua
                         const float *gamma, const float *beta, int relu, const float *chan_scale, long rows_per_image,
                         unsigned char *relu_mask, unsigned *amax_out, void *planes_out, const unsigned *amax_x,
                         const unsigned *amax_res, unsigned flags, void *stream);
+/* The join of a stage's first block together with its downsample norm in the backward pass (models/resnet.py:293-296): both
+ * norms' backward is taken of g = dy under the JOIN's sign bits, against conv3's output x and the downsample conv's output x2.
+ * rcf_bn_bwd_reduce2_mp: ONE reduction -> sums4 [4C] = [sum g | sum g xhat | sum g | sum g xhat2] (each norm's [2C] pair is
+ * contiguous: what rcf_bn_bwd_reduce_mp would give it, bit for bit); workspace: 2 x rcf_bn_stats_workspace_bytes(rows, C).
+ * rcf_bn_bwd_apply2_mp: ONE apply pass -> dx and second->dx (both fp32 / bf16, or with RCF_BN_DX_PLANES both as fp16 pair
+ * planes, each with its own bound in its own amax_out), the parameter gradients of both norms; dy and the sign bits are read
+ * once.  Same element operations in the same order as two rcf_bn_bwd_apply_mp calls with relu = 1 and this mask. */
+typedef struct rcf_bn_bwd_second {
+    const void *x;                 /* the second norm's input [rows][C], storage type of x */
+    int x_pitch;
+    void *dx;                      /* its input gradient */
+    int dx_pitch;
+    const float *mean, *invstd, *gamma;
+    const double *sums2;           /* [2C] (global under SyncBN) */
+    const double *sums2_local;     /* [2C] this rank's (parameter gradients); NULL = sums2 */
+    float *dgamma, *dbeta;         /* accumulated into; may be NULL */
+    unsigned *amax_out;            /* range of dx (fp32 / bf16: may be NULL) or, with planes, the bound they are scaled by */
+    const unsigned *amax_x;        /* planes: range of x */
+} rcf_bn_bwd_second;
+int rcf_bn_bwd_reduce2_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *x2, int x2_pitch,
+                          long rows, int C, const float *mean, const float *invstd, const float *mean2, const float *invstd2,
+                          const unsigned char *relu_mask, double *sums4, void *workspace, size_t workspace_bytes, unsigned flags,
+                          void *stream);
+int rcf_bn_bwd_apply2_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, void *dx, int dx_pitch,
+                         long rows, int C, const float *mean, const float *invstd, const float *gamma,
+                         const unsigned char *relu_mask, const double *sums2, const double *sums2_local, double count,
+                         float *dgamma, float *dbeta, unsigned *amax_out, const unsigned *amax_x, const unsigned *amax_dy,
+                         const rcf_bn_bwd_second *second, unsigned flags, void *stream);
 int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *y,
                          int y_pitch, long rows, int C, const float *mean, const float *invstd, int relu,
                          const unsigned char *relu_mask, const float *chan_scale, long rows_per_image, double *sums2,

@@ -61,6 +61,12 @@ class BnResNorm(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("mean", "invstd", "gamma", "beta")]
 
 
+class BnBwdSecond(ctypes.Structure):
+    """struct rcf_bn_bwd_second of include/rcf_hip.h"""
+    _fields_ = [("x", ctypes.c_void_p), ("x_pitch", c_int), ("dx", ctypes.c_void_p), ("dx_pitch", c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("mean", "invstd", "gamma", "sums2", "sums2_local", "dgamma", "dbeta", "amax_out", "amax_x")]
+
+
 class ConvRegion(ctypes.Structure):
     """mirror of rcf_conv_region"""
     _fields_ = [(n, c_int) for n in ("y0", "x0", "h", "w", "band")]
@@ -180,6 +186,9 @@ PROTOS = {
                                 P, P, P, P, c_uint, P]),
     "rcf_bn_apply_res_mp": (c_int, [P, c_int, c_int, P, c_int, P, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,
                                     P, P, P, P, c_uint, P]),
+    "rcf_bn_bwd_reduce2_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, P, P, P, P, P, c_size_t, c_uint, P]),
+    "rcf_bn_bwd_apply2_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, P, P, P, P, c_double, P, P, P, P, P, P,
+                                     c_uint, P]),
     "rcf_bn_bwd_reduce_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, P, P, c_int, P, P, c_long,
                                      P, P, c_size_t, c_uint, P]),
     "rcf_bn_bwd_apply_mp": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P,

@@ -201,6 +201,8 @@ class Schedule:
       defer_residual     fp32 step: a join does not write its identity branch's gradient; conv1's data gradient adds it
       lazy_downsample_norm  a stage's downsample norm has no apply pass: the join that adds it normalises the raw conv output on
                          the way in (bit-identical; one read and one write of the 4C-wide tensor less per stage)
+      merge_downsample_bwd  ... and in the backward pass that norm and the join share ONE reduction and ONE apply pass over the join's
+                         output gradient and sign bits (bit-identical to the separate passes)
       fold_bn            bf16 step: 1x1 conv -> norm (-> + residual -> ReLU) as ONE tile, statistics from the Gram matrix of the
                          conv's input, algebraic backward: neither the conv output nor its gradient exists (layers.conv_bn_fold)
       fold_max_k         ... for convs with at most this many input channels (the Gram matrix costs 2 rows K^2 FLOPs)
@@ -221,7 +223,7 @@ class Schedule:
                          (no multi-GPU box has been reachable from the build container: DESIGN.md section 7)."""
 
     __slots__ = ("overlap_wgrad", "late_wgrad", "side_priority", "overlap_teacher", "fuse_bn_stats", "fuse_bn_finalize",
-                 "fuse_bn_bwd", "relu_bitmask", "defer_residual", "lazy_downsample_norm", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
+                 "fuse_bn_bwd", "relu_bitmask", "defer_residual", "lazy_downsample_norm", "merge_downsample_bwd", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
                  "h2_kinds", "planes", "join_planes", "bf16_stem", "cache_weight_operands", "bulk_weight_prep", "grad_group",
                  "teacher_group")
 
@@ -229,6 +231,7 @@ class Schedule:
         self.overlap_wgrad = self.late_wgrad = self.overlap_teacher = True
         self.side_priority = 0
         self.fuse_bn_stats = self.fuse_bn_finalize = self.relu_bitmask = self.defer_residual = self.lazy_downsample_norm = True
+        self.merge_downsample_bwd = True
         self.fuse_bn_bwd = False
         self.fold_bn, self.fold_max_k, self.fold_masked_dgrad = True, 512, True
         self.fp16_pairs, self.h2_kinds, self.planes, self.join_planes = True, "fdw", True, "stage"

@@ -269,6 +269,99 @@ struct BwdOp {
     }
 };
 
+// ---- the join of a stage's first block and its (lazy) downsample norm in ONE reduction: both norms' backward sums are taken of
+// the same g = dy under the join's sign bits, against their own inputs x (conv3's output) and x2 (the downsample conv's).
+// Four column sums [sum g | sum g xhat | sum g | sum g xhat2] (the first repeated: each norm's [2C] pair is contiguous), every one
+// accumulated from the same addends in the same order as rcf_bn_bwd_reduce_mp would: bit-identical to the two passes.
+template <typename XT, typename YT, int V>
+struct BwdOp2 {
+    const YT *dy;
+    const XT *x, *x2;
+    const float *mean, *invstd, *mean2, *invstd2;
+    int dy_pitch, x_pitch, x2_pitch, C;
+    const unsigned char *mask;
+    fvec<V> mu, is, mu2, is2;
+    __device__ void init(int c0) {
+        mu = ldv<float, V>(mean + c0); is = ldv<float, V>(invstd + c0);
+        mu2 = ldv<float, V>(mean2 + c0); is2 = ldv<float, V>(invstd2 + c0);
+    }
+    __device__ void operator()(long r, int c0, float (&o)[3][V]) const {
+        fvec<V> g = ldv<YT, V>(dy + r * dy_pitch + c0);
+        const fvec<V> xv = ldv<XT, V>(x + r * x_pitch + c0), xw = ldv<XT, V>(x2 + r * x2_pitch + c0);
+        const unsigned char *mp = mask + r * (C >> 2) + (c0 >> 2);
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h) {
+            const unsigned m = mp[h];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g.q[h][e] = (m >> e) & 1u ? g.q[h][e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int h = e >> 2, k = e & 3;
+            o[0][e] = g.q[h][k];
+            o[1][e] = g.q[h][k] * ((xv.q[h][k] - mu.q[h][k]) * is.q[h][k]);
+            o[2][e] = g.q[h][k] * ((xw.q[h][k] - mu2.q[h][k]) * is2.q[h][k]);
+        }
+    }
+};
+
+// colreduce2_kernel with three accumulators; partial rows are [4C] = [s0 | s1 | s0 | s2]
+template <class F, int V>
+__global__ void __launch_bounds__(RED_THREADS) colreduce3_kernel(F f, long rows, int C, int cvB, int RG, long rows_per_chunk,
+                                                                 double *__restrict__ partial, Sweep sw = Sweep{0, 1, 0}) {
+    __shared__ double red[RED_THREADS * 3 * V];
+    const int tid = threadIdx.x;
+    const int cv = tid % cvB, rg = tid / cvB;
+    const int c0 = (blockIdx.y * cvB + cv) * V;
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    const long r1 = min(rows, r0 + rows_per_chunk);
+    double s[3][V];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[k][e] = 0;
+    if (rg < RG && c0 < C) {
+        f.init(c0);
+        auto take = [&](long r) {
+            float o[3][V];
+            f(r, c0, o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[k][e] += (double)o[k][e];
+        };
+        if (sw.mode) {
+            const long lend = sw.positions(rows), lstep = (long)gridDim.x * RG;
+            for (long l = (long)blockIdx.x * RG + rg; l < lend; l += lstep) {
+                const long r = sw.row(l);
+                if (r < rows) take(r);
+            }
+        } else {
+            for (long r = r0 + rg; r < r1; r += RG) take(r);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[(tid * 3 + k) * V + e] = s[k][e];
+    __syncthreads();
+    if (rg == 0 && c0 < C) {
+        for (int g = 1; g < RG; ++g)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[k][e] += red[((g * cvB + cv) * 3 + k) * V + e];
+        double *dst = partial + (long)blockIdx.x * 4 * C;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            dst[c0 + e] = s[0][e];
+            dst[C + c0 + e] = s[1][e];
+            dst[2 * C + c0 + e] = s[0][e];
+            dst[3 * C + c0 + e] = s[2][e];
+        }
+    }
+}
+
 __global__ void bn_finalize_kernel(const double *__restrict__ sums, double count, int C, float eps, float momentum,
                                    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ rmean,
                                    float *__restrict__ rvar) {
@@ -694,6 +787,130 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(
     }
 }
 
+// ---- ... and ONE apply pass for both norms (rcf_bn_bwd_apply2_mp): dy and the sign bits are read once, dx = the gradient of
+// conv3's output and dx2 = that of the downsample conv's come out together (fp32, or both as fp16 pair planes: PL = 1, each with
+// its own bound).  Per element the operations of bn_bwd_apply_kernel in its order.
+struct BwdSecond {
+    const void *x;
+    void *dx;
+    int x_pitch, dx_pitch;
+    const float *mean, *invstd, *gamma;
+    const double *sums2, *sums2_param;
+    float *dgamma, *dbeta;
+    unsigned *amax;
+    const unsigned *amax_x;
+};
+
+template <typename XT, typename YT, int V, int PL = 0>
+__global__ void __launch_bounds__(256) bn_bwd_apply2_kernel(
+    const YT *__restrict__ dy, int dy_pitch, const XT *__restrict__ x, int x_pitch, XT *__restrict__ dx, int dx_pitch, long rows,
+    int C, int cvt, int rpb, const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+    const double *__restrict__ sums2, const double *__restrict__ sums2_param, double count, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, const unsigned char *__restrict__ mask, unsigned *__restrict__ amax, Sweep sw,
+    const unsigned *__restrict__ amax_x, const unsigned *__restrict__ amax_dy, BwdSecond b2) {
+    const int CV = C / V;
+    const XT *__restrict__ x2 = reinterpret_cast<const XT *>(b2.x);
+    XT *__restrict__ dx2 = reinterpret_cast<XT *>(b2.dx);
+    float pls = 1.f, pls2 = 1.f;
+    if constexpr (PL != 0) {
+        const float ag = __uint_as_float(*amax_dy), ic = (float)(1.0 / count);
+        const float ax = __uint_as_float(*amax_x), ax2 = __uint_as_float(*b2.amax_x);
+        float b = 0.f, bb = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float is = invstd[c], X = (ax + fabsf(mean[c])) * is;
+            b = fmaxf(b, fabsf(gamma[c]) * is * (ag + fabsf((float)sums2[c] * ic) + X * fabsf((float)sums2[C + c] * ic)));
+            const float is2 = b2.invstd[c], X2 = (ax2 + fabsf(b2.mean[c])) * is2;
+            bb = fmaxf(bb, fabsf(b2.gamma[c]) * is2 * (ag + fabsf((float)b2.sums2[c] * ic) + X2 * fabsf((float)b2.sums2[C + c] * ic)));
+        }
+        b = block_max_f(b) * 1.0000005f;
+        __syncthreads();
+        bb = block_max_f(bb) * 1.0000005f;
+        const unsigned bits = __float_as_uint(b), bits2 = __float_as_uint(bb);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *amax = bits; *b2.amax = bits2; }
+        pls = pl_pow2(pl_exponent(bits));
+        pls2 = pl_pow2(pl_exponent(bits2));
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (dgamma) dgamma[c] += (float)sums2_param[C + c];
+            if (dbeta) dbeta[c] += (float)sums2_param[c];
+            if (b2.dgamma) b2.dgamma[c] += (float)b2.sums2_param[C + c];
+            if (b2.dbeta) b2.dbeta[c] += (float)b2.sums2_param[c];
+        }
+    }
+    const int cx = threadIdx.x % cvt, ry = threadIdx.x / cvt;
+    const int cv = blockIdx.y * cvt + cx;
+    const bool active = ry < rpb && cv < CV;
+    const int c0 = cv * V;
+    unsigned mx = 0u, mx2 = 0u;
+    if (active) {
+        const float inv_count = (float)(1.0 / count);
+        const fvec<V> mu = ldv<float, V>(mean + c0), is = ldv<float, V>(invstd + c0), ga = ldv<float, V>(gamma + c0);
+        const fvec<V> mu2 = ldv<float, V>(b2.mean + c0), is2 = ldv<float, V>(b2.invstd + c0), ga2 = ldv<float, V>(b2.gamma + c0);
+        fvec<V> sg, sgx, sg2, sgx2;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            sg.q[e >> 2][e & 3] = (float)sums2[c0 + e] * inv_count;
+            sgx.q[e >> 2][e & 3] = (float)sums2[C + c0 + e] * inv_count;
+            sg2.q[e >> 2][e & 3] = (float)b2.sums2[c0 + e] * inv_count;
+            sgx2.q[e >> 2][e & 3] = (float)b2.sums2[C + c0 + e] * inv_count;
+        }
+        const long rstep = (long)gridDim.x * rpb;
+        auto finish = [&](long r, fvec<V> g, const fvec<V> &xv, const fvec<V> &xw) {
+            const unsigned char *mp = mask + r * (C >> 2) + (c0 >> 2);
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const unsigned m = mp[h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g.q[h][e] = (m >> e) & 1u ? g.q[h][e] : 0.f;
+            }
+            fvec<V> o, o2;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int h = e >> 2, k = e & 3;
+                const float xh = (xv.q[h][k] - mu.q[h][k]) * is.q[h][k];
+                o.q[h][k] = ga.q[h][k] * is.q[h][k] * (g.q[h][k] - sg.q[h][k] - xh * sgx.q[h][k]);
+                const float xh2 = (xw.q[h][k] - mu2.q[h][k]) * is2.q[h][k];
+                o2.q[h][k] = ga2.q[h][k] * is2.q[h][k] * (g.q[h][k] - sg2.q[h][k] - xh2 * sgx2.q[h][k]);
+            }
+            if constexpr (PL != 0) {
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) {
+                    pl_store4(reinterpret_cast<char *>(dx) + r * (4L * C), C, c0 + 4 * h, o.q[h], pls);
+                    pl_store4(reinterpret_cast<char *>(dx2) + r * (4L * C), C, c0 + 4 * h, o2.q[h], pls2);
+                }
+            } else {
+                stv<XT, V>(dx + r * dx_pitch + c0, o);
+                stv<XT, V>(dx2 + r * b2.dx_pitch + c0, o2);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    mx = max(mx, __float_as_uint(fabsf(o.q[e >> 2][e & 3])));
+                    mx2 = max(mx2, __float_as_uint(fabsf(o2.q[e >> 2][e & 3])));
+                }
+            }
+        };
+        long l = (long)blockIdx.x * rpb + ry;
+        const long lend = sw.positions(rows);
+        for (; l + rstep < lend; l += 2 * rstep) {      // two rows in flight
+            const long ra = sw.row(l), rb = sw.row(l + rstep);
+            const bool va = ra < rows, vb = rb < rows;
+            fvec<V> g0{}, g1{}, x0{}, x1{}, w0{}, w1{};
+            if (va) { g0 = ldv<YT, V>(dy + ra * dy_pitch + c0); x0 = ldv<XT, V>(x + ra * x_pitch + c0); w0 = ldv<XT, V>(x2 + ra * b2.x_pitch + c0); }
+            if (vb) { g1 = ldv<YT, V>(dy + rb * dy_pitch + c0); x1 = ldv<XT, V>(x + rb * x_pitch + c0); w1 = ldv<XT, V>(x2 + rb * b2.x_pitch + c0); }
+            if (va) finish(ra, g0, x0, w0);
+            if (vb) finish(rb, g1, x1, w1);
+        }
+        if (l < lend) {
+            const long ra = sw.row(l);
+            if (ra < rows) finish(ra, ldv<YT, V>(dy + ra * dy_pitch + c0), ldv<XT, V>(x + ra * x_pitch + c0), ldv<XT, V>(x2 + ra * b2.x_pitch + c0));
+        }
+    }
+    if constexpr (PL == 0) {
+        if (amax) block_amax(mx, amax);
+        if (b2.amax) { __syncthreads(); block_amax(mx2, b2.amax); }
+    }
+}
+
 template <typename XT, int V>
 struct ColsumOp {
     const XT *x;
@@ -1055,4 +1272,76 @@ extern "C" int rcf_colsum_mp(const void *x, int xdt, long rows, int C, int pitch
 extern "C" int rcf_colsum_f32(const float *x, long rows, int C, int pitch, float *out, int beta, void *workspace,
                               size_t workspace_bytes, void *stream) {
     return rcf_colsum_mp(x, RCF_F32, rows, C, pitch, out, beta, workspace, workspace_bytes, stream);
+}
+
+
+/* ---- a stage's first block: the join and its (lazy) downsample norm in one reduction and one apply pass (include/rcf_hip.h) */
+extern "C" int rcf_bn_bwd_reduce2_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, const void *x2,
+                                     int x2_pitch, long rows, int C, const float *mean, const float *invstd, const float *mean2,
+                                     const float *invstd2, const unsigned char *relu_mask, double *sums4, void *workspace,
+                                     size_t workspace_bytes, unsigned flags, void *stream) {
+    if (!dy || !x || !x2 || !mean || !invstd || !mean2 || !invstd2 || !relu_mask || !sums4 || rows <= 0 || C <= 0 || C % 4) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || x2_pitch % 4 || xdt != ydt || (xdt != RCF_F32 && xdt != RCF_BF16)) return RCF_EINVAL;
+    if (!workspace || workspace_bytes < 2 * rcf_bn_stats_workspace_bytes(rows, C)) return RCF_EWORKSPACE;
+    const int V = (xdt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && x_pitch % 8 == 0 && x2_pitch % 8 == 0) ? 8 : 4;
+    const ColGeom g = col_geom(rows, C, V);
+    hipStream_t st = rcf_stream(stream);
+    if (xdt == RCF_BF16 && V == 8) {
+        BwdOp2<bf16_t, bf16_t, 8> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)x2, mean, invstd, mean2, invstd2, dy_pitch,
+                                     x_pitch, x2_pitch, C, relu_mask, {}, {}, {}, {}};
+        hipLaunchKernelGGL((colreduce3_kernel<BwdOp2<bf16_t, bf16_t, 8>, 8>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,
+                           rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 2, flags));
+    } else if (xdt == RCF_BF16) {
+        BwdOp2<bf16_t, bf16_t, 4> op{(const bf16_t *)dy, (const bf16_t *)x, (const bf16_t *)x2, mean, invstd, mean2, invstd2, dy_pitch,
+                                     x_pitch, x2_pitch, C, relu_mask, {}, {}, {}, {}};
+        hipLaunchKernelGGL((colreduce3_kernel<BwdOp2<bf16_t, bf16_t, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,
+                           rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 2, flags));
+    } else {
+        BwdOp2<float, float, 4> op{(const float *)dy, (const float *)x, (const float *)x2, mean, invstd, mean2, invstd2, dy_pitch,
+                                   x_pitch, x2_pitch, C, relu_mask, {}, {}, {}, {}};
+        hipLaunchKernelGGL((colreduce3_kernel<BwdOp2<float, float, 4>, 4>), dim3(g.chunks, g.cgroups), dim3(RED_THREADS), 0, st, op,
+                           rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 4, flags));
+    }
+    RCF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(4 * C, 32)), dim3(256), 0, st, (const double *)workspace, g.chunks, 4 * C, sums4);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_bn_bwd_apply2_mp(const void *dy, int ydt, int dy_pitch, const void *x, int xdt, int x_pitch, void *dx,
+                                    int dx_pitch, long rows, int C, const float *mean, const float *invstd, const float *gamma,
+                                    const unsigned char *relu_mask, const double *sums2, const double *sums2_local, double count,
+                                    float *dgamma, float *dbeta, unsigned *amax_out, const unsigned *amax_x,
+                                    const unsigned *amax_dy, const rcf_bn_bwd_second *second, unsigned flags, void *stream) {
+    if (!dy || !x || !dx || !mean || !invstd || !gamma || !sums2 || !relu_mask || !second || rows <= 0 || C <= 0 || C % 4 || count <= 0)
+        return RCF_EINVAL;
+    if (!second->x || !second->dx || !second->mean || !second->invstd || !second->gamma || !second->sums2) return RCF_EINVAL;
+    if (dy_pitch % 4 || x_pitch % 4 || dx_pitch % 4 || second->x_pitch % 4 || second->dx_pitch % 4 || xdt != ydt) return RCF_EINVAL;
+    BwdSecond b2{second->x, second->dx, second->x_pitch, second->dx_pitch, second->mean, second->invstd, second->gamma, second->sums2,
+                 second->sums2_local ? second->sums2_local : second->sums2, second->dgamma, second->dbeta, second->amax_out, second->amax_x};
+    const double *sp = sums2_local ? sums2_local : sums2;
+    if (flags & RCF_BN_DX_PLANES) {
+        if (xdt != RCF_F32 || C % 8 || dx_pitch != C || second->dx_pitch != C || !amax_x || !amax_dy || !amax_out || !second->amax_x ||
+            !second->amax_out || !rcf_aligned16(dx) || !rcf_aligned16(second->dx))
+            return RCF_EINVAL;
+        const EwGeom g = ew_geom(rows, C / 4);
+        hipLaunchKernelGGL((bn_bwd_apply2_kernel<float, float, 4, 1>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)dy, dy_pitch,
+                           (const float *)x, x_pitch, (float *)dx, dx_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, sums2, sp, count,
+                           dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 4, flags), amax_x, amax_dy, b2);
+    } else if (xdt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0 && second->x_pitch % 8 == 0 &&
+               second->dx_pitch % 8 == 0) {
+        const EwGeom g = ew_geom(rows, C / 8);
+        hipLaunchKernelGGL((bn_bwd_apply2_kernel<bf16_t, bf16_t, 8, 0>), g.grid, dim3(256), 0, rcf_stream(stream), (const bf16_t *)dy,
+                           dy_pitch, (const bf16_t *)x, x_pitch, (bf16_t *)dx, dx_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, sums2,
+                           sp, count, dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 2, flags), amax_x, amax_dy, b2);
+    } else if (xdt == RCF_F32) {
+        const EwGeom g = ew_geom(rows, C / 4);
+        hipLaunchKernelGGL((bn_bwd_apply2_kernel<float, float, 4, 0>), g.grid, dim3(256), 0, rcf_stream(stream), (const float *)dy, dy_pitch,
+                           (const float *)x, x_pitch, (float *)dx, dx_pitch, rows, C, g.cvt, g.rpb, mean, invstd, gamma, sums2, sp, count,
+                           dgamma, dbeta, relu_mask, amax_out, make_sweep(1, rows, g.rpb, (long)C * 4, flags), amax_x, amax_dy, b2);
+    } else {
+        return RCF_EINVAL;
+    }
+    RCF_LAUNCH_CHECK();
+    return 0;
 }

@@ -30,7 +30,7 @@ class Act:
     """An NHWC activation [N,H,W,C] plus its (lazily created) gradient buffer."""
     __slots__ = ("t", "grad", "needs_grad", "stats", "bn", "amax", "grad_amax", "planes", "split", "accepts_plane_grad",
                  "grad_is_planes", "stats_global", "bn_ctx", "first_reader", "grad_sums2", "pending_add", "addend_ok",
-                 "relu_out", "grad_masked", "grad_colsum", "bn_in", "relu_bits", "res_norm")
+                 "relu_out", "grad_masked", "grad_colsum", "bn_in", "relu_bits", "res_norm", "res_ctx", "res_done")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.grad, self.needs_grad = t, None, needs_grad
@@ -64,6 +64,9 @@ class Act:
         # a plain norm applied LAZILY (BatchNorm2d.fwd lazy=True): t is the norm's INPUT and (mean, invstd, gamma, beta) is what
         # the join that takes t as its residual normalises it by (ops.bn_apply res_norm) -- the norm's own apply pass never runs
         self.res_norm = None
+        # ... (the norm module, its input Act, its row count) for the join that runs that norm's backward beside its own
+        # (SCHED.merge_downsample_bwd: one reduction + one apply pass for both), and the flag by which it tells the norm's own closure
+        self.res_ctx, self.res_done = None, False
 
     def range(self):
         """max |t| as a device scalar, computed once per activation (every conv reading it shares the value)"""
@@ -609,6 +612,7 @@ class BatchNorm2d(nn.Module):
             y = None
             ya = Act(xt)
             ya.res_norm = (mean, invstd, self.weight.detach(), self.bias.detach())
+            ya.res_ctx = (self, x, count)
             ya.amax = x.amax                          # the range of the RAW tensor (what rcf_bn_apply_res_mp's bound starts from)
         else:
             y = ops.bn_apply(xt, mean, invstd, self.weight, self.bias, relu,
@@ -632,6 +636,9 @@ class BatchNorm2d(nn.Module):
             planes_at_fwd = bool(SCHED.planes)
 
             def bwd():
+                if ya.res_done:                       # the join ran this (lazy downsample) norm's backward beside its own
+                    ya.res_done = False
+                    return
                 # dx as fp16 pair planes when the conv that produced x takes its output gradient so (its data and weight gradient
                 # are the only readers); the bound needs the ranges of x and of dy
                 # (decided with the FORWARD pass's setting: a conv whose input exists as planes only cannot take an fp32 gradient,
@@ -657,6 +664,40 @@ class BatchNorm2d(nn.Module):
                     dy = ya.take_grad()
                 s2, ya.grad_sums2 = ya.grad_sums2, None          # from the epilogue of the data gradient that wrote dy last
                 s2_local = None
+                if (s2 is None and pend is None and SCHED.merge_downsample_bwd and residual is not None and residual.res_ctx is not None
+                        and residual.needs_grad and relu and rmask is not None and chan_scale is None and residual.grad is None
+                        and residual.pending_add is None and dy.dtype == xt.dtype == residual.t.dtype and dy.is_contiguous()):
+                    # a stage's first block: this join and its lazy downsample norm take their backward of the same masked gradient --
+                    # ONE reduction and ONE apply pass over dy and the sign bits for both (rcf_bn_bwd_reduce2_mp / _apply2_mp)
+                    bn_d, x_d, count_d = residual.res_ctx
+                    mean_d, invstd_d = residual.res_norm[0], residual.res_norm[1]
+                    dpl_d = (x_d.accepts_plane_grad and planes_at_fwd and x_d.t.dtype == torch.float32 and x_d.amax is not None
+                             and dy.dtype == torch.float32)
+                    if dpl_d == dpl and count_d == count and x_d.t.is_contiguous() and xt.is_contiguous():
+                        C = xt.shape[3]
+                        sums4 = ops.bn_bwd_reduce2(dy, xt, x_d.t, mean, invstd, mean_d, invstd_d, rmask)
+                        local4 = None
+                        if dist is not None and dist.on:
+                            local4 = sums4.clone()       # dgamma / dbeta stay per rank; the gradient all-reduce adds them
+                            dist.allreduce_sum(sums4)    # one exchange for both norms
+                        gx, _ = x.grad_slot()
+                        gxd, _ = x_d.grad_slot()
+                        fp = SCHED.fp16_pairs and xt.dtype == torch.float32
+                        gamax = x.grad_amax = ops.new_amax(dy.device) if fp else None
+                        gamax_d = x_d.grad_amax = ops.new_amax(dy.device) if fp else None
+                        ops.bn_bwd_apply2(dy, xt, mean, invstd, self.weight, rmask, sums4[:2 * C], count,
+                                          _param_grad(self.weight) if self.weight.requires_grad else None,
+                                          _param_grad(self.bias) if self.bias.requires_grad else None, gx,
+                                          x_d.t, mean_d, invstd_d, bn_d.weight, sums4[2 * C:],
+                                          _param_grad(bn_d.weight) if bn_d.weight.requires_grad else None,
+                                          _param_grad(bn_d.bias) if bn_d.bias.requires_grad else None, gxd,
+                                          sums2_local=local4[:2 * C] if local4 is not None else None,
+                                          sums2_2_local=local4[2 * C:] if local4 is not None else None,
+                                          amax_out=gamax, amax_out2=gamax_d, dx_planes=dpl, amax_x=x.amax if dpl else None,
+                                          amax_x2=x_d.amax if dpl else None, amax_dy=ady)
+                        x.grad_is_planes = x_d.grad_is_planes = dpl
+                        residual.res_done = True
+                        return
                 if isinstance(s2, tuple):                        # (global, local): exchanged already, together with the join's own
                     s2, s2_local = s2
                 else:

@@ -800,6 +800,33 @@ def bn_bwd_apply(dy, x, y, mean, invstd, gamma, relu, sums2, count, dgamma, dbet
     return dx
 
 
+def bn_bwd_reduce2(dy, x, x2, mean, invstd, mean2, invstd2, relu_mask):
+    """[sum g | sum g xhat | sum g | sum g xhat2] (fp64 [4C]) of g = dy under relu_mask against two norm inputs in ONE pass
+    (rcf_bn_bwd_reduce2_mp: a stage's first join + its downsample norm)"""
+    rows, C = _rows(x), x.shape[3]
+    sums4 = torch.empty(4 * C, dtype=torch.float64, device=x.device)
+    need = 2 * _lib.load().rcf_bn_stats_workspace_bytes(rows, C)
+    ws = workspace(need, x.device)
+    call("rcf_bn_bwd_reduce2_mp", _p(dy), _same_dt(dy), pitch_of(dy), _p(x), _same_dt(x, x2), pitch_of(x), _p(x2), pitch_of(x2), rows, C,
+         _p(mean), _p(invstd), _p(mean2), _p(invstd2), _p(relu_mask), _p(sums4), _p(ws), need, BN_FLAGS, _stream())
+    return sums4
+
+
+def bn_bwd_apply2(dy, x, mean, invstd, gamma, relu_mask, sums2, count, dgamma, dbeta, dx, x2, mean2, invstd2, gamma2, sums2_2,
+                  dgamma2, dbeta2, dx2, sums2_local=None, sums2_2_local=None, amax_out=None, amax_out2=None, dx_planes=False,
+                  amax_x=None, amax_x2=None, amax_dy=None):
+    """both norms' input gradients (and parameter gradients) in ONE pass over dy and the sign bits (rcf_bn_bwd_apply2_mp)"""
+    rows, C = _rows(x), x.shape[3]
+    sec = _lib.BnBwdSecond(x2.data_ptr(), pitch_of(x2), dx2.data_ptr(), pitch_of(dx2), mean2.data_ptr(), invstd2.data_ptr(),
+                           gamma2.data_ptr(), sums2_2.data_ptr(), sums2_2_local.data_ptr() if sums2_2_local is not None else None,
+                           dgamma2.data_ptr() if dgamma2 is not None else None, dbeta2.data_ptr() if dbeta2 is not None else None,
+                           amax_out2.data_ptr() if amax_out2 is not None else None, amax_x2.data_ptr() if amax_x2 is not None else None)
+    call("rcf_bn_bwd_apply2_mp", _p(dy), _same_dt(dy), pitch_of(dy), _p(x), _same_dt(x, dx, x2, dx2), pitch_of(x), _p(dx), pitch_of(dx),
+         rows, C, _p(mean), _p(invstd), _p(gamma), _p(relu_mask), _p(sums2), _p(sums2_local), float(count), _p(dgamma), _p(dbeta),
+         _p(amax_out), _p(amax_x), _p(amax_dy), byref(sec), BN_FLAGS | (_lib.BN_DX_PLANES if dx_planes else 0), _stream())
+    return dx, dx2
+
+
 def maxpool_fwd(x):
     N, H, W, C = x.shape
     assert x.is_contiguous()

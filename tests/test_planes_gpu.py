@@ -201,6 +201,44 @@ def test_join_normalises_its_residual_on_the_fly(dt, report):
     report(msg)
 
 
+@pytest.mark.parametrize("dt,planes", [("fp32", False), ("fp32", True), ("bf16", False)])
+def test_join_and_downsample_norm_share_their_backward_passes(dt, planes, report):
+    """rcf_bn_bwd_reduce2_mp / rcf_bn_bwd_apply2_mp: the join of a stage's first block and its downsample norm take their backward of
+    the same masked gradient in ONE reduction and ONE apply pass -- sums, both input gradients (fp32 / bf16 / pair planes with their
+    bounds) and both norms' parameter gradients bit-identical to the four separate passes."""
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 2, 31, 45, 256
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    z3 = (torch.randn(N, H, W, C, generator=g) * 1.7 + 0.2).to(DEV).to(tdt)
+    zd = (torch.randn(N, H, W, C, generator=g) * 2.5 - 0.7).to(DEV).to(tdt)
+    dy = torch.randn(N, H, W, C, generator=g).to(DEV).to(tdt)
+    ga3, gad = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    mask = torch.randint(0, 16, (N * H * W * C // 4,), generator=g, dtype=torch.uint8).to(DEV)
+    count = N * H * W
+    m3, i3 = ops.bn_finalize(ops.bn_stats(z3), count, 1e-5, 0.1)
+    md, idd = ops.bn_finalize(ops.bn_stats(zd), count, 1e-5, 0.1)
+    s3 = ops.bn_bwd_reduce(dy, z3, None, m3, i3, True, relu_mask=mask)
+    sd = ops.bn_bwd_reduce(dy, zd, None, md, idd, True, relu_mask=mask)
+    s4 = ops.bn_bwd_reduce2(dy, z3, zd, m3, i3, md, idd, mask)
+    assert torch.equal(s4[:2 * C], s3) and torch.equal(s4[2 * C:], sd)
+    ax3, axd, ag = ops.absmax(z3.float()), ops.absmax(zd.float()), ops.absmax(dy.float())
+    kw = dict(dx_planes=True, amax_dy=ag) if planes else {}
+    pg = [torch.zeros(C, device=DEV) for _ in range(8)]
+    a0, a1, b0, b1 = (ops.new_amax(DEV) for _ in range(4))
+    dx3 = ops.bn_bwd_apply(dy, z3, None, m3, i3, ga3, True, s3, count, pg[0], pg[1], relu_mask=mask, amax_out=a0,
+                           amax_x=ax3 if planes else None, **kw)
+    dxd = ops.bn_bwd_apply(dy, zd, None, md, idd, gad, True, sd, count, pg[2], pg[3], relu_mask=mask, amax_out=a1,
+                           amax_x=axd if planes else None, **kw)
+    e3, ed = torch.empty_like(z3), torch.empty_like(zd)
+    ops.bn_bwd_apply2(dy, z3, m3, i3, ga3, mask, s4[:2 * C], count, pg[4], pg[5], e3, zd, md, idd, gad, s4[2 * C:], pg[6], pg[7], ed,
+                      amax_out=b0, amax_out2=b1, dx_planes=planes, amax_x=ax3 if planes else None, amax_x2=axd if planes else None,
+                      amax_dy=ag if planes else None)
+    assert torch.equal(e3, dx3) and torch.equal(ed, dxd)
+    assert int(a0) == int(b0) and int(a1) == int(b1)
+    assert all(torch.equal(pg[i], pg[i + 4]) for i in range(4))
+    report(f"join + downsample norm, shared backward passes ({dt}, planes {planes}): sums, gradients, bounds and parameter gradients identical")
+
+
 def test_training_step_with_and_without_pair_planes(report):
     """the same step with the planes on (default) and off (every conv splits its fp32 operands in registers): what changes is
     where the split happens and the tile of some weight gradients, not the arithmetic"""
