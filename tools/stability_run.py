@@ -1,5 +1,5 @@
 """Many training steps on three alternating synthetic batches: the loss must stay finite and fall.
-usage: python tools/stability_run.py [fp32|bf16|both] [steps] [flag=value ...]   (flags of rcf_amd.layers, e.g. CACHE_WEIGHT_OPERANDS=0)"""
+usage: python tools/stability_run.py [fp32|bf16|both] [steps] [field=value ...]   (fields of rcf_amd.config.SCHED, e.g. fold_bn=0)"""
 import os, sys, time, types
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -7,10 +7,7 @@ import rcf_amd
 from rcf_amd import config, synth, layers
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-for kv in sys.argv[3:]:
-    k, v = kv.split("=")
-    setattr(layers, k, bool(int(v)))
-    print("layers." + k, "=", getattr(layers, k))
+config.SCHED.parse(sys.argv[3:])
 H, W, B = 480, 854, 8
 dev = torch.device("cuda:0")
 for prec in (("bf16", "fp32") if which == "both" else (which,)):
