@@ -106,6 +106,9 @@ typedef struct {
 #define RCF_CONV_NO_WGRAD_XCD 0x20u
 #define RCF_CONV_NO_COLMAP 0x40u
 #define RCF_CONV_KORDER_NATURAL 0x80u
+/* 1x1 convs with 4 / 8 / 16 output channels on 64 .. 512 input channels (the decode heads' classifiers) run as streaming fp32
+ * passes (csrc/thin.hip) instead of GEMM tiles with a handful of live columns; this bit keeps them on the GEMM kernels (A/B, tests) */
+#define RCF_CONV_NO_THIN 0x100u
 #define RCF_CONV_FP32_MFMA(v) ((((unsigned)(v) & 3u) + 1u) << 12)
 
 /* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order

@@ -2011,6 +2011,9 @@ int check_shape(const rcf_conv_shape *s) {
 // LDS tiles) instead of the fp16-pair / bf16-triple kernels; -1 = not asked for
 inline int fp32_mfma_variant(unsigned flags) { return (int)((flags >> 12) & 7u) - 1; }
 inline bool use_x3(unsigned flags) { return fp32_mfma_variant(flags) < 0; }
+// thin 1x1 convs (<= 16 output channels) leave the GEMM kernels for csrc/thin.hip's streaming passes -- on the default path only:
+// the RCF_CONV_FP32_MFMA test variants keep the kernels they are there to exercise
+inline bool thin_path(const rcf_conv_shape *s) { return use_x3(s->flags) && !(s->flags & RCF_CONV_NO_THIN) && rcf_thin_ok(s); }
 inline bool korder_chunked(unsigned flags) { return !(flags & RCF_CONV_KORDER_NATURAL); }
 
 inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
@@ -2392,6 +2395,7 @@ extern "C" int rcf_conv2d_fwd_region_f32(const float *x, const float *w, const f
                                          int beta, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!x || !w || !y || !rcf_aligned16(x) || !rcf_aligned16(w) || !rcf_aligned16(y)) return RCF_EINVAL;
+    if (!region && act == 0 && thin_path(s)) return rcf_thin_fwd(x, w, bias, y, s, beta, rcf_stream(stream));
     return conv2d_fwd_impl(x, w, bias, y, s, region, act, slope, beta, nullptr, stream, nullptr);
 }
 
@@ -2544,6 +2548,7 @@ extern "C" int rcf_conv2d_dgrad_region_f32(const float *dy, const float *w, floa
                                            size_t workspace_bytes, void *stream) {
     if (int e = check_shape(s)) return e;
     if (!dy || !w || !dx || !rcf_aligned16(dy) || !rcf_aligned16(w) || !rcf_aligned16(dx)) return RCF_EINVAL;
+    if (!region && thin_path(s)) return rcf_thin_dgrad(dy, w, dx, s, beta, rcf_stream(stream));
     return conv2d_dgrad_impl(dy, w, dx, s, region, beta, workspace, workspace_bytes, stream, nullptr);
 }
 
@@ -2671,6 +2676,7 @@ extern "C" size_t rcf_conv2d_wgrad_workspace_bytes(const rcf_conv_shape *s) {
 
 extern "C" size_t rcf_conv2d_wgrad_region_workspace_bytes(const rcf_conv_shape *s, const rcf_conv_region *region) {
     if (check_shape(s) || !region_ok(region, s->Ho, s->Wo)) return 0;
+    if (!region && thin_path(s)) return rcf_thin_wgrad_workspace_bytes(s);
     const WgradPlan pl = plan_wgrad(s, region);
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * s->Cout * s->R * s->S * s->Cin * sizeof(float);
@@ -2687,6 +2693,7 @@ extern "C" int rcf_conv2d_wgrad_region_f32(const float *x, const float *dy, floa
     if (int e = check_shape(s)) return e;
     if (!x || !dy || !dw || !rcf_aligned16(x) || !rcf_aligned16(dy) || !rcf_aligned16(dw)) return RCF_EINVAL;
     if (s->Cout % 4 || !region_ok(region, s->Ho, s->Wo)) return RCF_EINVAL;
+    if (!region && thin_path(s)) return rcf_thin_wgrad(x, dy, dw, s, beta, workspace, workspace_bytes, rcf_stream(stream));
     const WgradPlan pl = plan_wgrad(s, region);
     const size_t need = rcf_conv2d_wgrad_region_workspace_bytes(s, region);
     if (need > 0 && (!workspace || workspace_bytes < need || !rcf_aligned16(workspace))) return RCF_EWORKSPACE;

@@ -25,6 +25,15 @@ int rcf_crf_sort_pairs_u64(void *tmp, size_t tmp_bytes, const unsigned long long
                            const unsigned *v_in, unsigned *v_out, size_t n, int end_bit, hipStream_t st);
 int rcf_crf_inclusive_scan_i32(void *tmp, size_t tmp_bytes, const int *in, int *out, size_t n, hipStream_t st);
 
+// csrc/thin.hip: streaming kernels for 1x1 convs with 4 / 8 / 16 output channels (the decode heads' classifiers); fp32 tensors.
+// The fp32 conv entry points hand over when rcf_thin_ok(shape) holds, the launch covers the whole tensor and nothing is fused.
+bool rcf_thin_ok(const rcf_conv_shape *s);
+size_t rcf_thin_wgrad_workspace_bytes(const rcf_conv_shape *s);
+int rcf_thin_fwd(const float *x, const float *w, const float *bias, float *y, const rcf_conv_shape *s, int beta, hipStream_t st);
+int rcf_thin_dgrad(const float *dy, const float *w, float *dx, const rcf_conv_shape *s, int beta, hipStream_t st);
+int rcf_thin_wgrad(const float *x, const float *dy, float *dw, const rcf_conv_shape *s, int beta, void *workspace, size_t workspace_bytes,
+                   hipStream_t st);
+
 static inline int rcf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool rcf_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -132,6 +132,58 @@ def test_conv_fp16_pairs(case, xs, ws, gs, heavy, report):
         assert ei < max(4 * ri, 1e-5)      # measured 0.8e-6 ... 6.2e-6 (torch fp32: 1.2e-6 ... 1.5e-5); a dropped partial product is >= 5e-4
 
 
+@pytest.mark.parametrize("case", [(2, 256, 4, 33, 41), (1, 256, 8, 120, 214), (2, 256, 16, 30, 27), (3, 64, 4, 17, 19), (2, 512, 16, 12, 11),
+                                  (2, 128, 8, 21, 9)])
+def test_thin_1x1_convs(case, report):
+    """csrc/thin.hip: 1x1 convs with 4 / 8 / 16 output channels (the decode heads' classifiers, models/fcn_head.py conv_seg) as streaming
+    fp32 passes -- forward (+ bias, + accumulate), data gradient (+ accumulate, range of the result) and weight gradient (+ accumulate)
+    against float64 and against the GEMM kernels they replace (RCF_CONV_NO_THIN); exact products: at or below torch's fp32 error"""
+    from rcf_amd import _lib
+    N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double()
+    yref = F.conv2d(xd, wd, bd)
+    dy = torch.randn(yref.shape, generator=g)
+    yref.backward(dy.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = F.conv2d(x32, w32, b)
+    y32.backward(dy)
+
+    def rms(a, b_):
+        a, b_ = a.detach().double().cpu(), b_.detach().double().cpu()
+        return float(((a - b_) ** 2).mean().sqrt() / ((b_ ** 2).mean().sqrt() + 1e-300))
+    xg, wg, gg, bg = to_nhwc(x), cl_weight(w), to_nhwc(dy), b.to(DEV)
+    ax, aw, ag = ops.absmax(xg), ops.absmax(ops.weight_rsck(wg)), ops.absmax(gg)
+    out = {}
+    for thin in (True, False):
+        old = ops.set_conv_flags(0 if thin else _lib.CONV_NO_THIN)
+        try:
+            y = ops.conv2d_fwd(xg, wg, bg, 1, 0, 1, amax=(ax, aw))
+            y2 = ops.conv2d_fwd(xg, wg, bg, 1, 0, 1, amax=(ax, aw), out=y.clone(), beta=1)
+            ry = ops.new_amax(DEV)
+            dx = ops.conv2d_dgrad(gg, wg, xg.shape, 1, 0, 1, amax=(ag, aw), amax_y=ry)
+            dx2 = ops.conv2d_dgrad(gg, wg, xg.shape, 1, 0, 1, amax=(ag, aw), out=dx.clone(), beta=1)
+            dw = torch.full_like(wg, 0.5)
+            ops.conv2d_wgrad(xg, gg, wg, dw, 1, 0, 1, beta=1, amax=(ax, ag))
+        finally:
+            ops.set_conv_flags(old)
+        out[thin] = (y, y2, dx, dx2, dw, ry)
+    y, y2, dx, dx2, dw, ry = out[True]
+    e = (rms(from_nhwc(y), yref), rms(from_nhwc(dx), xd.grad), rms(dw.cpu() - 0.5, wd.grad))
+    r = (rms(y32, yref), rms(x32.grad, xd.grad), rms(w32.grad, wd.grad))
+    eg = (rms(from_nhwc(out[False][0]), yref), rms(from_nhwc(out[False][2]), xd.grad), rms(out[False][4].cpu() - 0.5, wd.grad))
+    report(f"thin 1x1 conv {case}: rms error vs float64 fwd {e[0]:.1e} dgrad {e[1]:.1e} wgrad {e[2]:.1e} | GEMM kernels {eg[0]:.1e} {eg[1]:.1e} "
+           f"{eg[2]:.1e} | torch fp32 {r[0]:.1e} {r[1]:.1e} {r[2]:.1e}")
+    for ei, ri in zip(e, r):
+        assert ei < max(2 * ri, 2e-7)
+    # accumulate forms: exactly twice the plain result less the bias once (y + (y) and dx + dx in fp32: one rounding)
+    assert rms(y2 - y, y) < 1e-6 and rms(dx2, 2 * dx) < 1e-6
+    assert float(ry.view(torch.float32)) == float(dx.abs().max())
+
+
 def test_conv_fp16_pairs_range_edges(report):
     """operand ranges at the edges: an all-zero tensor (range 0 -> scale 1, exact zeros out), magnitudes spread
     log-uniformly over 30 binary orders (elements far below the tensor's maximum lose bits, but only at 2^-39 of the

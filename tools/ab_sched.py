@@ -1,6 +1,7 @@
 """Same-process A/B of the training step under two settings of ONE config.SCHED field (interleaved rounds, median of AB_ROUNDS x 6
 steps); prints ms per step and the loss of a step taken from the same weights under each setting.
-usage: python tools/ab_sched.py <fp32|bf16> <field> <valueA> <valueB> [pairs]"""
+usage: python tools/ab_sched.py <fp32|bf16> <field> <valueA> <valueB> [pairs]
+(field `conv_flags`: the RCF_CONV_* bits OR-ed into every conv launch, e.g. 0 against 0x100 = RCF_CONV_NO_THIN)"""
 import copy
 import os
 import sys
@@ -12,7 +13,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rcf_amd
-from rcf_amd import config, synth
+from rcf_amd import config, ops, synth
+
+
+def apply(field, v):
+    if field == "conv_flags":
+        ops.set_conv_flags(int(v, 0))
+    else:
+        config.SCHED.parse([f"{field}={v}"])
 
 prec, field, va, vb = sys.argv[1:5]
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 8
@@ -29,12 +37,12 @@ batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows"
 settings = {f"{field}={va}": va, f"{field}={vb}": vb}
 res = {k: [] for k in settings}
 for name, v in settings.items():
-    config.SCHED.parse([f"{field}={v}"])
+    apply(field, v)
     for _ in range(3):
         tr.step(batch)
 for r in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for name, v in settings.items():
-        config.SCHED.parse([f"{field}={v}"])
+        apply(field, v)
         tr.step(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
