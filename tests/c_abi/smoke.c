@@ -120,6 +120,106 @@ static int conv_known_answer(void) {
     return 0;
 }
 
+/* 4b. round-5 entry points from plain C: (a) a residual join whose residual is the RAW output of the downsample conv, normalised on the
+ * way in (rcf_bn_apply_res_mp; models/resnet.py:293-296) against the same float operations in C loops; (b) a thin classifier conv
+ * (1x1, 64 -> 4: csrc/thin.hip behind rcf_conv2d_fwd_f32 / _dgrad_f32 / _wgrad_f32) against C loops. */
+static int round5_known_answers(void) {
+    enum { ROWS = 24, C = 8 };
+    float hx[ROWS * C], hr[ROWS * C], hy[ROWS * C], ref[ROWS * C];
+    float mean[C], invstd[C], gamma[C], beta[C], rmean[C], rinvstd[C], rgamma[C], rbeta[C];
+    for (int i = 0; i < ROWS * C; i++) { hx[i] = (float)((i * 37) % 23) * 0.25f - 2.5f; hr[i] = (float)((i * 13) % 17) * 0.5f - 4.f; }
+    for (int c = 0; c < C; c++) {
+        mean[c] = 0.1f * c; invstd[c] = 0.5f + 0.1f * c; gamma[c] = 1.f + 0.05f * c; beta[c] = -0.2f * c;
+        rmean[c] = -0.3f * c; rinvstd[c] = 0.25f + 0.05f * c; rgamma[c] = 0.9f; rbeta[c] = 0.1f * c;
+    }
+    for (int i = 0; i < ROWS * C; i++) {
+        const int c = i % C;
+        const float o = (hx[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        const float r = (hr[i] - rmean[c]) * rinvstd[c] * rgamma[c] + rbeta[c];
+        const float v = o + r;
+        ref[i] = v > 0.f ? v : 0.f;
+    }
+    float *dx, *dr, *dy, *dc;
+    unsigned char *dm, hm[ROWS * C / 4];
+    CK(hipMalloc((void **)&dx, sizeof hx)); CK(hipMalloc((void **)&dr, sizeof hr)); CK(hipMalloc((void **)&dy, sizeof hy));
+    CK(hipMalloc((void **)&dc, 8 * C * sizeof(float))); CK(hipMalloc((void **)&dm, sizeof hm));
+    CK(hipMemcpy(dx, hx, sizeof hx, hipMemcpyHostToDevice)); CK(hipMemcpy(dr, hr, sizeof hr, hipMemcpyHostToDevice));
+    const float *consts[8] = {mean, invstd, gamma, beta, rmean, rinvstd, rgamma, rbeta};
+    for (int k = 0; k < 8; k++) CK(hipMemcpy(dc + k * C, consts[k], C * sizeof(float), hipMemcpyHostToDevice));
+    rcf_bn_res_norm rn = {dc + 4 * C, dc + 5 * C, dc + 6 * C, dc + 7 * C};
+    int rc = rcf_bn_apply_res_mp(dx, RCF_F32, C, dr, C, &rn, dy, RCF_F32, C, ROWS, C, dc, dc + C, dc + 2 * C, dc + 3 * C, 1, NULL, 0, dm, NULL,
+                                 NULL, NULL, NULL, 0u, NULL);
+    if (rc != 0) { printf("rcf_bn_apply_res_mp returned %d\n", rc); return 30; }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hy, dy, sizeof hy, hipMemcpyDeviceToHost)); CK(hipMemcpy(hm, dm, sizeof hm, hipMemcpyDeviceToHost));
+    int bad = 0, badm = 0;
+    for (int i = 0; i < ROWS * C; i++) {
+        bad += !(fabsf(hy[i] - ref[i]) <= 1e-6f * (1.f + fabsf(ref[i])));
+        badm += ((hm[i / 4] >> (i % 4)) & 1) != (ref[i] > 0.f);
+    }
+    printf("bn_apply_res (join normalises its raw residual): %d of %d outputs, %d sign bits differ from the C loops\n", bad, ROWS * C, badm);
+    if (bad || badm) return 31;
+    /* a residual norm without a residual is an argument error, not a crash */
+    if (rcf_bn_apply_res_mp(dx, RCF_F32, C, NULL, 0, &rn, dy, RCF_F32, C, ROWS, C, dc, dc + C, dc + 2 * C, dc + 3 * C, 1, NULL, 0, NULL, NULL,
+                            NULL, NULL, NULL, 0u, NULL) != RCF_EINVAL) return 32;
+    hipFree(dx); hipFree(dr); hipFree(dy); hipFree(dc); hipFree(dm);
+    /* (b) thin conv */
+    enum { H = 5, W = 7, CI = 64, CO = 4 };
+    static float tx[H * W * CI], tw[CO * CI], tb[CO], ty[H * W * CO], tg[H * W * CO], tdx[H * W * CI], tdw[CO * CI];
+    static float ry[H * W * CO], rdx[H * W * CI], rdw[CO * CI];
+    for (int i = 0; i < H * W * CI; i++) tx[i] = (float)((i * 29) % 31) / 16.f - 1.f;
+    for (int i = 0; i < CO * CI; i++) tw[i] = (float)((i * 11) % 13) / 32.f - 0.2f;
+    for (int i = 0; i < CO; i++) tb[i] = 0.5f * i;
+    for (int i = 0; i < H * W * CO; i++) tg[i] = (float)((i * 7) % 9) / 8.f - 0.5f;
+    for (int p = 0; p < H * W; p++)
+        for (int n = 0; n < CO; n++) {
+            double a = tb[n];
+            for (int c = 0; c < CI; c++) a += (double)tx[p * CI + c] * tw[n * CI + c];
+            ry[p * CO + n] = (float)a;
+        }
+    for (int p = 0; p < H * W; p++)
+        for (int c = 0; c < CI; c++) {
+            double a = 0;
+            for (int n = 0; n < CO; n++) a += (double)tg[p * CO + n] * tw[n * CI + c];
+            rdx[p * CI + c] = (float)a;
+        }
+    for (int n = 0; n < CO; n++)
+        for (int c = 0; c < CI; c++) {
+            double a = 0;
+            for (int p = 0; p < H * W; p++) a += (double)tg[p * CO + n] * tx[p * CI + c];
+            rdw[n * CI + c] = (float)a;
+        }
+    float *gx, *gw, *gb, *gy, *gg, *gdx, *gdw;
+    void *ws;
+    CK(hipMalloc((void **)&gx, sizeof tx)); CK(hipMalloc((void **)&gw, sizeof tw)); CK(hipMalloc((void **)&gb, sizeof tb));
+    CK(hipMalloc((void **)&gy, sizeof ty)); CK(hipMalloc((void **)&gg, sizeof tg)); CK(hipMalloc((void **)&gdx, sizeof tdx));
+    CK(hipMalloc((void **)&gdw, sizeof tdw));
+    CK(hipMemcpy(gx, tx, sizeof tx, hipMemcpyHostToDevice)); CK(hipMemcpy(gw, tw, sizeof tw, hipMemcpyHostToDevice));
+    CK(hipMemcpy(gb, tb, sizeof tb, hipMemcpyHostToDevice)); CK(hipMemcpy(gg, tg, sizeof tg, hipMemcpyHostToDevice));
+    rcf_conv_shape s;
+    memset(&s, 0, sizeof s);
+    s.struct_bytes = sizeof s;
+    s.N = 1; s.H = H; s.W = W; s.Cin = CI; s.Ho = H; s.Wo = W; s.Cout = CO; s.R = 1; s.S = 1; s.stride = 1; s.pad = 0; s.dil = 1;
+    s.x_pitch = CI; s.y_pitch = CO;
+    const size_t need = rcf_conv2d_wgrad_workspace_bytes(&s);
+    CK(hipMalloc(&ws, need ? need : 16));
+    if (rcf_conv2d_fwd_f32(gx, gw, gb, gy, &s, 0, 0.f, 0, NULL) != 0) return 33;
+    if (rcf_conv2d_dgrad_f32(gg, gw, gdx, &s, 0, NULL, 0, NULL) != 0) return 33;
+    if (rcf_conv2d_wgrad_f32(gx, gg, gdw, &s, 0, ws, need, NULL) != 0) return 33;
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ty, gy, sizeof ty, hipMemcpyDeviceToHost)); CK(hipMemcpy(tdx, gdx, sizeof tdx, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(tdw, gdw, sizeof tdw, hipMemcpyDeviceToHost));
+    int b1 = 0, b2 = 0, b3 = 0;
+    for (int i = 0; i < H * W * CO; i++) b1 += !(fabsf(ty[i] - ry[i]) <= 2e-6f * (1.f + fabsf(ry[i])));
+    for (int i = 0; i < H * W * CI; i++) b2 += !(fabsf(tdx[i] - rdx[i]) <= 2e-6f * (1.f + fabsf(rdx[i])));
+    for (int i = 0; i < CO * CI; i++) b3 += !(fabsf(tdw[i] - rdw[i]) <= 2e-6f * (1.f + fabsf(rdw[i])));
+    printf("thin conv 64->4 (workspace %zu B): fwd %d of %d, dgrad %d of %d, wgrad %d of %d differ from the C loops\n", need, b1, H * W * CO,
+           b2, H * W * CI, b3, CO * CI);
+    if (b1 || b2 || b3) return 34;
+    hipFree(gx); hipFree(gw); hipFree(gb); hipFree(gy); hipFree(gg); hipFree(gdx); hipFree(gdw); hipFree(ws);
+    return 0;
+}
+
 /* 5. rcf_crf_soft (torchcrf_cpp.crf_soft, tools/torchCRF/src/torchcrf.cu:106-126) with caller-owned hipMalloc'd buffers.
  * (a) both potentials' weights 0: no pairwise term, the MAP is the arg-min of the unary energies on every pixel and the
  * marginals are softmax(-U) (torchcrf.cu:28,41: inactive potentials).  (b) the training configuration's potentials
@@ -230,6 +330,7 @@ int main(void) {
     hipFree(dx); hipFree(dy); hipFree(df);
     free(hx); free(hy); free(hf);
     { const int rc = conv_known_answer(); if (rc) return rc; }
+    { const int rc = round5_known_answers(); if (rc) return rc; }
     { const int rc = crf_known_answer(); if (rc) return rc; }
     printf("C ABI smoke: OK\n");
     return 0;
