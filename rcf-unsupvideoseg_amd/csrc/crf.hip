@@ -64,6 +64,7 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int cap_small;
     int *stat;                   // [F][4]  distinct keys of the small attempt, probe-limit flag, sampled distinct keys, -
     int sym;                     // 1: DenseCRF2D's symmetric kernel normalisation (rcf_crf_soft_ex), set per call by crf_infer
+    int norm_pending;            // host side: the normaliser of this lattice is still to come out of its first filter pass
     // sort build (build 3): rocPRIM's temporary storage, sized for F * E pairs
     char *sort_tmp;
     size_t sort_tmp_bytes;
@@ -919,21 +920,26 @@ constexpr int SHORT_LIST = 6;
 // depend on Q, so it is splatted, blurred and sliced ONCE per lattice (build_lattice) instead of every iteration
 // (same operations on the same inputs as the reference's third value channel: bit-identical normalisation).
 template <int MODE>
-__device__ __forceinline__ void acc_entry(const int2 pw, const float *__restrict__ Qf, long long &a0, long long &a1) {
+__device__ __forceinline__ void acc_entry(const int2 pw, const float *__restrict__ Qf, long long &a0, long long &a1, long long &a2) {
     const float wgt = __int_as_float(pw.y);
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         const float2 q = *reinterpret_cast<const float2 *>(Qf + (long)pw.x * MLAB);
         a0 += __double2ll_rn((double)(q.x * wgt) * FIX_SCALE);
         a1 += __double2ll_rn((double)(q.y * wgt) * FIX_SCALE);
+        if (MODE == 2) a2 += __double2ll_rn((double)wgt * FIX_SCALE);
     } else {
         a0 += __double2ll_rn((double)wgt * FIX_SCALE);
     }
 }
 __device__ __forceinline__ float fixed_to_float(long long a) { return (float)((double)a * (1.0 / FIX_SCALE)); }
+// MODE 2: the label channels AND the homogeneous channel of one list walk (the first filter pass after a build: the
+// normaliser comes out of the same splat / blur / slice as the first message -- same operations on the same inputs as the
+// stand-alone MODE 1 pass, so the same bits)
 template <int MODE>
-__device__ __forceinline__ void store_val(void *out, long i, long long a0, long long a1) {
-    if (MODE == 0) reinterpret_cast<float2 *>(out)[i] = make_float2(fixed_to_float(a0), fixed_to_float(a1));
+__device__ __forceinline__ void store_val(void *out, float *outz, long i, long long a0, long long a1, long long a2) {
+    if (MODE == 0 || MODE == 2) reinterpret_cast<float2 *>(out)[i] = make_float2(fixed_to_float(a0), fixed_to_float(a1));
     else reinterpret_cast<float *>(out)[i] = fixed_to_float(a0);
+    if (MODE == 2) outz[i] = fixed_to_float(a2);
 }
 // The per-iteration kernels take grid (frames, chunks): with the frame as the FASTEST grid index a frame's workgroups
 // all run on XCD frame % 8 (for 8 k frames per call), so its label values, lattice values and neighbour lists stay in
@@ -943,7 +949,8 @@ __device__ __forceinline__ void store_val(void *out, long i, long long a0, long 
 // kernel's 0.353-0.359 on smooth frames, slower on mixed batches -- the ~0.6 M 64-bit L2 atomics per frame and iteration
 // cost what the list walk costs.
 template <int MODE>
-__global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q, void *__restrict__ out) {
+__global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const float *__restrict__ Q, void *__restrict__ out,
+                                                           float *__restrict__ outz = nullptr) {
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const long Lf = Lt.L[f];
@@ -963,7 +970,7 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
             int beg = 0, n = 0;
             if (v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
             const bool big = n > GROUP_LIST;
-            long long a0 = 0, a1 = 0;
+            long long a0 = 0, a1 = 0, a2 = 0;
             if (!big) {
                 // up to GROUP_LIST / 16 records per lane, all loaded before the first label value is asked for: the list
                 // costs three dependent round trips (its extent, its records, their labels) whatever its length
@@ -975,24 +982,26 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
                 }
 #pragma unroll
                 for (int k = 0; k < GROUP_LIST / 16; ++k)
-                    if (pw[k].x >= 0) acc_entry<MODE>(pw[k], Qf, a0, a1);
+                    if (pw[k].x >= 0) acc_entry<MODE>(pw[k], Qf, a0, a1, a2);
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) {                   // sums inside the 16-lane group
                 a0 += __shfl_xor(a0, o, 64);
-                if (MODE == 0) a1 += __shfl_xor(a1, o, 64);
+                if (MODE != 1) a1 += __shfl_xor(a1, o, 64);
+                if (MODE == 2) a2 += __shfl_xor(a2, o, 64);
             }
-            if (sl == 0 && v < Lf && !big) store_val<MODE>(out, fb + v, a0, a1);
+            if (sl == 0 && v < Lf && !big) store_val<MODE>(out, outz, fb + v, a0, a1, a2);
             unsigned long long bigm = __ballot(big && sl == 0);
             while (bigm) {
                 const int j = __ffsll((long long)bigm) - 1;     // lane 16 * group of a long list
                 bigm &= bigm - 1;
                 const int bj = __shfl(beg, j, 64), nj = __shfl(n, j, 64);
-                long long b0 = 0, b1 = 0;
-                for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, b0, b1);
+                long long b0 = 0, b1 = 0, b2 = 0;
+                for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, b0, b1, b2);
                 b0 = wave_sum_ll(b0);
-                if (MODE == 0) b1 = wave_sum_ll(b1);
-                if (lane == 0) store_val<MODE>(out, fb + vb + (j >> 4), b0, b1);
+                if (MODE != 1) b1 = wave_sum_ll(b1);
+                if (MODE == 2) b2 = wave_sum_ll(b2);
+                if (lane == 0) store_val<MODE>(out, outz, fb + vb + (j >> 4), b0, b1, b2);
             }
         }
         return;
@@ -1004,20 +1013,21 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
         int beg = 0, n = 0;
         if (lane < chunk && v < Lf) { beg = Lt.off[fb + v]; n = Lt.cnt[fb + v]; }
         if (n > 0 && n <= SHORT_LIST) {
-            long long a0 = 0, a1 = 0;
-            for (int i = 0; i < n; i++) acc_entry<MODE>(Lt.csr[fb + beg + i], Qf, a0, a1);
-            store_val<MODE>(out, fb + v, a0, a1);
+            long long a0 = 0, a1 = 0, a2 = 0;
+            for (int i = 0; i < n; i++) acc_entry<MODE>(Lt.csr[fb + beg + i], Qf, a0, a1, a2);
+            store_val<MODE>(out, outz, fb + v, a0, a1, a2);
         }
         unsigned long long longm = __ballot(n > SHORT_LIST);
         while (longm) {
             const int j = __ffsll((long long)longm) - 1;
             longm &= longm - 1;
             const int bj = __shfl(beg, j, 64), nj = __shfl(n, j, 64);
-            long long a0 = 0, a1 = 0;
-            for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, a0, a1);
+            long long a0 = 0, a1 = 0, a2 = 0;
+            for (int i = lane; i < nj; i += 64) acc_entry<MODE>(Lt.csr[fb + bj + i], Qf, a0, a1, a2);
             a0 = wave_sum_ll(a0);
-            if (MODE == 0) a1 = wave_sum_ll(a1);
-            if (lane == 0) store_val<MODE>(out, fb + v0 + j, a0, a1);
+            if (MODE != 1) a1 = wave_sum_ll(a1);
+            if (MODE == 2) a2 = wave_sum_ll(a2);
+            if (lane == 0) store_val<MODE>(out, outz, fb + v0 + j, a0, a1, a2);
         }
     }
 }
@@ -1048,6 +1058,27 @@ __global__ void __launch_bounds__(256) blur_kernel(Lattice Lt, int axis, const T
     }
 }
 
+// the label channels and the homogeneous channel in one pass (first filter pass after a build): one read of the neighbour
+// pair serves both arrays
+__global__ void __launch_bounds__(256) blur2_kernel(Lattice Lt, int axis, const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                    const float *__restrict__ zin, float *__restrict__ zout) {
+    const int f = blockIdx.x;
+    const int nax2 = 2 * (Lt.pd + 1);
+    const long Lf = Lt.L[f];
+    const long fb = (long)f * Lt.E;
+    for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x) {
+        const int2 n = *reinterpret_cast<const int2 *>(Lt.nb + (fb * (nax2 / 2) + (long)axis * Lt.E + v) * 2);
+        const float2 me = in[fb + v];
+        const float zme = zin[fb + v];
+        float2 vp = make_float2(0.f, 0.f), vm = make_float2(0.f, 0.f);
+        float zp = 0.f, zm = 0.f;
+        if (n.x >= 0) { vp = in[fb + n.x]; zp = zin[fb + n.x]; }
+        if (n.y >= 0) { vm = in[fb + n.y]; zm = zin[fb + n.y]; }
+        out[fb + v] = blur3(vp, me, vm);
+        zout[fb + v] = blur3(zp, zme, zm);
+    }
+}
+
 // build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
 // sym: inv[p] = 1 / sqrt(that + 1e-20), the symmetric normalisation of DenseCRF2D (see rcf_crf_soft_ex)
 template <int PD>
@@ -1068,11 +1099,13 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
 
 // slice + Potts weight + (optionally) softmax and MAP.
 //   first: next = -U, else next = next_in;  next += w * slice;  last: Q = softmax(next) (+ MAP)
-template <int PD>      // compile-time dimension: the pd + 1 (weight, vertex, value) chains of a pixel are all in flight at once
+// NORM: the first filter pass after a build -- the blurred homogeneous channel z is sliced beside the labels and the
+// pixel's normaliser (slice_norm_kernel's operations in its order) is computed, stored for the later passes and used here
+template <int PD, bool NORM = false>      // compile-time dimension: the pd + 1 (weight, vertex, value) chains of a pixel are all in flight at once
 __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__restrict__ val,
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
-                                                    int last, int write_map, int sym) {
+                                                    int last, int write_map, int sym, const float *__restrict__ z = nullptr) {
     const int f = blockIdx.x;
     // 16 x 16 pixel tiles: the pixels of a tile share most of their lattice vertices (the values stay in the CU's L1)
     const int W = Lt.W, H = Lt.N / Lt.W, tiles_x = (W + 15) >> 4;
@@ -1082,16 +1115,24 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const int p = py * W + px;
     const int nax = (PD ? PD : Lt.pd) + 1;
     const long fb = (long)f * Lt.E;
-    float s0 = 0, s1 = 0;
+    float s0 = 0, s1 = 0, sw = 0;
 #pragma unroll
     for (int r = 0; r < nax; r++) {
         const long pe = fb + (long)r * Lt.N + p;
         const float wgt = Lt.weight[pe];
-        const float2 v = val[fb + Lt.vid[pe]];
+        const int vi = Lt.vid[pe];
+        const float2 v = val[fb + vi];
         s0 += wgt * v.x;
         s1 += wgt * v.y;
+        if (NORM) sw += wgt * z[fb + vi];
     }
-    const float inv = Lt.inv[(long)f * Lt.N + p];
+    float inv;
+    if (NORM) {
+        inv = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
+        Lt.inv[(long)f * Lt.N + p] = inv;
+    } else {
+        inv = Lt.inv[(long)f * Lt.N + p];
+    }
     const long qi = ((long)f * Lt.N + p) * MLAB;
     float n0, n1;
     if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
@@ -1316,6 +1357,7 @@ size_t carve_all(char *base, int W, int H, int F, CrfBuffers &b) {
     } while (0)
 
 int build_lattice_norm(Lattice &L, int F, hipStream_t st);
+int lattice_built(Lattice &L, int F, hipStream_t st);
 
 // kernels templated on the lattice dimension: the two potentials of the reference are pd = 2 and pd = 5
 #define PD_LAUNCH(pd_, kern, grid, block, st_, ...)                                              \
@@ -1407,7 +1449,7 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
         } else if (int e = build_lattice_packed(L, rgb, W, H, F, posdev, featdev, st)) {
             return e;
         }
-        return build_lattice_norm(L, F, st);
+        return lattice_built(L, F, st);
     }
     CK(hipMemsetAsync(L.entries, 0xff, (size_t)F * 2 * L.E * sizeof(int), st));
     PD_LAUNCH(L.pd, lattice_keys_kernel, gp, dim3(256), st, L, rgb, W, H, posdev, featdev);
@@ -1425,20 +1467,30 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
     hipLaunchKernelGGL(csr_scan_apply_kernel, dim3(nblk, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(csr_fill_kernel, ge, dim3(256), 0, st, L);
     RCF_LAUNCH_CHECK();
-    return build_lattice_norm(L, F, st);
+    return lattice_built(L, F, st);
+}
+
+// The normaliser of a freshly built lattice comes out of its FIRST filter pass (apply_lattice: splat MODE 2, blur2_kernel,
+// slice_kernel<PD, true>) -- one list walk, one set of neighbour reads and one slice less per lattice than the stand-alone pass
+// below, same bits.  The symmetric normalisation needs it BEFORE the first pass (the marginals are scaled by it): stand-alone.
+int lattice_built(Lattice &L, int F, hipStream_t st) {
+    if (L.sym) return build_lattice_norm(L, F, st);
+    L.norm_pending = 1;
+    return 0;
 }
 
 // homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
 int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
     const dim3 gp(F, rcf_cdiv(L.N, 256));                      // (frames, chunks): see splat_gather_kernel
     float *za = reinterpret_cast<float *>(L.val0), *zb = reinterpret_cast<float *>(L.val1);
-    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(F, 4096), dim3(256), 0, st, L, (const float *)nullptr, (void *)za);
+    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(F, 4096), dim3(256), 0, st, L, (const float *)nullptr, (void *)za, (float *)nullptr);
     for (int axis = 0; axis <= L.pd; axis++) {
         hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
     }
     PD_LAUNCH(L.pd, slice_norm_kernel, gp, dim3(256), st, L, (const float *)za, L.sym);
     RCF_LAUNCH_CHECK();
+    L.norm_pending = 0;
     return 0;
 }
 
@@ -1447,13 +1499,30 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
                   int first, int last, int write_map, hipStream_t st) {
     const dim3 gv(F, 1024), gp(F, rcf_cdiv(L.W, 16) * rcf_cdiv(L.N / L.W, 16));     // (frames, 16 x 16 tiles): see splat_gather_kernel
     float2 *a = L.val0, *b = L.val1;
-    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a);
+    if (L.norm_pending) {
+        // the build's key array is dead by now: its 16 bytes per entry hold the two homogeneous-channel buffers
+        float *za = reinterpret_cast<float *>(L.keys), *zb = za + (size_t)F * L.E;
+        hipLaunchKernelGGL(splat_gather_kernel<2>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, za);
+        for (int axis = 0; axis <= L.pd; axis++) {
+            hipLaunchKernelGGL(blur2_kernel, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
+            float2 *t = a; a = b; b = t;
+            float *tz = za; za = zb; zb = tz;
+        }
+        if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
+        else if (L.pd == 2) hipLaunchKernelGGL((slice_kernel<2, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
+        else hipLaunchKernelGGL((slice_kernel<0, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
+        RCF_LAUNCH_CHECK();
+        L.norm_pending = 0;
+        return 0;
+    }
+    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, (float *)nullptr);
     for (int axis = 0; axis <= L.pd; axis++) {
         hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
         float2 *t = a; a = b; b = t;
     }
-    PD_LAUNCH(L.pd, slice_kernel, gp, dim3(256), st, L, (const float2 *)a, unary, next, Qout, map, first, last,
-                       write_map, L.sym);
+    if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
+    else if (L.pd == 2) hipLaunchKernelGGL((slice_kernel<2, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
+    else hipLaunchKernelGGL((slice_kernel<0, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
     RCF_LAUNCH_CHECK();
     return 0;
 }
