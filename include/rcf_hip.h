@@ -548,6 +548,12 @@ int rcf_crf_soft(const uint8_t *rgb, const float *unary, int W, int H, int batch
 int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
                     float scomp_app, float sxy_app, float srgb_app, int iters, int normalization, int16_t *out_map,
                     float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream);
+/* rcf_crf_soft_ex on FLOAT colour features f32 [batch,H,W,3]: torchcrf_cpp.crf_soft accepts rgbFeat of any dtype and converts
+ * it to float unrounded (tools/torchCRF/src/torchcrf.cu:84-85); RCF itself passes uint8 (models/crf_head.py:43-55).  Always
+ * the array-of-keys lattice build (the RCF_CRF_BUILD_* bits are ignored). */
+int rcf_crf_soft_f32(const float *rgbf, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
+                     float scomp_app, float sxy_app, float srgb_app, int iters, int normalization, int16_t *out_map,
+                     float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream);
 int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,
                  float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, float confidence, int iters,
                  int16_t *out_map, float *q_out, int32_t *nvert, void *workspace, size_t workspace_bytes,

@@ -162,6 +162,20 @@ class ConvModule(nn.Module):
         return F.relu(x)
 
 
+class FixedDropout2d(nn.Module):
+    """nn.Dropout2d with its random draw replaced by a given one: `scale` [N, C] holds 0 for a dropped (sample, channel) plane
+    and 1 / (1 - p) for a kept one.  Test infrastructure: assigned to `head.dropout` of the reference's / the oracle's FCNHead
+    (models/fcn_head.py:144-145) so that both and the HIP path (FCNHead.keep_mask) see the same planes dropped."""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = torch.as_tensor(scale)
+
+    def forward(self, x):
+        assert tuple(x.shape[:2]) == tuple(self.scale.shape), (tuple(x.shape), tuple(self.scale.shape))
+        return x * self.scale.to(x.dtype)[:, :, None, None]
+
+
 class FCNHead(nn.Module):
     """models/fcn_head.py:50-140,142-147,211-218 + models/decode_head.py:45-90,141-170.
     The create_flownet=True branch (PWC-Lite, AMD baseline only) is off the RCF path."""

@@ -169,6 +169,8 @@ PROTOS = {
                              P, c_size_t, P]),
     "rcf_crf_soft_ex": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P,
                                 P, c_size_t, P]),
+    "rcf_crf_soft_f32": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P,
+                                 P, c_size_t, P]),
     "rcf_crf_hard": (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                              P, P, P, P, c_size_t, P]),
     "rcf_crf_prepare": (c_int, [P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),

@@ -19,7 +19,8 @@ def _check(t, name):
 
 def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
                      want_q=False, want_nvert=False, symmetric=False, build=0):
-    """rgb_u8 [n,H,W,3] uint8, unary [n,H*W,2] f32 -> MAP int16 [n,H,W] (+ Q [n,H*W,2], nvert [n,2]).
+    """rgb_u8 [n,H,W,3] uint8 (or float32: the features as they are, rcf_crf_soft_f32), unary [n,H*W,2] f32 -> MAP int16 [n,H,W]
+    (+ Q [n,H*W,2], nvert [n,2]).
     symmetric: pydensecrf's DenseCRF2D kernel normalisation (NORMALIZE_SYMMETRIC) instead of tools/torchCRF's.
     build: 0 default, 1 RCF_CRF_BUILD_ARRAY, 2 RCF_CRF_BUILD_SMALL_TABLE, 3 RCF_CRF_BUILD_SORT (identical results)"""
     _check(rgb_u8, "rgbFeat")
@@ -27,13 +28,16 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
     n = rgb_u8.shape[0]
     if tuple(rgb_u8.shape) != (n, H, W, 3) or tuple(unary.shape) != (n, H * W, 2):
         raise RuntimeError("shape check not satisfied")               # CHECK_COND, torchcrf.cu:55-82
+    if rgb_u8.dtype not in (torch.uint8, torch.float32) or unary.dtype != torch.float32:
+        raise RuntimeError("rgbFeat must be uint8 or float32, unaryEnergy float32")
     dev = rgb_u8.device
     out = torch.empty((n, H, W), dtype=torch.int16, device=dev)
     q = torch.empty((n, H * W, 2), dtype=torch.float32, device=dev) if want_q else None
     nv = torch.empty((n, 2), dtype=torch.int32, device=dev) if want_nvert else None
     need = _lib.load().rcf_crf_workspace_bytes(W, H, n)
     ws = workspace(need, dev)
-    _lib.call("rcf_crf_soft_ex", _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
+    entry = "rcf_crf_soft_ex" if rgb_u8.dtype == torch.uint8 else "rcf_crf_soft_f32"
+    _lib.call(entry, _p(rgb_u8), _p(unary), W, H, n, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app,
               int(iters), int(bool(symmetric)) | (int(build) << 8), _p(out), _p(q), _p(nv), _p(ws), need, _stream())
     res = (out,)
     if want_q:
@@ -45,18 +49,26 @@ def crf_soft_batched(rgb_u8, unary, W, H, scomp_smooth, sxy_smooth, scomp_app, s
 
 def crf_soft(rgbFeat, unaryEnergy, W, H, scompSmooth=3.0, sxySmooth=3.0, scompApp=10.0, sxyApp=60.0, srgbApp=20.0,
              iters=10):
-    """torchcrf_cpp.crf_soft: rgbFeat [H,W,3] (any dtype; uint8 on the RCF path), unary [H*W,2] f32."""
-    img = rgbFeat if rgbFeat.dtype == torch.uint8 else rgbFeat.round().clamp(0, 255).to(torch.uint8)
-    return crf_soft_batched(img.contiguous()[None], unaryEnergy.float()[None], W, H, scompSmooth, sxySmooth, scompApp,
+    """torchcrf_cpp.crf_soft: rgbFeat [H,W,3] (any dtype; uint8 on the RCF path), unary [H*W,2] f32.  A non-uint8 rgbFeat is
+    converted to float UNROUNDED, as tools/torchCRF/src/torchcrf.cu:84-85 does (`toType(Float)`), and filtered as it is."""
+    img = rgbFeat if rgbFeat.dtype == torch.uint8 else rgbFeat.float()
+    return crf_soft_batched(img.contiguous()[None], unaryEnergy.float().contiguous()[None], W, H, scompSmooth, sxySmooth, scompApp,
                             sxyApp, srgbApp, iters)[0]
 
 
 def crf_hard(rgbFeat, label, W, H, scompSmooth=3.0, sxySmooth=3.0, scompApp=10.0, sxyApp=60.0, srgbApp=20.0,
              confidence=0.5, iters=10):
-    """torchcrf_cpp.crf_hard: label int16 [H,W] (-1 = unknown)."""
+    """torchcrf_cpp.crf_hard: label int16 [H,W] (-1 = unknown).  The C ABI of this entry takes the uint8 image only: a float
+    rgbFeat must hold integers in [0, 255] (converted exactly) -- anything else raises instead of being rounded silently
+    (the reference would filter the unrounded floats, torchcrf.cu:84-85; use crf_soft for such features)."""
     _check(rgbFeat, "rgbFeat")
     _check(label, "label")
-    img = rgbFeat if rgbFeat.dtype == torch.uint8 else rgbFeat.round().clamp(0, 255).to(torch.uint8)
+    if rgbFeat.dtype == torch.uint8:
+        img = rgbFeat
+    else:
+        img = rgbFeat.round().clamp(0, 255).to(torch.uint8)
+        if not bool((img.to(rgbFeat.dtype) == rgbFeat).all()):
+            raise RuntimeError("crf_hard takes uint8 colours (or floats holding integers in [0, 255]); got non-integer features")
     dev = img.device
     out = torch.empty((1, H, W), dtype=torch.int16, device=dev)
     need = _lib.load().rcf_crf_workspace_bytes(W, H, 1)

@@ -520,14 +520,17 @@ __device__ __forceinline__ void pl_store4(char *pix, int C, int c0, const f32x4 
     *reinterpret_cast<f16x4 *>(pix + 2 * c0) = h;
     *reinterpret_cast<f16x4 *>(pix + 2 * C + 2 * c0) = m;
 }
-// block-wide max of a non-negative float over all threads (every thread calls it; result in every thread)
+// block-wide max of a non-negative float over all threads (every thread calls it; result in every thread).  Safe to call
+// back to back: the trailing barrier keeps a fast wave's next store out of the scratch a slow wave is still reading.
 __device__ __forceinline__ float block_max_f(float v) {
     __shared__ float sh_bm[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0) sh_bm[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(sh_bm[0], sh_bm[1]), fmaxf(sh_bm[2], sh_bm[3]));
+    const float r = fmaxf(fmaxf(sh_bm[0], sh_bm[1]), fmaxf(sh_bm[2], sh_bm[3]));
+    __syncthreads();
+    return r;
 }
 
 // PL: 0 y only; 1 y and its pair planes; 2 the pair planes only (the output's only consumers are convs).  The planes' scale comes

@@ -68,6 +68,9 @@ struct Lattice {           // device pointers of one potential, for all frames (
     // sort build (build 3): rocPRIM's temporary storage, sized for F * E pairs
     char *sort_tmp;
     size_t sort_tmp_bytes;
+    // rcf_crf_soft_f32: the colour features as the caller's floats [F][N][3] (torchcrf.cu:84-85 converts rgbFeat to float
+    // unrounded); nullptr = the u8 image.  Set per call by crf_infer.
+    const float *featf;
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
@@ -103,16 +106,24 @@ __device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return 
 // point's remainder-0 coordinates, the ranks and the pd+1 barycentric weights
 __device__ __forceinline__ void lattice_point(int pd, int p, int f, int N, int W, const uint8_t *__restrict__ rgb,
                                               float posdev, float featdev, int (&rem0)[PD_MAX + 1],
-                                              int (&rank)[PD_MAX + 1], float (&bary)[PD_MAX + 2]) {
+                                              int (&rank)[PD_MAX + 1], float (&bary)[PD_MAX + 2],
+                                              const float *__restrict__ featf = nullptr) {
     float pos[PD_MAX];
     const int wi = p % W, hi = p / W;
     pos[0] = (float)wi / posdev;
     pos[1] = (float)hi / posdev;
     if (pd == 5) {
-        const uint8_t *c = rgb + ((long)f * N + p) * 3;
-        pos[2] = (float)c[0] / featdev;
-        pos[3] = (float)c[1] / featdev;
-        pos[4] = (float)c[2] / featdev;
+        if (featf) {
+            const float *c = featf + ((long)f * N + p) * 3;
+            pos[2] = c[0] / featdev;
+            pos[3] = c[1] / featdev;
+            pos[4] = c[2] / featdev;
+        } else {
+            const uint8_t *c = rgb + ((long)f * N + p) * 3;
+            pos[2] = (float)c[0] / featdev;
+            pos[3] = (float)c[1] / featdev;
+            pos[4] = (float)c[2] / featdev;
+        }
     }
     float elevated[PD_MAX + 1];
     const float inv_std = (pd + 1) * sqrtf(2.0f / 3);
@@ -171,7 +182,7 @@ __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uin
     if (p >= Lt.N) return;
     int rem0[PD_MAX + 1], rank[PD_MAX + 1];
     float bary[PD_MAX + 2];
-    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary, Lt.featf);
     // entries are stored remainder-major (e = r*N + p): every later pass is coalesced along the pixels
     const long base = (long)f * Lt.E + p;
     for (int r = 0; r <= pd; r++) {
@@ -532,7 +543,7 @@ __global__ void __launch_bounds__(256) pk_estimate_kernel(Lattice Lt, const uint
     if (p < Lt.N) {
         int rem0[PD_MAX + 1], rank[PD_MAX + 1];
         float bary[PD_MAX + 2];
-        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary, Lt.featf);
         for (int r = 0; r < nax; r++) {
             short key[PD_MAX];
             lattice_key(pd, r, rem0, rank, key);
@@ -584,7 +595,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     if (live) {
         int rem0[PD_MAX + 1], rank[PD_MAX + 1];
         float bary[PD_MAX + 2];
-        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+        lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary, Lt.featf);
         for (int r = 0; r < nax; r++) {
             short key[PD_MAX];
             lattice_key(pd, r, rem0, rank, key);
@@ -803,7 +814,7 @@ __global__ void __launch_bounds__(256) sort_keys_kernel(Lattice Lt, const uint8_
     if (p >= Lt.N) return;
     int rem0[PD_MAX + 1], rank[PD_MAX + 1];
     float bary[PD_MAX + 2];
-    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary);
+    lattice_point(pd, p, f, Lt.N, W, rgb, posdev, featdev, rem0, rank, bary, Lt.featf);
     const long base = (long)f * Lt.E + p;
     for (int r = 0; r <= pd; r++) {
         short key[PD_MAX];
@@ -1529,9 +1540,11 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
 
 int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float scomp_smooth, float sxy_smooth,
               float scomp_app, float sxy_app, float srgb_app, int iters, int16_t *out_map, float *q_out,
-              int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0, int build = 0) {
+              int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0, int build = 0, const float *featf = nullptr) {
     b.smooth.sym = b.app.sym = sym;                                // per call, not per process: concurrent callers differ
-    b.smooth.build = b.app.build = build;
+    // float features are unbounded: the array-of-keys build (16-bit key coordinates, the reference's `short`) takes them
+    b.smooth.build = b.app.build = featf ? 1 : build;
+    b.smooth.featf = b.app.featf = featf;
     const bool has_s = scomp_smooth > 0.f && sxy_smooth > 0.f;     // torchcrf.cu:28
     const bool has_a = scomp_app > 0.f && sxy_app > 0.f;           // torchcrf.cu:41
     const long n = (long)F * W * H;
@@ -1576,14 +1589,15 @@ extern "C" size_t rcf_crf_workspace_bytes(int W, int H, int batch) {
 namespace {
 int crf_soft_impl(const uint8_t *rgb, const float *unary, int W, int H, int batch, float scomp_smooth, float sxy_smooth,
                   float scomp_app, float sxy_app, float srgb_app, int iters, int sym, int16_t *out_map, float *q_out,
-                  int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream, int build = 0) {
-    if (!rgb || !unary || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
+                  int32_t *nvert, void *workspace, size_t workspace_bytes, void *stream, int build = 0,
+                  const float *featf = nullptr) {
+    if ((!rgb && !featf) || !unary || !out_map || W <= 0 || H <= 0 || batch <= 0 || iters < 0) return RCF_EINVAL;
     if ((long)W * H * 6 >= (1L << 30)) return RCF_EINVAL;
     if (!workspace || workspace_bytes < rcf_crf_workspace_bytes(W, H, batch) || !rcf_aligned16(workspace)) return RCF_EWORKSPACE;
     CrfBuffers b;
     carve_all((char *)workspace, W, H, batch, b);
     return crf_infer(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters, out_map,
-                     q_out, nvert, b, rcf_stream(stream), sym, build);
+                     q_out, nvert, b, rcf_stream(stream), sym, build, featf);
 }
 }  // namespace
 
@@ -1610,6 +1624,19 @@ extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, in
     if (normalization != 0 && normalization != 1) return RCF_EINVAL;
     return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
                          normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream, build);
+}
+
+/* rcf_crf_soft_ex on float colour features [batch,H,W,3]: torchcrf_cpp.crf_soft converts ANY rgbFeat dtype to float without
+ * rounding (tools/torchCRF/src/torchcrf.cu:84-85), so a caller with non-integer features gets the lattice of exactly those
+ * values.  Always the array-of-keys build (the packed builds assume the u8 range). */
+extern "C" int rcf_crf_soft_f32(const float *rgbf, const float *unary, int W, int H, int batch, float scomp_smooth,
+                                float sxy_smooth, float scomp_app, float sxy_app, float srgb_app, int iters,
+                                int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    normalization &= 0xff;
+    if (!rgbf || (normalization != 0 && normalization != 1)) return RCF_EINVAL;
+    return crf_soft_impl(nullptr, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,
+                         normalization, out_map, q_out, nvert, workspace, workspace_bytes, stream, 1, rgbf);
 }
 
 extern "C" int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int batch, float scomp_smooth,

@@ -106,6 +106,14 @@ def make_batch(B, H, W, config_id=1, first_index=0):
     }
 
 
+def dropout_scale(n, channels, p=0.1, seed=0):
+    """f32 [n, channels]: one nn.Dropout2d draw written down -- Bernoulli(1 - p) per (sample, channel) plane, kept planes
+    scaled by 1 / (1 - p) (models/decode_head.py:84-87, models/fcn_head.py:142-147).  Parity tests hand the SAME draw to the
+    reference / oracle (oracle.FixedDropout2d) and to FCNHead.keep_mask."""
+    keep = (_rng(910000 + seed).uniform(size=(n, channels)) >= p).astype(np.float32)
+    return keep / np.float32(1.0 - p)
+
+
 def soft_blob_mask(H, W, seed):
     """f32 [H,W] in [0,1]: Gaussian-blurred blob (CRF input of SURVEY §8(d))."""
     g = _rng(seed)

@@ -225,11 +225,15 @@ def test_spatial_mixed_precision(report):
     assert max(e.values()) < 6e-3
 
 
-def _model_and_batch(H, W, B, variant=None):
+def _model_and_batch(H, W, B, variant=None, benched=False):
+    """benched: the configuration bench.py runs (SyncBN + Dropout2d 0.1) with the Dropout2d draw of tests/golden/dropout.*
+    injected into FCNHead.keep_mask (make_golden_dropout.py gave the reference the same draw)"""
     import copy
     import types
     from rcf_amd import config, synth
-    if variant is None:
+    if benched:
+        kw, oc = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="SyncBN"), None
+    elif variant is None:
         kw, oc = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN"), None
     else:
         kw, oc = config.variant_model_kwargs(variant, H, W)
@@ -237,6 +241,9 @@ def _model_and_batch(H, W, B, variant=None):
     m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    if benched:
+        m.decode_head2.keep_mask = torch.from_numpy(synth.dropout_scale(2 * B, m.decode_head2.channels, 0.1, 21)).to(DEV)
+        m.decode_head3.keep_mask = torch.from_numpy(synth.dropout_scale(B, m.decode_head3.channels, 0.1, 22)).to(DEV)
     nb = synth.make_batch(B, H, W, config_id=1)
     batch = {k: [torch.from_numpy(np.ascontiguousarray(x)).to(DEV) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
     return m, batch
@@ -287,9 +294,11 @@ def test_two_precisions_coexist_in_one_process(report):
     assert mixed == alone
 
 
-@pytest.mark.parametrize("tag", ["small", "480x854"])
-def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
-    """BASELINE configs[2] parity: the mixed-precision step against the REFERENCE run in fp32 and under
+@pytest.mark.parametrize("tag,benched", [("small", False), ("480x854", False), ("small", True), ("480x854", True)])
+def test_bf16_step_vs_reference_autocast_golden(tag, benched, golden_dir, report):
+    """(benched: the same criteria on the configuration bench.py times -- SyncBN + Dropout2d 0.1, the draw injected on both
+    sides, fixtures tests/golden/dropout.* from make_golden_dropout.py.)
+    BASELINE configs[2] parity: the mixed-precision step against the REFERENCE run in fp32 and under
     torch.autocast(bf16) (tests/golden/make_golden_bf16.py).  bf16 moves this randomly initialised network a lot -- the
     reference's own autocast run changes 9-11 % of the argmax decisions and the logits by 11-19 % of their range -- so the
     yardstick is the reference's own bf16-vs-fp32 deviation: the HIP bf16 step must stay within 3x of it on losses and
@@ -300,10 +309,11 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     up to which the reference's autocast run itself flips pixels."""
     import json
     import os
-    fx = json.load(open(os.path.join(golden_dir, "bf16.json")))[tag]
-    arr = np.load(os.path.join(golden_dir, "bf16.npz"))
+    stem = "dropout" if benched else "bf16"
+    fx = json.load(open(os.path.join(golden_dir, stem + ".json")))[tag]
+    arr = np.load(os.path.join(golden_dir, stem + ".npz"))
     H, W, B, C = fx["H"], fx["W"], fx["B"], fx["C"]
-    m, batch = _model_and_batch(H, W, B)
+    m, batch = _model_and_batch(H, W, B, benched=benched)
     tr = rcf_amd.Trainer(m, device=DEV, precision="bf16")
     losses = tr.step(batch)
     ref = fx["ref_bf16_vs_fp32"]
@@ -325,7 +335,7 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
         from rcf_amd import _lib
         old = ops.set_conv_flags(ops.CONV_FLAGS | _lib.CONV_KORDER_NATURAL)
         try:
-            m2, _ = _model_and_batch(H, W, B)
+            m2, _ = _model_and_batch(H, W, B, benched=benched)
             rcf_amd.Trainer(m2, device=DEV, precision="bf16").step(batch)
             e_g_alt = gradnorm_dev(m2)
         finally:
@@ -336,7 +346,7 @@ def test_bf16_step_vs_reference_autocast_golden(tag, golden_dir, report):
     mism = z.argmax(1) != am32
     sure = margin > 1.5 * ref["argmax_sure_margin"]
     n_sure_bad = int((mism & sure).sum())
-    msg = (f"bf16 step vs reference [{tag}] {H}x{W} B={B}: loss vs ref-fp32 " + " ".join(f"{k} {v:.2e}" for k, v in e_l.items()) +
+    msg = (f"bf16 step vs reference [{tag}{', SyncBN + injected Dropout2d draw' if benched else ''}] {H}x{W} B={B}: loss vs ref-fp32 " + " ".join(f"{k} {v:.2e}" for k, v in e_l.items()) +
            " (ref autocast: " + " ".join(f"{v:.2e}" for v in ref["loss"].values()) + ") vs ref-autocast " +
            " ".join(f"{v:.2e}" for v in e_l16.values()) + " | gradnorm vs ref-fp32 " +
            " ".join(f"{k} {v:.2e}/{ref['gradnorm'][k]:.2e}" for k, v in e_g.items()) +

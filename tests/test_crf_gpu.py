@@ -232,3 +232,41 @@ def test_crf_head_prepare_vs_reference_golden(golden_dir, report):
     assert mism == 0 and e < 1e-6
     out = head(img, msk)
     assert tuple(out.shape) == (1, H, W) and set(np.unique(out.cpu().numpy())) <= {0.0, 1.0}
+
+
+def test_crf_soft_float_features_vs_oracle(report):
+    """torchcrf_cpp.crf_soft accepts rgbFeat of any dtype and converts it to float UNROUNDED (tools/torchCRF/src/torchcrf.cu:84-85).
+    rcf_amd.crf_soft does the same through rcf_crf_soft_f32 (it used to round to u8 silently): a float
+    image with non-integer values -- and a few outside [0, 255] -- against the oracle on the same floats; a float image that
+    holds integers gives what the uint8 image gives, bit for bit; crf_hard refuses non-integer floats."""
+    H, W, iters, p = 64, 96, 5, (0., 0., 5., 60., 5.)
+    g = np.random.Generator(np.random.PCG64(77))
+    rgb8 = synth.smooth_rgb(H, W, 4400)
+    rgbf = rgb8.astype(np.float32) + g.uniform(-0.45, 0.45, size=rgb8.shape).astype(np.float32)
+    rgbf[::7, ::5] += 30.0                                         # leaves [0, 255] at the bright end: no clamp either
+    un = _unary(synth.soft_blob_mask(H, W, 4400))
+    t_un = torch.from_numpy(un).to(DEV)
+    m, q, nv = crf_soft_batched(torch.from_numpy(rgbf[None]).to(DEV), t_un[None], W, H, *p, iters, want_q=True, want_nvert=True)
+    mo, qo, nvo = crf_oracle.crf_soft_np(rgbf, un, W, H, *p, iters)
+    m8o, q8o, nv8o = crf_oracle.crf_soft_np(rgb8, un, W, H, *p, iters)
+    dq = float(np.abs(q[0].cpu().numpy() - qo).max())
+    sure = np.abs(qo[:, 1] - qo[:, 0]).reshape(H, W) > 1e-3
+    mism = int((m[0].cpu().numpy() != mo)[sure].sum())
+    moved = float(np.abs(qo - q8o).max())                          # what rounding the features would have changed
+    # the module surface (torchcrf_cpp.crf_soft signature): float64 in, converted to float32 unrounded
+    m_mod = rcf_amd.crf_soft(torch.from_numpy(rgbf.astype(np.float64)).to(DEV), t_un, W, H, *p, iters)
+    same_mod = bool(torch.equal(m_mod, m[0]))
+    # integers held in floats == the uint8 image
+    m_i = rcf_amd.crf_soft(torch.from_numpy(rgb8.astype(np.float32)).to(DEV), t_un, W, H, *p, iters)
+    m_u = rcf_amd.crf_soft(torch.from_numpy(rgb8).to(DEV), t_un, W, H, *p, iters)
+    report(f"crf_soft on float features {H}x{W}: vertices {tuple(nv[0].tolist())} vs oracle {nvo} (u8-rounded image: {nv8o}); "
+           f"max|dQ| {dq:.2e}, MAP mismatches on sure px {mism}; rounding the features would move Q by {moved:.2e}; "
+           f"module surface identical {same_mod}; integer-valued floats == uint8: {bool(torch.equal(m_i, m_u))}")
+    assert tuple(nv[0].tolist()) == nvo and nvo != nv8o
+    assert dq < 1e-4 and mism == 0 and moved > 10 * dq and same_mod and torch.equal(m_i, m_u)
+    lab = torch.from_numpy((synth.soft_blob_mask(H, W, 4400) > 0.5).astype(np.int16)).to(DEV)
+    with pytest.raises(RuntimeError, match="non-integer"):
+        rcf_amd.crf_hard(torch.from_numpy(rgbf).to(DEV), lab, W, H, *p, 0.5, iters)
+    h_i = rcf_amd.crf_hard(torch.from_numpy(rgb8.astype(np.float32)).to(DEV), lab, W, H, *p, 0.5, iters)
+    h_u = rcf_amd.crf_hard(torch.from_numpy(rgb8).to(DEV), lab, W, H, *p, 0.5, iters)
+    assert torch.equal(h_i, h_u)

@@ -17,20 +17,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, B = 64, 96, 2
 
 
-def _setup(mode="fp32"):
-    """mode: fp32 / bf16 (the stage-1 step in either precision) / stage21 (EMA teacher + CRF self-labels)"""
+def _setup(mode="fp32", pairs=None):
+    """mode: fp32 / bf16 (the stage-1 step in either precision) / stage21 (EMA teacher + CRF self-labels); a `_drop` suffix:
+    the configuration bench.py runs -- Dropout2d 0.1 in both FCN heads -- with ONE draw for the global batch, of which this
+    process takes the rows of its pairs (`pairs`: a slice; decode_head2 sees two frames per pair, decode_head3 one row)"""
     sys.path.insert(0, ROOT)
     import rcf_amd
     from rcf_amd import config, synth
+    drop = 0.1 if mode.endswith("_drop") else 0.0
     if mode == "stage21":
         kw = config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
         args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=1)
     else:
-        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
+        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=drop, norm="SyncBN")
         args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=None)
     m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    if drop:
+        sl = pairs if pairs is not None else slice(0, B)
+        s2 = synth.dropout_scale(2 * B, m.decode_head2.channels, drop, 21)[2 * sl.start:2 * sl.stop]
+        s3 = synth.dropout_scale(B, m.decode_head3.channels, drop, 22)[sl]
+        m.decode_head2.keep_mask, m.decode_head3.keep_mask = torch.from_numpy(s2).to("cuda:0"), torch.from_numpy(s3).to("cuda:0")
     nb = synth.make_batch(B, H, W, config_id=1)
     return rcf_amd, m, nb
 
@@ -43,13 +51,13 @@ def _batch(nb, sl, dev):
 def _worker(rank, world, port, q, mode="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rcf_amd, m, nb = _setup(mode)
-    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode == "bf16" else None)
-    assert tr.world == world
     per = B // world
+    rcf_amd, m, nb = _setup(mode, slice(rank * per, (rank + 1) * per))
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode.startswith("bf16") else None)
+    assert tr.world == world
     losses = tr.step(_batch(nb, slice(rank * per, (rank + 1) * per), "cuda:0"))
     torch.cuda.synchronize()
-    if mode != "fp32":
+    if not mode.startswith("fp32"):
         # SyncBN exchanges of this rank: one per batch norm and direction, less the conv1 / downsample pairs that share one
         bns = [(n, mod) for n, mod in m.named_modules() if type(mod).__name__ == "BatchNorm2d" and mod.training and mod.sync]
         n_bn = (sum(1 for n, _ in bns if "_ema" not in n), sum(1 for n, _ in bns if "_ema" in n))      # (student, EMA teacher)
@@ -70,18 +78,21 @@ def _worker(rank, world, port, q, mode="fp32"):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_global_batch_step(report):
+@pytest.mark.parametrize("mode", ["fp32", "fp32_drop"])
+def test_two_rank_step_equals_global_batch_step(mode, report):
+    """fp32_drop: with Dropout2d 0.1 (one injected draw over the global batch, split by pairs like the batch): the dropout scale
+    rides the decode heads' last SyncBN pass, whose statistics and backward sums cross the ranks"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + os.getpid() % 2000 + (0 if mode == "fp32" else 3)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    rcf_amd, m, nb = _setup()
+    rcf_amd, m, nb = _setup(mode)
     tr = rcf_amd.Trainer(m, device="cuda:0")
     losses = tr.step(_batch(nb, slice(0, B), "cuda:0"))
     named = dict(m.named_parameters())
@@ -93,11 +104,11 @@ def test_two_rank_step_equals_global_batch_step(report):
         assert np.array_equal(g, res[1][2][n]), "ranks disagree after the all-reduce"
         worst = max(worst, float(np.abs(g - ref).max() / (np.abs(ref).max() + 1e-30)))
     e_rv = float(np.abs(res[0][3] - m.backbone2.bn1.running_var.cpu().numpy()).max())
-    report(f"2-rank DP vs single process: loss {e_loss:.2e} worst sampled grad {worst:.2e} running_var {e_rv:.2e}")
+    report(f"2-rank DP [{mode}] vs single process: loss {e_loss:.2e} worst sampled grad {worst:.2e} running_var {e_rv:.2e}")
     assert e_loss < 1e-5 and worst < 1e-4 and e_rv < 1e-6      # measured 5e-8 / 1.6e-6 / 0
 
 
-@pytest.mark.parametrize("mode", ["bf16", "stage21"])
+@pytest.mark.parametrize("mode", ["bf16", "stage21", "bf16_drop"])
 def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     """the N > 1 path of the other two step flavours on ONE device (gloo): the mixed-precision step (BASELINE configs[2]) and the
     stage-2.1 step (EMA teacher with its own SyncBN exchanges + CRF) over two ranks against the single-process step on the global
@@ -105,7 +116,7 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     conv1 and downsample statistics travel together"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 1000 + (7 if mode == "bf16" else 13)
+    port = 29900 + os.getpid() % 1000 + {"bf16": 7, "stage21": 13, "bf16_drop": 17}[mode]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -114,7 +125,7 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
         p.join(timeout=120)
         assert p.exitcode == 0
     rcf_amd, m, nb = _setup(mode)
-    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode == "bf16" else None)
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode.startswith("bf16") else None)
     losses = {k: float(v) for k, v in tr.step(_batch(nb, slice(0, B), "cuda:0")).items()}
     gn = float(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5)
     # rank losses are per-rank means over half the batch: their mean is the global loss
@@ -127,8 +138,8 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     want = 2 * n_st - 8 + ((n_te - 4) if n_te else 0)
     report(f"2-rank {mode} step vs single process: losses {e}; gradient norm {e_gn:.1e}; SyncBN collectives per rank {count} for {n_st} "
            f"student + {n_te} teacher norms (one per norm and direction would be {2 * n_st + n_te})")
-    tol = 2e-2 if mode == "bf16" else 2e-4         # bf16: the two ranks round their halves of the batch independently
-    assert max(e.values()) < tol and e_gn < (5e-2 if mode == "bf16" else 2e-3)
+    tol = 2e-2 if mode.startswith("bf16") else 2e-4         # bf16: the two ranks round their halves of the batch independently
+    assert max(e.values()) < tol and e_gn < (5e-2 if mode.startswith("bf16") else 2e-3)
     assert res[0][2] == res[1][2] and count == want
 
 

@@ -34,14 +34,33 @@ def _batch(B, H, W, device):
             "paths": nb["paths"]}
 
 
-def _build(H, W, affine, device, cls):
-    kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, affine=affine, norm="BN")
+DROP_P, DROP_SEED2, DROP_SEED3 = 0.1, 21, 22              # tests/golden/make_golden_dropout.py
+
+
+def _build(H, W, affine, device, cls, benched=None):
+    """benched = B: the configuration bench.py runs -- SyncBN + Dropout2d 0.1 in both FCN heads
+    (configs/rcf/rcf_stage1.yaml:83-85,118,139) -- with the Dropout2d draw of the dropout.* fixtures injected: into
+    FCNHead.keep_mask here, as oracle.FixedDropout2d into the oracle (the reference took the same module when the fixtures
+    were made)."""
+    if benched is None:
+        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, affine=affine, norm="BN")
+    else:
+        kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=DROP_P, affine=affine, norm="SyncBN")
     kw.update(log_interval=10 ** 9, train_iter=1)
     m = cls(_args(), **copy.deepcopy(kw))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()}
     m.load_state_dict(sd)
-    return m.to(device)
+    m = m.to(device)
+    if benched is not None:
+        s2 = torch.from_numpy(synth.dropout_scale(2 * benched, m.decode_head2.channels, DROP_P, DROP_SEED2))
+        s3 = torch.from_numpy(synth.dropout_scale(benched, m.decode_head3.channels, DROP_P, DROP_SEED3))
+        if cls is rcf_amd.RCFModel:
+            m.decode_head2.keep_mask, m.decode_head3.keep_mask = s2.to(device), s3.to(device)
+        else:
+            import rcf_torch as orc
+            m.decode_head2.dropout, m.decode_head3.dropout = orc.FixedDropout2d(s2), orc.FixedDropout2d(s3)
+    return m
 
 
 def rel(a, b):
@@ -115,9 +134,10 @@ def test_train_step_vs_reference_golden(tag, H, W, affine, golden_dir, report):
     assert e_after < 1e-2
 
 
-@pytest.mark.parametrize("H,W,B", [(64, 96, 2), (480, 854, 1)])
-def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, monkeypatch, report):
-    """EVERY parameter gradient against float64 with the ReLU lottery taken out -- at the small geometry and at the FULL
+@pytest.mark.parametrize("H,W,B,benched", [(64, 96, 2, False), (480, 854, 1, False), (96, 160, 2, True), (480, 854, 1, True)])
+def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, benched, monkeypatch, report):
+    """(benched: SyncBN + Dropout2d 0.1 with an injected draw -- the configuration bench.py times, _build.)
+    EVERY parameter gradient against float64 with the ReLU lottery taken out -- at the small geometry and at the FULL
     480x854 frame size (one pair: the float64 oracle fits a host's memory), so that a full-size shape meets the tight
     criterion too.  A ReLU unit whose pre-activation lies
     within fp32 noise of zero falls either way in two equally valid fp32 evaluations, and one such unit moves a channel's
@@ -132,7 +152,8 @@ def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, monkeypatch, report
         avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
         if avail < 40:
             pytest.skip(f"the float64 oracle at {H}x{W} needs ~25 GB of host memory ({avail:.0f} GB available)")
-    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    bb = B if benched else None
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel, benched=bb)
     tr = rcf_amd.Trainer(hip, device=DEV)
     tr.fp.zero_grad()
     hip.train()
@@ -144,7 +165,7 @@ def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, monkeypatch, report
     masks = [m.permute(0, 3, 1, 2).contiguous().cpu() for m in trace]              # NHWC -> NCHW, forward order
 
     def forced_run(double):
-        m = _build(H, W, False, "cpu", orc.RCFModel)
+        m = _build(H, W, False, "cpu", orc.RCFModel, benched=bb)
         b = _batch(B, H, W, "cpu")
         if double:
             m = m.double()
@@ -179,7 +200,7 @@ def test_train_step_all_grads_at_fixed_relu_pattern(H, W, B, monkeypatch, report
             bad.append((n, e_hip, e_ref))
         if e_hip / max(e_ref, 1e-7) > worst_ratio:
             worst_ratio, worst_name, worst_abs, worst_ref = e_hip / max(e_ref, 1e-7), n, e_hip, e_ref
-    report(f"all-grads at the HIP run's ReLU pattern, {H}x{W} B={B} ({len(masks)} ReLU layers, {sum(int(m.numel()) for m in masks)} units) vs "
+    report(f"all-grads at the HIP run's ReLU pattern, {H}x{W} B={B}{' SyncBN + injected Dropout2d draw' if benched else ''} ({len(masks)} ReLU layers, {sum(int(m.numel()) for m in masks)} units) vs "
            f"float64: loss {e_loss:.2e}; worst HIP / CPU-fp32 error ratio {worst_ratio:.2f} at {worst_name} (HIP {worst_abs:.2e}, "
            f"CPU fp32 {worst_ref:.2e}); parameters over max(6x ref, 1e-4): {len(bad)} {bad[:4]}")
     assert e_loss < 1e-5 and not bad, bad
@@ -317,6 +338,62 @@ def test_fullsize_480x854_vs_reference_golden(golden_dir, report):
     assert e_logit < lim_logit and e_mask < lim_mask and e_mean < TOL and mism == 0
     assert max(e_loss.values()) < TOL
     assert all(e_gn[k] < lim_gn[k] for k in e_gn), (e_gn, lim_gn)
+
+
+@pytest.mark.parametrize("tag", ["small", "480x854"])
+def test_benched_config_dropout_syncbn_vs_reference_golden(tag, golden_dir, report):
+    """Parity ON THE CONFIGURATION bench.py RUNS: norm SyncBN and Dropout2d 0.1 in decode_head2 /
+    decode_head3 (models/decode_head.py:84-87, models/fcn_head.py:142-147).  The draw is injected: the reference model took it as
+    its `dropout` module when tests/golden/make_golden_dropout.py ran, this path takes it as FCNHead.keep_mask -- the scale then
+    travels through the last norm's apply pass, its backward bound, the thin classifier convs and `pair_concat`, none of which
+    the dropout-free fixtures exercise.  Criteria as everywhere: losses / logits 1e-4 of the reference, arg-max equal on every
+    pixel whose top-2 margin exceeds 1e-4 of the logits' range, module gradient norms and sampled gradients against float64
+    within 4x the reference's own fp32 spread."""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "dropout.json")))[tag]
+    arr = np.load(os.path.join(golden_dir, "dropout.npz"))
+    H, W, B, C = fx["H"], fx["W"], fx["B"], fx["C"]
+    model = _build(H, W, False, DEV, rcf_amd.RCFModel, benched=B)
+    assert model.decode_head2.dropout_ratio == DROP_P and model.backbone2.bn1.sync
+    assert int((model.decode_head2.keep_mask == 0).sum()) == fx["dropped_head2"]
+    assert int((model.decode_head3.keep_mask == 0).sum()) == fx["dropped_head3"]
+    tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=DEV)
+    losses = tr.step(_batch(B, H, W, DEV))
+    e_loss = {k: rel(float(losses[k]), v) for k, v in fx["loss_fp32"].items()}
+    z = rcf_amd.ops.nhwc_to_nchw(model.last_logits, C).cpu().numpy()
+    am = z.argmax(1).astype(np.uint8)
+    sure = arr[tag + "_margin_fp32"].astype(np.float32) > TOL
+    mism = int((am != arr[tag + "_argmax_fp32"])[sure].sum())
+    if tag == "small":
+        e_logits = rel(z, arr["small_logits_fp32"])
+        e_logits64 = rel(z, arr["small_logits_f64"])
+    else:
+        e_logits = rel(torch.softmax(torch.from_numpy(z), dim=1).mean(dim=(2, 3)).numpy(), arr[tag + "_mask_mean_fp32"])
+        e_logits64 = rel(z[:1], arr[tag + "_logits_f64_0"])
+    named = dict(model.named_parameters())
+    gn = {}
+    for n, p in named.items():
+        if p.grad is not None:
+            gn[n.split(".")[0]] = gn.get(n.split(".")[0], 0.0) + float(p.grad.double().pow(2).sum())
+    e_gn = {k: rel(np.sqrt(gn[k]), v) for k, v in fx["gradnorm_f64"].items()}
+    lim_gn = {k: max(TOL, 4 * v) for k, v in fx["ref32_err_gradnorm"].items()}
+    e_grad, lim_grad = {}, {}
+    for i, (name, err) in enumerate(fx["ref32_err_grad"].items()):
+        g = named[name].grad.detach().cpu().contiguous().numpy().ravel()[:256]
+        e_grad[name] = rel(g, arr[f"{tag}_truth_grad_{i}"])
+        lim_grad[name] = max(TOL, 4 * err)
+    report(f"benched configuration (SyncBN, Dropout2d draw injected: {fx['dropped_head2']} + {fx['dropped_head3']} planes dropped) "
+           f"[{tag}] {H}x{W} B={B} vs the reference: loss {e_loss} logits {'' if tag == 'small' else '(mask means) '}{e_logits:.2e} "
+           f"vs f64 {e_logits64:.2e} (ref32 {fx['ref32_err_logits']:.2e}) argmax mismatches (sure px) {mism} of {int(sure.sum())} "
+           f"gradnorm vs f64 {e_gn} (limits {lim_gn}) grad vs f64 {e_grad} (limits {lim_grad})")
+    assert max(e_loss.values()) < TOL and e_logits < TOL and mism == 0
+    assert e_logits64 < max(TOL, 4 * fx["ref32_err_logits"])
+    assert all(e_gn[k] < lim_gn[k] for k in e_gn), (e_gn, lim_gn)
+    assert all(e_grad[k] < lim_grad[k] for k in e_grad), (e_grad, lim_grad)
+    # the draw matters: the same step without it lands elsewhere (guards against a keep_mask that is silently ignored)
+    plain = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    l0 = float(rcf_amd.Trainer(plain, device=DEV).step(_batch(B, H, W, DEV))["loss"])
+    assert abs(l0 - float(losses["loss"])) / abs(l0) > 1e-4
 
 
 @pytest.mark.parametrize("variant", list(config.VARIANTS))

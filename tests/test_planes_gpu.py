@@ -290,6 +290,51 @@ def test_training_step_with_and_without_pair_planes(report):
     assert e_l < 1e-5 and max(e_g.values()) < 2e-3
 
 
+def test_training_step_lazy_norm_with_all_joins_as_planes(report):
+    """with SCHED.join_planes = "all" a stage's first-block join writes pair planes AND (lazy downsample norm)
+    normalises its residual on the fly -- the one place where bn_apply_kernel calls block_max_f twice in a row (the residual
+    norm's bound, then its own), which raced on the shared scratch before block_max_f got its trailing barrier.  The step with
+    the lazy norm on must be reproducible bit for bit (a race is timing) and agree with the step with it off (the two-pass form;
+    the planes' bound starts from the raw residual's range there, so the scale 2^k may differ and the two are equal to rounding,
+    not bit for bit) -- a plane scale off by a power of two in some workgroups would be a gross error."""
+    import copy
+    import types
+    from rcf_amd import config, layers, synth
+    H, W, B = 96, 160, 2
+    res = {}
+    old = layers.SCHED.set(join_planes="all")
+    try:
+        for lazy in (True, False):
+            layers.SCHED.set(lazy_downsample_norm=lazy)
+            kw = config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="BN")
+            kw.update(log_interval=10 ** 9, train_iter=1)
+            args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_test", object_channel=None, eval_save=False, eval_export=False)
+            m = rcf_amd.RCFModel(args, **copy.deepcopy(kw))
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+            m.to(DEV)
+            tr = rcf_amd.Trainer(m, lr=1e-4, weight_decay=1e-4, device=DEV)
+            nb = synth.make_batch(B, H, W, config_id=1)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+            batch = {k: [t(a) for a in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
+            runs = []
+            for _ in range(3):                                  # a race shows as run-to-run differences too
+                tr.fp.zero_grad()
+                m.train()
+                l = m(batch)
+                l["loss"].backward()
+                runs.append((float(l["loss"]), tr.fp.grad.clone()))
+            assert all(r[0] == runs[0][0] and torch.equal(r[1], runs[0][1]) for r in runs[1:]), "the step is not reproducible"
+            res[lazy] = runs[0]
+    finally:
+        layers.SCHED.set(**{k: old[k] for k in ("join_planes",)}, lazy_downsample_norm=True)
+    e_l = abs(res[True][0] - res[False][0]) / abs(res[False][0])
+    e_g = float((res[True][1] - res[False][1]).double().norm() / res[False][1].double().norm())
+    report(f"join_planes='all': step with the downsample norm applied inside the join vs as its own pass: reproducible over 3 runs; "
+           f"loss {e_l:.1e}, flat gradient {e_g:.1e} (norm-relative)")
+    assert e_l < 1e-5 and e_g < 2e-3
+
+
 @pytest.mark.parametrize("case", [
     # N, Cin, Cout, k, stride, pad, dil, H, W   (Cin = the batch norm's channels = the data gradient's output columns)
     (2, 256, 256, 3, 1, 2, 2, 60, 107),      # bn1 -> conv2 of layer3: 256-wide tile
