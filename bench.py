@@ -141,10 +141,25 @@ def main():
             by_serial = ops.PROFILE.stop()
         finally:
             layers.SCHED.overlap_wgrad = saved
+        # N > 1: what the collectives cost, so that a scaling run can be read (DistCtx.profile brackets every SyncBN exchange
+        # on the stream it is issued on; Trainer.profile brackets the wait for the gradient chunks at the end of backward)
+        comm = None
+        if world > 1:
+            d, nprof = model._dist(), 2
+            d.count, d.bytes, d.events, d.profile = 0, 0, [], True
+            trainer.profile, trainer.exposed = True, []
+            for _ in range(nprof):
+                trainer.step(batch)
+            ms, ex = d.profile_ms(), trainer.exposed_ms()
+            d.profile, trainer.profile = False, False
+            comm = {"syncbn_collectives": d.count // nprof, "syncbn_ms_per_step": round(sum(ms) / nprof, 3),
+                    "syncbn_bytes_per_step": d.bytes // nprof, "syncbn_max_us": round(1e3 * max(ms), 1) if ms else None,
+                    "allreduce_exposed_ms": round(sum(ex) / max(len(ex), 1), 3), "grad_communicator": trainer.grad_group_mode,
+                    "grad_bytes": int(trainer.fp.total) * 4, "grad_chunks": len(trainer.ranges or {}) or 1}
         barrier()
         del trainer, model
         torch.cuda.empty_cache()
-        return dt, loss_val, prof, by, by_serial
+        return dt, loss_val, prof, by, by_serial, comm
 
     def roofline_of(prof, name, kernel, peak, by=None, traffic=None):
         n, flops, ms = prof["launches"], prof["flops"], prof["ms"]
@@ -172,13 +187,13 @@ def main():
     # same kernel on the transposed weights = the data gradient 14.1-14.9, the plane weight gradient 13.4-14.1).  The forward pass
     # has no second stream beside it, so its live bracket and its one-stream bracket measure the same thing.
     fam32 = os.environ.get("RCF_BENCH_FAMILY", "conv_h2d_fwd")
-    dt, loss_val, prof, by32, by32s = step_leg("fp32", fam32, a.steps, a.warmup)
+    dt, loss_val, prof, by32, by32s, comm32 = step_leg("fp32", fam32, a.steps, a.warmup)
     frames = 2 * B * world * a.steps
     value = frames / dt
     out = {
         "metric": "training frames/sec at 480x854 (RCF stage-1)", "value": round(value, 3), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3xfp16-MFMA split)", "data": "synthetic",
         "priming_steps": PRIMING_STEPS,
         "arithmetic": "fp32 step, emulated on the fp16 matrix cores: every conv operand is scaled by a power of two into "
                       "fp16's range and split into 2 fp16 parts (22 significand bits), 3 partial products on fp16 MFMA, fp32 "
@@ -196,7 +211,7 @@ def main():
     bf = None
     if not a.no_bf16:
         fam16 = os.environ.get("RCF_BENCH_FAMILY_BF16", "conv_bf16_dgrad_wide")     # the largest share of the bf16 step (10.6 of 50.6 ms)
-        dt16, loss16, prof16, by16, by16s = step_leg("bf16", fam16, a.steps, a.warmup)
+        dt16, loss16, prof16, by16, by16s, comm16 = step_leg("bf16", fam16, a.steps, a.warmup)
         v16 = frames / dt16
         bf = {"workload": f"the same step in mixed precision (BASELINE configs[2]): bf16 activations and MFMA operands, fp32 "
                           f"accumulation, fp32 master weights / gradients / Adam; {B} pairs/GPU, dp{world}",
@@ -204,6 +219,10 @@ def main():
               "vs_fp32_step": round(v16 / value, 3), "loss": round(loss16, 6),
               "step_tflops_per_gpu": round(v16 / world * GF_PER_FRAME / 1e3, 2),
               "frac_of_bf16_mfma_roofline": round(v16 / world * GF_PER_FRAME / 1e3 / BF16_MFMA_PEAK_TF, 4)}
+        if comm16:
+            bf["comm"] = comm16
+    if comm32:
+        out["comm"] = comm32
     if rank == 0:
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -283,7 +302,7 @@ def main():
         # CRF, T=5) and the EMA teacher forward + update in the loop
         if not a.no_stage2 and world == 1:
             try:
-                out["stage2_step"] = stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, a.crf_iters)
+                out["stage2_step"] = stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, a.crf_iters, bf16=not a.no_bf16)
             except Exception as e:                              # noqa: BLE001
                 out["stage2_step"] = None
                 out["stage2_error"] = str(e)[:200]
@@ -355,8 +374,47 @@ def contract_line(out):
         line["warp_frac"] = out["warp_roofline"].get("frac")
     if isinstance(out.get("stage2_step"), dict):
         line["stage2_ms_per_step"] = out["stage2_step"].get("ms_per_step")
+        if out["stage2_step"].get("bf16_ms_per_step") is not None:
+            line["stage2_bf16_ms_per_step"] = out["stage2_step"]["bf16_ms_per_step"]
+    cm = out.get("comm")
+    if cm:                                                      # N > 1: what to read a scaling result against
+        line.update(pick(cm, ("syncbn_ms_per_step", "syncbn_collectives", "allreduce_exposed_ms")))
+        line["grad_comm"] = _clip(cm.get("grad_communicator", ""), 60)
+        cm16 = (out.get("bf16_step") or {}).get("comm")
+        if cm16:
+            line["bf16_syncbn_ms_per_step"] = cm16.get("syncbn_ms_per_step")
+            line["bf16_allreduce_exposed_ms"] = cm16.get("allreduce_exposed_ms")
     line["detail"] = "gpurun_out/bench_detail.json"
     return line
+
+
+# keys a contract line can lose, in this order, when it would not fit (the contract's own keys are never dropped)
+OPTIONAL_KEYS = ("detail", "bf16_allreduce_exposed_ms", "bf16_syncbn_ms_per_step", "grad_comm", "stage2_bf16_ms_per_step",
+                 "stage2_ms_per_step", "warp_frac", "crf_noise_frac", "crf_noise_ms_per_frame", "bf16_kernel_frac",
+                 "bf16_step_frac", "crf_frac", "crf_ms_per_frame", "bf16_ms_per_step", "bf16_frames_per_s",
+                 "allreduce_exposed_ms", "syncbn_collectives", "syncbn_ms_per_step")
+
+
+def fit_contract_line(line, limit=None):
+    """-> the JSON text of `line`, at most `limit` BYTES: optional keys go first, then the strings are clipped harder.  Never
+    raises: a benchmark that ran must print its line."""
+    limit = limit or CONTRACT_LINE_MAX
+    line = dict(line)
+    text = json.dumps(line)
+    for k in OPTIONAL_KEYS:
+        if len(text.encode()) <= limit:
+            return text
+        line.pop(k, None)
+        text = json.dumps(line)
+    for n in (80, 40, 16):
+        if len(text.encode()) <= limit:
+            return text
+        for sub, key in (("config", "workload"), ("roofline", "kernel"), ("cpu_baseline", "sample")):
+            if isinstance(line.get(sub), dict) and key in line[sub]:
+                line[sub][key] = _clip(line[sub][key], n)
+        line["metric"] = _clip(line.get("metric", ""), max(n, 48))
+        text = json.dumps(line)
+    return text
 
 
 def emit(out):
@@ -369,9 +427,7 @@ def emit(out):
     except OSError as e:                                        # a read-only tree must not cost the run its line
         print(f"bench_detail.json not written: {e}", file=sys.stderr)
     print("BENCH_DETAIL " + full, flush=True)
-    line = json.dumps(contract_line(out))
-    assert len(line) <= CONTRACT_LINE_MAX, f"contract line is {len(line)} bytes"
-    print(line, flush=True)
+    print(fit_contract_line(contract_line(out)), flush=True)
 
 
 def _free_port():
@@ -457,27 +513,39 @@ def crf_bench(torch, rcf_amd, synth, dev, H, W, iters, nframes=8, noise=False):
                          "frac": round(ach / HBM_PEAK_GBS, 4)}}
 
 
-def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, steps=3):
+def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, steps=3, bf16=True):
+    """the stage-2.1 step (the one BASELINE configs[3] trains with the CRF in the loop, models/rcf_model.py:490-529) in fp32 and,
+    `bf16`, in mixed precision (parity: tests/test_stage2_gpu.py::test_stage21_bf16_step_vs_reference_autocast)"""
     import types
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=1, eval_save=False, eval_export=False)
-    model = rcf_amd.RCFModel(args, **config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN",
-                                                                 refine_iters=iters))
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
-    tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev)
-    for _ in range(PRIMING_STEPS):                     # allocator / second-stream scratch reach their steady state
-        tr.step(batch)
-    torch.cuda.synchronize()
-    times = []
-    for _ in range(steps):                             # secondary leg: median of individually timed steps
-        t0 = time.perf_counter()
-        losses = tr.step(batch)
+
+    def leg(precision):
+        model = rcf_amd.RCFModel(args, **config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN",
+                                                                     refine_iters=iters))
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+        tr = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=precision)
+        for _ in range(PRIMING_STEPS):                 # allocator / second-stream scratch reach their steady state
+            tr.step(batch)
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    dt = sorted(times)[len(times) // 2]
-    return {"workload": f"stage 2.1 step: stage-1 step + EMA teacher forward + CRF (T={iters}) on {2 * B} frames + EMA update",
-            "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(2 * B / dt, 2),
-            "loss_crf": round(float(losses["loss_crf"]), 6)}
+        times = []
+        for _ in range(steps):                         # secondary leg: median of individually timed steps
+            t0 = time.perf_counter()
+            losses = tr.step(batch)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        lc = float(losses["loss_crf"])
+        del tr, model
+        torch.cuda.empty_cache()
+        return sorted(times)[len(times) // 2], lc
+    dt, lc = leg(None)
+    out = {"workload": f"stage 2.1 step: stage-1 step + EMA teacher forward + CRF (T={iters}) on {2 * B} frames + EMA update",
+           "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(2 * B / dt, 2), "loss_crf": round(lc, 6)}
+    if bf16:
+        dt16, lc16 = leg("bf16")
+        out.update({"bf16_ms_per_step": round(dt16 * 1e3, 2), "bf16_frames_per_s": round(2 * B / dt16, 2),
+                    "bf16_loss_crf": round(lc16, 6)})
+    return out
 
 
 def vit_bench(torch, rcf_amd, synth, dev, frames=4):

@@ -217,10 +217,14 @@ class Schedule:
       cache_weight_operands  derived weight operands once per weight update, not per launch
       bulk_weight_prep   ... for all weights of the model in two / three launches right after the optimizer step (trainer.WeightPrep)
     data parallel
-      grad_group         the gradient chunks' all-reduces on their OWN communicator (beside the default one that carries SyncBN)
-      teacher_group      stage 2.1: the EMA teacher's SyncBN exchanges on their own communicator
-                         Both default to False: one RCCL communicator in flight is the only configuration anyone has run
-                         (no multi-GPU box has been reachable from the build container: DESIGN.md section 7)."""
+      grad_group         the gradient chunks' all-reduces on their OWN communicator (beside the default one that carries SyncBN):
+                         "auto" (default) = try it -- new_group + one probe all-reduce in Trainer.__init__, every rank agreeing on
+                         the outcome through the default group -- and share the default communicator if any rank failed;
+                         True = own communicator or raise; False = always share.  On a shared communicator the 10-60 MB
+                         asynchronous chunks and the SyncBN exchanges queue on ONE RCCL stream in issue order, so every
+                         statistics exchange issued after a chunk waits for it (Trainer.grad_group_mode says what ran)
+      teacher_group      stage 2.1: the EMA teacher's SyncBN exchanges on their own communicator (default False: a third
+                         communicator only pays in stage 2.1 and no multi-GPU box has run one yet)."""
 
     __slots__ = ("overlap_wgrad", "late_wgrad", "side_priority", "overlap_teacher", "fuse_bn_stats", "fuse_bn_finalize",
                  "fuse_bn_bwd", "relu_bitmask", "defer_residual", "lazy_downsample_norm", "merge_downsample_bwd", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
@@ -236,7 +240,7 @@ class Schedule:
         self.fold_bn, self.fold_max_k, self.fold_masked_dgrad = True, 512, True
         self.fp16_pairs, self.h2_kinds, self.planes, self.join_planes = True, "fdw", True, "stage"
         self.bf16_stem = self.cache_weight_operands = self.bulk_weight_prep = True
-        self.grad_group = self.teacher_group = False
+        self.grad_group, self.teacher_group = "auto", False
 
     def set(self, **kw):
         """set several fields; returns the previous values (for a `finally: SCHED.set(**old)`)"""

@@ -94,6 +94,8 @@ class CRFHead(nn.Module):
         # sort build wins from ~1.4 x 10^5 vertices per frame up (noise-like frames of any size), loses below ~7 x 10^4 (natural
         # frames: 0.30 vs 0.43 ms per 480x854 frame).  The counts travel to the host by an asynchronous copy that is
         # only read once its event has completed: no host wait, and the masks do not depend on the choice.
+        # The choice is a heuristic on counts that are one or two calls old and read without synchronisation: it may differ from
+        # run to run and rank to rank BY DESIGN -- every build gives bit-identical masks (tests/test_crf_gpu.py).
         self.sort_build = "auto"
         self.last_build = 0
         self._nv_host = None
@@ -151,6 +153,9 @@ class CRFHead(nn.Module):
         N, H, W, _ = rgb.shape
         auto = self.sort_build == "auto"
         self.last_build = self._pick_build(H * W)
+        if self.last_build == 3 and N > 16:
+            self.last_build = 0              # csrc/crf.hip build_lattice: the sort build takes at most 16 frames per call (4 frame
+                                             # bits beside the 60 key bits) -- report the build that runs, not the one asked for
         m = crf_soft_batched(rgb, unary, W, H, self.scomp_smooth, self.sxy_smooth, self.scomp, self.sxy, self.srgb,
                              self.refine_iters, symmetric=symmetric, want_nvert=auto, build=self.last_build)
         if auto:

@@ -747,7 +747,8 @@ def fold_ok(conv, bn, x, residual=None):
     t = x.t
     return (SCHED.fold_bn and t.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
             and not conv.act and bn.training and conv.cin % 64 == 0 and conv.cin <= SCHED.fold_max_k
-            and (conv.cout in (64, 128) or conv.cout % 256 == 0) and t.is_contiguous() and bn.num_features == conv.cout
+            and (conv.cout in (64, 128) or conv.cout % 256 == 0) and ops.relu_mask_colsum_ok(conv.cout)
+            and t.is_contiguous() and bn.num_features == conv.cout
             and (residual is None or (residual.t.dtype == torch.bfloat16 and tuple(residual.t.shape[:3]) == tuple(t.shape[:3])
                                       and residual.t.shape[3] == conv.cout)))
 

@@ -632,6 +632,13 @@ def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True,
     return (out, bits) if want_bits else out
 
 
+def relu_mask_colsum_ok(C):
+    """does rcf_relu_mask_colsum_bf16 -- the fold's backward when no data gradient delivers the masked gradient -- take this
+    width?  The library's own predicate (its workspace query returns 0 for a width it refuses: 64 ... 2048 in powers of two
+    pass), so that layers.fold_ok cannot accept a conv whose backward would then fail."""
+    return _lib.load().rcf_relu_mask_colsum_bf16_workspace_bytes(64, int(C)) > 0
+
+
 def relu_mask_colsum(dy, y, out=None):
     """(g = y > 0 ? dy : 0, fp64 [2C] whose first half holds the column sums of g); out may be dy (in place)"""
     _need_cuda(dy, y)

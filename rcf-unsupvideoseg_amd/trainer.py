@@ -174,6 +174,44 @@ def _lib_call(name, *args):
     return _lib.call(name, *args)
 
 
+def make_grad_group(want, device):
+    """-> (process group or None, what it is): the communicator of the gradient chunks (SCHED.grad_group).  Collective: every
+    rank calls it at the same point and takes the same branches.  Two steps, each followed by an agreement (MIN of an ok flag
+    over the default group, so no rank goes on to wait on a group its peers gave up on): (1) new_group; (2) a probe
+    all-reduce, which makes RCCL create the communicator HERE (new_group alone is lazy), not inside the first backward.
+    If any rank failed, "auto" shares the default communicator on all ranks and True raises on all ranks."""
+    if want is False or want == 0:
+        return None, "shared with SyncBN (SCHED.grad_group = False)"
+    device = torch.device(device)
+
+    def agree(ok):
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag) == 1
+    err, g = "", None
+    try:
+        g = dist.new_group()
+    except Exception as e:                                  # noqa: BLE001 -- reported through the mode string, decided collectively
+        err = f"{type(e).__name__}: {e}"[:160]
+    good = agree(not err)
+    if good:
+        try:
+            probe = torch.ones(1, dtype=torch.float32, device=device)
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=g)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            if float(probe) != float(dist.get_world_size()):
+                err = "the probe all-reduce returned a wrong sum"
+        except Exception as e:                              # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:160]
+        good = agree(not err)
+    if good:
+        return g, "own communicator"
+    if want is True or want == 1:
+        raise RuntimeError(f"SCHED.grad_group = True but the gradient communicator could not be created ({err or 'on another rank'})")
+    return None, f"shared with SyncBN (own communicator failed: {err or 'on another rank'})"
+
+
 class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, epochs=200, power=0.9, min_lr=1e-6, device="cuda:0",
                  betas=(0.9, 0.999), eps=1e-8, force_group=False, precision=None):
@@ -192,19 +230,27 @@ class Trainer:
         # on a single GPU: tests/test_dist_gpu.py)
         self.chunked = self.world > 1 or (force_group and dist.is_available() and dist.is_initialized())
         self.ranges = self.fp.group_ranges(self.model) if self.chunked else None
-        # The gradient chunks travel on their OWN communicator: with one process group the asynchronous 10-60 MB chunk
-        # all-reduces and the small synchronous SyncBN all-reduces of the layers still in backward would share one
-        # RCCL stream in issue order, and every statistics exchange would queue behind the chunk before it.
-        # SCHED.grad_group (default False): the chunks share the default group -- two RCCL communicators in flight at once is a
-        # configuration no multi-GPU box has exercised yet, so it is opt-in until a measured run exists
-        own_group = bool(config.SCHED.grad_group)
-        self.grad_group = dist.new_group() if (self.chunked and own_group) else None
+        # The gradient chunks travel on their OWN communicator where one can be had: with one process group the asynchronous
+        # 10-60 MB chunk all-reduces and the small synchronous SyncBN all-reduces of the layers still in backward share one
+        # RCCL stream in issue order, and every statistics exchange queues behind the chunk before it.
+        # SCHED.grad_group: "auto" (default) tries the own communicator and falls back to the shared one, True insists, False shares.
+        self.grad_group, self.grad_group_mode = (self._make_grad_group(config.SCHED.grad_group) if self.chunked
+                                                 else (None, "none (one rank)"))
+        self.profile, self.exposed = False, []             # profile: events around the wait for the gradient chunks
         if self.chunked and hasattr(self.model, "make_teacher_group"):
             self.model.make_teacher_group()                 # stage 2.1, SCHED.teacher_group: created here, collectively
         self._pending, self._done = [], set()
         self.prep = None                                    # WeightPrep, built after the first optimizer step
         if self.ranges is not None and hasattr(self.model, "grad_ready_hook"):
             self.model.grad_ready_hook = self._grads_ready
+
+    def _make_grad_group(self, want):
+        return make_grad_group(want, self.device)
+
+    def exposed_ms(self):
+        """profile mode: per step, how long the compute stream stood waiting for the gradient chunks' all-reduces (ms)"""
+        torch.cuda.synchronize(self.device)
+        return [a.elapsed_time(b) for a, b in self.exposed]
 
     def _grads_ready(self, group):
         """tape mark: the group's gradients are final -> start their all-reduce behind the kernels queued so far"""
@@ -233,8 +279,14 @@ class Trainer:
             else:
                 for g in self.ranges:                           # groups whose mark did not fire (e.g. a frozen path)
                     self._grads_ready(g)
+                if self.profile:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 for h in self._pending:
                     h.wait()
+                if self.profile:
+                    e1.record()
+                    self.exposed.append((e0, e1))
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
                       self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)

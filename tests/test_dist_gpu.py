@@ -280,6 +280,10 @@ def test_bench_two_ranks_end_to_end(report):
     report(f"bench.py --gpus 2 (gloo, shared GPU): {d['value']} frames/s, {d['ms_per_step']} ms/step")
     assert d["n_gpus"] == 2 and d["config"]["global_pairs"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "roofline" in d and "cpu_baseline" not in d
+    # what a scaling run is read against: the SyncBN exchanges of a step counted and timed on the
+    # stream they are issued on, the wait for the gradient chunks at the end of backward, and which communicator carried them
+    assert d["syncbn_collectives"] == 106 and d["syncbn_ms_per_step"] > 0 and d["allreduce_exposed_ms"] >= 0
+    assert d["grad_comm"] == "own communicator", d["grad_comm"]
 
 
 def test_bench_self_launches_its_ranks(report):

@@ -191,6 +191,26 @@ def test_bench_contract_line_is_short_and_complete(capsys, tmp_path, monkeypatch
     fat["roofline"]["kernel"] = "k" * 500
     fat["cpu_baseline"]["sample"] = "s" * 500
     assert len(json.dumps(b.contract_line(fat))) <= b.CONTRACT_LINE_MAX
+    # ... and a line that would NOT fit is degraded, never refused: optional keys go, then the strings shrink;
+    # the contract's own keys stay and the size is counted in encoded bytes
+    huge = b.contract_line(fat)
+    huge["config"]["workload"] = "\u00e9" * 1500                        # 2 bytes each in UTF-8, 6 as JSON escapes
+    huge["roofline"]["kernel"] = "k" * 900
+    huge.update(comm_note="x" * 10)
+    text = b.fit_contract_line(huge)
+    small = json.loads(text)
+    assert len(text.encode()) <= b.CONTRACT_LINE_MAX
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in small, k
+    assert small["value"] == full["value"] and small["roofline"]["frac"] == full["roofline"]["frac"] and "detail" not in small
+    # N > 1: the communication keys a scaling run is read against travel on the line
+    multi = json.loads(json.dumps(full))
+    multi["comm"] = {"syncbn_collectives": 106, "syncbn_ms_per_step": 3.2, "allreduce_exposed_ms": 0.4,
+                     "grad_communicator": "own communicator"}
+    ml = b.contract_line(multi)
+    assert ml["syncbn_collectives"] == 106 and ml["allreduce_exposed_ms"] == 0.4 and ml["grad_comm"] == "own communicator"
+    assert len(b.fit_contract_line(ml).encode()) <= b.CONTRACT_LINE_MAX and "syncbn_ms_per_step" in json.loads(b.fit_contract_line(ml))
 
 
 def test_weight_operand_cache_invalidation(monkeypatch):
@@ -278,7 +298,7 @@ def test_schedule_object_is_the_only_home_of_the_step_knobs(monkeypatch):
     assert layers.SCHED is config.SCHED and ops.SCHED is config.SCHED
     d = config.Schedule().as_dict()
     assert d["overlap_wgrad"] and d["late_wgrad"] and d["planes"] and d["fold_bn"] and not d["fuse_bn_bwd"]
-    assert d["grad_group"] is False and d["teacher_group"] is False          # one communicator until a multi-GPU run exists
+    assert d["grad_group"] == "auto" and d["teacher_group"] is False         # own gradient communicator where one can be had
     for k in d:
         assert re.search(r"\b" + k + r"\b", config.Schedule.__doc__), f"Schedule.{k} is not documented"
     sc = config.Schedule()
