@@ -255,6 +255,16 @@ def main():
                                              if src else "timed region (one stream)"),
                                 "live_achieved": live["achieved"], "live_frac": live["frac"], "live_avg_launch_ms": live["avg_launch_ms"],
                                 "live_launches": live["launches"]})
+        # matrix-pipe busy fraction and effective clock of the same kernel family: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES /
+        # GRBM_GUI_ACTIVE passes over THIS command (tools/pmc_mfma.sh -> profiles/pmc_mfma.json, committed like the traffic):
+        # frac ~ mfma_busy x clock_ghz / 2.4 -- the chip clocks down under the convs' power draw (profiles/r06_pmc_headline_random_vs_zero.txt)
+        mpath = os.path.join(ROOT, "profiles", "pmc_mfma.json")
+        if os.path.exists(mpath) and (B, H, W) == (8, 480, 854):
+            mj = json.load(open(mpath)).get("by_family", {})
+            if fam32 in mj:
+                out["roofline"].update({"mfma_busy": mj[fam32]["mfma_busy"], "clock_ghz": mj[fam32]["clock_ghz"], "l2_hit": mj[fam32]["l2_hit"],
+                                        "mfma_busy_source": "profiles/pmc_mfma.json (committed rocprofv3 --pmc passes of this command), not measured in this run"})
+            out["pmc_by_family"] = {k: {q: v[q] for q in ("mfma_busy", "clock_ghz", "l2_hit", "launches")} for k, v in mj.items()}
         out["roofline"]["note"] = ("the family with the largest share of the step's kernel time; the deep convs are power-limited "
                                    "(the same launch runs 25-30 % faster on all-zero operands: LABNOTES.md), the family average "
                                    "includes the bottlenecks' short-K 1x1 layers (per-layer table: profiles/)")
@@ -354,7 +364,7 @@ def contract_line(out):
     if rl:
         line["roofline"] = {"kernel": _clip(str(rl.get("kernel", "")).split(" (")[0], 80),
                             **pick(rl, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
-                                        "flops_per_launch"))}
+                                        "flops_per_launch", "mfma_busy", "clock_ghz"))}
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {**pick(cb, ("value", "unit", "cores", "kind", "s_per_step", "timed_steps")),

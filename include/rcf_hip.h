@@ -109,6 +109,11 @@ typedef struct {
 /* 1x1 convs with 4 / 8 / 16 output channels on 64 .. 512 input channels (the decode heads' classifiers) run as streaming fp32
  * passes (csrc/thin.hip) instead of GEMM tiles with a handful of live columns; this bit keeps them on the GEMM kernels (A/B, tests) */
 #define RCF_CONV_NO_THIN 0x100u
+/* the forward / data-gradient tile kernels write their output with non-temporal (streaming) stores: the tile's 64 KB of output
+ * does not stay in the XCD's 4 MB L2, where -- with 64 tiles in flight per XCD -- it evicts the weights and the activation rows
+ * the neighbouring column tiles are still reading (tools/lab/gemm_lab, profiles/r06_gemm_lab_nt_stores.txt).  Results are
+ * bit-identical; a per-call choice (rcf_amd.layers decides per layer: SCHED.nt_stores). */
+#define RCF_CONV_NT_STORES 0x200u
 #define RCF_CONV_FP32_MFMA(v) ((((unsigned)(v) & 3u) + 1u) << 12)
 
 /* planes (rcf_conv_weight_pairs_bytes): fp16 h and m of w * 2^k, k from *amax_w, in the kernel's reading order

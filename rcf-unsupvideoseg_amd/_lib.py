@@ -35,7 +35,7 @@ CONV_X_PLANES, CONV_DY_PLANES = 0x2, 0x4
 WARP_PER_PIXEL = 0x100
 BN_SWEEP_OFF, BN_SWEEP_ALWAYS, BN_Y_PLANES_ONLY, BN_DX_PLANES = 0x1, 0x2, 0x4, 0x8
 CONV_H2P_NEVER, CONV_H2P_ALWAYS = 0x8, 0x10
-CONV_NO_WGRAD_XCD, CONV_NO_COLMAP, CONV_KORDER_NATURAL, CONV_NO_THIN = 0x20, 0x40, 0x80, 0x100
+CONV_NO_WGRAD_XCD, CONV_NO_COLMAP, CONV_KORDER_NATURAL, CONV_NO_THIN, CONV_NT_STORES = 0x20, 0x40, 0x80, 0x100, 0x200
 
 
 def CONV_FP32_MFMA(v):

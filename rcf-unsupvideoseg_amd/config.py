@@ -213,6 +213,9 @@ class Schedule:
       planes             fp32 step: the norms between the bottlenecks' convs write fp16 pair planes, those convs take both operands
                          by LDS-DMA
       join_planes        which joins are ALSO written as planes: "stage" (in front of a stage's first block) or "all"
+      nt_stores          forward / data-gradient tile kernels with at least this many output columns write their output with
+                         streaming (non-temporal) stores, RCF_CONV_NT_STORES: the tiles' output does not push the weights and the
+                         neighbouring column tiles' activation rows out of the XCD's L2 (0 = never; results bit-identical)
       bf16_stem          bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels)
       cache_weight_operands  derived weight operands once per weight update, not per launch
       bulk_weight_prep   ... for all weights of the model in two / three launches right after the optimizer step (trainer.WeightPrep)
@@ -228,7 +231,7 @@ class Schedule:
 
     __slots__ = ("overlap_wgrad", "late_wgrad", "side_priority", "overlap_teacher", "fuse_bn_stats", "fuse_bn_finalize",
                  "fuse_bn_bwd", "relu_bitmask", "defer_residual", "lazy_downsample_norm", "merge_downsample_bwd", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
-                 "h2_kinds", "planes", "join_planes", "bf16_stem", "cache_weight_operands", "bulk_weight_prep", "grad_group",
+                 "h2_kinds", "planes", "join_planes", "nt_stores", "bf16_stem", "cache_weight_operands", "bulk_weight_prep", "grad_group",
                  "teacher_group")
 
     def __init__(self):
@@ -241,6 +244,7 @@ class Schedule:
         self.fp16_pairs, self.h2_kinds, self.planes, self.join_planes = True, "fdw", True, "stage"
         self.bf16_stem = self.cache_weight_operands = self.bulk_weight_prep = True
         self.grad_group, self.teacher_group = "auto", False
+        self.nt_stores = 0
 
     def set(self, **kw):
         """set several fields; returns the previous values (for a `finally: SCHED.set(**old)`)"""

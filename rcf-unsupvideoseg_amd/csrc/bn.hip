@@ -138,24 +138,29 @@ __global__ void __launch_bounds__(RED_THREADS) colreduce2_kernel(F f, long rows,
     }
 }
 
-// out[i] = sum_k partial[k][i]: 32 outputs x 8 chunk-slices per block, fixed summation order
+// out[i] = sum_k partial[k][i]: COLS outputs x (256 / COLS) chunk-slices per block, fixed summation order.  The time of this
+// kernel is its DEPENDENT load rounds (chunks / slices / 4 chains), not its bytes: 32 columns x 8 slices over the 1024 partial
+// rows a batch-norm backward reduction leaves took 12.5 us for 4 MB (round 5 step profile: 58 launches, 0.72 ms); launch_partial_sum
+// narrows the column group until enough workgroups run and a thread has at most ~32 rows (round 6).
+template <int COLS>
 __global__ void __launch_bounds__(256) partial_sum_kernel(const double *__restrict__ partial, int chunks, int n,
                                                           double *__restrict__ out) {
+    constexpr int SL = 256 / COLS;
     __shared__ double sh[256];
-    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + j;
+    const int j = threadIdx.x % COLS, s = threadIdx.x / COLS;
+    const int i = blockIdx.x * COLS + j;
     double acc = 0;
     if (i < n) {
         // four independent chains (loads in flight), combined in a fixed order
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int k = s;
-        for (; k + 24 < chunks; k += 32) {
+        for (; k + 3 * SL < chunks; k += 4 * SL) {
             a0 += partial[(long)k * n + i];
-            a1 += partial[(long)(k + 8) * n + i];
-            a2 += partial[(long)(k + 16) * n + i];
-            a3 += partial[(long)(k + 24) * n + i];
+            a1 += partial[(long)(k + SL) * n + i];
+            a2 += partial[(long)(k + 2 * SL) * n + i];
+            a3 += partial[(long)(k + 3 * SL) * n + i];
         }
-        for (; k < chunks; k += 8) a0 += partial[(long)k * n + i];
+        for (; k < chunks; k += SL) a0 += partial[(long)k * n + i];
         acc = (a0 + a1) + (a2 + a3);
     }
     sh[threadIdx.x] = acc;
@@ -163,9 +168,18 @@ __global__ void __launch_bounds__(256) partial_sum_kernel(const double *__restri
     if (s == 0 && i < n) {
         double t = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += sh[q * 32 + j];
+        for (int q = 0; q < SL; ++q) t += sh[q * COLS + j];
         out[i] = t;
     }
+}
+// the column group of a reduction over `chunks` rows of n values: 32 (one 256-byte row piece per block and row) unless that
+// leaves a thread more than 32 rows or the chip fewer than 64 workgroups -- then 16, then 8 columns (64-byte pieces)
+inline void launch_partial_sum(const double *partial, int chunks, int n, double *out, hipStream_t st) {
+    int cols = 32;
+    while (cols > 8 && (chunks / (256 / cols) > 32 || rcf_cdiv(n, cols) < 64)) cols >>= 1;
+    if (cols == 32) hipLaunchKernelGGL(partial_sum_kernel<32>, dim3(rcf_cdiv(n, 32)), dim3(256), 0, st, partial, chunks, n, out);
+    else if (cols == 16) hipLaunchKernelGGL(partial_sum_kernel<16>, dim3(rcf_cdiv(n, 16)), dim3(256), 0, st, partial, chunks, n, out);
+    else hipLaunchKernelGGL(partial_sum_kernel<8>, dim3(rcf_cdiv(n, 8)), dim3(256), 0, st, partial, chunks, n, out);
 }
 
 // out[g][i] = sum of partial[k][i] over the g-th group of `per` rows (blockIdx.y = g); same fixed order as above
@@ -380,9 +394,12 @@ __global__ void bn_finalize_kernel(const double *__restrict__ sums, double count
 }
 
 // partial [chunks][2C] (sum | sum of squares per conv row tile) -> sums[2C] and, with fin.on, the batch-norm constants of
-// bn_finalize_kernel plus `num_batches_tracked += 1`, in the launch that finishes the reduction.  Long lists of row tiles
-// are first cut into G groups by partial_sum_groups_kernel (more workgroups than C/32 read), this kernel then adds the G
-// group rows.  (A single-launch form -- the workgroup that draws the last ticket of its channels adds the group rows --
+// bn_finalize_kernel plus `num_batches_tracked += 1`, in the launch that finishes the reduction.  Until round 5 long lists of
+// row tiles were first cut into G groups by partial_sum_groups_kernel (more workgroups than C/32 read) and this kernel added
+// the G group rows: two launches of ~5 us each, 54 times per step, on the forward critical path.  Round 6: ONE launch for
+// lists of 256 .. 1023 row tiles -- what the reduction costs is dependent load rounds per thread, so a workgroup takes fewer
+// channels (CH = 8 instead of 32) and more row slices (32 instead of 8): at most ~8 rounds of four loads in flight per thread,
+// C / 8 workgroups; longer lists keep the groups launch (rcf_sum_partials_bn).  (A single-launch form of ANOTHER kind -- the workgroup that draws the last ticket of its channels adds the group rows --
 // was measured at 37 us per call against 20 for the two launches: the agent-scope release fence every workgroup needs
 // before its ticket writes back an L2 full of the conv's dirty output.)
 struct FinArgs {
@@ -393,13 +410,15 @@ struct FinArgs {
     int on;
 };
 
+template <int CH>       // channels per workgroup: 512 threads = 2 halves x CH channels x (256 / CH) row slices
 __global__ void __launch_bounds__(512) sum_finalize_kernel(const double *__restrict__ partial, int chunks, int C,
                                                            double *__restrict__ out, FinArgs fin) {
-    // 512 threads: threads 0-255 add the sums, 256-511 the sums of squares of the block's 32 channels (8 row slices each)
+    // threads 0-255 add the sums, 256-511 the sums of squares of the block's CH channels (SL row slices each)
+    constexpr int SL = 256 / CH;
     __shared__ double sh[2][256];
     const int h = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int j = tid & 31, sl = tid >> 5;
-    const int c = blockIdx.x * 32 + j;
+    const int j = tid % CH, sl = tid / CH;
+    const int c = blockIdx.x * CH + j;
     const int k0 = 0, k1 = chunks;
     const long n = 2L * C;
     {
@@ -408,13 +427,13 @@ __global__ void __launch_bounds__(512) sum_finalize_kernel(const double *__restr
             const long col = (long)h * C + c;
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;        // four independent chains, combined in a fixed order
             int k = k0 + sl;
-            for (; k + 24 < k1; k += 32) {
+            for (; k + 3 * SL < k1; k += 4 * SL) {
                 a0 += partial[(long)k * n + col];
-                a1 += partial[(long)(k + 8) * n + col];
-                a2 += partial[(long)(k + 16) * n + col];
-                a3 += partial[(long)(k + 24) * n + col];
+                a1 += partial[(long)(k + SL) * n + col];
+                a2 += partial[(long)(k + 2 * SL) * n + col];
+                a3 += partial[(long)(k + 3 * SL) * n + col];
             }
-            for (; k < k1; k += 8) a0 += partial[(long)k * n + col];
+            for (; k < k1; k += SL) a0 += partial[(long)k * n + col];
             acc = (a0 + a1) + (a2 + a3);
         }
         sh[h][tid] = acc;
@@ -423,7 +442,7 @@ __global__ void __launch_bounds__(512) sum_finalize_kernel(const double *__restr
     double t = 0;                                          // threads with sl == 0: the block's sum for (half h, channel c)
     if (sl == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += sh[h][q * 32 + j];
+        for (int q = 0; q < SL; ++q) t += sh[h][q * CH + j];
     }
     __syncthreads();
     if (sl == 0) sh[h][j] = t;                             // hand both halves to the thread that finalizes the channel
@@ -966,16 +985,20 @@ int rcf_sum_partials_bn(const double *partial, int chunks, int C, double *sums, 
         fa.mean = fin->mean; fa.invstd = fin->invstd; fa.rmean = fin->running_mean; fa.rvar = fin->running_var;
         fa.nbt = fin->num_batches_tracked; fa.on = 1;
     }
-    if (scratch && chunks >= 256) {
-        // many row tiles: G groups of rows first, so that more than C/32 workgroups read
-        const int G = chunks >= 2048 ? 64 : 16, per = rcf_cdiv(chunks, G);
+    if (scratch && chunks >= 1024) {
+        // very long lists (the 3210 row tiles of layer1 at 8 pairs of 480x854): 64 groups of rows first -- the one-launch form
+        // with 4 channels per workgroup measured 21 us there against 10 + a launch boundary for the two launches
+        const int G = 64, per = rcf_cdiv(chunks, G);
         hipLaunchKernelGGL(partial_sum_groups_kernel, dim3(rcf_cdiv(2 * C, 32), G), dim3(256), 0, st, partial, chunks, per,
                            2 * C, scratch);
         RCF_LAUNCH_CHECK();
         partial = scratch;
         chunks = G;
     }
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(rcf_cdiv(C, 32)), dim3(512), 0, st, partial, chunks, C, sums, fa);
+    // many row tiles (256 .. 1023): fewer channels and more row slices per workgroup, so that a thread walks at most ~32 rows:
+    // 7.3 us in ONE launch against 5.3 + 4.8 us in two (round 6 step profile, 41 of the 54 forward reductions)
+    if (chunks >= 256) hipLaunchKernelGGL(sum_finalize_kernel<8>, dim3(rcf_cdiv(C, 8)), dim3(512), 0, st, partial, chunks, C, sums, fa);
+    else hipLaunchKernelGGL(sum_finalize_kernel<32>, dim3(rcf_cdiv(C, 32)), dim3(512), 0, st, partial, chunks, C, sums, fa);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1018,8 +1041,7 @@ extern "C" int rcf_bn_stats_mp(const void *x, int xdt, long rows, int C, int pit
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, 2 * C, sums);
+    launch_partial_sum((const double *)workspace, g.chunks, 2 * C, sums, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1042,7 +1064,7 @@ extern "C" int rcf_sum_partials_f64(const double *partial, int chunks, int n, do
         partial = scratch;
         chunks = G;
     }
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(n, 32)), dim3(256), 0, st, partial, chunks, n, out);
+    launch_partial_sum(partial, chunks, n, out, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1163,8 +1185,7 @@ extern "C" int rcf_bn_bwd_reduce_mp(const void *dy, int ydt, int dy_pitch, const
 #undef RCF_CALL
     }
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(2 * C, 32)), dim3(256), 0, st, (const double *)workspace,
-                       g.chunks, 2 * C, sums2);
+    launch_partial_sum((const double *)workspace, g.chunks, 2 * C, sums2, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1306,7 +1327,7 @@ extern "C" int rcf_bn_bwd_reduce2_mp(const void *dy, int ydt, int dy_pitch, cons
                            rows, C, g.cvB, g.RG, g.rows_per_chunk, (double *)workspace, make_sweep(2, rows, g.RG, (long)C * 4, flags));
     }
     RCF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(rcf_cdiv(4 * C, 32)), dim3(256), 0, st, (const double *)workspace, g.chunks, 4 * C, sums4);
+    launch_partial_sum((const double *)workspace, g.chunks, 4 * C, sums4, st);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -434,6 +434,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     // the same change there): the general loop tests columns / bias / activation / beta per quad and per element.
     // (a bias rides along as one uniform test per quad: the folded data gradient's second half, dx += x (-T) + c0)
     const bool lean = (p.bias == nullptr || (OBF && !want_stats)) && p.act == 0 && n0 + BN <= p.Ncol;
+    const bool nts = (p.flags & RCF_CONV_NT_STORES) != 0;      // RCF_CONV_NT_STORES: the tile's output does not stay in L2
     // What the lean epilogue READS -- the residual / mask tensor (EP 1, 2), the ballots (EP 3), the old output (beta, bf16) --
     // is asked for ahead of the stores, two column tiles (2 MR fragments) at a time: a load of the output tensor may not pass
     // an earlier store to it, so loads left beside their fragment's stores run as MR * NR dependent HBM round trips
@@ -570,7 +571,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
                             u32x2 a = pack4(q[g]), b = pack4(q[g + 1]);
                             const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                             const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-                            if (rowok[mr]) *reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                            if (rowok[mr]) {
+                                u32x4 *dst = reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh));
+                                if (nts) __builtin_nontemporal_store(u32x4{r0[0], r1[0], r0[1], r1[1]}, dst);
+                                else *dst = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                            }
                         }
                     } else {
                         float *yrow = reinterpret_cast<float *>(p.Y) + lin[mr] * p.y_pitch;

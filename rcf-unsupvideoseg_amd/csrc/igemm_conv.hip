@@ -588,6 +588,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
     // per quad and per element, which the compiler turns into ~170 instructions in four basic blocks per 16-byte
     // store; with 32 quads per thread that was three times the instructions of a 16-step K-loop (the 1x1 layers).
     const bool lean = NP == 2 && p.bias == nullptr && p.act == 0 && n0 + BN <= p.Ncol;
+    const bool nts = (p.flags & RCF_CONV_NT_STORES) != 0;      // RCF_CONV_NT_STORES: the tile's output does not stay in L2
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         float cs[16], cq[16];                             // this lane's pixels: sums / sums of squares per channel register
@@ -629,7 +630,8 @@ __device__ __forceinline__ void conv_epilogue_tr(const IgemmParams &p, f32x16 (&
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] += (m >> e) & 1u ? a[e] : 0.f;   // = the value rcf_bn_bwd_apply_mp's dres would hold
                         }
-                        dst[2 * g] = v;
+                        if (nts) __builtin_nontemporal_store(v, dst + 2 * g);
+                        else dst[2 * g] = v;
                         if constexpr (EXTRA == 1) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {

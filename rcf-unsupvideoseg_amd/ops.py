@@ -151,9 +151,13 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def _conv_shape(xshape, x_pitch, w, stride, pad, dil, y_pitch=None, amax=None, w_pairs=None, w_pairs_t=None, w_pairs2_t=None,
-                flags=0, amax_y=None):
+                flags=0, amax_y=None, nt_cols=0):
     """amax = (amax_x, amax_w, amax_dy): int32 [1] device tensors from absmax() or None -- the operand ranges that
-    select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h)"""
+    select the fp16-pair kernels (rcf_conv_shape in include/rcf_hip.h).
+    nt_cols: output columns of a forward / data-gradient launch -- from SCHED.nt_stores columns up the tile kernels write
+    their output with streaming stores (RCF_CONV_NT_STORES)"""
+    if SCHED.nt_stores and nt_cols >= SCHED.nt_stores:
+        flags = int(flags) | _lib.CONV_NT_STORES
     N, H, W, Cin = xshape
     Cout, Cin_w, R, S = w.shape
     assert Cin == Cin_w, f"channel mismatch {Cin} vs {Cin_w}"
@@ -322,7 +326,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=No
     `planes`); amax_y: new_amax() slot that receives the range of the output"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
-                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y)
+                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y, nt_cols=w.shape[0])
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
@@ -356,7 +360,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, dil=1, amax=None, w_pairs=None, bn=N
     x_planes / amax_y: as conv2d_fwd"""
     _need_cuda(x, w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, amax=None if amax is None else (amax[0], amax[1], None),
-                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y)
+                    w_pairs=w_pairs, flags=_lib.CONV_X_PLANES if x_planes else 0, amax_y=amax_y, nt_cols=w.shape[0])
     out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.float32, device=x.device)
     s.y_pitch = pitch_of(out)
     sums = torch.empty(2 * s.Cout, dtype=torch.float64, device=x.device)
@@ -396,7 +400,7 @@ def conv2d_dgrad(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, region
         w_pairs_t = None
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy),
                     amax=None if amax is None else (None, amax[1], amax[0]), w_pairs2_t=w_pairs_t,
-                    flags=_lib.CONV_DY_PLANES if dy_planes else 0, amax_y=amax_y)
+                    flags=_lib.CONV_DY_PLANES if dy_planes else 0, amax_y=amax_y, nt_cols=xshape[3])
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     fuse = (bn_bwd is not None and region is None and out.is_contiguous() and bn_bwd[0].dtype == torch.float32 and
             tuple(bn_bwd[0].shape) == tuple(out.shape) and _lib.load().rcf_conv2d_dgrad_bnsums_ok(byref(s)) == 1)
@@ -496,7 +500,7 @@ def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0,
     assert x.dtype == torch.bfloat16
     if w_bf16 is None:
         w_bf16 = weight_bf16(w)
-    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, nt_cols=w.shape[0])
     if out is None:
         out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=out_dtype, device=x.device)
     s.y_pitch = pitch_of(out)
@@ -531,7 +535,7 @@ def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, r
     assert dy.dtype == torch.bfloat16
     if out is None:
         out = torch.empty(tuple(xshape), dtype=torch.bfloat16, device=dy.device)
-    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy), w_pairs_t=w_t_bf16)
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy), w_pairs_t=w_t_bf16, nt_cols=xshape[3])
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = 0 if w_t_bf16 is not None else _lib.load().rcf_conv2d_dgrad_bf16_workspace_bytes(byref(s))
     ws = workspace(need, dy.device) if need else None
@@ -613,7 +617,7 @@ def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True,
     want_bits (with relu): also the ReLU's sign bits in tile order, (y, bits) -- for conv2d_dgrad_masked_bf16(mask_bits=)"""
     _need_cuda(x, w)
     assert x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)
-    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil)
+    s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, nt_cols=w.shape[0])
     out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.bfloat16, device=x.device)
     s.y_pitch = pitch_of(out)
     if residual is not None:
@@ -662,7 +666,7 @@ def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, str
     if mask_bits is not None:
         mask_src = None                       # the sign bits the forward tile wrote (1/16 of the bytes) instead of the tensor
         assert mask_bits.numel() == _lib.load().rcf_conv_relu_bits_bytes(xshape[0] * xshape[1] * xshape[2], xshape[3])
-    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy))
+    s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy), nt_cols=xshape[3])
     cs = ws = None
     need = 0
     if colsums:

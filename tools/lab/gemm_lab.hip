@@ -23,7 +23,9 @@ constexpr unsigned OOB = 0x80000000u;
 struct P {
     const bf16_t *A; const bf16_t *Bw; bf16_t *Y;
     int M, N, K, a_pitch, y_pitch, mtiles, ntiles, mtiles8;
-    int flags;        // 1 = no stores, 2 = every tile reads the rows of tile 0 (A hot in L2), 4 = no main loop
+    int flags;        // 1 = no stores, 2 = every tile reads the rows of tile 0 (A hot in L2), 4 = no main loop, 8 = non-temporal stores,
+                      // 16 = an XCD owns ONE column-tile group of every row tile (colmap), 32 = XCDs 0-3 / 4-7 own the two halves of the
+                      // column tiles, 64 = every tile reads the weights of column tile 0 (W hot in L2)
     int ntile_total, nwg;
 };
 
@@ -76,7 +78,10 @@ __device__ __forceinline__ void store_tile(const P &p, f32x16 (&acc)[MR][NR], in
                 u32x2 a = pack4(q0), b = pack4(q1);
                 const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-                if (ok) *reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                if (ok) {
+                    if (p.flags & 8) __builtin_nontemporal_store(u32x4{r0[0], r1[0], r0[1], r1[1]}, reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh)));
+                    else *reinterpret_cast<u32x4 *>(yrow + cb + 8 * (g + kh)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
             }
         }
     }
@@ -89,7 +94,18 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_base(P p) {
     constexpr int PA = BM * 64, PB = BN * 64, STAGE = PA + PB;
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     int tile_m, tile_n;
-    tile_of((int)blockIdx.x, p.mtiles8, p.ntiles, tile_m, tile_n);
+    if (p.flags & 16) {                         // XCD x owns the column tiles [x nt8, (x + 1) nt8) (ntiles % 8 == 0) of every row tile
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, nt8 = p.ntiles >> 3;
+        tile_m = k / nt8;
+        tile_n = x * nt8 + (k - tile_m * nt8);
+    } else if (p.flags & 32) {                  // XCDs 0-3 the first half of the column tiles, 4-7 the second; each walks a quarter of the rows
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, half = p.ntiles >> 1, mt4 = (p.mtiles + 3) >> 2;
+        tile_m = (x & 3) * mt4 + k / half;
+        tile_n = (x >> 2) * half + k % half;
+        if (k / half >= mt4) return;
+    } else {
+        tile_of((int)blockIdx.x, p.mtiles8, p.ntiles, tile_m, tile_n);
+    }
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,8 +123,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_base(P p) {
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-        const int j = n0 + arow + ROWS * i;
-        bbase[i] = j < p.N ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
+        const int j = ((p.flags & 64) ? 0 : n0) + arow + ROWS * i;
+        bbase[i] = (n0 + arow + ROWS * i) < p.N ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
     }
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -278,7 +294,18 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_rings(P p) {
     __shared__ __attribute__((aligned(16))) char smem[NSA * PA + NSB * PB];
     char *const ringA = smem, *const ringB = smem + NSA * PA;
     int tile_m, tile_n;
-    tile_of((int)blockIdx.x, p.mtiles8, p.ntiles, tile_m, tile_n);
+    if (p.flags & 16) {                         // XCD x owns the column tiles [x nt8, (x + 1) nt8) (ntiles % 8 == 0) of every row tile
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, nt8 = p.ntiles >> 3;
+        tile_m = k / nt8;
+        tile_n = x * nt8 + (k - tile_m * nt8);
+    } else if (p.flags & 32) {                  // XCDs 0-3 the first half of the column tiles, 4-7 the second; each walks a quarter of the rows
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, half = p.ntiles >> 1, mt4 = (p.mtiles + 3) >> 2;
+        tile_m = (x & 3) * mt4 + k / half;
+        tile_n = (x >> 2) * half + k % half;
+        if (k / half >= mt4) return;
+    } else {
+        tile_of((int)blockIdx.x, p.mtiles8, p.ntiles, tile_m, tile_n);
+    }
     if (tile_m >= p.mtiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -296,8 +323,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_rings(P p) {
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-        const int j = n0 + arow + ROWS * i;
-        bbase[i] = j < p.N ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
+        const int j = ((p.flags & 64) ? 0 : n0) + arow + ROWS * i;
+        bbase[i] = (n0 + arow + ROWS * i) < p.N ? (unsigned)j * 64u + (unsigned)kq * 16u : OOB;
     }
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -567,14 +594,20 @@ int main(int argc, char **argv) {
     struct V { const char *name; int kind; int flags; int nwg; };
     std::vector<V> vs = {
         {"base", 0, 0, 0}, {"base nostore", 0, 1, 0}, {"base hotA", 0, 2, 0}, {"base hotA nostore", 0, 3, 0}, {"base nomma(store only)", 0, 4, 0},
-        
+        {"base hotW", 0, 64, 0}, {"base hotA hotW", 0, 66, 0}, {"base nt-stores", 0, 8, 0}, {"base hotA nt-stores", 0, 10, 0},
+        {"colmap (XCD = col tiles)", 0, 16, 0}, {"colmap nt-stores", 0, 24, 0}, {"halves (4 XCDs per col half)", 0, 32, 0}, {"halves nt-stores", 0, 40, 0},
+
         {"teams 256wg", 5, 0, 256}, {"teams 256wg nostore", 5, 1, 256}, {"teams hotA", 5, 2, 256},
         {"persist 512wg", 1, 0, 512},
     };
     for (auto &v : vs) {
         p.flags = v.flags;
         auto launch = [&]() {
-            if (v.kind == 0) k_base<2, 4, 2, 2, 3><<<8 * p.mtiles8 * p.ntiles, 256>>>(p);
+            if (v.kind == 0 && (v.flags & 16) && p.ntiles % 8) return;
+            if (v.kind == 0 && (v.flags & 32) && p.ntiles % 2) return;
+            if (v.kind == 0 && (v.flags & 32)) k_base<2, 4, 2, 2, 3><<<8 * ((p.mtiles + 3) / 4) * (p.ntiles / 2), 256>>>(p);
+            else if (v.kind == 0 && (v.flags & 16)) k_base<2, 4, 2, 2, 3><<<p.mtiles * p.ntiles, 256>>>(p);
+            else if (v.kind == 0) k_base<2, 4, 2, 2, 3><<<8 * p.mtiles8 * p.ntiles, 256>>>(p);
             else if (v.kind == 5) k_teams<<<v.nwg, 512>>>(p);
             else if (v.kind == 2) k_rings<2, 4, 2, 2, 4, 3><<<8 * p.mtiles8 * p.ntiles, 256>>>(p);
             else if (v.kind == 3) k_rings<2, 4, 2, 2, 5, 2><<<8 * p.mtiles8 * p.ntiles, 256>>>(p);
@@ -585,7 +618,7 @@ int main(int argc, char **argv) {
         launch();
         CK(hipDeviceSynchronize());
         double maxerr = 0;
-        if (!(v.flags & 7)) {
+        if (!(v.flags & (7 | 64))) {
             for (int i = 0; i < nchk; ++i) {
                 CK(hipMemcpy(yrow.data(), Y + (long)rows[i] * N, N * 2, hipMemcpyDeviceToHost));
                 for (int c = 0; c < N; ++c) {
