@@ -265,7 +265,9 @@ int rcf_conv2d_dgrad_bf16(const void *dy, const float *w, void *dx, const rcf_co
  * are functions of two small moments of the conv's INPUT x [rows][K]: the column sums A1 [K] (rcf_colsum_mp) and the Gram
  * matrix S = x^T x [K][K] (rcf_conv2d_wgrad_bf16 with dy = x).  W [N][K] is the fp32 master weight; every routine rounds it to
  * bf16 as the conv kernels do.
- *   forward   rcf_fold_fwd_f32:       P = W S [N][K] (kept for the backward pass), sums = [sum z | sum z^2] (fp64 [2N]; SyncBN
+ *   forward   rcf_fold_fwd_f32:       P = W (S - A1 A1^T / rows_local) [N][K] + the N local means of z behind it (N K + N floats, kept
+ *                                     for the backward pass; the Gram matrix is centred in fp64 BEFORE the fp32 contraction, so the
+ *                                     variance w . P / n carries no mean^2 to cancel), sums = [sum z | sum z^2] (fp64 [2N]; SyncBN
  *                                     all-reduces them like any other statistics) and / or the finalized norm
  *             rcf_fold_finalize_f32:  mean, invstd, running statistics, num_batches_tracked as rcf_bn_finalize_f32, plus the
  *                                     folded constants scale = gamma invstd, shift = beta - mean scale (after the all-reduce)
@@ -292,10 +294,11 @@ typedef struct rcf_fold_finalize {
     long long *num_batches_tracked;      /* may be NULL */
 } rcf_fold_finalize;
 size_t rcf_fold_fwd_scratch_bytes(int N, int K);
-/* A1: fp64 [K] (the first half of rcf_bn_stats_mp's sums of x).  fin != NULL: the statistics are local, the norm is finalized by
- * the same launch (sums may be NULL); fin == NULL: sums only.  N % 64 == 0, K % 64 == 0. */
+/* A1: fp64 [K] (the first half of rcf_bn_stats_mp's sums of x); rows_local: the rows S and A1 were summed over (this rank's).
+ * P: N K + N floats.  fin != NULL: the statistics are local (fin->count == rows_local), the norm is finalized by the same launch
+ * (sums may be NULL); fin == NULL: sums only.  N % 64 == 0, K % 64 == 0. */
 int rcf_fold_fwd_f32(const float *S, const double *A1, const float *W, float *P, double *sums, const rcf_fold_finalize *fin,
-                     void *scratch, size_t scratch_bytes, int N, int K, void *stream);
+                     void *scratch, size_t scratch_bytes, double rows_local, int N, int K, void *stream);
 int rcf_fold_finalize_f32(const double *sums, int C, const rcf_fold_finalize *fin, void *stream);
 /* relu_bits (optional, with relu): receives the sign bits of y, one 64-bit wavefront ballot per (tile, wave, 32 x 32 sub-tile,
  * accumulator register) -- rcf_conv_relu_bits_bytes(rows, Cout) bytes, 1/16 of y; only a launch over the SAME [rows][Cout]
@@ -316,6 +319,7 @@ int rcf_fold_bwd_sums_f32(const float *G, const float *W, const double *colsums,
                           double *sums2, int N, int K, void *stream);
 size_t rcf_fold_bwd_scratch_bytes(int N, int K);
 int rcf_fold_wg_bf16(const float *W, const float *scale, void *wg_t_bf16, int N, int K, void *stream);
+/* P: rcf_fold_fwd_f32's (N K + N floats) */
 int rcf_fold_bwd_prepare_f32(const float *G, const float *P, const double *A1, const float *W, const double *sums2,
                              const double *sums2_local, double count, const float *mean, const float *invstd, const float *gamma,
                              float *dW, float *dgamma, float *dbeta, void *negT_bf16, float *c0, void *scratch,

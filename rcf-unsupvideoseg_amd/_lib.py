@@ -215,7 +215,7 @@ PROTOS = {
     "rcf_conv2d_wgrad_bf16_workspace_bytes": (c_size_t, [_CS, _CR]),
     "rcf_conv2d_wgrad_bf16": (c_int, [P, P, P, _CS, _CR, c_int, P, c_size_t, P]),
     "rcf_fold_fwd_scratch_bytes": (c_size_t, [c_int, c_int]),
-    "rcf_fold_fwd_f32": (c_int, [P, P, P, P, P, ctypes.POINTER(FoldFinalize), P, c_size_t, c_int, c_int, P]),
+    "rcf_fold_fwd_f32": (c_int, [P, P, P, P, P, ctypes.POINTER(FoldFinalize), P, c_size_t, c_double, c_int, c_int, P]),
     "rcf_fold_finalize_f32": (c_int, [P, c_int, ctypes.POINTER(FoldFinalize), P]),
     "rcf_conv_relu_bits_bytes": (c_size_t, [c_long, c_int]),
     "rcf_conv2d_fwd_affine_bf16": (c_int, [P, P, P, P, P, c_int, c_int, P, P, _CS, P]),

@@ -25,9 +25,13 @@ __device__ __forceinline__ float wr(float w) { return (float)(bf16_t)w; }
 // C_z[M][N] = sum over the inner range of split z of A(m, i) B(i, n): the small fp32 products of the fold (P = W S; T = W^T Wd).
 // A(m, i) = A[m sam + i sai] (one of the strides is 1), rounded to bf16 when ROUND_A (A is the master weight); B(i, n) = B[i sbi + n]
 // 64 x 64 tile per workgroup, 4 x 4 outputs per thread, inner steps of 16 through LDS.  M, N % 64 == 0, inner per split % 16 == 0.
-template <bool ROUND_A>
+// CENTER_B: B(i, n) = B[i sbi + n] - cvec[i] cvec[n] cinv, formed in fp64 as the tile is loaded -- P = W (S - A1 A1^T / n): the
+// Gram matrix is centred BEFORE the fp32 contraction (the variance as w^T S w / n - mean^2 loses
+// mean^2 / var of its digits in the K-long fp32 chain; after centring the chain's rounding is relative to the variance itself)
+template <bool ROUND_A, bool CENTER_B = false>
 __global__ void __launch_bounds__(256) small_gemm_kernel(const float *__restrict__ A, long sam, long sai, const float *__restrict__ B,
-                                                         long sbi, float *__restrict__ C, int M, int N, int inner_per_split) {
+                                                         long sbi, float *__restrict__ C, int M, int N, int inner_per_split,
+                                                         const double *__restrict__ cvec = nullptr, double cinv = 0.0) {
     __shared__ __attribute__((aligned(16))) float As[16][68], Bs[16][68];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -51,7 +55,13 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float *__restrict
         }
         {
             const int i = tid >> 4, nq = (tid & 15) * 4;
-            *reinterpret_cast<f32x4 *>(&Bs[i][nq]) = *reinterpret_cast<const f32x4 *>(B + (long)(ib + i) * sbi + n0 + nq);
+            f32x4 bv = *reinterpret_cast<const f32x4 *>(B + (long)(ib + i) * sbi + n0 + nq);
+            if constexpr (CENTER_B) {
+                const double ci = cvec[ib + i] * cinv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (float)((double)bv[e] - ci * cvec[n0 + nq + e]);
+            }
+            *reinterpret_cast<f32x4 *>(&Bs[i][nq]) = bv;
         }
         __syncthreads();
 #pragma unroll
@@ -79,8 +89,11 @@ inline int gemm_splits(int M, int N, int inner) {
     return z;
 }
 
-// P = sum of its Z partial products (written back as the final P[N][K]); sums[c] = A1 . W[c], sums[N + c] = W[c] . P[c] (fp64);
-// with `fin` the channel is finalized right here (local statistics).  One wavefront per channel.
+// P = sum of its Z partial products, the CENTRED P_c = W (S - A1 A1^T / n_local) (written back as the final P[N][K], followed by the
+// N local means of z, mloc = A1 . W[c] / n_local: what the backward pass needs to re-centre P on the global mean);
+// sums[c] = A1 . W[c], sums[N + c] = the UNcentred sum of z^2 = W[c] . P_c[c] + (A1 . W[c])^2 / n_local, put together in fp64 (what
+// SyncBN all-reduces); with `fin` the channel is finalized right here (local statistics: var = W[c] . P_c[c] / n, no subtraction).
+// One wavefront per channel.
 struct FoldFin {
     double count;
     float eps, momentum;
@@ -89,9 +102,10 @@ struct FoldFin {
     long long *nbt;
     int on;
 };
-__device__ __forceinline__ void fold_finalize_channel(const FoldFin &f, int c, double sz, double szz) {
+// centred: `szz` is sum (z - mean)^2 already (the local path); otherwise the plain sum of squares (after an all-reduce)
+__device__ __forceinline__ void fold_finalize_channel(const FoldFin &f, int c, double sz, double szz, bool centred = false) {
     const double m = sz / f.count;
-    double var = szz / f.count - m * m;
+    double var = centred ? szz / f.count : szz / f.count - m * m;
     if (var < 0) var = 0;
     const float mf = (float)m, is = (float)(1.0 / sqrt(var + (double)f.eps));
     f.mean[c] = mf;
@@ -107,7 +121,7 @@ __device__ __forceinline__ void fold_finalize_channel(const FoldFin &f, int c, d
 }
 __global__ void __launch_bounds__(256) fold_stats_kernel(const float *__restrict__ Ppart, int Z, const double *__restrict__ A1,
                                                          const float *__restrict__ W, float *__restrict__ P,
-                                                         double *__restrict__ sums, int N, int K, FoldFin fin) {
+                                                         double *__restrict__ sums, int N, int K, FoldFin fin, double rows_local) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c == 0 && lane == 0 && fin.on && fin.nbt) *fin.nbt += 1;
     if (c >= N) return;
@@ -123,8 +137,9 @@ __global__ void __launch_bounds__(256) fold_stats_kernel(const float *__restrict
     sz = wave_sum_d(sz);
     szz = wave_sum_d(szz);
     if (lane == 0) {
-        if (sums) { sums[c] = sz; sums[N + c] = szz; }
-        if (fin.on) fold_finalize_channel(fin, c, sz, szz);
+        P[(long)N * K + c] = (float)(sz / rows_local);                 // mloc: with local statistics exactly the mean below
+        if (sums) { sums[c] = sz; sums[N + c] = szz + sz * sz / rows_local; }
+        if (fin.on) fold_finalize_channel(fin, c, sz, szz, true);
     }
 }
 
@@ -203,7 +218,8 @@ __global__ void __launch_bounds__(256) fold_wg_kernel(const float *__restrict__ 
     wg_t[((long)(c >> 5) * K + k) * 32 + (c & 31)] = (bf16_t)(scale[c] * wr(W[i]));
 }
 
-// per (c, k): dW += a (G - m A1 - q invstd (P - mean A1));  Wd = a invstd q W (fp32, for T);  c0 partial sums over this
+// per (c, k): dW += a (G - m A1 - q invstd (P - mean A1)), with P - mean A1 = P_c - (mean - mloc) A1 from the centred P_c and the local
+// means rcf_fold_fwd_f32 left behind it (mean == mloc bit for bit with local statistics);  Wd = a invstd q W (fp32, for T);  c0 partial sums over this
 // workgroup's PREP_CH channels: c0p[chunk][k] = sum_c e_c W[c][k], e = a mean invstd q - a m;  per c: dgamma += sum g zhat, dbeta += sum g.
 // Thread = k (coalesced rows), a workgroup = PREP_CH channels x 256 k.
 constexpr int PREP_CH = 8;
@@ -218,6 +234,7 @@ __global__ void __launch_bounds__(256) fold_bwd_prep_kernel(const float *__restr
     const int k = blockIdx.x * 256 + threadIdx.x, cbase = blockIdx.y * PREP_CH;
     const bool live = k < K;
     const float a1 = live ? (float)A1[k] : 0.f;
+    const float *mloc = P + (long)N * K;
     const double inv_count = 1.0 / count;
     float part = 0.f;
 #pragma unroll
@@ -230,7 +247,7 @@ __global__ void __launch_bounds__(256) fold_bwd_prep_kernel(const float *__restr
         if (live) {
             const long i = (long)c * K + k;
             const float w = wr(W[i]);
-            if (dW) dW[i] += a * (G[i] - m * a1 - q * is * (P[i] - mu * a1));
+            if (dW) dW[i] += a * (G[i] - m * a1 - q * is * (P[i] - (mu - mloc[c]) * a1));
             Wd[i] = d * w;
             part = fmaf(e, w, part);
         }
@@ -285,15 +302,17 @@ extern "C" size_t rcf_fold_fwd_scratch_bytes(int N, int K) {
 /* fin == NULL: sums only (SyncBN: all-reduce them, then rcf_fold_finalize_f32); fin != NULL: local statistics, finalized in
  * the same launch (sums may be NULL) */
 extern "C" int rcf_fold_fwd_f32(const float *S, const double *A1, const float *W, float *P, double *sums,
-                                const rcf_fold_finalize *fin, void *scratch, size_t scratch_bytes, int N, int K, void *stream) {
-    if (!S || !A1 || !W || !P || (!sums && !fin) || N <= 0 || K <= 0 || N % 64 || K % 64) return RCF_EINVAL;
+                                const rcf_fold_finalize *fin, void *scratch, size_t scratch_bytes, double rows_local, int N, int K,
+                                void *stream) {
+    if (!S || !A1 || !W || !P || (!sums && !fin) || N <= 0 || K <= 0 || N % 64 || K % 64 || !(rows_local > 0)) return RCF_EINVAL;
+    if (fin && fin->count != rows_local) return RCF_EINVAL;          // finalizing here means the statistics ARE the local ones
     if (!scratch || scratch_bytes < rcf_fold_fwd_scratch_bytes(N, K)) return RCF_EWORKSPACE;
     if (fin && (!fin->gamma || !fin->beta || !fin->mean || !fin->invstd || !fin->scale || !fin->shift || !(fin->count > 0)))
         return RCF_EINVAL;
     hipStream_t st = rcf_stream(stream);
     const int Z = gemm_splits(N, K, K);
-    hipLaunchKernelGGL(small_gemm_kernel<true>, dim3(K / 64, N / 64, Z), dim3(256), 0, st, W, (long)K, 1L, S, (long)K,
-                       (float *)scratch, N, K, K / Z);
+    hipLaunchKernelGGL((small_gemm_kernel<true, true>), dim3(K / 64, N / 64, Z), dim3(256), 0, st, W, (long)K, 1L, S, (long)K,
+                       (float *)scratch, N, K, K / Z, A1, 1.0 / rows_local);
     RCF_LAUNCH_CHECK();
     FoldFin f{};
     if (fin) {
@@ -301,7 +320,8 @@ extern "C" int rcf_fold_fwd_f32(const float *S, const double *A1, const float *W
         f.mean = fin->mean; f.invstd = fin->invstd; f.scale = fin->scale; f.shift = fin->shift;
         f.rmean = fin->running_mean; f.rvar = fin->running_var; f.nbt = fin->num_batches_tracked; f.on = 1;
     }
-    hipLaunchKernelGGL(fold_stats_kernel, dim3(rcf_cdiv(N, 4)), dim3(256), 0, st, (const float *)scratch, Z, A1, W, P, sums, N, K, f);
+    hipLaunchKernelGGL(fold_stats_kernel, dim3(rcf_cdiv(N, 4)), dim3(256), 0, st, (const float *)scratch, Z, A1, W, P, sums, N, K, f,
+                       rows_local);
     RCF_LAUNCH_CHECK();
     return 0;
 }

@@ -767,7 +767,7 @@ def conv_bn_fold(conv, bn, x, tape, relu, residual=None, dist=None):
     A1 = ops.bn_stats(xt)                                   # fp64 [2K]: the column sums (and sums of squares, unused) of x
     count = rows
     if dist is not None and dist.on:                        # SyncBN: the statistics of the global batch
-        P, sums = ops.fold_fwd(S, A1, w)
+        P, sums = ops.fold_fwd(S, A1, w, rows=rows)
         dist.allreduce_sum(sums)
         count = rows * dist.world
         mean, invstd, scale, shift = ops.fold_finalize(sums, count, bn)

@@ -588,20 +588,22 @@ def _fold_fin(bn, count, device):
     return fin, (mean, invstd, scale, shift)
 
 
-def fold_fwd(S, A1, w, bn=None, count=None):
-    """P = W S [N,K] fp32 and the statistics of z = conv1x1(x, w) from the moments of x (A1: fp64 [K] column sums, S: Gram
-    matrix).  bn given (local statistics): returns (P, (mean, invstd, scale, shift)), the norm finalized in the same launch;
-    otherwise (P, sums fp64 [2N] = sum z | sum z^2) for fold_finalize after the all-reduce."""
+def fold_fwd(S, A1, w, bn=None, count=None, rows=None):
+    """The statistics of z = conv1x1(x, w) from the moments of x (A1: fp64 [K] column sums, S: Gram matrix, both over `rows` rows of
+    this rank) and P: flat fp32 [N K + N] = the centred product W (S - A1 A1^T / rows) followed by the local means of z, kept for
+    fold_bwd_prepare.  bn given (local statistics, count == rows): returns (P, (mean, invstd, scale, shift)), the norm finalized in
+    the same launch; otherwise (P, sums fp64 [2N] = sum z | sum z^2) for fold_finalize after the all-reduce."""
     N, K = w.shape[0], w.shape[1]
-    P = torch.empty((N, K, 1, 1), dtype=torch.float32, device=w.device)
+    rows = float(count if rows is None else rows)
+    P = torch.empty(N * K + N, dtype=torch.float32, device=w.device)
     need = _lib.load().rcf_fold_fwd_scratch_bytes(N, K)
     ws = workspace(need, w.device)
     if bn is not None:
         fin, outs = _fold_fin(bn, count, w.device)
-        call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), None, byref(fin), _p(ws), need, N, K, _stream())
+        call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), None, byref(fin), _p(ws), need, rows, N, K, _stream())
         return P, outs
     sums = torch.empty(2 * N, dtype=torch.float64, device=w.device)
-    call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), _p(sums), None, _p(ws), need, N, K, _stream())
+    call("rcf_fold_fwd_f32", _p(S), _p(A1), _p(weight_rsck(w)), _p(P), _p(sums), None, _p(ws), need, rows, N, K, _stream())
     return P, sums
 
 

@@ -17,6 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W, B = 64, 96, 2
 
 
+@pytest.fixture(autouse=True)
+def _restore_schedule():
+    """_setup / _stage_build set config.SCHED.fold_bn for their process -- the workers', and THIS one's for the reference run"""
+    sys.path.insert(0, ROOT)
+    import rcf_amd                                    # noqa
+    from rcf_amd import config
+    old = config.SCHED.fold_bn
+    yield
+    config.SCHED.set(fold_bn=old)
+
+
 def _setup(mode="fp32", pairs=None):
     """mode: fp32 / bf16 (the stage-1 step in either precision) / stage21 (EMA teacher + CRF self-labels); a `_drop` suffix:
     the configuration bench.py runs -- Dropout2d 0.1 in both FCN heads -- with ONE draw for the global batch, of which this
@@ -24,7 +35,8 @@ def _setup(mode="fp32", pairs=None):
     sys.path.insert(0, ROOT)
     import rcf_amd
     from rcf_amd import config, synth
-    drop = 0.1 if mode.endswith("_drop") else 0.0
+    drop = 0.1 if "_drop" in mode else 0.0
+    config.SCHED.set(fold_bn="_nofold" not in mode)      # "_nofold": the bf16 step with three passes per norm (this process only)
     if mode == "stage21":
         kw = config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.0, norm="SyncBN")
         args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_dist", object_channel=1)
@@ -108,15 +120,21 @@ def test_two_rank_step_equals_global_batch_step(mode, report):
     assert e_loss < 1e-5 and worst < 1e-4 and e_rv < 1e-6      # measured 5e-8 / 1.6e-6 / 0
 
 
-@pytest.mark.parametrize("mode", ["bf16", "stage21", "bf16_drop"])
+@pytest.mark.parametrize("mode", ["bf16", "stage21", "bf16_drop", "bf16_nofold", "bf16_drop_nofold"])
 def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     """the N > 1 path of the other two step flavours on ONE device (gloo): the mixed-precision step (BASELINE configs[2]) and the
     stage-2.1 step (EMA teacher with its own SyncBN exchanges + CRF) over two ranks against the single-process step on the global
     batch; and the number of SyncBN collectives a rank issues: one per norm and direction, minus one for each bottleneck whose
-    conv1 and downsample statistics travel together"""
+    conv1 and downsample statistics travel together.
+    bf16: with three passes per norm ("_nofold") the two evaluations share every rounding (the statistics are fp64 sums of identical
+    per-tile partials: the same fp32 constants on both sides) and the gradient norm agrees to 1e-3; with the FOLD (default) the
+    statistics come from per-rank Gram moments and differ in the last fp32 bits, bf16 roundings flip, and at 64x96 a ResNet-50's
+    gradients are chaotic in them (two valid bf16 evaluations of ONE stage already differ by 6-12 % in dx, each equally far from
+    float64: test_two_rank_bottleneck_stage_equals_global_batch, which is where the fold's SyncBN branch is held to the truth) --
+    the norm is then only sanity-bounded (30 %, the bound of test_bf16_step_runs_and_tracks_fp32)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 1000 + {"bf16": 7, "stage21": 13, "bf16_drop": 17}[mode]
+    port = 29900 + os.getpid() % 1000 + {"bf16": 7, "stage21": 13, "bf16_drop": 17, "bf16_nofold": 23, "bf16_drop_nofold": 29}[mode]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -139,7 +157,8 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     report(f"2-rank {mode} step vs single process: losses {e}; gradient norm {e_gn:.1e}; SyncBN collectives per rank {count} for {n_st} "
            f"student + {n_te} teacher norms (one per norm and direction would be {2 * n_st + n_te})")
     tol = 2e-2 if mode.startswith("bf16") else 2e-4         # bf16: the two ranks round their halves of the batch independently
-    assert max(e.values()) < tol and e_gn < (5e-2 if mode.startswith("bf16") else 2e-3)
+    lim_gn = 2e-3 if not mode.startswith("bf16") else (2e-2 if "_nofold" in mode else 0.3)
+    assert max(e.values()) < tol and e_gn < lim_gn, (e, e_gn, lim_gn)
     assert res[0][2] == res[1][2] and count == want
 
 
@@ -306,3 +325,115 @@ def test_bench_self_launches_its_ranks(report):
     assert d["bf16_frames_per_s"] > 0 and len(lines[0]) <= 2048 and "frac" in d["roofline"]
     detail = [l for l in r.stdout.splitlines() if l.startswith("BENCH_DETAIL ")]
     assert len(detail) == 1 and json.loads(detail[0][len("BENCH_DETAIL "):])["bf16_step"]["frames_per_s"] == d["bf16_frames_per_s"]
+
+
+def _stage_build(fold):
+    """a ResNet stage (a first block with its 1x1 downsample + two identity blocks, SyncBN) with seeded bf16-representable weights,
+    its input and output gradient (global batch of 2)"""
+    sys.path.insert(0, ROOT)
+    import rcf_amd                                    # noqa
+    from rcf_amd import backbone, config, layers
+    config.SCHED.set(fold_bn=fold)
+    N, inplanes, planes, stride, dil, Hs, Ws, nblocks = 2, 256, 128, 1, 2, 16, 21, 3
+    torch.manual_seed(1234)
+    cfg = dict(type="SyncBN", requires_grad=True)
+    down = backbone.Downsample(layers.Conv2d(inplanes, planes * 4, 1, stride=stride), backbone.make_norm(cfg, planes * 4))
+    blocks = [backbone.Bottleneck(inplanes, planes, stride, dil, down, cfg)]
+    blocks += [backbone.Bottleneck(planes * 4, planes, 1, dil, None, cfg) for _ in range(nblocks - 1)]
+    stage = backbone.Stage(blocks)
+    bf = lambda t: t.to(torch.bfloat16).to(t.dtype)
+    with torch.no_grad():
+        for n_, p_ in stage.named_parameters():
+            if p_.dim() == 4:
+                p_.copy_(bf(p_))
+            elif n_.endswith("weight"):
+                p_.copy_(torch.rand_like(p_) * 0.5 + 0.5)
+            else:
+                p_.copy_(torch.randn_like(p_) * 0.2)
+    x = bf(torch.relu(torch.randn(N, Hs, Ws, inplanes)))
+    x[1] += 0.25                                          # the two samples' statistics differ: local != global
+    dy = bf(torch.randn(N, Hs, Ws, planes * 4))
+    return stage.to("cuda:0").train(), bf(x), dy
+
+
+def _stage_run(stage, x, dy, dist_ctx):
+    from rcf_amd import layers, ops
+    ops.weights_changed()
+    tape = layers.Tape(act_dtype=torch.bfloat16)
+    xa = layers.Act(x.to(torch.bfloat16).to("cuda:0").contiguous())
+    ya = stage.fwd(xa, tape, dist_ctx)
+    ya.grad = dy.to(torch.bfloat16).to("cuda:0").contiguous()
+    tape.backward()
+    torch.cuda.synchronize()
+    return ya.t.float().cpu().numpy(), xa.grad.float().cpu().numpy(), {n: p.grad.detach().float().cpu().numpy() for n, p in stage.named_parameters()}
+
+
+def _stage_worker(rank, world, port, q, fold):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stage, x, dy = _stage_build(fold)
+    from rcf_amd.layers import DistCtx
+    ctx = DistCtx()
+    assert ctx.on
+    y, dx, grads = _stage_run(stage, x[rank:rank + 1], dy[rank:rank + 1], ctx)
+    for g in grads.values():                              # parameter gradients: what the trainer's gradient all-reduce does
+        t = torch.from_numpy(g)
+        dist.all_reduce(t)
+        g[...] = t.numpy()
+    q.put((rank, y, dx, grads, ctx.count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_two_rank_bottleneck_stage_equals_global_batch(fold, report):
+    """a ResNet stage under SyncBN on two ranks (one sample each) against the same stage on the global batch in one process, in
+    the bf16 step's two forms: three passes per norm, and the FOLD (layers.conv_bn_fold, whose SyncBN branch -- per-rank Gram
+    moments, all-reduced [sum z | sum z^2] and [sum g | sum g zhat], P re-centred on the global mean in the backward pass --
+    had no test of its own: ADVICE round 5).  The yardstick is float64 autograd on the global batch: outputs, input gradients and
+    summed parameter gradients of the two-rank evaluation must be as close to it as the one-process evaluation is (the two differ
+    from EACH OTHER by their bf16 rounding flips, which a stage amplifies to 6-12 % in dx: reported, not bounded)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31100 + os.getpid() % 800 + (1 if fold else 0)
+    procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, q, fold)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    stage, x, dy = _stage_build(fold)
+    y, dx, grads = _stage_run(stage, x, dy, None)
+    # float64 truth on the global batch (tests/test_fold_gpu.py's restatement of models/resnet.py:262-302)
+    import torch.nn.functional as F
+    params = {p_: p_.detach().double().cpu().requires_grad_(True) for p_ in stage.parameters()}
+    xr = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+
+    def cbn(conv, norm, t, relu):
+        z = F.conv2d(t, params[conv.weight], None, conv.stride, conv.padding, conv.dilation)
+        z = F.batch_norm(z, None, None, params[norm.weight], params[norm.bias], True, 0.1, norm.eps)
+        return z.clamp_min(0) if relu else z
+    t = xr
+    for b in stage.children():
+        o = cbn(b.conv3, b.bn3, cbn(b.conv2, b.bn2, cbn(b.conv1, b.bn1, t, True), True), False)
+        idt = t if b.downsample is None else cbn(getattr(b.downsample, "0"), getattr(b.downsample, "1"), t, False)
+        t = (o + idt).clamp_min(0)
+    t.backward(dy.double().permute(0, 3, 1, 2))
+    y64, dx64 = t.detach().permute(0, 2, 3, 1).numpy(), xr.grad.permute(0, 2, 3, 1).numpy()
+    g64 = {n: params[p_].grad.numpy() for n, p_ in stage.named_parameters()}
+    nrm = lambda a, b: float(np.linalg.norm(a.astype(np.float64).ravel() - b.ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+    y2, dx2 = np.concatenate([res[0][1], res[1][1]]), np.concatenate([res[0][2], res[1][2]])
+    one = dict(y=nrm(y, y64), dx=nrm(dx, dx64), **{n: nrm(grads[n], g64[n]) for n in g64})
+    two = dict(y=nrm(y2, y64), dx=nrm(dx2, dx64), **{n: nrm(res[0][3][n], g64[n]) for n in g64})
+    apart = dict(y=nrm(y2, y.astype(np.float64)), dx=nrm(dx2, dx.astype(np.float64)))
+    wp = lambda d: max(((k, v) for k, v in d.items() if k not in ("y", "dx")), key=lambda kv: kv[1])
+    report(f"2-rank bottleneck stage ({'fold' if fold else 'three passes'}) and the same stage on the global batch in one process, each against "
+           f"float64 (norm-relative): y {two['y']:.2e} / {one['y']:.2e}, dx {two['dx']:.2e} / {one['dx']:.2e}, worst parameter gradient "
+           f"{wp(two)[0]} {wp(two)[1]:.2e} / {wp(one)[0]} {wp(one)[1]:.2e}; the two evaluations from each other: y {apart['y']:.2e} dx {apart['dx']:.2e}; "
+           f"{res[0][4]} SyncBN exchanges per rank")
+    # two valid bf16 evaluations of a stage differ by their rounding flips (6-12 % in dx here); what must hold is that the two-rank one
+    # is as close to the truth as the one-process one
+    assert two["y"] < 1.25 * one["y"] + 1e-3 and two["dx"] < 1.25 * one["dx"] + 5e-3, (two["y"], one["y"], two["dx"], one["dx"])
+    for n in g64:
+        assert two[n] < 1.5 * one[n] + 1e-2, (n, two[n], one[n])

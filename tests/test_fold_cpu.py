@@ -50,3 +50,20 @@ def test_fold_algebra_equals_autograd(n, K, N, relu, res):
         assert torch.allclose(dW, W.grad, atol=1e-9) and torch.allclose(dX, X.grad, atol=1e-9)
         if res:
             assert torch.allclose(g, R.grad, atol=1e-12)
+        # the CENTRED form the kernels use since round 6 (rcf_fold_fwd_f32): P_c = W (S - A1 A1^T / n) -- the variance without a
+        # subtraction, P - mean A1 without one either; and its two-rank recombination (SyncBN): each rank centres on ITS means, the
+        # all-reduced sums are the uncentred ones put back together, the backward pass re-centres P_c on the global mean
+        Pc = W @ (S - torch.outer(A1, A1) / n)
+        assert torch.allclose((W * Pc).sum(1) / n, var, atol=1e-12) and torch.allclose(Pc, P - mu2[:, None] * A1[None], atol=1e-9)
+        h = n // 2
+        parts = []
+        for Xr in (X[:h], X[h:]):
+            Sr, Ar, nr = Xr.t() @ Xr, Xr.sum(0), Xr.shape[0]
+            Pcr = W @ (Sr - torch.outer(Ar, Ar) / nr)
+            szr = W @ Ar
+            parts.append((Pcr, Ar, szr / nr, szr, (W * Pcr).sum(1) + szr ** 2 / nr))
+        sz_all, szz_all = parts[0][3] + parts[1][3], parts[0][4] + parts[1][4]
+        assert torch.allclose(sz_all / n, mu, atol=1e-12) and torch.allclose(szz_all / n - (sz_all / n) ** 2, var, atol=1e-11)
+        dW2 = sum(a[:, None] * ((gr.t() @ Xr) - m[:, None] * Ar[None] - (q * inv2)[:, None] * (Pcr - (mu2 - mloc)[:, None] * Ar[None]))
+                  for (Pcr, Ar, mloc, _, _), gr, Xr in zip(parts, (g[:h], g[h:]), (X[:h], X[h:])))
+        assert torch.allclose(dW2, W.grad, atol=1e-9)

@@ -116,7 +116,7 @@ def test_fold_small_kernels_vs_float64(case, report):
     wd = Wm.view(C, K, 1, 1).to(DEV).contiguous(memory_format=torch.channels_last)
     S = ops.gram_bf16(xa)
     A1 = ops.bn_stats(xa)
-    P, sums = ops.fold_fwd(S, A1, wd)
+    P, sums = ops.fold_fwd(S, A1, wd, rows=n)
     bn = layers.BatchNorm2d(C).to(DEV)
     bn.weight.data.copy_(gam)
     bn.bias.data.copy_(bet)
@@ -128,7 +128,9 @@ def test_fold_small_kernels_vs_float64(case, report):
     P2, outs2 = ops.fold_fwd(S, A1, wd, bn2, n)
     assert torch.equal(P2, P) and all(torch.equal(a_, b_) for a_, b_ in zip(outs2, (mean, invstd, scale, shift)))
     assert torch.equal(bn2.running_mean, bn.running_mean) and torch.equal(bn2.running_var, bn.running_var) and int(bn2.num_batches_tracked) == 1
-    e_S, e_P = relerr(S.view(K, K), S64), relerr(P.view(C, K), P64)
+    # P is the CENTRED product W (S - A1 A1^T / n) (round 6), followed by the local means of z
+    e_S, e_P = relerr(S.view(K, K), S64), relerr(P[:C * K].view(C, K), P64 - mu[:, None] * A64[None])
+    assert relerr(P[C * K:], mu) < 1e-6
     e_sums = relerr(sums, torch.cat([sz, szz]))
     e_mu, e_inv = relerr(mean, mu), relerr(invstd, inv)
     e_aff = max(relerr(scale, gam.double() * inv), relerr(shift, bet.double() - mu * gam.double() * inv))
@@ -170,6 +172,109 @@ def test_fold_small_kernels_vs_float64(case, report):
     assert max(e_S, e_P, e_sums, e_mu, e_inv, e_aff, e_run) < 2e-5
     assert max(e_s2, e_dW, e_dg, e_db, e_c0) < 2e-4
     assert e_wg < 5e-3 and e_T < 5e-3
+
+
+def test_fold_small_kernels_two_rank_recombination(report):
+    """the SyncBN form of the fold without a process group: the rows split in two "ranks", each runs rcf_fold_fwd_f32 on ITS
+    moments (sums only), the sums are added as the all-reduce would, rcf_fold_finalize_f32 finalizes on the global count, and each
+    rank's rcf_fold_bwd_prepare_f32 re-centres its P on the GLOBAL mean: statistics and the summed dW / dgamma / dbeta against the
+    float64 algebra over all rows (this branch had no test of its own)."""
+    n, K, C = 3001, 128, 256
+    g = torch.Generator().manual_seed(12)
+    X = q(torch.relu(torch.randn(n, K, generator=g) + 0.8))
+    X[n // 2:] += 0.5                                          # the two halves have different means: mloc != the global mean
+    X = q(X)
+    Wm = torch.randn(C, K, generator=g) * (2.0 / K) ** 0.5
+    Wq, Xd = q(Wm).double(), X.double()
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    Z = Xd @ Wq.t()
+    mu, var = Z.mean(0), Z.var(0, unbiased=False)
+    inv = (var + 1e-5).rsqrt()
+    gq = q(torch.randn(n, C, generator=g) * (torch.rand(n, C, generator=g) > 0.5))
+    gd = gq.double()
+    sg, G64, A64 = gd.sum(0), gd.t() @ Xd, Xd.sum(0)
+    sgz = inv * ((Wq * G64).sum(1) - mu * sg)
+    a, m, qq = gam.double() * inv, sg / n, sgz / n
+    dW64 = a[:, None] * (G64 - m[:, None] * A64[None] - (qq * inv)[:, None] * ((Wq @ (Xd.t() @ Xd)) - mu[:, None] * A64[None]))
+    wd = Wm.view(C, K, 1, 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    bn = layers.BatchNorm2d(C).to(DEV)
+    bn.weight.data.copy_(gam)
+    bn.bias.data.copy_(bet)
+    halves = [(0, n // 2), (n // 2, n)]
+    ranks, sums = [], None
+    for lo, hi in halves:
+        xa = X[lo:hi].to(BF).to(DEV).view(1, 1, hi - lo, K).contiguous()
+        S, A1 = ops.gram_bf16(xa), ops.bn_stats(xa)
+        P, s_r = ops.fold_fwd(S, A1, wd, rows=hi - lo)
+        sums = s_r.clone() if sums is None else sums + s_r
+        ranks.append((xa, A1, P))
+    mean, invstd, scale, shift = ops.fold_finalize(sums, n, bn)
+    e_mu, e_inv = relerr(mean, mu), relerr(invstd, inv)
+    s2, parts = None, []
+    for (lo, hi), (xa, A1, P) in zip(halves, ranks):
+        ga = gq[lo:hi].to(BF).to(DEV).view(1, 1, hi - lo, C).contiguous()
+        G = torch.empty((C, K, 1, 1), dtype=torch.float32, device=DEV)
+        ops.conv2d_wgrad_bf16(xa, ga, wd, G, 1, 0, 1, beta=0)
+        cs = torch.cat([gd[lo:hi].sum(0), torch.zeros(C, dtype=torch.float64)]).to(DEV)
+        s2_r = ops.fold_bwd_sums(G, wd, cs, mean, invstd)
+        s2 = s2_r.clone() if s2 is None else s2 + s2_r
+        parts.append((G, s2_r))
+    dW = torch.zeros_like(wd)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    for (xa, A1, P), (G, s2_r) in zip(ranks, parts):
+        ops.fold_bwd_prepare(G, P, A1, wd, s2, s2_r, n, mean, invstd, bn.weight, dW, dgam, dbet)
+    e_dW, e_dg, e_db = relerr(dW.view(C, K), dW64), relerr(dgam, sgz), relerr(dbet, sg)
+    report(f"fold kernels over two 'ranks' ({n // 2} + {n - n // 2} rows, means apart): mean {e_mu:.1e} invstd {e_inv:.1e} | summed dW {e_dW:.1e} "
+           f"dgamma {e_dg:.1e} dbeta {e_db:.1e}")
+    assert max(e_mu, e_inv) < 2e-5 and max(e_dW, e_dg, e_db) < 2e-4
+
+
+def test_fold_statistics_of_badly_conditioned_channels(report):
+    """the folded norm took its variance as w^T S w / n - mean^2 with S and P = W S accumulated in fp32 -- for a
+    channel whose |mean| dwarfs its standard deviation the subtraction cancels what fp32 kept.  Since round 6 the Gram matrix is
+    centred in fp64 before the contraction (P = W (S - A1 A1^T / n)), so var = w . P / n has nothing to cancel.  Channels built to
+    hurt: an average of all inputs (mean^2 / var ~ K x 9), the same with a large offset input, a nearly dead channel (var ~ eps),
+    gamma = 0 and 1e-8; against float64, and against the UNFOLDED path (conv -> bn_stats -> finalize on the bf16 z)."""
+    n, K, C = 6000, 256, 64
+    g = torch.Generator().manual_seed(91)
+    X = q(torch.relu(torch.randn(n, K, generator=g) + 3.0))                  # mean 3, std 1: every input well away from zero
+    Wm = torch.randn(C, K, generator=g) * (2.0 / K) ** 0.5
+    Wm[0] = 1.0 / K                                                           # z_0 = the average of 256 inputs: mean 3, std 1/16
+    Wm[1] = 1.0 / K + torch.randn(K, generator=g) * 1e-3
+    Wm[2] = torch.randn(K, generator=g) * 1e-4                                # nearly dead: var ~ 1e-6, below eps = 1e-5
+    Wm[3] = 4.0 / K                                                           # mean 12, std 1/4
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gam[4], gam[5] = 0.0, 1e-8
+    Wq, Xd = q(Wm).double(), X.double()
+    Z = Xd @ Wq.t()
+    mu, var = Z.mean(0), Z.var(0, unbiased=False)
+    inv = (var + 1e-5).rsqrt()
+    xa = X.to(BF).to(DEV).view(1, 1, n, K)
+    wd = Wm.view(C, K, 1, 1).to(DEV).contiguous(memory_format=torch.channels_last)
+    bn = layers.BatchNorm2d(C).to(DEV)
+    bn.weight.data.copy_(gam)
+    bn.bias.data.copy_(bet)
+    S, A1 = ops.gram_bf16(xa), ops.bn_stats(xa)
+    P, (mean, invstd, scale, shift) = ops.fold_fwd(S, A1, wd, bn, n)
+    # the same statistics from the uncentred fp32 moments, as the kernels computed them until round 5 (restated in torch fp32)
+    S32, A32, W32 = S.view(K, K).float().cpu(), A1[:K].float().cpu(), q(Wm)
+    P32 = W32 @ S32
+    var_old = ((W32 * P32).sum(1).double() / n - ((W32.double() @ A1[:K].cpu()) / n) ** 2).clamp_min(0)
+    inv_old = (var_old + 1e-5).rsqrt()
+    # the unfolded path: statistics of the bf16-rounded conv output
+    zb = q(Z.float())
+    inv_unf = (zb.double().var(0, unbiased=False) + 1e-5).rsqrt()
+    rel = lambda a, b: ((a.double().cpu() - b).abs() / b.abs()).numpy()
+    e_new, e_old, e_unf = rel(invstd, inv), rel(inv_old, inv), rel(inv_unf, inv)
+    ratio = (mu ** 2 / var)[:4]
+    report(f"fold statistics, badly conditioned channels (mean^2 / var = {[f'{v:.0f}' for v in ratio.tolist()]}): invstd error vs float64, channels 0-3: "
+           f"centred {[f'{v:.1e}' for v in e_new[:4]]}, uncentred fp32 form {[f'{v:.1e}' for v in e_old[:4]]}, unfolded (bf16 z) "
+           f"{[f'{v:.1e}' for v in e_unf[:4]]}; worst over all {C} channels: centred {e_new.max():.1e}, uncentred {e_old.max():.1e}; "
+           f"mean {relerr(mean, mu):.1e}; scale of gamma = 0 / 1e-8: {float(scale[4]):.1e} / {float(scale[5]):.1e}")
+    assert relerr(mean, mu) < 1e-6
+    assert e_new.max() < 2e-4, e_new.max()                    # (the uncentred form: percent on channels 0, 1, 3)
+    assert e_new[[0, 1, 3]].max() < 0.1 * max(e_old[[0, 1, 3]].max(), 1e-3)
+    assert float(scale[4]) == 0.0 and abs(float(scale[5]) - 1e-8 * float(inv[5])) < 1e-12 and torch.isfinite(shift).all()
 
 
 class RefBottleneck(torch.nn.Module):
