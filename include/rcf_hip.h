@@ -578,6 +578,9 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
  * ones (10^6 vertices): what the caller picks when the previous call's vertex counts were high (rcf_amd.crf.CRFHead).
  * Needs keys that fit 12 bits per coordinate and batch <= 16; otherwise the default build runs. */
 #define RCF_CRF_BUILD_SORT 0x300
+/* the six blur passes of a filter as six launches (one per lattice axis) instead of three (two axes per launch, the first
+ * axis's values recomputed on the fly for the three vertices the second reads: same operations, same bits) -- tests and A/B */
+#define RCF_CRF_BLUR_SEQUENTIAL 0x400
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

@@ -34,6 +34,8 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int W;                 // image width (N = W * H): the per-pixel kernels walk 16 x 16 tiles
     long E;                // entries per frame = N*(pd+1)
     float w;               // Potts weight
+    int tune;              // per call (rcf_crf_soft_ex `normalization` bits 10-15): bit 0 RCF_CRF_BLUR_SEQUENTIAL (one launch per blur
+                           // axis instead of one per PAIR of axes), bits 1-3 the vertex kernels' grid (lab: 0 = the default)
     int build;             // per call (rcf_crf_soft_ex `normalization` bits): 0 packed build when the keys fit, 1 always the
                            // array-of-keys build, 2 packed build whose first-attempt table is tiny (exercises the overflow path)
     uint4 *keys;           // [F][E]   5 x int16 packed, zero padded
@@ -1090,6 +1092,47 @@ __global__ void __launch_bounds__(256) blur2_kernel(Lattice Lt, int axis, const 
     }
 }
 
+// TWO blur passes (axes `axis` and `axis + 1`) in one launch: out[v] = blur3(T[n+], T[v], T[n-]) along axis + 1 with
+// T[u] = blur3(in[m+(u)], in[u], in[m-(u)]) along `axis` evaluated on the fly for the three vertices the second pass reads -- the
+// same float operations on the same values as the two launches (whose intermediate array holds exactly these T), so the same
+// bits.  A blur launch over a natural frame's 7 x 10^4 vertices is two dependent round trips (neighbour pair, then values)
+// behind a launch boundary: 14 us for 23 MB; the pair costs three round trips and ONE boundary (round 6).  WITHZ: the
+// homogeneous channel rides along (first filter pass after a build, blur2_kernel's job).
+template <bool WITHZ>
+__global__ void __launch_bounds__(256) blur_pair_kernel(Lattice Lt, int axis, const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                        const float *__restrict__ zin, float *__restrict__ zout) {
+    const int f = blockIdx.x;
+    const int nax = Lt.pd + 1;
+    const long Lf = Lt.L[f];
+    const long fb = (long)f * Lt.E;
+    const int2 *nbA = reinterpret_cast<const int2 *>(Lt.nb + (fb * nax + (long)axis * Lt.E) * 2);
+    const int2 *nbB = reinterpret_cast<const int2 *>(Lt.nb + (fb * nax + (long)(axis + 1) * Lt.E) * 2);
+    for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x) {
+        const int2 nB = nbB[v];
+        const int2 nA0 = nbA[v];
+        int2 nAp = make_int2(-1, -1), nAm = make_int2(-1, -1);
+        if (nB.x >= 0) nAp = nbA[nB.x];
+        if (nB.y >= 0) nAm = nbA[nB.y];
+        auto first = [&](long u, const int2 n, float2 &t, float &tz) {      // the first pass's value at vertex u
+            const float2 me = in[fb + u];
+            float2 vp = make_float2(0.f, 0.f), vm = make_float2(0.f, 0.f);
+            float zme = 0.f, zp = 0.f, zm = 0.f;
+            if (WITHZ) zme = zin[fb + u];
+            if (n.x >= 0) { vp = in[fb + n.x]; if (WITHZ) zp = zin[fb + n.x]; }
+            if (n.y >= 0) { vm = in[fb + n.y]; if (WITHZ) zm = zin[fb + n.y]; }
+            t = blur3(vp, me, vm);
+            if (WITHZ) tz = blur3(zp, zme, zm);
+        };
+        float2 t0, tp = make_float2(0.f, 0.f), tm = make_float2(0.f, 0.f);
+        float z0 = 0.f, zp = 0.f, zm = 0.f;
+        first(v, nA0, t0, z0);
+        if (nB.x >= 0) first(nB.x, nAp, tp, zp);
+        if (nB.y >= 0) first(nB.y, nAm, tm, zm);
+        out[fb + v] = blur3(tp, t0, tm);
+        if (WITHZ) zout[fb + v] = blur3(zp, z0, zm);
+    }
+}
+
 // build time: inv[p] = 1 / sum_r w_r * z[vid_r]  (z = blurred homogeneous channel)
 // sym: inv[p] = 1 / sqrt(that + 1e-20), the symmetric normalisation of DenseCRF2D (see rcf_crf_soft_ex)
 template <int PD>
@@ -1508,14 +1551,21 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
 // tmp-free filter + Potts + softmax epilogue for one potential
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
                   int first, int last, int write_map, hipStream_t st) {
-    const dim3 gv(F, 1024), gp(F, rcf_cdiv(L.W, 16) * rcf_cdiv(L.N / L.W, 16));     // (frames, 16 x 16 tiles): see splat_gather_kernel
+    static const int GRIDS[8] = {1024, 256, 384, 512, 768, 2048, 128, 192};    // (L.tune >> 1) & 7: lab only
+    const dim3 gv(F, GRIDS[(L.tune >> 1) & 7]), gp(F, rcf_cdiv(L.W, 16) * rcf_cdiv(L.N / L.W, 16));     // (frames, 16 x 16 tiles): see splat_gather_kernel
+    const bool pairs = !(L.tune & 1);                          // RCF_CRF_BLUR_SEQUENTIAL: one launch per axis (tests, A/B)
     float2 *a = L.val0, *b = L.val1;
     if (L.norm_pending) {
         // the build's key array is dead by now: its 16 bytes per entry hold the two homogeneous-channel buffers
         float *za = reinterpret_cast<float *>(L.keys), *zb = za + (size_t)F * L.E;
         hipLaunchKernelGGL(splat_gather_kernel<2>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, za);
         for (int axis = 0; axis <= L.pd; axis++) {
-            hipLaunchKernelGGL(blur2_kernel, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
+            if (pairs && axis + 1 <= L.pd) {
+                hipLaunchKernelGGL(blur_pair_kernel<true>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
+                ++axis;
+            } else {
+                hipLaunchKernelGGL(blur2_kernel, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
+            }
             float2 *t = a; a = b; b = t;
             float *tz = za; za = zb; zb = tz;
         }
@@ -1528,7 +1578,12 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
     }
     hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, (float *)nullptr);
     for (int axis = 0; axis <= L.pd; axis++) {
-        hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
+        if (pairs && axis + 1 <= L.pd) {
+            hipLaunchKernelGGL(blur_pair_kernel<false>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)nullptr, (float *)nullptr);
+            ++axis;
+        } else {
+            hipLaunchKernelGGL(blur_kernel<float2>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b);
+        }
         float2 *t = a; a = b; b = t;
     }
     if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
@@ -1543,6 +1598,8 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
               int32_t *nvert, CrfBuffers &b, hipStream_t st, int sym = 0, int build = 0, const float *featf = nullptr) {
     b.smooth.sym = b.app.sym = sym;                                // per call, not per process: concurrent callers differ
     // float features are unbounded: the array-of-keys build (16-bit key coordinates, the reference's `short`) takes them
+    b.smooth.tune = b.app.tune = build >> 4;
+    build &= 3;
     b.smooth.build = b.app.build = featf ? 1 : build;
     b.smooth.featf = b.app.featf = featf;
     const bool has_s = scomp_smooth > 0.f && sxy_smooth > 0.f;     // torchcrf.cu:28
@@ -1619,7 +1676,8 @@ extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, in
                                int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
                                size_t workspace_bytes, void *stream) {
     // bits 8-9: lattice build (RCF_CRF_BUILD_*: tests and A/B measurements; identical results)
-    const int build = (normalization >> 8) & 3;
+    // bits 10-15: iteration variants (RCF_CRF_BLUR_SEQUENTIAL; lab grids) -- they travel to crf_infer above the build's two bits
+    const int build = ((normalization >> 8) & 3) | (((normalization >> 10) & 0x3f) << 4);
     normalization &= 0xff;
     if (normalization != 0 && normalization != 1) return RCF_EINVAL;
     return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,

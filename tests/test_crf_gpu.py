@@ -270,3 +270,24 @@ def test_crf_soft_float_features_vs_oracle(report):
     h_i = rcf_amd.crf_hard(torch.from_numpy(rgb8.astype(np.float32)).to(DEV), lab, W, H, *p, 0.5, iters)
     h_u = rcf_amd.crf_hard(torch.from_numpy(rgb8).to(DEV), lab, W, H, *p, 0.5, iters)
     assert torch.equal(h_i, h_u)
+
+
+@pytest.mark.parametrize("kind,params,iters", [("smooth", (0., 0., 5., 60., 5.), 5), ("noise", (0., 0., 5., 60., 5.), 3),
+                                               ("smooth", (3., 3., 5., 60., 5.), 2), ("smooth", (3., 3., 0., 60., 5.), 3)])
+def test_crf_blur_pairs_identical(kind, params, iters, report):
+    """round 6: a filter's six blur passes run as three launches of two axes each (blur_pair_kernel: the first axis's values are
+    recomputed on the fly for the three vertices the second axis reads -- the same float operations on the same values), the
+    position lattice's three as a pair + one.  Against one launch per axis (RCF_CRF_BLUR_SEQUENTIAL): MAP, marginals and vertex
+    counts bit for bit, on natural and noise frames, with the smoothness kernel on, and through the first pass that carries the
+    homogeneous channel along."""
+    H, W, F = 120, 214, 3
+    gen = synth.smooth_rgb if kind == "smooth" else synth.noise_rgb
+    rgb = torch.from_numpy(np.stack([gen(H, W, 4500 + i) for i in range(F)])).to(DEV)
+    un = torch.from_numpy(np.stack([_unary(synth.soft_blob_mask(H, W, 4500 + i)) for i in range(F)])).to(DEV)
+    out = {}
+    for seq in (0, 4):                                   # build bits: 4 = RCF_CRF_BLUR_SEQUENTIAL >> 8
+        out[seq] = crf_soft_batched(rgb, un, W, H, *params, iters, want_q=True, want_nvert=True, build=seq)
+    same = all(bool(torch.equal(a, b)) for a, b in zip(out[0], out[4]))
+    report(f"crf blur pairs vs one launch per axis ({kind}, params {params}, T={iters}): MAP / Q / vertex counts identical: {same}; "
+           f"vertices {out[0][2].tolist()}")
+    assert same
