@@ -651,6 +651,10 @@ int rcf_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       void *stream);
 int rcf_ema_update_f32(float *dest, const float *src, long n, float m, void *stream);
 int rcf_fill_f32(float *p, long n, float v, void *stream);
+/* nn.Dropout2d's draw as a per-(sample, channel) scale (models/decode_head.py:84-87, models/fcn_head.py:142-147): out[i] = 0 with
+ * probability p, 1 / (1 - p) otherwise, i < n = samples * channels; Philox4x32-10 keyed by `seed`, counter = i (reproducible
+ * whatever the launch geometry).  The batch-norm apply pass of the head's last conv module multiplies it in (chan_scale). */
+int rcf_dropout2d_scale_f32(float *out, long n, float p, unsigned long long seed, void *stream);
 
 /* ---- evaluation metric ---------------------------------------------------------------
  * main.py:200-235 + utils/eval_utils.py:5-52,120-123: masks [B,C,h,w] (fp32 softmax) are resized to the annotation size

@@ -182,6 +182,7 @@ PROTOS = {
     "rcf_adam_step_f32": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "rcf_ema_update_f32": (c_int, [P, P, c_long, c_float, P]),
     "rcf_fill_f32": (c_int, [P, c_long, c_float, P]),
+    "rcf_dropout2d_scale_f32": (c_int, [P, c_long, c_float, ctypes.c_ulonglong, P]),
     # mixed-precision (bf16 storage) forms
     "rcf_bn_stats_mp": (c_int, [P, c_int, c_long, c_int, c_int, P, P, c_size_t, P]),
     "rcf_bn_apply_mp": (c_int, [P, c_int, c_int, P, c_int, P, c_int, c_int, c_long, c_int, P, P, P, P, c_int, P, c_long, P,

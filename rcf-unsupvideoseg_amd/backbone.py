@@ -239,9 +239,11 @@ class FCNHead(nn.Module):
             if self.keep_mask is not None:
                 scale = self.keep_mask
             else:
-                keep = 1.0 - self.dropout_ratio
+                # the draw: one launch of the library's own counter-based generator, seeded from torch's HOST generator (so that
+                # torch.manual_seed governs it, as it governs the reference's nn.Dropout2d) -- no torch kernels in the step
                 src = (first if first is not None else x).t
-                scale = torch.bernoulli(torch.full((src.shape[0], self.channels), keep, device=src.device)) / keep
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                scale = ops.dropout2d_scale(src.shape[0], self.channels, self.dropout_ratio, seed, src.device)
         for i, m in enumerate(mods):
             cs = scale if i == len(mods) - 1 else None
             # a conv module whose successor is another conv module hands its output on as fp16 pair planes only

@@ -66,4 +66,37 @@ extern "C" int rcf_fill_f32(float *p, long n, float v, void *stream) {
     return 0;
 }
 
+namespace {
+// Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's own CUDA dropout uses): counter = (element index,
+// 0, 0, 0), key = the 64-bit seed.  One 32-bit word per element suffices here.
+__device__ __forceinline__ unsigned philox_word(unsigned long long idx, unsigned long long seed) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = 0u, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__global__ void dropout2d_scale_kernel(float *__restrict__ out, long n, float p, unsigned long long seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = (float)(philox_word((unsigned long long)i, seed) >> 8) * (1.0f / 16777216.0f);      // [0, 1), 24 bits
+    out[i] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+}  // namespace
+
+/* nn.Dropout2d's draw (models/decode_head.py:84-87): out[n][c] = 0 with probability p, 1 / (1 - p) otherwise -- the per-plane
+ * scale the batch-norm apply pass multiplies in (rcf_bn_apply_mp chan_scale).  Counter-based: the same (seed, n * C) always gives
+ * the same draw, whatever the launch geometry. */
+extern "C" int rcf_dropout2d_scale_f32(float *out, long n, float p, unsigned long long seed, void *stream) {
+    if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) return RCF_EINVAL;
+    hipLaunchKernelGGL(dropout2d_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rcf_stream(stream), out, n, p, seed);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" const char *rcf_version(void) { return "rcf_hip 0.1.0 gfx950"; }

@@ -1013,6 +1013,14 @@ def ema_update(dest, src, m, invalidate=True):
     call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
 
 
+def dropout2d_scale(n, channels, p, seed, device):
+    """nn.Dropout2d's draw as the [n, channels] fp32 scale the head's last batch-norm pass multiplies in: 0 with probability p,
+    1 / (1 - p) otherwise (rcf_dropout2d_scale_f32: Philox keyed by `seed`, one launch, no torch kernels)"""
+    out = torch.empty((n, channels), dtype=torch.float32, device=device)
+    call("rcf_dropout2d_scale_f32", _p(out), n * channels, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return out
+
+
 def fill(t, v, weights=False):
     """t[:] = v.  weights=True when `t` may be (part of) a parameter: the cached weight operands are dropped.  The callers in
     this package fill gradient buffers only -- a bump there would throw away, at the top of every step, the operands the

@@ -908,3 +908,41 @@ def test_warp_backward(report):
         e1, e2 = relerr(dx, xd.grad), relerr(dfl, fd.grad)
         report(f"warp bwd {pad}: dx {e1:.2e} dflow {e2:.2e}")
         assert e1 < 2e-5 and e2 < 2e-4
+
+
+def test_dropout2d_scale_draw(report):
+    """rcf_dropout2d_scale_f32 (round 6: the step's Dropout2d draw no longer goes through torch.bernoulli): values in {0, 1/(1-p)},
+    the dropped fraction within 4 sigma of p, a (seed, size) pair always gives the same draw, another seed another one, no visible
+    correlation between neighbouring elements; and torch.manual_seed governs the draw an FCNHead takes in training mode."""
+    n, C, p = 64, 256, 0.1
+    a = ops.dropout2d_scale(n, C, p, 1234, DEV)
+    b = ops.dropout2d_scale(n, C, p, 1234, DEV)
+    c = ops.dropout2d_scale(n, C, p, 1235, DEV)
+    vals = torch.unique(a).cpu().tolist()
+    frac = float((a == 0).float().mean())
+    sigma = (p * (1 - p) / (n * C)) ** 0.5
+    z = (a == 0).float()
+    corr = float(((z[:, 1:] - p) * (z[:, :-1] - p)).mean() / (p * (1 - p)))
+    big = ops.dropout2d_scale(4096, 512, 0.5, 7, DEV)
+    frac_big = float((big == 0).float().mean())
+    report(f"dropout2d draw: values {vals}, dropped {frac:.4f} (p = {p}, sigma {sigma:.4f}); same seed identical {bool(torch.equal(a, b))}, "
+           f"other seed differs on {float((a != c).float().mean()):.3f} of the planes; lag-1 correlation {corr:+.4f}; p = 0.5 over 2 M planes: {frac_big:.5f}")
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / (1 - p)) < 1e-6
+    assert abs(frac - p) < 4 * sigma and torch.equal(a, b) and not torch.equal(a, c) and abs(corr) < 0.05
+    assert abs(frac_big - 0.5) < 4 * (0.25 / (4096 * 512)) ** 0.5
+    # the model's heads: the draw follows torch's host generator
+    from rcf_amd import backbone
+    seen = []
+    orig = ops.dropout2d_scale
+    ops.dropout2d_scale = lambda *a_, **k_: (seen.append(orig(*a_, **k_)) or seen[-1])
+    try:
+        head = backbone.FCNHead(64, 32, num_classes=4, num_convs=1, concat_input=False, dropout_ratio=0.1,
+                                norm_cfg=dict(type="BN", requires_grad=True)).to(DEV).train()
+        from rcf_amd.layers import Act, Tape
+        x = torch.randn(2, 12, 16, 64, device=DEV)
+        for s_ in (5, 5, 6):
+            torch.manual_seed(s_)
+            head.fwd([Act(x, needs_grad=False)], Tape(enabled=False))
+    finally:
+        ops.dropout2d_scale = orig
+    assert len(seen) == 3 and torch.equal(seen[0], seen[1]) and not torch.equal(seen[0], seen[2])
