@@ -8,6 +8,11 @@ from ctypes import c_int, c_uint, c_long, c_float, c_double, c_void_p, c_size_t,
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librcf_hip.so")
+# The 16-bit storage type is a build parameter of the library (csrc/rcf_common.h): librcf_hip.so stores bf16, librcf_hip_f16.so
+# IEEE fp16 (the same sources; the four that touch 16-bit tensors compiled with -DRCF_HALF_F16).  ACTIVE names the one `call`
+# talks to; rcf_amd.ops.half_storage(dtype) switches it for the duration of a model's forward / backward.
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(HERE, "librcf_hip_f16.so")}
+ACTIVE = "bf16"
 
 
 class RcfHipError(RuntimeError):
@@ -235,29 +240,32 @@ PROTOS = {
 }
 F32, BF16 = 0, 1          # storage type codes (RCF_F32 / RCF_BF16)
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load librcf_hip.so; raises RcfHipError when it has not been built (no fallback)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RcfHipError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build) first; "
+def load(which=None):
+    """Load librcf_hip.so (or, which = "f16" / ACTIVE == "f16", librcf_hip_f16.so); raises RcfHipError when it has not been built
+    (no fallback)."""
+    which = which or ACTIVE
+    lib = _libs.get(which)
+    if lib is None:
+        path = LIB_PATHS[which]
+        if not os.path.exists(path):
+            raise RcfHipError(f"{path} is missing: run `python __graft_entry__.py` (build) first; "
                               "there is no CPU fallback for the product path")
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in PROTOS.items():
             fn = getattr(lib, name, None)
             if fn is None:
                 continue            # reported by missing_symbols(); calling it raises
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        _libs[which] = lib
+    return lib
 
 
-def missing_symbols():
-    lib = load()
+def missing_symbols(which=None):
+    lib = load(which)
     return [n for n in PROTOS if not hasattr(lib, n)]
 
 
@@ -265,7 +273,7 @@ def call(name, *args):
     """Call an int-returning entry point and raise on a non-zero status."""
     fn = getattr(load(), name, None)
     if fn is None:
-        raise RcfHipError(f"librcf_hip.so does not export {name}")
+        raise RcfHipError(f"{os.path.basename(LIB_PATHS[ACTIVE])} does not export {name}")
     rc = fn(*args)
     if PROTOS[name][0] is c_int and rc != 0:
         raise RcfHipError(f"{name} failed with status {rc}" + (" (bad argument)" if rc == -1 else

@@ -217,6 +217,8 @@ class Schedule:
                          streaming (non-temporal) stores, RCF_CONV_NT_STORES: the tiles' output does not push the weights and the
                          neighbouring column tiles' activation rows out of the XCD's L2 (0 = never; results bit-identical)
       bf16_stem          bf16 step: the stem conv on the bf16 kernels too (image padded to 8 channels)
+      autocast_fp16_as_bf16  a model called under torch.autocast(float16) with no explicit precision stores bf16 (rounds 2-5: no loss
+                         scaling needed) instead of fp16 (Lightning `precision: 16` as the reference runs it, with its GradScaler)
       cache_weight_operands  derived weight operands once per weight update, not per launch
       bulk_weight_prep   ... for all weights of the model in two / three launches right after the optimizer step (trainer.WeightPrep)
     data parallel
@@ -231,7 +233,7 @@ class Schedule:
 
     __slots__ = ("overlap_wgrad", "late_wgrad", "side_priority", "overlap_teacher", "fuse_bn_stats", "fuse_bn_finalize",
                  "fuse_bn_bwd", "relu_bitmask", "defer_residual", "lazy_downsample_norm", "merge_downsample_bwd", "fold_bn", "fold_max_k", "fold_masked_dgrad", "fp16_pairs",
-                 "h2_kinds", "planes", "join_planes", "nt_stores", "bf16_stem", "cache_weight_operands", "bulk_weight_prep", "grad_group",
+                 "h2_kinds", "planes", "join_planes", "nt_stores", "bf16_stem", "autocast_fp16_as_bf16", "cache_weight_operands", "bulk_weight_prep", "grad_group",
                  "teacher_group")
 
     def __init__(self):
@@ -245,6 +247,7 @@ class Schedule:
         self.bf16_stem = self.cache_weight_operands = self.bulk_weight_prep = True
         self.grad_group, self.teacher_group = "auto", False
         self.nt_stores = 0
+        self.autocast_fp16_as_bf16 = False
 
     def set(self, **kw):
         """set several fields; returns the previous values (for a `finally: SCHED.set(**old)`)"""

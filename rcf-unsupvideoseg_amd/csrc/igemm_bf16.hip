@@ -18,8 +18,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));      // bf16_t: the build's 16-bit storage type (rcf_common.h)
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -132,7 +132,7 @@ __device__ __forceinline__ void mma_step(const char *__restrict__ As, const char
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr)
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nr], a[mr], acc[mr][nr], 0, 0, 0);
+                acc[mr][nr] = RCF_MFMA_32X32X16_H(b[nr], a[mr], acc[mr][nr]);
     }
 }
 
@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 3) ? 2 :
     auto unpack_pair = [&](const u32x4 d, f32x4 &lo, f32x4 &hi) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-        lo = f32x4{__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u)};
-        hi = f32x4{__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u)};
+        lo = rcf_widen4(s0[0], s1[0]);
+        hi = rcf_widen4(s0[1], s1[1]);
     };
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradParams p) {
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = RCF_MFMA_32X32X16_H(a[mr], b[nr], acc[mr][nr]);
         }
     };
 
@@ -973,7 +973,7 @@ __device__ __forceinline__ void wgrad_tr_step(const char *__restrict__ As, const
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr)
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+                acc[mr][nr] = RCF_MFMA_32X32X16_H(a[mr], b[nr], acc[mr][nr]);
     }
 }
 

@@ -53,16 +53,38 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // Activations / activation gradients may be stored as bf16 (dtype code RCF_BF16) instead of fp32 (RCF_F32); every kernel
 // computes in fp32.  ld4 / st4 move FOUR consecutive channels (16 B of fp32, 8 B of bf16); bf16 -> fp32 is exact,
 // fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
+// The 16-bit storage type is a BUILD parameter (round 6): librcf_hip.so stores bf16 (the default: fp32's exponent range, no loss
+// scaling), librcf_hip_f16.so -- the four sources that touch 16-bit tensors (bn, spatial, igemm_bf16, foldbn) compiled again with
+// -DRCF_HALF_F16 -- stores IEEE fp16: Lightning's `precision: 16` of the STv2 / FBMS configs (fp16 autocast + GradScaler,
+// configs/rcf_stv2/rcf_stage1.yaml:57-60).  The type keeps its historical name `bf16_t` and the dtype code RCF_BF16 means "the
+// 16-bit type of the library the call goes to"; the MFMA instruction (v_mfma_f32_32x32x16_{bf16,f16}) and the widening
+// conversions (a shift for bf16, v_cvt for fp16) are the only places that differ.
+#ifdef RCF_HALF_F16
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x4_t __attribute__((ext_vector_type(4)));
+#define RCF_MFMA_32X32X16_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#define RCF_MFMA_32X32X16_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef bf16_t h16x2_t __attribute__((ext_vector_type(2)));
+// four packed 16-bit values (two dwords) -> fp32 (exact in both types)
+__device__ __forceinline__ f32x4 rcf_widen4(unsigned a, unsigned b) {
+#ifdef RCF_HALF_F16
+    const h16x2_t ha = __builtin_bit_cast(h16x2_t, a), hb = __builtin_bit_cast(h16x2_t, b);
+    return f32x4{(float)ha[0], (float)ha[1], (float)hb[0], (float)hb[1]};
+#else
+    return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+#endif
+}
 
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T *p);
 template <> __device__ __forceinline__ f32x4 ld4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t *p) {
     const u32x2_t r = *reinterpret_cast<const u32x2_t *>(p);
-    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
-                 __uint_as_float(r[1] & 0xffff0000u)};
+    return rcf_widen4(r[0], r[1]);
 }
 template <typename T> __device__ __forceinline__ void st4(T *p, f32x4 v);
 template <> __device__ __forceinline__ void st4<float>(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
@@ -75,15 +97,13 @@ template <typename T> __device__ __forceinline__ void st1(T *p, float v) { *p = 
 // V consecutive channels (V = 4 or 8) as fp32: one 16-byte access moves 8 bf16 channels
 template <int V> struct fvec { f32x4 q[V / 4]; };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
 template <typename T, int V> __device__ __forceinline__ fvec<V> ldv(const T *p) {
     fvec<V> r;
     if constexpr (V == 8 && sizeof(T) == 2) {
         const u32x4_t w = *reinterpret_cast<const u32x4_t *>(p);
-        r.q[0] = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
-                       __uint_as_float(w[1] & 0xffff0000u)};
-        r.q[1] = f32x4{__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u), __uint_as_float(w[3] << 16),
-                       __uint_as_float(w[3] & 0xffff0000u)};
+        r.q[0] = rcf_widen4(w[0], w[1]);
+        r.q[1] = rcf_widen4(w[2], w[3]);
     } else {
 #pragma unroll
         for (int h = 0; h < V / 4; ++h) r.q[h] = ld4(p + 4 * h);

@@ -186,9 +186,9 @@ class FlowAggregationHeadWithResidual(nn.Module):
         # bf16 step (act_dtype: the forward pass's activation type): the 64 -> 64 feature conv on the bf16-operand kernels, as
         # torch autocast runs it (models/flow_aggregation_head_with_residual.py:84-93 under configs/rcf_stv2's AMP); its
         # output stays fp32 for the fp32 loss tail.  a1 (Cin = 2 conv, fp32-MFMA) is rounded to bf16 once for all three directions.
-        bf = act_dtype == torch.bfloat16 and c2.cin % 8 == 0 and c2.cout % 8 == 0
+        bf = act_dtype in ops.H16 and c2.cin % 8 == 0 and c2.cout % 8 == 0
         if bf:
-            a1b = ops.cast(a1, torch.bfloat16)
+            a1b = ops.cast(a1, act_dtype)
             feat = ops.conv2d_fwd_bf16(a1b, c2.weight, None, c2.bias, 1, c2.padding, 1, act=1, slope=0.1, out_dtype=torch.float32)
         else:
             feat = ops.conv2d_fwd(a1, c2.weight, c2.bias, 1, c2.padding, 1, act=1, slope=0.1)
@@ -243,7 +243,7 @@ class FlowAggregationHeadWithResidual(nn.Module):
             # second 3x3 conv (64 -> 64): dfeat already carries the LeakyReLU derivative
             ops.colsum(dfeat, _param_grad(c2.bias), beta=1)
             if bf:
-                dfb = ops.cast(dfeat, torch.bfloat16)
+                dfb = ops.cast(dfeat, act_dtype)
                 ops.conv2d_wgrad_bf16(a1b, dfb, c2.weight, _param_grad(c2.weight), 1, c2.padding, 1, beta=1)
                 da1 = ops.cast(ops.conv2d_dgrad_bf16(dfb, c2.weight, a1.shape, 1, c2.padding, 1), torch.float32)
             else:

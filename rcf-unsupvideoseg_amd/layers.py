@@ -146,7 +146,7 @@ def join_side_stream(device=None):
 
 class Tape:
     def __init__(self, enabled=True, on_mark=None, act_dtype=torch.float32):
-        assert act_dtype in (torch.float32, torch.bfloat16)
+        assert act_dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.ops, self.enabled, self.on_mark, self.act_dtype = [], enabled, on_mark, act_dtype
 
     def push(self, fn):
@@ -165,9 +165,10 @@ class Tape:
             self.ops.append(fire)
 
     def backward(self):
-        while self.ops:
-            self.ops.pop()()
-        join_side_stream()
+        with ops.half_storage(self.act_dtype):               # the library build whose 16-bit type this pass's activations have
+            while self.ops:
+                self.ops.pop()()
+            join_side_stream()
 
 
 class DistCtx:
@@ -251,6 +252,8 @@ class Conv2d(nn.Module):
         instead of once per launch: valid while the weight's storage, torch version and the library's weight epoch stand"""
         if not SCHED.cache_weight_operands:
             return make()
+        if kind.startswith("bf16") and ops.half() == torch.float16:
+            kind = "f16" + kind[4:]                      # the 16-bit copies of the fp16 build are another operand
         key = ops.weight_key(self.weight)
         cache = self.__dict__.setdefault("_wcache", {})
         hit = cache.get(kind)
@@ -368,12 +371,12 @@ class Conv2d(nn.Module):
                         ops.colsum(dy, db, beta=0)
                         _param_grad(self.bias).add_(db[:self.cout])
                 wk = self.weight
-                if dy.dtype != torch.bfloat16:
+                if dy.dtype not in ops.H16:
                     # fp32 gradient of an fp32 output: as bf16 with the channels zero-padded to a multiple of 8
                     c8 = _round_up(dy.shape[3], 8)
                     d16 = (torch.zeros if c8 != dy.shape[3] else torch.empty)(tuple(dy.shape[:3]) + (c8,),
-                                                                                dtype=torch.bfloat16, device=dy.device)
-                    ops.cast(dy, torch.bfloat16, out=d16[..., :dy.shape[3]])
+                                                                                dtype=x.t.dtype, device=dy.device)
+                    ops.cast(dy, x.t.dtype, out=d16[..., :dy.shape[3]])
                     dy = d16
                     wk = self._packed_weight(8)
                 done_dgrad = [False]
@@ -383,7 +386,7 @@ class Conv2d(nn.Module):
                     wt = self._derived("bf16_t", lambda: ops.weight_bf16(wk, True)) if wk is self.weight else None
                     tile = 64 if self.cin <= 64 else (128 if self.cin <= 128 else 256)
                     if (SCHED.fold_masked_dgrad and x.relu_out and x.first_reader is tok and wt is not None and self.stride == 1
-                            and self.cin % tile == 0 and gx.dtype == torch.bfloat16 and x.t.dtype == torch.bfloat16):
+                            and self.cin % tile == 0 and gx.dtype in ops.H16 and x.t.dtype in ops.H16):
                         # x is the output of a folded conv + norm + ReLU and this is the LAST writer of its gradient: the mask of
                         # that ReLU and the column sums its backward needs come out of this epilogue (no pass over the gradient)
                         _, cs = ops.conv2d_dgrad_masked_bf16(dy, wk, x.t.shape, wt, x.t, gx, beta=beta, stride=self.stride,
@@ -421,7 +424,7 @@ class Conv2d(nn.Module):
         """Returns an Act with cout_pad channels (the padded ones are exactly zero).
         stats: the following layer is a training-mode batch norm; the conv epilogue produces its statistics.  Pass the
         BatchNorm2d itself (`bn.stats_request(dist)`) and the reduction of those statistics finalizes it in the same launch."""
-        if x.t.dtype == torch.bfloat16:
+        if x.t.dtype in ops.H16:
             return self._fwd_bf16(x, tape, out, stats)
         w, b = self._packed_weight(), self._packed_bias()
         ax = aw = wp = None
@@ -745,11 +748,11 @@ class BatchNorm2d(nn.Module):
 def fold_ok(conv, bn, x, residual=None):
     """can conv (1x1, stride 1) -> bn (training mode) [-> + residual] [-> ReLU] run as conv_bn_fold?"""
     t = x.t
-    return (SCHED.fold_bn and t.dtype == torch.bfloat16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
+    return (SCHED.fold_bn and t.dtype in ops.H16 and conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None
             and not conv.act and bn.training and conv.cin % 64 == 0 and conv.cin <= SCHED.fold_max_k
             and (conv.cout in (64, 128) or conv.cout % 256 == 0) and ops.relu_mask_colsum_ok(conv.cout)
             and t.is_contiguous() and bn.num_features == conv.cout
-            and (residual is None or (residual.t.dtype == torch.bfloat16 and tuple(residual.t.shape[:3]) == tuple(t.shape[:3])
+            and (residual is None or (residual.t.dtype == t.dtype and tuple(residual.t.shape[:3]) == tuple(t.shape[:3])
                                       and residual.t.shape[3] == conv.cout)))
 
 
@@ -940,7 +943,7 @@ def commuted_concat_conv(a, b, conv, tape):
     bi = bw + d                                  # input pixels the band's gradient reaches
     W = conv.weight
     dt = a.t.dtype
-    bf = dt == torch.bfloat16                    # bf16-operand kernels (mixed-precision step), else fp32-level kernels
+    bf = dt in ops.H16                           # 16-bit-operand kernels (mixed-precision step), else fp32-level kernels
     assert b.t.dtype == dt
     wa = W[:, :Ca].contiguous(memory_format=torch.channels_last)
     wbt = W[:, Ca:].contiguous(memory_format=torch.channels_last)

@@ -212,12 +212,21 @@ class RCFModel(nn.Module):
             self._tdist = DistCtx(group=tdist.new_group())
 
     def _select_precision(self):
+        """"fp32" | "bf16" | "fp16": the storage type of the activations between layers (weights, gradients and accumulation stay
+        fp32).  Unset, torch autocast decides as Lightning's `precision:` does: autocast(float16) -- `precision: 16`,
+        configs/rcf_stv2/rcf_stage1.yaml:57-60, to be used with a GradScaler like there -- stores fp16, autocast(bfloat16) bf16
+        (SCHED.autocast_fp16_as_bf16 = True restores rounds 2-5: any autocast as bf16 storage, no loss scaling needed)."""
         p = self.precision
         if p is None:
-            p = "bf16" if torch.is_autocast_enabled() else "fp32"
-        if p not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
-        self._act_dtype = torch.bfloat16 if p == "bf16" else torch.float32     # of THIS forward pass: every Tape it makes carries it
+            if torch.is_autocast_enabled():
+                fp16 = torch.get_autocast_dtype("cuda") == torch.float16 and not layers.SCHED.autocast_fp16_as_bf16
+                p = "fp16" if fp16 else "bf16"
+            else:
+                p = "fp32"
+        if p not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {p!r}")
+        # of THIS forward pass: every Tape it makes carries it
+        self._act_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[p]
         return p
 
     def _images_nhwc(self, imgs):
@@ -225,9 +234,9 @@ class RCFModel(nn.Module):
         x = imgs.reshape(B * I, C3, H, W).contiguous().float()
         if not x.is_cuda:
             raise RuntimeError("RCFModel (HIP) needs the batch on the GPU: there is no CPU fallback")
-        if self._act_dtype == torch.bfloat16 and layers.SCHED.bf16_stem:
-            # bf16 step: the stem conv takes bf16 operands like every other conv (torch autocast casts conv1's input too)
-            return Act(ops.cast(ops.nchw_to_nhwc(x, 8), torch.bfloat16), needs_grad=False)
+        if self._act_dtype in ops.H16 and layers.SCHED.bf16_stem:
+            # 16-bit step: the stem conv takes 16-bit operands like every other conv (torch autocast casts conv1's input too)
+            return Act(ops.cast(ops.nchw_to_nhwc(x, 8), self._act_dtype), needs_grad=False)
         return Act(ops.nchw_to_nhwc(x, 4), needs_grad=False)
 
     def run_backward(self, grad_out=None):
@@ -236,8 +245,9 @@ class RCFModel(nn.Module):
             raise RuntimeError("backward called twice or before forward")
         tape, self._tape = self._tape, None
         scale = 1.0 if grad_out is None else float(grad_out)
-        self._seed_backward(scale)
-        tape.backward()
+        with ops.half_storage(tape.act_dtype):               # the loss tail's backward launches kernels too
+            self._seed_backward(scale)
+            tape.backward()
 
     # ------------------------------------------------------------------ training forward
     def forward_train(self, imgs, gt_fw_flows, gt_bw_flows, pl_masks=None):
@@ -390,8 +400,10 @@ class RCFModel(nn.Module):
 
     def forward(self, x, return_pred_vis_list=False):
         imgs = torch.stack(x["imgs"], dim=1)
-        if self.training:
-            pl = torch.stack(x["pl_masks"], dim=1) if self.w_pl > 0 else None
-            return self.forward_train(imgs, torch.stack(x["gt_fw_flows"], dim=1),
-                                      torch.stack(x["gt_bw_flows"], dim=1), pl)
-        return self.forward_eval(imgs, x.get("seq_ids"), x.get("seq_names"), x.get("paths"), return_pred_vis_list)
+        self._select_precision()
+        with ops.half_storage(self._act_dtype):          # the library build that stores this pass's 16-bit type (ops.half_storage)
+            if self.training:
+                pl = torch.stack(x["pl_masks"], dim=1) if self.w_pl > 0 else None
+                return self.forward_train(imgs, torch.stack(x["gt_fw_flows"], dim=1),
+                                          torch.stack(x["gt_bw_flows"], dim=1), pl)
+            return self.forward_eval(imgs, x.get("seq_ids"), x.get("seq_names"), x.get("paths"), return_pred_vis_list)

@@ -23,11 +23,42 @@ def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+H16 = (torch.bfloat16, torch.float16)          # the 16-bit storage types (one per library build)
+
+
+def half():
+    """the 16-bit storage type of the library calls go to right now (torch.bfloat16, or torch.float16 inside half_storage(float16))"""
+    return torch.float16 if _lib.ACTIVE == "f16" else torch.bfloat16
+
+
+class half_storage:
+    """with half_storage(torch.float16): every library call goes to librcf_hip_f16.so (IEEE fp16 as the 16-bit storage type --
+    Lightning's `precision: 16`, configs/rcf_stv2/rcf_stage1.yaml:57-60); torch.bfloat16 -> librcf_hip.so (the default); any
+    other dtype (fp32 models) leaves the choice alone.  RCFModel wraps its forward and its backward in it."""
+
+    def __init__(self, dtype):
+        self.want = "f16" if dtype == torch.float16 else ("bf16" if dtype == torch.bfloat16 else None)
+
+    def __enter__(self):
+        self.old = _lib.ACTIVE
+        if self.want is not None:
+            _lib.ACTIVE = self.want
+        return self
+
+    def __exit__(self, *exc):
+        _lib.ACTIVE = self.old
+        return False
+
+
 def _dt(t):
-    """storage type code of an activation tensor (RCF_F32 / RCF_BF16 of include/rcf_hip.h)"""
+    """storage type code of an activation tensor (RCF_F32 / RCF_BF16 of include/rcf_hip.h; RCF_BF16 = "the 16-bit type of the
+    library the call goes to": a float16 tensor must not reach the bf16 build, nor the other way round)"""
     if t.dtype == torch.float32:
         return _lib.F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype in H16:
+        if t.dtype != half():
+            raise _lib.RcfHipError(f"a {t.dtype} tensor was handed to the library that stores {half()}: wrap the call in "
+                                   "rcf_amd.ops.half_storage(dtype)")
         return _lib.BF16
     raise _lib.RcfHipError(f"unsupported activation dtype {t.dtype}")
 
@@ -493,11 +524,12 @@ def weight_bf16(w, transpose=False):
 
 
 def conv2d_fwd_bf16(x, w, w_bf16=None, bias=None, stride=1, pad=0, dil=1, act=0, slope=0.0, out=None, beta=0, region=None,
-                    out_dtype=torch.bfloat16, stats=False, bn=None):
+                    out_dtype=None, stats=False, bn=None):
     """x: NHWC bf16; w: the fp32 master weight (shape only, unless w_bf16 is None); returns y (bf16 or fp32) and, with
     stats, the fp64 [2*Cout] batch-norm sums of the fp32 accumulators"""
     _need_cuda(x, w)
-    assert x.dtype == torch.bfloat16
+    assert x.dtype == half()
+    out_dtype = out_dtype or half()
     if w_bf16 is None:
         w_bf16 = weight_bf16(w)
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, nt_cols=w.shape[0])
@@ -532,9 +564,9 @@ def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, r
     """dy: NHWC bf16, w: fp32 master weight -> dx bf16 (region in INPUT coordinates).  w_t_bf16 = weight_bf16(w, True),
     prepared once per weight update (otherwise the launch casts into its workspace)"""
     _need_cuda(dy, w)
-    assert dy.dtype == torch.bfloat16
+    assert dy.dtype == half()
     if out is None:
-        out = torch.empty(tuple(xshape), dtype=torch.bfloat16, device=dy.device)
+        out = torch.empty(tuple(xshape), dtype=half(), device=dy.device)
     s = _conv_shape(xshape, pitch_of(out), w, stride, pad, dil, pitch_of(dy), w_pairs_t=w_t_bf16, nt_cols=xshape[3])
     assert tuple(dy.shape) == (s.N, s.Ho, s.Wo, s.Cout)
     need = 0 if w_t_bf16 is not None else _lib.load().rcf_conv2d_dgrad_bf16_workspace_bytes(byref(s))
@@ -553,7 +585,7 @@ def conv2d_dgrad_bf16(dy, w, xshape, stride=1, pad=0, dil=1, out=None, beta=0, r
 def conv2d_wgrad_bf16(x, dy, w_like, dw, stride=1, pad=0, dil=1, beta=1, region=None):
     """dw (fp32, the weight's memory layout) (+)= wgrad of bf16 x / dy (region in OUTPUT coordinates)"""
     _need_cuda(x, dy, dw)
-    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert x.dtype == half() and dy.dtype == half() and dw.dtype == torch.float32
     s = _conv_shape(x.shape, pitch_of(x), w_like, stride, pad, dil, pitch_of(dy))
     reg = _region(region)
     need = _lib.load().rcf_conv2d_wgrad_bf16_workspace_bytes(byref(s), reg)
@@ -618,9 +650,9 @@ def conv2d_fwd_affine_bf16(x, w, w_bf16, scale, shift, residual=None, relu=True,
     """y = [relu](conv(x, w) * scale[c] + shift[c] [+ residual]) in the conv's own epilogue (bf16 in, bf16 out).
     want_bits (with relu): also the ReLU's sign bits in tile order, (y, bits) -- for conv2d_dgrad_masked_bf16(mask_bits=)"""
     _need_cuda(x, w)
-    assert x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)
+    assert x.dtype == half() and (residual is None or residual.dtype == half())
     s = _conv_shape(x.shape, pitch_of(x), w, stride, pad, dil, nt_cols=w.shape[0])
-    out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((s.N, s.Ho, s.Wo, s.Cout), dtype=half(), device=x.device)
     s.y_pitch = pitch_of(out)
     if residual is not None:
         assert tuple(residual.shape) == tuple(out.shape)
@@ -648,7 +680,7 @@ def relu_mask_colsum_ok(C):
 def relu_mask_colsum(dy, y, out=None):
     """(g = y > 0 ? dy : 0, fp64 [2C] whose first half holds the column sums of g); out may be dy (in place)"""
     _need_cuda(dy, y)
-    assert dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and tuple(dy.shape) == tuple(y.shape)
+    assert dy.dtype == half() and y.dtype == half() and tuple(dy.shape) == tuple(y.shape)
     if out is None:
         out = torch.empty(tuple(dy.shape), dtype=dy.dtype, device=dy.device)
     rows, C = _rows(dy), dy.shape[3]
@@ -664,7 +696,7 @@ def conv2d_dgrad_masked_bf16(dy, w, xshape, w_t_bf16, mask_src, out, beta=0, str
     """dx = mask_src > 0 ? conv_transpose(dy, w) (+ dx) : 0 in the data gradient's epilogue, with the column sums of what it
     writes (fp64 [2 Cin], first half): the LAST writer of a ReLU output's gradient applies that ReLU's mask"""
     _need_cuda(dy, w)
-    assert dy.dtype == torch.bfloat16 and (mask_bits is not None or (mask_src.dtype == torch.bfloat16 and tuple(mask_src.shape) == tuple(xshape)))
+    assert dy.dtype == half() and (mask_bits is not None or (mask_src.dtype == half() and tuple(mask_src.shape) == tuple(xshape)))
     if mask_bits is not None:
         mask_src = None                       # the sign bits the forward tile wrote (1/16 of the bytes) instead of the tensor
         assert mask_bits.numel() == _lib.load().rcf_conv_relu_bits_bytes(xshape[0] * xshape[1] * xshape[2], xshape[3])
@@ -899,7 +931,7 @@ def nchw_to_nhwc(x, cpad=None):
 
 
 def nhwc_to_nchw(x, C=None):
-    if x.dtype == torch.bfloat16:
+    if x.dtype in H16:
         x = cast(x, torch.float32)
     N, H, W, Cx = x.shape
     C = C or Cx

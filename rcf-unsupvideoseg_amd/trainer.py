@@ -94,7 +94,8 @@ class WeightPrep:
     def __init__(self, model, precision, device):
         from . import layers, _lib
         lib = _lib.load()
-        self.bf16 = precision == "bf16"
+        self.bf16 = precision in ("bf16", "fp16")       # 16-bit operand copies (of the library build that stores that type)
+        self.half = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision)
         self.device = device
         self.convs = []
         for m in model.modules():
@@ -163,7 +164,8 @@ class WeightPrep:
             chk = ops.weight_checksum(m.weight) if ops.DEBUG_WEIGHT_CACHE else None
             cache = m.__dict__.setdefault("_wcache", {})
             if self.bf16:
-                cache["bf16"], cache["bf16_t"] = (key, self.out_f[i], chk), (key, self.out_t[i], chk)
+                k16 = "f16" if self.half == torch.float16 else "bf16"         # layers.Conv2d._derived's key of this 16-bit type
+                cache[k16], cache[k16 + "_t"] = (key, self.out_f[i], chk), (key, self.out_t[i], chk)
             else:
                 cache["amax"] = (key, self.amax[i:i + 1], chk)
                 cache["pairs"], cache["pairs_t"] = (key, self.out_f[i], chk), (key, self.out_t[i], chk)
@@ -212,9 +214,27 @@ def make_grad_group(want, device):
     return None, f"shared with SyncBN (own communicator failed: {err or 'on another rank'})"
 
 
+class LossScaler:
+    """torch.cuda.amp.GradScaler's policy (what Lightning's `precision: 16` wraps around main.py:158-178): the loss is multiplied
+    by `scale` before backward; a step whose gradients hold an inf / NaN is skipped and halves the scale, `growth_interval`
+    clean steps in a row double it.  Needed with fp16 storage only (bf16 has fp32's exponent range)."""
+
+    def __init__(self, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self.good_steps, self.skipped = 0, 0
+
+    def update(self, finite):
+        if finite:
+            self.good_steps += 1
+            if self.good_steps >= self.growth_interval:
+                self.scale, self.good_steps = self.scale * self.growth_factor, 0
+        else:
+            self.scale, self.good_steps, self.skipped = self.scale * self.backoff_factor, 0, self.skipped + 1
+
+
 class Trainer:
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, epochs=200, power=0.9, min_lr=1e-6, device="cuda:0",
-                 betas=(0.9, 0.999), eps=1e-8, force_group=False, precision=None):
+                 betas=(0.9, 0.999), eps=1e-8, force_group=False, precision=None, loss_scaler=None):
         self.model = model.to(device)
         if precision is not None:           # "bf16": bf16 activations / operands, fp32 master weights and gradients
             self.model.precision = precision
@@ -225,6 +245,8 @@ class Trainer:
         self.base_lr, self.weight_decay, self.epochs, self.power, self.min_lr = lr, weight_decay, epochs, power, min_lr
         self.betas, self.eps = betas, eps
         self.epoch, self.step_count = 0, 0
+        # precision "fp16" (IEEE half storage: Lightning `precision: 16`) trains with a loss scaler, as the reference's GradScaler
+        self.scaler = loss_scaler if loss_scaler is not None else (LossScaler() if precision == "fp16" else None)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # force_group: run the chunked asynchronous all-reduce path even with one rank (a dry run of the RCCL code path
         # on a single GPU: tests/test_dist_gpu.py)
@@ -272,7 +294,8 @@ class Trainer:
         with torch.no_grad():
             losses = self.model(batch)
         self._pending, self._done = [], set()
-        self.model.run_backward()
+        scale = self.scaler.scale if self.scaler is not None else 1.0
+        self.model.run_backward(scale if self.scaler is not None else None)
         if self.chunked:
             if self.ranges is None or not hasattr(self.model, "grad_ready_hook"):
                 dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.grad_group)
@@ -287,14 +310,22 @@ class Trainer:
                 if self.profile:
                     e1.record()
                     self.exposed.append((e0, e1))
+        if self.scaler is not None:
+            # GradScaler.step: unscale (inside Adam's grad_scale), skip the update when any gradient is not finite.  One host
+            # read per step (the range of the flat gradient buffer: NaN / inf have the largest bit patterns)
+            finite = (int(ops.absmax(self.fp.grad)) & 0x7FFFFFFF) < 0x7F800000
+            self.scaler.update(finite)
+            if not finite:
+                return losses
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr(), self.step_count,
-                      self.betas, self.eps, self.weight_decay, grad_scale=1.0 / self.world)
+                      self.betas, self.eps, self.weight_decay, grad_scale=1.0 / (self.world * scale))
         if self.prep is None and config.SCHED.bulk_weight_prep:
-            prec = self.model.precision or ("bf16" if torch.is_autocast_enabled() else "fp32")     # RCFModel._select_precision
+            prec = self.model._select_precision()
             self.prep = WeightPrep(self.model, prec, self.device)
         if self.prep is not None:
-            self.prep.run()                                 # the next forward finds every derived weight operand ready
+            with ops.half_storage(self.prep.half):
+                self.prep.run()                             # the next forward finds every derived weight operand ready
         if check_nan and math.isnan(float(losses["loss"])):
             raise Exception("loss is NaN")                      # main.py:176-177
         return losses

@@ -18,10 +18,12 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(rcf_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_header_symbols_exported_and_bound():
+@pytest.mark.parametrize("which", ["bf16", "f16"])
+def test_header_symbols_exported_and_bound(which):
+    """both builds of the library: librcf_hip.so (bf16 as the 16-bit storage type) and librcf_hip_f16.so (IEEE fp16)"""
     names = declared_functions()
     assert len(names) >= 30
-    lib = _lib.load()
+    lib = _lib.load(which)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/rcf_hip.h but not exported: {missing}"
     unbound = [n for n in names if n not in _lib.PROTOS]
@@ -58,3 +60,21 @@ def test_product_refuses_cpu_tensors():
         ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 1, 1))
     with pytest.raises(_lib.RcfHipError):
         ops.flow_warp(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 4, 4))
+
+
+def test_half_storage_switches_the_library_and_guards_the_types():
+    """rcf_amd.ops.half_storage: the 16-bit storage type is a property of the library BUILD; a context picks the build, a tensor of
+    the other 16-bit type is refused before any launch"""
+    import torch
+    from rcf_amd import ops
+    assert _lib.ACTIVE == "bf16" and ops.half() == torch.bfloat16
+    with ops.half_storage(torch.float16):
+        assert _lib.ACTIVE == "f16" and ops.half() == torch.float16 and _lib.load() is _lib.load("f16")
+        assert ops._dt(torch.zeros(1, dtype=torch.float16)) == _lib.BF16 and ops._dt(torch.zeros(1)) == _lib.F32
+        with pytest.raises(_lib.RcfHipError, match="half_storage"):
+            ops._dt(torch.zeros(1, dtype=torch.bfloat16))
+        with ops.half_storage(torch.float32):                       # an fp32 model inside: leaves the choice alone
+            assert _lib.ACTIVE == "f16"
+    assert _lib.ACTIVE == "bf16" and _lib.load() is _lib.load("bf16") and _lib.load("bf16") is not _lib.load("f16")
+    with pytest.raises(_lib.RcfHipError, match="half_storage"):
+        ops._dt(torch.zeros(1, dtype=torch.float16))
