@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--crf-iters", type=int, default=5)
     ap.add_argument("--no-stage2", action="store_true")
     ap.add_argument("--no-bf16", action="store_true")
+    ap.add_argument("--no-fp16", action="store_true")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -103,12 +104,16 @@ def main():
         model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(mask, dropout=0.1, norm="SyncBN"))
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
-        trainer = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=precision)
+        # fp16 storage trains with a loss scaler (GradScaler's policy); the bench starts it at 2^10 so that no step of the timed
+        # region is a skipped one (reported as `skipped_steps`: a skipped step does no Adam / weight preparation)
+        scaler = rcf_amd.trainer.LossScaler(2.0 ** 10) if precision == "fp16" else None
+        trainer = rcf_amd.Trainer(model, lr=1e-4, weight_decay=1e-4, device=dev, precision=precision, loss_scaler=scaler)
         # set-up, not measurement: priming steps let the caching allocator and the second stream's scratch reach their
         # steady state (the first steps hipMalloc); then the W untimed warm-up steps and the K timed ones of the contract
         for _ in range(PRIMING_STEPS + warmup):
             trainer.step(batch)
         barrier()
+        skipped0 = scaler.skipped if scaler is not None else 0
         ops.PROFILE.start(family)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -116,6 +121,9 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof = ops.PROFILE.stop()
+        if scaler is not None:
+            step_leg.fp16_info = {"loss_scale_log2": int(round(float(np.log2(scaler.scale)))), "skipped_steps_in_timed_region": scaler.skipped - skipped0,
+                                  "skipped_steps_before": skipped0}
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -123,7 +131,7 @@ def main():
         loss_val = float(losses["loss"])
         if loss_val != loss_val:
             raise SystemExit("loss is NaN")
-        fams = FAMILIES_BF16 if precision == "bf16" else FAMILIES_F32
+        fams = FAMILIES_F32 if precision == "fp32" else FAMILIES_BF16
         ops.PROFILE.start(list(fams))
         for _ in range(2):
             trainer.step(batch)
@@ -221,6 +229,18 @@ def main():
               "frac_of_bf16_mfma_roofline": round(v16 / world * GF_PER_FRAME / 1e3 / BF16_MFMA_PEAK_TF, 4)}
         if comm16:
             bf["comm"] = comm16
+    # ---- the same step with IEEE fp16 storage (Lightning `precision: 16` of the STv2 / FBMS configs, configs/rcf_stv2/rcf_stage1.yaml:57-60):
+    # librcf_hip_f16.so, loss scaling; same kernels as the bf16 step with v_mfma_f32_32x32x16_f16
+    f16 = None
+    if not a.no_bf16 and not a.no_fp16:
+        dtf, lossf, _, _, _, _ = step_leg("fp16", fam16, a.steps, a.warmup)
+        vf = frames / dtf
+        f16 = {"workload": "the same step with IEEE fp16 activation storage / MFMA operands (Lightning precision: 16), loss scaling, "
+                           f"fp32 master weights / gradients / Adam; {B} pairs/GPU, dp{world}", "dtype": "fp16",
+               "frames_per_s": round(vf, 3), "ms_per_step": round(dtf / a.steps * 1e3, 3), "loss": round(lossf, 6),
+               **getattr(step_leg, "fp16_info", {})}
+        out["fp16_step"] = f16
+        out["fp16_frames_per_s"], out["fp16_ms_per_step"] = f16["frames_per_s"], f16["ms_per_step"]
     if comm32:
         out["comm"] = comm32
     if rank == 0:
@@ -369,7 +389,7 @@ def contract_line(out):
     if cb:
         line["cpu_baseline"] = {**pick(cb, ("value", "unit", "cores", "kind", "s_per_step", "timed_steps")),
                                 "sample": _clip(cb.get("sample", ""), 160)}
-    line.update(pick(out, ("bf16_frames_per_s", "bf16_ms_per_step")))
+    line.update(pick(out, ("bf16_frames_per_s", "bf16_ms_per_step", "fp16_frames_per_s", "fp16_ms_per_step")))
     bf = out.get("bf16_step") or {}
     if bf.get("roofline"):
         line["bf16_kernel_frac"] = bf["roofline"].get("frac")
@@ -399,7 +419,7 @@ def contract_line(out):
 
 
 # keys a contract line can lose, in this order, when it would not fit (the contract's own keys are never dropped)
-OPTIONAL_KEYS = ("detail", "bf16_allreduce_exposed_ms", "bf16_syncbn_ms_per_step", "grad_comm", "stage2_bf16_ms_per_step",
+OPTIONAL_KEYS = ("detail", "fp16_ms_per_step", "fp16_frames_per_s", "bf16_allreduce_exposed_ms", "bf16_syncbn_ms_per_step", "grad_comm", "stage2_bf16_ms_per_step",
                  "stage2_ms_per_step", "warp_frac", "crf_noise_frac", "crf_noise_ms_per_frame", "bf16_kernel_frac",
                  "bf16_step_frac", "crf_frac", "crf_ms_per_frame", "bf16_ms_per_step", "bf16_frames_per_s",
                  "allreduce_exposed_ms", "syncbn_collectives", "syncbn_ms_per_step")

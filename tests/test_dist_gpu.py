@@ -55,6 +55,16 @@ def _setup(mode="fp32", pairs=None):
     return rcf_amd, m, nb
 
 
+def _precision(mode):
+    return "bf16" if mode.startswith("bf16") else ("fp16" if mode.startswith("fp16") else None)
+
+
+def _scaler(rcf_amd, mode):
+    """fp16 storage: a loss scale at which this net's gradients are finite from the first step (the scaler's walk down from 2^16 is
+    tests/test_fp16_gpu.py's subject), so that the one step compared here is an optimizer step on both sides"""
+    return rcf_amd.trainer.LossScaler(2.0 ** 8) if mode.startswith("fp16") else None
+
+
 def _batch(nb, sl, dev):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev)
     return {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
@@ -65,11 +75,13 @@ def _worker(rank, world, port, q, mode="fp32"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per = B // world
     rcf_amd, m, nb = _setup(mode, slice(rank * per, (rank + 1) * per))
-    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode.startswith("bf16") else None)
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision=_precision(mode), loss_scaler=_scaler(rcf_amd, mode))
     assert tr.world == world
     losses = tr.step(_batch(nb, slice(rank * per, (rank + 1) * per), "cuda:0"))
     torch.cuda.synchronize()
     if not mode.startswith("fp32"):
+        if tr.scaler is not None:
+            assert tr.scaler.skipped == 0 and tr.step_count == 1
         # SyncBN exchanges of this rank: one per batch norm and direction, less the conv1 / downsample pairs that share one
         bns = [(n, mod) for n, mod in m.named_modules() if type(mod).__name__ == "BatchNorm2d" and mod.training and mod.sync]
         n_bn = (sum(1 for n, _ in bns if "_ema" not in n), sum(1 for n, _ in bns if "_ema" in n))      # (student, EMA teacher)
@@ -120,7 +132,7 @@ def test_two_rank_step_equals_global_batch_step(mode, report):
     assert e_loss < 1e-5 and worst < 1e-4 and e_rv < 1e-6      # measured 5e-8 / 1.6e-6 / 0
 
 
-@pytest.mark.parametrize("mode", ["bf16", "stage21", "bf16_drop", "bf16_nofold", "bf16_drop_nofold"])
+@pytest.mark.parametrize("mode", ["bf16", "stage21", "bf16_drop", "bf16_nofold", "bf16_drop_nofold", "fp16_nofold", "fp16"])
 def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     """the N > 1 path of the other two step flavours on ONE device (gloo): the mixed-precision step (BASELINE configs[2]) and the
     stage-2.1 step (EMA teacher with its own SyncBN exchanges + CRF) over two ranks against the single-process step on the global
@@ -134,7 +146,8 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     the norm is then only sanity-bounded (30 %, the bound of test_bf16_step_runs_and_tracks_fp32)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 1000 + {"bf16": 7, "stage21": 13, "bf16_drop": 17, "bf16_nofold": 23, "bf16_drop_nofold": 29}[mode]
+    port = 29900 + os.getpid() % 1000 + {"bf16": 7, "stage21": 13, "bf16_drop": 17, "bf16_nofold": 23, "bf16_drop_nofold": 29,
+                                         "fp16_nofold": 31, "fp16": 37}[mode]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -143,9 +156,10 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
         p.join(timeout=120)
         assert p.exitcode == 0
     rcf_amd, m, nb = _setup(mode)
-    tr = rcf_amd.Trainer(m, device="cuda:0", precision="bf16" if mode.startswith("bf16") else None)
+    tr = rcf_amd.Trainer(m, device="cuda:0", precision=_precision(mode), loss_scaler=_scaler(rcf_amd, mode))
     losses = {k: float(v) for k, v in tr.step(_batch(nb, slice(0, B), "cuda:0")).items()}
     gn = float(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5)
+    # (fp16: both sides' gradients carry the same loss scale: the ratio below is scale-free)
     # rank losses are per-rank means over half the batch: their mean is the global loss
     e = {k: abs(0.5 * (res[0][1][k] + res[1][1][k]) - v) / (abs(v) + 1e-30) for k, v in losses.items()}
     e_gn = abs(res[0][4] / 2 - gn) / gn          # flat gradient after the all-reduce (sum over ranks) is scaled by 1/world in Adam
@@ -156,8 +170,9 @@ def test_two_rank_bf16_and_stage21_steps_equal_global_batch(mode, report):
     want = 2 * n_st - 8 + ((n_te - 4) if n_te else 0)
     report(f"2-rank {mode} step vs single process: losses {e}; gradient norm {e_gn:.1e}; SyncBN collectives per rank {count} for {n_st} "
            f"student + {n_te} teacher norms (one per norm and direction would be {2 * n_st + n_te})")
-    tol = 2e-2 if mode.startswith("bf16") else 2e-4         # bf16: the two ranks round their halves of the batch independently
-    lim_gn = 2e-3 if not mode.startswith("bf16") else (2e-2 if "_nofold" in mode else 0.3)
+    half = mode.startswith(("bf16", "fp16"))
+    tol = 2e-2 if half else 2e-4                             # 16-bit storage: the two ranks round their halves of the batch independently
+    lim_gn = 2e-3 if not half else (2e-2 if "_nofold" in mode else 0.3)
     assert max(e.values()) < tol and e_gn < lim_gn, (e, e_gn, lim_gn)
     assert res[0][2] == res[1][2] and count == want
 

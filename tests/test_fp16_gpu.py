@@ -229,3 +229,27 @@ def test_three_storage_types_coexist_in_one_process(report):
             mixed[prec].append(float(tr.step(batch)["loss"]))
     report(f"fp32 / bf16 / fp16 models interleaved: {mixed} alone: {alone}")
     assert mixed == alone and rcf_amd._lib.ACTIVE == "bf16"
+
+
+def test_fp16_step_fullsize_vs_reference_fp32(golden_dir, report):
+    """BASELINE's geometry (480x854, one pair) in fp16 storage against the REFERENCE's fp32 step (tests/golden/bf16.*): losses
+    closer than the reference's own bf16-autocast run is, and far fewer arg-max decisions flipped than by that run (fp16 keeps 10
+    significand bits, bf16 7) -- the statistic of test_bf16_step_vs_reference_autocast_golden, with the bf16 reference as the
+    ceiling"""
+    fx = json.load(open(os.path.join(golden_dir, "bf16.json")))["480x854"]
+    arr = np.load(os.path.join(golden_dir, "bf16.npz"))
+    Hh, Ww, B, C = fx["H"], fx["W"], fx["B"], fx["C"]
+    m, batch = _model_and_batch(Hh, Ww, B)
+    tr = rcf_amd.Trainer(m, device=DEV, precision="fp16", loss_scaler=rcf_amd.trainer.LossScaler(2.0 ** 8))
+    losses = tr.step(batch)
+    e_l = {k: abs(float(losses[k]) - v) / abs(v) for k, v in fx["loss_fp32"].items()}
+    ref = fx["ref_bf16_vs_fp32"]
+    z = ops.nhwc_to_nchw(m.last_logits, C).cpu()
+    am32 = torch.from_numpy(arr["480x854_argmax_fp32"].astype(np.int64))
+    flips = float((z.argmax(1) != am32).float().mean())
+    gn, finite = _gradnorms(m, tr.scaler.scale if tr.scaler.skipped == 0 else 1.0)
+    report(f"fp16 step at 480x854 B=1 vs the reference's fp32: losses " + " ".join(f"{k} {v:.1e}" for k, v in e_l.items()) +
+           f" (the reference's bf16 autocast: " + " ".join(f"{v:.1e}" for v in ref["loss"].values()) + f"); arg-max decisions flipped "
+           f"{flips:.4f} of the pixels (reference bf16 autocast {ref['argmax_mismatch_frac']:.4f}); gradients finite {finite}, {tr.scaler.skipped} skipped")
+    assert all(e_l[k] < max(ref["loss"][k], 2e-3) for k in e_l), e_l
+    assert flips < 0.5 * ref["argmax_mismatch_frac"] and finite
