@@ -3,7 +3,7 @@
 (DESIGN.md section 4.1's "power-limited" statement: the all-zero run does the same instructions on data that toggles nothing).
 fp32 step: conv_h2d_kernel<4,false,false> (forward), <4,false,true> (data gradient), igemm_wgrad_h2d_kernel<4,...> on fp16 pair
 planes; bf16 step: conv_bf16_kernel<2,4,...> forward / data gradient, wgrad_bf16_dma_kernel<4,...>.
-usage: python tools/pmc_headline.py <random|zero> [launches]"""
+usage: python tools/pmc_headline.py <random|zero> [launches] [bf16|fp16]   (the 16-bit kernels from librcf_hip.so or librcf_hip_f16.so)"""
 import os
 import sys
 
@@ -33,6 +33,7 @@ def to_planes(x, bound_bits):
 def main():
     mode = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    half = torch.float16 if (len(sys.argv) > 3 and sys.argv[3] == "fp16") else torch.bfloat16
     g = torch.Generator().manual_seed(3)
     for name, cin, cout, k, pad, dil in SHAPES:
         x = torch.randn(N, H, W, cin, generator=g).to(DEV)
@@ -44,16 +45,18 @@ def main():
         wp, wpt = ops.weight_pairs(w, aw), ops.weight_pairs_t(w, aw)
         xp, dyp = to_planes(x, ax), to_planes(dy, ag)
         y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.zeros_like(w)
-        xb, dyb = x.bfloat16(), dy.bfloat16()
-        wb, wbt = ops.weight_bf16(w), ops.weight_bf16(w, transpose=True)
+        xb, dyb = x.to(half), dy.to(half)
+        with ops.half_storage(half):
+            wb, wbt = ops.weight_bf16(w), ops.weight_bf16(w, transpose=True)
         yb, dxb = torch.empty_like(dyb), torch.empty_like(xb)
         for _ in range(reps):
             ops.conv2d_fwd_stats(xp, w, 1, pad, dil, amax=(ax, aw), w_pairs=wp, x_planes=True)
             ops.conv2d_dgrad(dyp, w, x.shape, 1, pad, dil, out=dx, amax=(ag, aw), w_pairs_t=wpt, dy_planes=True)
             ops.conv2d_wgrad(xp, dyp, w, dw, 1, pad, dil, beta=0, amax=(ax, ag), planes=True)
-            ops.conv2d_fwd_bf16(xb, w, wb, None, 1, pad, dil, out=yb)
-            ops.conv2d_dgrad_bf16(dyb, w, xb.shape, 1, pad, dil, out=dxb, w_t_bf16=wbt)
-            ops.conv2d_wgrad_bf16(xb, dyb, w, dw, 1, pad, dil, beta=0)
+            with ops.half_storage(half):
+                ops.conv2d_fwd_bf16(xb, w, wb, None, 1, pad, dil, out=yb)
+                ops.conv2d_dgrad_bf16(dyb, w, xb.shape, 1, pad, dil, out=dxb, w_t_bf16=wbt)
+                ops.conv2d_wgrad_bf16(xb, dyb, w, dw, 1, pad, dil, beta=0)
         torch.cuda.synchronize()
     print("done", mode)
 
