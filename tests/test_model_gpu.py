@@ -626,3 +626,36 @@ def test_fullsize_b8_gradients_vs_oracle(report):
     assert all(g32[k] < max(TOL, 4 * spread[k], vec_ref[k]) for k in go), (g32, spread, vec_ref)
     ref16 = json.load(open(os.path.join(here, "golden", "bf16.json")))["480x854"]["ref_bf16_vs_fp32"]
     assert all(g16[k] < max(3 * ref16["gradnorm"][k], 0.10) for k in g16), g16
+
+
+def test_b8_gradients_vs_reference(golden_dir, report):
+    """The backward at the REAL batch size against a REFERENCE-derived fixture (the 8 x 480x854 gradient
+    fixture is made by the oracle alone).  tests/golden/b8_reference.json (make_golden_b8.py): the reference model itself on 8 pairs
+    -- 16 frames through the backbone, batch-norm statistics over all of them -- at 192x320, the largest geometry whose float64
+    truth fits the build container; its fp32 losses, and `synth.grad_sketch` fingerprints of the float64 truth and of the
+    reference's own fp32 gradients (8 threads / 1 thread).  Criteria as at 480x854: losses 1e-4 of the reference; per module the
+    HIP step's gradient VECTOR error against float64 within 1.5 x the reference's own fp32 vector error (floor 1e-4), its norm
+    inside max(4 x the reference's norm error, the reference's vector error)."""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "b8_reference.json")))
+    H, W, B = fx["H"], fx["W"], fx["B"]
+    hip = _build(H, W, False, DEV, rcf_amd.RCFModel)
+    hip.train()
+    l = hip(_batch(B, H, W, DEV))
+    l["loss"].backward()
+    e_loss = {k: rel(float(l[k]), v) for k, v in fx["loss_ref_fp32"].items()}
+    sk = synth.grad_sketch({n: p.grad for n, p in hip.named_parameters() if p.grad is not None}, k=fx["sketch_k"])
+    assert sorted(sk) == sorted(fx["sketch_f64"]), "parameter names differ from the reference's"
+    mods = sorted(fx["gradnorm_f64"])
+    vec = {k: synth.sketch_error(sk, fx["sketch_f64"], k + ".") for k in mods}
+    vec_vs_ref = {k: synth.sketch_error(sk, fx["sketch_ref_fp32"], k + ".") for k in mods}
+    gn = _module_gradnorms(hip)
+    e_gn = {k: rel(gn[k], fx["gradnorm_f64"][k]) for k in mods}
+    vr, nr = fx["ref_fp32_vector_err"], fx["ref_fp32_norm_err"]
+    report(f"{H}x{W} b8 against the REFERENCE: losses " + " ".join(f"{k} {v:.1e}" for k, v in e_loss.items()) +
+           " | gradient vector error vs float64 (the reference's own fp32) " + " ".join(f"{k} {vec[k]:.1e} ({vr[k]:.1e})" for k in mods) +
+           " | vs the reference's fp32 gradients " + " ".join(f"{k} {vec_vs_ref[k]:.1e}" for k in mods) +
+           " | norm error vs float64 (the reference's) " + " ".join(f"{k} {e_gn[k]:.1e} ({nr[k]:.1e})" for k in mods))
+    assert max(e_loss.values()) < TOL
+    assert all(vec[k] < max(TOL, 1.5 * vr[k]) for k in mods), (vec, vr)
+    assert all(e_gn[k] < max(TOL, 4 * nr[k], vr[k]) for k in mods), (e_gn, nr, vr)
