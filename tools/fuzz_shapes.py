@@ -9,19 +9,20 @@ dev = torch.device("cuda:0")
 cases = [(96, 160, 1), (100, 164, 3), (128, 128, 2), (250, 330, 1), (97, 161, 2), (384, 384, 3), (480, 854, 1), (64, 64, 5)]
 bad = 0
 for (H, W, B) in cases:
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp16"):
         try:
             args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_fuzz", object_channel=None, eval_save=False, eval_export=False)
             model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN"))
             shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
             model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
-            tr = rcf_amd.Trainer(model, device=dev, precision=prec)
+            # fp16: a loss scale at which this net's gradients are finite from the first step (the scaler's walk is tests/test_fp16_gpu.py's)
+            tr = rcf_amd.Trainer(model, device=dev, precision=prec, loss_scaler=rcf_amd.trainer.LossScaler(2.0 ** 8) if prec == "fp16" else None)
             nb = synth.make_batch(B, H, W, config_id=3)
             t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
             batch = {k: [t(x) for x in nb[k]] for k in ("imgs", "gt_fw_flows", "gt_bw_flows")}
             ls = [float(tr.step(batch)["loss"]) for _ in range(3)]
             g = tr.fp.grad
-            ok = all(np.isfinite(ls)) and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+            ok = all(np.isfinite(ls)) and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 and (tr.scaler is None or tr.scaler.skipped == 0)
             model.eval()
             with torch.no_grad():
                 m = model({"imgs": [batch["imgs"][0]]})

@@ -1,5 +1,5 @@
 """Many training steps on three alternating synthetic batches: the loss must stay finite and fall.
-usage: python tools/stability_run.py [fp32|bf16|both] [steps] [field=value ...]   (fields of rcf_amd.config.SCHED, e.g. fold_bn=0)"""
+usage: python tools/stability_run.py [fp32|bf16|fp16|both|all] [steps] [field=value ...]   (fields of rcf_amd.config.SCHED, e.g. fold_bn=0)"""
 import os, sys, time, types
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -10,7 +10,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 config.SCHED.parse(sys.argv[3:])
 H, W, B = 480, 854, 8
 dev = torch.device("cuda:0")
-for prec in (("bf16", "fp32") if which == "both" else (which,)):
+for prec in (("bf16", "fp32") if which == "both" else (("bf16", "fp32", "fp16") if which == "all" else (which,))):
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=None, eval_save=False, eval_export=False)
     model = rcf_amd.RCFModel(args, **config.stage1_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="SyncBN"))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -29,6 +29,7 @@ for prec in (("bf16", "fp32") if which == "both" else (which,)):
             break
         if i % 5 == 0:
             hist.append(round(l, 3))
-    print(prec, "loss every 5 steps:", hist, "| first non-finite step:", first_bad, flush=True)
+    print(prec, "loss every 5 steps:", hist, "| first non-finite step:", first_bad,
+          "" if tr.scaler is None else f"| loss scale 2^{int(np.log2(tr.scaler.scale))}, {tr.scaler.skipped} skipped steps, {tr.step_count} optimizer steps", flush=True)
     del tr, model
     torch.cuda.empty_cache()
