@@ -176,6 +176,9 @@ def _lib_call(name, *args):
     return _lib.call(name, *args)
 
 
+_GRAD_GROUPS = {}          # (SCHED.grad_group, device, world) -> (process group or None, what it is): see Trainer._make_grad_group
+
+
 def make_grad_group(want, device):
     """-> (process group or None, what it is): the communicator of the gradient chunks (SCHED.grad_group).  Collective: every
     rank calls it at the same point and takes the same branches.  Two steps, each followed by an agreement (MIN of an ok flag
@@ -267,7 +270,12 @@ class Trainer:
             self.model.grad_ready_hook = self._grads_ready
 
     def _make_grad_group(self, want):
-        return make_grad_group(want, self.device)
+        # ONE gradient communicator per process: a second Trainer (bench.py builds one per precision) reuses it instead of
+        # leaving another RCCL communicator alive.  Collective all the same: every rank's Trainers are built in the same order.
+        key = (str(want), str(self.device), dist.get_world_size(), id(dist.distributed_c10d._get_default_group()))   # (this init_process_group's)
+        if key not in _GRAD_GROUPS:
+            _GRAD_GROUPS[key] = make_grad_group(want, self.device)
+        return _GRAD_GROUPS[key]
 
     def exposed_ms(self):
         """profile mode: per step, how long the compute stream stood waiting for the gradient chunks' all-reduces (ms)"""
