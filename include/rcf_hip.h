@@ -581,6 +581,13 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
 /* the six blur passes of a filter as six launches (one per lattice axis) instead of three (two axes per launch, the first
  * axis's values recomputed on the fly for the three vertices the second reads: same operations, same bits) -- tests and A/B */
 #define RCF_CRF_BLUR_SEQUENTIAL 0x400
+/* The splat of a filter pass.  Default: frames built by the packed build whose 16 x 16 pixel tiles share most of their vertices
+ * (natural images) take the TILE splat -- a scatter into the tile's short vertex list in LDS, one 64-bit atomic per distinct
+ * vertex of the tile and channel, no CSR list built -- the others the gather over the CSR lists.  Sums are in 2^-40 fixed point
+ * either way: identical bits.  SPLAT_GATHER: always the gather (A/B, tests); SPLAT_TILES: the tile splat for every frame the
+ * packed build made, whatever its content (tests). */
+#define RCF_CRF_SPLAT_GATHER 0x4000
+#define RCF_CRF_SPLAT_TILES 0x8000
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

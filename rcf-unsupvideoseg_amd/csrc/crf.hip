@@ -55,7 +55,6 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *L;                // [F]      vertex counts
     // packed build (12-bit key coordinates): the hash table holds the 64-bit keys themselves
     unsigned long long *table;   // [F][2E]  (aliases `keys`)
-    unsigned *cursor;            // [F][2E]  entries per bucket (aliases `entries`)
     int *rel;                    // [F][E]   position of the entry inside its vertex's CSR list
     int *slot_vid2;              // [F][2E]  bucket -> dense vertex id (-1 empty)
     int *slot_off;               // [F][2E]  bucket -> CSR offset
@@ -73,6 +72,23 @@ struct Lattice {           // device pointers of one potential, for all frames (
     // rcf_crf_soft_f32: the colour features as the caller's floats [F][N][3] (torchcrf.cu:84-85 converts rgbFeat to float
     // unrounded); nullptr = the u8 image.  Set per call by crf_infer.
     const float *featf;
+    // tile splat (packed build, frames whose 16 x 16 pixel tiles share most of their vertices: natural images): a workgroup adds
+    // its tile's 256 (pd + 1) entries into the tile's short list of distinct vertices in LDS (64-bit fixed point: the sums do not
+    // depend on the order) and stores one partial sum per distinct vertex; a vertex's partial sums -- one per tile that touches it
+    // -- lie next to each other (the build numbers the tiles of a vertex with the same atomic that reserves its CSR range), and
+    // the vertex pass adds them up: ~10x fewer values to gather than entries, no CSR list for such frames, the same bits.
+    unsigned long long *cursor64;    // [F][2E]  per bucket: entries (low half) and tiles (high half) counted by the build
+    unsigned short *tslot;       // [F][E]   the entry's position in its tile's list
+    int *tlist;                  // [F][tiles * 256 (pd + 1)]  per tile and list position: the bucket, then (tile_list_kernel) the
+                                 //          index of the partial sum this tile owns
+    int *tpos;                   // [F][tiles * 256 (pd + 1)]  the tile's ordinal among the tiles of that vertex, then (tile_list_kernel)
+                                 //          the vertex id (the slice stages the tile's vertex values in LDS through it)
+    int *tcnt;                   // [F][tiles]  length of the tile's list
+    int *tnew;                   // [F][tiles]  keys the tile was first to insert into the small table (overflow statistics)
+    long long *accg;             // [F][3E]  partial sums in 2^-40 fixed point, grouped by vertex (Lt.off / Lt.cnt in tile mode):
+                                 //          [E][2] label sums, then [E] homogeneous-channel sums
+    int tiles;                   // 16 x 16 tiles per frame
+    int tile_splat;              // host side: this build wrote the tile lists (stat[4 f + 3] = their total length per frame)
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
@@ -87,6 +103,14 @@ __device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
            (Lt.stat[4 * f] > Lt.cap_small / 2 || Lt.stat[4 * f + 1] != 0 || Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
 }
 __device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : (long)Lt.cap_small; }
+// does frame f take the tile splat?  Its tiles' lists together hold at most a quarter as many vertices as the frame has entries
+// (smooth 480x854 frames: ~5 %; noise: ~100 %, and those frames go through the sort build, which writes no lists).
+// tune bit 4 (RCF_CRF_SPLAT_GATHER): never; bit 5 (RCF_CRF_SPLAT_TILES): whenever the lists exist (tests).
+constexpr int TILE_SPLAT_RATIO = 4;
+__device__ __forceinline__ bool tile_mode(const Lattice &Lt, int f) {
+    if (!Lt.tile_splat || (Lt.tune & 16)) return false;
+    return (Lt.tune & 32) || (long)Lt.stat[4 * f + 3] * TILE_SPLAT_RATIO <= Lt.E;
+}
 
 __device__ __forceinline__ unsigned key_hash(const short *key, int pd) {
     unsigned k = 0;
@@ -520,10 +544,10 @@ __global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
         Lt.stat[4 * f + threadIdx.x] = 0;            // read by nobody before the estimate / insert kernels that follow
     }
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
-    unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
+    unsigned long long *cursor = Lt.cursor64 + (long)f * 2 * Lt.E;
     for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) {
         table[i] = PK_EMPTY;
-        cursor[i] = 0u;
+        cursor[i] = 0ull;
     }
 }
 
@@ -569,13 +593,16 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
                                                                    int H, float posdev, float featdev, int phase) {
     __shared__ unsigned long long lkey[LT_SLOTS];
     __shared__ unsigned lcnt[LT_SLOTS], lgs[LT_SLOTS], lbase[LT_SLOTS];
-    __shared__ int newkeys, skip;
+    __shared__ int newkeys, skip, ntile;
     const int pd = PD ? PD : Lt.pd, nax = pd + 1;
     const int f = blockIdx.x;                             // frame fastest: with 8 frames per call a frame's workgroups share one XCD
     const bool small = phase == 0 && (long)Lt.cap_small < 2 * Lt.E;      // an attempt that may overflow
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
+    int *tl = Lt.tlist + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
+    int *tp = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
     if (threadIdx.x == 0) {
         newkeys = 0;
+        ntile = 0;
         // the attempt already failed for this frame: nothing this workgroup inserts will be used
         skip = small && (__hip_atomic_load(Lt.stat + 4 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                          Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
@@ -616,7 +643,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     __syncthreads();
     // the block's distinct keys: insert into the frame's table, reserve the block's share of the vertex's list
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
-    unsigned *cursor = Lt.cursor + (long)f * 2 * Lt.E;
+    unsigned long long *cursor = Lt.cursor64 + (long)f * 2 * Lt.E;
     const unsigned nb = phase == 0 ? (unsigned)min((long)Lt.cap_small, 2 * Lt.E) : (unsigned)(2 * Lt.E);
     int mine = 0;
     for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) {
@@ -642,11 +669,23 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
             }
         }
         lgs[i] = h;
-        lbase[i] = placed ? atomicAdd(cursor + h, lcnt[i]) : 0u;
+        // ONE atomic reserves the tile's share of the vertex's CSR range (low half) and numbers the tile among the vertex's tiles
+        const unsigned long long old = placed ? atomicAdd(cursor + h, (unsigned long long)lcnt[i] | (1ull << 32)) : 0ull;
+        lbase[i] = (unsigned)old;
+        // the tile's list of distinct vertices (tile splat): position in arrival order -- the sums are order independent
+        const int ti = atomicAdd(&ntile, 1);
+        lcnt[i] = (unsigned)ti;                                  // (the count is spent)
+        tl[ti] = (int)h;
+        tp[ti] = (int)(old >> 32);
     }
     if (small && mine) atomicAdd(&newkeys, mine);
     __syncthreads();
-    if (small && threadIdx.x == 0 && newkeys) atomicAdd(Lt.stat + 4 * f, newkeys);
+    if (threadIdx.x == 0) {
+        // per tile, summed per frame by pk_totals_kernel: 1 620 atomics onto one counter per frame are served one after the other
+        // (measured: 130 us of this kernel per counter at 8 frames of 480x854)
+        Lt.tnew[(long)f * Lt.tiles + blockIdx.y] = small ? newkeys : 0;
+        Lt.tcnt[(long)f * Lt.tiles + blockIdx.y] = ntile;
+    }
     if (live) {
         const long base = (long)f * Lt.E + p;
         for (int r = 0; r < nax; r++) {
@@ -654,7 +693,28 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
             Lt.vid[e] = (int)lgs[lh[r]];                         // bucket for now; the fill pass turns it into the vertex id
             Lt.rel[e] = (int)lbase[lh[r]] + lrank[r];
             Lt.weight[e] = wgt[r];
+            Lt.tslot[e] = (unsigned short)lcnt[lh[r]];
         }
+    }
+}
+
+// stat[4 f] = distinct keys the frame's tiles inserted into the (small) table, stat[4 f + 3] = total length of its tiles' lists
+__global__ void __launch_bounds__(256) pk_totals_kernel(Lattice Lt, int phase) {
+    __shared__ int sh[2][4];
+    const int f = blockIdx.x;
+    if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform; phase 1 rewrote the overflowed frames only)
+    int a = 0, b = 0;
+    for (int t = threadIdx.x; t < Lt.tiles; t += blockDim.x) {
+        a += Lt.tnew[(long)f * Lt.tiles + t];
+        b += Lt.tcnt[(long)f * Lt.tiles + t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (phase == 0) Lt.stat[4 * f] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        Lt.stat[4 * f + 3] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
 
@@ -671,13 +731,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt) {
         return;
     }
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
-    const unsigned *cursor = Lt.cursor + (long)f * SS;
+    const unsigned long long *cursor = Lt.cursor64 + (long)f * SS;
+    const bool tile = tile_mode(Lt, f);         // the lists scanned are then the vertices' partial sums (one per tile), not their entries
     int fl[SCAN_ITEMS], cn[SCAN_ITEMS], sf = 0, sc = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         const long b = base + i;
-        cn[i] = (b < S) ? (int)cursor[b] : 0;
-        fl[i] = cn[i] > 0 ? 1 : 0;              // every inserted key counted at least one entry
+        const unsigned long long cu = (b < S) ? cursor[b] : 0ull;
+        cn[i] = tile ? (int)(cu >> 32) : (int)(unsigned)cu;
+        fl[i] = cu != 0ull ? 1 : 0;             // every inserted key counted at least one entry
         sf += fl[i];
         sc += cn[i];
     }
@@ -730,7 +792,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
     const int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
     const int addf = bs[blockIdx.x], addc = bs[gridDim.x + 1 + blockIdx.x];
     int *sv = Lt.slot_vid2 + (long)f * SS, *so = Lt.slot_off + (long)f * SS;
-    const unsigned *cursor = Lt.cursor + (long)f * SS;
+    const unsigned long long *cursor = Lt.cursor64 + (long)f * SS;
+    const bool tile = tile_mode(Lt, f);
     const long fb = (long)f * Lt.E;
     const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
@@ -744,7 +807,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
             sv[b] = v;
             Lt.vrep[fb + v] = (int)b;
             Lt.off[fb + v] = off;
-            Lt.cnt[fb + v] = (int)cursor[b];
+            Lt.cnt[fb + v] = tile ? (int)(cursor[b] >> 32) : (int)(unsigned)cursor[b];
         }
     }
 }
@@ -753,13 +816,34 @@ __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
     const long idx = (long)blockIdx.y * blockDim.x + threadIdx.x;
     const int f = blockIdx.x;
     if (idx >= Lt.E) return;
+    // tile mode: no list walk, and the slice finds its vertices through the tile's list (slice_kernel) -- nothing to do here, unless
+    // the stand-alone normaliser pass of the symmetric normalisation (slice_norm_kernel) is going to read the entries' vertex ids
+    if (tile_mode(Lt, f) && !Lt.sym) return;
     const long fb = (long)f * Lt.E, S = 2 * Lt.E;
     const int b = Lt.vid[fb + idx];
     const int v = Lt.slot_vid2[(long)f * S + b];
     const int pos = Lt.slot_off[(long)f * S + b] + Lt.rel[fb + idx];
     const int p = (int)(idx - (idx / Lt.N) * Lt.N);
-    Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));
+    if (!tile_mode(Lt, f)) Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));     // (tile splat: no list walk)
     Lt.vid[fb + idx] = v;
+}
+// tile splat: a tile's list position -> the index of the partial sum it owns: the vertex's range (the scan's offset of its bucket)
+// + the tile's ordinal among the vertex's tiles
+__global__ void __launch_bounds__(256) tile_list_kernel(Lattice Lt) {
+    const int f = blockIdx.x;
+    if (!tile_mode(Lt, f)) return;
+    const int nax = Lt.pd + 1;
+    const int *so = Lt.slot_off + (long)f * 2 * Lt.E, *sv = Lt.slot_vid2 + (long)f * 2 * Lt.E;
+    for (int t = blockIdx.y; t < Lt.tiles; t += gridDim.y) {
+        int *tl = Lt.tlist + ((long)f * Lt.tiles + t) * 256 * nax;
+        int *tp = Lt.tpos + ((long)f * Lt.tiles + t) * 256 * nax;
+        const int n = Lt.tcnt[(long)f * Lt.tiles + t];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int b = tl[i];
+            tl[i] = so[b] + tp[i];
+            tp[i] = sv[b];                     // the ordinal is spent: the vertex itself, for the slice
+        }
+    }
 }
 template <int PD>      // 2 / 5: the key arithmetic unrolls with a compile-time dimension; 0: Lt.pd at run time
 __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
@@ -968,6 +1052,28 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
     const int lane = threadIdx.x & 63;
     const long Lf = Lt.L[f];
     const long fb = (long)f * Lt.E;
+    if (tile_mode(Lt, f)) {
+        // the frame's entries were summed per tile (splat_tile_kernel): a vertex's value is the sum of its tiles' partial sums,
+        // which lie next to each other -- one lane per vertex (a handful of partial sums each)
+        const long long *g = Lt.accg + fb * 3;
+        for (long v = (long)blockIdx.y * blockDim.x + threadIdx.x; v < Lf; v += (long)gridDim.y * blockDim.x) {
+            const long beg = Lt.off[fb + v];
+            const int n = Lt.cnt[fb + v];
+            long long a0 = 0, a1 = 0, a2 = 0;
+            for (int i = 0; i < n; i++) {
+                if (MODE == 1) {
+                    a0 += g[2 * Lt.E + beg + i];
+                } else {
+                    const longlong2 pr = *reinterpret_cast<const longlong2 *>(g + (beg + i) * 2);
+                    a0 += pr.x;
+                    a1 += pr.y;
+                    if (MODE == 2) a2 += g[2 * Lt.E + beg + i];
+                }
+            }
+            store_val<MODE>(out, outz, fb + v, a0, a1, a2);
+        }
+        return;
+    }
     const float *Qf = Q + (long)f * Lt.N * MLAB;
     const int wpb = blockDim.x >> 6;
     if (Lt.E > 4 * Lf) {
@@ -1042,6 +1148,69 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
             if (MODE == 2) a2 = wave_sum_ll(a2);
             if (lane == 0) store_val<MODE>(out, outz, fb + v0 + j, a0, a1, a2);
         }
+    }
+}
+
+// The splat's first half on tile-mode frames (see Lattice::tslot): a pixel's pd + 1 entries add the SAME fixed-point terms acc_entry
+// adds, into the tile's list in LDS; the tile's sums go out as plain stores, one per distinct vertex and channel, to the place the
+// build gave this (tile, vertex) pair; splat_gather_kernel's tile-mode branch adds a vertex's partial sums.  Integer adds: the
+// result does not depend on any order -- the same bits as the list walk's.  (Measured on the way: 64-bit atomics from the tiles
+// straight into per-vertex sums cost 136 us per pass for 8 frames -- the L2 takes them at ~1.5 per clock and XCD -- against 41 us
+// for everything else in this kernel; the LDS atomics, same-address conflicts included, are ~2 us of it.)
+template <int MODE>
+__global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float *__restrict__ Q) {
+    constexpr int NCH = MODE == 2 ? 3 : (MODE == 1 ? 1 : 2);
+    constexpr int CAP = 256 * (PD_MAX + 1);                  // list entries per channel
+    __shared__ unsigned long long acc[NCH * CAP];
+    const int f = blockIdx.x;
+    if (!tile_mode(Lt, f)) return;
+    const int nax = Lt.pd + 1, stride = 256 * nax;
+    const int W = Lt.W, H = Lt.N / Lt.W, tiles_x = (W + 15) >> 4;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
+    const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
+    // Neighbouring pixels mostly hit the SAME vertex, and same-address LDS atomics of one instruction are served one after the
+    // other: a short list is kept in R copies, a lane adds into copy (x + 4 y) mod R -- 64 / R lanes per copy and wavefront
+    int R = 1;
+    while (R < 16 && 2 * R * n <= stride) R *= 2;
+    const int rep = ((threadIdx.x & 15) + 4 * (threadIdx.x >> 4)) & (R - 1);
+    for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) acc[c * CAP + i] = 0ull;
+    }
+    __syncthreads();
+    const long fb = (long)f * Lt.E;
+    if (py < H && px < W) {
+        const int p = py * W + px;
+        float2 q = make_float2(0.f, 0.f);
+        if (MODE != 1) q = *reinterpret_cast<const float2 *>(Q + ((long)f * Lt.N + p) * MLAB);
+        for (int r = 0; r < nax; r++) {
+            const long e = fb + (long)r * Lt.N + p;
+            const float wgt = Lt.weight[e];
+            const int s = rep * n + Lt.tslot[e];
+            if (MODE == 1) {
+                atomicAdd(&acc[s], (unsigned long long)__double2ll_rn((double)wgt * FIX_SCALE));
+            } else {
+                atomicAdd(&acc[s], (unsigned long long)__double2ll_rn((double)(q.x * wgt) * FIX_SCALE));
+                atomicAdd(&acc[CAP + s], (unsigned long long)__double2ll_rn((double)(q.y * wgt) * FIX_SCALE));
+                if (MODE == 2) atomicAdd(&acc[2 * CAP + s], (unsigned long long)__double2ll_rn((double)wgt * FIX_SCALE));
+            }
+        }
+    }
+    __syncthreads();
+    const int *tl = Lt.tlist + ((long)f * Lt.tiles + blockIdx.y) * stride;
+    unsigned long long *g = reinterpret_cast<unsigned long long *>(Lt.accg) + fb * 3;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long pos = tl[i];                              // this tile's partial sum of the vertex: nobody else writes it
+        unsigned long long a[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            a[c] = 0ull;
+            for (int k = 0; k < R; k++) a[c] += acc[c * CAP + k * n + i];
+        }
+        // [pos][2] label sums (one 16-byte store) in the first 2E values of the frame's 3E, [pos] homogeneous sums behind them
+        if (MODE != 1) *reinterpret_cast<ulonglong2 *>(g + pos * 2) = make_ulonglong2(a[0], a[1]);
+        if (MODE != 0) g[2 * Lt.E + pos] = a[NCH - 1];
     }
 }
 
@@ -1165,20 +1334,44 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const int W = Lt.W, H = Lt.N / Lt.W, tiles_x = (W + 15) >> 4;
     const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
     const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
-    if (py >= H || px >= W) return;
-    const int p = py * W + px;
     const int nax = (PD ? PD : Lt.pd) + 1;
     const long fb = (long)f * Lt.E;
+    // tile mode: the tile's distinct vertices are a short list (the build's): their values are fetched ONCE into LDS and a pixel
+    // reads them by its entries' list positions (2 bytes each) instead of gathering 8 bytes per entry by vertex id
+    __shared__ float2 sval[256 * (PD_MAX + 1)];
+    __shared__ float szv[NORM ? 256 * (PD_MAX + 1) : 1];
+    const bool tile = tile_mode(Lt, f);                   // (uniform)
+    if (tile) {
+        const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
+        const int *tv = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int vi = tv[i];
+            sval[i] = val[fb + vi];
+            if (NORM) szv[i] = z[fb + vi];
+        }
+        __syncthreads();
+    }
+    if (py >= H || px >= W) return;
+    const int p = py * W + px;
     float s0 = 0, s1 = 0, sw = 0;
 #pragma unroll
     for (int r = 0; r < nax; r++) {
         const long pe = fb + (long)r * Lt.N + p;
         const float wgt = Lt.weight[pe];
-        const int vi = Lt.vid[pe];
-        const float2 v = val[fb + vi];
+        float2 v;
+        float zz = 0.f;
+        if (tile) {
+            const int sl = Lt.tslot[pe];
+            v = sval[sl];
+            if (NORM) zz = szv[sl];
+        } else {
+            const int vi = Lt.vid[pe];
+            v = val[fb + vi];
+            if (NORM) zz = z[fb + vi];
+        }
         s0 += wgt * v.x;
         s1 += wgt * v.y;
-        if (NORM) sw += wgt * z[fb + vi];
+        if (NORM) sw += wgt * zz;
     }
     float inv;
     if (NORM) {
@@ -1377,12 +1570,20 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.blocksum = c.take<int>((size_t)F * (scan_blocks(L.E) + 1));
     L.L = c.take<int>(F);
     L.table = reinterpret_cast<unsigned long long *>(L.keys);      // 2E x 8 B == E x 16 B
-    L.cursor = reinterpret_cast<unsigned *>(L.entries);
     L.rel = c.take<int>(FE);
     L.slot_vid2 = c.take<int>(2 * FE);
     L.slot_off = c.take<int>(2 * FE);
     L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
     L.stat = c.take<int>((size_t)F * 4);
+    L.tiles = rcf_cdiv(W, 16) * rcf_cdiv(N / W, 16);
+    L.cursor64 = c.take<unsigned long long>(2 * FE);
+    L.tslot = c.take<unsigned short>(FE);
+    L.tlist = c.take<int>((size_t)F * L.tiles * 256 * (pd + 1));
+    L.tpos = c.take<int>((size_t)F * L.tiles * 256 * (pd + 1));
+    L.tcnt = c.take<int>((size_t)F * L.tiles);
+    L.tnew = c.take<int>((size_t)F * L.tiles);
+    L.accg = c.take<long long>(3 * FE);
+    L.tile_splat = 0;
     L.cap_small = 0;
     L.sort_tmp_bytes = rcf_crf_sort_tmp_bytes(FE);
     L.sort_tmp = c.take<char>(L.sort_tmp_bytes);
@@ -1443,18 +1644,22 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     // 480x854, T=5: 2^21 0.388, 2^19 0.371, 2^18 0.361 ms/frame); L.build 2 forces a tiny table (tests)
     const long small = L.build == 2 ? 1021 : ((1L << 18) - 1);
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
+    L.tile_splat = 1;                                            // every kernel below sees it (the struct travels by value)
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
         PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
     PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
+    hipLaunchKernelGGL(pk_totals_kernel, dim3(F), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
         hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
         PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
+        hipLaunchKernelGGL(pk_totals_kernel, dim3(F), dim3(256), 0, st, L, 1);
     }
     hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_fill_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(tile_list_kernel, dim3(F, 256), dim3(256), 0, st, L);
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
     PD_LAUNCH(L.pd, pk_neighbours_kernel, dim3(F, 2048), dim3(256), st, L);
     RCF_LAUNCH_CHECK();
@@ -1493,6 +1698,7 @@ int build_lattice_sorted(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
 int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float posdev, float featdev, float weight,
                   hipStream_t st) {
     L.w = weight;
+    L.tile_splat = 0;                                            // only the packed build writes the tile lists
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
     if (L.build != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
@@ -1533,11 +1739,22 @@ int lattice_built(Lattice &L, int F, hipStream_t st) {
     return 0;
 }
 
+// the splat of one filter pass: the per-tile sums of the frames in tile mode (the kernel returns at once on the others), then the
+// vertex pass -- the list walk over the entries, or the sum of a vertex's few per-tile partial sums
+template <int MODE>
+void launch_splat(Lattice &L, int F, const float *Q, void *out, float *outz, hipStream_t st) {
+    if (L.tile_splat && !(L.tune & 16)) hipLaunchKernelGGL(splat_tile_kernel<MODE>, dim3(F, L.tiles), dim3(256), 0, st, L, Q);
+    // (frames, 768): measured over 256 ... 4096 workgroups per frame -- the list walk of natural frames 233 us per pass of 8 frames
+    // against 240 at 4096, the tile-mode vertex pass 154 against 162 (a few 10^4 vertices per frame: most of 4096 x 256 lanes only
+    // start and stop), noise frames the same at every size
+    hipLaunchKernelGGL(splat_gather_kernel<MODE>, dim3(F, 768), dim3(256), 0, st, L, Q, out, outz);
+}
+
 // homogeneous channel: splat the weights, blur, slice -> per-pixel normaliser (once per lattice)
 int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
     const dim3 gp(F, rcf_cdiv(L.N, 256));                      // (frames, chunks): see splat_gather_kernel
     float *za = reinterpret_cast<float *>(L.val0), *zb = reinterpret_cast<float *>(L.val1);
-    hipLaunchKernelGGL(splat_gather_kernel<1>, dim3(F, 4096), dim3(256), 0, st, L, (const float *)nullptr, (void *)za, (float *)nullptr);
+    launch_splat<1>(L, F, nullptr, (void *)za, nullptr, st);
     for (int axis = 0; axis <= L.pd; axis++) {
         hipLaunchKernelGGL(blur_kernel<float>, dim3(F, 1024), dim3(256), 0, st, L, axis, (const float *)za, zb);
         float *t = za; za = zb; zb = t;
@@ -1558,7 +1775,7 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
     if (L.norm_pending) {
         // the build's key array is dead by now: its 16 bytes per entry hold the two homogeneous-channel buffers
         float *za = reinterpret_cast<float *>(L.keys), *zb = za + (size_t)F * L.E;
-        hipLaunchKernelGGL(splat_gather_kernel<2>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, za);
+        launch_splat<2>(L, F, Q, (void *)a, za, st);
         for (int axis = 0; axis <= L.pd; axis++) {
             if (pairs && axis + 1 <= L.pd) {
                 hipLaunchKernelGGL(blur_pair_kernel<true>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
@@ -1576,7 +1793,7 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
         L.norm_pending = 0;
         return 0;
     }
-    hipLaunchKernelGGL(splat_gather_kernel<0>, dim3(F, 4096), dim3(256), 0, st, L, Q, (void *)a, (float *)nullptr);
+    launch_splat<0>(L, F, Q, (void *)a, nullptr, st);
     for (int axis = 0; axis <= L.pd; axis++) {
         if (pairs && axis + 1 <= L.pd) {
             hipLaunchKernelGGL(blur_pair_kernel<false>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)nullptr, (float *)nullptr);

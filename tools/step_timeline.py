@@ -2,19 +2,21 @@
 (tools/prof_step.sh leaves it in gpurun_out/prof_<tag>/p_kernel_trace.csv).  The LAST step between two adam_kernel launches: per
 launch its start (ms since the step's first kernel), duration, the idle gap in front of it (against the latest end seen so far: what
 a one-stream run leaves between kernels), grid and the kernel's name; then the sums of kernel time and of gaps.
-usage: python tools/step_timeline.py gpurun_out/prof_<tag>/p_kernel_trace.csv [min_us=0] > timeline.txt"""
+usage: python tools/step_timeline.py gpurun_out/prof_<tag>/p_kernel_trace.csv [min_us=0] [first=<kernel-name part>] > timeline.txt
+`first=...`: units begin WITH a launch of that kernel instead of ending with adam_kernel (e.g. first=prepare_image_kernel: one CRF call)."""
 import csv
 import re
 import sys
 
 path = sys.argv[1]
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+first = next((a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("first=")), None)
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if (first or "adam_kernel") in r["Kernel_Name"]]
 if len(marks) < 2:
-    sys.exit("fewer than two optimizer steps in the trace")
-step = rows[marks[-2] + 1:marks[-1] + 1]
+    sys.exit("fewer than two units in the trace")
+step = rows[marks[-2]:marks[-1]] if first else rows[marks[-2] + 1:marks[-1] + 1]
 t0 = int(step[0]["Start_Timestamp"])
 last_end = t0
 busy = gaps = 0
