@@ -588,6 +588,10 @@ int rcf_crf_hard(const uint8_t *rgb, const int16_t *label, int W, int H, int bat
  * packed build made, whatever its content (tests). */
 #define RCF_CRF_SPLAT_GATHER 0x4000
 #define RCF_CRF_SPLAT_TILES 0x8000
+/* With ONE potential active, the slice of a filter pass hands a tile-mode frame's new marginals straight to the next pass's
+ * per-tile sums (one kernel reads the entries' weights and list positions once; the intermediate marginals are never written).
+ * SLICE_SPLAT_SEPARATE: slice and per-tile sums as two kernels, as with two potentials (tests, A/B; identical bits). */
+#define RCF_CRF_SLICE_SPLAT_SEPARATE 0x10000
 /* CRFHead pre-processing (models/crf_head.py:33-37,43-55,95-98): normalised NCHW image -> u8 HWC;
  * soft mask -> u8 quantisation -> unary energies.  scratch: batch uint32 (per-frame max). */
 int rcf_crf_prepare(const float *img_nchw, const float *mask, const float *mean3, const float *std3,

@@ -18,6 +18,9 @@
 //    MAPs and no atomics at all in the iteration (the reference does 3 float atomics per entry per
 //    iteration); 6 blur passes stream float4 vertex values; slice + Potts weight + softmax (+ MAP on
 //    the last iteration) are one kernel.
+//    Round 6: frames whose 16 x 16 pixel tiles share most of their vertices (natural images) take the splat as per-tile sums in
+//    LDS + a vertex pass over a vertex's few, contiguous per-tile partial sums, and build no CSR list (see Lattice::tslot,
+//    splat_tile_kernel, slice_kernel SPLAT) -- still integer sums, the same bits.
 //  * persistent caller-owned workspace, all frames of a batch in every launch (grid.y = frame).
 //  Algorithmic bytes per iteration: 192*N + 348*L, L = lattice vertices.
 #include "rcf_common.h"
@@ -813,19 +816,22 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
 }
 // entry -> (vertex id, CSR slot): a streaming pass, no atomics
 __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
-    const long idx = (long)blockIdx.y * blockDim.x + threadIdx.x;
     const int f = blockIdx.x;
-    if (idx >= Lt.E) return;
     // tile mode: no list walk, and the slice finds its vertices through the tile's list (slice_kernel) -- nothing to do here, unless
     // the stand-alone normaliser pass of the symmetric normalisation (slice_norm_kernel) is going to read the entries' vertex ids
-    if (tile_mode(Lt, f) && !Lt.sym) return;
+    const bool tile = tile_mode(Lt, f);
+    if (tile && !Lt.sym) return;
     const long fb = (long)f * Lt.E, S = 2 * Lt.E;
-    const int b = Lt.vid[fb + idx];
-    const int v = Lt.slot_vid2[(long)f * S + b];
-    const int pos = Lt.slot_off[(long)f * S + b] + Lt.rel[fb + idx];
-    const int p = (int)(idx - (idx / Lt.N) * Lt.N);
-    if (!tile_mode(Lt, f)) Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));     // (tile splat: no list walk)
-    Lt.vid[fb + idx] = v;
+    for (long idx = (long)blockIdx.y * blockDim.x + threadIdx.x; idx < Lt.E; idx += (long)gridDim.y * blockDim.x) {
+        const int b = Lt.vid[fb + idx];
+        const int v = Lt.slot_vid2[(long)f * S + b];
+        if (!tile) {
+            const int pos = Lt.slot_off[(long)f * S + b] + Lt.rel[fb + idx];
+            const int p = (int)(idx - (idx / Lt.N) * Lt.N);
+            Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));
+        }
+        Lt.vid[fb + idx] = v;
+    }
 }
 // tile splat: a tile's list position -> the index of the partial sum it owns: the vertex's range (the scan's offset of its bucket)
 // + the tile's ordinal among the vertex's tiles
@@ -1157,6 +1163,34 @@ __global__ void __launch_bounds__(256) splat_gather_kernel(Lattice Lt, const flo
 // result does not depend on any order -- the same bits as the list walk's.  (Measured on the way: 64-bit atomics from the tiles
 // straight into per-vertex sums cost 136 us per pass for 8 frames -- the L2 takes them at ~1.5 per clock and XCD -- against 41 us
 // for everything else in this kernel; the LDS atomics, same-address conflicts included, are ~2 us of it.)
+// Neighbouring pixels mostly hit the SAME vertex, and same-address LDS atomics of one instruction are served one after the other:
+// a short list is kept in R copies, lane (x, y) of the tile adds into copy (x + 4 y) mod R -- 64 / R lanes per copy and wavefront
+__device__ __forceinline__ int tile_copies(int n, int stride) {
+    int R = 1;
+    while (R < 16 && 2 * R * n <= stride) R *= 2;
+    return R;
+}
+__device__ __forceinline__ int tile_copy_of(int tid, int R) { return ((tid & 15) + 4 * (tid >> 4)) & (R - 1); }
+// the tile's sums (channel c of list position i, copy k: acc[c * CAP + k * n + i]) -> the partial sums this tile owns
+template <int MODE>
+__device__ __forceinline__ void tile_store_sums(const Lattice &Lt, int f, int t, int n, int R, const unsigned long long *acc) {
+    constexpr int NCH = MODE == 2 ? 3 : (MODE == 1 ? 1 : 2);
+    constexpr int CAP = 256 * (PD_MAX + 1);
+    const int *tl = Lt.tlist + ((long)f * Lt.tiles + t) * 256 * (Lt.pd + 1);
+    unsigned long long *g = reinterpret_cast<unsigned long long *>(Lt.accg) + (long)f * Lt.E * 3;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long pos = tl[i];                              // this tile's partial sum of the vertex: nobody else writes it
+        unsigned long long a[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            a[c] = 0ull;
+            for (int k = 0; k < R; k++) a[c] += acc[c * CAP + k * n + i];
+        }
+        // [pos][2] label sums (one 16-byte store) in the first 2E values of the frame's 3E, [pos] homogeneous sums behind them
+        if (MODE != 1) *reinterpret_cast<ulonglong2 *>(g + pos * 2) = make_ulonglong2(a[0], a[1]);
+        if (MODE != 0) g[2 * Lt.E + pos] = a[NCH - 1];
+    }
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float *__restrict__ Q) {
     constexpr int NCH = MODE == 2 ? 3 : (MODE == 1 ? 1 : 2);
@@ -1169,11 +1203,8 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
     const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
     const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
     const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
-    // Neighbouring pixels mostly hit the SAME vertex, and same-address LDS atomics of one instruction are served one after the
-    // other: a short list is kept in R copies, a lane adds into copy (x + 4 y) mod R -- 64 / R lanes per copy and wavefront
-    int R = 1;
-    while (R < 16 && 2 * R * n <= stride) R *= 2;
-    const int rep = ((threadIdx.x & 15) + 4 * (threadIdx.x >> 4)) & (R - 1);
+    const int R = tile_copies(n, stride);
+    const int rep = tile_copy_of(threadIdx.x, R);
     for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) acc[c * CAP + i] = 0ull;
@@ -1198,20 +1229,7 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
         }
     }
     __syncthreads();
-    const int *tl = Lt.tlist + ((long)f * Lt.tiles + blockIdx.y) * stride;
-    unsigned long long *g = reinterpret_cast<unsigned long long *>(Lt.accg) + fb * 3;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const long pos = tl[i];                              // this tile's partial sum of the vertex: nobody else writes it
-        unsigned long long a[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            a[c] = 0ull;
-            for (int k = 0; k < R; k++) a[c] += acc[c * CAP + k * n + i];
-        }
-        // [pos][2] label sums (one 16-byte store) in the first 2E values of the frame's 3E, [pos] homogeneous sums behind them
-        if (MODE != 1) *reinterpret_cast<ulonglong2 *>(g + pos * 2) = make_ulonglong2(a[0], a[1]);
-        if (MODE != 0) g[2 * Lt.E + pos] = a[NCH - 1];
-    }
+    tile_store_sums<MODE>(Lt, f, blockIdx.y, n, R, acc);
 }
 
 __device__ __forceinline__ float2 blur3(float2 p, float2 m, float2 q) {
@@ -1324,7 +1342,11 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
 //   first: next = -U, else next = next_in;  next += w * slice;  last: Q = softmax(next) (+ MAP)
 // NORM: the first filter pass after a build -- the blurred homogeneous channel z is sliced beside the labels and the
 // pixel's normaliser (slice_norm_kernel's operations in its order) is computed, stored for the later passes and used here
-template <int PD, bool NORM = false>      // compile-time dimension: the pd + 1 (weight, vertex, value) chains of a pixel are all in flight at once
+// SPLAT (single potential, not the last iteration): the marginals this pass produces are what the NEXT pass splats, and on a
+// tile-mode frame that splat's first half is per tile as well -- the pixel's new marginals go straight into the tile's sums (the
+// entries' weights and list positions are in registers already), splat_tile_kernel<0>'s adds and stores; Q itself is not written
+// (its only reader would have been that kernel).  Frames in list-walk mode write Q as always.
+template <int PD, bool NORM = false, bool SPLAT = false>      // compile-time dimension: the pd + 1 (weight, vertex, value) chains of a pixel are all in flight at once
 __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__restrict__ val,
                                                     const float *__restrict__ unary, float *__restrict__ next,
                                                     float *__restrict__ Q, short *__restrict__ map, int first,
@@ -1338,65 +1360,104 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const long fb = (long)f * Lt.E;
     // tile mode: the tile's distinct vertices are a short list (the build's): their values are fetched ONCE into LDS and a pixel
     // reads them by its entries' list positions (2 bytes each) instead of gathering 8 bytes per entry by vertex id
-    __shared__ float2 sval[256 * (PD_MAX + 1)];
-    __shared__ float szv[NORM ? 256 * (PD_MAX + 1) : 1];
+    constexpr int CAP = 256 * (PD_MAX + 1);
+    // SPLAT: the sums' 24 KB hold the staged values first (12 KB + 6 KB; dead once every lane has sliced)
+    __shared__ unsigned long long acc[SPLAT ? 2 * CAP : 1];
+    __shared__ float2 sval_own[SPLAT ? 1 : CAP];
+    __shared__ float szv_own[(NORM && !SPLAT) ? CAP : 1];
+    float2 *sval = SPLAT ? reinterpret_cast<float2 *>(acc) : sval_own;
+    float *szv = SPLAT ? reinterpret_cast<float *>(acc + CAP) : szv_own;
     const bool tile = tile_mode(Lt, f);                   // (uniform)
+    int n = 0, R = 1;
     if (tile) {
-        const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
+        n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
         const int *tv = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int vi = tv[i];
             sval[i] = val[fb + vi];
             if (NORM) szv[i] = z[fb + vi];
         }
+        if (SPLAT) R = tile_copies(n, 256 * nax);
         __syncthreads();
     }
-    if (py >= H || px >= W) return;
-    const int p = py * W + px;
-    float s0 = 0, s1 = 0, sw = 0;
+    const bool live = py < H && px < W;
+    const int p = live ? py * W + px : 0;
+    float wr[PD_MAX + 1];
+    int sr[PD_MAX + 1];
+    float qs0 = 0.f, qs1 = 0.f;
+    bool have_q = false;
+    if (live) {
+        float s0 = 0, s1 = 0, sw = 0;
 #pragma unroll
-    for (int r = 0; r < nax; r++) {
-        const long pe = fb + (long)r * Lt.N + p;
-        const float wgt = Lt.weight[pe];
-        float2 v;
-        float zz = 0.f;
-        if (tile) {
-            const int sl = Lt.tslot[pe];
-            v = sval[sl];
-            if (NORM) zz = szv[sl];
-        } else {
-            const int vi = Lt.vid[pe];
-            v = val[fb + vi];
-            if (NORM) zz = z[fb + vi];
+        for (int r = 0; r < nax; r++) {
+            const long pe = fb + (long)r * Lt.N + p;
+            const float wgt = Lt.weight[pe];
+            float2 v;
+            float zz = 0.f;
+            if (tile) {
+                const int sl = Lt.tslot[pe];
+                v = sval[sl];
+                if (NORM) zz = szv[sl];
+                if (SPLAT) { wr[r] = wgt; sr[r] = sl; }
+            } else {
+                const int vi = Lt.vid[pe];
+                v = val[fb + vi];
+                if (NORM) zz = z[fb + vi];
+            }
+            s0 += wgt * v.x;
+            s1 += wgt * v.y;
+            if (NORM) sw += wgt * zz;
         }
-        s0 += wgt * v.x;
-        s1 += wgt * v.y;
-        if (NORM) sw += wgt * zz;
+        float inv;
+        if (NORM) {
+            inv = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
+            Lt.inv[(long)f * Lt.N + p] = inv;
+        } else {
+            inv = Lt.inv[(long)f * Lt.N + p];
+        }
+        const long qi = ((long)f * Lt.N + p) * MLAB;
+        float n0, n1;
+        if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
+        else { n0 = next[qi]; n1 = next[qi + 1]; }
+        n0 += Lt.w * (s0 * inv);
+        n1 += Lt.w * (s1 * inv);
+        if (!last) {
+            next[qi] = n0;
+            next[qi + 1] = n1;
+        } else {
+            const float mx = n0 < n1 ? n1 : n0;
+            const float e0 = __expf(n0 - mx), e1 = __expf(n1 - mx);
+            const float tt = e0 + e1;
+            const float q0 = e0 / tt, q1 = e1 / tt;
+            // symmetric normalisation: what the next iteration splats is Q * norm (inv holds norm = 1/sqrt(K 1) there); the final
+            // iteration (write_map) leaves the marginals themselves
+            const float sc = (sym && !write_map) ? inv : 1.f;
+            qs0 = q0 * sc;
+            qs1 = q1 * sc;
+            have_q = true;
+            if (!(SPLAT && tile)) {
+                Q[qi] = qs0;
+                Q[qi + 1] = qs1;
+            }
+            if (write_map) map[(long)f * Lt.N + p] = (q0 < q1) ? 1 : 0;
+        }
     }
-    float inv;
-    if (NORM) {
-        inv = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
-        Lt.inv[(long)f * Lt.N + p] = inv;
-    } else {
-        inv = Lt.inv[(long)f * Lt.N + p];
+    if (SPLAT && tile) {
+        __syncthreads();                                   // every lane has read its values: the space becomes the sums
+        for (int i = threadIdx.x; i < R * n; i += blockDim.x) { acc[i] = 0ull; acc[CAP + i] = 0ull; }
+        __syncthreads();
+        if (have_q) {
+            const int rep = tile_copy_of(threadIdx.x, R);
+#pragma unroll
+            for (int r = 0; r < nax; r++) {
+                const int sl = rep * n + sr[r];
+                atomicAdd(&acc[sl], (unsigned long long)__double2ll_rn((double)(qs0 * wr[r]) * FIX_SCALE));
+                atomicAdd(&acc[CAP + sl], (unsigned long long)__double2ll_rn((double)(qs1 * wr[r]) * FIX_SCALE));
+            }
+        }
+        __syncthreads();
+        tile_store_sums<0>(Lt, f, blockIdx.y, n, R, acc);
     }
-    const long qi = ((long)f * Lt.N + p) * MLAB;
-    float n0, n1;
-    if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
-    else { n0 = next[qi]; n1 = next[qi + 1]; }
-    n0 += Lt.w * (s0 * inv);
-    n1 += Lt.w * (s1 * inv);
-    if (!last) { next[qi] = n0; next[qi + 1] = n1; return; }
-    const float mx = n0 < n1 ? n1 : n0;
-    const float e0 = __expf(n0 - mx), e1 = __expf(n1 - mx);
-    const float tt = e0 + e1;
-    const float q0 = e0 / tt, q1 = e1 / tt;
-    // symmetric normalisation: what the next iteration splats is Q * norm (inv holds norm = 1/sqrt(K 1) there); the final
-    // iteration (write_map) leaves the marginals themselves
-    const float sc = (sym && !write_map) ? inv : 1.f;
-    Q[qi] = q0 * sc;
-    Q[qi + 1] = q1 * sc;
-    if (write_map) map[(long)f * Lt.N + p] = (q0 < q1) ? 1 : 0;
 }
 
 // symmetric normalisation: Q *= norm before the first splat
@@ -1658,7 +1719,7 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
-    hipLaunchKernelGGL(pk_fill_kernel, ge, dim3(256), 0, st, L);
+    hipLaunchKernelGGL(pk_fill_kernel, dim3(F, 2048), dim3(256), 0, st, L);        // (returns at once on tile-mode frames)
     hipLaunchKernelGGL(tile_list_kernel, dim3(F, 256), dim3(256), 0, st, L);
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
     PD_LAUNCH(L.pd, pk_neighbours_kernel, dim3(F, 2048), dim3(256), st, L);
@@ -1742,8 +1803,9 @@ int lattice_built(Lattice &L, int F, hipStream_t st) {
 // the splat of one filter pass: the per-tile sums of the frames in tile mode (the kernel returns at once on the others), then the
 // vertex pass -- the list walk over the entries, or the sum of a vertex's few per-tile partial sums
 template <int MODE>
-void launch_splat(Lattice &L, int F, const float *Q, void *out, float *outz, hipStream_t st) {
-    if (L.tile_splat && !(L.tune & 16)) hipLaunchKernelGGL(splat_tile_kernel<MODE>, dim3(F, L.tiles), dim3(256), 0, st, L, Q);
+void launch_splat(Lattice &L, int F, const float *Q, void *out, float *outz, hipStream_t st, bool tiles_done = false) {
+    // tiles_done: the previous pass's slice already summed this pass's marginals per tile (slice_kernel SPLAT)
+    if (L.tile_splat && !(L.tune & 16) && !tiles_done) hipLaunchKernelGGL(splat_tile_kernel<MODE>, dim3(F, L.tiles), dim3(256), 0, st, L, Q);
     // (frames, 768): measured over 256 ... 4096 workgroups per frame -- the list walk of natural frames 233 us per pass of 8 frames
     // against 240 at 4096, the tile-mode vertex pass 154 against 162 (a few 10^4 vertices per frame: most of 4096 x 256 lanes only
     // start and stop), noise frames the same at every size
@@ -1766,8 +1828,17 @@ int build_lattice_norm(Lattice &L, int F, hipStream_t st) {
 }
 
 // tmp-free filter + Potts + softmax epilogue for one potential
+#define SLICE_LAUNCH(NORMv, SPLATv, zptr)                                                                                        \
+    do {                                                                                                                         \
+        if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, NORMv, SPLATv>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)(zptr)); \
+        else if (L.pd == 2) hipLaunchKernelGGL((slice_kernel<2, NORMv, SPLATv>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)(zptr)); \
+        else hipLaunchKernelGGL((slice_kernel<0, NORMv, SPLATv>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)(zptr)); \
+    } while (0)
+
+// tiles_done: this pass's per-tile sums exist already (the previous pass's slice made them); fuse_next: this pass's slice makes the
+// next pass's (single potential, not the last iteration, tile splat available: crf_infer)
 int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *next, float *Qout, short *map,
-                  int first, int last, int write_map, hipStream_t st) {
+                  int first, int last, int write_map, hipStream_t st, bool tiles_done = false, bool fuse_next = false) {
     static const int GRIDS[8] = {1024, 256, 384, 512, 768, 2048, 128, 192};    // (L.tune >> 1) & 7: lab only
     const dim3 gv(F, GRIDS[(L.tune >> 1) & 7]), gp(F, rcf_cdiv(L.W, 16) * rcf_cdiv(L.N / L.W, 16));     // (frames, 16 x 16 tiles): see splat_gather_kernel
     const bool pairs = !(L.tune & 1);                          // RCF_CRF_BLUR_SEQUENTIAL: one launch per axis (tests, A/B)
@@ -1775,7 +1846,7 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
     if (L.norm_pending) {
         // the build's key array is dead by now: its 16 bytes per entry hold the two homogeneous-channel buffers
         float *za = reinterpret_cast<float *>(L.keys), *zb = za + (size_t)F * L.E;
-        launch_splat<2>(L, F, Q, (void *)a, za, st);
+        launch_splat<2>(L, F, Q, (void *)a, za, st);             // (never tiles_done: the first pass of a call)
         for (int axis = 0; axis <= L.pd; axis++) {
             if (pairs && axis + 1 <= L.pd) {
                 hipLaunchKernelGGL(blur_pair_kernel<true>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)za, zb);
@@ -1786,14 +1857,13 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
             float2 *t = a; a = b; b = t;
             float *tz = za; za = zb; zb = tz;
         }
-        if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
-        else if (L.pd == 2) hipLaunchKernelGGL((slice_kernel<2, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
-        else hipLaunchKernelGGL((slice_kernel<0, true>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)za);
+        if (fuse_next) SLICE_LAUNCH(true, true, za);
+        else SLICE_LAUNCH(true, false, za);
         RCF_LAUNCH_CHECK();
         L.norm_pending = 0;
         return 0;
     }
-    launch_splat<0>(L, F, Q, (void *)a, nullptr, st);
+    launch_splat<0>(L, F, Q, (void *)a, nullptr, st, tiles_done);
     for (int axis = 0; axis <= L.pd; axis++) {
         if (pairs && axis + 1 <= L.pd) {
             hipLaunchKernelGGL(blur_pair_kernel<false>, gv, dim3(256), 0, st, L, axis, (const float2 *)a, b, (const float *)nullptr, (float *)nullptr);
@@ -1803,9 +1873,8 @@ int apply_lattice(Lattice &L, int F, const float *Q, const float *unary, float *
         }
         float2 *t = a; a = b; b = t;
     }
-    if (L.pd == 5) hipLaunchKernelGGL((slice_kernel<5, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
-    else if (L.pd == 2) hipLaunchKernelGGL((slice_kernel<2, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
-    else hipLaunchKernelGGL((slice_kernel<0, false>), gp, dim3(256), 0, st, L, (const float2 *)a, unary, next, Qout, map, first, last, write_map, L.sym, (const float *)nullptr);
+    if (fuse_next) SLICE_LAUNCH(false, true, nullptr);
+    else SLICE_LAUNCH(false, false, nullptr);
     RCF_LAUNCH_CHECK();
     return 0;
 }
@@ -1838,10 +1907,15 @@ int crf_infer(const uint8_t *rgb, const float *unary, int W, int H, int F, float
         hipLaunchKernelGGL(scale_q_kernel, dim3(rcf_cdiv(n, 256)), dim3(256), 0, st, b.cur, (has_a ? b.app : b.smooth).inv, n);
         RCF_LAUNCH_CHECK();
     }
+    // one potential: the slice of a pass hands its marginals straight to the next pass's per-tile sums (slice_kernel SPLAT) on the
+    // frames in tile mode; tune bit 6 (RCF_CRF_SLICE_SPLAT_SEPARATE): two kernels as with two potentials (tests, A/B)
+    Lattice &one = has_a ? b.app : b.smooth;
+    const bool fuse = npot == 1 && one.tile_splat && !(one.tune & (16 | 64));
     for (int it = 0; it < iters; it++) {
         const int wm = (it == iters - 1) ? 1 : 0;
-        if (has_s) if (int e = apply_lattice(b.smooth, F, b.cur, unary, b.next, b.cur, (short *)out_map, 1, has_a ? 0 : 1, wm, st)) return e;
-        if (has_a) if (int e = apply_lattice(b.app, F, b.cur, unary, b.next, b.cur, (short *)out_map, has_s ? 0 : 1, 1, wm, st)) return e;
+        const bool done = fuse && it > 0, nxt = fuse && it + 1 < iters;
+        if (has_s) if (int e = apply_lattice(b.smooth, F, b.cur, unary, b.next, b.cur, (short *)out_map, 1, has_a ? 0 : 1, wm, st, done, nxt)) return e;
+        if (has_a) if (int e = apply_lattice(b.app, F, b.cur, unary, b.next, b.cur, (short *)out_map, has_s ? 0 : 1, 1, wm, st, done, nxt)) return e;
     }
     if (q_out) CK(hipMemcpyAsync(q_out, b.cur, n * MLAB * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (nvert) {                                        // [F][2]: vertices of the position / appearance lattice (one launch)
@@ -1893,8 +1967,9 @@ extern "C" int rcf_crf_soft_ex(const uint8_t *rgb, const float *unary, int W, in
                                int normalization, int16_t *out_map, float *q_out, int32_t *nvert, void *workspace,
                                size_t workspace_bytes, void *stream) {
     // bits 8-9: lattice build (RCF_CRF_BUILD_*: tests and A/B measurements; identical results)
-    // bits 10-15: iteration variants (RCF_CRF_BLUR_SEQUENTIAL; lab grids) -- they travel to crf_infer above the build's two bits
-    const int build = ((normalization >> 8) & 3) | (((normalization >> 10) & 0x3f) << 4);
+    // bits 10-17: iteration variants (RCF_CRF_BLUR_SEQUENTIAL; lab grids; RCF_CRF_SPLAT_*; RCF_CRF_SLICE_SPLAT_SEPARATE) -- they
+    // travel to crf_infer above the build's two bits
+    const int build = ((normalization >> 8) & 3) | (((normalization >> 10) & 0xff) << 4);
     normalization &= 0xff;
     if (normalization != 0 && normalization != 1) return RCF_EINVAL;
     return crf_soft_impl(rgb, unary, W, H, batch, scomp_smooth, sxy_smooth, scomp_app, sxy_app, srgb_app, iters,

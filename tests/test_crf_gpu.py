@@ -302,16 +302,18 @@ def test_crf_tile_splat_identical(kind, size, params, iters, sym, report):
     vertex list in LDS (splat_tile_kernel: 64-bit fixed-point atomics, one flush per distinct vertex of the tile) and build no CSR
     list.  Against the gather over the CSR lists (RCF_CRF_SPLAT_GATHER): MAP, marginals and vertex counts bit for bit -- by the
     default rule, with the tile splat forced on every frame (noise: ~1 536 distinct vertices per tile), on sizes with partial tiles,
-    with the position kernel on, under the symmetric normalisation (the stand-alone homogeneous-channel pass), and through the
-    overflow path of the packed build (small table)."""
+    with the position kernel on, under the symmetric normalisation (the stand-alone homogeneous-channel pass), through the
+    overflow path of the packed build (small table), and with the slice handing its marginals straight to the next pass's per-tile
+    sums (one potential: the default) or not (RCF_CRF_SLICE_SPLAT_SEPARATE)."""
     H, W = size
     F = 3 if H < 400 else 2
     gen = synth.smooth_rgb if kind == "smooth" else synth.noise_rgb
     rgb = torch.from_numpy(np.stack([gen(H, W, 4700 + i) for i in range(F)])).to(DEV)
     un = torch.from_numpy(np.stack([_unary(synth.soft_blob_mask(H, W, 4700 + i)) for i in range(F)])).to(DEV)
-    GATHER, TILES, SMALL = 0x4000 >> 8, 0x8000 >> 8, 2
+    GATHER, TILES, SEPARATE, SMALL = 0x4000 >> 8, 0x8000 >> 8, 0x10000 >> 8, 2
     out = {}
-    for name, flags in (("gather", GATHER), ("default", 0), ("tiles", TILES), ("tiles+overflow", TILES | SMALL)):
+    for name, flags in (("gather", GATHER), ("default", 0), ("tiles", TILES), ("tiles+overflow", TILES | SMALL),
+                        ("tiles, slice and sums apart", TILES | SEPARATE)):
         out[name] = crf_soft_batched(rgb, un, W, H, *params, iters, want_q=True, want_nvert=True, symmetric=sym, build=flags)
     same = {k: all(bool(torch.equal(a, b)) for a, b in zip(out["gather"], v)) for k, v in out.items() if k != "gather"}
     report(f"crf tile splat vs gather ({kind} {H}x{W}, params {params}, T={iters}, symmetric {sym}): MAP / Q / vertex counts "
