@@ -220,7 +220,11 @@ __device__ __forceinline__ void block_amax(unsigned mx, unsigned *__restrict__ a
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     if ((threadIdx.x & 63) == 0) sh_amax[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax, max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3])));
+    if (threadIdx.x == 0) {
+        // only while it raises the running maximum: thousands of atomics onto one address are served one after the other
+        const unsigned m = max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3]));
+        if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+    }
 }
 
 template <typename XT, int V>

@@ -1019,6 +1019,9 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // lists of up to SHORT entries are summed by their own lane (noise-like images: ~1 entry per vertex),
 // longer lists (smooth images: tens to thousands of entries) by the whole wavefront, one after another.
 constexpr int SHORT_LIST = 6;
+// (Round 6, measured and dropped: round(p 2^40) in integer arithmetic -- the float's significand shifted by its exponent, rounded to
+// even by hand; bit-identical on 144 calls (tools/crf_hashes.py) and 3-7 % SLOWER than __double2ll_rn((double)p * 2^40): fp64
+// multiply and the conversion run at full rate on this chip, the 64-bit shifts and selects of the integer form do not pay.)
 // MODE 0: the two label channels (Q0*w, Q1*w) -> float2.  MODE 1: the homogeneous channel (w) -> float; it does not
 // depend on Q, so it is splatted, blurred and sliced ONCE per lattice (build_lattice) instead of every iteration
 // (same operations on the same inputs as the reference's third value channel: bit-identical normalisation).
@@ -1357,6 +1360,7 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
     const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
     const int nax = (PD ? PD : Lt.pd) + 1;
+    constexpr int NAXC = PD ? PD + 1 : PD_MAX + 1;        // compile-time loop bound (PD = 0: guarded by nax)
     const long fb = (long)f * Lt.E;
     // tile mode: the tile's distinct vertices are a short list (the build's): their values are fetched ONCE into LDS and a pixel
     // reads them by its entries' list positions (2 bytes each) instead of gathering 8 bytes per entry by vertex id
@@ -1389,7 +1393,8 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     if (live) {
         float s0 = 0, s1 = 0, sw = 0;
 #pragma unroll
-        for (int r = 0; r < nax; r++) {
+        for (int r = 0; r < NAXC; r++) {
+            if (!PD && r >= nax) break;
             const long pe = fb + (long)r * Lt.N + p;
             const float wgt = Lt.weight[pe];
             float2 v;
@@ -1449,7 +1454,8 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
         if (have_q) {
             const int rep = tile_copy_of(threadIdx.x, R);
 #pragma unroll
-            for (int r = 0; r < nax; r++) {
+            for (int r = 0; r < NAXC; r++) {
+                if (!PD && r >= nax) break;
                 const int sl = rep * n + sr[r];
                 atomicAdd(&acc[sl], (unsigned long long)__double2ll_rn((double)(qs0 * wr[r]) * FIX_SCALE));
                 atomicAdd(&acc[CAP + sl], (unsigned long long)__double2ll_rn((double)(qs1 * wr[r]) * FIX_SCALE));

@@ -479,7 +479,10 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax, max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+    if (threadIdx.x == 0) {
+        const unsigned m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));       // (only while it raises the running maximum)
+        if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+    }
 }
 
 // one K=16 step: 6 x MR x NR MFMAs (32x32x16 bf16), smallest partial products first.
@@ -1132,7 +1135,10 @@ __global__ void __launch_bounds__(256) wprep_absmax_kernel(const rcf_wprep_entry
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(t.amax, max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+    if (threadIdx.x == 0) {
+        const unsigned m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+        if (m > __hip_atomic_load(t.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(t.amax, m);
+    }
 }
 
 // out = [pairs | pairs2 (flags bit 0)] of rcf_conv_weight_pairs2_f32(transpose = 0): the same values as weight_pairs_kernel<false>
