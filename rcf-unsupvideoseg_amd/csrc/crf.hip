@@ -649,9 +649,22 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     unsigned long long *cursor = Lt.cursor64 + (long)f * 2 * Lt.E;
     const unsigned nb = phase == 0 ? (unsigned)min((long)Lt.cap_small, 2 * Lt.E) : (unsigned)(2 * Lt.E);
     int mine = 0;
-    for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x) {
+    // The distinct keys first become a dense list (its order is the tile's vertex list): a key's insert is two or three DEPENDENT
+    // device-scope round trips, and a thread that owned several of the ~150 occupied slots among its eight walked them one after the
+    // other -- dense, every thread has at most one key on a natural frame and the tile waits for one chain (round 6).
+    for (int i = threadIdx.x; i < LT_SLOTS; i += blockDim.x)
+        if (lkey[i] != PK_EMPTY) lgs[atomicAdd(&ntile, 1)] = (unsigned)i;           // (lgs is free until the inserts write it)
+    __syncthreads();
+    constexpr int KPT = LT_SLOTS / 256;                      // keys per thread at most (the list has <= 256 (pd + 1) <= LT_SLOTS entries)
+    int mykey[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) mykey[j] = threadIdx.x + 256 * j < ntile ? (int)lgs[threadIdx.x + 256 * j] : -1;
+    __syncthreads();                                         // every index is in registers: lgs may be overwritten
+#pragma unroll
+    for (int j = 0; j < KPT; j++) {
+        const int i = mykey[j], ti = threadIdx.x + 256 * j;
+        if (i < 0) continue;
         const unsigned long long k = lkey[i];
-        if (k == PK_EMPTY) continue;
         short key[PD_MAX];
         unpack64(k, pd, key);
         unsigned h = key_hash(key, pd) % nb;
@@ -675,9 +688,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
         // ONE atomic reserves the tile's share of the vertex's CSR range (low half) and numbers the tile among the vertex's tiles
         const unsigned long long old = placed ? atomicAdd(cursor + h, (unsigned long long)lcnt[i] | (1ull << 32)) : 0ull;
         lbase[i] = (unsigned)old;
-        // the tile's list of distinct vertices (tile splat): position in arrival order -- the sums are order independent
-        const int ti = atomicAdd(&ntile, 1);
-        lcnt[i] = (unsigned)ti;                                  // (the count is spent)
+        lcnt[i] = (unsigned)ti;                                  // (the count is spent) the key's place in the tile's vertex list
         tl[ti] = (int)h;
         tp[ti] = (int)(old >> 32);
     }
@@ -1175,14 +1186,15 @@ __device__ __forceinline__ int tile_copies(int n, int stride) {
 }
 __device__ __forceinline__ int tile_copy_of(int tid, int R) { return ((tid & 15) + 4 * (tid >> 4)) & (R - 1); }
 // the tile's sums (channel c of list position i, copy k: acc[c * CAP + k * n + i]) -> the partial sums this tile owns
+// pos0: tl[threadIdx.x], asked for by the caller before its barriers (natural frames: the whole list is <= 256 long)
 template <int MODE>
-__device__ __forceinline__ void tile_store_sums(const Lattice &Lt, int f, int t, int n, int R, const unsigned long long *acc) {
+__device__ __forceinline__ void tile_store_sums(const Lattice &Lt, int f, int t, int n, int R, const unsigned long long *acc, int pos0) {
     constexpr int NCH = MODE == 2 ? 3 : (MODE == 1 ? 1 : 2);
     constexpr int CAP = 256 * (PD_MAX + 1);
     const int *tl = Lt.tlist + ((long)f * Lt.tiles + t) * 256 * (Lt.pd + 1);
     unsigned long long *g = reinterpret_cast<unsigned long long *>(Lt.accg) + (long)f * Lt.E * 3;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const long pos = tl[i];                              // this tile's partial sum of the vertex: nobody else writes it
+        const long pos = i < 256 ? pos0 : tl[i];             // this tile's partial sum of the vertex: nobody else writes it
         unsigned long long a[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -1208,20 +1220,35 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
     const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
     const int R = tile_copies(n, stride);
     const int rep = tile_copy_of(threadIdx.x, R);
+    const long fb = (long)f * Lt.E;
+    const bool live = py < H && px < W;
+    const int p = live ? py * W + px : 0;
+    // everything the pixel reads from memory is asked for before the first barrier
+    float wr[PD_MAX + 1];
+    int sr[PD_MAX + 1];
+    float2 q = make_float2(0.f, 0.f);
+    if (live) {
+        if (MODE != 1) q = *reinterpret_cast<const float2 *>(Q + ((long)f * Lt.N + p) * MLAB);
+#pragma unroll
+        for (int r = 0; r <= PD_MAX; r++) {
+            if (r >= nax) break;
+            const long e = fb + (long)r * Lt.N + p;
+            wr[r] = Lt.weight[e];
+            sr[r] = Lt.tslot[e];
+        }
+    }
+    const int pos0 = (int)threadIdx.x < n ? Lt.tlist[((long)f * Lt.tiles + blockIdx.y) * stride + threadIdx.x] : 0;
     for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
 #pragma unroll
         for (int c = 0; c < NCH; c++) acc[c * CAP + i] = 0ull;
     }
     __syncthreads();
-    const long fb = (long)f * Lt.E;
-    if (py < H && px < W) {
-        const int p = py * W + px;
-        float2 q = make_float2(0.f, 0.f);
-        if (MODE != 1) q = *reinterpret_cast<const float2 *>(Q + ((long)f * Lt.N + p) * MLAB);
-        for (int r = 0; r < nax; r++) {
-            const long e = fb + (long)r * Lt.N + p;
-            const float wgt = Lt.weight[e];
-            const int s = rep * n + Lt.tslot[e];
+    if (live) {
+#pragma unroll
+        for (int r = 0; r <= PD_MAX; r++) {
+            if (r >= nax) break;
+            const float wgt = wr[r];
+            const int s = rep * n + sr[r];
             if (MODE == 1) {
                 atomicAdd(&acc[s], (unsigned long long)__double2ll_rn((double)wgt * FIX_SCALE));
             } else {
@@ -1232,7 +1259,7 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
         }
     }
     __syncthreads();
-    tile_store_sums<MODE>(Lt, f, blockIdx.y, n, R, acc);
+    tile_store_sums<MODE>(Lt, f, blockIdx.y, n, R, acc, pos0);
 }
 
 __device__ __forceinline__ float2 blur3(float2 p, float2 m, float2 q) {
@@ -1372,9 +1399,29 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
     float2 *sval = SPLAT ? reinterpret_cast<float2 *>(acc) : sval_own;
     float *szv = SPLAT ? reinterpret_cast<float *>(acc + CAP) : szv_own;
     const bool tile = tile_mode(Lt, f);                   // (uniform)
-    int n = 0, R = 1;
+    const bool live = py < H && px < W;
+    const int p = live ? py * W + px : 0;
+    // the pixel's own streams (weights, list positions, normaliser, unary) are asked for BEFORE the tile's values are staged: they
+    // depend on nothing in LDS, and behind the barrier their latency would come on top of the staging gather's
+    float wr[PD_MAX + 1];
+    int sr[PD_MAX + 1];
+    float inv_pre = 0.f;
+    float2 un_pre = make_float2(0.f, 0.f);
+    if (tile && live) {
+#pragma unroll
+        for (int r = 0; r < NAXC; r++) {
+            if (!PD && r >= nax) break;
+            const long pe = fb + (long)r * Lt.N + p;
+            wr[r] = Lt.weight[pe];
+            sr[r] = Lt.tslot[pe];
+        }
+        if (!NORM) inv_pre = Lt.inv[(long)f * Lt.N + p];
+        if (first) un_pre = *reinterpret_cast<const float2 *>(unary + ((long)f * Lt.N + p) * MLAB);
+    }
+    int n = 0, R = 1, pos0 = 0;
     if (tile) {
         n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
+        if (SPLAT && (int)threadIdx.x < n) pos0 = Lt.tlist[((long)f * Lt.tiles + blockIdx.y) * 256 * nax + threadIdx.x];
         const int *tv = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int vi = tv[i];
@@ -1384,10 +1431,6 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
         if (SPLAT) R = tile_copies(n, 256 * nax);
         __syncthreads();
     }
-    const bool live = py < H && px < W;
-    const int p = live ? py * W + px : 0;
-    float wr[PD_MAX + 1];
-    int sr[PD_MAX + 1];
     float qs0 = 0.f, qs1 = 0.f;
     bool have_q = false;
     if (live) {
@@ -1396,15 +1439,15 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
         for (int r = 0; r < NAXC; r++) {
             if (!PD && r >= nax) break;
             const long pe = fb + (long)r * Lt.N + p;
-            const float wgt = Lt.weight[pe];
+            float wgt;
             float2 v;
             float zz = 0.f;
             if (tile) {
-                const int sl = Lt.tslot[pe];
-                v = sval[sl];
-                if (NORM) zz = szv[sl];
-                if (SPLAT) { wr[r] = wgt; sr[r] = sl; }
+                wgt = wr[r];
+                v = sval[sr[r]];
+                if (NORM) zz = szv[sr[r]];
             } else {
+                wgt = Lt.weight[pe];
                 const int vi = Lt.vid[pe];
                 v = val[fb + vi];
                 if (NORM) zz = z[fb + vi];
@@ -1418,12 +1461,18 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
             inv = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
             Lt.inv[(long)f * Lt.N + p] = inv;
         } else {
-            inv = Lt.inv[(long)f * Lt.N + p];
+            inv = tile ? inv_pre : Lt.inv[(long)f * Lt.N + p];
         }
         const long qi = ((long)f * Lt.N + p) * MLAB;
         float n0, n1;
-        if (first) { n0 = -unary[qi]; n1 = -unary[qi + 1]; }
-        else { n0 = next[qi]; n1 = next[qi + 1]; }
+        if (first) {
+            if (!tile) un_pre = *reinterpret_cast<const float2 *>(unary + qi);
+            n0 = -un_pre.x;
+            n1 = -un_pre.y;
+        } else {
+            n0 = next[qi];
+            n1 = next[qi + 1];
+        }
         n0 += Lt.w * (s0 * inv);
         n1 += Lt.w * (s1 * inv);
         if (!last) {
@@ -1462,7 +1511,7 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
             }
         }
         __syncthreads();
-        tile_store_sums<0>(Lt, f, blockIdx.y, n, R, acc);
+        tile_store_sums<0>(Lt, f, blockIdx.y, n, R, acc, pos0);
     }
 }
 
