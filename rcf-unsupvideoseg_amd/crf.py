@@ -89,11 +89,12 @@ class CRFHead(nn.Module):
         self._mean, self._std = tuple(mean), tuple(std)
         self._consts = None
         # lattice build of the next call: "auto" = from the vertex counts of the PREVIOUS call (noise-like content -- more than
-        # SORT_ABOVE vertices per frame in the appearance lattice -- takes the sort build, RCF_CRF_BUILD_SORT, until a call comes
-        # in below SORT_BELOW); True / False = always / never.  Measured (tools/time_crf.py, profiles/r05_crf_sort_build.txt): the
-        # sort build wins from ~1.4 x 10^5 vertices per frame up (noise-like frames of any size), loses below ~7 x 10^4 (natural
-        # frames: 0.30 vs 0.43 ms per 480x854 frame).  The counts travel to the host by an asynchronous copy that is
-        # only read once its event has completed: no host wait, and the masks do not depend on the choice.
+        # SORT_ABOVE x (6 entries per pixel) vertices per frame in the appearance lattice -- takes the sort build,
+        # RCF_CRF_BUILD_SORT, until a call comes in below SORT_BELOW); True / False = always / never.  Measured with the round-6
+        # tile splat (tools/crf_texture_sweep.py, profiles/r06_crf_texture_sweep.txt: 480x854 frames with more and more pixel
+        # noise): at 10 % vertices per entry the packed build is ahead (0.50 vs 0.53 ms per frame, T = 5; per pass equal), at 14 %
+        # the sort build (0.60 vs 0.65; per pass 439 vs 503 us); clean natural frames sit at 3 % (0.15 vs 0.41).  The counts travel
+        # to the host by an asynchronous copy that is never waited for, and the masks do not depend on the choice.
         # The choice is a heuristic on counts that are one or two calls old and read without synchronisation: it may differ from
         # run to run and rank to rank BY DESIGN -- every build gives bit-identical masks (tests/test_crf_gpu.py).
         self.sort_build = "auto"
@@ -101,7 +102,7 @@ class CRFHead(nn.Module):
         self._nv_host = None
         self._sorting = False
 
-    SORT_ABOVE, SORT_BELOW = 120000, 90000
+    SORT_ABOVE, SORT_BELOW = 0.12, 0.09          # vertices per entry (6 entries per pixel)
 
     def _pick_build(self, npix):
         if self.sort_build != "auto":
@@ -112,7 +113,7 @@ class CRFHead(nn.Module):
             # 0.3 ms per frame here: its release flushes the caches the next call's kernels were about to hit)
             verts = float(self._nv_host[:, 1].float().mean())
             if verts > 0:
-                self._sorting = verts > (self.SORT_BELOW if self._sorting else self.SORT_ABOVE)
+                self._sorting = verts > (self.SORT_BELOW if self._sorting else self.SORT_ABOVE) * 6 * npix
         return 3 if self._sorting else 0
 
     def _note_counts(self, nv):

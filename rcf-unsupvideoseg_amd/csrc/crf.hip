@@ -106,13 +106,15 @@ __device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
            (Lt.stat[4 * f] > Lt.cap_small / 2 || Lt.stat[4 * f + 1] != 0 || Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
 }
 __device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : (long)Lt.cap_small; }
-// does frame f take the tile splat?  Its tiles' lists together hold at most a quarter as many vertices as the frame has entries
-// (smooth 480x854 frames: ~5 %; noise: ~100 %, and those frames go through the sort build, which writes no lists).
+// does frame f take the tile splat?  Its tiles' lists together hold at most 0.6 x as many vertices as the frame has entries.  Measured on
+// natural-looking 480x854 frames with +-0 ... +-64 of pixel noise on top (tools/crf_texture_sweep.py, profiles/r06_crf_texture_sweep.txt):
+// the tile splat beats the list walk while the lists total <= ~0.67 E (+-16: 0.655 against 0.684 ms per frame; +-20, 0.7 E: 0.82 against
+// 0.81), by 35-40 % on clean frames (lists ~0.1 E); beyond, every entry is nearly its own vertex and the sort build is the one to take.
 // tune bit 4 (RCF_CRF_SPLAT_GATHER): never; bit 5 (RCF_CRF_SPLAT_TILES): whenever the lists exist (tests).
-constexpr int TILE_SPLAT_RATIO = 4;
+constexpr long TILE_SPLAT_NUM = 3, TILE_SPLAT_DEN = 5;
 __device__ __forceinline__ bool tile_mode(const Lattice &Lt, int f) {
     if (!Lt.tile_splat || (Lt.tune & 16)) return false;
-    return (Lt.tune & 32) || (long)Lt.stat[4 * f + 3] * TILE_SPLAT_RATIO <= Lt.E;
+    return (Lt.tune & 32) || (long)Lt.stat[4 * f + 3] * TILE_SPLAT_DEN <= TILE_SPLAT_NUM * Lt.E;
 }
 
 __device__ __forceinline__ unsigned key_hash(const short *key, int pd) {

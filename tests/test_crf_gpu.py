@@ -137,7 +137,7 @@ def test_crf_head_picks_the_sort_build_for_noise_like_content(report):
     """CRFHead chooses the lattice build from the vertex counts of its PREVIOUS call (an asynchronous copy, no host wait): noise-like
     frames switch it to the sort build, natural ones back; the masks do not depend on the choice"""
     from rcf_amd import synth
-    H, W, n = 120, 214, 4
+    H, W, n = 480, 854, 2            # (the rule is in vertices per entry: 3 % on natural frames of this size, ~70-90 % on noise)
     head = rcf_amd.CRFHead(None, refine_iters=5)
     ref = rcf_amd.CRFHead(None, refine_iters=5)
     ref.sort_build = False
