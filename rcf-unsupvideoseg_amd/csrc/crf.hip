@@ -62,11 +62,12 @@ struct Lattice {           // device pointers of one potential, for all frames (
     int *slot_vid2;              // [F][2E]  bucket -> dense vertex id (-1 empty)
     int *slot_off;               // [F][2E]  bucket -> CSR offset
     int *blocksum2;              // [F][2][nblk2+1]
-    // The table is first tried with `cap_small` buckets (a natural 480x854 frame has ~7e4 distinct keys: the table
-    // then stays in the frame's L2 and the bucket scans are short); a frame that fills more than half of them, or
-    // needs a probe longer than PK_PROBE_LIMIT, is inserted again into all 2E buckets.
+    // The table is first tried with pk_cap(f) buckets -- `cap_small` (a natural 480x854 frame has ~7e4 distinct keys: the table
+    // then stays in the frame's L2 and the bucket scans are short) or, from the sampled estimate, a larger power of two; a
+    // frame that fills more than half of them, or needs a probe longer than PK_PROBE_LIMIT, is inserted again into all 2E buckets.
     int cap_small;
-    int *stat;                   // [F][4]  distinct keys of the small attempt, probe-limit flag, sampled distinct keys, -
+    int est;                     // host side: pk_estimate_kernel ran for this build (stat[4 f + 2] sizes the first attempt: pk_cap)
+    int *stat;                   // [F][4]  distinct keys of the first attempt, probe-limit flag, sampled distinct keys, total length of the tiles' lists
     int sym;                     // 1: DenseCRF2D's symmetric kernel normalisation (rcf_crf_soft_ex), set per call by crf_infer
     int norm_pending;            // host side: the normaliser of this lattice is still to come out of its first filter pass
     // sort build (build 3): rocPRIM's temporary storage, sized for F * E pairs
@@ -95,17 +96,35 @@ struct Lattice {           // device pointers of one potential, for all frames (
 };
 
 constexpr int PK_PROBE_LIMIT = 256;
-// pk_estimate_kernel: PK_SAMPLES blocks of 256 pixels per frame, spread over the image; a frame whose sampled blocks hold
-// more than half as many distinct keys as entries (noise-like content: ~1 key per entry; smooth content: a few percent)
-// cannot fit the small table and goes straight to the full one -- without this every workgroup of the first attempt
-// probes a table that is 10x over-subscribed (uniform-noise frames: 12.7 ms of the 25 ms build per 8 frames).
+// pk_estimate_kernel: PK_SAMPLES blocks of 256 pixels per frame, spread over the image; the number of keys that are distinct
+// within their block (noise-like content: ~1 key per entry; clean natural content: a third) sizes the frame's table (pk_cap below)
+// -- without it every workgroup of a noise frame's first attempt probed a table that was 10x over-subscribed (uniform-noise frames:
+// 12.7 ms of the 25 ms build per 8 frames, round 3).
 constexpr int PK_SAMPLES = 64;
-constexpr int PK_SAMPLE_LIMIT = PK_SAMPLES * 256 * 6 / 2;
-__device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
-    return (long)Lt.cap_small < 2 * Lt.E &&
-           (Lt.stat[4 * f] > Lt.cap_small / 2 || Lt.stat[4 * f + 1] != 0 || Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
+// Buckets of frame f's FIRST attempt (round 6).  Rounds 3-5 knew two sizes: 2^18 for natural frames, all 2E for the rest -- and the
+// rest began at 1.3 x 10^5 vertices, i.e. at natural frames with +-4 of sensor noise, which then cleared, filled, scanned and probed a
+// 4.9 M-bucket table (480x854: 1.7 of a call's 3.2 ms at +-8).  Now the size follows the sampled estimate: s = the fraction of the
+// sampled entries that are distinct within their 256-pixel block; the vertices per entry of a frame stay under an envelope of s
+// (measured over natural-looking frames with +-0 ... +-64 of pixel noise, profiles/r06_crf_texture_sweep.txt: s 0.30 -> 0.03-0.04,
+// 0.6 -> 0.06-0.09, 0.8 -> 0.09-0.13, 0.87 -> 0.11-0.17, 0.94 -> 0.19-0.27, 0.97 -> 0.3-0.37); the table gets the next
+// 2^k - 1 above twice that many buckets.  A frame that fills more than half of it, or probes longer than PK_PROBE_LIMIT, is redone in
+// all 2E buckets as before.  No estimate (small frames; the tests' tiny table): cap_small.
+__device__ __forceinline__ long pk_cap(const Lattice &Lt, int f) {
+    const long full = 2 * Lt.E;
+    if (!Lt.est) return (long)Lt.cap_small < full ? (long)Lt.cap_small : full;
+    const long samp = (long)PK_SAMPLES * 256 * (Lt.pd + 1), S = Lt.stat[4 * f + 2];
+    const long pct = S * 100 / samp;
+    const double vpe = pct <= 37 ? 0.045 : pct <= 57 ? 0.075 : pct <= 80 ? 0.13 : pct <= 90 ? 0.175 : pct <= 95 ? 0.27 : 1.0;
+    const long want = (long)(2.0 * vpe * (double)Lt.E);
+    long cap = Lt.cap_small;
+    while (cap < want) cap = 2 * cap + 1;
+    return cap < full ? cap : full;
 }
-__device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : (long)Lt.cap_small; }
+__device__ __forceinline__ bool pk_overflowed(const Lattice &Lt, int f) {
+    const long cap = pk_cap(Lt, f);
+    return cap < 2 * Lt.E && (Lt.stat[4 * f] > cap / 2 || Lt.stat[4 * f + 1] != 0);
+}
+__device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk_overflowed(Lt, f) ? 2 * Lt.E : pk_cap(Lt, f); }
 // does frame f take the tile splat?  Its tiles' lists together hold at most 0.6 x as many vertices as the frame has entries.  Measured on
 // natural-looking 480x854 frames with +-0 ... +-64 of pixel noise on top (tools/crf_texture_sweep.py, profiles/r06_crf_texture_sweep.txt):
 // the tile splat beats the list walk while the lists total <= ~0.67 E (+-16: 0.655 against 0.684 ms per frame; +-20, 0.7 E: 0.82 against
@@ -537,16 +556,18 @@ __device__ __forceinline__ void unpack64(unsigned long long k, int pd, short *ke
     for (int i = 0; i < pd; i++) key[i] = (short)((int)((k >> (12 * i)) & 0xfffu) - 2048);
 }
 
-// buckets [0, n) of every frame's table <- empty (phase 0: n = cap_small and the attempt's statistics are reset;
-// phase 1: n = 2E, only for the frames whose small attempt overflowed)
+// the per-frame statistics <- 0 (before the estimate, which the table's size depends on)
+__global__ void pk_stat_reset_kernel(Lattice Lt, int F) {
+    for (int i = threadIdx.x; i < 4 * F; i += blockDim.x) Lt.stat[i] = 0;
+}
+// buckets [0, n) of every frame's table <- empty (phase 0: n = the first attempt's size, pk_cap; phase 1: n = 2E, only for the
+// frames whose first attempt overflowed)
 __global__ void __launch_bounds__(256) pk_clear_kernel(Lattice Lt, int phase) {
     const int f = blockIdx.x;
-    long n = Lt.cap_small;
+    long n = pk_cap(Lt, f);
     if (phase == 1) {
         if (!pk_overflowed(Lt, f)) return;
         n = 2 * Lt.E;
-    } else if (blockIdx.y == 0 && threadIdx.x < 4) {
-        Lt.stat[4 * f + threadIdx.x] = 0;            // read by nobody before the estimate / insert kernels that follow
     }
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
     unsigned long long *cursor = Lt.cursor64 + (long)f * 2 * Lt.E;
@@ -601,7 +622,8 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     __shared__ int newkeys, skip, ntile;
     const int pd = PD ? PD : Lt.pd, nax = pd + 1;
     const int f = blockIdx.x;                             // frame fastest: with 8 frames per call a frame's workgroups share one XCD
-    const bool small = phase == 0 && (long)Lt.cap_small < 2 * Lt.E;      // an attempt that may overflow
+    const long cap0 = pk_cap(Lt, f);
+    const bool small = phase == 0 && cap0 < 2 * Lt.E;                    // an attempt that may overflow
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
     int *tl = Lt.tlist + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
     int *tp = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
@@ -609,8 +631,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
         newkeys = 0;
         ntile = 0;
         // the attempt already failed for this frame: nothing this workgroup inserts will be used
-        skip = small && (__hip_atomic_load(Lt.stat + 4 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                         Lt.stat[4 * f + 2] > PK_SAMPLE_LIMIT);
+        skip = small && __hip_atomic_load(Lt.stat + 4 * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     }
     __syncthreads();
     if (skip) return;
@@ -649,7 +670,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     // the block's distinct keys: insert into the frame's table, reserve the block's share of the vertex's list
     unsigned long long *table = Lt.table + (long)f * 2 * Lt.E;
     unsigned long long *cursor = Lt.cursor64 + (long)f * 2 * Lt.E;
-    const unsigned nb = phase == 0 ? (unsigned)min((long)Lt.cap_small, 2 * Lt.E) : (unsigned)(2 * Lt.E);
+    const unsigned nb = phase == 0 ? (unsigned)cap0 : (unsigned)(2 * Lt.E);
     int mine = 0;
     // The distinct keys first become a dense list (its order is the tile's vertex list): a key's insert is two or three DEPENDENT
     // device-scope round trips, and a thread that owned several of the ~150 occupied slots among its eight walked them one after the
@@ -1703,6 +1724,7 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.accg = c.take<long long>(3 * FE);
     L.tile_splat = 0;
     L.cap_small = 0;
+    L.est = 0;
     L.sort_tmp_bytes = rcf_crf_sort_tmp_bytes(FE);
     L.sort_tmp = c.take<char>(L.sort_tmp_bytes);
 }
@@ -1763,9 +1785,10 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     const long small = L.build == 2 ? 1021 : ((1L << 18) - 1);
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
     L.tile_splat = 1;                                            // every kernel below sees it (the struct travels by value)
+    L.est = (L.build != 2 && L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES) ? 1 : 0;
+    hipLaunchKernelGGL(pk_stat_reset_kernel, dim3(1), dim3(64), 0, st, L, F);
+    if (L.est) PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
     hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 0);
-    if (L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES)
-        PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
     PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
     hipLaunchKernelGGL(pk_totals_kernel, dim3(F), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
