@@ -1800,7 +1800,7 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
     hipLaunchKernelGGL(pk_fill_kernel, dim3(F, 2048), dim3(256), 0, st, L);        // (returns at once on tile-mode frames)
-    hipLaunchKernelGGL(tile_list_kernel, dim3(F, 256), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(tile_list_kernel, dim3(F, L.tiles), dim3(256), 0, st, L);      // one workgroup per tile: two dependent gathers per entry
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
     PD_LAUNCH(L.pd, pk_neighbours_kernel, dim3(F, 2048), dim3(256), st, L);
     RCF_LAUNCH_CHECK();
