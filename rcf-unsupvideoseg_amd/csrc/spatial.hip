@@ -295,14 +295,27 @@ __global__ void __launch_bounds__(256) resize_rows_fwd_kernel(const T *__restric
 // resize_rows_fwd_kernel issues 16 (its 230 us per 420 MB of output were L2 read bandwidth: 7.3 TB/s of 16-byte gathers).
 // Same taps, same weights (src_index itself), same expression tree: hy (hx a + lx b) + ly (hx c + lx d) -- the horizontal blends
 // of the two source rows first, as there -- so the outputs are bit-identical.
+// frame > 0 (round 6): only the output pixels within `frame` of the border are written, and the grid holds only the source pixels
+// that have such an output -- the border frame of thickness ts = (frame + 1) / 2 of the source, enumerated by frame_yx, grid
+// (its pixels x channel vectors / 256, images).  The whole-tensor grid of resize_rows_fwd_kernel returned at once in 70 % of its
+// 8 x 10^5 workgroups on decode_head2's border band and spent 16 loads per output on the rest: 523 -> ~300 us.
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize2x_fwd_kernel(const T *__restrict__ x, int x_pitch, T *__restrict__ y,
-                                                           int y_pitch, int Hi, int Wi, int C) {
+                                                           int y_pitch, int Hi, int Wi, int C, int frame = 0, int ts = 0) {
     const int CV = C / V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int j = idx / CV, cv = idx - j * CV;
-    if (j >= Wi) return;
-    const int n = blockIdx.y / Hi, i = blockIdx.y - n * Hi;                 // block-uniform
+    int n, i, j;
+    const int q = idx / CV, cv = idx - q * CV;
+    if (frame > 0) {
+        if (q >= 2 * ts * Wi + 2 * ts * (Hi - 2 * ts)) return;
+        n = blockIdx.y;
+        frame_yx(q, Hi, Wi, ts, i, j);
+    } else {
+        j = q;
+        if (j >= Wi) return;
+        n = blockIdx.y / Hi;
+        i = blockIdx.y - n * Hi;                                            // block-uniform
+    }
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     const int rr[3] = {max(i - 1, 0), i, min(i + 1, Hi - 1)}, cc[3] = {max(j - 1, 0), j, min(j + 1, Wi - 1)};
     const T *base = x + (long)n * Hi * Wi * x_pitch + cv * V;
@@ -349,6 +362,7 @@ __global__ void __launch_bounds__(256) resize2x_fwd_kernel(const T *__restrict__
                     const float u = first ? h[1][b].q[q][e] : h[2][b].q[q][e];
                     o.q[q][e] = hy * t + ly * u;
                 }
+            if (frame > 0 && !in_frame(2 * i + a, 2 * j + b, Ho, Wo, frame)) continue;
             stv<T, V>(y + (((long)n * Ho + 2 * i + a) * Wo + 2 * j + b) * y_pitch + cv * V, o);
         }
     }
@@ -358,14 +372,27 @@ __global__ void __launch_bounds__(256) resize2x_fwd_kernel(const T *__restrict__
 // can reach it, one output row at a time -- 36 loads for 4 inputs where resize_rows_bwd_kernel issues 16 per input.  Every
 // input accumulates the same terms g * (wy * wx) (tap_weight itself, zero weights skipped) in the same order (output rows
 // upwards, columns upwards): bit-identical.
+// frame > 0 (round 6; beta = 1 only): dy counts as zero (and is not read) off the border frame, and the grid holds only the 2 x 2
+// input blocks within tb blocks of the border (the others see no frame pixel and, accumulating, have nothing to write): the same
+// terms in the same order as resize_rows_bwd_kernel's frame form, which gathered 16 taps per input pixel (686 us on
+// decode_head2's band in fp32: 4 GB of 16-byte L2 reads).
 template <typename T, int V>
 __global__ void __launch_bounds__(256) resize2x_bwd_kernel(const T *__restrict__ dy, int dy_pitch, T *__restrict__ dx,
-                                                           int dx_pitch, int beta, int Hi, int Wi, int C) {
+                                                           int dx_pitch, int beta, int Hi, int Wi, int C, int frame = 0, int tb = 0) {
     const int CV = C / V, Wh = (Wi + 1) >> 1, Hh = (Hi + 1) >> 1;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int j2 = idx / CV, cv = idx - j2 * CV;
-    if (j2 >= Wh) return;
-    const int n = blockIdx.y / Hh, i2 = blockIdx.y - n * Hh;                // block-uniform
+    int n, i2, j2;
+    const int q = idx / CV, cv = idx - q * CV;
+    if (frame > 0) {
+        if (q >= 2 * tb * Wh + 2 * tb * (Hh - 2 * tb)) return;
+        n = blockIdx.y;
+        frame_yx(q, Hh, Wh, tb, i2, j2);
+    } else {
+        j2 = q;
+        if (j2 >= Wh) return;
+        n = blockIdx.y / Hh;
+        i2 = blockIdx.y - n * Hh;                                           // block-uniform
+    }
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     const int i0 = 2 * i2, j0 = 2 * j2;
     fvec<V> acc[2][2];
@@ -392,6 +419,7 @@ __global__ void __launch_bounds__(256) resize2x_bwd_kernel(const T *__restrict__
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             if (wx[0][k] == 0.f && wx[1][k] == 0.f) continue;               // also: column out of range
+            if (frame > 0 && !in_frame(yo, xo0 + k, Ho, Wo, frame)) continue;
             const fvec<V> g = ldv<T, V>(row + (long)k * dy_pitch);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -658,11 +686,29 @@ extern "C" int rcf_resize_bilinear_nhwc_fwd_mp(const void *x, int x_pitch, void 
         (long)Wi * (C / 4) < (1L << 30)) {
         if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {
             hipLaunchKernelGGL((resize2x_fwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wi * (C / 8), 256), N * Hi), dim3(256), 0,
-                               rcf_stream(stream), (const bf16_t *)x, x_pitch, (bf16_t *)y, y_pitch, Hi, Wi, C);
+                               rcf_stream(stream), (const bf16_t *)x, x_pitch, (bf16_t *)y, y_pitch, Hi, Wi, C, 0, 0);
         } else {
 #define RCF_CALL(T)                                                                                                       \
     hipLaunchKernelGGL((resize2x_fwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wi * (C / 4), 256), N * Hi), dim3(256), 0,         \
-                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, C)
+                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, C, 0, 0)
+            RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+        }
+        RCF_LAUNCH_CHECK();
+        return 0;
+    }
+    // the border frame of an exact 2x up-sampling (decode_head2's commuted conv): the 2x kernel over the source pixels that reach it
+    const int ts = (frame + 1) / 2;
+    if (!general && frame > 0 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && 2 * ts < Hi && 2 * ts < Wi && N <= 65535 &&
+        (long)Wi * Hi * (C / 4) < (1L << 30)) {
+        const long Qs = 2L * ts * Wi + 2L * ts * (Hi - 2 * ts);
+        if (dt == RCF_BF16 && C % 8 == 0 && x_pitch % 8 == 0 && y_pitch % 8 == 0) {
+            hipLaunchKernelGGL((resize2x_fwd_kernel<bf16_t, 8>), dim3(rcf_cdiv(Qs * (C / 8), 256), N), dim3(256), 0,
+                               rcf_stream(stream), (const bf16_t *)x, x_pitch, (bf16_t *)y, y_pitch, Hi, Wi, C, frame, ts);
+        } else {
+#define RCF_CALL(T)                                                                                                       \
+    hipLaunchKernelGGL((resize2x_fwd_kernel<T, 4>), dim3(rcf_cdiv(Qs * (C / 4), 256), N), dim3(256), 0,                     \
+                       rcf_stream(stream), (const T *)x, x_pitch, (T *)y, y_pitch, Hi, Wi, C, frame, ts)
             RCF_DISPATCH1(dt, RCF_CALL);
 #undef RCF_CALL
         }
@@ -728,16 +774,38 @@ extern "C" int rcf_resize_bilinear_nhwc_bwd_mp(const void *dy, int dy_pitch, voi
         const int Hh = (Hi + 1) / 2, Wh = (Wi + 1) / 2;
         if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {
             hipLaunchKernelGGL((resize2x_bwd_kernel<bf16_t, 8>), dim3(rcf_cdiv((long)Wh * (C / 8), 256), N * Hh), dim3(256), 0,
-                               rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (bf16_t *)dx, dx_pitch, beta, Hi, Wi, C);
+                               rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (bf16_t *)dx, dx_pitch, beta, Hi, Wi, C, 0, 0);
         } else {
 #define RCF_CALL(T)                                                                                                       \
     hipLaunchKernelGGL((resize2x_bwd_kernel<T, 4>), dim3(rcf_cdiv((long)Wh * (C / 4), 256), N * Hh), dim3(256), 0,         \
-                       rcf_stream(stream), (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, Hi, Wi, C)
+                       rcf_stream(stream), (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, Hi, Wi, C, 0, 0)
             RCF_DISPATCH1(dt, RCF_CALL);
 #undef RCF_CALL
         }
         RCF_LAUNCH_CHECK();
         return 0;
+    }
+    // the border frame of an exact 2x up-sampling, accumulating: the 2x kernel over the 2 x 2 input blocks that see the frame -- input
+    // rows 0 .. frame / 2 (and their mirror images), i.e. (frame / 2 + 2) / 2 blocks, + 1 for odd sizes (a block that sees no frame
+    // pixel adds nothing)
+    {
+        const int Hh = (Hi + 1) / 2, Wh = (Wi + 1) / 2, tb = (frame / 2 + 2) / 2 + 1;
+        if (!general && frame > 0 && beta && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && 2 * tb < Hh && 2 * tb < Wh && N <= 65535 &&
+            (long)Wh * Hh * (C / 4) < (1L << 30)) {
+            const long Qb = 2L * tb * Wh + 2L * tb * (Hh - 2 * tb);
+            if (dt == RCF_BF16 && C % 8 == 0 && dy_pitch % 8 == 0 && dx_pitch % 8 == 0) {
+                hipLaunchKernelGGL((resize2x_bwd_kernel<bf16_t, 8>), dim3(rcf_cdiv(Qb * (C / 8), 256), N), dim3(256), 0,
+                                   rcf_stream(stream), (const bf16_t *)dy, dy_pitch, (bf16_t *)dx, dx_pitch, beta, Hi, Wi, C, frame, tb);
+            } else {
+#define RCF_CALL(T)                                                                                                       \
+    hipLaunchKernelGGL((resize2x_bwd_kernel<T, 4>), dim3(rcf_cdiv(Qb * (C / 4), 256), N), dim3(256), 0,                     \
+                       rcf_stream(stream), (const T *)dy, dy_pitch, (T *)dx, dx_pitch, beta, Hi, Wi, C, frame, tb)
+                RCF_DISPATCH1(dt, RCF_CALL);
+#undef RCF_CALL
+            }
+            RCF_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if ((long)N * Hi <= 65535 && (long)Wi * (C / 4) < (1L << 30)) {
         const float sh = host_scale(Hi, Ho, align_corners), sw = host_scale(Wi, Wo, align_corners);

@@ -841,6 +841,40 @@ def test_resize_frame_variants(report):
     assert ok_f and e_b < 1e-6
 
 
+@pytest.mark.parametrize("hi,wi,t,dt", [(24, 30, 5, torch.float32), (25, 31, 6, torch.float32), (60, 107, 13, torch.float32),
+                                        (24, 30, 5, torch.bfloat16), (33, 28, 7, torch.bfloat16)])
+def test_resize2x_frame_forms(hi, wi, t, dt, report):
+    """round 6: the border frame of an exact 2x up-sampling (decode_head2's commuted conv) runs on the 2x kernels over the source
+    pixels / 2 x 2 input blocks that reach the frame (grids of the frame's size): forward = exactly the frame's pixels of the whole
+    resize (bit for bit, the rest untouched); backward, accumulating = the whole backward of a gradient zeroed off the frame added to
+    what was there (NaNs planted off the frame are never read), bit for bit against the general kernel's frame form on the same data"""
+    g = torch.Generator().manual_seed(hi * 100 + wi + t)
+    N, C = 2, 16
+    x = torch.randn(N, hi, wi, C, generator=g).to(DEV).to(dt)
+    full = ops.resize_nhwc_fwd(x, (2 * hi, 2 * wi), False)
+    out = torch.full_like(full, 7.0)
+    ops.resize_nhwc_fwd(x, (2 * hi, 2 * wi), False, out=out, frame=t)
+    m = torch.ones(2 * hi, 2 * wi, dtype=torch.bool)
+    m[t:-t, t:-t] = False
+    m = m.to(DEV)
+    ok_f = bool(torch.equal(out[:, m], full[:, m])) and float((out[:, ~m].float() - 7.0).abs().max()) == 0.0
+    dy = torch.randn(N, 2 * hi, 2 * wi, C, generator=g).to(DEV).to(dt)
+    masked = dy.clone()
+    masked[:, ~m] = 0
+    base = torch.randn(N, hi, wi, C, generator=g).to(DEV).to(dt)
+    ref = base.clone()
+    ops.resize_nhwc_bwd(masked, (hi, wi), False, out=ref, beta=1)                       # whole tensor, 2x kernel
+    poisoned = dy.clone()
+    poisoned[:, ~m] = float("nan")
+    got = base.clone()
+    ops.resize_nhwc_bwd(poisoned, (hi, wi), False, out=got, beta=1, frame=t)
+    same = bool(torch.equal(got, ref))
+    e_b = float((got.float() - ref.float()).abs().max())
+    report(f"resize 2x frame forms ({hi}x{wi}, frame {t}, {dt}): forward exact {ok_f}; backward (accumulating) identical to the whole "
+           f"backward of the masked gradient: {same} (max |d| {e_b:.1e})")
+    assert ok_f and same
+
+
 @pytest.mark.parametrize("H,W", [(6, 10), (7, 9), (12, 854)])
 def test_warp_odd_shapes_vs_oracle(H, W, report):
     """flow_warp / fused warp+L1 on shapes whose rows are not multiples of the wavefront or of 4 (and the real
