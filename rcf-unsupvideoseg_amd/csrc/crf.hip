@@ -1588,14 +1588,11 @@ __device__ __forceinline__ unsigned to_u8(float v) {
 }
 // 4 pixels per thread: float4 loads from the three planes, 12 output bytes as three 32-bit stores
 __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restrict__ img,
-                                                            const float *__restrict__ mask,
                                                             const float *__restrict__ mean3,
-                                                            const float *__restrict__ std3, int unstd, float crf_scale,
-                                                            uint8_t *__restrict__ rgb, unsigned *__restrict__ qmax,
-                                                            int HW) {
+                                                            const float *__restrict__ std3, int unstd,
+                                                            uint8_t *__restrict__ rgb, int HW) {
     const int f = blockIdx.y;
     const int p4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    unsigned q = 0;
     if (p4 < HW) {
         const bool full = (p4 + 3 < HW) && (HW % 4 == 0);
         unsigned bytes[12];
@@ -1603,8 +1600,6 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
             float4 pl[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) pl[c] = *reinterpret_cast<const float4 *>(img + ((long)f * 3 + c) * HW + p4);
-            const float4 mk = *reinterpret_cast<const float4 *>(mask + (long)f * HW + p4);
-            const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -1613,9 +1608,6 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
                     if (unstd) v = v * std3[c] + mean3[c];
                     bytes[3 * j + c] = to_u8(v);
                 }
-                float m = mv[j] * 255.f / crf_scale;
-                m = fminf(fmaxf(m, 0.f), 255.f);
-                q = max(q, (unsigned)(uint8_t)m);
             }
         } else {
             for (int j = 0; j < 4; j++) {
@@ -1627,9 +1619,6 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
                     if (unstd) v = v * std3[c] + mean3[c];
                     bytes[3 * j + c] = to_u8(v);
                 }
-                float m = mask[(long)f * HW + p] * 255.f / crf_scale;
-                m = fminf(fmaxf(m, 0.f), 255.f);
-                q = max(q, (unsigned)(uint8_t)m);
             }
         }
         uint8_t *dst = rgb + ((long)f * HW + p4) * 3;
@@ -1643,16 +1632,25 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
                 for (int c = 0; c < 3; c++) dst[3 * j + c] = (uint8_t)bytes[3 * j + c];
         }
     }
-    // Same-address atomics serialise (~75 ns each here): one per wavefront cost 100+ of this kernel's 150 us.  One per
-    // workgroup, and only while it would raise the running maximum (it saturates after a few workgroups).
+}
+
+// per-frame maximum of the quantised mask (models/crf_head.py:43-55 divides by it): QMAX_BLOCKS workgroups per frame, one atomicMax
+// each.  Until round 6 this sat at the end of prepare_image_kernel: 401 workgroups per frame, each waiting at a barrier for a
+// device-scope load of the running maximum and, while it still read 0, adding its own atomic -- 67 of that kernel's 77 us.
+constexpr int QMAX_BLOCKS = 32;
+__global__ void __launch_bounds__(256) mask_qmax_kernel(const float *__restrict__ mask, float crf_scale, unsigned *__restrict__ qmax, int HW) {
+    const int f = blockIdx.y;
+    unsigned q = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        float m = mask[(long)f * HW + p] * 255.f / crf_scale;
+        m = fminf(fmaxf(m, 0.f), 255.f);
+        q = max(q, (unsigned)(uint8_t)m);
+    }
     __shared__ unsigned wq[4];
     for (int o = 32; o > 0; o >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, o, 64));
     if ((threadIdx.x & 63) == 0) wq[threadIdx.x >> 6] = q;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        q = max(max(wq[0], wq[1]), max(wq[2], wq[3]));
-        if (q > __hip_atomic_load(qmax + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qmax + f, q);
-    }
+    if (threadIdx.x == 0) atomicMax(qmax + f, max(max(wq[0], wq[1]), max(wq[2], wq[3])));
 }
 
 __global__ void __launch_bounds__(256) prepare_unary_kernel(const float *__restrict__ mask, float crf_scale,
@@ -2098,8 +2096,8 @@ extern "C" int rcf_crf_prepare(const float *img_nchw, const float *mask, const f
     const int HW = H * W;
     CK(hipMemsetAsync(scratch, 0, batch * sizeof(uint32_t), st));
     const dim3 g(rcf_cdiv(HW, 256), batch), g4(rcf_cdiv(rcf_cdiv(HW, 4), 256), batch);
-    hipLaunchKernelGGL(prepare_image_kernel, g4, dim3(256), 0, st, img_nchw, mask, mean3, std3, unstandardize, crf_scale,
-                       rgb_out, (unsigned *)scratch, HW);
+    hipLaunchKernelGGL(mask_qmax_kernel, dim3(QMAX_BLOCKS, batch), dim3(256), 0, st, mask, crf_scale, (unsigned *)scratch, HW);
+    hipLaunchKernelGGL(prepare_image_kernel, g4, dim3(256), 0, st, img_nchw, mean3, std3, unstandardize, rgb_out, HW);
     hipLaunchKernelGGL(prepare_unary_kernel, g, dim3(256), 0, st, mask, crf_scale, (const unsigned *)scratch, unary_out,
                        HW);
     RCF_LAUNCH_CHECK();
