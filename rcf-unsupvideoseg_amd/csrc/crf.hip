@@ -1637,20 +1637,21 @@ __global__ void __launch_bounds__(256) prepare_image_kernel(const float *__restr
 // per-frame maximum of the quantised mask (models/crf_head.py:43-55 divides by it): QMAX_BLOCKS workgroups per frame, one atomicMax
 // each.  Until round 6 this sat at the end of prepare_image_kernel: 401 workgroups per frame, each waiting at a barrier for a
 // device-scope load of the running maximum and, while it still read 0, adding its own atomic -- 67 of that kernel's 77 us.
-constexpr int QMAX_BLOCKS = 32;
+constexpr int QMAX_BLOCKS = 128;
 __global__ void __launch_bounds__(256) mask_qmax_kernel(const float *__restrict__ mask, float crf_scale, unsigned *__restrict__ qmax, int HW) {
     const int f = blockIdx.y;
-    unsigned q = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-        float m = mask[(long)f * HW + p] * 255.f / crf_scale;
-        m = fminf(fmaxf(m, 0.f), 255.f);
-        q = max(q, (unsigned)(uint8_t)m);
-    }
-    __shared__ unsigned wq[4];
-    for (int o = 32; o > 0; o >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, o, 64));
-    if ((threadIdx.x & 63) == 0) wq[threadIdx.x >> 6] = q;
+    float mx = 0.f;                         // the quantisation is monotone: the maximum of the masks, quantised once
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) mx = fmaxf(mx, mask[(long)f * HW + p]);
+    __shared__ float wq[4];
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) wq[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(qmax + f, max(max(wq[0], wq[1]), max(wq[2], wq[3])));
+    if (threadIdx.x == 0) {
+        float m = fmaxf(fmaxf(wq[0], wq[1]), fmaxf(wq[2], wq[3])) * 255.f / crf_scale;
+        m = fminf(fmaxf(m, 0.f), 255.f);
+        const unsigned q = (unsigned)(uint8_t)m;
+        if (q > __hip_atomic_load(qmax + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(qmax + f, q);
+    }
 }
 
 __global__ void __launch_bounds__(256) prepare_unary_kernel(const float *__restrict__ mask, float crf_scale,
