@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     constexpr int KPT = LT_SLOTS / 256;                      // keys per thread at most (the list has <= 256 (pd + 1) <= LT_SLOTS entries)
     int mykey[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; j++) mykey[j] = threadIdx.x + 256 * j < ntile ? (int)lgs[threadIdx.x + 256 * j] : -1;
+    for (int j = 0; j < KPT; j++) mykey[j] = (int)threadIdx.x + 256 * j < ntile ? (int)lgs[threadIdx.x + 256 * j] : -1;
     __syncthreads();                                         // every index is in registers: lgs may be overwritten
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
