@@ -625,8 +625,11 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     const long cap0 = pk_cap(Lt, f);
     const bool small = phase == 0 && cap0 < 2 * Lt.E;                    // an attempt that may overflow
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
-    int *tl = Lt.tlist + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
-    int *tp = Lt.tpos + ((long)f * Lt.tiles + blockIdx.y) * 256 * nax;
+    // a workgroup walks every gridDim.y-th tile: ONE each in the first attempt's launch; the second attempt's launch -- which returns
+    // here for every frame on nearly every call -- is small (12 960 workgroups that only start and stop cost 15 us)
+    for (int tile = (int)blockIdx.y; tile < Lt.tiles; tile += (int)gridDim.y) {
+    int *tl = Lt.tlist + ((long)f * Lt.tiles + tile) * 256 * nax;
+    int *tp = Lt.tpos + ((long)f * Lt.tiles + tile) * 256 * nax;
     if (threadIdx.x == 0) {
         newkeys = 0;
         ntile = 0;
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     // vertices, so the tile's 1 536 entries collapse to fewer distinct keys and fewer of them go to the global table
     // (the global inserts -- dependent device-scope atomics -- are what this kernel waits for).
     const int tiles_x = (W + 15) >> 4;
-    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int py = ty * 16 + (threadIdx.x >> 4), px = tx * 16 + (threadIdx.x & 15);
     const bool live = py < H && px < W;
     const int p = live ? py * W + px : 0;
@@ -720,8 +723,8 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     if (threadIdx.x == 0) {
         // per tile, summed per frame by pk_totals_kernel: 1 620 atomics onto one counter per frame are served one after the other
         // (measured: 130 us of this kernel per counter at 8 frames of 480x854)
-        Lt.tnew[(long)f * Lt.tiles + blockIdx.y] = small ? newkeys : 0;
-        Lt.tcnt[(long)f * Lt.tiles + blockIdx.y] = ntile;
+        Lt.tnew[(long)f * Lt.tiles + tile] = small ? newkeys : 0;
+        Lt.tcnt[(long)f * Lt.tiles + tile] = ntile;
     }
     if (live) {
         const long base = (long)f * Lt.E + p;
@@ -732,6 +735,8 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
             Lt.weight[e] = wgt[r];
             Lt.tslot[e] = (unsigned short)lcnt[lh[r]];
         }
+    }
+    __syncthreads();                                     // the next tile reuses the LDS tables
     }
 }
 
@@ -756,48 +761,51 @@ __global__ void __launch_bounds__(256) pk_totals_kernel(Lattice Lt, int phase) {
 }
 
 // exclusive scans over the table's buckets: vertex numbering (occupied flag) and CSR offsets (entry counts)
-__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt) {
+// (grid-stride over the nblk tiles of the full table: a natural frame's table fills 128 of the 2 402 -- the launch is 256 workgroups
+// per frame, not 2 402 that mostly start and stop)
+__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_local_kernel(Lattice Lt, int nblk) {
     const int f = blockIdx.y;
     const long SS = 2 * Lt.E, S = pk_buckets(Lt, f);          // frame stride of the bucket arrays, buckets in use
-    if ((long)blockIdx.x * SCAN_TILE >= S) {                   // past the table in use: empty tile
-        if (threadIdx.x == 0) {
-            int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
-            bs[blockIdx.x] = 0;
-            bs[gridDim.x + 1 + blockIdx.x] = 0;
-        }
-        return;
-    }
-    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+    int *bs = Lt.blocksum2 + (long)f * 2 * (nblk + 1);
     const unsigned long long *cursor = Lt.cursor64 + (long)f * SS;
     const bool tile = tile_mode(Lt, f);         // the lists scanned are then the vertices' partial sums (one per tile), not their entries
-    int fl[SCAN_ITEMS], cn[SCAN_ITEMS], sf = 0, sc = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const long b = base + i;
-        const unsigned long long cu = (b < S) ? cursor[b] : 0ull;
-        cn[i] = tile ? (int)(cu >> 32) : (int)(unsigned)cu;
-        fl[i] = cu != 0ull ? 1 : 0;             // every inserted key counted at least one entry
-        sf += fl[i];
-        sc += cn[i];
-    }
-    int tf, tc;
-    int of = block_exclusive_scan(sf, &tf);
-    int oc = block_exclusive_scan(sc, &tc);
     int *sv = Lt.slot_vid2 + (long)f * SS, *so = Lt.slot_off + (long)f * SS;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const long b = base + i;
-        if (b < S) {
-            sv[b] = fl[i] ? of : -1;
-            if (fl[i]) so[b] = oc;              // offsets are only ever read for occupied buckets
+    for (int vb = blockIdx.x; vb < nblk; vb += gridDim.x) {
+        if ((long)vb * SCAN_TILE >= S) {                       // past the table in use: empty tile
+            if (threadIdx.x == 0) {
+                bs[vb] = 0;
+                bs[nblk + 1 + vb] = 0;
+            }
+            continue;
         }
-        of += fl[i];
-        oc += cn[i];
-    }
-    if (threadIdx.x == 0) {
-        int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
-        bs[blockIdx.x] = tf;
-        bs[gridDim.x + 1 + blockIdx.x] = tc;
+        const long base = (long)vb * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+        int fl[SCAN_ITEMS], cn[SCAN_ITEMS], sf = 0, sc = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const long b = base + i;
+            const unsigned long long cu = (b < S) ? cursor[b] : 0ull;
+            cn[i] = tile ? (int)(cu >> 32) : (int)(unsigned)cu;
+            fl[i] = cu != 0ull ? 1 : 0;             // every inserted key counted at least one entry
+            sf += fl[i];
+            sc += cn[i];
+        }
+        int tf, tc;
+        int of = block_exclusive_scan(sf, &tf);
+        int oc = block_exclusive_scan(sc, &tc);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const long b = base + i;
+            if (b < S) {
+                sv[b] = fl[i] ? of : -1;
+                if (fl[i]) so[b] = oc;              // offsets are only ever read for occupied buckets
+            }
+            of += fl[i];
+            oc += cn[i];
+        }
+        if (threadIdx.x == 0) {
+            bs[vb] = tf;
+            bs[nblk + 1 + vb] = tc;
+        }
     }
 }
 __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_blocks_kernel(Lattice Lt, int nblk) {
@@ -822,29 +830,30 @@ __global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_blocks_kernel(Lattice Lt, 
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt) {
+__global__ void __launch_bounds__(SCAN_BLOCK) pk_scan_apply_kernel(Lattice Lt, int nblk) {
     const int f = blockIdx.y;
     const long SS = 2 * Lt.E, S = pk_buckets(Lt, f);
-    if ((long)blockIdx.x * SCAN_TILE >= S) return;
-    const int *bs = Lt.blocksum2 + (long)f * 2 * (gridDim.x + 1);
-    const int addf = bs[blockIdx.x], addc = bs[gridDim.x + 1 + blockIdx.x];
+    const int *bs = Lt.blocksum2 + (long)f * 2 * (nblk + 1);
     int *sv = Lt.slot_vid2 + (long)f * SS, *so = Lt.slot_off + (long)f * SS;
     const unsigned long long *cursor = Lt.cursor64 + (long)f * SS;
     const bool tile = tile_mode(Lt, f);
     const long fb = (long)f * Lt.E;
-    const long base = (long)blockIdx.x * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
+    for (int vb = blockIdx.x; vb < nblk && (long)vb * SCAN_TILE < S; vb += gridDim.x) {
+        const int addf = bs[vb], addc = bs[nblk + 1 + vb];
+        const long base = (long)vb * SCAN_TILE + (long)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const long b = base + i;
-        if (b >= S) continue;
-        if (sv[b] >= 0) {
-            const int off = so[b] + addc;
-            so[b] = off;
-            const int v = sv[b] + addf;
-            sv[b] = v;
-            Lt.vrep[fb + v] = (int)b;
-            Lt.off[fb + v] = off;
-            Lt.cnt[fb + v] = tile ? (int)(cursor[b] >> 32) : (int)(unsigned)cursor[b];
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const long b = base + i;
+            if (b >= S) continue;
+            if (sv[b] >= 0) {
+                const int off = so[b] + addc;
+                so[b] = off;
+                const int v = sv[b] + addf;
+                sv[b] = v;
+                Lt.vrep[fb + v] = (int)b;
+                Lt.off[fb + v] = off;
+                Lt.cnt[fb + v] = tile ? (int)(cursor[b] >> 32) : (int)(unsigned)cursor[b];
+            }
         }
     }
 }
@@ -1791,13 +1800,14 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 0);
     hipLaunchKernelGGL(pk_totals_kernel, dim3(F), dim3(256), 0, st, L, 0);
     if (L.cap_small < 2 * L.E) {           // frames that overflowed the small table: all 2E buckets (others return at once)
-        hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 1024), dim3(256), 0, st, L, 1);
-        PD_LAUNCH(L.pd, lattice_build_packed_kernel, gpf, dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
+        hipLaunchKernelGGL(pk_clear_kernel, dim3(F, 256), dim3(256), 0, st, L, 1);
+        PD_LAUNCH(L.pd, lattice_build_packed_kernel, dim3(F, 256), dim3(256), st, L, rgb, W, H, posdev, featdev, 1);
         hipLaunchKernelGGL(pk_totals_kernel, dim3(F), dim3(256), 0, st, L, 1);
     }
-    hipLaunchKernelGGL(pk_scan_local_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
+    const int gscan = nblk2 < 256 ? nblk2 : 256;
+    hipLaunchKernelGGL(pk_scan_local_kernel, dim3(gscan, F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_scan_blocks_kernel, dim3(F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
-    hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(nblk2, F), dim3(SCAN_BLOCK), 0, st, L);
+    hipLaunchKernelGGL(pk_scan_apply_kernel, dim3(gscan, F), dim3(SCAN_BLOCK), 0, st, L, nblk2);
     hipLaunchKernelGGL(pk_fill_kernel, dim3(F, 2048), dim3(256), 0, st, L);        // (returns at once on tile-mode frames)
     hipLaunchKernelGGL(tile_list_kernel, dim3(F, L.tiles), dim3(256), 0, st, L);      // one workgroup per tile: two dependent gathers per entry
     hipLaunchKernelGGL(neighbours_init_kernel, dim3(2048, F), dim3(256), 0, st, L);
