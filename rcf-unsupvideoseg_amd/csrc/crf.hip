@@ -905,8 +905,10 @@ __global__ void __launch_bounds__(256) pk_neighbours_kernel(Lattice Lt) {
     const unsigned nbk = (unsigned)pk_buckets(Lt, f);          // the modulus the insert used
     const long total = Lf * nax;
     for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.y * blockDim.x) {
-        const long v = i / nax;
-        const int axis = (int)(i - v * nax);
+        // axis-major: the lanes of a wavefront take consecutive vertices of ONE axis (their representative slots and their own
+        // neighbour entries are then consecutive in memory; vertex-major, six lanes shared a vertex and wrote six arrays)
+        const int axis = (int)(i / Lf);
+        const long v = i - (long)axis * Lf;
         short key[8];
         unpack64(table[Lt.vrep[(long)f * Lt.E + v]], pd, key);
         for (int k = 0; k < pd; k++) key[k] = (short)(key[k] + 1);
