@@ -661,6 +661,18 @@ int rcf_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
                       float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                       void *stream);
 int rcf_ema_update_f32(float *dest, const float *src, long n, float m, void *stream);
+/* ... over ALL entries of a state dict in one launch (utils/model_utils.py:33-38 loops over them: ~500 launches of a few
+ * microseconds per step for the EMA teacher, which the host cannot enqueue as fast as the GPU runs them -- 5.7 ms of idle GPU per
+ * bf16 stage-2.1 step).  `chunks_dev`: device array of `count` chunks, one workgroup each; kind 0: fp32 dest = dest m + src (1 - m),
+ * kind 1: int64 counters (num_batches_tracked), dest = trunc(float(dest) m + float(src) one_minus_m_counter) -- what torch's
+ * int64 * python-float arithmetic gives the reference. */
+typedef struct rcf_ema_chunk {
+    void *dst;
+    const void *src;
+    long n;
+    long kind;
+} rcf_ema_chunk;
+int rcf_ema_update_multi(const rcf_ema_chunk *chunks_dev, int count, float m, float one_minus_m_counter, void *stream);
 int rcf_fill_f32(float *p, long n, float v, void *stream);
 /* nn.Dropout2d's draw as a per-(sample, channel) scale (models/decode_head.py:84-87, models/fcn_head.py:142-147): out[i] = 0 with
  * probability p, 1 / (1 - p) otherwise, i < n = samples * channels; Philox4x32-10 keyed by `seed`, counter = i (reproducible

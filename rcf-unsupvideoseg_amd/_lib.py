@@ -186,6 +186,7 @@ PROTOS = {
     "rcf_lrelu_bwd_f32": (c_int, [P, P, P, c_long, c_float, P]),
     "rcf_adam_step_f32": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "rcf_ema_update_f32": (c_int, [P, P, c_long, c_float, P]),
+    "rcf_ema_update_multi": (c_int, [P, c_int, c_float, c_float, P]),
     "rcf_fill_f32": (c_int, [P, c_long, c_float, P]),
     "rcf_dropout2d_scale_f32": (c_int, [P, c_long, c_float, ctypes.c_ulonglong, P]),
     # mixed-precision (bf16 storage) forms

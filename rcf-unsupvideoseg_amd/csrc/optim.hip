@@ -34,6 +34,25 @@ __global__ void __launch_bounds__(256) ema_kernel(float *__restrict__ d, const f
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) d[i] = d[i] * m + s[i] * (1.0f - m);
 }
 
+// every entry of a state dict in ONE launch: a workgroup takes one chunk {dst, src, count, kind} of the table (kind 0: fp32,
+// d = d m + s (1 - m); kind 1: int64 counters -- num_batches_tracked -- d = trunc(float(d) m + float(s) (1 - m)), what torch's
+// int64 * python-float -> float32 -> copy_ into int64 computes, utils/model_utils.py:33-38)
+__global__ void __launch_bounds__(256) ema_multi_kernel(const rcf_ema_chunk *__restrict__ tab, float m, float om, float om_counter) {
+    const rcf_ema_chunk c = tab[blockIdx.x];
+    if (c.kind == 0) {
+        float *d = static_cast<float *>(c.dst);
+        const float *s = static_cast<const float *>(c.src);
+        for (long i = threadIdx.x; i < c.n; i += blockDim.x) d[i] = d[i] * m + s[i] * om;
+    } else {
+        long long *d = static_cast<long long *>(c.dst);
+        const long long *s = static_cast<const long long *>(c.src);
+        for (long i = threadIdx.x; i < c.n; i += blockDim.x) {
+            const float a = (float)d[i] * m, b = (float)s[i] * om_counter;
+            d[i] = (long long)(a + b);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float *__restrict__ p, long n, float v) {
     const long step = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) p[i] = v;
@@ -55,6 +74,14 @@ extern "C" int rcf_adam_step_f32(float *param, const float *grad, float *exp_avg
 extern "C" int rcf_ema_update_f32(float *dest, const float *src, long n, float m, void *stream) {
     if (!dest || !src || n <= 0) return RCF_EINVAL;
     hipLaunchKernelGGL(ema_kernel, dim3(ew_blocks(n)), dim3(256), 0, rcf_stream(stream), dest, src, n, m);
+    RCF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int rcf_ema_update_multi(const rcf_ema_chunk *chunks_dev, int count, float m, float one_minus_m_counter, void *stream) {
+    if (!chunks_dev || count <= 0) return RCF_EINVAL;
+    // fp32 entries: 1.0f - m like rcf_ema_update_f32 (same bits as the per-tensor launches); counters: the caller's float(1.0 - m)
+    hipLaunchKernelGGL(ema_multi_kernel, dim3((unsigned)count), dim3(256), 0, rcf_stream(stream), chunks_dev, m, 1.0f - m, one_minus_m_counter);
     RCF_LAUNCH_CHECK();
     return 0;
 }

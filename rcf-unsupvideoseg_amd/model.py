@@ -88,19 +88,49 @@ def copy_param_and_buffer(src, dest):
     ops.weights_changed()            # `.data` writes do not bump `_version`: drop every cached weight operand
 
 
+EMA_CHUNK = 1 << 16          # elements per workgroup of rcf_ema_update_multi
+
+
+class _EmaPlan:
+    """the chunk table of one (source, EMA copy) pair for rcf_ema_update_multi: built once, valid while no tensor of either module
+    is re-allocated (`key`: every tensor's address)"""
+
+    def __init__(self, pairs, key, device):
+        rows, self.others = [], []
+        for d, s in pairs:
+            kind = 0 if d.dtype == torch.float32 else (1 if d.dtype == torch.int64 else -1)
+            same_order = (d.is_contiguous() and s.is_contiguous()) or (
+                d.dim() == 4 and d.stride() == s.stride() and d.permute(0, 2, 3, 1).is_contiguous())   # channels_last conv weights
+            if kind < 0 or s.dtype != d.dtype or not d.is_cuda or not same_order or d.numel() == 0:
+                self.others.append((d, s))
+                continue
+            n, size = d.numel(), d.element_size()
+            for o in range(0, n, EMA_CHUNK):
+                rows.append((d.data_ptr() + o * size, s.data_ptr() + o * size, min(EMA_CHUNK, n - o), kind))
+        self.key, self.count = key, len(rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device) if rows else None
+
+
+def _state_tensors(mod):
+    return list(mod.parameters()) + list(mod.buffers())
+
+
 @torch.no_grad()
 def momentum_update_param_and_buffer(src, dest, m):
-    """utils/model_utils.py:33-38: dest = dest*m + src*(1-m) over every state-dict entry (float
-    entries through the fused HIP kernel; num_batches_tracked keeps the reference's int64 truncation)."""
-    s, d = src.state_dict(), dest.state_dict()
-    for k in s:
-        if d[k].dtype == torch.float32 and d[k].is_cuda and d[k].is_contiguous() and s[k].is_contiguous():
-            ops.ema_update(d[k], s[k], m, invalidate=False)
-        elif d[k].dtype == torch.float32 and d[k].is_cuda:
-            # channels_last conv weights: same memory order on both sides
-            ops.ema_update(d[k].permute(0, 2, 3, 1), s[k].permute(0, 2, 3, 1), m, invalidate=False)
-        else:
-            d[k].data.copy_(d[k].data * m + s[k].data * (1.0 - m))
+    """utils/model_utils.py:33-38: dest = dest*m + src*(1-m) over every state-dict entry -- in ONE launch (rcf_ema_update_multi: the
+    float entries and the int64 num_batches_tracked counters with the reference's truncation); until round 6 one launch per float
+    entry and four torch kernels per counter: ~500 launches of 2-4 us that the host enqueues more slowly than the GPU runs them."""
+    st, dt = _state_tensors(src), _state_tensors(dest)
+    key = tuple(t.data_ptr() for t in st) + tuple(t.data_ptr() for t in dt)
+    plan = getattr(dest, "_ema_plan", None)
+    if plan is None or plan.key != key:
+        s, d = src.state_dict(), dest.state_dict()
+        plan = _EmaPlan([(d[k], s[k]) for k in s], key, dt[0].device if dt else torch.device("cpu"))
+        object.__setattr__(dest, "_ema_plan", plan)              # (not a submodule / buffer: stays out of the state dict)
+    if plan.table is not None:
+        ops.ema_update_multi(plan.table, plan.count, m)
+    for d, s in plan.others:
+        d.data.copy_(d.data * m + s.data * (1.0 - m))
     ops.weights_changed(dest)            # only `dest` was written: the source's cached operands stay valid
 
 

@@ -1045,6 +1045,13 @@ def ema_update(dest, src, m, invalidate=True):
     call("rcf_ema_update_f32", _p(dest), _p(src), dest.numel(), m, _stream())
 
 
+def ema_update_multi(table, count, m):
+    """every entry of a state dict in one launch: `table` int64 [count, 4] on the device = rcf_ema_chunk {dst, src, n, kind}
+    (model._EmaPlan).  Counters (kind 1) take float(1.0 - m) as torch's int64 * python-float arithmetic does."""
+    import numpy as np
+    call("rcf_ema_update_multi", _p(table), int(count), float(m), float(np.float32(1.0 - float(m))), _stream())
+
+
 def dropout2d_scale(n, channels, p, seed, device):
     """nn.Dropout2d's draw as the [n, channels] fp32 scale the head's last batch-norm pass multiplies in: 0 with probability p,
     1 / (1 - p) otherwise (rcf_dropout2d_scale_f32: Philox keyed by `seed`, one launch, no torch kernels)"""

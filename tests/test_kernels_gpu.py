@@ -980,3 +980,51 @@ def test_dropout2d_scale_draw(report):
     finally:
         ops.dropout2d_scale = orig
     assert len(seen) == 3 and torch.equal(seen[0], seen[1]) and not torch.equal(seen[0], seen[2])
+
+
+def test_ema_update_of_a_state_dict_in_one_launch(report):
+    """round 6: momentum_update_param_and_buffer (utils/model_utils.py:33-38) runs every entry of the state dict through ONE launch
+    (rcf_ema_update_multi: chunk table built once per module pair).  Float entries: the bits of the per-tensor kernel
+    (d m + s (1.0f - m), no fused multiply-add); channels_last conv weights in their own memory order; the int64
+    num_batches_tracked counters exactly as torch's int64 * python-float arithmetic leaves them (the reference's truncation);
+    the table follows a re-allocation of the tensors."""
+    from rcf_amd import layers
+    from rcf_amd.model import momentum_update_param_and_buffer
+    torch.manual_seed(3)
+
+    def make():
+        m = torch.nn.Sequential()
+        m.add_module("c1", layers.Conv2d(8, 16, 3))
+        m.add_module("b1", layers.BatchNorm2d(16))
+        m.add_module("c2", layers.Conv2d(16, 200, 1))
+        m.add_module("b2", layers.BatchNorm2d(200))
+        return m.to(DEV)
+    src, dst = make(), make()
+    with torch.no_grad():
+        for mod, seed in ((src, 1), (dst, 2)):
+            g = torch.Generator().manual_seed(seed)
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                if t.dtype == torch.float32:
+                    t.copy_(torch.randn(t.shape, generator=g).to(DEV))
+        src.b1.num_batches_tracked.fill_(1234567)
+        dst.b1.num_batches_tracked.fill_(41)
+        src.b2.num_batches_tracked.fill_(3)
+        dst.b2.num_batches_tracked.fill_(100000)
+    for rnd, m in enumerate((0.999, 0.9, 0.5)):
+        want = {}
+        mf = torch.tensor(m, dtype=torch.float32, device=DEV)
+        for (k, s_), (_, d_) in zip(src.state_dict().items(), dst.state_dict().items()):
+            if d_.dtype == torch.float32:
+                want[k] = d_ * mf + s_ * (torch.tensor(1.0, dtype=torch.float32, device=DEV) - mf)
+            else:
+                want[k] = (d_ * m + s_ * (1.0 - m)).to(d_.dtype)            # the reference's expression on the int64 counter
+        if rnd == 2:                                                        # re-allocate: the cached table must be rebuilt
+            with torch.no_grad():
+                dst.c2.weight.data = dst.c2.weight.data.clone()
+                want["c2.weight"] = dst.c2.weight.data * mf + src.c2.weight.data * (torch.tensor(1.0, dtype=torch.float32, device=DEV) - mf)
+        momentum_update_param_and_buffer(src, dst, m)
+        got = dst.state_dict()
+        bad = [k for k in want if not torch.equal(got[k], want[k])]
+        report(f"EMA of a state dict in one launch, m = {m}: {len(want)} entries ({dst._ema_plan.count} chunks), mismatching: {bad}; "
+               f"counters {int(got['b1.num_batches_tracked'])}, {int(got['b2.num_batches_tracked'])}")
+        assert not bad
