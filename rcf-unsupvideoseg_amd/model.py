@@ -121,7 +121,7 @@ def momentum_update_param_and_buffer(src, dest, m):
     float entries and the int64 num_batches_tracked counters with the reference's truncation); until round 6 one launch per float
     entry and four torch kernels per counter: ~500 launches of 2-4 us that the host enqueues more slowly than the GPU runs them."""
     st, dt = _state_tensors(src), _state_tensors(dest)
-    key = tuple(t.data_ptr() for t in st) + tuple(t.data_ptr() for t in dt)
+    key = tuple((t.data_ptr(), t.numel()) for t in st) + tuple((t.data_ptr(), t.numel()) for t in dt)
     plan = getattr(dest, "_ema_plan", None)
     if plan is None or plan.key != key:
         s, d = src.state_dict(), dest.state_dict()
