@@ -286,7 +286,7 @@ def main():
                                         "mfma_busy_source": "profiles/pmc_mfma.json (committed rocprofv3 --pmc passes of this command), not measured in this run"})
             out["pmc_by_family"] = {k: {q: v[q] for q in ("mfma_busy", "clock_ghz", "l2_hit", "launches")} for k, v in mj.items()}
         out["roofline"]["note"] = ("the family with the largest share of the step's kernel time; the deep convs are power-limited "
-                                   "(the same launch runs 25-30 % faster on all-zero operands: LABNOTES.md), the family average "
+                                   "(the same launches run 18-23 % faster, at 2.3-2.4 GHz, on all-zero operands: profiles/r06_pmc_headline_random_vs_zero.txt), the family average "
                                    "includes the bottlenecks' short-K 1x1 layers (per-layer table: profiles/)")
         if fam32 in by32s and by32s[fam32]["ms"] > 0:
             out["roofline"]["achieved_one_stream"] = round(by32s[fam32]["flops"] / (by32s[fam32]["ms"] * 1e-3) / 1e12, 2)
