@@ -549,7 +549,7 @@ def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, step
     import types
     args = types.SimpleNamespace(checkpoints_dir="/tmp/rcf_bench", object_channel=1, eval_save=False, eval_export=False)
 
-    def leg(precision):
+    def leg(precision, iters=iters):
         model = rcf_amd.RCFModel(args, **config.stage21_model_kwargs(config.mask_size_for(H, W), dropout=0.1, norm="BN",
                                                                      refine_iters=iters))
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -575,6 +575,10 @@ def stage2_bench(torch, rcf_amd, config, synth, dev, H, W, B, batch, iters, step
         dt16, lc16 = leg("bf16")
         out.update({"bf16_ms_per_step": round(dt16 * 1e3, 2), "bf16_frames_per_s": round(2 * B / dt16, 2),
                     "bf16_loss_crf": round(lc16, 6)})
+        # the reference's own stage-2.1 config leaves CRFHead at its default of T = 50 iterations (configs/rcf/rcf_stage2.1.yaml:150-151,
+        # models/crf_head.py:13): the CRF runs on the second stream beside the student's forward
+        dt50, _ = leg("bf16", 50)
+        out["bf16_ms_per_step_crf_T50"] = round(dt50 * 1e3, 2)
     return out
 
 
