@@ -92,6 +92,11 @@ struct Lattice {           // device pointers of one potential, for all frames (
     long long *accg;             // [F][3E]  partial sums in 2^-40 fixed point, grouped by vertex (Lt.off / Lt.cnt in tile mode):
                                  //          [E][2] label sums, then [E] homogeneous-channel sums
     int tiles;                   // 16 x 16 tiles per frame
+    long Ep;                     // frame stride of `weight` and `tslot`: tiles * 256 * (pd + 1) >= E (whole tiles)
+    int wtile;                   // host side: `weight` / `tslot` are TILE-major ((tile (pd + 1) + r) 256 + position in the 16 x 16 tile:
+                                 // the packed build -- its kernels and every kernel of a filter pass walk the image in these tiles, and a
+                                 // tile's 256 weights of one remainder are then one contiguous KB instead of sixteen 64-byte row pieces:
+                                 // -7 % per pass); 0: remainder-major r N + p (array-of-keys and sort builds)
     int tile_splat;              // host side: this build wrote the tile lists (stat[4 f + 3] = their total length per frame)
 };
 
@@ -134,6 +139,17 @@ constexpr long TILE_SPLAT_NUM = 3, TILE_SPLAT_DEN = 5;
 __device__ __forceinline__ bool tile_mode(const Lattice &Lt, int f) {
     if (!Lt.tile_splat || (Lt.tune & 16)) return false;
     return (Lt.tune & 32) || (long)Lt.stat[4 * f + 3] * TILE_SPLAT_DEN <= TILE_SPLAT_NUM * Lt.E;
+}
+// where entry (remainder r, pixel p) of frame f lives in Lt.weight / Lt.tslot (see Lattice::wtile)
+__device__ __forceinline__ long widx(const Lattice &Lt, int f, int r, int p) {
+    const long base = (long)f * Lt.Ep;
+    if (!Lt.wtile) return base + (long)r * Lt.N + p;
+    const int py = p / Lt.W, px = p - py * Lt.W, tiles_x = (Lt.W + 15) >> 4;
+    return base + ((long)((py >> 4) * tiles_x + (px >> 4)) * (Lt.pd + 1) + r) * 256 + (((py & 15) << 4) | (px & 15));
+}
+// ... for thread t of the workgroup that owns tile `tile` (pixel p): no divisions
+__device__ __forceinline__ long widx_tile(const Lattice &Lt, int f, int tile, int r, int t, int p) {
+    return (long)f * Lt.Ep + (Lt.wtile ? ((long)tile * (Lt.pd + 1) + r) * 256 + t : (long)r * Lt.N + p);
 }
 
 __device__ __forceinline__ unsigned key_hash(const short *key, int pd) {
@@ -239,7 +255,7 @@ __global__ void __launch_bounds__(256) lattice_keys_kernel(Lattice Lt, const uin
         short key[PD_MAX];
         lattice_key(pd, r, rem0, rank, key);
         Lt.keys[base + (long)r * Lt.N] = pack_key(key, pd);
-        Lt.weight[base + (long)r * Lt.N] = bary[r];
+        Lt.weight[(long)f * Lt.Ep + (long)r * Lt.N + p] = bary[r];
     }
 }
 
@@ -533,7 +549,7 @@ __global__ void __launch_bounds__(256) csr_fill_kernel(Lattice Lt) {
         // fixed-point sum of the gather does not depend on it.
         const int pos = Lt.off[fb + v] + base + (lane - seg);
         const int p = (int)(idx - (idx / Lt.N) * Lt.N);
-        Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + e]));
+        Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[(long)f * Lt.Ep + e]));
     }
 }
 
@@ -732,8 +748,9 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
             const long e = base + (long)r * Lt.N;
             Lt.vid[e] = (int)lgs[lh[r]];                         // bucket for now; the fill pass turns it into the vertex id
             Lt.rel[e] = (int)lbase[lh[r]] + lrank[r];
-            Lt.weight[e] = wgt[r];
-            Lt.tslot[e] = (unsigned short)lcnt[lh[r]];
+            const long we = widx_tile(Lt, f, tile, r, threadIdx.x, p);
+            Lt.weight[we] = wgt[r];
+            Lt.tslot[we] = (unsigned short)lcnt[lh[r]];
         }
     }
     __syncthreads();                                     // the next tile reuses the LDS tables
@@ -870,8 +887,8 @@ __global__ void __launch_bounds__(256) pk_fill_kernel(Lattice Lt) {
         const int v = Lt.slot_vid2[(long)f * S + b];
         if (!tile) {
             const int pos = Lt.slot_off[(long)f * S + b] + Lt.rel[fb + idx];
-            const int p = (int)(idx - (idx / Lt.N) * Lt.N);
-            Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[fb + idx]));
+            const int r = (int)(idx / Lt.N), p = (int)(idx - (long)r * Lt.N);
+            Lt.csr[fb + pos] = make_int2(p, __float_as_int(Lt.weight[widx(Lt, f, r, p)]));
         }
         Lt.vid[fb + idx] = v;
     }
@@ -959,7 +976,7 @@ __global__ void __launch_bounds__(256) sort_keys_kernel(Lattice Lt, const uint8_
         const long e = base + (long)r * Lt.N;
         K[e] = ((unsigned long long)f << 60) | pack64(key, pd);
         V[e] = (unsigned)(r * Lt.N + p);
-        Lt.weight[e] = bary[r];
+        Lt.weight[(long)f * Lt.Ep + (long)r * Lt.N + p] = bary[r];
     }
 }
 
@@ -982,7 +999,7 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(Lattice Lt, const uns
         const int v = runs[g] - 1 - base;
         const unsigned e = V[g];
         Lt.vid[fb + e] = v;
-        Lt.csr[g] = make_int2((int)(e % (unsigned)Lt.N), __float_as_int(Lt.weight[fb + e]));
+        Lt.csr[g] = make_int2((int)(e % (unsigned)Lt.N), __float_as_int(Lt.weight[(long)f * Lt.Ep + e]));
         if (flag[g]) {
             Lt.off[fb + v] = (int)i;
             ukey[fb + v] = K[g] & KEY60;
@@ -1254,7 +1271,6 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
     const int n = Lt.tcnt[(long)f * Lt.tiles + blockIdx.y];
     const int R = tile_copies(n, stride);
     const int rep = tile_copy_of(threadIdx.x, R);
-    const long fb = (long)f * Lt.E;
     const bool live = py < H && px < W;
     const int p = live ? py * W + px : 0;
     // everything the pixel reads from memory is asked for before the first barrier
@@ -1266,7 +1282,7 @@ __global__ void __launch_bounds__(256) splat_tile_kernel(Lattice Lt, const float
 #pragma unroll
         for (int r = 0; r <= PD_MAX; r++) {
             if (r >= nax) break;
-            const long e = fb + (long)r * Lt.N + p;
+            const long e = widx_tile(Lt, f, blockIdx.y, r, threadIdx.x, p);
             wr[r] = Lt.weight[e];
             sr[r] = Lt.tslot[e];
         }
@@ -1397,7 +1413,7 @@ __global__ void __launch_bounds__(256) slice_norm_kernel(Lattice Lt, const float
 #pragma unroll
     for (int r = 0; r <= pd; r++) {
         const long pe = fb + (long)r * Lt.N + p;
-        sw += Lt.weight[pe] * z[fb + Lt.vid[pe]];
+        sw += Lt.weight[widx(Lt, f, r, p)] * z[fb + Lt.vid[pe]];
     }
     Lt.inv[(long)f * Lt.N + p] = sym ? (float)(1.0 / sqrt((double)sw + 1e-20)) : (float)(1.0 / sw);
 }
@@ -1445,7 +1461,7 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
 #pragma unroll
         for (int r = 0; r < NAXC; r++) {
             if (!PD && r >= nax) break;
-            const long pe = fb + (long)r * Lt.N + p;
+            const long pe = widx_tile(Lt, f, blockIdx.y, r, threadIdx.x, p);
             wr[r] = Lt.weight[pe];
             sr[r] = Lt.tslot[pe];
         }
@@ -1481,7 +1497,7 @@ __global__ void __launch_bounds__(256) slice_kernel(Lattice Lt, const float2 *__
                 v = sval[sr[r]];
                 if (NORM) zz = szv[sr[r]];
             } else {
-                wgt = Lt.weight[pe];
+                wgt = Lt.weight[widx_tile(Lt, f, blockIdx.y, r, threadIdx.x, p)];
                 const int vi = Lt.vid[pe];
                 v = val[fb + vi];
                 if (NORM) zz = z[fb + vi];
@@ -1703,8 +1719,11 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.W = W;
     L.E = (long)N * (pd + 1);
     const size_t FE = (size_t)F * L.E;
+    L.tiles = rcf_cdiv(W, 16) * rcf_cdiv(N / W, 16);
+    L.Ep = (long)L.tiles * 256 * (pd + 1);
+    L.wtile = 0;
     L.keys = c.take<uint4>(FE);
-    L.weight = c.take<float>(FE);
+    L.weight = c.take<float>((size_t)F * L.Ep);
     L.entries = c.take<int>(2 * FE);
     L.vid = c.take<int>(FE);
     L.slot_vid = c.take<int>(FE);
@@ -1724,9 +1743,8 @@ void carve_lattice(Carver &c, Lattice &L, int pd, int N, int F, int W) {
     L.slot_off = c.take<int>(2 * FE);
     L.blocksum2 = c.take<int>((size_t)F * 2 * (scan_blocks(2 * L.E) + 1));
     L.stat = c.take<int>((size_t)F * 4);
-    L.tiles = rcf_cdiv(W, 16) * rcf_cdiv(N / W, 16);
     L.cursor64 = c.take<unsigned long long>(2 * FE);
-    L.tslot = c.take<unsigned short>(FE);
+    L.tslot = c.take<unsigned short>((size_t)F * L.Ep);
     L.tlist = c.take<int>((size_t)F * L.tiles * 256 * (pd + 1));
     L.tpos = c.take<int>((size_t)F * L.tiles * 256 * (pd + 1));
     L.tcnt = c.take<int>((size_t)F * L.tiles);
@@ -1795,6 +1813,7 @@ int build_lattice_packed(Lattice &L, const uint8_t *rgb, int W, int H, int F, fl
     const long small = L.build == 2 ? 1021 : ((1L << 18) - 1);
     L.cap_small = (int)(small < 2 * L.E ? small : 2 * L.E);
     L.tile_splat = 1;                                            // every kernel below sees it (the struct travels by value)
+    L.wtile = 1;
     L.est = (L.build != 2 && L.cap_small < 2 * L.E && rcf_cdiv(L.N, 256) >= 4 * PK_SAMPLES) ? 1 : 0;
     hipLaunchKernelGGL(pk_stat_reset_kernel, dim3(1), dim3(64), 0, st, L, F);
     if (L.est) PD_LAUNCH(L.pd, pk_estimate_kernel, dim3(PK_SAMPLES, F), dim3(256), st, L, rgb, W, posdev, featdev);
@@ -1851,6 +1870,7 @@ int build_lattice(Lattice &L, const uint8_t *rgb, int W, int H, int F, float pos
                   hipStream_t st) {
     L.w = weight;
     L.tile_splat = 0;                                            // only the packed build writes the tile lists
+    L.wtile = 0;                                                 // ... and stores the weights tile-major
     const dim3 gp(rcf_cdiv(L.N, 256), F), ge(rcf_cdiv(L.E, 256), F);
     const int nblk = scan_blocks(L.E);
     if (L.build != 1 && keys_fit_12bit(L.pd, W, H, posdev, featdev)) {
