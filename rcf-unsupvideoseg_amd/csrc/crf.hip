@@ -134,11 +134,19 @@ __device__ __forceinline__ long pk_buckets(const Lattice &Lt, int f) { return pk
 // natural-looking 480x854 frames with +-0 ... +-64 of pixel noise on top (tools/crf_texture_sweep.py, profiles/r06_crf_texture_sweep.txt):
 // the tile splat beats the list walk while the lists total <= ~0.67 E (+-16: 0.655 against 0.684 ms per frame; +-20, 0.7 E: 0.82 against
 // 0.81), by 35-40 % on clean frames (lists ~0.1 E); beyond, every entry is nearly its own vertex and the sort build is the one to take.
+// With the sampled estimate (Lt.est: frames of >= 256 x 256 pixels) the decision is taken BEFORE the build from the sampled distinct
+// fraction -- over that sweep lists of 0.6 E correspond to 88 % (+-16: 83-87.5 % and 0.56-0.59 E; +-24: 93-94.5 % and 0.78 E) -- so that the
+// build writes only what the frame's mode reads (tile mode: no per-entry bucket / CSR position, 8 of 14 bytes per entry; list walk: no
+// tile lists).  Without it, from the lists' exact total after the build.
 // tune bit 4 (RCF_CRF_SPLAT_GATHER): never; bit 5 (RCF_CRF_SPLAT_TILES): whenever the lists exist (tests).
 constexpr long TILE_SPLAT_NUM = 3, TILE_SPLAT_DEN = 5;
+constexpr long TILE_SPLAT_EST_PCT = 88;
+__device__ __forceinline__ bool tile_mode_known(const Lattice &Lt) { return Lt.est || (Lt.tune & (16 | 32)) || !Lt.tile_splat; }
 __device__ __forceinline__ bool tile_mode(const Lattice &Lt, int f) {
     if (!Lt.tile_splat || (Lt.tune & 16)) return false;
-    return (Lt.tune & 32) || (long)Lt.stat[4 * f + 3] * TILE_SPLAT_DEN <= TILE_SPLAT_NUM * Lt.E;
+    if (Lt.tune & 32) return true;
+    if (Lt.est) return (long)Lt.stat[4 * f + 2] * 100 <= TILE_SPLAT_EST_PCT * ((long)PK_SAMPLES * 256 * (Lt.pd + 1));
+    return (long)Lt.stat[4 * f + 3] * TILE_SPLAT_DEN <= TILE_SPLAT_NUM * Lt.E;
 }
 // where entry (remainder r, pixel p) of frame f lives in Lt.weight / Lt.tslot (see Lattice::wtile)
 __device__ __forceinline__ long widx(const Lattice &Lt, int f, int r, int p) {
@@ -640,6 +648,9 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
     const int f = blockIdx.x;                             // frame fastest: with 8 frames per call a frame's workgroups share one XCD
     const long cap0 = pk_cap(Lt, f);
     const bool small = phase == 0 && cap0 < 2 * Lt.E;                    // an attempt that may overflow
+    // what the frame's mode will read (tile_mode): everything while the mode is still open
+    const bool known = tile_mode_known(Lt), tmode = known && tile_mode(Lt, f);
+    const bool want_tile = !known || tmode, want_list = !known || !tmode, want_vid = want_list || Lt.sym;
     if (phase == 1 && !pk_overflowed(Lt, f)) return;                     // (uniform: the statistics are final by now)
     // a workgroup walks every gridDim.y-th tile: ONE each in the first attempt's launch; the second attempt's launch -- which returns
     // here for every frame on nearly every call -- is small (12 960 workgroups that only start and stop cost 15 us)
@@ -731,8 +742,10 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
         const unsigned long long old = placed ? atomicAdd(cursor + h, (unsigned long long)lcnt[i] | (1ull << 32)) : 0ull;
         lbase[i] = (unsigned)old;
         lcnt[i] = (unsigned)ti;                                  // (the count is spent) the key's place in the tile's vertex list
-        tl[ti] = (int)h;
-        tp[ti] = (int)(old >> 32);
+        if (want_tile) {
+            tl[ti] = (int)h;
+            tp[ti] = (int)(old >> 32);
+        }
     }
     if (small && mine) atomicAdd(&newkeys, mine);
     __syncthreads();
@@ -746,11 +759,11 @@ __global__ void __launch_bounds__(256) lattice_build_packed_kernel(Lattice Lt, c
         const long base = (long)f * Lt.E + p;
         for (int r = 0; r < nax; r++) {
             const long e = base + (long)r * Lt.N;
-            Lt.vid[e] = (int)lgs[lh[r]];                         // bucket for now; the fill pass turns it into the vertex id
-            Lt.rel[e] = (int)lbase[lh[r]] + lrank[r];
+            if (want_vid) Lt.vid[e] = (int)lgs[lh[r]];           // bucket for now; the fill pass turns it into the vertex id
+            if (want_list) Lt.rel[e] = (int)lbase[lh[r]] + lrank[r];
             const long we = widx_tile(Lt, f, tile, r, threadIdx.x, p);
             Lt.weight[we] = wgt[r];
-            Lt.tslot[we] = (unsigned short)lcnt[lh[r]];
+            if (want_tile) Lt.tslot[we] = (unsigned short)lcnt[lh[r]];
         }
     }
     __syncthreads();                                     // the next tile reuses the LDS tables
