@@ -319,3 +319,31 @@ def test_crf_tile_splat_identical(kind, size, params, iters, sym, report):
     report(f"crf tile splat vs gather ({kind} {H}x{W}, params {params}, T={iters}, symmetric {sym}): MAP / Q / vertex counts "
            f"identical: {same}; vertices {out['gather'][2].tolist()}")
     assert all(same.values()), same
+
+
+def test_crf_forms_agree_on_random_calls(report):
+    """40 random calls (sizes 5 ... 200, 1 ... 4 frames, clean / textured / noisy content, one or two potentials, both normalisations, T = 0 ... 3):
+    the list walk, the tile splat (default rule and forced, fused and separate slice, small-table overflow) and the sort build give the
+    same MAP, marginals and vertex counts bit for bit (tools/fuzz_crf.py runs hundreds of these)."""
+    rng = np.random.default_rng(5)
+    GATHER, TILES, SEPARATE, SMALL, SORT = 0x4000 >> 8, 0x8000 >> 8, 0x10000 >> 8, 2, 3
+    bad = []
+    for c in range(40):
+        H, W, F, T = int(rng.integers(5, 201)), int(rng.integers(5, 201)), int(rng.integers(1, 5)), int(rng.integers(0, 4))
+        amp = int(rng.choice([0, 0, 3, 10, 40, 255]))
+        frames = [np.clip(synth.smooth_rgb(H, W, 9500 + 10 * c + i).astype(np.int32) + rng.integers(-amp, amp + 1, (H, W, 3)), 0, 255).astype(np.uint8)
+                  for i in range(F)]
+        rgb = torch.from_numpy(np.stack(frames)).to(DEV)
+        un = torch.from_numpy(np.stack([_unary(synth.soft_blob_mask(H, W, 9500 + 10 * c + i)) for i in range(F)])).to(DEV)
+        two = bool(rng.integers(0, 3) == 0)
+        sym = bool(not two and rng.integers(0, 3) == 0)
+        params = (3.0, 3.0, 5.0, 60.0, 5.0) if two else (0.0, 0.0, 5.0, 60.0, 5.0)
+        ref = None
+        for name, fl in (("gather", GATHER), ("default", 0), ("tiles", TILES), ("tiles separate", TILES | SEPARATE), ("tiles overflow", TILES | SMALL), ("sort", SORT)):
+            r = crf_soft_batched(rgb, un, W, H, *params, T, want_q=True, want_nvert=True, symmetric=sym, build=fl)
+            if ref is None:
+                ref = r
+            elif not all(bool(torch.equal(a, b)) for a, b in zip(ref, r)):
+                bad.append((c, H, W, F, T, amp, two, sym, name))
+    report(f"CRF forms on 40 random calls: mismatches {bad}")
+    assert not bad
